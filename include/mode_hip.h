@@ -1,0 +1,264 @@
+/*
+ * mode_hip.h — C-ABI of libmode_hip.so: the MI355X (gfx950 / CDNA4) implementation of the MoDE denoising hot path.
+ *
+ * The reference (intuitive-robots/MoDE_Diffusion_Policy) has NO FFI / operator-plugin boundary for this path: the seam
+ * is Hydra `_target_` instantiation of Python classes.  This header therefore defines the C-ABI that
+ * sits UNDER the Python mirror of those classes (the .py files of mode_diffusion_policy_amd); each entry point cites the reference
+ * code it replaces (paths relative to the reference checkout).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes; no torch / C++ types in signatures.
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocations in practice) unless it says "host".
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *   - functions never allocate, never synchronise, never throw; they are hipGraph-capture safe.
+ *   - return 0 on success, a negative ModeStatus for argument errors, or a positive hipError_t from the launch.
+ *   - all matrices are row-major; "weight" matrices are stored exactly like torch.nn.Linear.weight: [out, in].
+ */
+#ifndef MODE_HIP_H
+#define MODE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MODE_HIP_ABI_VERSION 1
+
+typedef enum ModeStatus {
+  MODE_OK = 0,
+  MODE_ERR_BAD_ARG = -1,       /* null pointer / inconsistent sizes */
+  MODE_ERR_UNSUPPORTED = -2,   /* shape or flag combination the kernels do not implement */
+  MODE_ERR_WORKSPACE = -3      /* workspace too small */
+} ModeStatus;
+
+typedef enum ModeDType { MODE_BF16 = 0, MODE_F32 = 1 } ModeDType;
+
+/* GEMM epilogues (applied to acc = A @ W^T, fp32 accumulators) */
+typedef enum ModeEpilogue {
+  MODE_EPI_NONE = 0,      /* C = acc                                                     */
+  MODE_EPI_BIAS = 1,      /* C = acc + bias[n]                (nn.Linear with bias)      */
+  MODE_EPI_BIAS_GELU = 2, /* C = gelu_erf(acc + bias[n])      (router mlp.0 + GELU)      */
+  MODE_EPI_RESIDUAL = 3,  /* C = acc + resid[m, n] (fp32)     (c_proj + residual)        */
+  MODE_EPI_SWIGLU = 4     /* W is [2*N, K]; C[m,n] = (acc[m,n]+b[n]) * silu(acc[m,N+n]+b[N+n])   (SwishGLU) */
+} ModeEpilogue;
+
+int mode_hip_version(void);
+const char* mode_hip_status_string(int status);
+/* Tuning knobs (process-wide).  "gemm_glds": 1 = stage GEMM tiles with global_load_lds (default), 0 = through VGPRs. */
+int mode_set_option(const char* key, int value);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * mode_gemm — C[M,N] = epilogue(A[M,K] @ W[N,K]^T), optionally grouped (MoE) and row-gathered.
+ * Replaces every nn.Linear on the path (modedit.py:108-111 q/k/v/c_proj, :194-202 router, :86/:255 expert MLPs,
+ * :683-686 embeddings) and the per-expert Python loop's GEMMs (modedit.py:561-566).
+ *   dtype MODE_BF16: A, W bf16; MFMA 16x16x32 bf16, fp32 accumulate. Requires K % 64 == 0.
+ *   dtype MODE_F32 : A, W fp32; MFMA 16x16x4 f32 (bit-exact fp32 fma chain).  Any K.
+ * Grouped mode (tiles != NULL): `tiles` is the device tile table written by mode_moe_dispatch_meta
+ *   (int32 triples {expert, row_begin, row_end} in SORTED-row coordinates, *num_tiles valid entries); the expert id
+ *   selects W + expert*w_expert_stride and bias + expert*bias_expert_stride (strides in ELEMENTS).  M is then the
+ *   total number of sorted rows (N_tokens * top_k) and max_tiles bounds the launch grid.
+ * a_rows (optional): int32[M]; logical row m of A is read from A[a_rows[m]] (MoE gather by the dispatch permutation).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ModeGemmDesc {
+  int32_t dtype;              /* ModeDType of A and W                                     */
+  int32_t epilogue;           /* ModeEpilogue                                             */
+  int32_t out_dtype;          /* ModeDType of C                                           */
+  int32_t M, N, K;            /* N = number of OUTPUT columns                             */
+  const void* A;  int64_t lda;
+  const void* W;  int64_t ldw;  int64_t w_expert_stride;
+  const float* bias;          int64_t bias_expert_stride;
+  const float* resid;         int64_t ldr;
+  void* C;        int64_t ldc;
+  const int32_t* a_rows;      /* optional gather                                          */
+  const int32_t* tiles;       /* optional grouped tile table (device)                     */
+  const int32_t* num_tiles;   /* device scalar                                            */
+  int32_t max_tiles;          /* grid bound for grouped launches                          */
+  int32_t tile_m;             /* must equal the BM the tile table was built for (128 bf16 / 64 f32) */
+} ModeGemmDesc;
+int mode_gemm(const ModeGemmDesc* desc, void* stream);
+int mode_gemm_tile_m(int dtype);   /* BM used by the grouped tile table for this dtype */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * mode_rmsnorm_cond_fwd — y = x / max(||x||_2 * D^-1/2, eps) * g  (+ cond[row / rows_per_cond])
+ * Replaces RMSNorm (modedit.py:72-80) and the additive conditioning `ln_1(x) + c` (modedit.py:532); with cond == NULL
+ * it is the plain ln_2 / final ln (modedit.py:539, 818).  x fp32 [rows, D]; writes any of y_f32 / y_lp (may be NULL).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int mode_rmsnorm_cond_fwd(const float* x, const float* g, const float* cond, int rows, int D, int rows_per_cond,
+                          float eps, float* y_f32, void* y_lp, int lp_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * mode_attn_block_fwd — per (sample, head): qk-RMSNorm over head_dim (learned gains, eps), causal softmax(QK^T/sqrt(hd)) V.
+ * Replaces Attention.forward minus the four Linears (modedit.py:125-127, 145-165; SDPA is_causal=True at :149).
+ * qkv is the packed [B*T, 3*D] output of the fused QKV GEMM ([q | k | v] along columns); y is [B*T, D] (heads merged).
+ * T <= 16 (the path's sequence is 14 tokens), head_dim % 32 == 0 for bf16.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int mode_attn_block_fwd(const void* qkv, const float* q_gain, const float* k_gain, void* y, int dtype,
+                        int B, int T, int H, int head_dim, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * mode_sigma_embed — e1[r, :] = (ln(sigma[r]) / 4) * w[:, 0] + b        (modedit.py:823-828, Linear(1, D))
+ * (the following Linear(D, D) `sigma_linear` is a mode_gemm in fp32).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int mode_sigma_embed(const float* sigma, const float* w, const float* b, float* e1, int R, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * mode_moe_route_topk_f32 — router tail on R distinct conditioning rows, fp32 end to end (bit-exact integers):
+ *   shifted = logits - rowmax ; probs = clamp(softmax(shifted), 1e-9, 1-1e-9) ; top-k by prob (descending, ties ->
+ *   lower expert id) ; w = probs[topk] (/ sum when normalize).      (modedit.py:345-349, 392, 398-399, 418-419)
+ * logits [R, E] fp32 in; outputs (any may be NULL): shifted [R,E], probs [R,E], topk_idx int32 [R,k], topk_w [R,k].
+ * ------------------------------------------------------------------------------------------------------------------ */
+int mode_moe_route_topk_f32(const float* logits, int R, int E, int k, int normalize, float* shifted, float* probs,
+                            int32_t* topk_idx, float* topk_w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * mode_moe_dispatch_meta — token-dispatch metadata for one layer; replaces the boolean-mask gather / index_put loop
+ * (modedit.py:555-572) with a canonical permutation: experts ascending, token ids ascending within an expert.
+ * Inputs: idx int32 [R, k] and w fp32 [R, k] on R distinct routing rows; token n uses row n / tokens_per_row
+ *         (tokens_per_row = T for the noise-conditioned router, 1 for per-token routing such as training multinomial).
+ * Outputs: counts int32 [E]; offsets int32 [E+1]; perm int32 [N*k] sorted row -> token id;
+ *          pos int32 [N*k]: (token, j) -> sorted row, j enumerating the token's experts in ASCENDING expert id;
+ *          posw fp32 [N*k]: combine weight for (token, j);
+ *          tiles int32 [max_tiles*3] {expert, row_begin, row_end}; num_tiles int32 [1].
+ * ------------------------------------------------------------------------------------------------------------------ */
+int mode_moe_dispatch_meta(const int32_t* idx, const float* w, int R, int tokens_per_row, int N, int E, int k,
+                           int tile_m, int32_t* counts, int32_t* offsets, int32_t* perm, int32_t* pos, float* posw,
+                           int32_t* tiles, int32_t* num_tiles, int max_tiles, void* stream);
+int mode_moe_max_tiles(int N, int E, int k, int tile_m);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * mode_moe_combine_norm_fwd — x_next[t] = u[t] + sum_j posw[t,j] * Y[pos[t,j]]  (ascending expert order; the residual is
+ * the NORMALISED stream u, modedit.py:539/595), then optionally the next block's  h = RMSNorm(x_next; g) + cond
+ * (modedit.py:532).  u fp32 [N,D]; Y [N*k, D] (y_dtype); writes x_next fp32 (may alias u) and h (lp dtype; may be NULL).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int mode_moe_combine_norm_fwd(const float* u, const void* Y, int y_dtype, const int32_t* pos, const float* posw,
+                              int N, int D, int k, const float* g, const float* cond, int rows_per_cond, float eps,
+                              float* x_next, void* h, int h_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * mode_embed_tokens_fwd — builds the input sequence and the first block's conditioned norm in one pass:
+ *   [ emb_t | goal_e + pos[0] | img_e[0..n_img) + pos[1] | (actions * c_in) @ Wact^T + pos[1..A] ]
+ * (modedit.py:760-790, 847-860; c_in from score_wrappers.py:42).  emb_t / goal_e / img_e are fp32 outputs of mode_gemm.
+ *   emb_row_stride: 0 when one sigma row is shared by the whole batch (sampler), D otherwise; same for cond.
+ * Writes x fp32 [B*T, D] and h = RMSNorm(x; g)+cond in h_dtype.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ModeEmbedDesc {
+  int32_t B, T, D, A_len, A_dim, n_img, use_noise_token;
+  const float* emb_t;   int64_t emb_row_stride;
+  const float* goal_e;  /* [B, D]         */
+  const float* img_e;   /* [B, n_img, D]  */
+  const float* actions; /* [B, A_len, A_dim] */
+  const float* c_in;    /* [B] or NULL (=1); c_in_stride 0 => shared scalar */
+  int64_t c_in_stride;
+  const float* w_act;   /* [D, A_dim]     */
+  const float* pos;     /* [1 + A_len, D] */
+  const float* g;       /* ln_1 gain of block 0 */
+  const float* cond;    int64_t cond_row_stride;
+  float eps;
+  float* x; void* h; int32_t h_dtype;
+} ModeEmbedDesc;
+int mode_embed_tokens_fwd(const ModeEmbedDesc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * mode_head_ddim_fwd — last block's MoE combine, final RMSNorm, output head and the EDM / DDIM epilogue on the action
+ * tokens only:  F = Linear(D, A)(RMSNorm(u + sum_j w Y))  (modedit.py:807-808, 818);
+ *   denoised = F * c_out + x_a * c_skip (score_wrappers.py:79-80);  x_next = r * x_a + (1 - r) * denoised,
+ *   r = sigma_next / sigma (gc_sampling.py:948-950).
+ * scal: fp32 [B or 1][4] = {c_skip, c_out, r, unused}; scal == NULL => write F only (training / raw forward).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ModeHeadDesc {
+  int32_t B, T, D, A_len, A_dim, k;
+  const float* u; const void* Y; int32_t y_dtype;
+  const int32_t* pos; const float* posw;
+  const float* g; float eps;
+  const float* w_out; const float* b_out;     /* [A_dim, D], [A_dim] */
+  const float* x_a;                            /* current noisy actions [B, A_len, A_dim] (un-scaled) or NULL */
+  const float* scal; int64_t scal_stride;      /* 0 => shared by the batch */
+  float* F;                                    /* [B, A_len, A_dim] raw network output (may be NULL) */
+  float* denoised;                             /* may be NULL */
+  float* x_next;                               /* may be NULL; may alias x_a */
+} ModeHeadDesc;
+int mode_head_ddim_fwd(const ModeHeadDesc* d, void* stream);
+
+/* mode_ddim_edm_step — the same elementwise epilogue standalone (used by the generic, un-fused sampler path). */
+int mode_ddim_edm_step(const float* F, const float* x_a, const float* scal, int64_t scal_stride, int B, int per_sample,
+                       float* denoised, float* x_next, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Whole-denoiser forward: the launch chain of one MoDeDiT.forward (modedit.py:741-821) [+ GCDenoiser.forward scalings
+ * + one sample_ddim update], issued from C++ so a 10-step sampler is ~100 back-to-back launches per step with no host
+ * logic in between (and can be captured into a hipGraph by the caller).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ModeDims {
+  int32_t D, H, L, E, k, T, A_len, A_dim, O, G, n_img, use_noise_token, router_normalize;
+  float eps;
+} ModeDims;
+
+/* Per-layer weight table (device pointers).  lp = low-precision compute dtype (bf16 or f32), same layout as torch. */
+typedef struct ModeLayerWeights {
+  const float* ln1_g; const float* ln2_g; const float* qn_g; const float* kn_g;
+  const void* wqkv;  const float* bqkv;     /* [3D, D] rows = [query; key; value], [3D]          */
+  const void* wo;                            /* [D, D]                                            */
+  const float* r_w0; const float* r_b0;      /* router mlp.0 [2D, D], [2D]   (always fp32)        */
+  const float* r_w3; const float* r_b3;      /* router mlp.3 [E, 2D], [E]                         */
+  const void* w1;    const float* b1;        /* [E][8D, D], [E][8D]   expert SwishGLU projection  */
+  const void* w2;                            /* [E][D, 4D]                                        */
+} ModeLayerWeights;
+
+typedef struct ModeModelWeights {
+  const float* pos; const float* w_se; const float* b_se; const float* w_sl;   /* fp32 */
+  const float* w_tok; const float* w_goal; const float* w_act;                /* fp32 [D,O] [D,G] [D,A] */
+  const float* ln_g; const float* w_out; const float* b_out;
+  const ModeLayerWeights* layers;                                             /* host array of L entries */
+} ModeModelWeights;
+
+/* Dispatch-metadata record of one layer (4-byte word offsets inside the record), see mode_moe_dispatch_meta. */
+typedef struct ModeMetaLayout {
+  int32_t counts, offsets, num_tiles, perm, pos, posw, tiles;   /* word offsets */
+  int32_t total_words;                                          /* record size (multiple of 4 words) */
+  int32_t max_tiles;
+} ModeMetaLayout;
+int mode_moe_meta_layout(int N, int E, int k, int tile_m, ModeMetaLayout* out);
+
+/* Batched dispatch: nbatch records (e.g. L layers, or steps*L for a whole sampler run) in one launch.
+ * topk_idx/topk_w: [nbatch][R][k] (idx_bstride elements apart); meta: [nbatch][layout.total_words]. */
+int mode_dit_dispatch(const int32_t* topk_idx, const float* topk_w, int nbatch, int64_t idx_bstride, int R,
+                      int tokens_per_row, int N, int E, int k, int tile_m, int32_t* meta, void* stream);
+
+size_t mode_dit_workspace_bytes(const ModeDims* dims, int B, int R, int dtype);
+
+/* sigma [R] -> emb_t [R, D]:  Linear(1,D)(ln(sigma)/4) -> Linear(D,D)   (modedit.py:823-832).  fp32. */
+int mode_dit_sigma_embed(const ModeDims* dims, const ModeModelWeights* w, const float* sigma, int R, float* emb_t,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Hoisted, step-invariant embeddings (modedit.py:760, 765): img_e [B*n_img, D] = state_images @ tok_emb^T,
+ * goal_e [B, D] = goals @ goal_emb^T.  fp32 MFMA. */
+int mode_dit_embed_obs(const ModeDims* dims, const ModeModelWeights* w, const float* state_images, const float* goals,
+                       int B, float* img_e, float* goal_e, void* stream);
+
+/* Routing for all L layers on R distinct conditioning rows (cond = emb_t, or emb_t + goal_e with use_goal_in_routing):
+ * per layer Linear(D,2D)+GELU -> Linear(2D,E) -> softmax/clamp/top-k.   (modedit.py:194-202, 336, 345-349, 392)
+ * Outputs (device, caller-owned): topk_idx int32 [L, R, k]; topk_w fp32 [L, R, k]; probs / shifted fp32 [L, R, E] or NULL. */
+int mode_dit_route(const ModeDims* dims, const ModeModelWeights* w, const float* cond, int R,
+                   int32_t* topk_idx, float* topk_w, float* probs, float* shifted,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+typedef struct ModeForwardArgs {
+  int32_t B; int32_t dtype;
+  const float* emb_t; int64_t emb_row_stride;        /* sigma token rows; stride 0 => one row shared by the whole batch      */
+  const float* cond;  int64_t cond_row_stride;       /* additive conditioning c (normally == emb_t)                          */
+  const int32_t* meta; int64_t meta_layer_stride;    /* L dispatch records (mode_dit_dispatch); stride in 4-byte words       */
+  const float* goal_e; const float* img_e;           /* hoisted embeddings fp32 [B,D], [B,n_img,D]                           */
+  const float* actions;                              /* [B, A_len, A_dim] un-scaled noisy actions                            */
+  const float* c_in; int64_t c_in_stride;            /* NULL => 1                                                            */
+  const float* scal; int64_t scal_stride;            /* {c_skip,c_out,r,_} per sample (stride 4) / shared (0); NULL => F only */
+  float* F; float* denoised; float* x_next;
+} ModeForwardArgs;
+int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w, const ModeForwardArgs* a,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODE_HIP_H */

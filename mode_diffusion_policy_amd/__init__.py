@@ -1,0 +1,6 @@
+"""MI355X-native MoDE denoising hot path (drop-in for the reference's MoDeDiT / GCDenoiser / sample_ddim)."""
+from .modedit import MoDeDiT, NoiseBlockMoE  # noqa: F401
+from .score_wrappers import GCDenoiser  # noqa: F401
+from .gc_sampling import get_sigmas_exponential, sample_ddim  # noqa: F401
+
+__all__ = ["MoDeDiT", "NoiseBlockMoE", "GCDenoiser", "sample_ddim", "get_sigmas_exponential"]

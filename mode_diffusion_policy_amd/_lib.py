@@ -1,0 +1,136 @@
+"""ctypes binding of libmode_hip.so (C-ABI declared in include/mode_hip.h).
+
+The HIP library IS the product: there is no CPU / PyTorch fallback.  If the shared object is missing or a symbol is
+absent, loading fails loudly (``ModeHipUnavailable``) and every operator that needs it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("MODE_HIP_LIB", os.path.join(_HERE, "libmode_hip.so"))
+
+MODE_BF16, MODE_F32 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3, 4
+ABI_VERSION = 1
+
+c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+
+class ModeHipUnavailable(RuntimeError):
+    pass
+
+
+class ModeGemmDesc(C.Structure):
+    _fields_ = [("dtype", c_i32), ("epilogue", c_i32), ("out_dtype", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
+                ("A", c_vp), ("lda", c_i64), ("W", c_vp), ("ldw", c_i64), ("w_expert_stride", c_i64),
+                ("bias", c_vp), ("bias_expert_stride", c_i64), ("resid", c_vp), ("ldr", c_i64), ("C", c_vp), ("ldc", c_i64),
+                ("a_rows", c_vp), ("tiles", c_vp), ("num_tiles", c_vp), ("max_tiles", c_i32), ("tile_m", c_i32)]
+
+
+class ModeEmbedDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("T", c_i32), ("D", c_i32), ("A_len", c_i32), ("A_dim", c_i32), ("n_img", c_i32),
+                ("use_noise_token", c_i32), ("emb_t", c_vp), ("emb_row_stride", c_i64), ("goal_e", c_vp), ("img_e", c_vp),
+                ("actions", c_vp), ("c_in", c_vp), ("c_in_stride", c_i64), ("w_act", c_vp), ("pos", c_vp), ("g", c_vp),
+                ("cond", c_vp), ("cond_row_stride", c_i64), ("eps", c_f32), ("x", c_vp), ("h", c_vp), ("h_dtype", c_i32)]
+
+
+class ModeHeadDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("T", c_i32), ("D", c_i32), ("A_len", c_i32), ("A_dim", c_i32), ("k", c_i32),
+                ("u", c_vp), ("Y", c_vp), ("y_dtype", c_i32), ("pos", c_vp), ("posw", c_vp), ("g", c_vp), ("eps", c_f32),
+                ("w_out", c_vp), ("b_out", c_vp), ("x_a", c_vp), ("scal", c_vp), ("scal_stride", c_i64),
+                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp)]
+
+
+class ModeDims(C.Structure):
+    _fields_ = [("D", c_i32), ("H", c_i32), ("L", c_i32), ("E", c_i32), ("k", c_i32), ("T", c_i32), ("A_len", c_i32),
+                ("A_dim", c_i32), ("O", c_i32), ("G", c_i32), ("n_img", c_i32), ("use_noise_token", c_i32),
+                ("router_normalize", c_i32), ("eps", c_f32)]
+
+
+class ModeLayerWeights(C.Structure):
+    _fields_ = [("ln1_g", c_vp), ("ln2_g", c_vp), ("qn_g", c_vp), ("kn_g", c_vp), ("wqkv", c_vp), ("bqkv", c_vp),
+                ("wo", c_vp), ("r_w0", c_vp), ("r_b0", c_vp), ("r_w3", c_vp), ("r_b3", c_vp), ("w1", c_vp), ("b1", c_vp),
+                ("w2", c_vp)]
+
+
+class ModeModelWeights(C.Structure):
+    _fields_ = [("pos", c_vp), ("w_se", c_vp), ("b_se", c_vp), ("w_sl", c_vp), ("w_tok", c_vp), ("w_goal", c_vp),
+                ("w_act", c_vp), ("ln_g", c_vp), ("w_out", c_vp), ("b_out", c_vp), ("layers", C.POINTER(ModeLayerWeights))]
+
+
+class ModeMetaLayout(C.Structure):
+    _fields_ = [("counts", c_i32), ("offsets", c_i32), ("num_tiles", c_i32), ("perm", c_i32), ("pos", c_i32),
+                ("posw", c_i32), ("tiles", c_i32), ("total_words", c_i32), ("max_tiles", c_i32)]
+
+
+class ModeForwardArgs(C.Structure):
+    _fields_ = [("B", c_i32), ("dtype", c_i32), ("emb_t", c_vp), ("emb_row_stride", c_i64), ("cond", c_vp),
+                ("cond_row_stride", c_i64), ("meta", c_vp), ("meta_layer_stride", c_i64), ("goal_e", c_vp), ("img_e", c_vp),
+                ("actions", c_vp), ("c_in", c_vp), ("c_in_stride", c_i64), ("scal", c_vp), ("scal_stride", c_i64),
+                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp)]
+
+
+P = C.POINTER
+# name -> (restype, argtypes): every symbol include/mode_hip.h declares
+PROTOTYPES = {
+    "mode_hip_version": (C.c_int, []),
+    "mode_hip_status_string": (C.c_char_p, [C.c_int]),
+    "mode_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "mode_gemm": (C.c_int, [P(ModeGemmDesc), c_vp]),
+    "mode_gemm_tile_m": (C.c_int, [C.c_int]),
+    "mode_rmsnorm_cond_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_f32, c_vp, c_vp, C.c_int, c_vp]),
+    "mode_attn_block_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32, c_vp]),
+    "mode_sigma_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, c_vp]),
+    "mode_moe_route_topk_f32": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mode_moe_dispatch_meta": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp,
+                                         c_vp, c_vp, c_vp, c_vp, C.c_int, c_vp]),
+    "mode_moe_max_tiles": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mode_moe_combine_norm_fwd": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp, C.c_int,
+                                            c_f32, c_vp, c_vp, C.c_int, c_vp]),
+    "mode_embed_tokens_fwd": (C.c_int, [P(ModeEmbedDesc), c_vp]),
+    "mode_head_ddim_fwd": (C.c_int, [P(ModeHeadDesc), c_vp]),
+    "mode_ddim_edm_step": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
+    "mode_moe_meta_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P(ModeMetaLayout)]),
+    "mode_dit_dispatch": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
+    "mode_dit_workspace_bytes": (c_sz, [P(ModeDims), C.c_int, C.c_int, C.c_int]),
+    "mode_dit_sigma_embed": (C.c_int, [P(ModeDims), P(ModeModelWeights), c_vp, C.c_int, c_vp, c_vp, c_sz, c_vp]),
+    "mode_dit_embed_obs": (C.c_int, [P(ModeDims), P(ModeModelWeights), c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
+    "mode_dit_route": (C.c_int, [P(ModeDims), P(ModeModelWeights), c_vp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mode_dit_forward": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeForwardArgs), c_vp, c_sz, c_vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and type every entry point.  Raises ModeHipUnavailable if the library or any symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ModeHipUnavailable(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            f"`make -C mode_diffusion_policy_amd/csrc`. There is no CPU fallback for the MoDE denoising path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise ModeHipUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ModeHipUnavailable(f"{LIB_PATH} lacks symbol {name}") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.mode_hip_version() != ABI_VERSION:
+        raise ModeHipUnavailable(f"ABI version mismatch: library {lib.mode_hip_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mode_hip_status_string(rc).decode()
+        raise RuntimeError(f"libmode_hip {what} failed: {msg} (status {rc})")

@@ -1,0 +1,192 @@
+// Tiny-T causal attention for the 14-token MoDE sequence (modedit.py:125-127, 145-165): B*H independent problems of
+// T <= 16 tokens, head_dim 32..128.  One wave64 per (sample, head), four per workgroup, no LDS at all:
+//   * q/k rows are read straight into MFMA fragments (16 B per lane), qk-RMSNorm is a 4-lane-group shuffle reduction on those
+//     fragments, S^T = K Q^T runs on v_mfma_f32_16x16x32_bf16 (T padded to 16) so that each lane ends up owning one
+//     QUERY column and 4 key rows: the causal softmax is 4 local values + two xor-shuffles,
+//   * the probabilities are already laid out as the B operand of  O^T = V^T P^T  (k-slots 4..7 of each lane group are zero
+//     padding), so P never moves between lanes; each lane then owns 4 consecutive head-dim outputs of one query -> 8-byte stores.
+// fp32 parity mode: a plain VALU kernel with the same math (one wave per (sample, head), LDS-staged q/k/v).
+#include "mode_common.h"
+
+namespace mode {
+
+template <int NKS>   // head_dim = 32 * NKS
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ qg,
+                                                        const float* __restrict__ kg, uint16_t* __restrict__ y, int B, int T,
+                                                        int H, float eps) {
+  constexpr int HD = 32 * NKS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int prob = blockIdx.x * 4 + wave;
+  if (prob >= B * H) return;
+  const int b = prob / H, h = prob % H;
+  const int D = H * HD;
+  const long ld = 3L * D;
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool tv = fr < T;
+  const uint16_t* rowp = qkv + ((long)b * T + (tv ? fr : 0)) * ld + h * HD + fq * 8;
+
+  // ---- load q / k fragments: token row fr, dims ks*32 + fq*8 + [0,8)
+  float qf[NKS][8], kf[NKS][8];
+  float qss = 0.f, kss = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    uint4 rq = make_uint4(0, 0, 0, 0), rk = make_uint4(0, 0, 0, 0);
+    if (tv) {
+      rq = *reinterpret_cast<const uint4*>(rowp + ks * 32);
+      rk = *reinterpret_cast<const uint4*>(rowp + D + ks * 32);
+    }
+    const uint32_t uq[4] = {rq.x, rq.y, rq.z, rq.w}, uk[4] = {rk.x, rk.y, rk.z, rk.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      qf[ks][2 * i] = bf16_bits_to_f32(uq[i] & 0xffff); qf[ks][2 * i + 1] = bf16_bits_to_f32(uq[i] >> 16);
+      kf[ks][2 * i] = bf16_bits_to_f32(uk[i] & 0xffff); kf[ks][2 * i + 1] = bf16_bits_to_f32(uk[i] >> 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { qss += qf[ks][i] * qf[ks][i]; kss += kf[ks][i] * kf[ks][i]; }
+  }
+  // row norm: the 4 lane groups (fq) of a token hold disjoint dims -> xor 16, 32
+  qss += __shfl_xor(qss, 16, 64); qss += __shfl_xor(qss, 32, 64);
+  kss += __shfl_xor(kss, 16, 64); kss += __shfl_xor(kss, 32, 64);
+  const float qn = fmaxf(sqrtf(qss) * rsqrtf((float)HD), eps), kn = fmaxf(sqrtf(kss) * rsqrtf((float)HD), eps);
+
+  bf16x8 qfrag[NKS], kfrag[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const float4 g0 = *reinterpret_cast<const float4*>(qg + ks * 32 + fq * 8), g1 = *reinterpret_cast<const float4*>(qg + ks * 32 + fq * 8 + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(kg + ks * 32 + fq * 8), h1 = *reinterpret_cast<const float4*>(kg + ks * 32 + fq * 8 + 4);
+    const float gq[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, gk[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    uint32_t pq[4], pk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pq[i] = pack_bf16x2(qf[ks][2 * i] / qn * gq[2 * i], qf[ks][2 * i + 1] / qn * gq[2 * i + 1]);
+      pk[i] = pack_bf16x2(kf[ks][2 * i] / kn * gk[2 * i], kf[ks][2 * i + 1] / kn * gk[2 * i + 1]);
+    }
+    uint4 tq = make_uint4(pq[0], pq[1], pq[2], pq[3]), tk = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    qfrag[ks] = *reinterpret_cast<bf16x8*>(&tq);
+    kfrag[ks] = *reinterpret_cast<bf16x8*>(&tk);
+  }
+
+  // ---- S^T[key][query] = sum_d K[key][d] Q[query][d]; lane: query = fr, keys = fq*4 + r
+  f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag[ks], qfrag[ks], st, 0, 0, 0);
+  const float scale = rsqrtf((float)HD);
+  float s[4], mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int key = fq * 4 + r;
+    s[r] = (key <= fr && key < T) ? st[r] * scale : -INFINITY;     // is_causal=True (modedit.py:149)
+    mx = fmaxf(mx, s[r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float p[4], sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { p[r] = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - mx); sum += p[r]; }
+  sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  uint4 tp = make_uint4(pack_bf16x2(p[0] * inv, p[1] * inv), pack_bf16x2(p[2] * inv, p[3] * inv), 0u, 0u);
+  const bf16x8 pfrag = *reinterpret_cast<bf16x8*>(&tp);          // B operand: slots 0..3 = keys fq*4+r, slots 4..7 = 0
+
+  // ---- O^T[d][query] = sum_key V[key][d] P[query][key]; A operand = V^T fragment: row d = db*16 + fr, slots j<4 = keys fq*4+j
+  const uint16_t* vbase = qkv + (long)b * T * ld + 2L * D + h * HD;
+  uint16_t* yrow = y + ((long)b * T + fr) * D + h * HD + fq * 4;
+#pragma unroll
+  for (int db = 0; db < HD / 16; ++db) {
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = fq * 4 + j;
+      v[j] = (key < T) ? (uint32_t)vbase[(long)key * ld + db * 16 + fr] : 0u;
+    }
+    uint4 tvv = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), 0u, 0u);
+    const bf16x8 vfrag = *reinterpret_cast<bf16x8*>(&tvv);
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag, o, 0, 0, 0);     // D[row = d_local][col = query]
+    if (tv) {
+      uint2 pk; pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
+      *reinterpret_cast<uint2*>(yrow + db * 16) = pk;                           // y[b, query=fr, h*HD + db*16 + fq*4 + r]
+    }
+  }
+}
+
+// fp32 parity kernel: one wave per (b,h); q,k,v rows staged in LDS; plain VALU math in the reference's order.
+__global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ qg,
+                                                      const float* __restrict__ kg, float* __restrict__ y, int B, int T, int H,
+                                                      int HD, float eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sq = reinterpret_cast<float*>(smem);          // [T][HD]
+  float* sk = sq + T * HD;
+  float* sv = sk + T * HD;
+  float* sp = sv + T * HD;                             // [T][T]
+  const int lane = threadIdx.x, b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD;
+  const long ld = 3L * D;
+  for (int i = lane; i < T * HD; i += 64) {
+    const int t = i / HD, d = i % HD;
+    const float* r = qkv + ((long)b * T + t) * ld + h * HD + d;
+    sq[i] = r[0]; sk[i] = r[D]; sv[i] = r[2 * D];
+  }
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {                        // qk-RMSNorm (modedit.py:126-127, 145-146)
+    float a = 0.f, c = 0.f;
+    for (int d = lane; d < HD; d += 64) { a += sq[t * HD + d] * sq[t * HD + d]; c += sk[t * HD + d] * sk[t * HD + d]; }
+    a = wave_sum(a); c = wave_sum(c);
+    const float qn = fmaxf(sqrtf(a) * rsqrtf((float)HD), eps), kn = fmaxf(sqrtf(c) * rsqrtf((float)HD), eps);
+    for (int d = lane; d < HD; d += 64) { sq[t * HD + d] = sq[t * HD + d] / qn * qg[d]; sk[t * HD + d] = sk[t * HD + d] / kn * kg[d]; }
+  }
+  __syncthreads();
+  const float scale = rsqrtf((float)HD);
+  for (int i = lane; i < T * T; i += 64) {
+    const int qi = i / T, ki = i % T;
+    float a = -INFINITY;
+    if (ki <= qi) {
+      a = 0.f;
+      for (int d = 0; d < HD; ++d) a = fmaf(sq[qi * HD + d], sk[ki * HD + d], a);
+      a *= scale;
+    }
+    sp[i] = a;
+  }
+  __syncthreads();
+  if (lane < T) {
+    float mx = -INFINITY;
+    for (int ki = 0; ki <= lane; ++ki) mx = fmaxf(mx, sp[lane * T + ki]);
+    float sum = 0.f;
+    for (int ki = 0; ki < T; ++ki) { const float e = (ki <= lane) ? expf(sp[lane * T + ki] - mx) : 0.f; sp[lane * T + ki] = e; sum += e; }
+    for (int ki = 0; ki < T; ++ki) sp[lane * T + ki] /= sum;
+  }
+  __syncthreads();
+  for (int i = lane; i < T * HD; i += 64) {
+    const int qi = i / HD, d = i % HD;
+    float a = 0.f;
+    for (int ki = 0; ki <= qi; ++ki) a = fmaf(sp[qi * T + ki], sv[ki * HD + d], a);
+    y[((long)b * T + qi) * D + h * HD + d] = a;
+  }
+}
+
+}  // namespace mode
+
+using namespace mode;
+
+extern "C" int mode_attn_block_fwd(const void* qkv, const float* q_gain, const float* k_gain, void* y, int dtype, int B, int T, int H,
+                                   int head_dim, float eps, void* stream) {
+  if (!qkv || !q_gain || !k_gain || !y || B < 0 || T <= 0 || H <= 0) return MODE_ERR_BAD_ARG;
+  if (B == 0) return MODE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MODE_BF16) {
+    if (T > 16 || head_dim % 32 != 0 || head_dim > 128) return MODE_ERR_UNSUPPORTED;
+    const dim3 grid((B * H + 3) / 4), blk(256);
+    const uint16_t* in = (const uint16_t*)qkv; uint16_t* out = (uint16_t*)y;
+    switch (head_dim / 32) {
+      case 1: hipLaunchKernelGGL(attn_bf16_kernel<1>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, eps); break;
+      case 2: hipLaunchKernelGGL(attn_bf16_kernel<2>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, eps); break;
+      case 3: hipLaunchKernelGGL(attn_bf16_kernel<3>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, eps); break;
+      case 4: hipLaunchKernelGGL(attn_bf16_kernel<4>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, eps); break;
+      default: return MODE_ERR_UNSUPPORTED;
+    }
+  } else {
+    const size_t lds = ((size_t)3 * T * head_dim + (size_t)T * T) * 4;
+    if (lds > 64 * 1024) return MODE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(attn_f32_kernel, dim3(B * H), dim3(64), lds, s, (const float*)qkv, q_gain, k_gain, (float*)y, B, T, H, head_dim, eps);
+  }
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}

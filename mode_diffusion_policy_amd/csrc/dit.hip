@@ -1,0 +1,269 @@
+// C-ABI glue + the whole-denoiser launch chain (MoDeDiT.forward, modedit.py:741-821) issued from C++:
+// 1 + 7*L kernels per denoise step, zero host synchronisation (the reference crosses device->host ~120 times per forward,
+// SURVEY.md §3.1), hipGraph-capture safe.
+#include "mode_common.h"
+
+#include <string.h>
+
+namespace mode {
+int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s);
+int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s);
+struct MetaBatch {
+  const int* idx; const float* w; long idx_bstride;
+  int* counts; int* offsets; int* perm; int* pos; float* posw; int* tiles; int* num_tiles; long out_bstride;
+};
+int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N, int E, int k, int tile_m, int max_tiles, hipStream_t s);
+
+extern int g_use_glds;
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct WsLayout {
+  size_t x, h, qkv, y, hbuf, ybuf, meta, e1, hid, logits, total;
+};
+
+static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
+  const size_t esz = dtype == MODE_BF16 ? 2 : 4;
+  const size_t N = (size_t)B * d.T, NK = N * d.k, D = d.D;
+  ModeMetaLayout ml;
+  mode_moe_meta_layout((int)N, d.E, d.k, mode_gemm_tile_m(dtype), &ml);
+  WsLayout w{};
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  w.x = take(N * D * 4);
+  w.h = take(N * D * esz);
+  w.qkv = take(N * 3 * D * esz);
+  w.y = take(N * D * esz);
+  w.hbuf = take(NK * 4 * D * esz);
+  w.ybuf = take(NK * D * 4);
+  w.meta = take((size_t)d.L * ml.total_words * 4);
+  const size_t Rr = R > 0 ? R : 1;
+  w.e1 = take(Rr * D * 4);
+  w.hid = take(Rr * 2 * D * 4);
+  w.logits = take(Rr * d.E * 4);
+  w.total = o;
+  return w;
+}
+
+static int check_dims(const ModeDims* d) {
+  if (!d) return MODE_ERR_BAD_ARG;
+  if (d->D <= 0 || d->H <= 0 || d->D % d->H || d->L <= 0 || d->E <= 0 || d->k <= 0 || d->k > d->E) return MODE_ERR_BAD_ARG;
+  if (d->T != (d->use_noise_token ? 1 : 0) + 1 + d->n_img + d->A_len) return MODE_ERR_UNSUPPORTED;
+  if (d->D % 4 || d->A_dim > 8 || d->T > 16) return MODE_ERR_UNSUPPORTED;
+  return MODE_OK;
+}
+
+}  // namespace mode
+
+using namespace mode;
+
+extern "C" int mode_hip_version(void) { return MODE_HIP_ABI_VERSION; }
+
+extern "C" const char* mode_hip_status_string(int status) {
+  switch (status) {
+    case MODE_OK: return "ok";
+    case MODE_ERR_BAD_ARG: return "bad argument";
+    case MODE_ERR_UNSUPPORTED: return "unsupported shape/flag combination";
+    case MODE_ERR_WORKSPACE: return "workspace too small";
+    default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown status";
+  }
+}
+
+extern "C" int mode_set_option(const char* key, int value) {
+  if (!key) return MODE_ERR_BAD_ARG;
+  if (!strcmp(key, "gemm_glds")) { g_use_glds = value ? 1 : 0; return MODE_OK; }
+  return MODE_ERR_UNSUPPORTED;
+}
+
+extern "C" int mode_gemm_tile_m(int dtype) { return dtype == MODE_BF16 ? 128 : 64; }
+
+extern "C" int mode_gemm(const ModeGemmDesc* d, void* stream) {
+  if (!d || !d->A || !d->W || !d->C || d->M < 0 || d->N <= 0) return MODE_ERR_BAD_ARG;
+  if (d->tiles && !d->num_tiles) return MODE_ERR_BAD_ARG;
+  if (d->dtype == MODE_BF16) return gemm_bf16_launch(d, (hipStream_t)stream);
+  if (d->dtype == MODE_F32) return gemm_f32_launch(d, (hipStream_t)stream);
+  return MODE_ERR_BAD_ARG;
+}
+
+extern "C" int mode_moe_meta_layout(int N, int E, int k, int tile_m, ModeMetaLayout* out) {
+  if (!out || N < 0 || E <= 0 || k <= 0 || tile_m <= 0) return MODE_ERR_BAD_ARG;
+  const int NK = N * k;
+  const int mt = mode_moe_max_tiles(N, E, k, tile_m);
+  int o = 0;
+  auto take = [&](int words) { int r = o; o = (o + words + 3) & ~3; return r; };
+  out->counts = take(E);
+  out->offsets = take(E + 1);
+  out->num_tiles = take(1);
+  out->perm = take(NK);
+  out->pos = take(NK);
+  out->posw = take(NK);
+  out->tiles = take(mt * 3);
+  out->total_words = o;
+  out->max_tiles = mt;
+  return MODE_OK;
+}
+
+extern "C" int mode_dit_dispatch(const int32_t* topk_idx, const float* topk_w, int nbatch, int64_t idx_bstride, int R, int tokens_per_row,
+                                 int N, int E, int k, int tile_m, int32_t* meta, void* stream) {
+  if (!topk_idx || !topk_w || !meta || nbatch < 0) return MODE_ERR_BAD_ARG;
+  ModeMetaLayout ml;
+  int rc = mode_moe_meta_layout(N, E, k, tile_m, &ml);
+  if (rc) return rc;
+  MetaBatch mb{topk_idx, topk_w, (long)idx_bstride, meta + ml.counts, meta + ml.offsets, meta + ml.perm, meta + ml.pos,
+               reinterpret_cast<float*>(meta + ml.posw), meta + ml.tiles, meta + ml.num_tiles, (long)ml.total_words};
+  return dispatch_meta_batched(mb, nbatch, R, tokens_per_row, N, E, k, tile_m, ml.max_tiles, (hipStream_t)stream);
+}
+
+extern "C" size_t mode_dit_workspace_bytes(const ModeDims* dims, int B, int R, int dtype) {
+  if (check_dims(dims) != MODE_OK || B < 0) return 0;
+  return ws_layout(*dims, B, R, dtype).total;
+}
+
+static ModeGemmDesc gemm_desc(int dtype, int epi, int out_dtype, int M, int N, int K, const void* A, long lda, const void* W, long ldw,
+                              void* C, long ldc) {
+  ModeGemmDesc g;
+  memset(&g, 0, sizeof(g));
+  g.dtype = dtype; g.epilogue = epi; g.out_dtype = out_dtype; g.M = M; g.N = N; g.K = K;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc;
+  g.tile_m = mode_gemm_tile_m(dtype);
+  return g;
+}
+
+extern "C" int mode_dit_sigma_embed(const ModeDims* dims, const ModeModelWeights* w, const float* sigma, int R, float* emb_t,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_dims(dims);
+  if (rc) return rc;
+  if (!w || !sigma || !emb_t || !workspace || R <= 0) return MODE_ERR_BAD_ARG;
+  const WsLayout L = ws_layout(*dims, 0, R, MODE_F32);
+  if (workspace_bytes < L.total) return MODE_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  float* e1 = (float*)(ws + L.e1);
+  rc = mode_sigma_embed(sigma, w->w_se, w->b_se, e1, R, dims->D, stream);
+  if (rc) return rc;
+  ModeGemmDesc g = gemm_desc(MODE_F32, MODE_EPI_NONE, MODE_F32, R, dims->D, dims->D, e1, dims->D, w->w_sl, dims->D, emb_t, dims->D);
+  return mode_gemm(&g, stream);
+}
+
+extern "C" int mode_dit_embed_obs(const ModeDims* dims, const ModeModelWeights* w, const float* state_images, const float* goals, int B,
+                                  float* img_e, float* goal_e, void* stream) {
+  int rc = check_dims(dims);
+  if (rc) return rc;
+  if (!w || !state_images || !goals || !img_e || !goal_e || B <= 0) return MODE_ERR_BAD_ARG;
+  ModeGemmDesc g = gemm_desc(MODE_F32, MODE_EPI_NONE, MODE_F32, B * dims->n_img, dims->D, dims->O, state_images, dims->O, w->w_tok,
+                             dims->O, img_e, dims->D);
+  rc = mode_gemm(&g, stream);
+  if (rc) return rc;
+  g = gemm_desc(MODE_F32, MODE_EPI_NONE, MODE_F32, B, dims->D, dims->G, goals, dims->G, w->w_goal, dims->G, goal_e, dims->D);
+  return mode_gemm(&g, stream);
+}
+
+extern "C" int mode_dit_route(const ModeDims* dims, const ModeModelWeights* w, const float* cond, int R, int32_t* topk_idx, float* topk_w,
+                              float* probs, float* shifted, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_dims(dims);
+  if (rc) return rc;
+  if (!w || !w->layers || !cond || !topk_idx || !topk_w || !workspace || R <= 0) return MODE_ERR_BAD_ARG;
+  const WsLayout L = ws_layout(*dims, 0, R, MODE_F32);
+  if (workspace_bytes < L.total) return MODE_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  float* hid = (float*)(ws + L.hid);
+  float* logits = (float*)(ws + L.logits);
+  const int D = dims->D, E = dims->E, k = dims->k;
+  for (int l = 0; l < dims->L; ++l) {
+    const ModeLayerWeights& lw = w->layers[l];
+    ModeGemmDesc g = gemm_desc(MODE_F32, MODE_EPI_BIAS_GELU, MODE_F32, R, 2 * D, D, cond, D, lw.r_w0, D, hid, 2 * D);
+    g.bias = lw.r_b0;
+    rc = mode_gemm(&g, stream);
+    if (rc) return rc;
+    g = gemm_desc(MODE_F32, MODE_EPI_BIAS, MODE_F32, R, E, 2 * D, hid, 2 * D, lw.r_w3, 2 * D, logits, E);
+    g.bias = lw.r_b3;
+    rc = mode_gemm(&g, stream);
+    if (rc) return rc;
+    rc = mode_moe_route_topk_f32(logits, R, E, k, dims->router_normalize, shifted ? shifted + (long)l * R * E : nullptr,
+                                 probs ? probs + (long)l * R * E : nullptr, topk_idx + (long)l * R * k, topk_w + (long)l * R * k, stream);
+    if (rc) return rc;
+  }
+  return MODE_OK;
+}
+
+extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w, const ModeForwardArgs* a, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  int rc = check_dims(dims);
+  if (rc) return rc;
+  if (!w || !w->layers || !a || !workspace) return MODE_ERR_BAD_ARG;
+  if (!a->meta || !a->goal_e || !a->img_e || !a->actions || !a->cond) return MODE_ERR_BAD_ARG;
+  if (a->B <= 0) return MODE_OK;
+  const ModeDims& d = *dims;
+  const int dt = a->dtype, B = a->B, T = d.T, D = d.D, N = B * T, NK = N * d.k;
+  if (dt == MODE_BF16 && (D % 64 || (D / d.H) % 32 || (D / d.H) > 128)) return MODE_ERR_UNSUPPORTED;
+  const WsLayout L = ws_layout(d, B, 0, dt);
+  if (workspace_bytes < L.total) return MODE_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  float* x = (float*)(ws + L.x);
+  void* h = ws + L.h; void* qkv = ws + L.qkv; void* yat = ws + L.y; void* hbuf = ws + L.hbuf;
+  float* ybuf = (float*)(ws + L.ybuf);
+  const int tile_m = mode_gemm_tile_m(dt);
+  ModeMetaLayout ml;
+  mode_moe_meta_layout(N, d.E, d.k, tile_m, &ml);
+  const int cond_rpc = T;   // one conditioning row per sample
+  // cond addressing: row b at cond + b*cond_row_stride.  rmsnorm/combine kernels index cond by (row / rows_per_cond) * D, so a
+  // shared row (stride 0) is expressed as rows_per_cond = N (every token maps to row 0).
+  const int rpc = a->cond_row_stride == 0 ? N : cond_rpc;
+  if (a->cond_row_stride != 0 && a->cond_row_stride != D) return MODE_ERR_UNSUPPORTED;
+
+  // ---- sequence assembly + block 0's ln_1 + c
+  ModeEmbedDesc e;
+  memset(&e, 0, sizeof(e));
+  e.B = B; e.T = T; e.D = D; e.A_len = d.A_len; e.A_dim = d.A_dim; e.n_img = d.n_img; e.use_noise_token = d.use_noise_token;
+  e.emb_t = a->emb_t; e.emb_row_stride = a->emb_row_stride; e.goal_e = a->goal_e; e.img_e = a->img_e; e.actions = a->actions;
+  e.c_in = a->c_in; e.c_in_stride = a->c_in_stride; e.w_act = w->w_act; e.pos = w->pos; e.g = w->layers[0].ln1_g;
+  e.cond = a->cond; e.cond_row_stride = a->cond_row_stride; e.eps = d.eps; e.x = x; e.h = h; e.h_dtype = dt;
+  rc = mode_embed_tokens_fwd(&e, stream);
+  if (rc) return rc;
+
+  for (int l = 0; l < d.L; ++l) {
+    const ModeLayerWeights& lw = w->layers[l];
+    const int32_t* meta = a->meta + (long)l * a->meta_layer_stride;
+    // q,k,v as ONE GEMM [N,D] x [3D,D]^T + bias   (modedit.py:108-110, 141-143)
+    ModeGemmDesc g = gemm_desc(dt, MODE_EPI_BIAS, dt, N, 3 * D, D, h, D, lw.wqkv, D, qkv, 3 * D);
+    g.bias = lw.bqkv;
+    rc = mode_gemm(&g, stream);
+    if (rc) return rc;
+    rc = mode_attn_block_fwd(qkv, lw.qn_g, lw.kn_g, yat, dt, B, T, d.H, D / d.H, d.eps, stream);
+    if (rc) return rc;
+    // c_proj (no bias) + residual, in place on the fp32 stream   (modedit.py:111, 166, 532)
+    g = gemm_desc(dt, MODE_EPI_RESIDUAL, MODE_F32, N, D, D, yat, D, lw.wo, D, x, D);
+    g.resid = x; g.ldr = D;
+    rc = mode_gemm(&g, stream);
+    if (rc) return rc;
+    // x = ln_2(x): overwrites the stream (modedit.py:539); low-precision copy feeds the experts
+    rc = mode_rmsnorm_cond_fwd(x, lw.ln2_g, nullptr, N, D, 1, d.eps, x, h, dt, stream);
+    if (rc) return rc;
+    // experts: gather -> grouped GEMM (SwishGLU epilogue) -> grouped GEMM   (modedit.py:561-566, 83-90, 247-255)
+    g = gemm_desc(dt, MODE_EPI_SWIGLU, dt, NK, 4 * D, D, h, D, lw.w1, D, hbuf, 4 * D);
+    g.bias = lw.b1; g.w_expert_stride = 8L * D * D; g.bias_expert_stride = 8L * D;
+    g.a_rows = meta + ml.perm; g.tiles = meta + ml.tiles; g.num_tiles = meta + ml.num_tiles; g.max_tiles = ml.max_tiles;
+    rc = mode_gemm(&g, stream);
+    if (rc) return rc;
+    g = gemm_desc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 4 * D, hbuf, 4 * D, lw.w2, 4 * D, ybuf, D);
+    g.w_expert_stride = 4L * D * D;
+    g.tiles = meta + ml.tiles; g.num_tiles = meta + ml.num_tiles; g.max_tiles = ml.max_tiles;
+    rc = mode_gemm(&g, stream);
+    if (rc) return rc;
+    if (l + 1 < d.L) {
+      // weighted combine + residual (from the normalised stream) + next block's ln_1 + c
+      rc = mode_moe_combine_norm_fwd(x, ybuf, MODE_F32, meta + ml.pos, reinterpret_cast<const float*>(meta + ml.posw), N, D, d.k,
+                                     w->layers[l + 1].ln1_g, a->cond, rpc, d.eps, x, h, dt, stream);
+      if (rc) return rc;
+    } else {
+      ModeHeadDesc hd;
+      memset(&hd, 0, sizeof(hd));
+      hd.B = B; hd.T = T; hd.D = D; hd.A_len = d.A_len; hd.A_dim = d.A_dim; hd.k = d.k;
+      hd.u = x; hd.Y = ybuf; hd.y_dtype = MODE_F32; hd.pos = meta + ml.pos; hd.posw = reinterpret_cast<const float*>(meta + ml.posw);
+      hd.g = w->ln_g; hd.eps = d.eps; hd.w_out = w->w_out; hd.b_out = w->b_out;
+      hd.x_a = a->actions; hd.scal = a->scal; hd.scal_stride = a->scal_stride;
+      hd.F = a->F; hd.denoised = a->denoised; hd.x_next = a->x_next;
+      rc = mode_head_ddim_fwd(&hd, stream);
+      if (rc) return rc;
+    }
+  }
+  return MODE_OK;
+}

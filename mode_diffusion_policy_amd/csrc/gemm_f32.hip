@@ -1,0 +1,195 @@
+// fp32 MFMA GEMM for gfx950: same contract as the bf16 kernel (plain / gathered / grouped, same epilogues) on
+// v_mfma_f32_16x16x4_f32 — bit-exactly a k-ordered fp32 fma chain, so the noise-conditioned router (whose top-k
+// integers must match the fp32 reference) and the fp32 parity mode of the whole denoiser run on the matrix cores
+// without any reduced-precision step.  64x64x16 tile, 4 wave64 (2x2), each wave 2x2 accumulators of 16x16.
+// General in M, N, K (guarded loads/stores); float4 global loads when K % 16 == 0 and rows are 16-byte aligned.
+#include "mode_common.h"
+
+namespace mode {
+
+constexpr int FBM = 64, FBN = 64, FBK = 16, FNT = 256, FLD = FBK + 1;
+
+struct GemmF32Params {
+  const float* A; long lda;
+  const float* W; long ldw; long w_estride;
+  const float* bias; long bias_estride;
+  const float* resid; long ldr;
+  void* C; long ldc;
+  const int* a_rows; const int* tiles; const int* num_tiles;
+  int M, N, K, m_tiles, n_tiles;
+};
+
+template <int EPI, bool OUT_BF16, bool VEC>
+__global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
+  __shared__ float sA[2][FBM * FLD];
+  __shared__ float sB[2][FBN * FLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int mt = blockIdx.x / p.n_tiles, nt = blockIdx.x % p.n_tiles;
+
+  int row0, row_end, expert = 0;
+  if (p.tiles) {
+    if (mt >= *p.num_tiles) return;
+    expert = p.tiles[mt * 3 + 0]; row0 = p.tiles[mt * 3 + 1]; row_end = p.tiles[mt * 3 + 2];
+  } else {
+    row0 = mt * FBM; row_end = min(p.M, row0 + FBM);
+  }
+  const float* W = p.W + (long)expert * p.w_estride;
+  const float* bias = p.bias ? p.bias + (long)expert * p.bias_estride : nullptr;
+  constexpr int NOUT = (EPI == MODE_EPI_SWIGLU) ? 32 : FBN;
+  const int n0 = nt * NOUT;
+
+  // staging: thread -> tile row (tid>>2), k quad (tid&3)
+  const int tr = tid >> 2, kq = (tid & 3) * 4;
+  const int s = min(row0 + tr, row_end - 1);
+  const long arow = p.a_rows ? (long)p.a_rows[s] : (long)s;
+  const float* a_src = p.A + arow * p.lda + kq;
+  long brow;
+  if constexpr (EPI == MODE_EPI_SWIGLU) brow = (long)min(n0 + (tr & 31), p.N - 1) + ((tr >= 32) ? p.N : 0);
+  else brow = min(n0 + tr, p.N - 1);
+  const float* b_src = W + brow * p.ldw + kq;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_row[2], b_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a_row[i] = (wm * 32 + i * 16 + fr) * FLD;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int br;
+    if constexpr (EPI == MODE_EPI_SWIGLU) br = (j == 0) ? wn * 16 : 32 + wn * 16;
+    else br = wn * 32 + j * 16;
+    b_row[j] = (br + fr) * FLD;
+  }
+
+  const int nk = (p.K + FBK - 1) / FBK;
+  float4 ra, rb;
+  auto gload = [&](int kt) {
+    const int k = kt * FBK + kq;
+    if constexpr (VEC) {
+      ra = *reinterpret_cast<const float4*>(a_src + kt * FBK);
+      rb = *reinterpret_cast<const float4*>(b_src + kt * FBK);
+    } else {
+      const float* a = a_src + kt * FBK; const float* b = b_src + kt * FBK;
+      ra.x = (k + 0 < p.K) ? a[0] : 0.f; ra.y = (k + 1 < p.K) ? a[1] : 0.f;
+      ra.z = (k + 2 < p.K) ? a[2] : 0.f; ra.w = (k + 3 < p.K) ? a[3] : 0.f;
+      rb.x = (k + 0 < p.K) ? b[0] : 0.f; rb.y = (k + 1 < p.K) ? b[1] : 0.f;
+      rb.z = (k + 2 < p.K) ? b[2] : 0.f; rb.w = (k + 3 < p.K) ? b[3] : 0.f;
+    }
+  };
+  auto commit = [&](int buf) {
+    float* a = &sA[buf][tr * FLD + kq]; float* b = &sB[buf][tr * FLD + kq];
+    a[0] = ra.x; a[1] = ra.y; a[2] = ra.z; a[3] = ra.w;
+    b[0] = rb.x; b[1] = rb.y; b[2] = rb.z; b[3] = rb.w;
+  };
+
+  gload(0); commit(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    const bool more = (kt + 1) < nk;
+    if (more) gload(kt + 1);
+    const float* At = sA[kt & 1]; const float* Bt = sB[kt & 1];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = At[a_row[i] + kk * 4 + fq];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = Bt[b_row[j] + kk * 4 + fq];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);   // swapped: D[n][m]
+    }
+    if (more) commit((kt + 1) & 1);
+  }
+
+  const int rows_valid = row_end - row0;
+  auto store = [&](long m, int n, float v) {
+    if (n < p.N) {
+      if constexpr (OUT_BF16) reinterpret_cast<uint16_t*>(p.C)[m * p.ldc + n] = f32_to_bf16_bits(v);
+      else reinterpret_cast<float*>(p.C)[m * p.ldc + n] = v;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ml = wm * 32 + i * 16 + fr;
+    if (ml >= rows_valid) continue;
+    const long m = row0 + ml;
+    if constexpr (EPI == MODE_EPI_SWIGLU) {
+      const int n = n0 + wn * 16 + fq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (n + r < p.N) {
+          const float v = acc[i][0][r] + bias[n + r], g = acc[i][1][r] + bias[p.N + n + r];
+          store(m, n + r, v * silu_f(g));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 32 + j * 16 + fq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < p.N) {
+            float v = acc[i][j][r];
+            if constexpr (EPI == MODE_EPI_BIAS || EPI == MODE_EPI_BIAS_GELU) v += bias[n + r];
+            if constexpr (EPI == MODE_EPI_BIAS_GELU) v = gelu_erf_f(v);
+            if constexpr (EPI == MODE_EPI_RESIDUAL) v += p.resid[m * p.ldr + n + r];
+            store(m, n + r, v);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, bool OUT_BF16>
+static int launch_f32(const GemmF32Params& p, int nblk, bool vec, hipStream_t s) {
+  if (vec) hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, true>), dim3(nblk), dim3(FNT), 0, s, p);
+  else hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, false>), dim3(nblk), dim3(FNT), 0, s, p);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s) {
+  if (d->K <= 0) return MODE_ERR_UNSUPPORTED;
+  if (d->tiles && d->tile_m != FBM) return MODE_ERR_BAD_ARG;
+  if ((d->epilogue == MODE_EPI_BIAS || d->epilogue == MODE_EPI_BIAS_GELU || d->epilogue == MODE_EPI_SWIGLU) && !d->bias)
+    return MODE_ERR_BAD_ARG;
+  if (d->epilogue == MODE_EPI_RESIDUAL && !d->resid) return MODE_ERR_BAD_ARG;
+  if (d->M <= 0) return MODE_OK;
+  GemmF32Params p;
+  p.A = (const float*)d->A; p.lda = d->lda;
+  p.W = (const float*)d->W; p.ldw = d->ldw; p.w_estride = d->w_expert_stride;
+  p.bias = d->bias; p.bias_estride = d->bias_expert_stride;
+  p.resid = d->resid; p.ldr = d->ldr; p.C = d->C; p.ldc = d->ldc;
+  p.a_rows = d->a_rows; p.tiles = d->tiles; p.num_tiles = d->num_tiles;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  const int nout = (d->epilogue == MODE_EPI_SWIGLU) ? 32 : FBN;
+  p.n_tiles = (d->N + nout - 1) / nout;
+  p.m_tiles = d->tiles ? d->max_tiles : (d->M + FBM - 1) / FBM;
+  const int nblk = p.m_tiles * p.n_tiles;
+  const bool vec = (d->K % FBK == 0) && (d->lda % 4 == 0) && (d->ldw % 4 == 0) && (d->w_expert_stride % 4 == 0) &&
+                   (((uintptr_t)d->A | (uintptr_t)d->W) % 16 == 0);
+  const bool ob = d->out_dtype == MODE_BF16;
+#define MODE_CASE(E) \
+  case E: return ob ? launch_f32<E, true>(p, nblk, vec, s) : launch_f32<E, false>(p, nblk, vec, s);
+  switch (d->epilogue) {
+    MODE_CASE(MODE_EPI_NONE)
+    MODE_CASE(MODE_EPI_BIAS)
+    MODE_CASE(MODE_EPI_BIAS_GELU)
+    MODE_CASE(MODE_EPI_RESIDUAL)
+    MODE_CASE(MODE_EPI_SWIGLU)
+    default: return MODE_ERR_BAD_ARG;
+  }
+#undef MODE_CASE
+}
+
+}  // namespace mode

@@ -1,0 +1,160 @@
+// MoE routing tail and token-dispatch metadata (integer work; outputs must be bit-exact against the fp32 reference).
+//   route_topk   : softmax / clamp / top-k / renormalise with wave-shuffle reductions over EP = pow2(E) lanes per row
+//                  (modedit.py:345-349, 392, 398-399, 418-419)
+//   dispatch_meta: canonical permutation of the reference's boolean-mask loop — experts ascending, token ids ascending
+//                  inside an expert (modedit.py:561-566) — via ballot/popcount block scans; also emits the inverse map
+//                  (token, ascending-expert slot) -> sorted row used by the combine kernels and the grouped-GEMM tile table.
+#include "mode_common.h"
+
+namespace mode {
+
+// ---- route: EP lanes cooperate on one row (EP = power of two >= E, <= 64)
+__global__ __launch_bounds__(256) void route_topk_kernel(const float* __restrict__ logits, int R, int E, int EP, int k,
+                                                         int normalize, float* shifted, float* probs, int* topk_idx,
+                                                         float* topk_w) {
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = gtid / EP, e = gtid % EP;
+  const bool rv = row < R;                      // whole EP-lane group is uniform in rv (EP divides 64)
+  const bool ev = rv && e < E;
+  float lg = ev ? logits[(long)row * E + e] : -INFINITY;
+  float mx = lg;
+  for (int o = EP >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const float sh = lg - mx;                     // logits - rowmax   (temperature 1.0, modedit.py:345)
+  const float ex = ev ? expf(sh) : 0.f;
+  float sum = ex;
+  for (int o = EP >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  float p = ex / sum;
+  p = fminf(fmaxf(p, 1e-9f), 1.0f - 1e-9f);     // clamp(1e-9, 1-1e-9)  (:349)
+  if (ev) {
+    if (shifted) shifted[(long)row * E + e] = sh;
+    if (probs) probs[(long)row * E + e] = p;
+  }
+  // k rounds of arg-max; ties -> lower expert id (torch.topk tie order is unspecified; exact ties are outside the contract)
+  float cand = ev ? p : -1.f;
+  float wsum = 0.f;
+  float myw = 0.f; int myslot = -1;
+  for (int j = 0; j < k; ++j) {
+    float bv = cand; int bi = e;
+    for (int o = EP >> 1; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    wsum += bv;
+    if (bi == e) { myslot = j; myw = bv; cand = -2.f; }
+  }
+  if (ev && myslot >= 0) {
+    if (topk_idx) topk_idx[(long)row * k + myslot] = e;
+    if (topk_w) topk_w[(long)row * k + myslot] = normalize ? myw / wsum : myw;
+  }
+}
+
+// ---- dispatch metadata: one workgroup per problem (layer); blockDim = 1024
+struct MetaBatch {
+  const int* idx; const float* w; long idx_bstride;          // [R,k] per problem
+  int* counts; int* offsets; int* perm; int* pos; float* posw; int* tiles; int* num_tiles; long out_bstride;  // strides in 4-byte words
+};
+
+__global__ __launch_bounds__(1024) void dispatch_meta_kernel(MetaBatch mb, int R, int tpr, int N, int E, int k, int tile_m,
+                                                             int max_tiles) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  __shared__ int s_offsets[65];
+  const long bo = (long)blockIdx.x * mb.out_bstride;
+  const int* idx = mb.idx + (long)blockIdx.x * mb.idx_bstride;
+  const float* w = mb.w + (long)blockIdx.x * mb.idx_bstride;
+  int* counts = mb.counts + bo; int* offsets = mb.offsets + bo; int* perm = mb.perm + bo; int* pos = mb.pos + bo;
+  float* posw = mb.posw + bo; int* tiles = mb.tiles + bo; int* num_tiles = mb.num_tiles + bo;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+
+  if (tid == 0) s_offsets[0] = 0;
+  for (int e = 0; e < E; ++e) {
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < N; c0 += blockDim.x) {
+      const int n = c0 + tid;
+      int slot = -1, jasc = 0;
+      if (n < N) {
+        const int* ri = idx + (long)(n / tpr) * k;
+        for (int j = 0; j < k; ++j) {
+          const int v = ri[j];
+          if (v == e) slot = j;
+          jasc += (v < e) ? 1 : 0;                        // how many of this token's experts precede e (ascending order)
+        }
+      }
+      const bool f = slot >= 0;
+      const unsigned long long bal = __ballot(f);
+      const int wrank = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wave[wave] = __popcll(bal);
+      __syncthreads();
+      int wbase = 0, total = 0;
+      for (int i = 0; i < nw; ++i) { const int c = s_wave[i]; if (i < wave) wbase += c; total += c; }
+      const int base = s_base;
+      if (f) {
+        const int srow = s_offsets[e] + base + wbase + wrank;
+        perm[srow] = n;
+        pos[(long)n * k + jasc] = srow;
+        posw[(long)n * k + jasc] = w[(long)(n / tpr) * k + slot];
+      }
+      __syncthreads();
+      if (tid == 0) s_base = base + total;
+    }
+    __syncthreads();
+    if (tid == 0) { counts[e] = s_base; s_offsets[e + 1] = s_offsets[e] + s_base; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int nt = 0;
+    for (int e = 0; e <= E; ++e) offsets[e] = s_offsets[e];
+    for (int e = 0; e < E; ++e) {
+      for (int r = s_offsets[e]; r < s_offsets[e + 1] && nt < max_tiles; r += tile_m) {
+        tiles[nt * 3 + 0] = e; tiles[nt * 3 + 1] = r; tiles[nt * 3 + 2] = min(r + tile_m, s_offsets[e + 1]);
+        ++nt;
+      }
+    }
+    *num_tiles = nt;
+  }
+}
+
+}  // namespace mode
+
+using namespace mode;
+
+extern "C" int mode_moe_route_topk_f32(const float* logits, int R, int E, int k, int normalize, float* shifted, float* probs,
+                                       int32_t* topk_idx, float* topk_w, void* stream) {
+  if (!logits || R < 0 || E <= 0 || k <= 0 || k > E) return MODE_ERR_BAD_ARG;
+  if (E > 64) return MODE_ERR_UNSUPPORTED;
+  if (R == 0) return MODE_OK;
+  int EP = 1;
+  while (EP < E) EP <<= 1;
+  const long threads = (long)R * EP;
+  hipLaunchKernelGGL(route_topk_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, R, E, EP, k, normalize,
+                     shifted, probs, topk_idx, topk_w);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_moe_max_tiles(int N, int E, int k, int tile_m) {
+  if (tile_m <= 0) return 0;
+  return (int)(((long)N * k + tile_m - 1) / tile_m) + E;
+}
+
+namespace mode {
+int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N, int E, int k, int tile_m, int max_tiles,
+                          hipStream_t s) {
+  if (E > 64 || k > E || tpr <= 0 || R * (long)tpr < N) return MODE_ERR_BAD_ARG;
+  if (nbatch == 0) return MODE_OK;
+  hipLaunchKernelGGL(dispatch_meta_kernel, dim3(nbatch), dim3(1024), 0, s, mb, R, tpr, N, E, k, tile_m, max_tiles);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+}  // namespace mode
+
+extern "C" int mode_moe_dispatch_meta(const int32_t* idx, const float* w, int R, int tokens_per_row, int N, int E, int k, int tile_m,
+                                      int32_t* counts, int32_t* offsets, int32_t* perm, int32_t* pos, float* posw, int32_t* tiles,
+                                      int32_t* num_tiles, int max_tiles, void* stream) {
+  if (!idx || !w || !counts || !offsets || !perm || !pos || !posw || !tiles || !num_tiles) return MODE_ERR_BAD_ARG;
+  if (max_tiles < mode_moe_max_tiles(N, E, k, tile_m)) return MODE_ERR_BAD_ARG;
+  MetaBatch mb{idx, w, 0, counts, offsets, perm, pos, posw, tiles, num_tiles, 0};
+  return dispatch_meta_batched(mb, 1, R, tokens_per_row, N, E, k, tile_m, max_tiles, (hipStream_t)stream);
+}

@@ -1,0 +1,322 @@
+// Row-wise fused kernels (HBM-bound): one wave64 per token row, row cached in LDS between the reduce and the normalise
+// pass, wave-shuffle reductions, float4 / 8-byte bf16 vector accesses.  D % 4 == 0.
+//   rmsnorm_cond      : ln_1(x)+c / ln_2 / final ln                        (modedit.py:72-80, 532, 539, 818)
+//   combine_norm      : MoE weighted combine + residual + next block's ln_1+c   (modedit.py:566, 595, 532)
+//   embed_tokens      : sequence assembly + first ln_1+c                    (modedit.py:760-790, 847-860)
+//   head_ddim         : last combine + final ln + Linear(D,A) + EDM/DDIM update  (modedit.py:807-808; score_wrappers.py:79-80;
+//                                                                             gc_sampling.py:948-950)
+#include "mode_common.h"
+
+namespace mode {
+
+constexpr int ROWS_PER_BLOCK = 4;   // 4 waves
+
+// normalise the cached row: y = v / max(sqrt(ssq) * D^-1/2, eps) * g (+ cond); write fp32 and/or low-precision copies
+template <bool LP_BF16>
+__device__ __forceinline__ void norm_store(const float* row, int D, float ssq, const float* g, const float* cond, float eps,
+                                           float* y_f32, void* y_lp, int lane) {
+  const float nrm = fmaxf(sqrtf(ssq) * rsqrtf((float)D), eps);
+  for (int d = lane * 4; d < D; d += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(row + d);
+    const float4 gg = *reinterpret_cast<const float4*>(g + d);
+    float4 o = make_float4(v.x / nrm * gg.x, v.y / nrm * gg.y, v.z / nrm * gg.z, v.w / nrm * gg.w);
+    if (cond) {
+      const float4 c = *reinterpret_cast<const float4*>(cond + d);
+      o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+    }
+    if (y_f32) *reinterpret_cast<float4*>(y_f32 + d) = o;
+    if (y_lp) {
+      if constexpr (LP_BF16) {
+        uint2 pk; pk.x = pack_bf16x2(o.x, o.y); pk.y = pack_bf16x2(o.z, o.w);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(y_lp) + d) = pk;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(y_lp) + d) = o;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float4 load_y4(const void* Y, bool y_bf16, long off) {
+  if (y_bf16) {
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(Y) + off);
+    return make_float4(bf16_bits_to_f32(r.x & 0xffff), bf16_bits_to_f32(r.x >> 16), bf16_bits_to_f32(r.y & 0xffff),
+                       bf16_bits_to_f32(r.y >> 16));
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Y) + off);
+}
+
+// ------------------------------------------------------------------------------------------------------------ rmsnorm
+template <bool LP_BF16>
+__global__ __launch_bounds__(256) void rmsnorm_cond_kernel(const float* x, const float* __restrict__ g,
+                                                           const float* __restrict__ cond, int rows, int D, int rpc, float eps,
+                                                           float* y_f32, void* y_lp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (row >= rows) return;
+  float* cache = reinterpret_cast<float*>(smem) + (size_t)wave * D;
+  const float* xr = x + (long)row * D;
+  float ssq = 0.f;
+  for (int d = lane * 4; d < D; d += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + d);
+    *reinterpret_cast<float4*>(cache + d) = v;
+    ssq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ssq = wave_sum(ssq);
+  norm_store<LP_BF16>(cache, D, ssq, g, cond ? cond + (long)(row / rpc) * D : nullptr, eps,
+                      y_f32 ? y_f32 + (long)row * D : nullptr,
+                      y_lp ? (void*)((char*)y_lp + (long)row * D * (LP_BF16 ? 2 : 4)) : nullptr, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------- combine + norm
+template <bool LP_BF16>
+__global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const void* __restrict__ Y, int y_bf16,
+                                                           const int* __restrict__ pos, const float* __restrict__ posw, int N,
+                                                           int D, int k, const float* __restrict__ g,
+                                                           const float* __restrict__ cond, int rpc, float eps, float* x_next,
+                                                           void* h) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (row >= N) return;
+  float* cache = reinterpret_cast<float*>(smem) + (size_t)wave * D;
+  const float* ur = u + (long)row * D;
+  float ssq = 0.f;
+  for (int d = lane * 4; d < D; d += 256) {
+    const float4 uu = *reinterpret_cast<const float4*>(ur + d);
+    float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < k; ++j) {                       // ascending expert id: next += w * expert(x)   (modedit.py:566)
+      const long p = pos[(long)row * k + j];
+      const float w = posw[(long)row * k + j];
+      const float4 y = load_y4(Y, y_bf16 != 0, p * D + d);
+      nx.x = __fadd_rn(nx.x, __fmul_rn(w, y.x)); nx.y = __fadd_rn(nx.y, __fmul_rn(w, y.y));
+      nx.z = __fadd_rn(nx.z, __fmul_rn(w, y.z)); nx.w = __fadd_rn(nx.w, __fmul_rn(w, y.w));
+    }
+    const float4 v = make_float4(uu.x + nx.x, uu.y + nx.y, uu.z + nx.z, uu.w + nx.w);   // x + next_states (:595)
+    *reinterpret_cast<float4*>(cache + d) = v;
+    if (x_next) *reinterpret_cast<float4*>(x_next + (long)row * D + d) = v;
+    ssq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (!h) return;
+  ssq = wave_sum(ssq);
+  norm_store<LP_BF16>(cache, D, ssq, g, cond ? cond + (long)(row / rpc) * D : nullptr, eps, nullptr,
+                      (void*)((char*)h + (long)row * D * (LP_BF16 ? 2 : 4)), lane);
+}
+
+// --------------------------------------------------------------------------------------------------------------- embed
+template <bool LP_BF16>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const ModeEmbedDesc e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + wave;
+  const int D = e.D, T = e.T;
+  if (row >= e.B * T) return;
+  const int b = row / T, t = row % T;
+  float* cache = reinterpret_cast<float*>(smem) + (size_t)wave * D;
+  const int t0 = e.use_noise_token ? 1 : 0;            // first goal position
+  const int t_img = t0 + 1, t_act = t_img + e.n_img;   // goal_seq_len == 1 on this path
+  const float cin = e.c_in ? e.c_in[(long)b * e.c_in_stride] : 1.0f;
+  float a[8];
+  const int ai = t - t_act;
+  if (ai >= 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (j < e.A_dim) ? e.actions[((long)b * e.A_len + ai) * e.A_dim + j] * cin : 0.f;
+  }
+  float ssq = 0.f;
+  for (int d = lane * 4; d < D; d += 256) {
+    float4 v;
+    if (t < t0) {
+      v = *reinterpret_cast<const float4*>(e.emb_t + (long)b * e.emb_row_stride + d);
+    } else if (t < t_img) {
+      const float4 ge = *reinterpret_cast<const float4*>(e.goal_e + (long)b * D + d);
+      const float4 pp = *reinterpret_cast<const float4*>(e.pos + d);
+      v = make_float4(ge.x + pp.x, ge.y + pp.y, ge.z + pp.z, ge.w + pp.w);
+    } else if (t < t_act) {
+      const float4 ie = *reinterpret_cast<const float4*>(e.img_e + ((long)b * e.n_img + (t - t_img)) * D + d);
+      const float4 pp = *reinterpret_cast<const float4*>(e.pos + D + d);            // both image tokens share pos row 1
+      v = make_float4(ie.x + pp.x, ie.y + pp.y, ie.z + pp.z, ie.w + pp.w);
+    } else {
+      const float4 pp = *reinterpret_cast<const float4*>(e.pos + (long)(1 + ai) * D + d);
+      float o[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float* wr = e.w_act + (long)(d + c) * e.A_dim;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j < e.A_dim) s = fmaf(a[j], wr[j], s);
+        o[c] = s;
+      }
+      v = make_float4(o[0] + pp.x, o[1] + pp.y, o[2] + pp.z, o[3] + pp.w);
+    }
+    *reinterpret_cast<float4*>(cache + d) = v;
+    *reinterpret_cast<float4*>(e.x + (long)row * D + d) = v;
+    ssq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ssq = wave_sum(ssq);
+  norm_store<LP_BF16>(cache, D, ssq, e.g, e.cond ? e.cond + (long)b * e.cond_row_stride : nullptr, e.eps, nullptr,
+                      (void*)((char*)e.h + (long)row * D * (LP_BF16 ? 2 : 4)), lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- head
+__global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ar = blockIdx.x * ROWS_PER_BLOCK + wave;          // action-row index in [0, B*A_len)
+  if (ar >= h.B * h.A_len) return;
+  const int b = ar / h.A_len, ai = ar % h.A_len, D = h.D;
+  const long row = (long)b * h.T + (h.T - h.A_len) + ai;      // last A_len tokens (modedit.py:807)
+  float* cache = reinterpret_cast<float*>(smem) + (size_t)wave * D;
+  const float* ur = h.u + row * D;
+  const bool ybf = h.y_dtype == MODE_BF16;
+  float ssq = 0.f;
+  for (int d = lane * 4; d < D; d += 256) {
+    const float4 uu = *reinterpret_cast<const float4*>(ur + d);
+    float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < h.k; ++j) {
+      const long p = h.pos[row * h.k + j];
+      const float w = h.posw[row * h.k + j];
+      const float4 y = load_y4(h.Y, ybf, p * D + d);
+      nx.x = __fadd_rn(nx.x, __fmul_rn(w, y.x)); nx.y = __fadd_rn(nx.y, __fmul_rn(w, y.y));
+      nx.z = __fadd_rn(nx.z, __fmul_rn(w, y.z)); nx.w = __fadd_rn(nx.w, __fmul_rn(w, y.w));
+    }
+    const float4 v = make_float4(uu.x + nx.x, uu.y + nx.y, uu.z + nx.z, uu.w + nx.w);
+    *reinterpret_cast<float4*>(cache + d) = v;
+    ssq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ssq = wave_sum(ssq);
+  const float nrm = fmaxf(sqrtf(ssq) * rsqrtf((float)D), h.eps);
+  float accv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) accv[j] = 0.f;
+  for (int d = lane * 4; d < D; d += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(cache + d);
+    const float4 gg = *reinterpret_cast<const float4*>(h.g + d);
+    const float4 n = make_float4(v.x / nrm * gg.x, v.y / nrm * gg.y, v.z / nrm * gg.z, v.w / nrm * gg.w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < h.A_dim) {
+        const float4 w = *reinterpret_cast<const float4*>(h.w_out + (long)j * D + d);
+        accv[j] += n.x * w.x + n.y * w.y + n.z * w.z + n.w * w.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) accv[j] = wave_sum(accv[j]);
+  if (lane < h.A_dim) {
+    float F = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (lane == j) F = accv[j];
+    F += h.b_out[lane];
+    const long o = (long)ar * h.A_dim + lane;
+    if (h.F) h.F[o] = F;
+    if (h.scal) {
+      const float* sc = h.scal + (long)b * h.scal_stride;
+      const float xa = h.x_a[o];
+      const float den = F * sc[1] + xa * sc[0];           // F*c_out + x*c_skip      (score_wrappers.py:79-80)
+      if (h.denoised) h.denoised[o] = den;
+      if (h.x_next) h.x_next[o] = sc[2] * xa + (1.0f - sc[2]) * den;   // r*x + (1-r)*denoised (gc_sampling.py:948-950)
+    }
+  }
+}
+
+__global__ void ddim_edm_step_kernel(const float* F, const float* x_a, const float* scal, long scal_stride, int B,
+                                     int per_sample, float* denoised, float* x_next) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * per_sample) return;
+  const float* sc = scal + (i / per_sample) * scal_stride;
+  const float xa = x_a[i];
+  const float den = F[i] * sc[1] + xa * sc[0];
+  if (denoised) denoised[i] = den;
+  if (x_next) x_next[i] = sc[2] * xa + (1.0f - sc[2]) * den;
+}
+
+__global__ void sigma_embed_kernel(const float* sigma, const float* w, const float* b, float* e1, int R, int D) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)R * D) return;
+  const int r = i / D, d = i % D;
+  e1[i] = (logf(sigma[r]) / 4.0f) * w[d] + b[d];             // sigma.log()/4 -> Linear(1, D)   (modedit.py:824-828)
+}
+
+}  // namespace mode
+
+using namespace mode;
+
+extern "C" int mode_rmsnorm_cond_fwd(const float* x, const float* g, const float* cond, int rows, int D, int rows_per_cond,
+                                     float eps, float* y_f32, void* y_lp, int lp_dtype, void* stream) {
+  if (!x || !g || rows < 0 || D <= 0 || (D & 3)) return MODE_ERR_BAD_ARG;
+  if (rows == 0) return MODE_OK;
+  if (rows_per_cond <= 0) rows_per_cond = 1;
+  const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  const size_t lds = (size_t)ROWS_PER_BLOCK * D * 4;
+  if (lp_dtype == MODE_BF16)
+    hipLaunchKernelGGL(rmsnorm_cond_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, x, g, cond, rows, D, rows_per_cond, eps, y_f32, y_lp);
+  else
+    hipLaunchKernelGGL(rmsnorm_cond_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, x, g, cond, rows, D, rows_per_cond, eps, y_f32, y_lp);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_moe_combine_norm_fwd(const float* u, const void* Y, int y_dtype, const int32_t* pos, const float* posw, int N,
+                                         int D, int k, const float* g, const float* cond, int rows_per_cond, float eps,
+                                         float* x_next, void* h, int h_dtype, void* stream) {
+  if (!u || !Y || !pos || !posw || N < 0 || D <= 0 || (D & 3) || k <= 0) return MODE_ERR_BAD_ARG;
+  if (h && !g) return MODE_ERR_BAD_ARG;
+  if (N == 0) return MODE_OK;
+  if (rows_per_cond <= 0) rows_per_cond = 1;
+  const dim3 grid((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  const size_t lds = (size_t)ROWS_PER_BLOCK * D * 4;
+  const int ybf = y_dtype == MODE_BF16;
+  if (h_dtype == MODE_BF16)
+    hipLaunchKernelGGL(combine_norm_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, u, Y, ybf, pos, posw, N, D, k, g, cond, rows_per_cond, eps, x_next, h);
+  else
+    hipLaunchKernelGGL(combine_norm_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, u, Y, ybf, pos, posw, N, D, k, g, cond, rows_per_cond, eps, x_next, h);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_embed_tokens_fwd(const ModeEmbedDesc* d, void* stream) {
+  if (!d || !d->goal_e || !d->img_e || !d->actions || !d->w_act || !d->pos || !d->g || !d->x || !d->h) return MODE_ERR_BAD_ARG;
+  if (d->use_noise_token && !d->emb_t) return MODE_ERR_BAD_ARG;
+  if ((d->D & 3) || d->A_dim > 8 || d->T != (d->use_noise_token ? 1 : 0) + 1 + d->n_img + d->A_len) return MODE_ERR_UNSUPPORTED;
+  const int rows = d->B * d->T;
+  if (rows == 0) return MODE_OK;
+  const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  const size_t lds = (size_t)ROWS_PER_BLOCK * d->D * 4;
+  if (d->h_dtype == MODE_BF16) hipLaunchKernelGGL(embed_tokens_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(embed_tokens_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, *d);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_head_ddim_fwd(const ModeHeadDesc* d, void* stream) {
+  if (!d || !d->u || !d->Y || !d->pos || !d->posw || !d->g || !d->w_out || !d->b_out) return MODE_ERR_BAD_ARG;
+  if (d->scal && !d->x_a) return MODE_ERR_BAD_ARG;
+  if ((d->D & 3) || d->A_dim > 8) return MODE_ERR_UNSUPPORTED;
+  const int rows = d->B * d->A_len;
+  if (rows == 0) return MODE_OK;
+  const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  const size_t lds = (size_t)ROWS_PER_BLOCK * d->D * 4;
+  hipLaunchKernelGGL(head_ddim_kernel, grid, dim3(256), lds, (hipStream_t)stream, *d);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_ddim_edm_step(const float* F, const float* x_a, const float* scal, int64_t scal_stride, int B, int per_sample,
+                                  float* denoised, float* x_next, void* stream) {
+  if (!F || !x_a || !scal) return MODE_ERR_BAD_ARG;
+  const long n = (long)B * per_sample;
+  if (n == 0) return MODE_OK;
+  hipLaunchKernelGGL(ddim_edm_step_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, F, x_a, scal, (long)scal_stride, B,
+                     per_sample, denoised, x_next);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_sigma_embed(const float* sigma, const float* w, const float* b, float* e1, int R, int D, void* stream) {
+  if (!sigma || !w || !b || !e1) return MODE_ERR_BAD_ARG;
+  const long n = (long)R * D;
+  if (n == 0) return MODE_OK;
+  hipLaunchKernelGGL(sigma_embed_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sigma, w, b, e1, R, D);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}

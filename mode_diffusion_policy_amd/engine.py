@@ -1,0 +1,150 @@
+"""Host-side driver of the HIP denoiser: weight shadows, workspaces and the launch chain.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic of the hot path runs in libmode_hip.so.
+Weight shadows are plain casts of the reference-layout tensors (q/k/v concatenated, experts stacked) — the on-disk
+``state_dict`` layout is never changed; shadows are rebuilt when any parameter's (data_ptr, _version) changes
+(optimizer step, ``load_state_dict``, EMA swap — SURVEY.md §7 "weight-layout staleness").
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+_DT = {"bf16": (L.MODE_BF16, torch.bfloat16), "fp32": (L.MODE_F32, torch.float32)}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class DitEngine:
+    def __init__(self, model, compute_dtype: str = "bf16"):
+        if compute_dtype not in _DT:
+            raise ValueError(f"compute_dtype must be one of {list(_DT)}")
+        self.model = model
+        self.compute_dtype = compute_dtype
+        self.dt, self.tdt = _DT[compute_dtype]
+        self.lib = L.load()
+        self._wkey = None
+        self._keep: Dict[str, torch.Tensor] = {}
+        self._ws: Optional[torch.Tensor] = None
+        m = model
+        self.dims = L.ModeDims(D=m.embed_dim, H=m.n_heads, L=m.num_layers, E=m.num_experts, k=m.top_k, T=m.seq_len,
+                               A_len=m.action_seq_len, A_dim=m.action_dim, O=m.obs_dim, G=m.goal_dim, n_img=m.n_img_tokens,
+                               use_noise_token=int(m.use_noise_token_as_input), router_normalize=int(m.router_normalize),
+                               eps=1e-6)
+        self.tile_m = self.lib.mode_gemm_tile_m(self.dt)
+
+    # ------------------------------------------------------------------ weights
+    def _key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
+    def ensure_weights(self) -> None:
+        key = self._key()
+        if key == self._wkey:
+            return
+        m, tdt = self.model, self.tdt
+        dev = m.pos_emb.device
+        if dev.type != "cuda":
+            raise L.ModeHipUnavailable("MoDeDiT parameters must live on a ROCm device: the denoising path has no CPU implementation")
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        keep: Dict[str, torch.Tensor] = {}
+        layers = (L.ModeLayerWeights * m.num_layers)()
+        with torch.no_grad():
+            for i, blk in enumerate(m.blocks):
+                a = blk.attn
+                k = f"l{i}."
+                keep[k + "wqkv"] = torch.cat([a.query.weight, a.key.weight, a.value.weight], 0).to(tdt).contiguous()
+                keep[k + "bqkv"] = torch.cat([a.query.bias, a.key.bias, a.value.bias], 0).float().contiguous()
+                keep[k + "wo"] = a.c_proj.weight.detach().to(tdt).contiguous()
+                ex = [blk.experts[f"expert_{e}"].mlp for e in range(m.num_experts)]
+                keep[k + "w1"] = torch.stack([x[0].project.weight for x in ex]).to(tdt).contiguous()
+                keep[k + "b1"] = torch.stack([x[0].project.bias for x in ex]).float().contiguous()
+                keep[k + "w2"] = torch.stack([x[2].weight for x in ex]).to(tdt).contiguous()
+                r = blk.router.router.mlp
+                for nm, t in (("ln1", blk.ln_1.g), ("ln2", blk.ln_2.g), ("qn", a.q_norm.g), ("kn", a.k_norm.g),
+                              ("rw0", r[0].weight), ("rb0", r[0].bias), ("rw3", r[3].weight), ("rb3", r[3].bias)):
+                    keep[k + nm] = f32(t)
+                lw = layers[i]
+                lw.ln1_g, lw.ln2_g, lw.qn_g, lw.kn_g = (_ptr(keep[k + n]) for n in ("ln1", "ln2", "qn", "kn"))
+                lw.wqkv, lw.bqkv, lw.wo = _ptr(keep[k + "wqkv"]), _ptr(keep[k + "bqkv"]), _ptr(keep[k + "wo"])
+                lw.r_w0, lw.r_b0, lw.r_w3, lw.r_b3 = (_ptr(keep[k + n]) for n in ("rw0", "rb0", "rw3", "rb3"))
+                lw.w1, lw.b1, lw.w2 = _ptr(keep[k + "w1"]), _ptr(keep[k + "b1"]), _ptr(keep[k + "w2"])
+            for nm, t in (("pos", m.pos_emb[0]), ("w_se", m.sigma_emb.weight), ("b_se", m.sigma_emb.bias),
+                          ("w_sl", m.sigma_linear.weight), ("w_tok", m.tok_emb.weight), ("w_goal", m.goal_emb.weight),
+                          ("w_act", m.action_emb.weight), ("ln_g", m.ln.g), ("w_out", m.out.weight), ("b_out", m.out.bias)):
+                keep[nm] = f32(t)
+        mw = L.ModeModelWeights()
+        for nm in ("pos", "w_se", "b_se", "w_sl", "w_tok", "w_goal", "w_act", "ln_g", "w_out", "b_out"):
+            setattr(mw, nm, _ptr(keep[nm]))
+        mw.layers = C.cast(layers, C.POINTER(L.ModeLayerWeights))
+        self._keep, self._layers, self._mw, self._wkey = keep, layers, mw, key
+        self.device = dev
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, B: int, R: int) -> Tuple[int, int]:
+        need = self.lib.mode_dit_workspace_bytes(C.byref(self.dims), B, R, self.dt)
+        if need == 0:
+            raise RuntimeError("unsupported MoDeDiT dimensions for the HIP path")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws.data_ptr(), self._ws.numel()
+
+    def meta_layout(self, N: int) -> L.ModeMetaLayout:
+        ml = L.ModeMetaLayout()
+        L.check(self.lib.mode_moe_meta_layout(N, self.dims.E, self.dims.k, self.tile_m, C.byref(ml)), "meta_layout")
+        return ml
+
+    # ------------------------------------------------------------------ building blocks (each = a few launches, no sync)
+    def sigma_embed(self, sigma: torch.Tensor) -> torch.Tensor:
+        R = sigma.numel()
+        emb = torch.empty(R, self.dims.D, dtype=torch.float32, device=self.device)
+        ws, wsn = self.workspace(0, R)
+        L.check(self.lib.mode_dit_sigma_embed(C.byref(self.dims), C.byref(self._mw), sigma.data_ptr(), R, emb.data_ptr(), ws, wsn,
+                                              _stream()), "sigma_embed")
+        return emb
+
+    def embed_obs(self, state_images: torch.Tensor, goals: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        B = state_images.shape[0]
+        img_e = torch.empty(B * self.dims.n_img, self.dims.D, dtype=torch.float32, device=self.device)
+        goal_e = torch.empty(B, self.dims.D, dtype=torch.float32, device=self.device)
+        L.check(self.lib.mode_dit_embed_obs(C.byref(self.dims), C.byref(self._mw), state_images.data_ptr(), goals.data_ptr(), B,
+                                            img_e.data_ptr(), goal_e.data_ptr(), _stream()), "embed_obs")
+        return img_e, goal_e
+
+    def route(self, cond: torch.Tensor, want_probs: bool = False):
+        R, d = cond.shape[0], self.dims
+        idx = torch.empty(d.L, R, d.k, dtype=torch.int32, device=self.device)
+        w = torch.empty(d.L, R, d.k, dtype=torch.float32, device=self.device)
+        probs = torch.empty(d.L, R, d.E, dtype=torch.float32, device=self.device) if want_probs else None
+        shifted = torch.empty(d.L, R, d.E, dtype=torch.float32, device=self.device) if want_probs else None
+        ws, wsn = self.workspace(0, R)
+        L.check(self.lib.mode_dit_route(C.byref(d), C.byref(self._mw), cond.data_ptr(), R, idx.data_ptr(), w.data_ptr(),
+                                        _ptr(probs), _ptr(shifted), ws, wsn, _stream()), "route")
+        return idx, w, probs, shifted
+
+    def dispatch(self, idx: torch.Tensor, w: torch.Tensor, nbatch: int, R: int, tokens_per_row: int, N: int) -> torch.Tensor:
+        ml = self.meta_layout(N)
+        meta = torch.empty(nbatch, ml.total_words, dtype=torch.int32, device=self.device)
+        L.check(self.lib.mode_dit_dispatch(idx.data_ptr(), w.data_ptr(), nbatch, R * self.dims.k, R, tokens_per_row, N, self.dims.E,
+                                           self.dims.k, self.tile_m, meta.data_ptr(), _stream()), "dispatch")
+        return meta
+
+    def forward(self, B: int, emb_t, emb_stride: int, cond, cond_stride: int, meta_ptr: int, meta_layer_stride: int, goal_e, img_e,
+                actions, c_in=None, c_in_stride: int = 0, scal_ptr: Optional[int] = None, scal_stride: int = 0, F=None,
+                denoised=None, x_next=None) -> None:
+        a = L.ModeForwardArgs(B=B, dtype=self.dt, emb_t=_ptr(emb_t), emb_row_stride=emb_stride, cond=_ptr(cond),
+                              cond_row_stride=cond_stride, meta=meta_ptr, meta_layer_stride=meta_layer_stride,
+                              goal_e=_ptr(goal_e), img_e=_ptr(img_e), actions=_ptr(actions), c_in=_ptr(c_in) if torch.is_tensor(c_in) else c_in,
+                              c_in_stride=c_in_stride, scal=scal_ptr, scal_stride=scal_stride, F=_ptr(F), denoised=_ptr(denoised),
+                              x_next=_ptr(x_next))
+        ws, wsn = self.workspace(B, 0)
+        L.check(self.lib.mode_dit_forward(C.byref(self.dims), C.byref(self._mw), C.byref(a), ws, wsn, _stream()), "dit_forward")

@@ -1,0 +1,417 @@
+"""Drop-in mirror of the reference's ``mode.models.networks.modedit`` for the denoising path.
+
+Same constructor keys (conf/model/mode_agent.yaml:46-76), same ``forward(states, actions, goals, sigma, uncond)`` signature
+(modedit.py:741-809), same ``state_dict`` key set and the same side-channel attributes the agent reaches
+through (``blocks``, ``logits_per_layer``, ``probs_per_layer``, expert-usage counters, ``freeze_router`` …) — but the module
+tree below only HOLDS parameters; every FLOP of ``forward`` runs in the HIP library (``engine.DitEngine``).
+There is no CPU / eager fallback: calling ``forward`` without the library or off-device raises.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .engine import DitEngine
+
+logger = logging.getLogger(__name__)
+
+
+class _Holder(nn.Module):
+    """Parameter container; its own forward is never part of the product path."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise L.ModeHipUnavailable("parameter holder: the MoDE denoiser only runs through the HIP engine")
+
+
+class RMSNorm(_Holder):
+    """gain ``g`` of x / max(||x||·dim^-1/2, eps) · g  (modedit.py:72-80)."""
+
+    def __init__(self, dim: int, eps: float = 1e-8):
+        super().__init__()
+        self.scale, self.eps = dim ** -0.5, eps
+        self.g = nn.Parameter(torch.ones(dim))
+
+
+class SwishGLU(_Holder):
+    """``project`` = Linear(in, 2*out): first half value, second half gate (modedit.py:83-90)."""
+
+    def __init__(self, in_dim: int, out_dim: int):
+        super().__init__()
+        self.project = nn.Linear(in_dim, 2 * out_dim)
+
+
+class Mlp(_Holder):
+    """Expert MLP holder: mlp.0 = SwishGLU(D,4D), mlp.2 = Linear(4D,D,no bias) (modedit.py:220-265)."""
+
+    def __init__(self, n_embd: int, bias: bool = False, dropout: float = 0.0):
+        super().__init__()
+        self.mlp = nn.Sequential(SwishGLU(n_embd, 4 * n_embd), nn.Dropout(dropout), nn.Linear(4 * n_embd, n_embd, bias=bias))
+
+
+class Attention(_Holder):
+    """q/k/v Linear(+bias), c_proj (no bias), qk-RMSNorm gains (modedit.py:94-129)."""
+
+    def __init__(self, n_embd: int, n_head: int, attn_pdrop: float):
+        super().__init__()
+        assert n_embd % n_head == 0
+        self.key = nn.Linear(n_embd, n_embd)
+        self.query = nn.Linear(n_embd, n_embd)
+        self.value = nn.Linear(n_embd, n_embd)
+        self.c_proj = nn.Linear(n_embd, n_embd, bias=False)
+        self.q_norm = RMSNorm(n_embd // n_head, eps=1e-6)
+        self.k_norm = RMSNorm(n_embd // n_head, eps=1e-6)
+        self.n_head, self.n_embd, self.attn_pdrop = n_head, n_embd, attn_pdrop
+
+
+class CondRouterMLP(_Holder):
+    """Linear(D,2D) -> GELU -> Dropout(0) -> Linear(2D,E), init N(0,0.02)/zero bias (modedit.py:170-217)."""
+
+    def __init__(self, n_embd: int, num_experts: int):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(n_embd, 2 * n_embd), nn.GELU(), nn.Dropout(0), nn.Linear(2 * n_embd, num_experts))
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, mean=0.0, std=0.02)
+                nn.init.zeros_(m.bias)
+
+
+class RouterCond(_Holder):
+    def __init__(self, n_embd: int, num_experts: int, top_k: int, use_argmax: bool, normalize: bool):
+        super().__init__()
+        self.num_experts, self.top_k, self.use_argmax, self.normalize = num_experts, top_k, use_argmax, normalize
+        self.temperature = 1.0
+        self.router = CondRouterMLP(n_embd, num_experts)
+        self.logits = None
+
+
+class NoiseBlockMoE(_Holder):
+    """One MoE-DiT block (modedit.py:424-528).  ``isinstance(block, NoiseBlockMoE)`` is what the agent's expert-usage
+    logging checks (mode_agent.py:470-476)."""
+
+    def __init__(self, n_embd, n_heads, attn_pdrop, mlp_pdrop, num_experts=4, top_k=2, router_normalize=True, use_argmax=False):
+        super().__init__()
+        self.n_embd = n_embd
+        self.ln_1 = RMSNorm(n_embd, eps=1e-6)
+        self.attn = Attention(n_embd, n_heads, attn_pdrop)
+        self.ln_2 = RMSNorm(n_embd, eps=1e-6)
+        self.router = RouterCond(n_embd, num_experts, top_k, use_argmax, router_normalize)
+        self.experts = nn.ModuleDict({f"expert_{i}": Mlp(n_embd, bias=False, dropout=mlp_pdrop) for i in range(num_experts)})
+        self.num_experts = num_experts
+        self.logits = None
+        self.probs = None
+        self.expert_usage = torch.zeros(num_experts)
+        self.inference_expert_usage = torch.zeros(num_experts)
+        self.total_tokens_processed = 0
+        self.fused_experts = {}     # {sigma bits: (e0, e1, p0, p1)} — routing cache; weights are never duplicated
+        self.routing_info = {}
+
+    def get_expert_usage(self):
+        return self.inference_expert_usage
+
+    def reset_expert_usage(self):
+        self.expert_usage.zero_()
+        self.inference_expert_usage.zero_()
+        self.total_tokens_processed = 0
+
+    def reset_expert_cache(self):
+        self.fused_experts = {}
+        self.routing_info = {}
+
+
+class MoDeDiT(nn.Module):
+    """Mixture-of-Experts Diffusion Transformer denoiser on MI355X (reference: modedit.py:641-1090)."""
+
+    def __init__(self, obs_dim: int, goal_dim: int, device: str, goal_conditioned: bool, action_dim: int, embed_dim: int,
+                 embed_pdrob: float, attn_pdrop: float, n_layers: int, n_heads: int, goal_seq_len: int, obs_seq_len: int,
+                 action_seq_len: int, state_dim=None, mlp_pdrop: float = 0.1, goal_drop: float = 0.1, linear_output: bool = True,
+                 use_proprio: bool = False, cond_router: bool = True, num_experts: int = 4, top_k: int = 2,
+                 router_normalize: bool = True, use_goal_in_routing: bool = False, use_argmax: bool = False, causal: bool = True,
+                 use_shared_expert: bool = False, use_noise_token_as_input: bool = True, use_custom_attn_mask: bool = False,
+                 init_style: str = "default", compute_dtype: str = "bf16", n_img_tokens: int = 2):
+        super().__init__()
+        # flag combinations the reference itself cannot run or that leave the benchmarked path
+        unsupported = dict(use_proprio=use_proprio, use_custom_attn_mask=use_custom_attn_mask, use_shared_expert=use_shared_expert,
+                           not_goal_conditioned=not goal_conditioned, not_linear_output=not linear_output,
+                           not_cond_router=not cond_router, not_causal=not causal)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"MoDeDiT (HIP): unsupported configuration flags: {bad}")
+        if goal_seq_len != 1 or obs_seq_len != 1:
+            raise NotImplementedError("MoDeDiT (HIP): goal_seq_len == obs_seq_len == 1 is the only layout the reference ships")
+        if embed_pdrob:
+            raise NotImplementedError("MoDeDiT (HIP): embed_pdrob must be 0 (as in conf/model/mode_agent.yaml:61)")
+        self.device = device
+        self.use_proprio = use_proprio
+        self.obs_dim, self.goal_dim, self.action_dim, self.embed_dim = obs_dim, goal_dim, action_dim, embed_dim
+        self.sigma_emb = nn.Linear(1, embed_dim)
+        self.sigma_linear = nn.Linear(embed_dim, embed_dim, bias=False)
+        seq_size = goal_seq_len + obs_seq_len - 1 + action_seq_len
+        self.tok_emb = nn.Linear(obs_dim, embed_dim, bias=False)
+        self.gripper_embed = nn.Linear(obs_dim, embed_dim, bias=False)        # dead in the reference too (never gets a grad)
+        self.goal_emb = nn.Linear(goal_dim, embed_dim, bias=False)
+        self.action_emb = nn.Linear(action_dim, embed_dim, bias=False)
+        self.pos_emb = nn.Parameter(torch.zeros(1, seq_size, embed_dim))
+        self.cond_mask_prob = goal_drop
+        self.attn_pdrop, self.mlp_pdrop = attn_pdrop, mlp_pdrop
+        self.num_layers, self.n_heads = n_layers, n_heads
+        self.blocks = nn.ModuleList([
+            NoiseBlockMoE(embed_dim, n_heads, attn_pdrop, mlp_pdrop, num_experts=num_experts, top_k=top_k,
+                          router_normalize=router_normalize, use_argmax=use_argmax) for _ in range(n_layers)])
+        self.ln = RMSNorm(embed_dim, eps=1e-6)
+        self.linear_output = linear_output
+        self.out = nn.Linear(embed_dim, action_dim)
+        self.goal_seq_len, self.action_seq_len = goal_seq_len, action_seq_len
+        self.num_experts, self.top_k = num_experts, top_k
+        self.router_normalize, self.use_argmax = router_normalize, use_argmax
+        self.use_shared_expert = use_shared_expert
+        self.use_noise_token_as_input = use_noise_token_as_input
+        self.use_goal_in_routing = use_goal_in_routing
+        self.init_style = init_style           # accepted and ignored, like the reference
+        self.goal_conditioned, self.causal = goal_conditioned, causal
+        self.n_img_tokens = n_img_tokens
+        self.seq_len = (1 if use_noise_token_as_input else 0) + goal_seq_len + n_img_tokens + action_seq_len
+        self.logits_per_layer = None
+        self.probs_per_layer = None
+        self.compute_dtype = compute_dtype
+        self._engine: Optional[DitEngine] = None
+        self._route_cache = {}
+
+    # ------------------------------------------------------------------ engine access
+    @property
+    def engine(self) -> DitEngine:
+        if self._engine is None or self._engine.compute_dtype != self.compute_dtype:
+            self._engine = DitEngine(self, self.compute_dtype)
+        self._engine.ensure_weights()
+        return self._engine
+
+    # ------------------------------------------------------------------ reference-compatible helpers
+    def get_params(self):
+        return self.parameters()
+
+    def preprocess_goals(self, goals, states_length, uncond=False):
+        """modedit.py:862-880 (incl. the element-wise Bernoulli goal mask in training, :882-893)."""
+        if goals.dim() == 2:
+            goals = goals.unsqueeze(1)
+        if goals.shape[1] == states_length and self.goal_seq_len == 1:
+            goals = goals[:, :1, :]
+        if goals.shape[-1] == 2 * self.obs_dim:
+            goals = goals[:, :, : self.obs_dim]
+        if self.training and self.cond_mask_prob > 0.0:
+            mask = torch.bernoulli(torch.full_like(goals, self.cond_mask_prob))
+            goals = goals * (1.0 - mask)
+        if uncond:
+            goals = torch.zeros_like(goals)
+        return goals
+
+    def forward(self, states, actions, goals, sigma, uncond: Optional[bool] = False):
+        """states: {'state_images': (B, 2, obs_dim)}; actions (B, A_len, A_dim); goals (B,1,G)|(B,G); sigma (B,)|() -> (B, A_len, A_dim)."""
+        if self.training:
+            from .training import dit_forward_train   # autograd path (HIP forward + backward kernels)
+            return dit_forward_train(self, states, actions, goals, sigma, uncond)
+        eng = self.engine
+        dev = eng.device
+        B = actions.shape[0]
+        T, D = self.seq_len, self.embed_dim
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        img = f(states["state_images"])
+        if img.dim() != 3 or img.shape[1] != self.n_img_tokens or img.shape[2] != self.obs_dim:
+            raise ValueError(f"state_images must be (B, {self.n_img_tokens}, {self.obs_dim}), got {tuple(img.shape)}")
+        goals = f(self.preprocess_goals(goals, 1, uncond=bool(uncond)))
+        acts = f(actions)
+        sig = f(sigma).reshape(-1)
+        if sig.numel() not in (1, B):
+            raise ValueError("sigma must be a scalar or have one entry per sample")
+        R = sig.numel()
+        emb_t = eng.sigma_embed(sig)
+        img_e, goal_e = eng.embed_obs(img, goals)
+        cond = emb_t
+        if self.use_goal_in_routing:                                       # modedit.py:801-802
+            cond = (emb_t.expand(B, D) + goal_e).contiguous()
+            R = B
+        idx, w, _, _ = eng.route(cond)
+        N = B * T
+        meta = eng.dispatch(idx, w, self.num_layers, R, N if R == 1 else T, N)
+        ml = eng.meta_layout(N)
+        F = torch.empty(B, self.action_seq_len, self.action_dim, dtype=torch.float32, device=dev)
+        eng.forward(B, emb_t, 0 if emb_t.shape[0] == 1 else D, cond, 0 if cond.shape[0] == 1 else D,
+                    meta.data_ptr(), ml.total_words, goal_e, img_e, acts, F=F)
+        self._last_topk = idx
+        self._account_usage(meta, ml, N)
+        self.logits_per_layer = [None] * self.num_layers                   # only populated in training (modedit.py:584-593)
+        self.probs_per_layer = [None] * self.num_layers
+        return F
+
+    # ------------------------------------------------------------------ fused EDM forward / DDIM sampler
+    def _prep_obs(self, eng, states, goals, uncond=False):
+        f = lambda t: t.detach().to(device=eng.device, dtype=torch.float32).contiguous()
+        img = f(states["state_images"])
+        if img.dim() != 3 or img.shape[1] != self.n_img_tokens or img.shape[2] != self.obs_dim:
+            raise ValueError(f"state_images must be (B, {self.n_img_tokens}, {self.obs_dim}), got {tuple(img.shape)}")
+        goals = f(self.preprocess_goals(goals, 1, uncond=bool(uncond)))
+        return img, goals.reshape(img.shape[0], -1).contiguous()
+
+    @torch.no_grad()
+    def denoise(self, states, action, goals, sigma, sigma_data: float):
+        """GCDenoiser.forward (score_wrappers.py:65-80) with c_in / c_out / c_skip fused into the HIP chain."""
+        eng = self.engine
+        dev, B, T, D = eng.device, action.shape[0], self.seq_len, self.embed_dim
+        img, goals = self._prep_obs(eng, states, goals)
+        x = action.detach().to(device=dev, dtype=torch.float32).contiguous()
+        sig = sigma.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        if sig.numel() not in (1, B):
+            raise ValueError("sigma must be a scalar or have one entry per sample")
+        R = sig.numel()
+        s2 = sig * sig + sigma_data ** 2
+        c_in = (1.0 / s2.sqrt()).contiguous()
+        scal = torch.stack([sigma_data ** 2 / s2, sig * sigma_data / s2.sqrt(), torch.zeros_like(sig), torch.zeros_like(sig)], 1).contiguous()
+        emb_t = eng.sigma_embed(sig)
+        img_e, goal_e = eng.embed_obs(img, goals)
+        cond = emb_t
+        if self.use_goal_in_routing:
+            cond = (emb_t.expand(B, D) + goal_e).contiguous()
+        Rr = cond.shape[0]
+        idx, w, _, _ = eng.route(cond)
+        N = B * T
+        meta = eng.dispatch(idx, w, self.num_layers, Rr, N if Rr == 1 else T, N)
+        ml = eng.meta_layout(N)
+        den = torch.empty_like(x)
+        eng.forward(B, emb_t, 0 if R == 1 else D, cond, 0 if Rr == 1 else D, meta.data_ptr(), ml.total_words, goal_e, img_e, x,
+                    c_in=c_in, c_in_stride=0 if R == 1 else 1, scal_ptr=scal.data_ptr(), scal_stride=0 if R == 1 else 4, denoised=den)
+        self._last_topk = idx
+        self._account_usage(meta, ml, N)
+        return den
+
+    def _ddim_chain(self, eng, img, goals, x, sigmas, sigma_data: float):
+        """Launch chain of a whole DDIM run; pure launches + tiny torch index math, no host sync -> capturable."""
+        B, T, D, Ly = x.shape[0], self.seq_len, self.embed_dim, self.num_layers
+        n = sigmas.numel() - 1
+        sig, nxt = sigmas[:-1].contiguous(), sigmas[1:]
+        s2 = sig * sig + sigma_data ** 2
+        c_in = (1.0 / s2.sqrt()).contiguous()
+        scal = torch.stack([sigma_data ** 2 / s2, sig * sigma_data / s2.sqrt(), nxt / sig, torch.zeros_like(sig)], 1).contiguous()
+        emb_all = eng.sigma_embed(sig)                                   # [n, D]: one conditioning row per step
+        img_e, goal_e = eng.embed_obs(img, goals)                        # step-invariant, hoisted (modedit.py:760,765)
+        idx, w, _, _ = eng.route(emb_all)                                # [L, n, k]: routing for ALL steps up front
+        N = B * T
+        meta = eng.dispatch(idx, w, Ly * n, 1, N, N)                     # record (l, s) at l*n + s
+        ml = eng.meta_layout(N)
+        for s in range(n):
+            e = emb_all[s]
+            eng.forward(B, e, 0, e, 0, meta.data_ptr() + 4 * s * ml.total_words, n * ml.total_words, goal_e, img_e, x,
+                        c_in=c_in.data_ptr() + 4 * s, c_in_stride=0, scal_ptr=scal.data_ptr() + 16 * s, scal_stride=0, x_next=x)
+        return idx, meta, ml
+
+    @torch.no_grad()
+    def sample_ddim_fused(self, states, action, goals, sigmas, sigma_data: float):
+        """sample_ddim (gc_sampling.py:922-951) o GCDenoiser o MoDeDiT as one hipGraph replay."""
+        import os
+        eng = self.engine
+        dev, B = eng.device, action.shape[0]
+        img, goals = self._prep_obs(eng, states, goals)
+        sig = sigmas.detach().to(device=dev, dtype=torch.float32).contiguous()
+        x0 = action.detach().to(device=dev, dtype=torch.float32)
+        if self.use_goal_in_routing:                                     # routing depends on the sample: per-step generic path
+            x = x0.clone()
+            for i in range(sig.numel() - 1):
+                den = self.denoise({"state_images": img}, x, goals, sig[i].reshape(1), sigma_data)
+                r = sig[i + 1] / sig[i]
+                x = r * x + (1.0 - r) * den
+            return x
+        use_graph = os.environ.get("MODE_HIP_GRAPH", "1") != "0"
+        if not use_graph:
+            x = x0.clone().contiguous()
+            idx, meta, ml = self._ddim_chain(eng, img, goals, x, sig, sigma_data)
+            self._last_topk = idx
+            return x
+        key = (B, sig.numel(), eng.compute_dtype, eng._wkey, str(dev), float(sigma_data))
+        ent = self._route_cache.get("graph")
+        if ent is None or ent["key"] != key:
+            st = dict(key=key, img=img.clone(), goals=goals.clone(), x=x0.clone().contiguous(), sig=sig.clone())
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                                # warm-up: sizes the workspace, loads code objects
+                self._ddim_chain(eng, st["img"], st["goals"], st["x"], st["sig"], sigma_data)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["idx"], st["meta"], st["ml"] = self._ddim_chain(eng, st["img"], st["goals"], st["x"], st["sig"], sigma_data)
+            st["graph"] = g
+            self._route_cache["graph"] = ent = st
+        ent["img"].copy_(img); ent["goals"].copy_(goals); ent["x"].copy_(x0); ent["sig"].copy_(sig)
+        ent["graph"].replay()
+        self._last_topk = ent["idx"]
+        return ent["x"].clone()
+
+    def _account_usage(self, meta, ml, n_tokens):
+        """Expert-usage counters (modedit.py:568-572, 594) kept on-device; no host sync on the hot path."""
+        counts = meta[:, ml.counts: ml.counts + self.num_experts]
+        if getattr(self, "_usage_dev", None) is None or self._usage_dev.device != counts.device:
+            self._usage_dev = torch.zeros(self.num_layers, self.num_experts, dtype=torch.int64, device=counts.device)
+        self._usage_dev += counts
+        for blk in self.blocks:
+            blk.total_tokens_processed += n_tokens
+
+    def sync_expert_usage(self):
+        """Fold the device-side counters into the per-block host tensors the agent's heat-map reads (mode_agent.py:466-511)."""
+        if getattr(self, "_usage_dev", None) is not None:
+            host = self._usage_dev.cpu().to(torch.float32)
+            for i, blk in enumerate(self.blocks):
+                blk.inference_expert_usage += host[i]
+            self._usage_dev.zero_()
+
+    # ------------------------------------------------------------------ aux losses (training side channel)
+    def load_balancing_loss(self):
+        """modedit.py:898-928."""
+        terms = [b.probs["load_balancing_term"] for b in self.blocks if b.probs is not None]
+        return sum(terms) / len(terms) if terms else 0.0
+
+    def compute_router_z_loss(self, eps=1e-6):
+        """modedit.py:930-969 (on the max-shifted logits, as the reference does)."""
+        z = [torch.log(torch.exp(lg).sum(-1) + eps).pow(2).mean() for lg in self.logits_per_layer]
+        return sum(z) / len(z)
+
+    # ------------------------------------------------------------------ per-sigma routing cache (reference: fused expert cache)
+    def precompute_experts_for_inference(self, sigma, goal=None):
+        """Reference modedit.py:971-992 duplicates two experts' weights per (sigma, layer) (~12 GB at C2) and keys the cache on a
+        Python float mean that only hits at B=1.  Here only the routing decision (e0,e1,p0,p1) is cached,
+        keyed on the exact sigma bits; weights are never copied."""
+        if self.training:
+            return
+        eng = self.engine
+        sig = sigma.detach().to(device=eng.device, dtype=torch.float32).reshape(-1)[:1].contiguous()
+        emb = eng.sigma_embed(sig)
+        cond = emb
+        if self.use_goal_in_routing and goal is not None:
+            _, goal_e = eng.embed_obs(torch.zeros(1, self.n_img_tokens, self.obs_dim, device=eng.device),
+                                      goal.detach().to(eng.device, torch.float32).reshape(1, -1).contiguous())
+            cond = emb + goal_e
+        idx, w, _, _ = eng.route(cond.contiguous())
+        key = float(sig.item())
+        idx_h, w_h = idx.cpu(), w.cpu()
+        for i, blk in enumerate(self.blocks):
+            blk.fused_experts[key] = (idx_h[i, 0].tolist(), w_h[i, 0].tolist())
+            blk.routing_info[key] = {"indices": idx_h[i, 0].numpy(), "probs": w_h[i, 0].numpy()}
+
+    def reset_all_caches(self):
+        for blk in self.blocks:
+            blk.reset_expert_cache()
+
+    def freeze_router(self):
+        for blk in self.blocks:
+            blk.router.eval()
+            for p in blk.router.parameters():
+                p.requires_grad = False
+
+    def unfreeze_router(self):
+        for blk in self.blocks:
+            blk.router.train()
+            for p in blk.router.parameters():
+                p.requires_grad = True
+
+    def prepare_for_finetuning(self, freeze_routers: bool = True, freeze_expert_weights: float = 0.3, reset_expert_stats: bool = True):
+        if freeze_routers:
+            self.freeze_router()

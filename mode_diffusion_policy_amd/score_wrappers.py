@@ -1,0 +1,59 @@
+"""Mirror of ``mode.models.edm_diffusion.score_wrappers.GCDenoiser`` (Karras/EDM preconditioner) on the HIP denoiser.
+
+``forward`` fuses the three scalings into the HIP launch chain: ``c_in`` is applied while the action tokens are embedded and
+``F*c_out + x*c_skip`` is the epilogue of the output-head kernel (reference: score_wrappers.py:65-80 = 3 extra elementwise
+launches + temporaries per call).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .modedit import MoDeDiT
+from .utils import append_dims
+
+
+def _instantiate(cfg):
+    """Accept a ready module, or a Hydra/OmegaConf node / plain dict with ``_target_`` (the agent passes a DictConfig because
+    it is built with ``_recursive_: false``; score_wrappers.py:28)."""
+    if isinstance(cfg, nn.Module):
+        return cfg
+    try:
+        import hydra
+        return hydra.utils.instantiate(cfg)
+    except ImportError:
+        kw = {k: v for k, v in dict(cfg).items() if k not in ("_target_", "_recursive_")}
+        return MoDeDiT(**kw)
+
+
+class GCDenoiser(nn.Module):
+    def __init__(self, inner_model, sigma_data=1.0):
+        super().__init__()
+        self.inner_model = _instantiate(inner_model)
+        self.sigma_data = sigma_data
+
+    def get_scalings(self, sigma):
+        """c_skip, c_out, c_in   (score_wrappers.py:31-43)."""
+        c_skip = self.sigma_data ** 2 / (sigma ** 2 + self.sigma_data ** 2)
+        c_out = sigma * self.sigma_data / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        c_in = 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        return c_skip, c_out, c_in
+
+    def loss(self, state, action, goal, noise, sigma, **kwargs):
+        """Score-matching loss (score_wrappers.py:45-63) -> (loss, model_output)."""
+        c_skip, c_out, c_in = [append_dims(x, action.ndim) for x in self.get_scalings(sigma)]
+        noised_input = action + noise * append_dims(sigma, action.ndim)
+        model_output = self.inner_model(state, noised_input * c_in, goal, sigma, **kwargs)
+        target = (action - c_skip * noised_input) / c_out
+        return (model_output - target).pow(2).flatten(1).mean(), model_output
+
+    def forward(self, state, action, goal, sigma, **kwargs):
+        """D(x; sigma) = F(x*c_in)*c_out + x*c_skip   (score_wrappers.py:65-80)."""
+        m = self.inner_model
+        if isinstance(m, MoDeDiT) and not m.training and not kwargs:
+            return m.denoise(state, action, goal, sigma, self.sigma_data)
+        c_skip, c_out, c_in = [append_dims(x, action.ndim) for x in self.get_scalings(sigma)]
+        return m(state, action * c_in, goal, sigma, **kwargs) * c_out + action * c_skip
+
+    def get_params(self):
+        return self.inner_model.parameters()

@@ -1,0 +1,89 @@
+"""Thin test-side wrappers that call the C-ABI (ctypes) with torch device tensors."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from mode_diffusion_policy_amd import _lib as L
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def p(t):
+    return None if t is None else t.data_ptr()
+
+
+def dt_of(t):
+    return L.MODE_BF16 if t.dtype == torch.bfloat16 else L.MODE_F32
+
+
+def gemm(A, W, epilogue=L.EPI_NONE, bias=None, resid=None, out_dtype=None, n_out=None, a_rows=None, tiles=None, num_tiles=None,
+         max_tiles=0, M=None, w_estride=0, b_estride=0):
+    lib = L.load()
+    out_dtype = out_dtype or A.dtype
+    K = A.shape[-1]
+    Wm = W if W.dim() == 2 else W[0]
+    N = n_out if n_out is not None else (Wm.shape[0] // 2 if epilogue == L.EPI_SWIGLU else Wm.shape[0])
+    M = M if M is not None else A.shape[0]
+    Cc = torch.full((M, N), float("nan"), dtype=out_dtype, device=A.device)
+    d = L.ModeGemmDesc(dtype=dt_of(A), epilogue=epilogue, out_dtype=L.MODE_BF16 if out_dtype == torch.bfloat16 else L.MODE_F32,
+                       M=M, N=N, K=K, A=p(A), lda=A.stride(0), W=p(W), ldw=Wm.stride(0), w_expert_stride=w_estride,
+                       bias=p(bias), bias_expert_stride=b_estride, resid=p(resid), ldr=(resid.stride(0) if resid is not None else 0),
+                       C=p(Cc), ldc=Cc.stride(0), a_rows=p(a_rows), tiles=p(tiles), num_tiles=p(num_tiles), max_tiles=max_tiles,
+                       tile_m=lib.mode_gemm_tile_m(dt_of(A)))
+    L.check(lib.mode_gemm(C.byref(d), stream()), "gemm")
+    return Cc
+
+
+def route_topk(logits, k, normalize=True):
+    lib = L.load()
+    R, E = logits.shape
+    sh = torch.empty_like(logits); pr = torch.empty_like(logits)
+    idx = torch.full((R, k), -1, dtype=torch.int32, device=logits.device)
+    w = torch.empty(R, k, dtype=torch.float32, device=logits.device)
+    L.check(lib.mode_moe_route_topk_f32(p(logits), R, E, k, int(normalize), p(sh), p(pr), p(idx), p(w), stream()), "route")
+    return sh, pr, idx, w
+
+
+def dispatch_meta(idx, w, tokens_per_row, N, E, tile_m):
+    lib = L.load()
+    R, k = idx.shape
+    mt = lib.mode_moe_max_tiles(N, E, k, tile_m)
+    dev = idx.device
+    i32 = lambda *s: torch.full(s, -1, dtype=torch.int32, device=dev)
+    counts, offsets, perm, pos = i32(E), i32(E + 1), i32(N * k), i32(N * k)
+    posw = torch.empty(N * k, dtype=torch.float32, device=dev)
+    tiles, nt = i32(mt * 3), i32(1)
+    L.check(lib.mode_moe_dispatch_meta(p(idx), p(w), R, tokens_per_row, N, E, k, tile_m, p(counts), p(offsets), p(perm), p(pos), p(posw),
+                                       p(tiles), p(nt), mt, stream()), "dispatch_meta")
+    return dict(counts=counts, offsets=offsets, perm=perm, pos=pos, posw=posw, tiles=tiles, num_tiles=nt, max_tiles=mt)
+
+
+def rmsnorm(x, g, cond=None, rows_per_cond=1, eps=1e-6, lp_dtype=torch.bfloat16, want_f32=True):
+    lib = L.load()
+    rows, D = x.shape
+    y32 = torch.empty_like(x) if want_f32 else None
+    ylp = torch.empty(rows, D, dtype=lp_dtype, device=x.device)
+    L.check(lib.mode_rmsnorm_cond_fwd(p(x), p(g), p(cond), rows, D, rows_per_cond, eps, p(y32), p(ylp),
+                                      L.MODE_BF16 if lp_dtype == torch.bfloat16 else L.MODE_F32, stream()), "rmsnorm")
+    return y32, ylp
+
+
+def attn(qkv, qg, kg, B, T, H, hd, eps=1e-6):
+    lib = L.load()
+    y = torch.full((B * T, H * hd), float("nan"), dtype=qkv.dtype, device=qkv.device)
+    L.check(lib.mode_attn_block_fwd(p(qkv), p(qg), p(kg), p(y), dt_of(qkv), B, T, H, hd, eps, stream()), "attn")
+    return y
+
+
+def combine_norm(u, Y, pos, posw, k, g, cond, rows_per_cond, eps=1e-6, h_dtype=torch.bfloat16):
+    lib = L.load()
+    N, D = u.shape
+    xn = torch.empty_like(u)
+    h = torch.empty(N, D, dtype=h_dtype, device=u.device)
+    L.check(lib.mode_moe_combine_norm_fwd(p(u), p(Y), dt_of(Y), p(pos), p(posw), N, D, k, p(g), p(cond), rows_per_cond, eps, p(xn), p(h),
+                                          L.MODE_BF16 if h_dtype == torch.bfloat16 else L.MODE_F32, stream()), "combine_norm")
+    return xn, h

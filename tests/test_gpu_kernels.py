@@ -1,0 +1,215 @@
+"""GPU parity tests of the individual HIP kernels, called through the C-ABI, against the oracle / plain fp32 torch math
+on the same seeded inputs.  Integer outputs bit-exact; bf16 kernels within bf16 rounding of an fp32 reference fed the same
+bf16-rounded inputs; fp32 kernels <= 1e-5."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mode_diffusion_policy_amd import _lib as L  # noqa: E402
+from oracle import mode_oracle as O  # noqa: E402
+
+import hip_helpers as H  # noqa: E402
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+# ----------------------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1792, 3072, 1024), (100, 192, 64), (257, 1024, 256), (14, 64, 128), (1, 128, 64)])
+@pytest.mark.parametrize("glds", [1, 0])
+def test_gemm_bf16_plain_bias(M, N, K, glds):
+    # asymmetric operands: a transposed/permuted C-write cannot pass
+    A = rnd(M, K, seed=1).to(torch.bfloat16); W = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+    b = rnd(N, seed=3)
+    ref = A.float() @ W.float().t() + b
+    L.load().mode_set_option(b"gemm_glds", glds)      # both staging variants (LDS-DMA / VGPR) must agree with the reference
+    try:
+        out = H.gemm(A.to(dev()), W.to(dev()), L.EPI_BIAS, bias=b.to(dev()), out_dtype=torch.float32)
+        assert rel(out, ref) < 2e-3
+        out16 = H.gemm(A.to(dev()), W.to(dev()), L.EPI_BIAS, bias=b.to(dev()), out_dtype=torch.bfloat16)
+        assert rel(out16.float(), ref) < 6e-3
+    finally:
+        L.load().mode_set_option(b"gemm_glds", 1)
+
+
+def test_gemm_bf16_identity_asymmetric():
+    """A = I with an asymmetric W catches row<->col swaps in the MFMA C layout (guide: 'A=I-check with ASYMMETRIC B')."""
+    K = 128
+    A = torch.eye(K).to(torch.bfloat16)
+    W = (torch.arange(256 * K).reshape(256, K) % 251).float().to(torch.bfloat16)
+    out = H.gemm(A.to(dev()), W.to(dev()), out_dtype=torch.float32)
+    assert torch.equal(out.cpu(), W.float().t().contiguous())
+
+
+@pytest.mark.parametrize("M,D", [(300, 256), (3584, 1024)])
+def test_gemm_bf16_swiglu_residual(M, D):
+    A = rnd(M, D, seed=4).to(torch.bfloat16); W1 = rnd(8 * D, D, seed=5, scale=D ** -0.5).to(torch.bfloat16); b1 = rnd(8 * D, seed=6, scale=0.1)
+    h = A.float() @ W1.float().t() + b1
+    ref = h[:, : 4 * D] * torch.nn.functional.silu(h[:, 4 * D:])
+    out = H.gemm(A.to(dev()), W1.to(dev()), L.EPI_SWIGLU, bias=b1.to(dev()), out_dtype=torch.float32)
+    assert out.shape == (M, 4 * D) and rel(out, ref) < 3e-3
+    Wo = rnd(D, D, seed=7, scale=D ** -0.5).to(torch.bfloat16); r = rnd(M, D, seed=8)
+    out2 = H.gemm(A.to(dev()), Wo.to(dev()), L.EPI_RESIDUAL, resid=r.to(dev()), out_dtype=torch.float32)
+    assert rel(out2, A.float() @ Wo.float().t() + r) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("N_tok,E,k,D", [(70, 4, 2, 64), (1792, 4, 2, 256), (112, 2, 1, 256), (5, 4, 2, 64)])
+def test_grouped_gather_gemm(dtype, N_tok, E, k, D):
+    """dispatch meta -> gathered grouped SwiGLU GEMM -> grouped GEMM, vs the oracle's per-expert loop (modedit.py:561-566)."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    probs = torch.rand(N_tok, E, generator=g)
+    idx = torch.sort(probs, dim=-1, descending=True, stable=True).indices[:, :k].contiguous()
+    w = probs.gather(1, idx); w = w / w.sum(-1, keepdim=True)
+    tile_m = lib.mode_gemm_tile_m(L.MODE_BF16 if dtype == torch.bfloat16 else L.MODE_F32)
+    meta = H.dispatch_meta(idx.int().to(dev()), w.to(dev()), 1, N_tok, E, tile_m)
+    counts, perm, slot = O.dispatch_permutation(idx, E)
+    assert torch.equal(meta["counts"].cpu().long(), counts)
+    assert torch.equal(meta["perm"].cpu().long(), perm)                       # bit-exact permutation
+    u = rnd(N_tok, D, seed=12).to(dtype)
+    W1 = rnd(E, 8 * D, D, seed=13, scale=D ** -0.5).to(dtype); b1 = rnd(E, 8 * D, seed=14, scale=0.1)
+    W2 = rnd(E, D, 4 * D, seed=15, scale=(4 * D) ** -0.5).to(dtype)
+    Hs = H.gemm(u.to(dev()), W1.to(dev()), L.EPI_SWIGLU, bias=b1.to(dev()), out_dtype=dtype, a_rows=meta["perm"], tiles=meta["tiles"],
+                num_tiles=meta["num_tiles"], max_tiles=meta["max_tiles"], M=N_tok * k, w_estride=8 * D * D, b_estride=8 * D)
+    Y = H.gemm(Hs, W2.to(dev()), L.EPI_NONE, out_dtype=torch.float32, tiles=meta["tiles"], num_tiles=meta["num_tiles"],
+               max_tiles=meta["max_tiles"], M=N_tok * k, w_estride=4 * D * D)
+    # reference in sorted-row order
+    off = 0; Href = torch.zeros(N_tok * k, 4 * D); Yref = torch.zeros(N_tok * k, D)
+    for e in range(E):
+        n = int(counts[e]); rows = perm[off: off + n]
+        h = u[rows].float() @ W1[e].float().t() + b1[e]
+        hh = h[:, : 4 * D] * torch.nn.functional.silu(h[:, 4 * D:])
+        Href[off: off + n] = hh
+        hq = hh.to(dtype).float()                                            # the kernel chain rounds H to the compute dtype
+        Yref[off: off + n] = hq @ W2[e].float().t()
+        off += n
+    tol = 4e-3 if dtype == torch.bfloat16 else 1e-5
+    assert rel(Hs.float(), Href) < tol * 2
+    assert rel(Y, Yref) < tol * 2
+    # combine + norm (ascending expert order, residual from u)
+    gain = 1 + 0.1 * rnd(D, seed=16); cond = rnd(3, D, seed=17)
+    rpc = (N_tok + 2) // 3
+    u32 = u.float()
+    xn, hh = H.combine_norm(u32.to(dev()), Y, meta["pos"], meta["posw"], k, gain.to(dev()), cond.to(dev()), rpc, h_dtype=dtype)
+    nxt = torch.zeros(N_tok, D); off = 0
+    Yc = Y.cpu()
+    for e in range(E):
+        n = int(counts[e]); rows = perm[off: off + n]; sl = slot[off: off + n]
+        nxt[rows] += w[rows, sl].unsqueeze(-1) * Yc[off: off + n]
+        off += n
+    xref = u32 + nxt
+    assert rel(xn, xref) < 1e-6
+    href = O.rmsnorm(xref, gain) + cond[torch.arange(N_tok) // rpc]
+    assert rel(hh.float(), href) < (5e-3 if dtype == torch.bfloat16 else 1e-6)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(37, 4, 512, L.EPI_BIAS), (128, 512, 256, L.EPI_BIAS_GELU), (10, 2, 512, L.EPI_BIAS),
+                                       (256, 1024, 2048, L.EPI_NONE), (65, 130, 30, L.EPI_NONE), (16, 64, 7, L.EPI_NONE)])
+def test_gemm_f32(M, N, K, epi):
+    A = rnd(M, K, seed=21); W = rnd(N, K, seed=22, scale=K ** -0.5); b = rnd(N, seed=23)
+    ref = A @ W.t()
+    if epi != L.EPI_NONE:
+        ref = ref + b
+    if epi == L.EPI_BIAS_GELU:
+        ref = torch.nn.functional.gelu(ref)
+    out = H.gemm(A.to(dev()), W.to(dev()), epi, bias=b.to(dev()) if epi != L.EPI_NONE else None)
+    assert rel(out, ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("rows,D", [(7, 64), (1792, 1024), (112, 256)])
+def test_rmsnorm_cond(rows, D):
+    x = rnd(rows, D, seed=31, scale=3.0); g = 1 + 0.1 * rnd(D, seed=32); c = rnd((rows + 13) // 14, D, seed=33)
+    ref = O.rmsnorm(x, g) + c[torch.arange(rows) // 14]
+    y32, ylp = H.rmsnorm(x.to(dev()), g.to(dev()), c.to(dev()), 14)
+    assert rel(y32, ref) < 1e-6 and rel(ylp.float(), ref) < 4e-3
+    y32b, _ = H.rmsnorm(x.to(dev()), g.to(dev()), None, 1)
+    assert rel(y32b, O.rmsnorm(x, g)) < 1e-6
+    z = torch.zeros(4, D)                                         # eps clamp: all-zero row stays finite (norm.clamp(min=eps))
+    y0, _ = H.rmsnorm(z.to(dev()), g.to(dev()), None, 1)
+    assert torch.isfinite(y0).all() and float(y0.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,Hh,hd", [(3, 14, 4, 32), (8, 14, 8, 128), (128, 14, 8, 128), (2, 13, 2, 64), (1, 16, 1, 32)])
+def test_attention(dtype, B, T, Hh, hd):
+    D = Hh * hd
+    qkv = rnd(B * T, 3 * D, seed=41).to(dtype)
+    qg = 1 + 0.1 * rnd(hd, seed=42); kg = 1 + 0.1 * rnd(hd, seed=43)
+    y = H.attn(qkv.to(dev()), qg.to(dev()), kg.to(dev()), B, T, Hh, hd)
+    q, k, v = (t.float().view(B, T, Hh, hd).transpose(1, 2) for t in qkv.split(D, dim=-1))
+    q = O.rmsnorm(q, qg); k = O.rmsnorm(k, kg)
+    att = (q @ k.transpose(-2, -1)) / math.sqrt(hd)
+    att = att.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril(), float("-inf")).softmax(-1)
+    ref = (att @ v).transpose(1, 2).reshape(B * T, D)
+    assert not torch.isnan(y.float()).any()
+    assert rel(y.float(), ref) < (1.2e-2 if dtype == torch.bfloat16 else 1e-5)
+    # causality property: token 0 attends only to itself -> y[:,0] == v[:,0]
+    y0 = y.float().cpu().view(B, T, D)[:, 0]
+    v0 = qkv.float().view(B, T, 3 * D)[:, 0, 2 * D:]
+    assert rel(y0, v0) < (8e-3 if dtype == torch.bfloat16 else 1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------- routing
+@pytest.mark.parametrize("R,E,k", [(1, 4, 2), (128, 4, 2), (8, 2, 1), (77, 8, 3), (5, 3, 2)])
+def test_route_topk_bit_exact(R, E, k):
+    logits = rnd(R, E, seed=51, scale=2.0)
+    sh, pr, idx, w = H.route_topk(logits.to(dev()), k, True)
+    lg = logits - logits.max(-1, keepdim=True).values
+    probs = torch.softmax(lg, -1).clamp(1e-9, 1 - 1e-9)
+    ridx, rw = O.topk_route(probs, k, True)
+    assert torch.equal(sh.cpu(), lg)
+    assert torch.equal(idx.cpu().long(), ridx)                    # bit-exact integers
+    assert rel(pr, probs) < 1e-6 and rel(w, rw) < 1e-6
+    # exact tie -> lower expert id first (documented tie rule)
+    t = torch.zeros(2, E); sh2, pr2, idx2, _ = H.route_topk(t.to(dev()), k, True)
+    assert idx2.cpu().tolist() == [list(range(k))] * 2
+
+
+@pytest.mark.parametrize("R,tpr,E,k", [(8, 14, 4, 2), (1, 1792, 4, 2), (112, 1, 2, 1), (1792, 1, 4, 2), (3000, 1, 4, 2)])
+def test_dispatch_meta_bit_exact(R, tpr, E, k):
+    lib = L.load()
+    g = torch.Generator().manual_seed(61)
+    probs = torch.rand(R, E, generator=g)
+    if R == 1:
+        probs = torch.tensor([[0.1, 0.5, 0.05, 0.35]])[:, :E]
+    idx = torch.multinomial(probs, k, replacement=False, generator=g)          # unsorted slots, like training (modedit.py:390)
+    w = probs.gather(1, idx)
+    N = R * tpr
+    for tile_m in (128, 64):
+        meta = H.dispatch_meta(idx.int().to(dev()), w.to(dev()), tpr, N, E, tile_m)
+        tok_idx = idx.repeat_interleave(tpr, 0)
+        counts, perm, slot = O.dispatch_permutation(tok_idx, E)
+        assert torch.equal(meta["counts"].cpu().long(), counts)
+        assert torch.equal(meta["offsets"].cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]))
+        assert torch.equal(meta["perm"].cpu().long(), perm)
+        pos = meta["pos"].cpu().long().view(N, k); posw = meta["posw"].cpu().view(N, k)
+        # pos[t, j] is the sorted row of token t's j-th expert in ASCENDING expert order
+        srt = torch.sort(tok_idx, dim=-1)
+        wtok = w.repeat_interleave(tpr, 0).gather(1, srt.indices)
+        assert torch.equal(perm[pos.reshape(-1)], torch.arange(N).repeat_interleave(k))
+        assert torch.equal(posw, wtok)
+        nt = int(meta["num_tiles"].cpu())
+        tiles = meta["tiles"].cpu().view(-1, 3)[:nt]
+        assert nt == int(((counts + tile_m - 1) // tile_m).sum())
+        cover = torch.zeros(N * k, dtype=torch.int32)
+        offs = meta["offsets"].cpu()
+        for e, r0, r1 in tiles.tolist():
+            assert offs[e] <= r0 < r1 <= offs[e + 1] and r1 - r0 <= tile_m
+            cover[r0:r1] += 1
+        assert bool((cover == 1).all())
