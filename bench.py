@@ -1,0 +1,224 @@
+"""bench.py — MoDE denoising hot path on MI355X.
+
+Metric (BASELINE.json): denoise-steps/sec at B=128 with the 10-step DDIM chunk, full MoDE denoiser (12 layers, d=1024, 8 heads,
+4 experts top-2, obs_dim 2048, goal_dim 512), bf16 MFMA compute with fp32 accumulate / fp32 router, synthetic CALVIN-shaped
+inputs, random-init weights (no datasets or checkpoints are reachable).
+
+A bench "step" = ONE 10-step DDIM chunk over one batch of B=128 action chunks (sample_ddim o GCDenoiser o MoDeDiT, i.e. 10
+denoiser forwards + 10 fused EDM/DDIM updates, replayed as one hipGraph).  value = n_gpus * steps * 10 / wall  [denoise-steps/s].
+Multi-GPU (inference): replicas only — each rank denoises its own B=128 batch, no data-path collective;
+the data-parallel *training* exchange is benchmarked with --mode train once the backward kernels land.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+C2 = dict(obs_dim=2048, goal_dim=512, embed_dim=1024, n_layers=12, n_heads=8, num_experts=4, top_k=2)
+B_PER_GPU = 128
+N_SAMPLING_STEPS = 10
+SIGMA_DATA, SIGMA_MIN, SIGMA_MAX = 0.5, 1e-3, 80.0
+MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md (AMD's 5 PF figure is 2:1 sparse)
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_denoise_step(B, L=12, D=1024, H=8, T=14, E=4, k=2, O=2048, G=512, A=7, A_len=10):
+    """Algorithmic FLOPs of one denoiser forward on the whole batch (SURVEY.md §8d / BASELINE.md §4)."""
+    N = B * T
+    hd = D // H
+    per_layer = 6 * N * D * D + 4 * B * H * T * T * hd + 2 * N * D * D + (4 * B * D * D + 4 * B * D * E) + k * 24 * N * D * D
+    return L * per_layer + 2 * B * (2 * O * D + G * D + A_len * A * D + D * D + A_len * D * A)
+
+
+def build_model(device, dtype="bf16"):
+    import mode_diffusion_policy_amd as M
+    torch.manual_seed(0)
+    m = M.MoDeDiT(obs_dim=C2["obs_dim"], goal_dim=C2["goal_dim"], device=str(device), goal_conditioned=True, action_dim=7,
+                  embed_dim=C2["embed_dim"], embed_pdrob=0, attn_pdrop=0.3, n_layers=C2["n_layers"], n_heads=C2["n_heads"],
+                  goal_seq_len=1, obs_seq_len=1, action_seq_len=10, mlp_pdrop=0.1, goal_drop=0.1, num_experts=C2["num_experts"],
+                  top_k=C2["top_k"], compute_dtype=dtype)
+    return M, M.GCDenoiser(m.to(device).eval(), SIGMA_DATA).eval()
+
+
+def synthetic_inputs(device, B):
+    g = torch.Generator(device="cpu").manual_seed(0)
+    img = torch.randn(B, 2, C2["obs_dim"], generator=g).to(device)
+    goal = torch.randn(B, 1, C2["goal_dim"], generator=g).to(device)
+    x0 = (torch.randn(B, 10, 7, generator=g) * SIGMA_MAX).to(device)
+    return img, goal, x0
+
+
+def dominant_kernel_roofline(den, device, reps=60):
+    """Dominant kernel = grouped bf16 MFMA GEMM with SwishGLU epilogue (expert up-projection: 47 % of all FLOPs).  Launch it in
+    isolation at the benchmark's exact shape (3584 gathered rows = 1792 tokens x top-2, K = 1024, 2 x 4096 weight rows per expert),
+    cycling through the 12 layers' weights, timed with HIP events on the stream it is launched on."""
+    import ctypes as C
+    from mode_diffusion_policy_amd import _lib as L
+    m = den.inner_model
+    eng = m.engine
+    lib = L.load()
+    D, E, k, T = 1024, 4, 2, 14
+    N = B_PER_GPU * T
+    idx = torch.tensor([[1, 2]], dtype=torch.int32, device=device)
+    w = torch.tensor([[0.6, 0.4]], dtype=torch.float32, device=device)
+    meta = eng.dispatch(idx, w, 1, 1, N, N)
+    ml = eng.meta_layout(N)
+    mp = meta.data_ptr()
+    u = torch.randn(N, D, device=device).to(torch.bfloat16)
+    Hb = torch.empty(N * k, 4 * D, dtype=torch.bfloat16, device=device)
+    descs = []
+    for l in range(m.num_layers):
+        kp = eng._keep
+        d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_SWIGLU, out_dtype=L.MODE_BF16, M=N * k, N=4 * D, K=D, A=u.data_ptr(), lda=D,
+                           W=kp[f"l{l}.w1"].data_ptr(), ldw=D, w_expert_stride=8 * D * D, bias=kp[f"l{l}.b1"].data_ptr(),
+                           bias_expert_stride=8 * D, resid=None, ldr=0, C=Hb.data_ptr(), ldc=4 * D, a_rows=mp + 4 * ml.perm,
+                           tiles=mp + 4 * ml.tiles, num_tiles=mp + 4 * ml.num_tiles, max_tiles=ml.max_tiles, tile_m=128)
+        descs.append(d)
+    st = torch.cuda.current_stream().cuda_stream
+    for d in descs:
+        L.check(lib.mode_gemm(C.byref(d), st))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(reps):
+        lib.mode_gemm(C.byref(descs[i % len(descs)]), st)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    flops = 2.0 * (N * k) * D * (8 * D)
+    ach = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_bf16_kernel<SWIGLU> (grouped expert up-projection, M=3584 K=1024 N=2x4096)",
+            "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+            "traffic": None, "avg_launch_us": round(us, 2), "flops_per_launch": flops}
+
+
+def cpu_baseline():
+    """The oracle (pure-torch fp32 CPU restatement, parity-pinned to the reference) on this box's host cores, bounded sample."""
+    from oracle import mode_oracle as O
+    from oracle.weights import param_spec
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.DiTConfig(**C2)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for name, shape in param_spec(cfg):
+        if name.endswith(".g"):
+            sd[name] = torch.ones(shape)
+        elif name.endswith("bias") or name == "pos_emb":
+            sd[name] = torch.zeros(shape)
+        else:
+            sd[name] = torch.randn(shape, generator=g) * (shape[-1] ** -0.5)
+    B = B_PER_GPU
+    img = torch.randn(B, 2, cfg.obs_dim, generator=g); goal = torch.randn(B, 1, cfg.goal_dim, generator=g)
+    x = torch.randn(B, 10, 7, generator=g) * SIGMA_MAX
+    sig = O.get_sigmas_exponential(N_SAMPLING_STEPS, SIGMA_MIN, SIGMA_MAX)
+    with torch.no_grad():
+        O.denoiser_forward(sd, cfg, SIGMA_DATA, img, x, goal, sig[0] * torch.ones(B))     # warm-up
+        n, t0 = 0, time.perf_counter()
+        while n < 3 or (time.perf_counter() - t0 < 8.0 and n < 10):
+            x = O.ddim_update(x, O.denoiser_forward(sd, cfg, SIGMA_DATA, img, x, goal, sig[n % 10] * torch.ones(B)),
+                              float(sig[n % 10]), float(sig[n % 10 + 1]))
+            n += 1
+        dt = time.perf_counter() - t0
+    model = ""
+    try:
+        model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": round(n / dt, 4), "unit": "denoise-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} denoise steps (GCDenoiser.forward + DDIM update) of the full config-2 model at B=128, fp32, "
+                      f"oracle/mode_oracle.py with torch.set_num_threads({cores}); cpu: {model}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    M, den = build_model(device, args.dtype)
+    img, goal, x0 = synthetic_inputs(device, B_PER_GPU)
+    sig = M.get_sigmas_exponential(N_SAMPLING_STEPS, SIGMA_MIN, SIGMA_MAX).to(device)
+    state = {"state_images": img}
+
+    def chunk():
+        return M.sample_ddim(den, state, x0, goal, sig, disable=True)
+
+    for _ in range(max(args.warmup, 1)):
+        out = chunk()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all(), "non-finite actions"
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = chunk()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_gpus = world
+    denoise_steps = n_gpus * args.steps * N_SAMPLING_STEPS
+    value = denoise_steps / elapsed
+    res = {
+        "metric": "denoise-steps/sec (B=128, 10-step chunk)", "value": round(value, 2), "unit": "denoise-steps/s", "n_gpus": n_gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "configs[1]: full MoDE denoiser (12 layers, d=1024, 8 heads, 4 experts top-2, obs 2048, goal 512), "
+                               "B=128 per GPU, one step = one 10-step DDIM chunk (sample_ddim o GCDenoiser o MoDeDiT), eval, "
+                               "uniform sigma per step, random-init weights",
+                   "global_batch": B_PER_GPU * n_gpus, "denoise_steps_per_step": N_SAMPLING_STEPS,
+                   "parallelism": f"replicas x{n_gpus} (no data-path collective)"},
+        "action_chunks_per_s": round(value * B_PER_GPU / N_SAMPLING_STEPS, 1),
+        "ms_per_denoise_step": round(elapsed / (args.steps * N_SAMPLING_STEPS) * 1e3, 4),
+    }
+    if rank == 0:
+        fl = flops_per_denoise_step(B_PER_GPU)
+        res["e2e_tflops_per_gpu"] = round(fl * args.steps * N_SAMPLING_STEPS / elapsed / 1e12, 1)
+        res["e2e_mfma_frac"] = round(res["e2e_tflops_per_gpu"] / MFMA_BF16_PEAK_TFLOPS, 4)
+        if args.dtype == "bf16":
+            res["roofline"] = dominant_kernel_roofline(den, device)
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

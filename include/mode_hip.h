@@ -92,7 +92,7 @@ int mode_rmsnorm_cond_fwd(const float* x, const float* g, const float* cond, int
  * mode_attn_block_fwd — per (sample, head): qk-RMSNorm over head_dim (learned gains, eps), causal softmax(QK^T/sqrt(hd)) V.
  * Replaces Attention.forward minus the four Linears (modedit.py:125-127, 145-165; SDPA is_causal=True at :149).
  * qkv is the packed [B*T, 3*D] output of the fused QKV GEMM ([q | k | v] along columns); y is [B*T, D] (heads merged).
- * T <= 16 (the path's sequence is 14 tokens), head_dim % 32 == 0 for bf16.
+ * T <= 16 (the path's sequence is 14 tokens), head_dim % 16 == 0 and <= 128 for bf16.
  * ------------------------------------------------------------------------------------------------------------------ */
 int mode_attn_block_fwd(const void* qkv, const float* q_gain, const float* k_gain, void* y, int dtype,
                         int B, int T, int H, int head_dim, float eps, void* stream);

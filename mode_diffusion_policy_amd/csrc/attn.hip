@@ -10,11 +10,10 @@
 
 namespace mode {
 
-template <int NKS>   // head_dim = 32 * NKS
+template <int NKS>   // 32*(NKS-1) < head_dim <= 32*NKS, head_dim % 16 == 0 (dims past head_dim are zero k-slots)
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ qg,
                                                         const float* __restrict__ kg, uint16_t* __restrict__ y, int B, int T,
-                                                        int H, float eps) {
-  constexpr int HD = 32 * NKS;
+                                                        int H, int HD, float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int prob = blockIdx.x * 4 + wave;
   if (prob >= B * H) return;
@@ -31,7 +30,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     uint4 rq = make_uint4(0, 0, 0, 0), rk = make_uint4(0, 0, 0, 0);
-    if (tv) {
+    if (tv && ks * 32 + fq * 8 < HD) {
       rq = *reinterpret_cast<const uint4*>(rowp + ks * 32);
       rk = *reinterpret_cast<const uint4*>(rowp + D + ks * 32);
     }
@@ -52,8 +51,9 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
   bf16x8 qfrag[NKS], kfrag[NKS];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
-    const float4 g0 = *reinterpret_cast<const float4*>(qg + ks * 32 + fq * 8), g1 = *reinterpret_cast<const float4*>(qg + ks * 32 + fq * 8 + 4);
-    const float4 h0 = *reinterpret_cast<const float4*>(kg + ks * 32 + fq * 8), h1 = *reinterpret_cast<const float4*>(kg + ks * 32 + fq * 8 + 4);
+    const int dg = (ks * 32 + fq * 8 < HD) ? ks * 32 + fq * 8 : 0;      // padded k-slots carry zeros; any valid gain address works
+    const float4 g0 = *reinterpret_cast<const float4*>(qg + dg), g1 = *reinterpret_cast<const float4*>(qg + dg + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(kg + dg), h1 = *reinterpret_cast<const float4*>(kg + dg + 4);
     const float gq[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, gk[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
     uint32_t pq[4], pk[4];
 #pragma unroll
@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
   const uint16_t* vbase = qkv + (long)b * T * ld + 2L * D + h * HD;
   uint16_t* yrow = y + ((long)b * T + fr) * D + h * HD + fq * 4;
 #pragma unroll
-  for (int db = 0; db < HD / 16; ++db) {
+  for (int db = 0; db < 2 * NKS; ++db) {
+    if (db * 16 >= HD) break;
     uint32_t v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -172,14 +173,14 @@ extern "C" int mode_attn_block_fwd(const void* qkv, const float* q_gain, const f
   if (B == 0) return MODE_OK;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MODE_BF16) {
-    if (T > 16 || head_dim % 32 != 0 || head_dim > 128) return MODE_ERR_UNSUPPORTED;
+    if (T > 16 || head_dim % 16 != 0 || head_dim > 128) return MODE_ERR_UNSUPPORTED;
     const dim3 grid((B * H + 3) / 4), blk(256);
     const uint16_t* in = (const uint16_t*)qkv; uint16_t* out = (uint16_t*)y;
-    switch (head_dim / 32) {
-      case 1: hipLaunchKernelGGL(attn_bf16_kernel<1>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, eps); break;
-      case 2: hipLaunchKernelGGL(attn_bf16_kernel<2>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, eps); break;
-      case 3: hipLaunchKernelGGL(attn_bf16_kernel<3>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, eps); break;
-      case 4: hipLaunchKernelGGL(attn_bf16_kernel<4>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, eps); break;
+    switch ((head_dim + 31) / 32) {
+      case 1: hipLaunchKernelGGL(attn_bf16_kernel<1>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, head_dim, eps); break;
+      case 2: hipLaunchKernelGGL(attn_bf16_kernel<2>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, head_dim, eps); break;
+      case 3: hipLaunchKernelGGL(attn_bf16_kernel<3>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, head_dim, eps); break;
+      case 4: hipLaunchKernelGGL(attn_bf16_kernel<4>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, head_dim, eps); break;
       default: return MODE_ERR_UNSUPPORTED;
     }
   } else {

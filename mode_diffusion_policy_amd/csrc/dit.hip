@@ -193,7 +193,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
   if (a->B <= 0) return MODE_OK;
   const ModeDims& d = *dims;
   const int dt = a->dtype, B = a->B, T = d.T, D = d.D, N = B * T, NK = N * d.k;
-  if (dt == MODE_BF16 && (D % 64 || (D / d.H) % 32 || (D / d.H) > 128)) return MODE_ERR_UNSUPPORTED;
+  if (dt == MODE_BF16 && (D % 64 || (D / d.H) % 16 || (D / d.H) > 128)) return MODE_ERR_UNSUPPORTED;
   const WsLayout L = ws_layout(d, B, 0, dt);
   if (workspace_bytes < L.total) return MODE_ERR_WORKSPACE;
   char* ws = (char*)workspace;

@@ -146,7 +146,7 @@ def test_rmsnorm_cond(rows, D):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("B,T,Hh,hd", [(3, 14, 4, 32), (8, 14, 8, 128), (128, 14, 8, 128), (2, 13, 2, 64), (1, 16, 1, 32)])
+@pytest.mark.parametrize("B,T,Hh,hd", [(3, 14, 4, 32), (8, 14, 8, 128), (128, 14, 8, 128), (2, 13, 2, 64), (1, 16, 1, 32), (6, 14, 4, 16), (2, 14, 2, 48)])
 def test_attention(dtype, B, T, Hh, hd):
     D = Hh * hd
     qkv = rnd(B * T, 3 * D, seed=41).to(dtype)
