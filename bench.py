@@ -83,7 +83,7 @@ def dominant_kernel_roofline(den, device, reps=60):
         d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_SWIGLU, out_dtype=L.MODE_BF16, M=N * k, N=4 * D, K=D, A=u.data_ptr(), lda=D,
                            W=kp[f"l{l}.w1"].data_ptr(), ldw=D, w_expert_stride=8 * D * D, bias=kp[f"l{l}.b1"].data_ptr(),
                            bias_expert_stride=8 * D, resid=None, ldr=0, C=Hb.data_ptr(), ldc=4 * D, a_rows=mp + 4 * ml.perm,
-                           tiles=mp + 4 * ml.tiles, num_tiles=mp + 4 * ml.num_tiles, max_tiles=ml.max_tiles, tile_m=128)
+                           expert_offsets=mp + 4 * ml.offsets, num_experts=E)
         descs.append(d)
     st = torch.cuda.current_stream().cuda_stream
     for d in descs:
@@ -107,7 +107,13 @@ def cpu_baseline():
     """The oracle (pure-torch fp32 CPU restatement, parity-pinned to the reference) on this box's host cores, bounded sample."""
     from oracle import mode_oracle as O
     from oracle.weights import param_spec
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                            # container CPU quota (cgroup v2): "max" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except Exception:
+        pass
     torch.set_num_threads(cores)
     cfg = O.DiTConfig(**C2)
     g = torch.Generator().manual_seed(0)
@@ -126,7 +132,7 @@ def cpu_baseline():
     with torch.no_grad():
         O.denoiser_forward(sd, cfg, SIGMA_DATA, img, x, goal, sig[0] * torch.ones(B))     # warm-up
         n, t0 = 0, time.perf_counter()
-        while n < 3 or (time.perf_counter() - t0 < 8.0 and n < 10):
+        while n < 2 or (time.perf_counter() - t0 < 8.0 and n < 10):
             x = O.ddim_update(x, O.denoiser_forward(sd, cfg, SIGMA_DATA, img, x, goal, sig[n % 10] * torch.ones(B)),
                               float(sig[n % 10]), float(sig[n % 10 + 1]))
             n += 1

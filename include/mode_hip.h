@@ -46,7 +46,9 @@ typedef enum ModeEpilogue {
 
 int mode_hip_version(void);
 const char* mode_hip_status_string(int status);
-/* Tuning knobs (process-wide).  "gemm_glds": 1 = stage GEMM tiles with global_load_lds (default), 0 = through VGPRs. */
+/* Tuning knobs (process-wide).  "gemm_cfg": bf16 GEMM tile geometry, 0 = auto (default), 1 = 128x128 ring-2, 2 = 128x128 ring-3,
+ * 3 = 256x128 ring-3, 4 = 128x64 ring-3, 5 = 128x64 ring-4, 6 = 128x128 single-buffered (3 workgroups/CU), 7 = 128x64 single-buffered,
+ * 8 = 128x64 ring-2. */
 int mode_set_option(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -55,10 +57,10 @@ int mode_set_option(const char* key, int value);
  * :683-686 embeddings) and the per-expert Python loop's GEMMs (modedit.py:561-566).
  *   dtype MODE_BF16: A, W bf16; MFMA 16x16x32 bf16, fp32 accumulate. Requires K % 64 == 0.
  *   dtype MODE_F32 : A, W fp32; MFMA 16x16x4 f32 (bit-exact fp32 fma chain).  Any K.
- * Grouped mode (tiles != NULL): `tiles` is the device tile table written by mode_moe_dispatch_meta
- *   (int32 triples {expert, row_begin, row_end} in SORTED-row coordinates, *num_tiles valid entries); the expert id
+ * Grouped mode (expert_offsets != NULL): rows are sorted by expert and expert e owns the SORTED rows
+ *   [expert_offsets[e], expert_offsets[e+1]) (device int32[num_experts+1], written by mode_moe_dispatch_meta); the expert id
  *   selects W + expert*w_expert_stride and bias + expert*bias_expert_stride (strides in ELEMENTS).  M is then the
- *   total number of sorted rows (N_tokens * top_k) and max_tiles bounds the launch grid.
+ *   total number of sorted rows (N_tokens * top_k).  Workgroups derive their (expert, row range) on the device: no host sync.
  * a_rows (optional): int32[M]; logical row m of A is read from A[a_rows[m]] (MoE gather by the dispatch permutation).
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct ModeGemmDesc {
@@ -71,14 +73,11 @@ typedef struct ModeGemmDesc {
   const float* bias;          int64_t bias_expert_stride;
   const float* resid;         int64_t ldr;
   void* C;        int64_t ldc;
-  const int32_t* a_rows;      /* optional gather                                          */
-  const int32_t* tiles;       /* optional grouped tile table (device)                     */
-  const int32_t* num_tiles;   /* device scalar                                            */
-  int32_t max_tiles;          /* grid bound for grouped launches                          */
-  int32_t tile_m;             /* must equal the BM the tile table was built for (128 bf16 / 64 f32) */
+  const int32_t* a_rows;          /* optional gather                                      */
+  const int32_t* expert_offsets;  /* optional grouped mode: device int32[num_experts + 1]  */
+  int32_t num_experts;
 } ModeGemmDesc;
 int mode_gemm(const ModeGemmDesc* desc, void* stream);
-int mode_gemm_tile_m(int dtype);   /* BM used by the grouped tile table for this dtype */
 
 /* ------------------------------------------------------------------------------------------------------------------
  * mode_rmsnorm_cond_fwd — y = x / max(||x||_2 * D^-1/2, eps) * g  (+ cond[row / rows_per_cond])
@@ -119,13 +118,10 @@ int mode_moe_route_topk_f32(const float* logits, int R, int E, int k, int normal
  *         (tokens_per_row = T for the noise-conditioned router, 1 for per-token routing such as training multinomial).
  * Outputs: counts int32 [E]; offsets int32 [E+1]; perm int32 [N*k] sorted row -> token id;
  *          pos int32 [N*k]: (token, j) -> sorted row, j enumerating the token's experts in ASCENDING expert id;
- *          posw fp32 [N*k]: combine weight for (token, j);
- *          tiles int32 [max_tiles*3] {expert, row_begin, row_end}; num_tiles int32 [1].
+ *          posw fp32 [N*k]: combine weight for (token, j).
  * ------------------------------------------------------------------------------------------------------------------ */
 int mode_moe_dispatch_meta(const int32_t* idx, const float* w, int R, int tokens_per_row, int N, int E, int k,
-                           int tile_m, int32_t* counts, int32_t* offsets, int32_t* perm, int32_t* pos, float* posw,
-                           int32_t* tiles, int32_t* num_tiles, int max_tiles, void* stream);
-int mode_moe_max_tiles(int N, int E, int k, int tile_m);
+                           int32_t* counts, int32_t* offsets, int32_t* perm, int32_t* pos, float* posw, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * mode_moe_combine_norm_fwd — x_next[t] = u[t] + sum_j posw[t,j] * Y[pos[t,j]]  (ascending expert order; the residual is
@@ -215,16 +211,15 @@ typedef struct ModeModelWeights {
 
 /* Dispatch-metadata record of one layer (4-byte word offsets inside the record), see mode_moe_dispatch_meta. */
 typedef struct ModeMetaLayout {
-  int32_t counts, offsets, num_tiles, perm, pos, posw, tiles;   /* word offsets */
-  int32_t total_words;                                          /* record size (multiple of 4 words) */
-  int32_t max_tiles;
+  int32_t counts, offsets, perm, pos, posw;   /* word offsets */
+  int32_t total_words;                        /* record size (multiple of 4 words) */
 } ModeMetaLayout;
-int mode_moe_meta_layout(int N, int E, int k, int tile_m, ModeMetaLayout* out);
+int mode_moe_meta_layout(int N, int E, int k, ModeMetaLayout* out);
 
 /* Batched dispatch: nbatch records (e.g. L layers, or steps*L for a whole sampler run) in one launch.
  * topk_idx/topk_w: [nbatch][R][k] (idx_bstride elements apart); meta: [nbatch][layout.total_words]. */
 int mode_dit_dispatch(const int32_t* topk_idx, const float* topk_w, int nbatch, int64_t idx_bstride, int R,
-                      int tokens_per_row, int N, int E, int k, int tile_m, int32_t* meta, void* stream);
+                      int tokens_per_row, int N, int E, int k, int32_t* meta, void* stream);
 
 size_t mode_dit_workspace_bytes(const ModeDims* dims, int B, int R, int dtype);
 

@@ -27,7 +27,7 @@ class ModeGemmDesc(C.Structure):
     _fields_ = [("dtype", c_i32), ("epilogue", c_i32), ("out_dtype", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("A", c_vp), ("lda", c_i64), ("W", c_vp), ("ldw", c_i64), ("w_expert_stride", c_i64),
                 ("bias", c_vp), ("bias_expert_stride", c_i64), ("resid", c_vp), ("ldr", c_i64), ("C", c_vp), ("ldc", c_i64),
-                ("a_rows", c_vp), ("tiles", c_vp), ("num_tiles", c_vp), ("max_tiles", c_i32), ("tile_m", c_i32)]
+                ("a_rows", c_vp), ("expert_offsets", c_vp), ("num_experts", c_i32)]
 
 
 class ModeEmbedDesc(C.Structure):
@@ -62,8 +62,7 @@ class ModeModelWeights(C.Structure):
 
 
 class ModeMetaLayout(C.Structure):
-    _fields_ = [("counts", c_i32), ("offsets", c_i32), ("num_tiles", c_i32), ("perm", c_i32), ("pos", c_i32),
-                ("posw", c_i32), ("tiles", c_i32), ("total_words", c_i32), ("max_tiles", c_i32)]
+    _fields_ = [("counts", c_i32), ("offsets", c_i32), ("perm", c_i32), ("pos", c_i32), ("posw", c_i32), ("total_words", c_i32)]
 
 
 class ModeForwardArgs(C.Structure):
@@ -80,21 +79,18 @@ PROTOTYPES = {
     "mode_hip_status_string": (C.c_char_p, [C.c_int]),
     "mode_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "mode_gemm": (C.c_int, [P(ModeGemmDesc), c_vp]),
-    "mode_gemm_tile_m": (C.c_int, [C.c_int]),
     "mode_rmsnorm_cond_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_f32, c_vp, c_vp, C.c_int, c_vp]),
     "mode_attn_block_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32, c_vp]),
     "mode_sigma_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, c_vp]),
     "mode_moe_route_topk_f32": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "mode_moe_dispatch_meta": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp,
-                                         c_vp, c_vp, c_vp, c_vp, C.c_int, c_vp]),
-    "mode_moe_max_tiles": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mode_moe_dispatch_meta": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mode_moe_combine_norm_fwd": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp, C.c_int,
                                             c_f32, c_vp, c_vp, C.c_int, c_vp]),
     "mode_embed_tokens_fwd": (C.c_int, [P(ModeEmbedDesc), c_vp]),
     "mode_head_ddim_fwd": (C.c_int, [P(ModeHeadDesc), c_vp]),
     "mode_ddim_edm_step": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
-    "mode_moe_meta_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P(ModeMetaLayout)]),
-    "mode_dit_dispatch": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
+    "mode_moe_meta_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, P(ModeMetaLayout)]),
+    "mode_dit_dispatch": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
     "mode_dit_workspace_bytes": (c_sz, [P(ModeDims), C.c_int, C.c_int, C.c_int]),
     "mode_dit_sigma_embed": (C.c_int, [P(ModeDims), P(ModeModelWeights), c_vp, C.c_int, c_vp, c_vp, c_sz, c_vp]),
     "mode_dit_embed_obs": (C.c_int, [P(ModeDims), P(ModeModelWeights), c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),

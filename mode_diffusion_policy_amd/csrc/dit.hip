@@ -10,11 +10,11 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s);
 int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s);
 struct MetaBatch {
   const int* idx; const float* w; long idx_bstride;
-  int* counts; int* offsets; int* perm; int* pos; float* posw; int* tiles; int* num_tiles; long out_bstride;
+  int* counts; int* offsets; int* perm; int* pos; float* posw; long out_bstride;
 };
-int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N, int E, int k, int tile_m, int max_tiles, hipStream_t s);
+int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N, int E, int k, hipStream_t s);
 
-extern int g_use_glds;
+extern int g_gemm_cfg;
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
@@ -25,7 +25,7 @@ static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
   const size_t esz = dtype == MODE_BF16 ? 2 : 4;
   const size_t N = (size_t)B * d.T, NK = N * d.k, D = d.D;
   ModeMetaLayout ml;
-  mode_moe_meta_layout((int)N, d.E, d.k, mode_gemm_tile_m(dtype), &ml);
+  mode_moe_meta_layout((int)N, d.E, d.k, &ml);
   WsLayout w{};
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -70,47 +70,41 @@ extern "C" const char* mode_hip_status_string(int status) {
 
 extern "C" int mode_set_option(const char* key, int value) {
   if (!key) return MODE_ERR_BAD_ARG;
-  if (!strcmp(key, "gemm_glds")) { g_use_glds = value ? 1 : 0; return MODE_OK; }
+  if (!strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return MODE_OK; }
   return MODE_ERR_UNSUPPORTED;
 }
 
-extern "C" int mode_gemm_tile_m(int dtype) { return dtype == MODE_BF16 ? 128 : 64; }
-
 extern "C" int mode_gemm(const ModeGemmDesc* d, void* stream) {
   if (!d || !d->A || !d->W || !d->C || d->M < 0 || d->N <= 0) return MODE_ERR_BAD_ARG;
-  if (d->tiles && !d->num_tiles) return MODE_ERR_BAD_ARG;
+  if (d->expert_offsets && d->num_experts <= 0) return MODE_ERR_BAD_ARG;
   if (d->dtype == MODE_BF16) return gemm_bf16_launch(d, (hipStream_t)stream);
   if (d->dtype == MODE_F32) return gemm_f32_launch(d, (hipStream_t)stream);
   return MODE_ERR_BAD_ARG;
 }
 
-extern "C" int mode_moe_meta_layout(int N, int E, int k, int tile_m, ModeMetaLayout* out) {
-  if (!out || N < 0 || E <= 0 || k <= 0 || tile_m <= 0) return MODE_ERR_BAD_ARG;
+extern "C" int mode_moe_meta_layout(int N, int E, int k, ModeMetaLayout* out) {
+  if (!out || N < 0 || E <= 0 || k <= 0) return MODE_ERR_BAD_ARG;
   const int NK = N * k;
-  const int mt = mode_moe_max_tiles(N, E, k, tile_m);
   int o = 0;
   auto take = [&](int words) { int r = o; o = (o + words + 3) & ~3; return r; };
   out->counts = take(E);
   out->offsets = take(E + 1);
-  out->num_tiles = take(1);
   out->perm = take(NK);
   out->pos = take(NK);
   out->posw = take(NK);
-  out->tiles = take(mt * 3);
   out->total_words = o;
-  out->max_tiles = mt;
   return MODE_OK;
 }
 
 extern "C" int mode_dit_dispatch(const int32_t* topk_idx, const float* topk_w, int nbatch, int64_t idx_bstride, int R, int tokens_per_row,
-                                 int N, int E, int k, int tile_m, int32_t* meta, void* stream) {
+                                 int N, int E, int k, int32_t* meta, void* stream) {
   if (!topk_idx || !topk_w || !meta || nbatch < 0) return MODE_ERR_BAD_ARG;
   ModeMetaLayout ml;
-  int rc = mode_moe_meta_layout(N, E, k, tile_m, &ml);
+  int rc = mode_moe_meta_layout(N, E, k, &ml);
   if (rc) return rc;
   MetaBatch mb{topk_idx, topk_w, (long)idx_bstride, meta + ml.counts, meta + ml.offsets, meta + ml.perm, meta + ml.pos,
-               reinterpret_cast<float*>(meta + ml.posw), meta + ml.tiles, meta + ml.num_tiles, (long)ml.total_words};
-  return dispatch_meta_batched(mb, nbatch, R, tokens_per_row, N, E, k, tile_m, ml.max_tiles, (hipStream_t)stream);
+               reinterpret_cast<float*>(meta + ml.posw), (long)ml.total_words};
+  return dispatch_meta_batched(mb, nbatch, R, tokens_per_row, N, E, k, (hipStream_t)stream);
 }
 
 extern "C" size_t mode_dit_workspace_bytes(const ModeDims* dims, int B, int R, int dtype) {
@@ -124,7 +118,6 @@ static ModeGemmDesc gemm_desc(int dtype, int epi, int out_dtype, int M, int N, i
   memset(&g, 0, sizeof(g));
   g.dtype = dtype; g.epilogue = epi; g.out_dtype = out_dtype; g.M = M; g.N = N; g.K = K;
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc;
-  g.tile_m = mode_gemm_tile_m(dtype);
   return g;
 }
 
@@ -200,9 +193,8 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
   float* x = (float*)(ws + L.x);
   void* h = ws + L.h; void* qkv = ws + L.qkv; void* yat = ws + L.y; void* hbuf = ws + L.hbuf;
   float* ybuf = (float*)(ws + L.ybuf);
-  const int tile_m = mode_gemm_tile_m(dt);
   ModeMetaLayout ml;
-  mode_moe_meta_layout(N, d.E, d.k, tile_m, &ml);
+  mode_moe_meta_layout(N, d.E, d.k, &ml);
   const int cond_rpc = T;   // one conditioning row per sample
   // cond addressing: row b at cond + b*cond_row_stride.  rmsnorm/combine kernels index cond by (row / rows_per_cond) * D, so a
   // shared row (stride 0) is expressed as rows_per_cond = N (every token maps to row 0).
@@ -240,12 +232,12 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     // experts: gather -> grouped GEMM (SwishGLU epilogue) -> grouped GEMM   (modedit.py:561-566, 83-90, 247-255)
     g = gemm_desc(dt, MODE_EPI_SWIGLU, dt, NK, 4 * D, D, h, D, lw.w1, D, hbuf, 4 * D);
     g.bias = lw.b1; g.w_expert_stride = 8L * D * D; g.bias_expert_stride = 8L * D;
-    g.a_rows = meta + ml.perm; g.tiles = meta + ml.tiles; g.num_tiles = meta + ml.num_tiles; g.max_tiles = ml.max_tiles;
+    g.a_rows = meta + ml.perm; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
     g = gemm_desc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 4 * D, hbuf, 4 * D, lw.w2, 4 * D, ybuf, D);
     g.w_expert_stride = 4L * D * D;
-    g.tiles = meta + ml.tiles; g.num_tiles = meta + ml.num_tiles; g.max_tiles = ml.max_tiles;
+    g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
     if (l + 1 < d.L) {

@@ -1,30 +1,35 @@
 // bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue(A[M,K] @ W[N,K]^T), plain / row-gathered / grouped (MoE).
 //
 // Design (MI355X-first):
-//   * 128x128x64 workgroup tile, 256 threads = 4 wave64 in a 2x2 grid, each wave a 64x64 sub-tile held as 4x4
-//     v_mfma_f32_16x16x32_bf16 accumulators (64 fp32 regs/lane).
+//   * Workgroup tile BM x BN x 64 with WM x WN wave64s, each wave a (BM/WM) x (BN/WN) sub-tile of v_mfma_f32_16x16x32_bf16
+//     accumulators.  Shipped geometries: 256x128 (8 waves), 128x128 (4 waves), 128x64 (4 waves; small-N / small-M problems that would
+//     not fill 256 CUs with bigger tiles).
 //   * Both operands are K-contiguous ([out,in] nn.Linear weights are exactly the "B^T" layout MFMA wants), so every
 //     fragment is one 16-byte ds_read_b128.
-//   * LDS image: [128 rows][64 k] bf16 (128-byte rows) with the 16-byte chunk index XOR-swizzled by (row & 7): the 16 lanes of
-//     a ds_read_b128 group then hit 16 distinct 16-byte slots (conflict-free), and the image is written lane-linearly so the
-//     tile can be filled by `global_load_lds_dwordx4` (HBM/L2 -> LDS without VGPR staging) with the inverse swizzle applied to
-//     the per-lane SOURCE address (rule: linear destination + swizzled source + swizzled read).
-//   * Double-buffered LDS (2 x 32 KiB), one barrier per K-step; tile t+1 streams in while tile t feeds the MFMAs.
+//   * LDS image per operand tile: [rows][64 k] bf16 (128-byte rows) with the 16-byte chunk index XOR-swizzled by (row & 7): the 16 lanes
+//     of a ds_read_b128 group hit 16 distinct 16-byte slots (measured SQ_LDS_BANK_CONFLICT = 0), and the image is written lane-linearly so
+//     the tile is filled by `global_load_lds_dwordx4` (L2/HBM -> LDS DMA, no VGPR staging) with the inverse swizzle applied to the per-lane
+//     SOURCE address (linear destination + swizzled source + swizzled read).
+//   * NS-slot LDS ring with COUNTED `s_waitcnt vmcnt(N)` and a raw `s_barrier` (never __syncthreads, which drains vmcnt): the loads of
+//     the younger tiles stay in flight across the barrier, one barrier per 64-deep K-step.
+//   * Two-phase software pipeline inside a K-step: MFMA operands are double-buffered in VGPRs, so the ds_reads of one k32 half are
+//     always in flight under the 16..32 MFMAs of the other half (measured: an un-pipelined read->wait->MFMA body left the matrix pipe
+//     idle for the whole LDS round trip twice per K-step).
 //   * MFMA operands are issued swapped (W fragment as "A", activation fragment as "B") so each lane owns 4 CONSECUTIVE
-//     output columns of one row: bias / SwiGLU / residual epilogues run in registers and stores are 8/16 bytes per lane.
-//   * SwiGLU epilogue: a workgroup takes 64 "value" rows and the matching 64 "gate" rows of W1 (rows n and 4D+n, the
+//     output columns of one row: bias / SwiGLU epilogues run in registers.
+//   * SwiGLU epilogue: a workgroup takes BN/2 "value" rows and the matching BN/2 "gate" rows of W1 (rows n and 4D+n, the
 //     reference's tensor_split(2)) so value*silu(gate) never leaves registers and the on-disk weight layout is untouched.
-//   * Grouped mode: blockIdx -> (m-tile from the device tile table, n-tile); the expert id picks the weight slab.  No host sync.
-//   * Workgroup ids are remapped per XCD and rasterised in 8-m-tile groups so the 64 tiles resident on one XCD share
-//     ~4 MiB of operands (one XCD L2).
+//   * Output tile is transposed through LDS (padded rows, conflict-free) so global stores — and the fp32 residual read of the
+//     c_proj epilogue — are full contiguous row segments, 16 bytes per lane (measured: direct 8-byte fragment stores cost 18 us of
+//     the 88 us expert up-projection).
+//   * Grouped mode: blockIdx -> (expert, row range) from the device-side expert offsets; the expert id picks the weight slab.  No host sync.
+//   * Workgroup ids are remapped per XCD and rasterised in m-tile groups so the tiles resident on one XCD share
+//     ~4 MiB of operands (one XCD L2; measured TCC hit rate 85 %).
 #include "mode_common.h"
 
 namespace mode {
 
-constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
-constexpr int GROUP_M = 8;
+constexpr int BK = 64;
 
 struct GemmParams {
   const uint16_t* A; long lda;
@@ -32,229 +37,317 @@ struct GemmParams {
   const float* bias; long bias_estride;
   const float* resid; long ldr;
   void* C; long ldc;
-  const int* a_rows; const int* tiles; const int* num_tiles;
+  const int* a_rows; const int* offsets; int E;
   int M, N, K, m_tiles, n_tiles;
 };
 
-template <bool GLDS>
-__device__ __forceinline__ void stage_tile(char* lds_tile, const uint16_t* const (&src)[4], int koff, int wave, int lane,
-                                           uint4 (&regs)[4]) {
-  // wave w fills rows [w*32, w*32+32): 4 pieces of 8 rows x 128 B = 1 KiB, lane i -> byte i*16 of the piece.
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint16_t* g = src[q] + koff;
-    if constexpr (GLDS) {
-      char* dst = lds_tile + (wave * 32 + q * 8) * 128;   // wave-uniform base; hardware adds lane*16
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    } else {
-      regs[q] = *reinterpret_cast<const uint4*>(g);
-    }
-  }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// wait until at most `tiles` K-tiles (LOADS VMEM ops each) are still in flight for this wave
+template <int LOADS, int MAXT>
+__device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
+  if (MAXT >= 3 && tiles >= 3) wait_vmcnt<3 * LOADS>();
+  else if (MAXT >= 2 && tiles == 2) wait_vmcnt<2 * LOADS>();
+  else if (MAXT >= 1 && tiles == 1) wait_vmcnt<LOADS>();
+  else wait_vmcnt<0>();
 }
 
-__device__ __forceinline__ void commit_tile(char* lds_tile, int wave, int lane, const uint4 (&regs)[4]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    *reinterpret_cast<uint4*>(lds_tile + (wave * 32 + q * 8) * 128 + lane * 16) = regs[q];
-}
-
-template <int EPI, bool OUT_BF16, bool GLDS>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmParams p) {
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16>
+__global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kernel(const GemmParams p) {
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;         // 1-KiB DMA pieces (8 rows x 128 B) per wave per operand tile
+  constexpr int LOADS = PA + PB;                              // VMEM ops per wave per K-tile
+  constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2;
+  constexpr int GROUP_M = (BM >= 256) ? 4 : 8;
+  constexpr int NOUT = (EPI == MODE_EPI_SWIGLU) ? BN / 2 : BN;      // output columns per n-tile
+  constexpr int ESZ = OUT_BF16 ? 2 : 4;
+  constexpr int CROW = NOUT * ESZ;                            // LDS row of the output tile; 16-B chunks XOR-swizzled by the row
+  constexpr int CPR = CROW / 16;                              // 16-byte chunks per output row
+  constexpr int CSWZ = (CPR < 16 ? CPR : 16) - 1;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into whole DMA pieces per wave");
+  static_assert(EPI != MODE_EPI_SWIGLU || (FN % 2 == 0), "SwiGLU needs value+gate fragments in every wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
 
-  // ---- block -> (m-tile, n-tile)
+  // ---- block -> (m-tile, n-tile): XCD-contiguous chunks, GROUP_M m-tiles rasterised m-fastest
   const int nblk = p.m_tiles * p.n_tiles;
-  int sb = xcd_remap(blockIdx.x, nblk);
+  const int sb = xcd_remap(blockIdx.x, nblk);
   const int per_group = GROUP_M * p.n_tiles;
   const int grp = sb / per_group, first_m = grp * GROUP_M;
   const int gsz = min(p.m_tiles - first_m, GROUP_M);
   const int rem = sb - grp * per_group;
   const int mt = first_m + rem % gsz, nt = rem / gsz;
 
-  int row0, row_end, expert = 0;
-  if (p.tiles) {
-    if (mt >= *p.num_tiles) return;
-    expert = p.tiles[mt * 3 + 0]; row0 = p.tiles[mt * 3 + 1]; row_end = p.tiles[mt * 3 + 2];
+  int row0 = 0, row_end = 0, expert = 0;
+  if (p.offsets) {
+    // grouped (MoE): rows are sorted by expert; expert e owns sorted rows [offsets[e], offsets[e+1]) and ceil(count/BM) m-tiles.
+    // The offsets are fetched with independent scalar loads (no dependent chain), then scanned in registers.
+    int t = mt;
+    bool found = false;
+    if (p.E <= 8) {
+      int o[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) o[e] = p.offsets[min(e, p.E)];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (!found && e < p.E) {
+          const int nt_e = (o[e + 1] - o[e] + BM - 1) / BM;
+          if (t < nt_e) { row0 = o[e] + t * BM; row_end = min(o[e + 1], row0 + BM); expert = e; found = true; }
+          else t -= nt_e;
+        }
+      }
+    } else {
+      for (int e = 0; e < p.E && !found; ++e) {
+        const int o0 = p.offsets[e], o1 = p.offsets[e + 1];
+        const int nt_e = (o1 - o0 + BM - 1) / BM;
+        if (t < nt_e) { row0 = o0 + t * BM; row_end = min(o1, row0 + BM); expert = e; found = true; }
+        else t -= nt_e;
+      }
+    }
+    if (!found) return;
   } else {
     row0 = mt * BM; row_end = min(p.M, row0 + BM);
   }
   const uint16_t* W = p.W + (long)expert * p.w_estride;
   const float* bias = p.bias ? p.bias + (long)expert * p.bias_estride : nullptr;
-  constexpr int NOUT = (EPI == MODE_EPI_SWIGLU) ? 64 : BN;      // output columns per n-tile
   const int n0 = nt * NOUT;
 
-  // ---- per-thread source rows for staging (fixed over the K loop).  lane i -> row (i>>3) of an 8-row piece,
-  //      physical 16-B chunk (i&7), logical chunk (i&7)^(i>>3)  [row & 7 == i>>3 because pieces start at multiples of 8].
+  // ---- per-thread DMA sources (fixed over the K loop).  lane i -> row (i>>3) of an 8-row piece, physical 16-B chunk (i&7),
+  //      logical chunk (i&7)^(i>>3)   [row & 7 == i>>3 because pieces start at multiples of 8].
   const int r8 = lane >> 3, lchunk = (lane & 7) ^ r8;
-  const uint16_t* a_src[4];
-  const uint16_t* b_src[4];
+  const uint16_t* a_src[PA];
+  const uint16_t* b_src[PB];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int tr = wave * 32 + q * 8 + r8;                       // tile row 0..127
-    int s = min(row0 + tr, row_end - 1);                         // clamp: rows past the segment re-read a valid row
+  for (int q = 0; q < PA; ++q) {
+    const int tr = (wave * PA + q) * 8 + r8;
+    const int s = min(row0 + tr, row_end - 1);                   // rows past the segment re-read a valid row (never stored)
     const long arow = p.a_rows ? (long)p.a_rows[s] : (long)s;
     a_src[q] = p.A + arow * p.lda + lchunk * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const int tr = (wave * PB + q) * 8 + r8;
     long brow;
-    if constexpr (EPI == MODE_EPI_SWIGLU) brow = (long)min(n0 + (tr & 63), p.N - 1) + ((tr >= 64) ? p.N : 0);
+    if constexpr (EPI == MODE_EPI_SWIGLU) brow = (long)min(n0 + (tr % (BN / 2)), p.N - 1) + ((tr >= BN / 2) ? p.N : 0);
     else brow = min(n0 + tr, p.N - 1);
     b_src[q] = W + brow * p.ldw + lchunk * 8;
   }
 
-  f32x4 acc[4][4];
+  auto stage = [&](int slot, int kt) {
+    char* base = smem + slot * STAGE_BYTES;
+    const int koff = kt * BK;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int q = 0; q < PA; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + koff),
+                                       (__attribute__((address_space(3))) void*)(base + (wave * PA + q) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < PB; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[q] + koff),
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave * PB + q) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- fragment read offsets (bytes inside one operand tile); lane -> row (l&15), k-chunk (l>>4) [+4 for the 2nd k32 step]
   const int fr = lane & 15, fq = lane >> 4;
-  int a_off[4], b_off[4];
+  int a_off[FM], b_off[FN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) a_off[i] = (wm * 64 + i * 16 + fr) * 128;
+  for (int i = 0; i < FM; ++i) a_off[i] = (wm * TM + i * 16 + fr) * 128;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < FN; ++j) {
     int br;
-    if constexpr (EPI == MODE_EPI_SWIGLU) br = (j < 2) ? (wn * 32 + j * 16) : (64 + wn * 32 + (j - 2) * 16);
-    else br = wn * 64 + j * 16;
-    b_off[j] = (br + fr) * 128;
+    if constexpr (EPI == MODE_EPI_SWIGLU) br = (j < FN / 2) ? (wn * (TN / 2) + j * 16) : (BN / 2 + wn * (TN / 2) + (j - FN / 2) * 16);
+    else br = wn * TN + j * 16;
+    b_off[j] = A_BYTES + (br + fr) * 128;
   }
   const int sw = fr & 7;                                          // row & 7 for every fragment row of this lane
-  const int c0 = ((fq) ^ sw) * 16, c1 = ((fq + 4) ^ sw) * 16;
+  const int c0 = (fq ^ sw) * 16, c1 = ((fq + 4) ^ sw) * 16;
 
+  bf16x8 fa0[FM], fb0[FN], fa1[FM], fb1[FN];                     // double-buffered MFMA operands (software pipeline)
+  auto read_frags = [&](bf16x8(&fa)[FM], bf16x8(&fb)[FN], const char* T, int co) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(T + a_off[i] + co);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(T + b_off[j] + co);
+  };
+  auto mma = [&](const bf16x8(&fa)[FM], const bf16x8(&fb)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // swapped operands: D[n][m]
+  };
+
+  // ---- main loop
   const int nk = p.K / BK;
-  uint4 ra[4], rb[4];
-
-  // prologue: stage tile 0
-  stage_tile<GLDS>(smem, a_src, 0, wave, lane, ra);
-  stage_tile<GLDS>(smem + TILE_BYTES, b_src, 0, wave, lane, rb);
-  if constexpr (!GLDS) { commit_tile(smem, wave, lane, ra); commit_tile(smem + TILE_BYTES, wave, lane, rb); }
-
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    if (s < nk) stage(s, s);
+  int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    char* cur = smem + (kt & 1) * STAGE_BYTES;
-    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const bool more = (kt + 1) < nk;
-    if (more) {
-      stage_tile<GLDS>(nxt, a_src, (kt + 1) * BK, wave, lane, ra);
-      stage_tile<GLDS>(nxt + TILE_BYTES, b_src, (kt + 1) * BK, wave, lane, rb);
+    // tile kt landed for this wave's pieces; up to NS-1 younger tiles stay in flight across the barrier
+    wait_tiles_in_flight<LOADS, NS - 1>(min(NS - 1, nk - 1 - kt));
+    __builtin_amdgcn_s_barrier();                                  // tile kt visible to all waves
+    const char* T = smem + slot * STAGE_BYTES;
+    read_frags(fa0, fb0, T, c0);                                   // both k32 halves are requested up front: the second half's LDS
+    read_frags(fa1, fb1, T, c1);                                   // round trip hides under the first half's MFMAs
+    __builtin_amdgcn_sched_barrier(0);                             // keep all 2*(FM+FN) reads ahead of the MFMAs
+    mma(fa0, fb0);
+    mma(fa1, fb1);
+    if (kt + NS < nk) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                // every wave is done reading tile kt -> refill its slot
+      stage(slot, kt + NS);
     }
-    const char* At = cur;
-    const char* Bt = cur + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int co = ks ? c1 : c0;
-      bf16x8 af[4], bfg[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(At + a_off[i] + co);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfg[j] = *reinterpret_cast<const bf16x8*>(Bt + b_off[j] + co);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfg[j], af[i], acc[i][j], 0, 0, 0);   // swapped: D[n][m]
-    }
-    if constexpr (!GLDS) {
-      if (more) { commit_tile(nxt, wave, lane, ra); commit_tile(nxt + TILE_BYTES, wave, lane, rb); }
-    }
+    slot = (slot + 1 == NS) ? 0 : slot + 1;
   }
 
-  // ---- epilogue: lane owns row m = .. + (l&15), columns n = .. + (l>>4)*4 + {0..3}
-  const int rows_valid = row_end - row0;
+  // ---- epilogue: bias / SwiGLU in registers (lane owns row ..+(l&15), 4 consecutive columns) -> swizzled LDS tile -> coalesced stores
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                    // all waves are done reading operand tiles
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ml = wm * 64 + i * 16 + fr;
-    if (ml >= rows_valid) continue;
-    const long m = row0 + ml;
+  for (int i = 0; i < FM; ++i) {
+    const int ml = wm * TM + i * 16 + fr;
+    char* crow = smem + ml * CROW;
+    const int rsw = ml & CSWZ;
+    auto cpos = [&](int nl) { const int b = nl * ESZ; return crow + ((((b >> 4) ^ rsw) << 4) | (b & 15)); };
     if constexpr (EPI == MODE_EPI_SWIGLU) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 32 + j * 16 + fq * 4;
-        if (n >= p.N) continue;
+      for (int j = 0; j < FN / 2; ++j) {
+        const int nl = wn * (TN / 2) + j * 16 + fq * 4;
+        const int n = min(n0 + nl, p.N - 4);
         const float4 bp = *reinterpret_cast<const float4*>(bias + n);
         const float4 bg = *reinterpret_cast<const float4*>(bias + p.N + n);
-        const f32x4 v = acc[i][j], g = acc[i][j + 2];
+        const f32x4 v = acc[i][j], g = acc[i][j + FN / 2];
         const float o0 = (v[0] + bp.x) * silu_f(g[0] + bg.x), o1 = (v[1] + bp.y) * silu_f(g[1] + bg.y);
         const float o2 = (v[2] + bp.z) * silu_f(g[2] + bg.z), o3 = (v[3] + bp.w) * silu_f(g[3] + bg.w);
-        if constexpr (OUT_BF16) {
-          uint2 o; o.x = pack_bf16x2(o0, o1); o.y = pack_bf16x2(o2, o3);
-          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + m * p.ldc + n) = o;
-        } else {
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = make_float4(o0, o1, o2, o3);
-        }
+        if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(cpos(nl)) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+        else *reinterpret_cast<float4*>(cpos(nl)) = make_float4(o0, o1, o2, o3);
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + fq * 4;
-        if (n >= p.N) continue;
+      for (int j = 0; j < FN; ++j) {
+        const int nl = wn * TN + j * 16 + fq * 4;
         f32x4 v = acc[i][j];
         if constexpr (EPI == MODE_EPI_BIAS || EPI == MODE_EPI_BIAS_GELU) {
-          const float4 b = *reinterpret_cast<const float4*>(bias + n);
+          const float4 b = *reinterpret_cast<const float4*>(bias + min(n0 + nl, p.N - 4));
           v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
           if constexpr (EPI == MODE_EPI_BIAS_GELU) {
             v[0] = gelu_erf_f(v[0]); v[1] = gelu_erf_f(v[1]); v[2] = gelu_erf_f(v[2]); v[3] = gelu_erf_f(v[3]);
           }
-        } else if constexpr (EPI == MODE_EPI_RESIDUAL) {
-          const float4 r = *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n);
-          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
         }
-        if constexpr (OUT_BF16) {
-          uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + m * p.ldc + n) = o;
-        } else {
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(cpos(nl)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        else *reinterpret_cast<float4*>(cpos(nl)) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    constexpr int EPC = 16 / ESZ;                                  // elements per chunk
+    const int rows_valid = row_end - row0;
+    for (int c = tid; c < BM * CPR; c += NT) {
+      const int ml = c / CPR, ch = c % CPR;
+      const int n = n0 + ch * EPC;
+      if (ml >= rows_valid || n >= p.N) continue;
+      const long m = row0 + ml;
+      uint4 v = *reinterpret_cast<const uint4*>(smem + ml * CROW + ((ch ^ (ml & CSWZ)) << 4));
+      if constexpr (EPI == MODE_EPI_RESIDUAL && !OUT_BF16) {
+        const float4 r = *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n);
+        float4 f = *reinterpret_cast<float4*>(&v);
+        f.x += r.x; f.y += r.y; f.z += r.z; f.w += r.w;
+        v = *reinterpret_cast<uint4*>(&f);
+      }
+      if constexpr (OUT_BF16) {
+        if (n + 8 <= p.N) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + m * p.ldc + n) = v;
+        else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + m * p.ldc + n) = make_uint2(v.x, v.y);   // N % 8 == 4 tail
+      } else {
+        *reinterpret_cast<uint4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = v;
       }
     }
   }
 }
 
-template <int EPI, bool OUT_BF16>
-static int launch_epi(const GemmParams& p, int nblk, bool glds, hipStream_t s) {
-  const size_t lds = 2 * STAGE_BYTES;
-  if (glds) {
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OUT_BF16, true>), dim3(nblk), dim3(NTHREADS), lds, s, p);
-  } else {
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OUT_BF16, false>), dim3(nblk), dim3(NTHREADS), lds, s, p);
+// ------------------------------------------------------------------------------------------------------------ host side
+// geometry ids (also the values of the "gemm_cfg" option; 0 = auto)
+enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x128_NS3 = 2, CFG_256x128_NS3 = 3, CFG_128x64_NS3 = 4, CFG_128x64_NS4 = 5,
+       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8 };
+int g_gemm_cfg = CFG_AUTO;
+
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16>
+static int launch_cfg(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
+  constexpr int NOUT = (EPI == MODE_EPI_SWIGLU) ? BN / 2 : BN;
+  constexpr size_t RING = (size_t)NS * (BM + BN) * BK * 2, OUTT = (size_t)BM * NOUT * (OUT_BF16 ? 2 : 4);
+  constexpr size_t LDS = RING > OUTT ? RING : OUTT;
+  p.n_tiles = (d->N + NOUT - 1) / NOUT;
+  p.m_tiles = (d->M + BM - 1) / BM + (d->expert_offsets ? d->num_experts : 0);
+  auto kern = gemm_bf16_kernel<BM, BN, WM, WN, NS, EPI, OUT_BF16>;
+  static bool attr_set = false;
+  if (!attr_set && LDS > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
   }
+  hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles), dim3(WM * WN * 64), LDS, s, p);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
 
-int g_use_glds = -1;
+template <int EPI, bool OUT_BF16>
+static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipStream_t s) {
+  switch (cfg) {
+    case CFG_128x128_NS2: return launch_cfg<128, 128, 2, 2, 2, EPI, OUT_BF16>(p, d, s);
+    case CFG_128x128_NS3: return launch_cfg<128, 128, 2, 2, 3, EPI, OUT_BF16>(p, d, s);
+    case CFG_256x128_NS3: return launch_cfg<256, 128, 4, 2, 3, EPI, OUT_BF16>(p, d, s);
+    case CFG_128x64_NS3: return launch_cfg<128, 64, 2, 2, 3, EPI, OUT_BF16>(p, d, s);
+    case CFG_128x64_NS4: return launch_cfg<128, 64, 2, 2, 4, EPI, OUT_BF16>(p, d, s);
+    case CFG_128x128_NS1: return launch_cfg<128, 128, 2, 2, 1, EPI, OUT_BF16>(p, d, s);
+    case CFG_128x64_NS1: return launch_cfg<128, 64, 2, 2, 1, EPI, OUT_BF16>(p, d, s);
+    case CFG_128x64_NS2: return launch_cfg<128, 64, 2, 2, 2, EPI, OUT_BF16>(p, d, s);
+    default: return MODE_ERR_BAD_ARG;
+  }
+}
+
+// Tile-geometry heuristic for 256 CUs, from scripts/gemm_bench.py / gemm_ksweep.py on the config-2 layer shapes:
+//   >= 1024 tiles of 128x128 : single-buffered 128x128 at 3 workgroups/CU (other workgroups hide the fill latency)   [expert up-projection]
+//   >= 256                   : double-buffered 128x128 ring                                                          [QKV]
+//   fewer                    : 128x64 tiles so that >= 1 workgroup lands on every CU; deeper ring for long K          [c_proj, expert down-proj]
+static int pick_cfg(const ModeGemmDesc* d) {
+  const long rows = d->M;
+  const int nout128 = (d->epilogue == MODE_EPI_SWIGLU) ? 64 : 128;
+  const long t128 = ((rows + 127) / 128) * ((d->N + nout128 - 1) / nout128);
+  if (t128 >= 1024) return CFG_128x128_NS1;
+  if (t128 >= 256) return CFG_128x128_NS2;
+  return d->K >= 2048 ? CFG_128x64_NS3 : CFG_128x64_NS2;
+}
 
 int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
   if (d->K % BK != 0 || d->K <= 0) return MODE_ERR_UNSUPPORTED;
   if (d->N % 4 != 0 || d->lda % 8 != 0 || d->ldw % 8 != 0 || d->ldc % 4 != 0) return MODE_ERR_UNSUPPORTED;
-  if (d->tiles && d->tile_m != BM) return MODE_ERR_BAD_ARG;
   if ((d->epilogue == MODE_EPI_BIAS || d->epilogue == MODE_EPI_BIAS_GELU || d->epilogue == MODE_EPI_SWIGLU) && !d->bias)
     return MODE_ERR_BAD_ARG;
-  if (d->epilogue == MODE_EPI_RESIDUAL && !d->resid) return MODE_ERR_BAD_ARG;
+  if (d->epilogue == MODE_EPI_RESIDUAL && (!d->resid || d->out_dtype != MODE_F32 || d->ldr % 4)) return MODE_ERR_BAD_ARG;
   if (d->M <= 0) return MODE_OK;
-  if (g_use_glds < 0) {
-    const char* e = getenv("MODE_GEMM_GLDS");
-    g_use_glds = (e && e[0] == '0') ? 0 : 1;
-  }
   GemmParams p;
   p.A = (const uint16_t*)d->A; p.lda = d->lda;
   p.W = (const uint16_t*)d->W; p.ldw = d->ldw; p.w_estride = d->w_expert_stride;
   p.bias = d->bias; p.bias_estride = d->bias_expert_stride;
   p.resid = d->resid; p.ldr = d->ldr; p.C = d->C; p.ldc = d->ldc;
-  p.a_rows = d->a_rows; p.tiles = d->tiles; p.num_tiles = d->num_tiles;
+  p.a_rows = d->a_rows; p.offsets = d->expert_offsets; p.E = d->num_experts;
   p.M = d->M; p.N = d->N; p.K = d->K;
-  const int nout = (d->epilogue == MODE_EPI_SWIGLU) ? 64 : BN;
-  p.n_tiles = (d->N + nout - 1) / nout;
-  p.m_tiles = d->tiles ? d->max_tiles : (d->M + BM - 1) / BM;
-  const int nblk = p.m_tiles * p.n_tiles;
+  p.m_tiles = p.n_tiles = 0;
+  const int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d);
   const bool ob = d->out_dtype == MODE_BF16;
-  const bool glds = g_use_glds != 0;
-#define MODE_CASE(E)                                                          \
-  case E: return ob ? launch_epi<E, true>(p, nblk, glds, s) : launch_epi<E, false>(p, nblk, glds, s);
+#define MODE_CASE(E) \
+  case E: return ob ? launch_epi<E, true>(p, d, cfg, s) : launch_epi<E, false>(p, d, cfg, s);
   switch (d->epilogue) {
     MODE_CASE(MODE_EPI_NONE)
     MODE_CASE(MODE_EPI_BIAS)

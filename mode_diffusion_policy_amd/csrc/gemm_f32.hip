@@ -15,7 +15,7 @@ struct GemmF32Params {
   const float* bias; long bias_estride;
   const float* resid; long ldr;
   void* C; long ldc;
-  const int* a_rows; const int* tiles; const int* num_tiles;
+  const int* a_rows; const int* offsets; int E;
   int M, N, K, m_tiles, n_tiles;
 };
 
@@ -27,10 +27,18 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int mt = blockIdx.x / p.n_tiles, nt = blockIdx.x % p.n_tiles;
 
-  int row0, row_end, expert = 0;
-  if (p.tiles) {
-    if (mt >= *p.num_tiles) return;
-    expert = p.tiles[mt * 3 + 0]; row0 = p.tiles[mt * 3 + 1]; row_end = p.tiles[mt * 3 + 2];
+  int row0 = 0, row_end = 0, expert = 0;
+  if (p.offsets) {
+    int t = mt, e = 0;
+    bool found = false;
+    for (; e < p.E; ++e) {
+      const int o0 = p.offsets[e], o1 = p.offsets[e + 1];
+      const int nt_e = (o1 - o0 + FBM - 1) / FBM;
+      if (t < nt_e) { row0 = o0 + t * FBM; row_end = min(o1, row0 + FBM); found = true; break; }
+      t -= nt_e;
+    }
+    if (!found) return;
+    expert = e;
   } else {
     row0 = mt * FBM; row_end = min(p.M, row0 + FBM);
   }
@@ -160,7 +168,6 @@ static int launch_f32(const GemmF32Params& p, int nblk, bool vec, hipStream_t s)
 
 int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s) {
   if (d->K <= 0) return MODE_ERR_UNSUPPORTED;
-  if (d->tiles && d->tile_m != FBM) return MODE_ERR_BAD_ARG;
   if ((d->epilogue == MODE_EPI_BIAS || d->epilogue == MODE_EPI_BIAS_GELU || d->epilogue == MODE_EPI_SWIGLU) && !d->bias)
     return MODE_ERR_BAD_ARG;
   if (d->epilogue == MODE_EPI_RESIDUAL && !d->resid) return MODE_ERR_BAD_ARG;
@@ -170,11 +177,11 @@ int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.W = (const float*)d->W; p.ldw = d->ldw; p.w_estride = d->w_expert_stride;
   p.bias = d->bias; p.bias_estride = d->bias_expert_stride;
   p.resid = d->resid; p.ldr = d->ldr; p.C = d->C; p.ldc = d->ldc;
-  p.a_rows = d->a_rows; p.tiles = d->tiles; p.num_tiles = d->num_tiles;
+  p.a_rows = d->a_rows; p.offsets = d->expert_offsets; p.E = d->num_experts;
   p.M = d->M; p.N = d->N; p.K = d->K;
   const int nout = (d->epilogue == MODE_EPI_SWIGLU) ? 32 : FBN;
   p.n_tiles = (d->N + nout - 1) / nout;
-  p.m_tiles = d->tiles ? d->max_tiles : (d->M + FBM - 1) / FBM;
+  p.m_tiles = (d->M + FBM - 1) / FBM + (d->expert_offsets ? d->num_experts : 0);
   const int nblk = p.m_tiles * p.n_tiles;
   const bool vec = (d->K % FBK == 0) && (d->lda % 4 == 0) && (d->ldw % 4 == 0) && (d->w_expert_stride % 4 == 0) &&
                    (((uintptr_t)d->A | (uintptr_t)d->W) % 16 == 0);

@@ -20,8 +20,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
   return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two fp32 -> packed bf16x2 (round-to-nearest-even): one v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+  bf16x2_t v;
+  v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 // ---- wave64 reductions via cross-lane shuffles ----------------------------------------------------------------------
@@ -36,7 +40,7 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float silu_f(float g) { return g / (1.0f + __expf(-g)); }
+__device__ __forceinline__ float silu_f(float g) { return __fdividef(g, 1.0f + __expf(-g)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // XCD-aware, bijective remap of a linear workgroup id: hardware places block b on XCD b % 8 (observed, speed only), so give

@@ -3,7 +3,7 @@
 //                  (modedit.py:345-349, 392, 398-399, 418-419)
 //   dispatch_meta: canonical permutation of the reference's boolean-mask loop — experts ascending, token ids ascending
 //                  inside an expert (modedit.py:561-566) — via ballot/popcount block scans; also emits the inverse map
-//                  (token, ascending-expert slot) -> sorted row used by the combine kernels and the grouped-GEMM tile table.
+//                  (token, ascending-expert slot) -> sorted row used by the combine kernels; the grouped GEMMs read `offsets`.
 #include "mode_common.h"
 
 namespace mode {
@@ -52,11 +52,10 @@ __global__ __launch_bounds__(256) void route_topk_kernel(const float* __restrict
 // ---- dispatch metadata: one workgroup per problem (layer); blockDim = 1024
 struct MetaBatch {
   const int* idx; const float* w; long idx_bstride;          // [R,k] per problem
-  int* counts; int* offsets; int* perm; int* pos; float* posw; int* tiles; int* num_tiles; long out_bstride;  // strides in 4-byte words
+  int* counts; int* offsets; int* perm; int* pos; float* posw; long out_bstride;  // strides in 4-byte words
 };
 
-__global__ __launch_bounds__(1024) void dispatch_meta_kernel(MetaBatch mb, int R, int tpr, int N, int E, int k, int tile_m,
-                                                             int max_tiles) {
+__global__ __launch_bounds__(1024) void dispatch_meta_kernel(MetaBatch mb, int R, int tpr, int N, int E, int k) {
   __shared__ int s_wave[16];
   __shared__ int s_base;
   __shared__ int s_offsets[65];
@@ -64,7 +63,7 @@ __global__ __launch_bounds__(1024) void dispatch_meta_kernel(MetaBatch mb, int R
   const int* idx = mb.idx + (long)blockIdx.x * mb.idx_bstride;
   const float* w = mb.w + (long)blockIdx.x * mb.idx_bstride;
   int* counts = mb.counts + bo; int* offsets = mb.offsets + bo; int* perm = mb.perm + bo; int* pos = mb.pos + bo;
-  float* posw = mb.posw + bo; int* tiles = mb.tiles + bo; int* num_tiles = mb.num_tiles + bo;
+  float* posw = mb.posw + bo;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
 
   if (tid == 0) s_offsets[0] = 0;
@@ -103,17 +102,8 @@ __global__ __launch_bounds__(1024) void dispatch_meta_kernel(MetaBatch mb, int R
     if (tid == 0) { counts[e] = s_base; s_offsets[e + 1] = s_offsets[e] + s_base; }
     __syncthreads();
   }
-  if (tid == 0) {
-    int nt = 0;
+  if (tid == 0)
     for (int e = 0; e <= E; ++e) offsets[e] = s_offsets[e];
-    for (int e = 0; e < E; ++e) {
-      for (int r = s_offsets[e]; r < s_offsets[e + 1] && nt < max_tiles; r += tile_m) {
-        tiles[nt * 3 + 0] = e; tiles[nt * 3 + 1] = r; tiles[nt * 3 + 2] = min(r + tile_m, s_offsets[e + 1]);
-        ++nt;
-      }
-    }
-    *num_tiles = nt;
-  }
 }
 
 }  // namespace mode
@@ -134,27 +124,19 @@ extern "C" int mode_moe_route_topk_f32(const float* logits, int R, int E, int k,
   return MODE_OK;
 }
 
-extern "C" int mode_moe_max_tiles(int N, int E, int k, int tile_m) {
-  if (tile_m <= 0) return 0;
-  return (int)(((long)N * k + tile_m - 1) / tile_m) + E;
-}
-
 namespace mode {
-int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N, int E, int k, int tile_m, int max_tiles,
-                          hipStream_t s) {
+int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N, int E, int k, hipStream_t s) {
   if (E > 64 || k > E || tpr <= 0 || R * (long)tpr < N) return MODE_ERR_BAD_ARG;
   if (nbatch == 0) return MODE_OK;
-  hipLaunchKernelGGL(dispatch_meta_kernel, dim3(nbatch), dim3(1024), 0, s, mb, R, tpr, N, E, k, tile_m, max_tiles);
+  hipLaunchKernelGGL(dispatch_meta_kernel, dim3(nbatch), dim3(1024), 0, s, mb, R, tpr, N, E, k);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
 }  // namespace mode
 
-extern "C" int mode_moe_dispatch_meta(const int32_t* idx, const float* w, int R, int tokens_per_row, int N, int E, int k, int tile_m,
-                                      int32_t* counts, int32_t* offsets, int32_t* perm, int32_t* pos, float* posw, int32_t* tiles,
-                                      int32_t* num_tiles, int max_tiles, void* stream) {
-  if (!idx || !w || !counts || !offsets || !perm || !pos || !posw || !tiles || !num_tiles) return MODE_ERR_BAD_ARG;
-  if (max_tiles < mode_moe_max_tiles(N, E, k, tile_m)) return MODE_ERR_BAD_ARG;
-  MetaBatch mb{idx, w, 0, counts, offsets, perm, pos, posw, tiles, num_tiles, 0};
-  return dispatch_meta_batched(mb, 1, R, tokens_per_row, N, E, k, tile_m, max_tiles, (hipStream_t)stream);
+extern "C" int mode_moe_dispatch_meta(const int32_t* idx, const float* w, int R, int tokens_per_row, int N, int E, int k, int32_t* counts,
+                                      int32_t* offsets, int32_t* perm, int32_t* pos, float* posw, void* stream) {
+  if (!idx || !w || !counts || !offsets || !perm || !pos || !posw) return MODE_ERR_BAD_ARG;
+  MetaBatch mb{idx, w, 0, counts, offsets, perm, pos, posw, 0};
+  return dispatch_meta_batched(mb, 1, R, tokens_per_row, N, E, k, (hipStream_t)stream);
 }

@@ -41,7 +41,6 @@ class DitEngine:
                                A_len=m.action_seq_len, A_dim=m.action_dim, O=m.obs_dim, G=m.goal_dim, n_img=m.n_img_tokens,
                                use_noise_token=int(m.use_noise_token_as_input), router_normalize=int(m.router_normalize),
                                eps=1e-6)
-        self.tile_m = self.lib.mode_gemm_tile_m(self.dt)
 
     # ------------------------------------------------------------------ weights
     def _key(self):
@@ -100,7 +99,7 @@ class DitEngine:
 
     def meta_layout(self, N: int) -> L.ModeMetaLayout:
         ml = L.ModeMetaLayout()
-        L.check(self.lib.mode_moe_meta_layout(N, self.dims.E, self.dims.k, self.tile_m, C.byref(ml)), "meta_layout")
+        L.check(self.lib.mode_moe_meta_layout(N, self.dims.E, self.dims.k, C.byref(ml)), "meta_layout")
         return ml
 
     # ------------------------------------------------------------------ building blocks (each = a few launches, no sync)
@@ -135,7 +134,7 @@ class DitEngine:
         ml = self.meta_layout(N)
         meta = torch.empty(nbatch, ml.total_words, dtype=torch.int32, device=self.device)
         L.check(self.lib.mode_dit_dispatch(idx.data_ptr(), w.data_ptr(), nbatch, R * self.dims.k, R, tokens_per_row, N, self.dims.E,
-                                           self.dims.k, self.tile_m, meta.data_ptr(), _stream()), "dispatch")
+                                           self.dims.k, meta.data_ptr(), _stream()), "dispatch")
         return meta
 
     def forward(self, B: int, emb_t, emb_stride: int, cond, cond_stride: int, meta_ptr: int, meta_layer_stride: int, goal_e, img_e,

@@ -20,8 +20,8 @@ def dt_of(t):
     return L.MODE_BF16 if t.dtype == torch.bfloat16 else L.MODE_F32
 
 
-def gemm(A, W, epilogue=L.EPI_NONE, bias=None, resid=None, out_dtype=None, n_out=None, a_rows=None, tiles=None, num_tiles=None,
-         max_tiles=0, M=None, w_estride=0, b_estride=0):
+def gemm(A, W, epilogue=L.EPI_NONE, bias=None, resid=None, out_dtype=None, n_out=None, a_rows=None, offsets=None, num_experts=0,
+         M=None, w_estride=0, b_estride=0):
     lib = L.load()
     out_dtype = out_dtype or A.dtype
     K = A.shape[-1]
@@ -32,8 +32,7 @@ def gemm(A, W, epilogue=L.EPI_NONE, bias=None, resid=None, out_dtype=None, n_out
     d = L.ModeGemmDesc(dtype=dt_of(A), epilogue=epilogue, out_dtype=L.MODE_BF16 if out_dtype == torch.bfloat16 else L.MODE_F32,
                        M=M, N=N, K=K, A=p(A), lda=A.stride(0), W=p(W), ldw=Wm.stride(0), w_expert_stride=w_estride,
                        bias=p(bias), bias_expert_stride=b_estride, resid=p(resid), ldr=(resid.stride(0) if resid is not None else 0),
-                       C=p(Cc), ldc=Cc.stride(0), a_rows=p(a_rows), tiles=p(tiles), num_tiles=p(num_tiles), max_tiles=max_tiles,
-                       tile_m=lib.mode_gemm_tile_m(dt_of(A)))
+                       C=p(Cc), ldc=Cc.stride(0), a_rows=p(a_rows), expert_offsets=p(offsets), num_experts=num_experts)
     L.check(lib.mode_gemm(C.byref(d), stream()), "gemm")
     return Cc
 
@@ -48,18 +47,16 @@ def route_topk(logits, k, normalize=True):
     return sh, pr, idx, w
 
 
-def dispatch_meta(idx, w, tokens_per_row, N, E, tile_m):
+def dispatch_meta(idx, w, tokens_per_row, N, E):
     lib = L.load()
     R, k = idx.shape
-    mt = lib.mode_moe_max_tiles(N, E, k, tile_m)
     dev = idx.device
     i32 = lambda *s: torch.full(s, -1, dtype=torch.int32, device=dev)
     counts, offsets, perm, pos = i32(E), i32(E + 1), i32(N * k), i32(N * k)
     posw = torch.empty(N * k, dtype=torch.float32, device=dev)
-    tiles, nt = i32(mt * 3), i32(1)
-    L.check(lib.mode_moe_dispatch_meta(p(idx), p(w), R, tokens_per_row, N, E, k, tile_m, p(counts), p(offsets), p(perm), p(pos), p(posw),
-                                       p(tiles), p(nt), mt, stream()), "dispatch_meta")
-    return dict(counts=counts, offsets=offsets, perm=perm, pos=pos, posw=posw, tiles=tiles, num_tiles=nt, max_tiles=mt)
+    L.check(lib.mode_moe_dispatch_meta(p(idx), p(w), R, tokens_per_row, N, E, k, p(counts), p(offsets), p(perm), p(pos), p(posw),
+                                       stream()), "dispatch_meta")
+    return dict(counts=counts, offsets=offsets, perm=perm, pos=pos, posw=posw)
 
 
 def rmsnorm(x, g, cond=None, rows_per_cond=1, eps=1e-6, lp_dtype=torch.bfloat16, want_f32=True):

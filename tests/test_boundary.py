@@ -33,8 +33,7 @@ def test_header_symbols_all_exported():
         assert hasattr(lib, name), name
     assert lib.mode_hip_version() == L.ABI_VERSION
     assert lib.mode_hip_status_string(-2).decode().startswith("unsupported")
-    assert lib.mode_gemm_tile_m(L.MODE_BF16) == 128 and lib.mode_gemm_tile_m(L.MODE_F32) == 64
-    assert lib.mode_moe_max_tiles(1792, 4, 2, 128) == 28 + 4
+    assert lib.mode_set_option(b"gemm_cfg", 0) == 0 and lib.mode_set_option(b"nope", 1) == -2
 
 
 def test_ctypes_struct_sizes_match_header_layout():
@@ -42,9 +41,9 @@ def test_ctypes_struct_sizes_match_header_layout():
     import ctypes as C
     lib = L.load()
     ml = L.ModeMetaLayout()
-    assert lib.mode_moe_meta_layout(1792, 4, 2, 128, C.byref(ml)) == 0
-    assert ml.max_tiles == 32 and ml.perm % 4 == 0 and ml.total_words >= 3 * 3584 + 32 * 3
-    assert ml.counts < ml.offsets < ml.num_tiles < ml.perm < ml.pos < ml.posw < ml.tiles < ml.total_words
+    assert lib.mode_moe_meta_layout(1792, 4, 2, C.byref(ml)) == 0
+    assert ml.perm % 4 == 0 and ml.total_words >= 3 * 3584 + 9
+    assert ml.counts < ml.offsets < ml.perm < ml.pos < ml.posw < ml.total_words
     dims = L.ModeDims(D=1024, H=8, L=12, E=4, k=2, T=14, A_len=10, A_dim=7, O=2048, G=512, n_img=2, use_noise_token=1,
                       router_normalize=1, eps=1e-6)
     nb = lib.mode_dit_workspace_bytes(C.byref(dims), 128, 10, L.MODE_BF16)

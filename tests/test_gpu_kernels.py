@@ -30,20 +30,20 @@ def rnd(*shape, seed=0, scale=1.0):
 
 # ----------------------------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1792, 3072, 1024), (100, 192, 64), (257, 1024, 256), (14, 64, 128), (1, 128, 64)])
-@pytest.mark.parametrize("glds", [1, 0])
-def test_gemm_bf16_plain_bias(M, N, K, glds):
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+def test_gemm_bf16_plain_bias(M, N, K, cfg):
     # asymmetric operands: a transposed/permuted C-write cannot pass
     A = rnd(M, K, seed=1).to(torch.bfloat16); W = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
     b = rnd(N, seed=3)
     ref = A.float() @ W.float().t() + b
-    L.load().mode_set_option(b"gemm_glds", glds)      # both staging variants (LDS-DMA / VGPR) must agree with the reference
+    L.load().mode_set_option(b"gemm_cfg", cfg)       # every tile geometry / ring depth (0 = auto heuristic) must agree
     try:
         out = H.gemm(A.to(dev()), W.to(dev()), L.EPI_BIAS, bias=b.to(dev()), out_dtype=torch.float32)
         assert rel(out, ref) < 2e-3
         out16 = H.gemm(A.to(dev()), W.to(dev()), L.EPI_BIAS, bias=b.to(dev()), out_dtype=torch.bfloat16)
         assert rel(out16.float(), ref) < 6e-3
     finally:
-        L.load().mode_set_option(b"gemm_glds", 1)
+        L.load().mode_set_option(b"gemm_cfg", 0)
 
 
 def test_gemm_bf16_identity_asymmetric():
@@ -55,8 +55,17 @@ def test_gemm_bf16_identity_asymmetric():
     assert torch.equal(out.cpu(), W.float().t().contiguous())
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 6, 7, 8])
 @pytest.mark.parametrize("M,D", [(300, 256), (3584, 1024)])
-def test_gemm_bf16_swiglu_residual(M, D):
+def test_gemm_bf16_swiglu_residual(M, D, cfg):
+    L.load().mode_set_option(b"gemm_cfg", cfg)
+    try:
+        _swiglu_residual(M, D)
+    finally:
+        L.load().mode_set_option(b"gemm_cfg", 0)
+
+
+def _swiglu_residual(M, D):
     A = rnd(M, D, seed=4).to(torch.bfloat16); W1 = rnd(8 * D, D, seed=5, scale=D ** -0.5).to(torch.bfloat16); b1 = rnd(8 * D, seed=6, scale=0.1)
     h = A.float() @ W1.float().t() + b1
     ref = h[:, : 4 * D] * torch.nn.functional.silu(h[:, 4 * D:])
@@ -67,27 +76,35 @@ def test_gemm_bf16_swiglu_residual(M, D):
     assert rel(out2, A.float() @ Wo.float().t() + r) < 2e-3
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 6, 8])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("N_tok,E,k,D", [(70, 4, 2, 64), (1792, 4, 2, 256), (112, 2, 1, 256), (5, 4, 2, 64)])
-def test_grouped_gather_gemm(dtype, N_tok, E, k, D):
+@pytest.mark.parametrize("N_tok,E,k,D", [(70, 4, 2, 64), (1792, 4, 2, 256), (112, 2, 1, 256), (5, 4, 2, 64), (900, 4, 2, 128)])
+def test_grouped_gather_gemm(dtype, N_tok, E, k, D, cfg):
+    L.load().mode_set_option(b"gemm_cfg", cfg)
+    try:
+        _grouped_gather_gemm(dtype, N_tok, E, k, D)
+    finally:
+        L.load().mode_set_option(b"gemm_cfg", 0)
+
+
+def _grouped_gather_gemm(dtype, N_tok, E, k, D):
     """dispatch meta -> gathered grouped SwiGLU GEMM -> grouped GEMM, vs the oracle's per-expert loop (modedit.py:561-566)."""
     lib = L.load()
     g = torch.Generator().manual_seed(11)
     probs = torch.rand(N_tok, E, generator=g)
     idx = torch.sort(probs, dim=-1, descending=True, stable=True).indices[:, :k].contiguous()
     w = probs.gather(1, idx); w = w / w.sum(-1, keepdim=True)
-    tile_m = lib.mode_gemm_tile_m(L.MODE_BF16 if dtype == torch.bfloat16 else L.MODE_F32)
-    meta = H.dispatch_meta(idx.int().to(dev()), w.to(dev()), 1, N_tok, E, tile_m)
+    meta = H.dispatch_meta(idx.int().to(dev()), w.to(dev()), 1, N_tok, E)
     counts, perm, slot = O.dispatch_permutation(idx, E)
     assert torch.equal(meta["counts"].cpu().long(), counts)
     assert torch.equal(meta["perm"].cpu().long(), perm)                       # bit-exact permutation
     u = rnd(N_tok, D, seed=12).to(dtype)
     W1 = rnd(E, 8 * D, D, seed=13, scale=D ** -0.5).to(dtype); b1 = rnd(E, 8 * D, seed=14, scale=0.1)
     W2 = rnd(E, D, 4 * D, seed=15, scale=(4 * D) ** -0.5).to(dtype)
-    Hs = H.gemm(u.to(dev()), W1.to(dev()), L.EPI_SWIGLU, bias=b1.to(dev()), out_dtype=dtype, a_rows=meta["perm"], tiles=meta["tiles"],
-                num_tiles=meta["num_tiles"], max_tiles=meta["max_tiles"], M=N_tok * k, w_estride=8 * D * D, b_estride=8 * D)
-    Y = H.gemm(Hs, W2.to(dev()), L.EPI_NONE, out_dtype=torch.float32, tiles=meta["tiles"], num_tiles=meta["num_tiles"],
-               max_tiles=meta["max_tiles"], M=N_tok * k, w_estride=4 * D * D)
+    Hs = H.gemm(u.to(dev()), W1.to(dev()), L.EPI_SWIGLU, bias=b1.to(dev()), out_dtype=dtype, a_rows=meta["perm"], offsets=meta["offsets"],
+                num_experts=E, M=N_tok * k, w_estride=8 * D * D, b_estride=8 * D)
+    Y = H.gemm(Hs, W2.to(dev()), L.EPI_NONE, out_dtype=torch.float32, offsets=meta["offsets"], num_experts=E, M=N_tok * k,
+               w_estride=4 * D * D)
     # reference in sorted-row order
     off = 0; Href = torch.zeros(N_tok * k, 4 * D); Yref = torch.zeros(N_tok * k, D)
     for e in range(E):
@@ -191,25 +208,15 @@ def test_dispatch_meta_bit_exact(R, tpr, E, k):
     idx = torch.multinomial(probs, k, replacement=False, generator=g)          # unsorted slots, like training (modedit.py:390)
     w = probs.gather(1, idx)
     N = R * tpr
-    for tile_m in (128, 64):
-        meta = H.dispatch_meta(idx.int().to(dev()), w.to(dev()), tpr, N, E, tile_m)
-        tok_idx = idx.repeat_interleave(tpr, 0)
-        counts, perm, slot = O.dispatch_permutation(tok_idx, E)
-        assert torch.equal(meta["counts"].cpu().long(), counts)
-        assert torch.equal(meta["offsets"].cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]))
-        assert torch.equal(meta["perm"].cpu().long(), perm)
-        pos = meta["pos"].cpu().long().view(N, k); posw = meta["posw"].cpu().view(N, k)
-        # pos[t, j] is the sorted row of token t's j-th expert in ASCENDING expert order
-        srt = torch.sort(tok_idx, dim=-1)
-        wtok = w.repeat_interleave(tpr, 0).gather(1, srt.indices)
-        assert torch.equal(perm[pos.reshape(-1)], torch.arange(N).repeat_interleave(k))
-        assert torch.equal(posw, wtok)
-        nt = int(meta["num_tiles"].cpu())
-        tiles = meta["tiles"].cpu().view(-1, 3)[:nt]
-        assert nt == int(((counts + tile_m - 1) // tile_m).sum())
-        cover = torch.zeros(N * k, dtype=torch.int32)
-        offs = meta["offsets"].cpu()
-        for e, r0, r1 in tiles.tolist():
-            assert offs[e] <= r0 < r1 <= offs[e + 1] and r1 - r0 <= tile_m
-            cover[r0:r1] += 1
-        assert bool((cover == 1).all())
+    meta = H.dispatch_meta(idx.int().to(dev()), w.to(dev()), tpr, N, E)
+    tok_idx = idx.repeat_interleave(tpr, 0)
+    counts, perm, slot = O.dispatch_permutation(tok_idx, E)
+    assert torch.equal(meta["counts"].cpu().long(), counts)
+    assert torch.equal(meta["offsets"].cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]))
+    assert torch.equal(meta["perm"].cpu().long(), perm)
+    pos = meta["pos"].cpu().long().view(N, k); posw = meta["posw"].cpu().view(N, k)
+    # pos[t, j] is the sorted row of token t's j-th expert in ASCENDING expert order
+    srt = torch.sort(tok_idx, dim=-1)
+    wtok = w.repeat_interleave(tpr, 0).gather(1, srt.indices)
+    assert torch.equal(perm[pos.reshape(-1)], torch.arange(N).repeat_interleave(k))
+    assert torch.equal(posw, wtok)
