@@ -164,7 +164,7 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:       # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)

@@ -48,7 +48,7 @@ int mode_hip_version(void);
 const char* mode_hip_status_string(int status);
 /* Tuning knobs (process-wide).  "gemm_cfg": bf16 GEMM tile geometry, 0 = auto (default), 1 = 128x128 ring-2, 2 = 128x128 ring-3,
  * 3 = 256x128 ring-3, 4 = 128x64 ring-3, 5 = 128x64 ring-4, 6 = 128x128 single-buffered (3 workgroups/CU), 7 = 128x64 single-buffered,
- * 8 = 128x64 ring-2. */
+ * 8 = 128x64 ring-2, 9 = 256x256 ring-2 (8 waves), 10 = 256x128 ring-2. */
 int mode_set_option(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -76,6 +76,8 @@ typedef struct ModeGemmDesc {
   const int32_t* a_rows;          /* optional gather                                      */
   const int32_t* expert_offsets;  /* optional grouped mode: device int32[num_experts + 1]  */
   int32_t num_experts;
+  int32_t split_k;                /* bf16 only, epilogue NONE: K is cut into split_k slices; slice z writes its partial sums to   */
+  int64_t split_stride;           /* C + z*split_stride (elements).  0/1 = no split.  The consumer adds the slabs in slice order. */
 } ModeGemmDesc;
 int mode_gemm(const ModeGemmDesc* desc, void* stream);
 

@@ -27,7 +27,7 @@ class ModeGemmDesc(C.Structure):
     _fields_ = [("dtype", c_i32), ("epilogue", c_i32), ("out_dtype", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("A", c_vp), ("lda", c_i64), ("W", c_vp), ("ldw", c_i64), ("w_expert_stride", c_i64),
                 ("bias", c_vp), ("bias_expert_stride", c_i64), ("resid", c_vp), ("ldr", c_i64), ("C", c_vp), ("ldc", c_i64),
-                ("a_rows", c_vp), ("expert_offsets", c_vp), ("num_experts", c_i32)]
+                ("a_rows", c_vp), ("expert_offsets", c_vp), ("num_experts", c_i32), ("split_k", c_i32), ("split_stride", c_i64)]
 
 
 class ModeEmbedDesc(C.Structure):

@@ -39,6 +39,7 @@ struct GemmParams {
   void* C; long ldc;
   const int* a_rows; const int* offsets; int E;
   int M, N, K, m_tiles, n_tiles;
+  int split_k; long split_stride;     // split-K: blockIdx.y = K-slice, output slab = C + slice*split_stride elements
 };
 
 template <int N>
@@ -187,10 +188,11 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
   };
 
   // ---- main loop
-  const int nk = p.K / BK;
+  const int nk = p.K / BK / p.split_k;                            // K-tiles of this slice
+  const int kt0 = blockIdx.y * nk;
 #pragma unroll
   for (int s = 0; s < NS; ++s)
-    if (s < nk) stage(s, s);
+    if (s < nk) stage(s, kt0 + s);
   int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt landed for this wave's pieces; up to NS-1 younger tiles stay in flight across the barrier
@@ -205,61 +207,67 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
     if (kt + NS < nk) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                // every wave is done reading tile kt -> refill its slot
-      stage(slot, kt + NS);
+      stage(slot, kt0 + kt + NS);
     }
     slot = (slot + 1 == NS) ? 0 : slot + 1;
   }
 
-  // ---- epilogue: bias / SwiGLU in registers (lane owns row ..+(l&15), 4 consecutive columns) -> swizzled LDS tile -> coalesced stores
+  // ---- epilogue: bias / SwiGLU in registers (lane owns row ..+(l&15), 4 consecutive columns) -> swizzled LDS tile -> coalesced stores.
+  //      One pass per wave-row group (TM rows), so the staging tile (TM x NOUT) always fits the operand ring.
+  char* Cout = reinterpret_cast<char*>(p.C) + (long)blockIdx.y * p.split_stride * ESZ;
+  const int rows_valid = row_end - row0;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                    // all waves are done reading operand tiles
+#pragma unroll 1
+  for (int g = 0; g < WM; ++g) {
+    if (wm == g) {
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int ml = wm * TM + i * 16 + fr;
-    char* crow = smem + ml * CROW;
-    const int rsw = ml & CSWZ;
-    auto cpos = [&](int nl) { const int b = nl * ESZ; return crow + ((((b >> 4) ^ rsw) << 4) | (b & 15)); };
-    if constexpr (EPI == MODE_EPI_SWIGLU) {
+      for (int i = 0; i < FM; ++i) {
+        const int rl = i * 16 + fr;                                // row inside this pass
+        char* crow = smem + rl * CROW;
+        const int rsw = rl & CSWZ;
+        auto cpos = [&](int nl) { const int b = nl * ESZ; return crow + ((((b >> 4) ^ rsw) << 4) | (b & 15)); };
+        if constexpr (EPI == MODE_EPI_SWIGLU) {
 #pragma unroll
-      for (int j = 0; j < FN / 2; ++j) {
-        const int nl = wn * (TN / 2) + j * 16 + fq * 4;
-        const int n = min(n0 + nl, p.N - 4);
-        const float4 bp = *reinterpret_cast<const float4*>(bias + n);
-        const float4 bg = *reinterpret_cast<const float4*>(bias + p.N + n);
-        const f32x4 v = acc[i][j], g = acc[i][j + FN / 2];
-        const float o0 = (v[0] + bp.x) * silu_f(g[0] + bg.x), o1 = (v[1] + bp.y) * silu_f(g[1] + bg.y);
-        const float o2 = (v[2] + bp.z) * silu_f(g[2] + bg.z), o3 = (v[3] + bp.w) * silu_f(g[3] + bg.w);
-        if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(cpos(nl)) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
-        else *reinterpret_cast<float4*>(cpos(nl)) = make_float4(o0, o1, o2, o3);
-      }
-    } else {
+          for (int j = 0; j < FN / 2; ++j) {
+            const int nl = wn * (TN / 2) + j * 16 + fq * 4;
+            const int n = min(n0 + nl, p.N - 4);
+            const float4 bp = *reinterpret_cast<const float4*>(bias + n);
+            const float4 bg = *reinterpret_cast<const float4*>(bias + p.N + n);
+            const f32x4 v = acc[i][j], gt = acc[i][j + FN / 2];
+            const float o0 = (v[0] + bp.x) * silu_f(gt[0] + bg.x), o1 = (v[1] + bp.y) * silu_f(gt[1] + bg.y);
+            const float o2 = (v[2] + bp.z) * silu_f(gt[2] + bg.z), o3 = (v[3] + bp.w) * silu_f(gt[3] + bg.w);
+            if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(cpos(nl)) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+            else *reinterpret_cast<float4*>(cpos(nl)) = make_float4(o0, o1, o2, o3);
+          }
+        } else {
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int nl = wn * TN + j * 16 + fq * 4;
-        f32x4 v = acc[i][j];
-        if constexpr (EPI == MODE_EPI_BIAS || EPI == MODE_EPI_BIAS_GELU) {
-          const float4 b = *reinterpret_cast<const float4*>(bias + min(n0 + nl, p.N - 4));
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-          if constexpr (EPI == MODE_EPI_BIAS_GELU) {
-            v[0] = gelu_erf_f(v[0]); v[1] = gelu_erf_f(v[1]); v[2] = gelu_erf_f(v[2]); v[3] = gelu_erf_f(v[3]);
+          for (int j = 0; j < FN; ++j) {
+            const int nl = wn * TN + j * 16 + fq * 4;
+            f32x4 v = acc[i][j];
+            if constexpr (EPI == MODE_EPI_BIAS || EPI == MODE_EPI_BIAS_GELU) {
+              const float4 b = *reinterpret_cast<const float4*>(bias + min(n0 + nl, p.N - 4));
+              v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+              if constexpr (EPI == MODE_EPI_BIAS_GELU) {
+                v[0] = gelu_erf_f(v[0]); v[1] = gelu_erf_f(v[1]); v[2] = gelu_erf_f(v[2]); v[3] = gelu_erf_f(v[3]);
+              }
+            }
+            if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(cpos(nl)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            else *reinterpret_cast<float4*>(cpos(nl)) = make_float4(v[0], v[1], v[2], v[3]);
           }
         }
-        if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(cpos(nl)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        else *reinterpret_cast<float4*>(cpos(nl)) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  {
-    constexpr int EPC = 16 / ESZ;                                  // elements per chunk
-    const int rows_valid = row_end - row0;
-    for (int c = tid; c < BM * CPR; c += NT) {
-      const int ml = c / CPR, ch = c % CPR;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int EPC = 16 / ESZ;                                  // elements per 16-byte chunk
+    for (int c = tid; c < TM * CPR; c += NT) {
+      const int rl = c / CPR, ch = c % CPR;
+      const int ml = g * TM + rl;
       const int n = n0 + ch * EPC;
       if (ml >= rows_valid || n >= p.N) continue;
       const long m = row0 + ml;
-      uint4 v = *reinterpret_cast<const uint4*>(smem + ml * CROW + ((ch ^ (ml & CSWZ)) << 4));
+      uint4 v = *reinterpret_cast<const uint4*>(smem + rl * CROW + ((ch ^ (rl & CSWZ)) << 4));
       if constexpr (EPI == MODE_EPI_RESIDUAL && !OUT_BF16) {
         const float4 r = *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n);
         float4 f = *reinterpret_cast<float4*>(&v);
@@ -267,11 +275,15 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
         v = *reinterpret_cast<uint4*>(&f);
       }
       if constexpr (OUT_BF16) {
-        if (n + 8 <= p.N) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + m * p.ldc + n) = v;
-        else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + m * p.ldc + n) = make_uint2(v.x, v.y);   // N % 8 == 4 tail
+        if (n + 8 <= p.N) *reinterpret_cast<uint4*>(Cout + (m * p.ldc + n) * 2) = v;
+        else *reinterpret_cast<uint2*>(Cout + (m * p.ldc + n) * 2) = make_uint2(v.x, v.y);   // N % 8 == 4 tail
       } else {
-        *reinterpret_cast<uint4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = v;
+        *reinterpret_cast<uint4*>(Cout + (m * p.ldc + n) * 4) = v;
       }
+    }
+    if (g + 1 < WM) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
   }
 }
@@ -279,13 +291,13 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
 // ------------------------------------------------------------------------------------------------------------ host side
 // geometry ids (also the values of the "gemm_cfg" option; 0 = auto)
 enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x128_NS3 = 2, CFG_256x128_NS3 = 3, CFG_128x64_NS3 = 4, CFG_128x64_NS4 = 5,
-       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8 };
+       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10 };
 int g_gemm_cfg = CFG_AUTO;
 
 template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16>
 static int launch_cfg(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   constexpr int NOUT = (EPI == MODE_EPI_SWIGLU) ? BN / 2 : BN;
-  constexpr size_t RING = (size_t)NS * (BM + BN) * BK * 2, OUTT = (size_t)BM * NOUT * (OUT_BF16 ? 2 : 4);
+  constexpr size_t RING = (size_t)NS * (BM + BN) * BK * 2, OUTT = (size_t)(BM / WM) * NOUT * (OUT_BF16 ? 2 : 4);
   constexpr size_t LDS = RING > OUTT ? RING : OUTT;
   p.n_tiles = (d->N + NOUT - 1) / NOUT;
   p.m_tiles = (d->M + BM - 1) / BM + (d->expert_offsets ? d->num_experts : 0);
@@ -296,7 +308,7 @@ static int launch_cfg(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles), dim3(WM * WN * 64), LDS, s, p);
+  hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles, p.split_k), dim3(WM * WN * 64), LDS, s, p);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
@@ -312,6 +324,8 @@ static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipSt
     case CFG_128x128_NS1: return launch_cfg<128, 128, 2, 2, 1, EPI, OUT_BF16>(p, d, s);
     case CFG_128x64_NS1: return launch_cfg<128, 64, 2, 2, 1, EPI, OUT_BF16>(p, d, s);
     case CFG_128x64_NS2: return launch_cfg<128, 64, 2, 2, 2, EPI, OUT_BF16>(p, d, s);
+    case CFG_256x256_NS2: return launch_cfg<256, 256, 2, 4, 2, EPI, OUT_BF16>(p, d, s);
+    case CFG_256x128_NS2: return launch_cfg<256, 128, 4, 2, 2, EPI, OUT_BF16>(p, d, s);
     default: return MODE_ERR_BAD_ARG;
   }
 }
@@ -344,6 +358,9 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.a_rows = d->a_rows; p.offsets = d->expert_offsets; p.E = d->num_experts;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.m_tiles = p.n_tiles = 0;
+  p.split_k = d->split_k > 1 ? d->split_k : 1; p.split_stride = d->split_stride;
+  if (d->K % (BK * p.split_k) != 0) return MODE_ERR_UNSUPPORTED;
+  if (p.split_k > 1 && d->epilogue != MODE_EPI_NONE) return MODE_ERR_UNSUPPORTED;
   const int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d);
   const bool ob = d->out_dtype == MODE_BF16;
 #define MODE_CASE(E) \
