@@ -78,7 +78,10 @@ typedef struct ModeGemmDesc {
   int32_t num_experts;
   int32_t split_k;                /* bf16 only, epilogue NONE: K is cut into split_k slices; slice z writes its partial sums to   */
   int64_t split_stride;           /* C + z*split_stride (elements).  0/1 = no split.  The consumer adds the slabs in slice order. */
+  int32_t flags;                  /* MODE_GEMM_SKINNY_OK: fp32, M <= 16 may use the weight-streaming GEMV kernel (wave-tree reduction
+                                     instead of the MFMA k-ordered chain: same fp32 accuracy, different rounding)                   */
 } ModeGemmDesc;
+#define MODE_GEMM_SKINNY_OK 1
 int mode_gemm(const ModeGemmDesc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -128,11 +131,12 @@ int mode_moe_dispatch_meta(const int32_t* idx, const float* w, int R, int tokens
 /* ------------------------------------------------------------------------------------------------------------------
  * mode_moe_combine_norm_fwd — x_next[t] = u[t] + sum_j posw[t,j] * Y[pos[t,j]]  (ascending expert order; the residual is
  * the NORMALISED stream u, modedit.py:539/595), then optionally the next block's  h = RMSNorm(x_next; g) + cond
- * (modedit.py:532).  u fp32 [N,D]; Y [N*k, D] (y_dtype); writes x_next fp32 (may alias u) and h (lp dtype; may be NULL).
+ * (modedit.py:532).  u fp32 [N,D]; Y [N*k, D] (y_dtype), optionally y_splits split-K slabs y_split_stride elements apart that are
+ * added in slice order; writes x_next fp32 (may alias u) and h (lp dtype; may be NULL).
  * ------------------------------------------------------------------------------------------------------------------ */
-int mode_moe_combine_norm_fwd(const float* u, const void* Y, int y_dtype, const int32_t* pos, const float* posw,
-                              int N, int D, int k, const float* g, const float* cond, int rows_per_cond, float eps,
-                              float* x_next, void* h, int h_dtype, void* stream);
+int mode_moe_combine_norm_fwd(const float* u, const void* Y, int y_dtype, int y_splits, int64_t y_split_stride,
+                              const int32_t* pos, const float* posw, int N, int D, int k, const float* g, const float* cond,
+                              int rows_per_cond, float eps, float* x_next, void* h, int h_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * mode_embed_tokens_fwd — builds the input sequence and the first block's conditioned norm in one pass:
@@ -167,7 +171,7 @@ int mode_embed_tokens_fwd(const ModeEmbedDesc* d, void* stream);
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct ModeHeadDesc {
   int32_t B, T, D, A_len, A_dim, k;
-  const float* u; const void* Y; int32_t y_dtype;
+  const float* u; const void* Y; int32_t y_dtype; int32_t y_splits; int64_t y_split_stride;
   const int32_t* pos; const float* posw;
   const float* g; float eps;
   const float* w_out; const float* b_out;     /* [A_dim, D], [A_dim] */

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("MODE_HIP_LIB", os.path.join(_HERE, "libmode_hip.so"))
 MODE_BF16, MODE_F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3, 4
 ABI_VERSION = 1
+GEMM_SKINNY_OK = 1
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -27,7 +28,7 @@ class ModeGemmDesc(C.Structure):
     _fields_ = [("dtype", c_i32), ("epilogue", c_i32), ("out_dtype", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("A", c_vp), ("lda", c_i64), ("W", c_vp), ("ldw", c_i64), ("w_expert_stride", c_i64),
                 ("bias", c_vp), ("bias_expert_stride", c_i64), ("resid", c_vp), ("ldr", c_i64), ("C", c_vp), ("ldc", c_i64),
-                ("a_rows", c_vp), ("expert_offsets", c_vp), ("num_experts", c_i32), ("split_k", c_i32), ("split_stride", c_i64)]
+                ("a_rows", c_vp), ("expert_offsets", c_vp), ("num_experts", c_i32), ("split_k", c_i32), ("split_stride", c_i64), ("flags", c_i32)]
 
 
 class ModeEmbedDesc(C.Structure):
@@ -39,7 +40,7 @@ class ModeEmbedDesc(C.Structure):
 
 class ModeHeadDesc(C.Structure):
     _fields_ = [("B", c_i32), ("T", c_i32), ("D", c_i32), ("A_len", c_i32), ("A_dim", c_i32), ("k", c_i32),
-                ("u", c_vp), ("Y", c_vp), ("y_dtype", c_i32), ("pos", c_vp), ("posw", c_vp), ("g", c_vp), ("eps", c_f32),
+                ("u", c_vp), ("Y", c_vp), ("y_dtype", c_i32), ("y_splits", c_i32), ("y_split_stride", c_i64), ("pos", c_vp), ("posw", c_vp), ("g", c_vp), ("eps", c_f32),
                 ("w_out", c_vp), ("b_out", c_vp), ("x_a", c_vp), ("scal", c_vp), ("scal_stride", c_i64),
                 ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp)]
 
@@ -84,7 +85,7 @@ PROTOTYPES = {
     "mode_sigma_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, c_vp]),
     "mode_moe_route_topk_f32": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mode_moe_dispatch_meta": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "mode_moe_combine_norm_fwd": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp, C.c_int,
+    "mode_moe_combine_norm_fwd": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, c_i64, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp, C.c_int,
                                             c_f32, c_vp, c_vp, C.c_int, c_vp]),
     "mode_embed_tokens_fwd": (C.c_int, [P(ModeEmbedDesc), c_vp]),
     "mode_head_ddim_fwd": (C.c_int, [P(ModeHeadDesc), c_vp]),

@@ -24,6 +24,20 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
   const bool tv = fr < T;
   const uint16_t* rowp = qkv + ((long)b * T + (tv ? fr : 0)) * ld + h * HD + fq * 8;
 
+  // ---- V^T fragments first: 4 keys x 1 dim per d-block, requested before anything else so the global latency hides under QK^T/softmax
+  const uint16_t* vbase = qkv + (long)b * T * ld + 2L * D + h * HD;
+  uint32_t vv[2 * NKS][2];
+#pragma unroll
+  for (int db = 0; db < 2 * NKS; ++db) {
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = fq * 4 + j;
+      v[j] = (key < T && db * 16 < HD) ? (uint32_t)vbase[(long)key * ld + db * 16 + fr] : 0u;
+    }
+    vv[db][0] = v[0] | (v[1] << 16); vv[db][1] = v[2] | (v[3] << 16);
+  }
+
   // ---- load q / k fragments: token row fr, dims ks*32 + fq*8 + [0,8)
   float qf[NKS][8], kf[NKS][8];
   float qss = 0.f, kss = 0.f;
@@ -88,22 +102,14 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
   const bf16x8 pfrag = *reinterpret_cast<bf16x8*>(&tp);          // B operand: slots 0..3 = keys fq*4+r, slots 4..7 = 0
 
   // ---- O^T[d][query] = sum_key V[key][d] P[query][key]; A operand = V^T fragment: row d = db*16 + fr, slots j<4 = keys fq*4+j
-  const uint16_t* vbase = qkv + (long)b * T * ld + 2L * D + h * HD;
   uint16_t* yrow = y + ((long)b * T + fr) * D + h * HD + fq * 4;
 #pragma unroll
   for (int db = 0; db < 2 * NKS; ++db) {
-    if (db * 16 >= HD) break;
-    uint32_t v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int key = fq * 4 + j;
-      v[j] = (key < T) ? (uint32_t)vbase[(long)key * ld + db * 16 + fr] : 0u;
-    }
-    uint4 tvv = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), 0u, 0u);
+    uint4 tvv = make_uint4(vv[db][0], vv[db][1], 0u, 0u);
     const bf16x8 vfrag = *reinterpret_cast<bf16x8*>(&tvv);
     f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
     o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag, o, 0, 0, 0);     // D[row = d_local][col = query]
-    if (tv) {
+    if (tv && db * 16 < HD) {
       uint2 pk; pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
       *reinterpret_cast<uint2*>(yrow + db * 16) = pk;                           // y[b, query=fr, h*HD + db*16 + fq*4 + r]
     }

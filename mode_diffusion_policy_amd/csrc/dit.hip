@@ -34,7 +34,7 @@ static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
   w.qkv = take(N * 3 * D * esz);
   w.y = take(N * D * esz);
   w.hbuf = take(NK * 4 * D * esz);
-  w.ybuf = take(NK * D * 4);
+  w.ybuf = take(NK * D * 4);        // expert outputs (compute dtype; sized for fp32)
   w.meta = take((size_t)d.L * ml.total_words * 4);
   const size_t Rr = R > 0 ? R : 1;
   w.e1 = take(Rr * D * 4);
@@ -163,11 +163,11 @@ extern "C" int mode_dit_route(const ModeDims* dims, const ModeModelWeights* w, c
   for (int l = 0; l < dims->L; ++l) {
     const ModeLayerWeights& lw = w->layers[l];
     ModeGemmDesc g = gemm_desc(MODE_F32, MODE_EPI_BIAS_GELU, MODE_F32, R, 2 * D, D, cond, D, lw.r_w0, D, hid, 2 * D);
-    g.bias = lw.r_b0;
+    g.bias = lw.r_b0; g.flags = MODE_GEMM_SKINNY_OK;       // R <= 16 distinct sigma rows (sampler): stream the router weights once
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
     g = gemm_desc(MODE_F32, MODE_EPI_BIAS, MODE_F32, R, E, 2 * D, hid, 2 * D, lw.r_w3, 2 * D, logits, E);
-    g.bias = lw.r_b3;
+    g.bias = lw.r_b3; g.flags = MODE_GEMM_SKINNY_OK;
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
     rc = mode_moe_route_topk_f32(logits, R, E, k, dims->router_normalize, shifted ? shifted + (long)l * R * E : nullptr,
@@ -192,7 +192,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
   char* ws = (char*)workspace;
   float* x = (float*)(ws + L.x);
   void* h = ws + L.h; void* qkv = ws + L.qkv; void* yat = ws + L.y; void* hbuf = ws + L.hbuf;
-  float* ybuf = (float*)(ws + L.ybuf);
+  void* ybuf = ws + L.ybuf;
   ModeMetaLayout ml;
   mode_moe_meta_layout(N, d.E, d.k, &ml);
   const int cond_rpc = T;   // one conditioning row per sample
@@ -235,21 +235,21 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     g.a_rows = meta + ml.perm; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
-    g = gemm_desc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 4 * D, hbuf, 4 * D, lw.w2, 4 * D, ybuf, D);
+    g = gemm_desc(dt, MODE_EPI_NONE, dt, NK, D, 4 * D, hbuf, 4 * D, lw.w2, 4 * D, ybuf, D);   // bf16 Y like the reference's autocast Linear
     g.w_expert_stride = 4L * D * D;
     g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
     if (l + 1 < d.L) {
       // weighted combine + residual (from the normalised stream) + next block's ln_1 + c
-      rc = mode_moe_combine_norm_fwd(x, ybuf, MODE_F32, meta + ml.pos, reinterpret_cast<const float*>(meta + ml.posw), N, D, d.k,
+      rc = mode_moe_combine_norm_fwd(x, ybuf, dt, 1, 0, meta + ml.pos, reinterpret_cast<const float*>(meta + ml.posw), N, D, d.k,
                                      w->layers[l + 1].ln1_g, a->cond, rpc, d.eps, x, h, dt, stream);
       if (rc) return rc;
     } else {
       ModeHeadDesc hd;
       memset(&hd, 0, sizeof(hd));
       hd.B = B; hd.T = T; hd.D = D; hd.A_len = d.A_len; hd.A_dim = d.A_dim; hd.k = d.k;
-      hd.u = x; hd.Y = ybuf; hd.y_dtype = MODE_F32; hd.pos = meta + ml.pos; hd.posw = reinterpret_cast<const float*>(meta + ml.posw);
+      hd.u = x; hd.Y = ybuf; hd.y_dtype = dt; hd.y_splits = 1; hd.y_split_stride = 0; hd.pos = meta + ml.pos; hd.posw = reinterpret_cast<const float*>(meta + ml.posw);
       hd.g = w->ln_g; hd.eps = d.eps; hd.w_out = w->w_out; hd.b_out = w->b_out;
       hd.x_a = a->actions; hd.scal = a->scal; hd.scal_stride = a->scal_stride;
       hd.F = a->F; hd.denoised = a->denoised; hd.x_next = a->x_next;

@@ -213,17 +213,19 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
   }
 
   // ---- epilogue: bias / SwiGLU in registers (lane owns row ..+(l&15), 4 consecutive columns) -> swizzled LDS tile -> coalesced stores.
-  //      One pass per wave-row group (TM rows), so the staging tile (TM x NOUT) always fits the operand ring.
+  //      One pass when the whole output tile fits the operand ring, else one pass per wave-row group (TM rows).
   char* Cout = reinterpret_cast<char*>(p.C) + (long)blockIdx.y * p.split_stride * ESZ;
   const int rows_valid = row_end - row0;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                    // all waves are done reading operand tiles
+  constexpr int EPASS = (BM * CROW <= NS * STAGE_BYTES) ? 1 : WM;   // epilogue passes
+  constexpr int RP = BM / EPASS;                                   // rows per pass
 #pragma unroll 1
-  for (int g = 0; g < WM; ++g) {
-    if (wm == g) {
+  for (int g = 0; g < EPASS; ++g) {
+    if (EPASS == 1 || wm == g) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const int rl = i * 16 + fr;                                // row inside this pass
+        const int rl = (EPASS == 1 ? wm * TM : 0) + i * 16 + fr;   // row inside this pass
         char* crow = smem + rl * CROW;
         const int rsw = rl & CSWZ;
         auto cpos = [&](int nl) { const int b = nl * ESZ; return crow + ((((b >> 4) ^ rsw) << 4) | (b & 15)); };
@@ -261,9 +263,9 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     constexpr int EPC = 16 / ESZ;                                  // elements per 16-byte chunk
-    for (int c = tid; c < TM * CPR; c += NT) {
+    for (int c = tid; c < RP * CPR; c += NT) {
       const int rl = c / CPR, ch = c % CPR;
-      const int ml = g * TM + rl;
+      const int ml = g * RP + rl;
       const int n = n0 + ch * EPC;
       if (ml >= rows_valid || n >= p.N) continue;
       const long m = row0 + ml;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
         *reinterpret_cast<uint4*>(Cout + (m * p.ldc + n) * 4) = v;
       }
     }
-    if (g + 1 < WM) {
+    if (g + 1 < EPASS) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -298,7 +300,7 @@ template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16>
 static int launch_cfg(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   constexpr int NOUT = (EPI == MODE_EPI_SWIGLU) ? BN / 2 : BN;
   constexpr size_t RING = (size_t)NS * (BM + BN) * BK * 2, OUTT = (size_t)(BM / WM) * NOUT * (OUT_BF16 ? 2 : 4);
-  constexpr size_t LDS = RING > OUTT ? RING : OUTT;
+  constexpr size_t LDS = RING > OUTT ? RING : OUTT;   // whole tile in one pass when it fits the ring, else TM rows per pass
   p.n_tiles = (d->N + NOUT - 1) / NOUT;
   p.m_tiles = (d->M + BM - 1) / BM + (d->expert_offsets ? d->num_experts : 0);
   auto kern = gemm_bf16_kernel<BM, BN, WM, WN, NS, EPI, OUT_BF16>;

@@ -158,6 +158,56 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
   }
 }
 
+// ---- skinny path: M <= 16 rows (the noise-conditioned router on the sampler's distinct sigma rows, sigma_linear on R rows).
+// HBM-bound weight stream: one wave per output feature reads its weight row once (float4 per lane, coalesced) and reuses it
+// for all R activation rows (L1/L2-resident), fixed-order per-lane partial sums + xor-butterfly -> deterministic fp32.
+template <int EPI>
+__global__ __launch_bounds__(256) void linear_f32_skinny_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ W, long ldw,
+                                                                 const float* __restrict__ bias, float* __restrict__ Y, long ldy, int R,
+                                                                 int N, int K) {
+  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* w = W + (long)n * ldw;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 wv = *reinterpret_cast<const float4*>(w + k);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r < R) {
+        const float4 xv = *reinterpret_cast<const float4*>(X + (long)r * ldx + k);
+        acc[r] = fmaf(xv.x, wv.x, acc[r]); acc[r] = fmaf(xv.y, wv.y, acc[r]);
+        acc[r] = fmaf(xv.z, wv.z, acc[r]); acc[r] = fmaf(xv.w, wv.w, acc[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (r < R) {
+      float v = wave_sum(acc[r]);
+      if (lane == 0) {
+        if constexpr (EPI == MODE_EPI_BIAS || EPI == MODE_EPI_BIAS_GELU) v += bias[n];
+        if constexpr (EPI == MODE_EPI_BIAS_GELU) v = gelu_erf_f(v);
+        Y[(long)r * ldy + n] = v;
+      }
+    }
+  }
+}
+
+static int launch_skinny(const ModeGemmDesc* d, hipStream_t s) {
+  const dim3 grid((d->N + 3) / 4), blk(256);
+  const float* X = (const float*)d->A; const float* W = (const float*)d->W; float* Y = (float*)d->C;
+  switch (d->epilogue) {
+    case MODE_EPI_NONE: hipLaunchKernelGGL(linear_f32_skinny_kernel<MODE_EPI_NONE>, grid, blk, 0, s, X, d->lda, W, d->ldw, d->bias, Y, d->ldc, d->M, d->N, d->K); break;
+    case MODE_EPI_BIAS: hipLaunchKernelGGL(linear_f32_skinny_kernel<MODE_EPI_BIAS>, grid, blk, 0, s, X, d->lda, W, d->ldw, d->bias, Y, d->ldc, d->M, d->N, d->K); break;
+    case MODE_EPI_BIAS_GELU: hipLaunchKernelGGL(linear_f32_skinny_kernel<MODE_EPI_BIAS_GELU>, grid, blk, 0, s, X, d->lda, W, d->ldw, d->bias, Y, d->ldc, d->M, d->N, d->K); break;
+    default: return MODE_ERR_BAD_ARG;
+  }
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
 template <int EPI, bool OUT_BF16>
 static int launch_f32(const GemmF32Params& p, int nblk, bool vec, hipStream_t s) {
   if (vec) hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, true>), dim3(nblk), dim3(FNT), 0, s, p);
@@ -172,6 +222,10 @@ int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s) {
     return MODE_ERR_BAD_ARG;
   if (d->epilogue == MODE_EPI_RESIDUAL && !d->resid) return MODE_ERR_BAD_ARG;
   if (d->M <= 0) return MODE_OK;
+  if ((d->flags & MODE_GEMM_SKINNY_OK) && d->M <= 16 && !d->a_rows && !d->expert_offsets && d->out_dtype == MODE_F32 && d->K % 4 == 0 && d->lda % 4 == 0 && d->ldw % 4 == 0 &&
+      (d->epilogue == MODE_EPI_NONE || d->epilogue == MODE_EPI_BIAS || d->epilogue == MODE_EPI_BIAS_GELU) &&
+      (((uintptr_t)d->A | (uintptr_t)d->W) % 16 == 0))
+    return launch_skinny(d, s);
   GemmF32Params p;
   p.A = (const float*)d->A; p.lda = d->lda;
   p.W = (const float*)d->W; p.ldw = d->ldw; p.w_estride = d->w_expert_stride;

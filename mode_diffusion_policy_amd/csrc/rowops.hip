@@ -11,12 +11,24 @@ namespace mode {
 
 constexpr int ROWS_PER_BLOCK = 4;   // 4 waves
 
+// Visit the float4 chunks of one row owned by this lane: d = lane*4 + c*256.  NCH > 0 (D == 256*NCH) fully unrolls, so every
+// global load of the row is in flight before the first use; NCH == 0 is the generic (any D % 4 == 0) loop.
+template <int NCH, typename F>
+__device__ __forceinline__ void for_chunks(int D, int lane, F&& f) {
+  if constexpr (NCH > 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) f(lane * 4 + c * 256);
+  } else {
+    for (int d = lane * 4; d < D; d += 256) f(d);
+  }
+}
+
 // normalise the cached row: y = v / max(sqrt(ssq) * D^-1/2, eps) * g (+ cond); write fp32 and/or low-precision copies
-template <bool LP_BF16>
+template <bool LP_BF16, int NCH>
 __device__ __forceinline__ void norm_store(const float* row, int D, float ssq, const float* g, const float* cond, float eps,
                                            float* y_f32, void* y_lp, int lane) {
   const float nrm = fmaxf(sqrtf(ssq) * rsqrtf((float)D), eps);
-  for (int d = lane * 4; d < D; d += 256) {
+  for_chunks<NCH>(D, lane, [&](int d) {
     const float4 v = *reinterpret_cast<const float4*>(row + d);
     const float4 gg = *reinterpret_cast<const float4*>(g + d);
     float4 o = make_float4(v.x / nrm * gg.x, v.y / nrm * gg.y, v.z / nrm * gg.z, v.w / nrm * gg.w);
@@ -33,7 +45,7 @@ __device__ __forceinline__ void norm_store(const float* row, int D, float ssq, c
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(y_lp) + d) = o;
       }
     }
-  }
+  });
 }
 
 __device__ __forceinline__ float4 load_y4(const void* Y, bool y_bf16, long off) {
@@ -46,7 +58,7 @@ __device__ __forceinline__ float4 load_y4(const void* Y, bool y_bf16, long off) 
 }
 
 // ------------------------------------------------------------------------------------------------------------ rmsnorm
-template <bool LP_BF16>
+template <bool LP_BF16, int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_cond_kernel(const float* x, const float* __restrict__ g,
                                                            const float* __restrict__ cond, int rows, int D, int rpc, float eps,
                                                            float* y_f32, void* y_lp) {
@@ -57,22 +69,23 @@ __global__ __launch_bounds__(256) void rmsnorm_cond_kernel(const float* x, const
   float* cache = reinterpret_cast<float*>(smem) + (size_t)wave * D;
   const float* xr = x + (long)row * D;
   float ssq = 0.f;
-  for (int d = lane * 4; d < D; d += 256) {
+  for_chunks<NCH>(D, lane, [&](int d) {
     const float4 v = *reinterpret_cast<const float4*>(xr + d);
     *reinterpret_cast<float4*>(cache + d) = v;
     ssq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-  }
+  });
   ssq = wave_sum(ssq);
-  norm_store<LP_BF16>(cache, D, ssq, g, cond ? cond + (long)(row / rpc) * D : nullptr, eps,
+  norm_store<LP_BF16, NCH>(cache, D, ssq, g, cond ? cond + (long)(row / rpc) * D : nullptr, eps,
                       y_f32 ? y_f32 + (long)row * D : nullptr,
                       y_lp ? (void*)((char*)y_lp + (long)row * D * (LP_BF16 ? 2 : 4)) : nullptr, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------- combine + norm
-template <bool LP_BF16>
-__global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const void* __restrict__ Y, int y_bf16,
-                                                           const int* __restrict__ pos, const float* __restrict__ posw, int N,
-                                                           int D, int k, const float* __restrict__ g,
+template <bool LP_BF16, int NCH, int KK>   // KK = top_k when known at compile time (1, 2), else 0
+__global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const void* __restrict__ Y, int y_bf16, int y_splits,
+                                                           long y_split_stride, const int* __restrict__ pos,
+                                                           const float* __restrict__ posw, int N, int D, int k,
+                                                           const float* __restrict__ g,
                                                            const float* __restrict__ cond, int rpc, float eps, float* x_next,
                                                            void* h) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,26 +94,38 @@ __global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const
   if (row >= N) return;
   float* cache = reinterpret_cast<float*>(smem) + (size_t)wave * D;
   const float* ur = u + (long)row * D;
+  const int kk = KK ? KK : k;
+  long prow[KK ? KK : 8]; float pw[KK ? KK : 8];
+#pragma unroll
+  for (int j = 0; j < (KK ? KK : 8); ++j) {
+    if (j < kk) { prow[j] = (long)pos[(long)row * kk + j] * D; pw[j] = posw[(long)row * kk + j]; }
+  }
   float ssq = 0.f;
-  for (int d = lane * 4; d < D; d += 256) {
+  for_chunks<NCH>(D, lane, [&](int d) {
     const float4 uu = *reinterpret_cast<const float4*>(ur + d);
     float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = 0; j < k; ++j) {                       // ascending expert id: next += w * expert(x)   (modedit.py:566)
-      const long p = pos[(long)row * k + j];
-      const float w = posw[(long)row * k + j];
-      const float4 y = load_y4(Y, y_bf16 != 0, p * D + d);
-      nx.x = __fadd_rn(nx.x, __fmul_rn(w, y.x)); nx.y = __fadd_rn(nx.y, __fmul_rn(w, y.y));
-      nx.z = __fadd_rn(nx.z, __fmul_rn(w, y.z)); nx.w = __fadd_rn(nx.w, __fmul_rn(w, y.w));
+#pragma unroll
+    for (int j = 0; j < (KK ? KK : 8); ++j) {           // ascending expert id: next += w * expert(x)   (modedit.py:566)
+      if (j < kk) {
+        float4 y = load_y4(Y, y_bf16 != 0, prow[j] + d);
+        for (int z = 1; z < y_splits; ++z) {            // split-K slabs of the down-projection, added in slice order
+          const float4 t = load_y4(Y, y_bf16 != 0, (long)z * y_split_stride + prow[j] + d);
+          y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+        }
+        const float w = pw[j];
+        nx.x = __fadd_rn(nx.x, __fmul_rn(w, y.x)); nx.y = __fadd_rn(nx.y, __fmul_rn(w, y.y));
+        nx.z = __fadd_rn(nx.z, __fmul_rn(w, y.z)); nx.w = __fadd_rn(nx.w, __fmul_rn(w, y.w));
+      }
     }
     const float4 v = make_float4(uu.x + nx.x, uu.y + nx.y, uu.z + nx.z, uu.w + nx.w);   // x + next_states (:595)
     *reinterpret_cast<float4*>(cache + d) = v;
     if (x_next) *reinterpret_cast<float4*>(x_next + (long)row * D + d) = v;
     ssq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-  }
+  });
   if (!h) return;
   ssq = wave_sum(ssq);
-  norm_store<LP_BF16>(cache, D, ssq, g, cond ? cond + (long)(row / rpc) * D : nullptr, eps, nullptr,
-                      (void*)((char*)h + (long)row * D * (LP_BF16 ? 2 : 4)), lane);
+  norm_store<LP_BF16, NCH>(cache, D, ssq, g, cond ? cond + (long)(row / rpc) * D : nullptr, eps, nullptr,
+                           (void*)((char*)h + (long)row * D * (LP_BF16 ? 2 : 4)), lane);
 }
 
 // --------------------------------------------------------------------------------------------------------------- embed
@@ -153,7 +178,7 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const ModeEmbedDesc e
     ssq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
   ssq = wave_sum(ssq);
-  norm_store<LP_BF16>(cache, D, ssq, e.g, e.cond ? e.cond + (long)b * e.cond_row_stride : nullptr, e.eps, nullptr,
+  norm_store<LP_BF16, 0>(cache, D, ssq, e.g, e.cond ? e.cond + (long)b * e.cond_row_stride : nullptr, e.eps, nullptr,
                       (void*)((char*)e.h + (long)row * D * (LP_BF16 ? 2 : 4)), lane);
 }
 
@@ -175,7 +200,11 @@ __global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
     for (int j = 0; j < h.k; ++j) {
       const long p = h.pos[row * h.k + j];
       const float w = h.posw[row * h.k + j];
-      const float4 y = load_y4(h.Y, ybf, p * D + d);
+      float4 y = load_y4(h.Y, ybf, p * D + d);
+      for (int z = 1; z < h.y_splits; ++z) {
+        const float4 t = load_y4(h.Y, ybf, (long)z * h.y_split_stride + p * D + d);
+        y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+      }
       nx.x = __fadd_rn(nx.x, __fmul_rn(w, y.x)); nx.y = __fadd_rn(nx.y, __fmul_rn(w, y.y));
       nx.z = __fadd_rn(nx.z, __fmul_rn(w, y.z)); nx.w = __fadd_rn(nx.w, __fmul_rn(w, y.w));
     }
@@ -241,6 +270,17 @@ __global__ void sigma_embed_kernel(const float* sigma, const float* w, const flo
 
 using namespace mode;
 
+template <bool LP>
+static void launch_rmsnorm(dim3 grid, size_t lds, hipStream_t st, const float* x, const float* g, const float* cond, int rows, int D, int rpc,
+                           float eps, float* y_f32, void* y_lp) {
+  switch (D) {
+    case 256: hipLaunchKernelGGL((rmsnorm_cond_kernel<LP, 1>), grid, dim3(256), lds, st, x, g, cond, rows, D, rpc, eps, y_f32, y_lp); break;
+    case 512: hipLaunchKernelGGL((rmsnorm_cond_kernel<LP, 2>), grid, dim3(256), lds, st, x, g, cond, rows, D, rpc, eps, y_f32, y_lp); break;
+    case 1024: hipLaunchKernelGGL((rmsnorm_cond_kernel<LP, 4>), grid, dim3(256), lds, st, x, g, cond, rows, D, rpc, eps, y_f32, y_lp); break;
+    default: hipLaunchKernelGGL((rmsnorm_cond_kernel<LP, 0>), grid, dim3(256), lds, st, x, g, cond, rows, D, rpc, eps, y_f32, y_lp);
+  }
+}
+
 extern "C" int mode_rmsnorm_cond_fwd(const float* x, const float* g, const float* cond, int rows, int D, int rows_per_cond,
                                      float eps, float* y_f32, void* y_lp, int lp_dtype, void* stream) {
   if (!x || !g || rows < 0 || D <= 0 || (D & 3)) return MODE_ERR_BAD_ARG;
@@ -248,28 +288,47 @@ extern "C" int mode_rmsnorm_cond_fwd(const float* x, const float* g, const float
   if (rows_per_cond <= 0) rows_per_cond = 1;
   const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   const size_t lds = (size_t)ROWS_PER_BLOCK * D * 4;
-  if (lp_dtype == MODE_BF16)
-    hipLaunchKernelGGL(rmsnorm_cond_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, x, g, cond, rows, D, rows_per_cond, eps, y_f32, y_lp);
-  else
-    hipLaunchKernelGGL(rmsnorm_cond_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, x, g, cond, rows, D, rows_per_cond, eps, y_f32, y_lp);
+  if (lp_dtype == MODE_BF16) launch_rmsnorm<true>(grid, lds, (hipStream_t)stream, x, g, cond, rows, D, rows_per_cond, eps, y_f32, y_lp);
+  else launch_rmsnorm<false>(grid, lds, (hipStream_t)stream, x, g, cond, rows, D, rows_per_cond, eps, y_f32, y_lp);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
 
-extern "C" int mode_moe_combine_norm_fwd(const float* u, const void* Y, int y_dtype, const int32_t* pos, const float* posw, int N,
-                                         int D, int k, const float* g, const float* cond, int rows_per_cond, float eps,
-                                         float* x_next, void* h, int h_dtype, void* stream) {
-  if (!u || !Y || !pos || !posw || N < 0 || D <= 0 || (D & 3) || k <= 0) return MODE_ERR_BAD_ARG;
+template <bool LP, int NCH>
+static void launch_combine_k(dim3 grid, size_t lds, hipStream_t st, const float* u, const void* Y, int ybf, int ys, long yss, const int* pos,
+                             const float* posw, int N, int D, int k, const float* g, const float* cond, int rpc, float eps, float* x_next,
+                             void* h) {
+  if (k == 2) hipLaunchKernelGGL((combine_norm_kernel<LP, NCH, 2>), grid, dim3(256), lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h);
+  else if (k == 1) hipLaunchKernelGGL((combine_norm_kernel<LP, NCH, 1>), grid, dim3(256), lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h);
+  else hipLaunchKernelGGL((combine_norm_kernel<LP, NCH, 0>), grid, dim3(256), lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h);
+}
+
+template <bool LP>
+static void launch_combine(dim3 grid, size_t lds, hipStream_t st, const float* u, const void* Y, int ybf, int ys, long yss, const int* pos,
+                           const float* posw, int N, int D, int k, const float* g, const float* cond, int rpc, float eps, float* x_next, void* h) {
+  switch (D) {
+    case 256: launch_combine_k<LP, 1>(grid, lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h); break;
+    case 512: launch_combine_k<LP, 2>(grid, lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h); break;
+    case 1024: launch_combine_k<LP, 4>(grid, lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h); break;
+    default: launch_combine_k<LP, 0>(grid, lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h);
+  }
+}
+
+extern "C" int mode_moe_combine_norm_fwd(const float* u, const void* Y, int y_dtype, int y_splits, int64_t y_split_stride, const int32_t* pos,
+                                         const float* posw, int N, int D, int k, const float* g, const float* cond, int rows_per_cond,
+                                         float eps, float* x_next, void* h, int h_dtype, void* stream) {
+  if (!u || !Y || !pos || !posw || N < 0 || D <= 0 || (D & 3) || k <= 0 || k > 8) return MODE_ERR_BAD_ARG;
   if (h && !g) return MODE_ERR_BAD_ARG;
   if (N == 0) return MODE_OK;
   if (rows_per_cond <= 0) rows_per_cond = 1;
+  if (y_splits < 1) y_splits = 1;
   const dim3 grid((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   const size_t lds = (size_t)ROWS_PER_BLOCK * D * 4;
   const int ybf = y_dtype == MODE_BF16;
   if (h_dtype == MODE_BF16)
-    hipLaunchKernelGGL(combine_norm_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, u, Y, ybf, pos, posw, N, D, k, g, cond, rows_per_cond, eps, x_next, h);
+    launch_combine<true>(grid, lds, (hipStream_t)stream, u, Y, ybf, y_splits, (long)y_split_stride, pos, posw, N, D, k, g, cond, rows_per_cond, eps, x_next, h);
   else
-    hipLaunchKernelGGL(combine_norm_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, u, Y, ybf, pos, posw, N, D, k, g, cond, rows_per_cond, eps, x_next, h);
+    launch_combine<false>(grid, lds, (hipStream_t)stream, u, Y, ybf, y_splits, (long)y_split_stride, pos, posw, N, D, k, g, cond, rows_per_cond, eps, x_next, h);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }

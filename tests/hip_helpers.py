@@ -21,7 +21,7 @@ def dt_of(t):
 
 
 def gemm(A, W, epilogue=L.EPI_NONE, bias=None, resid=None, out_dtype=None, n_out=None, a_rows=None, offsets=None, num_experts=0,
-         M=None, w_estride=0, b_estride=0):
+         M=None, w_estride=0, b_estride=0, flags=0):
     lib = L.load()
     out_dtype = out_dtype or A.dtype
     K = A.shape[-1]
@@ -32,7 +32,7 @@ def gemm(A, W, epilogue=L.EPI_NONE, bias=None, resid=None, out_dtype=None, n_out
     d = L.ModeGemmDesc(dtype=dt_of(A), epilogue=epilogue, out_dtype=L.MODE_BF16 if out_dtype == torch.bfloat16 else L.MODE_F32,
                        M=M, N=N, K=K, A=p(A), lda=A.stride(0), W=p(W), ldw=Wm.stride(0), w_expert_stride=w_estride,
                        bias=p(bias), bias_expert_stride=b_estride, resid=p(resid), ldr=(resid.stride(0) if resid is not None else 0),
-                       C=p(Cc), ldc=Cc.stride(0), a_rows=p(a_rows), expert_offsets=p(offsets), num_experts=num_experts)
+                       C=p(Cc), ldc=Cc.stride(0), a_rows=p(a_rows), expert_offsets=p(offsets), num_experts=num_experts, flags=flags)
     L.check(lib.mode_gemm(C.byref(d), stream()), "gemm")
     return Cc
 
@@ -81,6 +81,6 @@ def combine_norm(u, Y, pos, posw, k, g, cond, rows_per_cond, eps=1e-6, h_dtype=t
     N, D = u.shape
     xn = torch.empty_like(u)
     h = torch.empty(N, D, dtype=h_dtype, device=u.device)
-    L.check(lib.mode_moe_combine_norm_fwd(p(u), p(Y), dt_of(Y), p(pos), p(posw), N, D, k, p(g), p(cond), rows_per_cond, eps, p(xn), p(h),
+    L.check(lib.mode_moe_combine_norm_fwd(p(u), p(Y), dt_of(Y), 1, 0, p(pos), p(posw), N, D, k, p(g), p(cond), rows_per_cond, eps, p(xn), p(h),
                                           L.MODE_BF16 if h_dtype == torch.bfloat16 else L.MODE_F32, stream()), "combine_norm")
     return xn, h

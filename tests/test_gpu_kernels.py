@@ -157,7 +157,8 @@ def test_gemm_bf16_split_k(cfg, S):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(37, 4, 512, L.EPI_BIAS), (128, 512, 256, L.EPI_BIAS_GELU), (10, 2, 512, L.EPI_BIAS),
-                                       (256, 1024, 2048, L.EPI_NONE), (65, 130, 30, L.EPI_NONE), (16, 64, 7, L.EPI_NONE)])
+                                       (256, 1024, 2048, L.EPI_NONE), (65, 130, 30, L.EPI_NONE), (16, 64, 7, L.EPI_NONE),
+                                       (10, 2048, 1024, L.EPI_BIAS_GELU), (10, 4, 2048, L.EPI_BIAS), (1, 1024, 1024, L.EPI_NONE), (16, 6, 100, L.EPI_BIAS)])
 def test_gemm_f32(M, N, K, epi):
     A = rnd(M, K, seed=21); W = rnd(N, K, seed=22, scale=K ** -0.5); b = rnd(N, seed=23)
     ref = A @ W.t()
@@ -165,8 +166,9 @@ def test_gemm_f32(M, N, K, epi):
         ref = ref + b
     if epi == L.EPI_BIAS_GELU:
         ref = torch.nn.functional.gelu(ref)
-    out = H.gemm(A.to(dev()), W.to(dev()), epi, bias=b.to(dev()) if epi != L.EPI_NONE else None)
-    assert rel(out, ref) < 1e-5
+    for flags in (0, L.GEMM_SKINNY_OK):          # MFMA k-ordered chain, and the skinny weight-streaming GEMV (taken when M <= 16)
+        out = H.gemm(A.to(dev()), W.to(dev()), epi, bias=b.to(dev()) if epi != L.EPI_NONE else None, flags=flags)
+        assert rel(out, ref) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------------------ row kernels
