@@ -45,6 +45,23 @@ struct GemmParams {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ds_read_b128 the compiler does not track: the MFMA operands are requested with hand-counted lgkmcnt waits so the second k32 half's
+// LDS round trip stays in flight under the first half's MFMAs (hipcc's own scoreboard emitted lgkmcnt(0) before the first MFMA).
+template <int OFF>
+__device__ __forceinline__ void lds_read128(bf16x8& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int STRIDE, int CNT, int I = 0>
+__device__ __forceinline__ void lds_read_seq(bf16x8* dst, uint32_t addr) {
+  if constexpr (I < CNT) {
+    lds_read128<I * STRIDE>(dst[I], addr);
+    lds_read_seq<STRIDE, CNT, I + 1>(dst, addr);
+  }
+}
+
 // wait until at most `tiles` K-tiles (LOADS VMEM ops each) are still in flight for this wave
 template <int LOADS, int MAXT>
 __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
@@ -157,27 +174,20 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- fragment read offsets (bytes inside one operand tile); lane -> row (l&15), k-chunk (l>>4) [+4 for the 2nd k32 step]
+  // ---- fragment addressing: lane -> row (l&15), k-chunk (l>>4) [+4 for the 2nd k32 half]; fragment i/j = immediate offset i*16 rows
   const int fr = lane & 15, fq = lane >> 4;
-  int a_off[FM], b_off[FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) a_off[i] = (wm * TM + i * 16 + fr) * 128;
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    int br;
-    if constexpr (EPI == MODE_EPI_SWIGLU) br = (j < FN / 2) ? (wn * (TN / 2) + j * 16) : (BN / 2 + wn * (TN / 2) + (j - FN / 2) * 16);
-    else br = wn * TN + j * 16;
-    b_off[j] = A_BYTES + (br + fr) * 128;
-  }
   const int sw = fr & 7;                                          // row & 7 for every fragment row of this lane
   const int c0 = (fq ^ sw) * 16, c1 = ((fq + 4) ^ sw) * 16;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t a_base = lds0 + (wm * TM + fr) * 128;
+  constexpr int BJ = (EPI == MODE_EPI_SWIGLU) ? FN / 2 : FN;       // B fragments per contiguous run (value / gate runs for SwiGLU)
+  const uint32_t b_base = lds0 + A_BYTES + ((EPI == MODE_EPI_SWIGLU ? wn * (TN / 2) : wn * TN) + fr) * 128;
 
-  bf16x8 fa0[FM], fb0[FN], fa1[FM], fb1[FN];                     // double-buffered MFMA operands (software pipeline)
-  auto read_frags = [&](bf16x8(&fa)[FM], bf16x8(&fb)[FN], const char* T, int co) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(T + a_off[i] + co);
-#pragma unroll
-    for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(T + b_off[j] + co);
+  bf16x8 fa0[FM], fb0[FN], fa1[FM], fb1[FN];                     // both k32 halves of a K-step live in VGPRs
+  auto read_frags = [&](bf16x8* fa, bf16x8* fb, uint32_t slot_off, int co) {
+    lds_read_seq<2048, FM>(fa, a_base + slot_off + co);
+    lds_read_seq<2048, BJ>(fb, b_base + slot_off + co);
+    if constexpr (EPI == MODE_EPI_SWIGLU) lds_read_seq<2048, BJ>(fb + BJ, b_base + slot_off + co + (BN / 2) * 128);
   };
   auto mma = [&](const bf16x8(&fa)[FM], const bf16x8(&fb)[FN]) {
 #pragma unroll
@@ -190,33 +200,43 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
   // ---- main loop
   const int nk = p.K / BK / p.split_k;                            // K-tiles of this slice
   const int kt0 = blockIdx.y * nk;
+  constexpr int PRE = (NS == 1) ? 1 : NS - 1;                      // tiles in flight before the loop
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
+  for (int s = 0; s < PRE; ++s)
     if (s < nk) stage(s, kt0 + s);
   int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt landed for this wave's pieces; up to NS-1 younger tiles stay in flight across the barrier
-    wait_tiles_in_flight<LOADS, NS - 1>(min(NS - 1, nk - 1 - kt));
-    __builtin_amdgcn_s_barrier();                                  // tile kt visible to all waves
-    const char* T = smem + slot * STAGE_BYTES;
-    read_frags(fa0, fb0, T, c0);                                   // both k32 halves are requested up front: the second half's LDS
-    read_frags(fa1, fb1, T, c1);                                   // round trip hides under the first half's MFMAs
-    __builtin_amdgcn_sched_barrier(0);                             // keep all 2*(FM+FN) reads ahead of the MFMAs
-    mma(fa0, fb0);
-    mma(fa1, fb1);
-    if (kt + NS < nk) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                // every wave is done reading tile kt -> refill its slot
-      stage(slot, kt0 + kt + NS);
+    // tile kt landed for this wave's pieces; younger tiles stay in flight across the barrier
+    wait_tiles_in_flight<LOADS, (NS >= 2 ? NS - 2 : 0)>(min(NS - 2, nk - 1 - kt));
+    __builtin_amdgcn_s_barrier();                                  // tile kt visible to all waves; everyone is done with tile kt-1
+    if constexpr (NS >= 2) {
+      if (kt + NS - 1 < nk) stage((slot + NS - 1) % NS, kt0 + kt + NS - 1);   // refill the slot tile kt-1 just vacated
     }
-    slot = (slot + 1 == NS) ? 0 : slot + 1;
+    const uint32_t so = slot * STAGE_BYTES;
+    read_frags(fa0, fb0, so, c0);
+    read_frags(fa1, fb1, so, c1);
+    wait_lgkmcnt<FM + FN>();                                       // first half arrived, second half still in flight
+    __builtin_amdgcn_sched_barrier(0);
+    mma(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);                             // keep the first half's MFMAs above the second wait
+    wait_lgkmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    mma(fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NS == 1) {
+      if (kt + 1 < nk) {
+        __builtin_amdgcn_s_barrier();                              // single buffer: every wave is done reading before the refill
+        stage(0, kt0 + kt + 1);
+      }
+    } else {
+      slot = (slot + 1 == NS) ? 0 : slot + 1;
+    }
   }
 
   // ---- epilogue: bias / SwiGLU in registers (lane owns row ..+(l&15), 4 consecutive columns) -> swizzled LDS tile -> coalesced stores.
   //      One pass when the whole output tile fits the operand ring, else one pass per wave-row group (TM rows).
   char* Cout = reinterpret_cast<char*>(p.C) + (long)blockIdx.y * p.split_stride * ESZ;
   const int rows_valid = row_end - row0;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                    // all waves are done reading operand tiles
   constexpr int EPASS = (BM * CROW <= NS * STAGE_BYTES) ? 1 : WM;   // epilogue passes
   constexpr int RP = BM / EPASS;                                   // rows per pass

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--only", default="")
+    ap.add_argument("--splitk", type=int, default=1)
     a = ap.parse_args()
     lib = L.load()
     for o in a.opt:
@@ -38,13 +39,13 @@ def main():
     w1 = [torch.randn(E, 8 * D, D, device=dev).to(bf) * 0.03 for _ in range(nl)]; b1 = torch.randn(E, 8 * D, device=dev)
     w2 = [torch.randn(E, D, 4 * D, device=dev).to(bf) * 0.015 for _ in range(nl)]
     qkv = torch.empty(N, 3 * D, dtype=bf, device=dev); xr = torch.randn(N, D, device=dev); xo = torch.empty(N, D, device=dev)
-    Hb = torch.empty(NK, 4 * D, dtype=bf, device=dev); Y = torch.empty(NK, D, device=dev)
+    Hb = torch.empty(NK, 4 * D, dtype=bf, device=dev); Y = torch.empty(max(a.splitk, 1), NK, D, device=dev)
     hin = torch.randn(NK, 4 * D, device=dev).to(bf)
 
     def desc(**kw):
         base = dict(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=N, N=D, K=D, A=x.data_ptr(), lda=D, W=None, ldw=D,
                     w_expert_stride=0, bias=None, bias_expert_stride=0, resid=None, ldr=0, C=None, ldc=D, a_rows=None, expert_offsets=None,
-                    num_experts=0)
+                    num_experts=0, split_k=1, split_stride=0, flags=0)
         base.update(kw)
         return L.ModeGemmDesc(**base)
     shapes = {
@@ -56,7 +57,8 @@ def main():
                                                                    bias=b1.data_ptr(), bias_expert_stride=8 * D, C=Hb.data_ptr(), ldc=4 * D,
                                                                    a_rows=mp + 4 * ml.perm, expert_offsets=mp + 4 * ml.offsets, num_experts=E) for i in range(nl)], 2.0 * NK * D * 8 * D),
         "gemm2 grouped [3584x4096]x[2x1024x4096]": ([desc(out_dtype=L.MODE_F32, M=NK, N=D, K=4 * D, A=hin.data_ptr(), lda=4 * D, W=w2[i].data_ptr(), ldw=4 * D,
-                                                            w_expert_stride=4 * D * D, C=Y.data_ptr(), expert_offsets=mp + 4 * ml.offsets, num_experts=E) for i in range(nl)], 2.0 * NK * 4 * D * D),
+                                                            w_expert_stride=4 * D * D, C=Y.data_ptr(), expert_offsets=mp + 4 * ml.offsets, num_experts=E, split_k=a.splitk,
+                                                            split_stride=NK * D) for i in range(nl)], 2.0 * NK * 4 * D * D),
     }
     tot_us = 0.0
     for name, (ds, fl) in shapes.items():
