@@ -203,6 +203,27 @@ def main():
     sig_c2 = O.rand_log_logistic((16,), math_log(0.5), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(9))
     forward_fixture("F7_c2block", "c2block", 16, 300, sig_c2)
 
+    # ---- F9 constructor-flag variants the reference can actually run: T=13 without the noise token,
+    #      goal-conditioned routing, un-normalised router weights, B=1 (what the reference's rollouts use)
+    for tag, over, B in (("nonoise", dict(use_noise_token_as_input=False), 5), ("goalroute", dict(use_goal_in_routing=True), 5),
+                         ("nonorm", dict(router_normalize=False), 5), ("b1", dict(), 1)):
+        cfg = get_config("c1e4"); sd = make_state_dict(cfg, 220); inp = make_inputs(cfg, B, 221)
+        import dataclasses
+        ocfg = dataclasses.replace(cfg, **{k: v for k, v in over.items()})
+        m = _ref_model(modedit, cfg, sd, **over)
+        cap, hs = _hook_router(m)
+        sig = sig_c1[:B]
+        with torch.no_grad():
+            out = m({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], sig)
+        for h in hs:
+            h.remove()
+        o_out, aux = O.dit_forward(sd, ocfg, inp["state_images"], inp["actions"], inp["goals"], sig, return_aux=True)
+        assert torch.equal(torch.stack(cap["idx"]), torch.stack(aux.topk_idx)), tag
+        np.savez(os.path.join(OUT, f"F9_{tag}.npz"), cfg="c1e4", seed=220, B=B, sigma=sig.numpy(), out=out.numpy(),
+                 topk_idx=torch.stack(cap["idx"]).numpy(), margin=_margin(cap["probs"], cfg.top_k), **{k: np.array(v) for k, v in over.items()})
+        report[f"F9_{tag}"] = _rel(o_out, out)
+        report[f"F9_{tag}.margin"] = _margin(cap["probs"], cfg.top_k)
+
     # ---- F8 optimizer groups (mode_agent.py:365-384) — rule restated from the reference text (agent not importable)
     cfg = get_config("c1e4")
     m = _ref_model(modedit, cfg, make_state_dict(cfg, 210))

@@ -46,6 +46,19 @@ def test_forward_fixture(golden, name):
         assert rel(torch.stack(aux.block_out), g["block_out"]) < TOL
 
 
+@pytest.mark.parametrize("tag", ["nonoise", "goalroute", "nonorm", "b1"])
+def test_flag_variant_fixture(golden, tag):
+    """Constructor-flag variants the reference can run: T=13, goal-conditioned routing, raw router weights, B=1."""
+    import dataclasses
+    g = golden(f"F9_{tag}")
+    over = {k: bool(g[k]) for k in ("use_noise_token_as_input", "use_goal_in_routing", "router_normalize") if k in g.files}
+    cfg = dataclasses.replace(get_config("c1e4"), **over)
+    B = int(g["B"]); sd = make_state_dict(cfg, int(g["seed"])); inp = make_inputs(cfg, B, int(g["seed"]) + 1)
+    out, aux = O.dit_forward(sd, cfg, inp["state_images"], inp["actions"], inp["goals"], torch.from_numpy(g["sigma"]), return_aux=True)
+    assert np.array_equal(torch.stack(aux.topk_idx).numpy(), g["topk_idx"])
+    assert rel(out, g["out"]) < TOL
+
+
 @pytest.mark.parametrize("cfgname", ["c1", "c1e4"])
 def test_ddim_fixture(golden, cfgname):
     g = golden(f"F4_{cfgname}_ddim")
