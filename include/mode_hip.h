@@ -96,10 +96,17 @@ int mode_rmsnorm_cond_fwd(const float* x, const float* g, const float* cond, int
  * mode_attn_block_fwd — per (sample, head): qk-RMSNorm over head_dim (learned gains, eps), causal softmax(QK^T/sqrt(hd)) V.
  * Replaces Attention.forward minus the four Linears (modedit.py:125-127, 145-165; SDPA is_causal=True at :149).
  * qkv is the packed [B*T, 3*D] output of the fused QKV GEMM ([q | k | v] along columns); y is [B*T, D] (heads merged).
- * T <= 16 (the path's sequence is 14 tokens), head_dim % 16 == 0 and <= 128 for bf16.
+ * T <= 16 (the path's sequence is 14 tokens), head_dim % 16 == 0 and <= 128 for bf16.  p_drop > 0 (training only) drops
+ * probabilities after the softmax exactly where SDPA does.
  * ------------------------------------------------------------------------------------------------------------------ */
 int mode_attn_block_fwd(const void* qkv, const float* q_gain, const float* k_gain, void* y, int dtype,
-                        int B, int T, int H, int head_dim, float eps, void* stream);
+                        int B, int T, int H, int head_dim, float eps, uint32_t seed, float p_drop, void* stream);
+/* backward of the above (training): dy [B*T, D] -> dqkv [B*T, 3D]; dgq_partial / dgk_partial [B*H, head_dim] are per-(sample, head)
+ * partial gradients of the qk-norm gains (reduce with mode_colsum).  Attention dropout (SDPA dropout_p, modedit.py:149) is a
+ * counter-based hash mask keyed by (seed, sample, head, query, key), regenerated here. */
+int mode_attn_block_bwd(const void* qkv, const float* q_gain, const float* k_gain, const void* dy, void* dqkv,
+                        float* dgq_partial, float* dgk_partial, int dtype, int B, int T, int H, int head_dim, float eps,
+                        uint32_t seed, float p_drop, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * mode_sigma_embed — e1[r, :] = (ln(sigma[r]) / 4) * w[:, 0] + b        (modedit.py:823-828, Linear(1, D))
@@ -186,6 +193,40 @@ int mode_head_ddim_fwd(const ModeHeadDesc* d, void* stream);
 /* mode_ddim_edm_step — the same elementwise epilogue standalone (used by the generic, un-fused sampler path). */
 int mode_ddim_edm_step(const float* F, const float* x_a, const float* scal, int64_t scal_stride, int B, int per_sample,
                        float* denoised, float* x_next, void* stream);
+
+/* ==================================================================================================================
+ * Training-side operators (score-matching step: SURVEY.md §8 rows 13-17).  Deterministic: no floating-point atomics.
+ * ================================================================================================================== */
+
+/* mode_transpose — dst[c, dcol(r)] = src[srow(r), c]: feeds the weight-gradient GEMMs (dW = dY^T X, autograd of nn.Linear) with
+ * K-contiguous operands.  src_rows (optional) gathers rows (MoE permutation); dst_cols (optional) places row r at an arbitrary
+ * destination column (per-expert 64-padded positions from mode_moe_dispatch_meta's `prow`); untouched columns keep their content
+ * (zero the buffer first for padding). */
+int mode_transpose(const void* src, int64_t ld_src, int rows, int cols, void* dst, int64_t ld_dst, const int32_t* src_rows,
+                   const int32_t* dst_cols, int dtype, void* stream);
+
+/* mode_colsum — out[s, c] (+)= sum_{r in segment s} X[r, c]  (bias / RMSNorm-gain / conditioning gradients).
+ * Segments: seg_offsets (device int32[nseg+1]) or uniform seg_len or the whole matrix (nseg = 1).  Two deterministic stages. */
+size_t mode_colsum_workspace_bytes(int rows, int cols, int nseg);
+int mode_colsum(const void* X, int64_t ld, int rows, int cols, int dtype, const int32_t* seg_offsets, int seg_len, int nseg,
+                float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* mode_swiglu_fwd/_bwd — H = value * silu(gate) * dropout  on P = [value | gate] (SwishGLU + nn.Dropout, modedit.py:83-90, 254).
+ * The keep-mask is hash(seed, element index): the backward regenerates it.  p_drop = 0 disables dropout. */
+int mode_swiglu_fwd(const void* P, void* Hd, int64_t rows, int Hdim, int dtype, uint32_t seed, float p_drop, void* stream);
+int mode_swiglu_bwd(const void* P, const void* dHd, void* dP, int64_t rows, int Hdim, int dtype, uint32_t seed, float p_drop,
+                    void* stream);
+
+/* mode_rmsnorm_bwd — backward of RMSNorm (modedit.py:72-80).  dy[row] = dy_a[row] + dy_b[row] + sum_j G[pos[row*k + j]] (any may be
+ * NULL / k = 0; the gather-sum is the MoE dispatch backward); dx (+)= d/dx; dg_partial [ceil(rows/4), D] per-workgroup partial gain
+ * gradients (reduce with mode_colsum); dy_out (optional) receives the assembled dy (the conditioning gradient needs it). */
+int mode_rmsnorm_bwd(const float* x, const float* g, const float* dy_a, const float* dy_b, const float* G, const int32_t* pos, int k,
+                     int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* stream);
+
+/* mode_moe_combine_bwd — backward of next[t] += w[t,e] * expert_e(u[t]) (modedit.py:566): dYs[pos[t,j]] = posw[t,j] * dy[t] (sorted
+ * rows, compute dtype) and dw[t,j] = <dy[t], Y[pos[t,j]]> (router-weight gradient, SURVEY §8 a-bis). */
+int mode_moe_combine_bwd(const float* dy, const void* Y, int y_dtype, const int32_t* pos, const float* posw, int N, int D, int k,
+                         void* dYs, float* dw, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Whole-denoiser forward: the launch chain of one MoDeDiT.forward (modedit.py:741-821) [+ GCDenoiser.forward scalings

@@ -81,7 +81,9 @@ PROTOTYPES = {
     "mode_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "mode_gemm": (C.c_int, [P(ModeGemmDesc), c_vp]),
     "mode_rmsnorm_cond_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_f32, c_vp, c_vp, C.c_int, c_vp]),
-    "mode_attn_block_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32, c_vp]),
+    "mode_attn_block_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32, C.c_uint32, c_f32, c_vp]),
+    "mode_attn_block_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32, C.c_uint32,
+                                      c_f32, c_vp]),
     "mode_sigma_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, c_vp]),
     "mode_moe_route_topk_f32": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mode_moe_dispatch_meta": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -90,6 +92,13 @@ PROTOTYPES = {
     "mode_embed_tokens_fwd": (C.c_int, [P(ModeEmbedDesc), c_vp]),
     "mode_head_ddim_fwd": (C.c_int, [P(ModeHeadDesc), c_vp]),
     "mode_ddim_edm_step": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
+    "mode_transpose": (C.c_int, [c_vp, c_i64, C.c_int, C.c_int, c_vp, c_i64, c_vp, c_vp, C.c_int, c_vp]),
+    "mode_colsum_workspace_bytes": (c_sz, [C.c_int, C.c_int, C.c_int]),
+    "mode_colsum": (C.c_int, [c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_vp, c_sz, c_vp]),
+    "mode_swiglu_fwd": (C.c_int, [c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_uint32, c_f32, c_vp]),
+    "mode_swiglu_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_uint32, c_f32, c_vp]),
+    "mode_rmsnorm_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_f32, c_vp, C.c_int, c_vp, c_vp, c_vp]),
+    "mode_moe_combine_bwd": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
     "mode_moe_meta_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, P(ModeMetaLayout)]),
     "mode_dit_dispatch": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
     "mode_dit_workspace_bytes": (c_sz, [P(ModeDims), C.c_int, C.c_int, C.c_int]),

@@ -10,10 +10,19 @@
 
 namespace mode {
 
+__device__ __forceinline__ uint32_t ahash_u32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+// attention-dropout keep mask (SDPA dropout_p, modedit.py:149): element (problem, query, key) of stream `seed`
+__device__ __forceinline__ bool attn_keep(uint32_t seed, int prob, int T, int q, int k, uint32_t thresh) {
+  return ahash_u32(ahash_u32((uint32_t)((prob * T + q) * T + k) ^ seed) + 0x9e3779b9U) >= thresh;
+}
+
 template <int NKS>   // 32*(NKS-1) < head_dim <= 32*NKS, head_dim % 16 == 0 (dims past head_dim are zero k-slots)
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ qg,
                                                         const float* __restrict__ kg, uint16_t* __restrict__ y, int B, int T,
-                                                        int H, int HD, float eps) {
+                                                        int H, int HD, float eps, uint32_t seed, uint32_t thresh, float inv_keep) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int prob = blockIdx.x * 4 + wave;
   if (prob >= B * H) return;
@@ -98,7 +107,12 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
   for (int r = 0; r < 4; ++r) { p[r] = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - mx); sum += p[r]; }
   sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
-  uint4 tp = make_uint4(pack_bf16x2(p[0] * inv, p[1] * inv), pack_bf16x2(p[2] * inv, p[3] * inv), 0u, 0u);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    p[r] *= inv;
+    if (thresh) p[r] = attn_keep(seed, prob, T, fr, fq * 4 + r, thresh) ? p[r] * inv_keep : 0.f;
+  }
+  uint4 tp = make_uint4(pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), 0u, 0u);
   const bf16x8 pfrag = *reinterpret_cast<bf16x8*>(&tp);          // B operand: slots 0..3 = keys fq*4+r, slots 4..7 = 0
 
   // ---- O^T[d][query] = sum_key V[key][d] P[query][key]; A operand = V^T fragment: row d = db*16 + fr, slots j<4 = keys fq*4+j
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
 // fp32 parity kernel: one wave per (b,h); q,k,v rows staged in LDS; plain VALU math in the reference's order.
 __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ qg,
                                                       const float* __restrict__ kg, float* __restrict__ y, int B, int T, int H,
-                                                      int HD, float eps) {
+                                                      int HD, float eps, uint32_t seed, uint32_t thresh, float inv_keep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sq = reinterpret_cast<float*>(smem);          // [T][HD]
   float* sk = sq + T * HD;
@@ -158,7 +172,11 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
     for (int ki = 0; ki <= lane; ++ki) mx = fmaxf(mx, sp[lane * T + ki]);
     float sum = 0.f;
     for (int ki = 0; ki < T; ++ki) { const float e = (ki <= lane) ? expf(sp[lane * T + ki] - mx) : 0.f; sp[lane * T + ki] = e; sum += e; }
-    for (int ki = 0; ki < T; ++ki) sp[lane * T + ki] /= sum;
+    for (int ki = 0; ki < T; ++ki) {
+      float pv = sp[lane * T + ki] / sum;
+      if (thresh) pv = attn_keep(seed, blockIdx.x, T, lane, ki, thresh) ? pv * inv_keep : 0.f;
+      sp[lane * T + ki] = pv;
+    }
   }
   __syncthreads();
   for (int i = lane; i < T * HD; i += 64) {
@@ -169,31 +187,167 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
   }
 }
 
+// ---- backward (training): one wave per (sample, head), everything in LDS, plain fp32 VALU in the forward's order.
+// dY [B*T, D] (T2 = bf16/f32) -> dqkv [B*T, 3D]; per-workgroup partial gradients of the qk-norm gains: dgq/dgk [B*H, HD].
+template <typename T2>
+__global__ __launch_bounds__(64) void attn_bwd_kernel(const T2* __restrict__ qkv, const float* __restrict__ qg, const float* __restrict__ kg,
+                                                      const T2* __restrict__ dY, T2* __restrict__ dqkv, float* __restrict__ dgq_part,
+                                                      float* __restrict__ dgk_part, int B, int T, int H, int HD, float eps, uint32_t seed,
+                                                      uint32_t thresh, float inv_keep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sq = reinterpret_cast<float*>(smem);          // raw q  [T][HD]
+  float* sk = sq + T * HD;                             // raw k
+  float* sv = sk + T * HD;                             // v
+  float* sdo = sv + T * HD;                            // dO
+  float* sdq = sdo + T * HD;                           // d q_hat
+  float* sdk = sdq + T * HD;                           // d k_hat
+  float* sp = sdk + T * HD;                            // P (after dropout scaling: Pd)   [T][T]
+  float* sds = sp + T * T;                             // dS                               [T][T]
+  float* srq = sds + T * T;                            // 1/norm per token (q)             [T]
+  float* srk = srq + T;                                // (k)
+  const int lane = threadIdx.x, prob = blockIdx.x, b = prob / H, h = prob % H, D = H * HD;
+  const long ld = 3L * D;
+  auto LD = [](const T2* p) -> float { if constexpr (sizeof(T2) == 2) return bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(p)); else return *reinterpret_cast<const float*>(p); };
+  auto ST = [](T2* p, float v) { if constexpr (sizeof(T2) == 2) *reinterpret_cast<uint16_t*>(p) = f32_to_bf16_bits(v); else *reinterpret_cast<float*>(p) = v; };
+  for (int i = lane; i < T * HD; i += 64) {
+    const int t = i / HD, d = i % HD;
+    const T2* r = qkv + ((long)b * T + t) * ld + h * HD + d;
+    sq[i] = LD(r); sk[i] = LD(r + D); sv[i] = LD(r + 2 * D);
+    sdo[i] = LD(dY + ((long)b * T + t) * D + h * HD + d);
+  }
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    float a = 0.f, c = 0.f;
+    for (int d = lane; d < HD; d += 64) { a += sq[t * HD + d] * sq[t * HD + d]; c += sk[t * HD + d] * sk[t * HD + d]; }
+    a = wave_sum(a); c = wave_sum(c);
+    if (lane == 0) {
+      srq[t] = 1.0f / fmaxf(sqrtf(a) * rsqrtf((float)HD), eps);
+      srk[t] = 1.0f / fmaxf(sqrtf(c) * rsqrtf((float)HD), eps);
+    }
+  }
+  __syncthreads();
+  const float scale = rsqrtf((float)HD);
+  // S = q_hat k_hat^T * scale (causal) and dPd = dO V^T
+  for (int i = lane; i < T * T; i += 64) {
+    const int qi = i / T, ki = i % T;
+    float s = -INFINITY, dp = 0.f;
+    if (ki <= qi) {
+      s = 0.f;
+      for (int d = 0; d < HD; ++d) {
+        s = fmaf(sq[qi * HD + d] * srq[qi] * qg[d], sk[ki * HD + d] * srk[ki] * kg[d], s);
+        dp = fmaf(sdo[qi * HD + d], sv[ki * HD + d], dp);
+      }
+      s *= scale;
+    }
+    sp[i] = s; sds[i] = dp;
+  }
+  __syncthreads();
+  if (lane < T) {                                       // softmax row, dropout, dS = P * (dP - sum(dP*P)) * scale
+    const int qi = lane;
+    float mx = -INFINITY;
+    for (int ki = 0; ki <= qi; ++ki) mx = fmaxf(mx, sp[qi * T + ki]);
+    float sum = 0.f;
+    for (int ki = 0; ki <= qi; ++ki) sum += expf(sp[qi * T + ki] - mx);
+    float rs = 0.f;
+    for (int ki = 0; ki < T; ++ki) {
+      float pv = (ki <= qi) ? expf(sp[qi * T + ki] - mx) / sum : 0.f;
+      float m = 1.0f;
+      if (thresh) m = attn_keep(seed, prob, T, qi, ki, thresh) ? inv_keep : 0.f;
+      const float dP = sds[qi * T + ki] * m;          // gradient wrt the un-dropped probability
+      rs += dP * pv;
+      sp[qi * T + ki] = pv;                            // keep P; Pd = P*m is re-derived below
+      sds[qi * T + ki] = dP;
+    }
+    for (int ki = 0; ki < T; ++ki) sds[qi * T + ki] = sp[qi * T + ki] * (sds[qi * T + ki] - rs) * scale;
+  }
+  __syncthreads();
+  // dV[j][d] = sum_{i>=j} Pd[i][j] dO[i][d];  dq_hat[i][d] = sum_{j<=i} dS[i][j] k_hat[j][d];  dk_hat[j][d] = sum_{i>=j} dS[i][j] q_hat[i][d]
+  for (int i = lane; i < T * HD; i += 64) {
+    const int t = i / HD, d = i % HD;
+    float dv = 0.f, dq = 0.f, dk = 0.f;
+    for (int u = 0; u < T; ++u) {
+      if (u >= t) {
+        float pd = sp[u * T + t];
+        if (thresh) pd = attn_keep(seed, prob, T, u, t, thresh) ? pd * inv_keep : 0.f;
+        dv = fmaf(pd, sdo[u * HD + d], dv);
+        dk = fmaf(sds[u * T + t], sq[u * HD + d] * srq[u] * qg[d], dk);
+      }
+      if (u <= t) dq = fmaf(sds[t * T + u], sk[u * HD + d] * srk[u] * kg[d], dq);
+    }
+    sdq[i] = dq; sdk[i] = dk;
+    ST(dqkv + ((long)b * T + t) * ld + 2 * D + h * HD + d, dv);
+  }
+  __syncthreads();
+  // qk-RMSNorm backward (x_hat = x * r * g): dx = g*dxh*r - x * <g*dxh, x> * r^3 / HD  (clamped rows: dx = g*dxh/eps)
+  for (int t = 0; t < T; ++t) {
+    float cq = 0.f, ck = 0.f;
+    for (int d = lane; d < HD; d += 64) { cq += qg[d] * sdq[t * HD + d] * sq[t * HD + d]; ck += kg[d] * sdk[t * HD + d] * sk[t * HD + d]; }
+    cq = wave_sum(cq); ck = wave_sum(ck);
+    const float rq = srq[t], rk = srk[t];
+    const bool clq = rq >= 1.0f / eps, clk = rk >= 1.0f / eps;
+    for (int d = lane; d < HD; d += 64) {
+      const float dq = qg[d] * sdq[t * HD + d] * rq - (clq ? 0.f : sq[t * HD + d] * cq * rq * rq * rq / (float)HD);
+      const float dk = kg[d] * sdk[t * HD + d] * rk - (clk ? 0.f : sk[t * HD + d] * ck * rk * rk * rk / (float)HD);
+      ST(dqkv + ((long)b * T + t) * ld + h * HD + d, dq);
+      ST(dqkv + ((long)b * T + t) * ld + D + h * HD + d, dk);
+    }
+  }
+  for (int d = lane; d < HD; d += 64) {                 // gain-gradient partials of this (sample, head)
+    float a = 0.f, c = 0.f;
+    for (int t = 0; t < T; ++t) { a += sdq[t * HD + d] * sq[t * HD + d] * srq[t]; c += sdk[t * HD + d] * sk[t * HD + d] * srk[t]; }
+    dgq_part[(long)prob * HD + d] = a; dgk_part[(long)prob * HD + d] = c;
+  }
+}
+
 }  // namespace mode
 
 using namespace mode;
 
+static inline uint32_t attn_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)((double)p * 4294967296.0); }
+
 extern "C" int mode_attn_block_fwd(const void* qkv, const float* q_gain, const float* k_gain, void* y, int dtype, int B, int T, int H,
-                                   int head_dim, float eps, void* stream) {
+                                   int head_dim, float eps, uint32_t seed, float p_drop, void* stream) {
   if (!qkv || !q_gain || !k_gain || !y || B < 0 || T <= 0 || H <= 0) return MODE_ERR_BAD_ARG;
   if (B == 0) return MODE_OK;
+  if (p_drop < 0.f || p_drop >= 1.f) return MODE_ERR_BAD_ARG;
+  const uint32_t th = attn_thresh(p_drop); const float ik = 1.0f / (1.0f - p_drop);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MODE_BF16) {
     if (T > 16 || head_dim % 16 != 0 || head_dim > 128) return MODE_ERR_UNSUPPORTED;
     const dim3 grid((B * H + 3) / 4), blk(256);
     const uint16_t* in = (const uint16_t*)qkv; uint16_t* out = (uint16_t*)y;
     switch ((head_dim + 31) / 32) {
-      case 1: hipLaunchKernelGGL(attn_bf16_kernel<1>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, head_dim, eps); break;
-      case 2: hipLaunchKernelGGL(attn_bf16_kernel<2>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, head_dim, eps); break;
-      case 3: hipLaunchKernelGGL(attn_bf16_kernel<3>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, head_dim, eps); break;
-      case 4: hipLaunchKernelGGL(attn_bf16_kernel<4>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, head_dim, eps); break;
+      case 1: hipLaunchKernelGGL(attn_bf16_kernel<1>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, head_dim, eps, seed, th, ik); break;
+      case 2: hipLaunchKernelGGL(attn_bf16_kernel<2>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, head_dim, eps, seed, th, ik); break;
+      case 3: hipLaunchKernelGGL(attn_bf16_kernel<3>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, head_dim, eps, seed, th, ik); break;
+      case 4: hipLaunchKernelGGL(attn_bf16_kernel<4>, grid, blk, 0, s, in, q_gain, k_gain, out, B, T, H, head_dim, eps, seed, th, ik); break;
       default: return MODE_ERR_UNSUPPORTED;
     }
   } else {
     const size_t lds = ((size_t)3 * T * head_dim + (size_t)T * T) * 4;
     if (lds > 64 * 1024) return MODE_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(attn_f32_kernel, dim3(B * H), dim3(64), lds, s, (const float*)qkv, q_gain, k_gain, (float*)y, B, T, H, head_dim, eps);
+    hipLaunchKernelGGL(attn_f32_kernel, dim3(B * H), dim3(64), lds, s, (const float*)qkv, q_gain, k_gain, (float*)y, B, T, H, head_dim, eps, seed, th, ik);
   }
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_attn_block_bwd(const void* qkv, const float* q_gain, const float* k_gain, const void* dy, void* dqkv, float* dgq_partial,
+                                   float* dgk_partial, int dtype, int B, int T, int H, int head_dim, float eps, uint32_t seed, float p_drop,
+                                   void* stream) {
+  if (!qkv || !q_gain || !k_gain || !dy || !dqkv || !dgq_partial || !dgk_partial || B < 0 || T <= 0 || H <= 0) return MODE_ERR_BAD_ARG;
+  if (p_drop < 0.f || p_drop >= 1.f) return MODE_ERR_BAD_ARG;
+  if (B == 0) return MODE_OK;
+  const size_t lds = ((size_t)6 * T * head_dim + 2 * (size_t)T * T + 2 * T) * 4;
+  if (lds > 64 * 1024) return MODE_ERR_UNSUPPORTED;
+  const uint32_t th = attn_thresh(p_drop); const float ik = 1.0f / (1.0f - p_drop);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MODE_BF16)
+    hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, dim3(B * H), dim3(64), lds, s, (const uint16_t*)qkv, q_gain, k_gain, (const uint16_t*)dy, (uint16_t*)dqkv,
+                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik);
+  else
+    hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B * H), dim3(64), lds, s, (const float*)qkv, q_gain, k_gain, (const float*)dy, (float*)dqkv,
+                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }

@@ -219,7 +219,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     g.bias = lw.bqkv;
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
-    rc = mode_attn_block_fwd(qkv, lw.qn_g, lw.kn_g, yat, dt, B, T, d.H, D / d.H, d.eps, stream);
+    rc = mode_attn_block_fwd(qkv, lw.qn_g, lw.kn_g, yat, dt, B, T, d.H, D / d.H, d.eps, 0u, 0.0f, stream);
     if (rc) return rc;
     // c_proj (no bias) + residual, in place on the fp32 stream   (modedit.py:111, 166, 532)
     g = gemm_desc(dt, MODE_EPI_RESIDUAL, MODE_F32, N, D, D, yat, D, lw.wo, D, x, D);

@@ -1,0 +1,311 @@
+// Backward / training-side row kernels of the MoDE denoiser (HBM-bound, deterministic: no float atomics anywhere).
+//   transpose          : [R,C] -> [C,R'] with optional row gather and per-row destination column (per-expert 64-padding), feeds the
+//                        weight-gradient GEMMs (dW = dY^T X) in the K-contiguous layout the MFMA kernel wants
+//   colsum             : bias / gain / conditioning gradients (segmented column sums), two deterministic stages
+//   swiglu_fwd / _bwd  : SwishGLU + expert dropout (modedit.py:83-90, 254); mask is a counter-based hash of (seed, element) so the
+//                        backward regenerates it instead of storing it
+//   rmsnorm_bwd        : backward of x / max(rms, eps) * g (+ the MoE gather-sum of the expert input gradients fused in front)
+//   combine_bwd        : backward of next += w * expert(x): dY (sorted rows) and the router-weight gradients <dy, E_e(u)>
+#include "mode_common.h"
+
+namespace mode {
+
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {            // lowbias32 (Wellons): good avalanche, 6 ALU ops
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+// keep-mask for dropout: element `idx` of stream `seed` survives with probability 1-p (thresh = p * 2^32)
+__device__ __forceinline__ bool drop_keep(uint32_t seed, uint64_t idx, uint32_t thresh) {
+  return hash_u32(hash_u32((uint32_t)idx ^ seed) + (uint32_t)(idx >> 32) * 0x9e3779b9U) >= thresh;
+}
+
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<uint16_t>(const uint16_t* p) { return bf16_bits_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<uint16_t>(uint16_t* p, float v) { *p = f32_to_bf16_bits(v); }
+
+// -------------------------------------------------------------------------------------------------------------- transpose
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, long ld_src, int rows, int cols, T* __restrict__ dst,
+                                                        long ld_dst, const int* __restrict__ src_rows, const int* __restrict__ dst_cols) {
+  __shared__ T tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < rows && c < cols) {
+      const long sr = src_rows ? src_rows[r] : r;
+      tile[i][tx] = src[sr * ld_src + c];
+    }
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) {
+      const long dc = dst_cols ? dst_cols[r] : r;
+      dst[(long)c * ld_dst + dc] = tile[tx][i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ colsum
+// stage 1: block (x = 64-column group, y = row split, z = segment) -> partial[z][y][col]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const T* __restrict__ X, long ld, int rows, int cols, const int* __restrict__ seg_off,
+                                                            int seg_len, int nsplit, float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int seg = blockIdx.z, sp = blockIdx.y;
+  int o0, o1;
+  if (seg_off) { o0 = seg_off[seg]; o1 = seg_off[seg + 1]; }
+  else if (seg_len > 0) { o0 = seg * seg_len; o1 = min(rows, o0 + seg_len); }
+  else { o0 = 0; o1 = rows; }
+  const int chunk = (o1 - o0 + nsplit - 1) / nsplit;
+  const int ra = o0 + sp * chunk, rb = min(o1, ra + chunk);
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < cols)
+    for (int r = ra + ty; r < rb; r += 4) acc += ld1<T>(X + (long)r * ld + c);
+  red[ty][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (ty == 0 && c < cols)
+    partial[((long)seg * nsplit + sp) * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// stage 2: out[seg][col] (+)= sum over splits in order
+__global__ void colsum_stage2_kernel(const float* __restrict__ partial, int nseg, int nsplit, int cols, float* __restrict__ out, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nseg * cols) return;
+  const int seg = i / cols, c = i % cols;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += partial[((long)seg * nsplit + k) * cols + c];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ swiglu
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* __restrict__ P, T* __restrict__ Hd, long rows, int Hdim, uint32_t seed,
+                                                         uint32_t thresh, float inv_keep) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;           // one thread per 4 output elements
+  const long n4 = rows * Hdim / 4;
+  if (i >= n4) return;
+  const long r = (i * 4) / Hdim; const int c = (i * 4) % Hdim;
+  const T* pr = P + r * 2 * Hdim;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float v = ld1<T>(pr + c + j), g = ld1<T>(pr + Hdim + c + j);
+    float h = v * (g / (1.0f + __expf(-g)));
+    if (thresh) h = drop_keep(seed, (uint64_t)(r * Hdim + c + j), thresh) ? h * inv_keep : 0.f;
+    st1<T>(Hd + r * Hdim + c + j, h);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ P, const T* __restrict__ dHd, T* __restrict__ dP, long rows, int Hdim,
+                                                         uint32_t seed, uint32_t thresh, float inv_keep) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n4 = rows * Hdim / 4;
+  if (i >= n4) return;
+  const long r = (i * 4) / Hdim; const int c = (i * 4) % Hdim;
+  const T* pr = P + r * 2 * Hdim;
+  T* dr = dP + r * 2 * Hdim;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float v = ld1<T>(pr + c + j), g = ld1<T>(pr + Hdim + c + j);
+    float dh = ld1<T>(dHd + r * Hdim + c + j);
+    if (thresh) dh = drop_keep(seed, (uint64_t)(r * Hdim + c + j), thresh) ? dh * inv_keep : 0.f;
+    const float sg = 1.0f / (1.0f + __expf(-g));
+    st1<T>(dr + c + j, dh * g * sg);                                     // d/d value = silu(gate)
+    st1<T>(dr + Hdim + c + j, dh * v * sg * (1.0f + g * (1.0f - sg)));    // d/d gate  = value * silu'(gate)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------ rmsnorm bwd
+// One wave per row.  dy[row] = (dy_a ? dy_a[row] : 0) + (dy_b ? dy_b[row] : 0) + sum_j G[pos[row*k+j]]   (all fp32)
+// dx[row] (+)= (g*dy)/n - x * <g*dy, x> / (D n^3)   with n = max(||x||/sqrt(D), eps)  [clamped branch: dx = g*dy/eps]
+// dg partial: dgp[block][d] = sum over the block's 4 rows of dy_d * x_d / n  (reduced by colsum stage 2)
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* dy_a,
+                                                          const float* dy_b, const float* __restrict__ G, const int* __restrict__ pos, int k,
+                                                          int rows, int D, float eps, float* dx, int accumulate, float* __restrict__ dgp,
+                                                          float* __restrict__ dy_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sx = reinterpret_cast<float*>(smem);                       // [4][D] x rows
+  float* sd = sx + 4 * D;                                            // [4][D] dy rows
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  const bool valid = row < rows;
+  float ssq = 0.f, dot = 0.f;
+  if (valid) {
+    for (int d = lane * 4; d < D; d += 256) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + (long)row * D + d);
+      float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dy_a) { const float4 t = *reinterpret_cast<const float4*>(dy_a + (long)row * D + d); dv.x += t.x; dv.y += t.y; dv.z += t.z; dv.w += t.w; }
+      if (dy_b) { const float4 t = *reinterpret_cast<const float4*>(dy_b + (long)row * D + d); dv.x += t.x; dv.y += t.y; dv.z += t.z; dv.w += t.w; }
+      for (int j = 0; j < k; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(G + (long)pos[(long)row * k + j] * D + d);
+        dv.x += t.x; dv.y += t.y; dv.z += t.z; dv.w += t.w;
+      }
+      const float4 gv = *reinterpret_cast<const float4*>(g + d);
+      *reinterpret_cast<float4*>(sx + wave * D + d) = xv;
+      *reinterpret_cast<float4*>(sd + wave * D + d) = dv;
+      if (dy_out) *reinterpret_cast<float4*>(dy_out + (long)row * D + d) = dv;
+      ssq += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+      dot += gv.x * dv.x * xv.x + gv.y * dv.y * xv.y + gv.z * dv.z * xv.z + gv.w * dv.w * xv.w;
+    }
+  }
+  ssq = wave_sum(ssq); dot = wave_sum(dot);
+  const float rms = sqrtf(ssq) * rsqrtf((float)D);
+  const bool clamped = rms < eps;
+  const float n = clamped ? eps : rms;
+  const float rn = 1.0f / n;
+  const float coef = clamped ? 0.f : dot * rn * rn * rn / (float)D;
+  if (valid) {
+    for (int d = lane * 4; d < D; d += 256) {
+      const float4 xv = *reinterpret_cast<const float4*>(sx + wave * D + d);
+      const float4 dv = *reinterpret_cast<const float4*>(sd + wave * D + d);
+      const float4 gv = *reinterpret_cast<const float4*>(g + d);
+      float4 o = make_float4(gv.x * dv.x * rn - xv.x * coef, gv.y * dv.y * rn - xv.y * coef, gv.z * dv.z * rn - xv.z * coef,
+                             gv.w * dv.w * rn - xv.w * coef);
+      float* dst = dx + (long)row * D + d;
+      if (accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+      *reinterpret_cast<float4*>(dst) = o;
+      // stash dy * x / n for the gain gradient in place of dy
+      *reinterpret_cast<float4*>(sd + wave * D + d) = make_float4(dv.x * xv.x * rn, dv.y * xv.y * rn, dv.z * xv.z * rn, dv.w * xv.w * rn);
+    }
+  } else {
+    for (int d = lane * 4; d < D; d += 256) *reinterpret_cast<float4*>(sd + wave * D + d) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  if (dgp) {
+    for (int d = threadIdx.x; d < D; d += 256)
+      dgp[(long)blockIdx.x * D + d] = (sd[d] + sd[D + d]) + (sd[2 * D + d] + sd[3 * D + d]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------ combine bwd
+// one wave per token: dYs[pos[t,j]] = posw[t,j] * dy[t]  (lp), dw[t,j] = <dy[t], Y[pos[t,j]]>
+template <typename T>
+__global__ __launch_bounds__(256) void combine_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ Y, const int* __restrict__ pos,
+                                                          const float* __restrict__ posw, int N, int D, int k, T* __restrict__ dYs,
+                                                          float* __restrict__ dw) {
+  const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= N) return;
+  for (int j = 0; j < k; ++j) {
+    const long p = pos[(long)t * k + j];
+    const float w = posw[(long)t * k + j];
+    float acc = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+      const float4 g = *reinterpret_cast<const float4*>(dy + (long)t * D + d);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float gv = (&g.x)[c];
+        acc += gv * ld1<T>(Y + p * D + d + c);
+        st1<T>(dYs + p * D + d + c, w * gv);
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dw[(long)t * k + j] = acc;
+  }
+}
+
+}  // namespace mode
+
+using namespace mode;
+
+extern "C" int mode_transpose(const void* src, int64_t ld_src, int rows, int cols, void* dst, int64_t ld_dst, const int32_t* src_rows,
+                              const int32_t* dst_cols, int dtype, void* stream) {
+  if (!src || !dst || rows < 0 || cols < 0) return MODE_ERR_BAD_ARG;
+  if (rows == 0 || cols == 0) return MODE_OK;
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (dtype == MODE_BF16)
+    hipLaunchKernelGGL(transpose_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, (long)ld_src, rows, cols,
+                       (uint16_t*)dst, (long)ld_dst, src_rows, dst_cols);
+  else
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, (long)ld_src, rows, cols,
+                       (float*)dst, (long)ld_dst, src_rows, dst_cols);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" size_t mode_colsum_workspace_bytes(int rows, int cols, int nseg) {
+  if (nseg < 1) nseg = 1;
+  int nsplit = 1;
+  const long per = (long)((cols + 63) / 64) * nseg;
+  while (per * nsplit < 1024 && nsplit * 64 < rows) nsplit *= 2;
+  return (size_t)nseg * nsplit * cols * 4;
+}
+
+extern "C" int mode_colsum(const void* X, int64_t ld, int rows, int cols, int dtype, const int32_t* seg_offsets, int seg_len, int nseg,
+                           float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!X || !out || !workspace || rows < 0 || cols <= 0) return MODE_ERR_BAD_ARG;
+  if (nseg < 1) nseg = 1;
+  int nsplit = 1;
+  const long per = (long)((cols + 63) / 64) * nseg;
+  while (per * nsplit < 1024 && nsplit * 64 < rows) nsplit *= 2;
+  if (workspace_bytes < (size_t)nseg * nsplit * cols * 4) return MODE_ERR_WORKSPACE;
+  float* partial = (float*)workspace;
+  const dim3 grid((cols + 63) / 64, nsplit, nseg);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MODE_BF16)
+    hipLaunchKernelGGL(colsum_stage1_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)X, (long)ld, rows, cols, seg_offsets, seg_len, nsplit, partial);
+  else
+    hipLaunchKernelGGL(colsum_stage1_kernel<float>, grid, dim3(256), 0, s, (const float*)X, (long)ld, rows, cols, seg_offsets, seg_len, nsplit, partial);
+  MODE_LAUNCH_CHECK();
+  const long n = (long)nseg * cols;
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, nseg, nsplit, cols, out, accumulate);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+static inline uint32_t drop_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)((double)p * 4294967296.0); }
+
+extern "C" int mode_swiglu_fwd(const void* P, void* Hd, int64_t rows, int Hdim, int dtype, uint32_t seed, float p_drop, void* stream) {
+  if (!P || !Hd || rows < 0 || Hdim <= 0 || (Hdim & 3) || p_drop < 0.f || p_drop >= 1.f) return MODE_ERR_BAD_ARG;
+  const long n4 = rows * Hdim / 4;
+  if (n4 == 0) return MODE_OK;
+  const float ik = 1.0f / (1.0f - p_drop);
+  if (dtype == MODE_BF16)
+    hipLaunchKernelGGL(swiglu_fwd_kernel<uint16_t>, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)P, (uint16_t*)Hd, (long)rows, Hdim, seed, drop_thresh(p_drop), ik);
+  else
+    hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)P, (float*)Hd, (long)rows, Hdim, seed, drop_thresh(p_drop), ik);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_swiglu_bwd(const void* P, const void* dHd, void* dP, int64_t rows, int Hdim, int dtype, uint32_t seed, float p_drop,
+                               void* stream) {
+  if (!P || !dHd || !dP || rows < 0 || Hdim <= 0 || (Hdim & 3) || p_drop < 0.f || p_drop >= 1.f) return MODE_ERR_BAD_ARG;
+  const long n4 = rows * Hdim / 4;
+  if (n4 == 0) return MODE_OK;
+  const float ik = 1.0f / (1.0f - p_drop);
+  if (dtype == MODE_BF16)
+    hipLaunchKernelGGL(swiglu_bwd_kernel<uint16_t>, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)P, (const uint16_t*)dHd, (uint16_t*)dP, (long)rows, Hdim, seed, drop_thresh(p_drop), ik);
+  else
+    hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)P, (const float*)dHd, (float*)dP, (long)rows, Hdim, seed, drop_thresh(p_drop), ik);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_rmsnorm_bwd(const float* x, const float* g, const float* dy_a, const float* dy_b, const float* G, const int32_t* pos, int k,
+                                int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* stream) {
+  if (!x || !g || !dx || rows < 0 || D <= 0 || (D & 3) || (k > 0 && (!G || !pos))) return MODE_ERR_BAD_ARG;
+  if (rows == 0) return MODE_OK;
+  const size_t lds = (size_t)8 * D * 4;
+  if (lds > 64 * 1024) return MODE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), lds, (hipStream_t)stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx,
+                     accumulate, dg_partial, dy_out);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_moe_combine_bwd(const float* dy, const void* Y, int y_dtype, const int32_t* pos, const float* posw, int N, int D, int k,
+                                    void* dYs, float* dw, void* stream) {
+  if (!dy || !Y || !pos || !posw || !dYs || !dw || N < 0 || D <= 0 || (D & 3) || k <= 0) return MODE_ERR_BAD_ARG;
+  if (N == 0) return MODE_OK;
+  if (y_dtype == MODE_BF16)
+    hipLaunchKernelGGL(combine_bwd_kernel<uint16_t>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (const uint16_t*)Y, pos, posw, N, D, k, (uint16_t*)dYs, dw);
+  else
+    hipLaunchKernelGGL(combine_bwd_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (const float*)Y, pos, posw, N, D, k, (float*)dYs, dw);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}

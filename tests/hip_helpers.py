@@ -69,10 +69,10 @@ def rmsnorm(x, g, cond=None, rows_per_cond=1, eps=1e-6, lp_dtype=torch.bfloat16,
     return y32, ylp
 
 
-def attn(qkv, qg, kg, B, T, H, hd, eps=1e-6):
+def attn(qkv, qg, kg, B, T, H, hd, eps=1e-6, seed=0, p_drop=0.0):
     lib = L.load()
     y = torch.full((B * T, H * hd), float("nan"), dtype=qkv.dtype, device=qkv.device)
-    L.check(lib.mode_attn_block_fwd(p(qkv), p(qg), p(kg), p(y), dt_of(qkv), B, T, H, hd, eps, stream()), "attn")
+    L.check(lib.mode_attn_block_fwd(p(qkv), p(qg), p(kg), p(y), dt_of(qkv), B, T, H, hd, eps, seed, p_drop, stream()), "attn")
     return y
 
 

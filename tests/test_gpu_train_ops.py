@@ -1,0 +1,186 @@
+"""GPU parity of the training-side HIP kernels (through the C-ABI) against plain fp32 PyTorch autograd of the same op."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mode_diffusion_policy_amd import _lib as L  # noqa: E402
+from oracle import mode_oracle as O  # noqa: E402
+
+import hip_helpers as H  # noqa: E402
+
+dev = lambda: torch.device("cuda:0")
+DT = {torch.bfloat16: L.MODE_BF16, torch.float32: L.MODE_F32}
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("R,Ccols", [(70, 33), (1792, 1024), (200, 64)])
+def test_transpose_gather_pad(dtype, R, Ccols):
+    lib = L.load()
+    src = rnd(R + 5, Ccols, seed=1).to(dtype).to(dev())
+    g = torch.Generator().manual_seed(2)
+    rows = torch.randperm(R + 5, generator=g)[:R].int()
+    dcols = (torch.arange(R) + (torch.arange(R) >= R // 2).int() * 7).int()          # a gap of 7 padded columns in the middle
+    ld = R + 7
+    dst = torch.zeros(Ccols, ld, dtype=dtype, device=dev())
+    rows_d, dcols_d = rows.to(dev()), dcols.to(dev())                                 # keep device copies alive across the launch
+    L.check(lib.mode_transpose(src.data_ptr(), src.stride(0), R, Ccols, dst.data_ptr(), ld, rows_d.data_ptr(),
+                               dcols_d.data_ptr(), DT[dtype], H.stream()))
+    ref = torch.zeros(Ccols, ld, dtype=dtype)
+    ref[:, dcols.long()] = src.cpu()[rows.long()].t()
+    assert torch.equal(dst.cpu(), ref)
+    dst2 = torch.empty(Ccols, R, dtype=dtype, device=dev())
+    L.check(lib.mode_transpose(src.data_ptr(), src.stride(0), R, Ccols, dst2.data_ptr(), R, None, None, DT[dtype], H.stream()))
+    assert torch.equal(dst2.cpu(), src.cpu()[:R].t())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_colsum_segments(dtype):
+    lib = L.load()
+    R, Cc = 3584, 8192 if dtype == torch.bfloat16 else 1024
+    X = rnd(R, Cc, seed=3).to(dtype).to(dev())
+    offs = torch.tensor([0, 1000, 1000, 2500, R], dtype=torch.int32, device=dev())
+    wsb = lib.mode_colsum_workspace_bytes(R, Cc, 4)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    out = torch.empty(4, Cc, device=dev())
+    L.check(lib.mode_colsum(X.data_ptr(), Cc, R, Cc, DT[dtype], offs.data_ptr(), 0, 4, out.data_ptr(), 0, ws.data_ptr(), wsb, H.stream()))
+    Xc = X.float().cpu()
+    ref = torch.stack([Xc[0:1000].sum(0), Xc[1000:1000].sum(0), Xc[1000:2500].sum(0), Xc[2500:].sum(0)])
+    assert rel(out, ref) < 1e-5
+    # uniform segments (per-sample sums over T=14 token rows) + accumulate
+    nseg = R // 14
+    wsb = lib.mode_colsum_workspace_bytes(R, Cc, nseg); ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    out2 = torch.ones(nseg, Cc, device=dev())
+    L.check(lib.mode_colsum(X.data_ptr(), Cc, R, Cc, DT[dtype], None, 14, nseg, out2.data_ptr(), 1, ws.data_ptr(), wsb, H.stream()))
+    assert rel(out2, 1 + Xc.view(nseg, 14, Cc).sum(1)) < 1e-5
+    # determinism
+    out3 = torch.ones(nseg, Cc, device=dev())
+    L.check(lib.mode_colsum(X.data_ptr(), Cc, R, Cc, DT[dtype], None, 14, nseg, out3.data_ptr(), 1, ws.data_ptr(), wsb, H.stream()))
+    assert torch.equal(out2, out3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_swiglu_fwd_bwd(dtype, p):
+    lib = L.load()
+    R, Hd = 300, 256
+    P = rnd(R, 2 * Hd, seed=4).to(dtype)
+    dH = rnd(R, Hd, seed=5).to(dtype)
+    out = torch.empty(R, Hd, dtype=dtype, device=dev()); dP = torch.empty(R, 2 * Hd, dtype=dtype, device=dev())
+    Pd, dHd = P.to(dev()), dH.to(dev())
+    L.check(lib.mode_swiglu_fwd(Pd.data_ptr(), out.data_ptr(), R, Hd, DT[dtype], 1234, p, H.stream()))
+    L.check(lib.mode_swiglu_bwd(Pd.data_ptr(), dHd.data_ptr(), dP.data_ptr(), R, Hd, DT[dtype], 1234, p, H.stream()))
+    Pf = P.float().requires_grad_(True)
+    h = Pf[:, :Hd] * torch.nn.functional.silu(Pf[:, Hd:])
+    o = out.float().cpu()
+    if p == 0:
+        mask = torch.ones_like(h)
+    else:
+        mask = (o != 0).float() / (1 - p)                                         # mask recovered from the forward output
+        keep = float((o != 0).float().mean())
+        assert abs(keep - (1 - p)) < 0.02                                         # Bernoulli(1-p) keep rate
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel(o, (h * mask).detach()) < tol
+    (h * mask).backward(dH.float())
+    assert rel(dP.float(), Pf.grad) < tol                                         # same mask regenerated in the backward
+
+
+@pytest.mark.parametrize("rows,D,k", [(37, 64, 0), (1792, 1024, 2), (112, 256, 1)])
+def test_rmsnorm_bwd_with_gather(rows, D, k):
+    lib = L.load()
+    x = rnd(rows, D, seed=6, scale=2.0); g = 1 + 0.1 * rnd(D, seed=7)
+    x[3] = 0.0                                                                     # eps-clamped row
+    da = rnd(rows, D, seed=8); db = rnd(rows, D, seed=9)
+    NK = rows * max(k, 1)
+    Gm = rnd(NK, D, seed=10); pos = torch.randperm(NK, generator=torch.Generator().manual_seed(11)).int()
+    dx0 = rnd(rows, D, seed=12)
+    dx = dx0.clone().to(dev()); nb = (rows + 3) // 4
+    dgp = torch.empty(nb, D, device=dev()); dyo = torch.empty(rows, D, device=dev())
+    xd, gd, dad, dbd, Gd, pd = (t.to(dev()) for t in (x, g, da, db, Gm, pos))
+    L.check(lib.mode_rmsnorm_bwd(xd.data_ptr(), gd.data_ptr(), dad.data_ptr(), dbd.data_ptr(), Gd.data_ptr() if k else None,
+                                 pd.data_ptr() if k else None, k, rows, D, 1e-6, dx.data_ptr(), 1, dgp.data_ptr(), dyo.data_ptr(), H.stream()))
+    xr = x.clone().requires_grad_(True); gr = g.clone().requires_grad_(True)
+    dy = da + db
+    if k:
+        dy = dy + Gm[pos.long()].view(rows, k, D).sum(1)
+    O.rmsnorm(xr, gr).backward(dy)
+    assert rel(dyo, dy) < 1e-6
+    assert rel(dx, dx0 + xr.grad) < 1e-5
+    assert rel(dgp.sum(0), gr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_combine_bwd(dtype):
+    lib = L.load()
+    N, D, k = 200, 256, 2
+    dy = rnd(N, D, seed=13); Y = rnd(N * k, D, seed=14).to(dtype)
+    pos = torch.randperm(N * k, generator=torch.Generator().manual_seed(15)).int(); posw = torch.rand(N * k, generator=torch.Generator().manual_seed(16))
+    dYs = torch.zeros(N * k, D, dtype=dtype, device=dev()); dw = torch.empty(N * k, device=dev())
+    dyd, Yd, pd, pwd = dy.to(dev()), Y.to(dev()), pos.to(dev()), posw.to(dev())
+    L.check(lib.mode_moe_combine_bwd(dyd.data_ptr(), Yd.data_ptr(), DT[dtype], pd.data_ptr(), pwd.data_ptr(), N, D, k, dYs.data_ptr(), dw.data_ptr(),
+                                     H.stream()))
+    Yf = Y.float().requires_grad_(True); w = posw.clone().requires_grad_(True)
+    nxt = (w.view(N, k, 1) * Yf[pos.long()].view(N, k, D)).sum(1)
+    nxt.backward(dy)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel(dYs.float(), Yf.grad) < tol
+    assert rel(dw, w.grad) < 1e-5
+
+
+def _attn_ref(qkv, qg, kg, B, T, Hh, hd, mask=None):
+    D = Hh * hd
+    q, k, v = (t.view(B, T, Hh, hd).transpose(1, 2) for t in qkv.split(D, dim=-1))
+    q = O.rmsnorm(q, qg); k = O.rmsnorm(k, kg)
+    att = (q @ k.transpose(-2, -1)) / (hd ** 0.5)
+    att = att.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril(), float("-inf")).softmax(-1)
+    if mask is not None:
+        att = att * mask
+    return (att @ v).transpose(1, 2).reshape(B * T, D)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,Hh,hd,p", [(3, 14, 4, 32, 0.0), (8, 14, 8, 128, 0.0), (4, 14, 2, 32, 0.3), (2, 13, 2, 64, 0.0)])
+def test_attention_backward(dtype, B, T, Hh, hd, p):
+    lib = L.load()
+    D = Hh * hd
+    qkv = rnd(B * T, 3 * D, seed=21).to(dtype)
+    qg = 1 + 0.1 * rnd(hd, seed=22); kg = 1 + 0.1 * rnd(hd, seed=23)
+    dy = rnd(B * T, D, seed=24).to(dtype)
+    seed = 777
+    mask = None
+    if p > 0:                                                                 # recover the hash mask: V := one-hot(token) -> O[:, :T] = Pd
+        probe = qkv.clone().float().view(B, T, 3, Hh, hd)
+        probe[:, :, 2] = 0
+        for t in range(T):
+            probe[:, t, 2, :, t] = 1.0
+        yp = H.attn(probe.view(B * T, 3 * D).to(dtype).to(dev()), qg.to(dev()), kg.to(dev()), B, T, Hh, hd, seed=seed, p_drop=p)
+        Pd = yp.float().cpu().view(B, T, Hh, hd)[..., :T].permute(0, 2, 1, 3)                # [B,H,q,k]
+        tril = torch.ones(T, T).tril().bool()
+        mask = ((Pd != 0) & tril).float() / (1 - p)
+        keep = float(((Pd != 0) & tril).float().sum() / (B * Hh * tril.sum()))
+        assert abs(keep - (1 - p)) < 0.06
+    qd, qgd, kgd, dyd = qkv.to(dev()), qg.to(dev()), kg.to(dev()), dy.to(dev())
+    dqkv = torch.full((B * T, 3 * D), float("nan"), dtype=dtype, device=dev())
+    pq = torch.empty(B * Hh, hd, device=dev()); pk = torch.empty(B * Hh, hd, device=dev())
+    L.check(lib.mode_attn_block_bwd(qd.data_ptr(), qgd.data_ptr(), kgd.data_ptr(), dyd.data_ptr(), dqkv.data_ptr(), pq.data_ptr(), pk.data_ptr(),
+                                    DT[dtype], B, T, Hh, hd, 1e-6, seed, p, H.stream()))
+    x = qkv.float().requires_grad_(True); a = qg.clone().requires_grad_(True); c = kg.clone().requires_grad_(True)
+    y = _attn_ref(x, a, c, B, T, Hh, hd, mask)
+    y.backward(dy.float())
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    assert rel(dqkv.float(), x.grad) < tol
+    assert rel(pq.sum(0), a.grad) < tol and rel(pk.sum(0), c.grad) < tol
+    if p > 0:                                                                 # forward with the same mask
+        yf = H.attn(qd, qgd, kgd, B, T, Hh, hd, seed=seed, p_drop=p)
+        assert rel(yf.float(), y.detach()) < (2e-2 if dtype == torch.bfloat16 else 1e-5)
