@@ -78,6 +78,9 @@ typedef struct ModeGemmDesc {
   int32_t num_experts;
   int32_t split_k;                /* bf16 only, epilogue NONE: K is cut into split_k slices; slice z writes its partial sums to   */
   int64_t split_stride;           /* C + z*split_stride (elements).  0/1 = no split.  The consumer adds the slabs in slice order. */
+  const int32_t* k_group_offsets; /* optional K-group mode (per-expert weight gradients dW_e = dY_e^T X_e): device int32[num_k_groups+1],  */
+  int32_t num_k_groups;           /* group z contracts over K in [off[z], off[z+1]) (multiples of 64 for bf16) and writes                 */
+  int64_t c_group_stride;         /* C + z*c_group_stride (elements); an empty range yields an all-zero C_z                                */
   int32_t flags;                  /* MODE_GEMM_SKINNY_OK: fp32, M <= 16 may use the weight-streaming GEMV kernel (wave-tree reduction
                                      instead of the MFMA k-ordered chain: same fp32 accuracy, different rounding)                   */
 } ModeGemmDesc;
@@ -130,10 +133,13 @@ int mode_moe_route_topk_f32(const float* logits, int R, int E, int k, int normal
  *         (tokens_per_row = T for the noise-conditioned router, 1 for per-token routing such as training multinomial).
  * Outputs: counts int32 [E]; offsets int32 [E+1]; perm int32 [N*k] sorted row -> token id;
  *          pos int32 [N*k]: (token, j) -> sorted row, j enumerating the token's experts in ASCENDING expert id;
- *          posw fp32 [N*k]: combine weight for (token, j).
+ *          posw fp32 [N*k]: combine weight for (token, j);
+ *          (optional, both or neither) poffsets int32 [E+1]: expert starts when every expert's rows are padded to a multiple of 64,
+ *          prow int32 [N*k]: sorted row -> padded position  (layout of the transposed operands of the weight-gradient GEMMs).
  * ------------------------------------------------------------------------------------------------------------------ */
 int mode_moe_dispatch_meta(const int32_t* idx, const float* w, int R, int tokens_per_row, int N, int E, int k,
-                           int32_t* counts, int32_t* offsets, int32_t* perm, int32_t* pos, float* posw, void* stream);
+                           int32_t* counts, int32_t* offsets, int32_t* perm, int32_t* pos, float* posw,
+                           int32_t* poffsets, int32_t* prow, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * mode_moe_combine_norm_fwd — x_next[t] = u[t] + sum_j posw[t,j] * Y[pos[t,j]]  (ascending expert order; the residual is
@@ -258,8 +264,9 @@ typedef struct ModeModelWeights {
 
 /* Dispatch-metadata record of one layer (4-byte word offsets inside the record), see mode_moe_dispatch_meta. */
 typedef struct ModeMetaLayout {
-  int32_t counts, offsets, perm, pos, posw;   /* word offsets */
+  int32_t counts, offsets, perm, pos, posw, poffsets, prow;   /* word offsets */
   int32_t total_words;                        /* record size (multiple of 4 words) */
+  int32_t padded_rows;                        /* static bound on poffsets[E]: ceil64(N*k) + 64*E */
 } ModeMetaLayout;
 int mode_moe_meta_layout(int N, int E, int k, ModeMetaLayout* out);
 

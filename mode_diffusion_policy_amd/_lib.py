@@ -28,7 +28,8 @@ class ModeGemmDesc(C.Structure):
     _fields_ = [("dtype", c_i32), ("epilogue", c_i32), ("out_dtype", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("A", c_vp), ("lda", c_i64), ("W", c_vp), ("ldw", c_i64), ("w_expert_stride", c_i64),
                 ("bias", c_vp), ("bias_expert_stride", c_i64), ("resid", c_vp), ("ldr", c_i64), ("C", c_vp), ("ldc", c_i64),
-                ("a_rows", c_vp), ("expert_offsets", c_vp), ("num_experts", c_i32), ("split_k", c_i32), ("split_stride", c_i64), ("flags", c_i32)]
+                ("a_rows", c_vp), ("expert_offsets", c_vp), ("num_experts", c_i32), ("split_k", c_i32), ("split_stride", c_i64), ("k_group_offsets", c_vp), ("num_k_groups", c_i32),
+                ("c_group_stride", c_i64), ("flags", c_i32)]
 
 
 class ModeEmbedDesc(C.Structure):
@@ -63,7 +64,8 @@ class ModeModelWeights(C.Structure):
 
 
 class ModeMetaLayout(C.Structure):
-    _fields_ = [("counts", c_i32), ("offsets", c_i32), ("perm", c_i32), ("pos", c_i32), ("posw", c_i32), ("total_words", c_i32)]
+    _fields_ = [("counts", c_i32), ("offsets", c_i32), ("perm", c_i32), ("pos", c_i32), ("posw", c_i32), ("poffsets", c_i32), ("prow", c_i32),
+                ("total_words", c_i32), ("padded_rows", c_i32)]
 
 
 class ModeForwardArgs(C.Structure):
@@ -86,7 +88,7 @@ PROTOTYPES = {
                                       c_f32, c_vp]),
     "mode_sigma_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, c_vp]),
     "mode_moe_route_topk_f32": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "mode_moe_dispatch_meta": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mode_moe_dispatch_meta": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mode_moe_combine_norm_fwd": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, c_i64, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp, C.c_int,
                                             c_f32, c_vp, c_vp, C.c_int, c_vp]),
     "mode_embed_tokens_fwd": (C.c_int, [P(ModeEmbedDesc), c_vp]),

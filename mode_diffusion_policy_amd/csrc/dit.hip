@@ -10,7 +10,7 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s);
 int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s);
 struct MetaBatch {
   const int* idx; const float* w; long idx_bstride;
-  int* counts; int* offsets; int* perm; int* pos; float* posw; long out_bstride;
+  int* counts; int* offsets; int* perm; int* pos; float* posw; int* poffsets; int* prow; long out_bstride;
 };
 int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N, int E, int k, hipStream_t s);
 
@@ -92,7 +92,10 @@ extern "C" int mode_moe_meta_layout(int N, int E, int k, ModeMetaLayout* out) {
   out->perm = take(NK);
   out->pos = take(NK);
   out->posw = take(NK);
+  out->poffsets = take(E + 1);
+  out->prow = take(NK);
   out->total_words = o;
+  out->padded_rows = (NK + 63) / 64 * 64 + 64 * E;
   return MODE_OK;
 }
 
@@ -103,7 +106,7 @@ extern "C" int mode_dit_dispatch(const int32_t* topk_idx, const float* topk_w, i
   int rc = mode_moe_meta_layout(N, E, k, &ml);
   if (rc) return rc;
   MetaBatch mb{topk_idx, topk_w, (long)idx_bstride, meta + ml.counts, meta + ml.offsets, meta + ml.perm, meta + ml.pos,
-               reinterpret_cast<float*>(meta + ml.posw), (long)ml.total_words};
+               reinterpret_cast<float*>(meta + ml.posw), meta + ml.poffsets, meta + ml.prow, (long)ml.total_words};
   return dispatch_meta_batched(mb, nbatch, R, tokens_per_row, N, E, k, (hipStream_t)stream);
 }
 

@@ -40,6 +40,7 @@ struct GemmParams {
   const int* a_rows; const int* offsets; int E;
   int M, N, K, m_tiles, n_tiles;
   int split_k; long split_stride;     // split-K: blockIdx.y = K-slice, output slab = C + slice*split_stride elements
+  const int* koffs; long c_gstride;   // K-groups (weight gradients per expert): blockIdx.z = group, K range [koffs[z], koffs[z+1])
 };
 
 template <int N>
@@ -198,8 +199,12 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
   };
 
   // ---- main loop
-  const int nk = p.K / BK / p.split_k;                            // K-tiles of this slice
-  const int kt0 = blockIdx.y * nk;
+  int nk = p.K / BK / p.split_k;                                  // K-tiles of this slice
+  int kt0 = blockIdx.y * nk;
+  if (p.koffs) {                                                   // K-group mode: this workgroup reduces over one expert's (64-padded) rows
+    const int kb = p.koffs[blockIdx.z], ke = p.koffs[blockIdx.z + 1];
+    kt0 = kb / BK; nk = (ke - kb) / BK;
+  }
   constexpr int PRE = (NS == 1) ? 1 : NS - 1;                      // tiles in flight before the loop
 #pragma unroll
   for (int s = 0; s < PRE; ++s)
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
 
   // ---- epilogue: bias / SwiGLU in registers (lane owns row ..+(l&15), 4 consecutive columns) -> swizzled LDS tile -> coalesced stores.
   //      One pass when the whole output tile fits the operand ring, else one pass per wave-row group (TM rows).
-  char* Cout = reinterpret_cast<char*>(p.C) + (long)blockIdx.y * p.split_stride * ESZ;
+  char* Cout = reinterpret_cast<char*>(p.C) + ((long)blockIdx.y * p.split_stride + (long)blockIdx.z * p.c_gstride) * ESZ;
   const int rows_valid = row_end - row0;
   __builtin_amdgcn_s_barrier();                                    // all waves are done reading operand tiles
   constexpr int EPASS = (BM * CROW <= NS * STAGE_BYTES) ? 1 : WM;   // epilogue passes
@@ -330,7 +335,7 @@ static int launch_cfg(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles, p.split_k), dim3(WM * WN * 64), LDS, s, p);
+  hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles, p.split_k, d->k_group_offsets ? d->num_k_groups : 1), dim3(WM * WN * 64), LDS, s, p);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
@@ -383,6 +388,8 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.split_k = d->split_k > 1 ? d->split_k : 1; p.split_stride = d->split_stride;
   if (d->K % (BK * p.split_k) != 0) return MODE_ERR_UNSUPPORTED;
   if (p.split_k > 1 && d->epilogue != MODE_EPI_NONE) return MODE_ERR_UNSUPPORTED;
+  p.koffs = d->k_group_offsets; p.c_gstride = d->c_group_stride;
+  if (p.koffs && (d->num_k_groups <= 0 || p.split_k > 1 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
   const int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d);
   const bool ob = d->out_dtype == MODE_BF16;
 #define MODE_CASE(E) \

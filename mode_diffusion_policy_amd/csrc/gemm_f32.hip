@@ -16,6 +16,7 @@ struct GemmF32Params {
   const float* resid; long ldr;
   void* C; long ldc;
   const int* a_rows; const int* offsets; int E;
+  const int* koffs; long c_gstride;
   int M, N, K, m_tiles, n_tiles;
 };
 
@@ -75,19 +76,21 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
     b_row[j] = (br + fr) * FLD;
   }
 
-  const int nk = (p.K + FBK - 1) / FBK;
+  int kbeg = 0, kend = p.K;
+  if (p.koffs) { kbeg = p.koffs[blockIdx.z]; kend = p.koffs[blockIdx.z + 1]; }
+  const int nk = (kend - kbeg + FBK - 1) / FBK;
   float4 ra, rb;
   auto gload = [&](int kt) {
-    const int k = kt * FBK + kq;
+    const int k = kbeg + kt * FBK + kq;
     if constexpr (VEC) {
-      ra = *reinterpret_cast<const float4*>(a_src + kt * FBK);
-      rb = *reinterpret_cast<const float4*>(b_src + kt * FBK);
+      ra = *reinterpret_cast<const float4*>(a_src + kbeg + kt * FBK);
+      rb = *reinterpret_cast<const float4*>(b_src + kbeg + kt * FBK);
     } else {
-      const float* a = a_src + kt * FBK; const float* b = b_src + kt * FBK;
-      ra.x = (k + 0 < p.K) ? a[0] : 0.f; ra.y = (k + 1 < p.K) ? a[1] : 0.f;
-      ra.z = (k + 2 < p.K) ? a[2] : 0.f; ra.w = (k + 3 < p.K) ? a[3] : 0.f;
-      rb.x = (k + 0 < p.K) ? b[0] : 0.f; rb.y = (k + 1 < p.K) ? b[1] : 0.f;
-      rb.z = (k + 2 < p.K) ? b[2] : 0.f; rb.w = (k + 3 < p.K) ? b[3] : 0.f;
+      const float* a = a_src + kbeg + kt * FBK; const float* b = b_src + kbeg + kt * FBK;
+      ra.x = (k + 0 < kend) ? a[0] : 0.f; ra.y = (k + 1 < kend) ? a[1] : 0.f;
+      ra.z = (k + 2 < kend) ? a[2] : 0.f; ra.w = (k + 3 < kend) ? a[3] : 0.f;
+      rb.x = (k + 0 < kend) ? b[0] : 0.f; rb.y = (k + 1 < kend) ? b[1] : 0.f;
+      rb.z = (k + 2 < kend) ? b[2] : 0.f; rb.w = (k + 3 < kend) ? b[3] : 0.f;
     }
   };
   auto commit = [&](int buf) {
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
     b[0] = rb.x; b[1] = rb.y; b[2] = rb.z; b[3] = rb.w;
   };
 
-  gload(0); commit(0);
+  if (nk > 0) { gload(0); commit(0); }
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
     const bool more = (kt + 1) < nk;
@@ -121,8 +124,9 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
   const int rows_valid = row_end - row0;
   auto store = [&](long m, int n, float v) {
     if (n < p.N) {
-      if constexpr (OUT_BF16) reinterpret_cast<uint16_t*>(p.C)[m * p.ldc + n] = f32_to_bf16_bits(v);
-      else reinterpret_cast<float*>(p.C)[m * p.ldc + n] = v;
+      const long o = (long)blockIdx.z * p.c_gstride + m * p.ldc + n;
+      if constexpr (OUT_BF16) reinterpret_cast<uint16_t*>(p.C)[o] = f32_to_bf16_bits(v);
+      else reinterpret_cast<float*>(p.C)[o] = v;
     }
   };
 #pragma unroll
@@ -209,9 +213,9 @@ static int launch_skinny(const ModeGemmDesc* d, hipStream_t s) {
 }
 
 template <int EPI, bool OUT_BF16>
-static int launch_f32(const GemmF32Params& p, int nblk, bool vec, hipStream_t s) {
-  if (vec) hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, true>), dim3(nblk), dim3(FNT), 0, s, p);
-  else hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, false>), dim3(nblk), dim3(FNT), 0, s, p);
+static int launch_f32(const GemmF32Params& p, int nblk, bool vec, int ngroups, hipStream_t s) {
+  if (vec) hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, true>), dim3(nblk, 1, ngroups), dim3(FNT), 0, s, p);
+  else hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, false>), dim3(nblk, 1, ngroups), dim3(FNT), 0, s, p);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
@@ -240,8 +244,11 @@ int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s) {
   const bool vec = (d->K % FBK == 0) && (d->lda % 4 == 0) && (d->ldw % 4 == 0) && (d->w_expert_stride % 4 == 0) &&
                    (((uintptr_t)d->A | (uintptr_t)d->W) % 16 == 0);
   const bool ob = d->out_dtype == MODE_BF16;
+  p.koffs = d->k_group_offsets; p.c_gstride = d->c_group_stride;
+  const int ng = d->k_group_offsets ? d->num_k_groups : 1;
+  if (d->k_group_offsets && (d->num_k_groups <= 0 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
 #define MODE_CASE(E) \
-  case E: return ob ? launch_f32<E, true>(p, nblk, vec, s) : launch_f32<E, false>(p, nblk, vec, s);
+  case E: return ob ? launch_f32<E, true>(p, nblk, vec, ng, s) : launch_f32<E, false>(p, nblk, vec, ng, s);
   switch (d->epilogue) {
     MODE_CASE(MODE_EPI_NONE)
     MODE_CASE(MODE_EPI_BIAS)

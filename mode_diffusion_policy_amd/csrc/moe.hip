@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void route_topk_kernel(const float* __restrict
 // ---- dispatch metadata: one workgroup per problem (layer); blockDim = 1024
 struct MetaBatch {
   const int* idx; const float* w; long idx_bstride;          // [R,k] per problem
-  int* counts; int* offsets; int* perm; int* pos; float* posw; long out_bstride;  // strides in 4-byte words
+  int* counts; int* offsets; int* perm; int* pos; float* posw; int* poffsets; int* prow; long out_bstride;  // strides in 4-byte words
 };
 
 __global__ __launch_bounds__(1024) void dispatch_meta_kernel(MetaBatch mb, int R, int tpr, int N, int E, int k) {
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(1024) void dispatch_meta_kernel(MetaBatch mb, int R
   const float* w = mb.w + (long)blockIdx.x * mb.idx_bstride;
   int* counts = mb.counts + bo; int* offsets = mb.offsets + bo; int* perm = mb.perm + bo; int* pos = mb.pos + bo;
   float* posw = mb.posw + bo;
+  int* poffsets = mb.poffsets ? mb.poffsets + bo : nullptr; int* prow = mb.prow ? mb.prow + bo : nullptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
 
   if (tid == 0) s_offsets[0] = 0;
@@ -104,6 +105,17 @@ __global__ __launch_bounds__(1024) void dispatch_meta_kernel(MetaBatch mb, int R
   }
   if (tid == 0)
     for (int e = 0; e <= E; ++e) offsets[e] = s_offsets[e];
+  if (poffsets) {
+    // 64-padded layout for the weight-gradient GEMMs: expert e's rows start at poffsets[e] (multiple of 64); prow[p] = padded position
+    __shared__ int s_poff[65];
+    if (tid == 0) {
+      int a = 0;
+      for (int e = 0; e <= E; ++e) { s_poff[e] = a; poffsets[e] = a; if (e < E) a += (s_offsets[e + 1] - s_offsets[e] + 63) / 64 * 64; }
+    }
+    __syncthreads();
+    for (int e = 0; e < E; ++e)
+      for (int r = s_offsets[e] + tid; r < s_offsets[e + 1]; r += blockDim.x) prow[r] = s_poff[e] + (r - s_offsets[e]);
+  }
 }
 
 }  // namespace mode
@@ -135,8 +147,9 @@ int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N
 }  // namespace mode
 
 extern "C" int mode_moe_dispatch_meta(const int32_t* idx, const float* w, int R, int tokens_per_row, int N, int E, int k, int32_t* counts,
-                                      int32_t* offsets, int32_t* perm, int32_t* pos, float* posw, void* stream) {
-  if (!idx || !w || !counts || !offsets || !perm || !pos || !posw) return MODE_ERR_BAD_ARG;
-  MetaBatch mb{idx, w, 0, counts, offsets, perm, pos, posw, 0};
+                                      int32_t* offsets, int32_t* perm, int32_t* pos, float* posw, int32_t* poffsets, int32_t* prow,
+                                      void* stream) {
+  if (!idx || !w || !counts || !offsets || !perm || !pos || !posw || (!poffsets != !prow)) return MODE_ERR_BAD_ARG;
+  MetaBatch mb{idx, w, 0, counts, offsets, perm, pos, posw, poffsets, prow, 0};
   return dispatch_meta_batched(mb, 1, R, tokens_per_row, N, E, k, (hipStream_t)stream);
 }

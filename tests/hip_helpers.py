@@ -54,9 +54,10 @@ def dispatch_meta(idx, w, tokens_per_row, N, E):
     i32 = lambda *s: torch.full(s, -1, dtype=torch.int32, device=dev)
     counts, offsets, perm, pos = i32(E), i32(E + 1), i32(N * k), i32(N * k)
     posw = torch.empty(N * k, dtype=torch.float32, device=dev)
+    poffsets, prow = i32(E + 1), i32(N * k)
     L.check(lib.mode_moe_dispatch_meta(p(idx), p(w), R, tokens_per_row, N, E, k, p(counts), p(offsets), p(perm), p(pos), p(posw),
-                                       stream()), "dispatch_meta")
-    return dict(counts=counts, offsets=offsets, perm=perm, pos=pos, posw=posw)
+                                       p(poffsets), p(prow), stream()), "dispatch_meta")
+    return dict(counts=counts, offsets=offsets, perm=perm, pos=pos, posw=posw, poffsets=poffsets, prow=prow)
 
 
 def rmsnorm(x, g, cond=None, rows_per_cond=1, eps=1e-6, lp_dtype=torch.bfloat16, want_f32=True):

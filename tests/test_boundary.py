@@ -43,7 +43,8 @@ def test_ctypes_struct_sizes_match_header_layout():
     ml = L.ModeMetaLayout()
     assert lib.mode_moe_meta_layout(1792, 4, 2, C.byref(ml)) == 0
     assert ml.perm % 4 == 0 and ml.total_words >= 3 * 3584 + 9
-    assert ml.counts < ml.offsets < ml.perm < ml.pos < ml.posw < ml.total_words
+    assert ml.counts < ml.offsets < ml.perm < ml.pos < ml.posw < ml.poffsets < ml.prow < ml.total_words
+    assert ml.padded_rows == 3584 + 256
     dims = L.ModeDims(D=1024, H=8, L=12, E=4, k=2, T=14, A_len=10, A_dim=7, O=2048, G=512, n_img=2, use_noise_token=1,
                       router_normalize=1, eps=1e-6)
     nb = lib.mode_dit_workspace_bytes(C.byref(dims), 128, 10, L.MODE_BF16)

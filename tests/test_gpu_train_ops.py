@@ -184,3 +184,33 @@ def test_attention_backward(dtype, B, T, Hh, hd, p):
     if p > 0:                                                                 # forward with the same mask
         yf = H.attn(qd, qgd, kgd, B, T, Hh, hd, seed=seed, p_drop=p)
         assert rel(yf.float(), y.detach()) < (2e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_expert_weight_gradient_gemm(dtype):
+    """dW2_e = dY_e^T H_e for all experts in ONE launch: transposes into the 64-padded per-expert layout + K-group GEMM."""
+    lib = L.load()
+    N, E, k, D, Hd = 300, 4, 2, 64, 256
+    g = torch.Generator().manual_seed(31)
+    probs = torch.rand(N, E, generator=g); probs[:, 3] = 0                       # expert 3 gets no token -> its gradient must be exactly 0
+    idx = torch.sort(probs, dim=-1, descending=True, stable=True).indices[:, :k].contiguous()
+    w = probs.gather(1, idx)
+    meta = H.dispatch_meta(idx.int().to(dev()), w.to(dev()), 1, N, E)
+    counts = meta["counts"].cpu().long(); poff = meta["poffsets"].cpu().long()
+    assert torch.equal(poff[1:] - poff[:-1], (counts + 63) // 64 * 64)
+    NK = N * k; NKp = (NK + 63) // 64 * 64 + 64 * E
+    dY = rnd(NK, D, seed=32).to(dtype).to(dev()); Hs = rnd(NK, Hd, seed=33).to(dtype).to(dev())
+    dYT = torch.zeros(D, NKp, dtype=dtype, device=dev()); HT = torch.zeros(Hd, NKp, dtype=dtype, device=dev())
+    L.check(lib.mode_transpose(dY.data_ptr(), D, NK, D, dYT.data_ptr(), NKp, None, meta["prow"].data_ptr(), DT[dtype], H.stream()))
+    L.check(lib.mode_transpose(Hs.data_ptr(), Hd, NK, Hd, HT.data_ptr(), NKp, None, meta["prow"].data_ptr(), DT[dtype], H.stream()))
+    dW = torch.full((E, D, Hd), float("nan"), device=dev())
+    d = L.ModeGemmDesc(dtype=DT[dtype], epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=D, N=Hd, K=NKp, A=dYT.data_ptr(), lda=NKp, W=HT.data_ptr(),
+                       ldw=NKp, C=dW.data_ptr(), ldc=Hd, k_group_offsets=meta["poffsets"].data_ptr(), num_k_groups=E, c_group_stride=D * Hd)
+    L.check(lib.mode_gemm(C.byref(d), H.stream()))
+    offs = meta["offsets"].cpu().long()
+    for e in range(E):
+        ref = dY[offs[e]: offs[e + 1]].float().cpu().t() @ Hs[offs[e]: offs[e + 1]].float().cpu()
+        if counts[e] == 0:
+            assert float(dW[e].abs().max()) == 0.0
+        else:
+            assert rel(dW[e], ref) < (3e-3 if dtype == torch.bfloat16 else 1e-5)
