@@ -227,12 +227,24 @@ int mode_swiglu_bwd(const void* P, const void* dHd, void* dP, int64_t rows, int 
  * NULL / k = 0; the gather-sum is the MoE dispatch backward); dx (+)= d/dx; dg_partial [ceil(rows/4), D] per-workgroup partial gain
  * gradients (reduce with mode_colsum); dy_out (optional) receives the assembled dy (the conditioning gradient needs it). */
 int mode_rmsnorm_bwd(const float* x, const float* g, const float* dy_a, const float* dy_b, const float* G, const int32_t* pos, int k,
-                     int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* stream);
+                     int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* dx_lp,
+                     int lp_dtype, void* stream);   /* dx_lp (optional): compute-dtype copy of the final dx (next GEMM's operand) */
 
 /* mode_moe_combine_bwd — backward of next[t] += w[t,e] * expert_e(u[t]) (modedit.py:566): dYs[pos[t,j]] = posw[t,j] * dy[t] (sorted
  * rows, compute dtype) and dw[t,j] = <dy[t], Y[pos[t,j]]> (router-weight gradient, SURVEY §8 a-bis). */
 int mode_moe_combine_bwd(const float* dy, const void* Y, int y_dtype, const int32_t* pos, const float* posw, int N, int D, int k,
                          void* dYs, float* dw, void* stream);
+
+/* Small fp32 helpers of the backward chain. */
+int mode_rowcopy_f32(const float* src, int64_t ld_src, int s0, int sstride, const int32_t* sidx, float* dst, int64_t ld_dst, int d0,
+                     int dstride, const int32_t* didx, const float* add, int64_t ld_add, int n, int D, void* stream);
+int mode_gelu_fwd(const float* pre, float* out, int64_t n, void* stream);                       /* router GELU (modedit.py:198)      */
+int mode_gelu_bwd(const float* pre, const float* dout, float* dpre, int64_t n, void* stream);
+/* Router backward on distinct conditioning rows: dw [B*T, k] (slot j = j-th expert in ASCENDING id, as mode_moe_combine_bwd writes it),
+ * idx [B or B*T, k] top-k ids, probs [B, E] -> dlogits [B, E]; through renormalisation, clamp and softmax (SURVEY §8 a-bis). */
+int mode_moe_router_bwd(const float* dw, const int32_t* idx, const float* probs, int B, int T, int E, int k, int normalize,
+                        int idx_per_token, float* dlogits, void* stream);
+int mode_sigma_embed_bwd(const float* de1, const float* sigma, int B, int D, float* dw, float* db, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Whole-denoiser forward: the launch chain of one MoDeDiT.forward (modedit.py:741-821) [+ GCDenoiser.forward scalings
@@ -290,8 +302,12 @@ int mode_dit_embed_obs(const ModeDims* dims, const ModeModelWeights* w, const fl
  * per layer Linear(D,2D)+GELU -> Linear(2D,E) -> softmax/clamp/top-k.   (modedit.py:194-202, 336, 345-349, 392)
  * Outputs (device, caller-owned): topk_idx int32 [L, R, k]; topk_w fp32 [L, R, k]; probs / shifted fp32 [L, R, E] or NULL. */
 int mode_dit_route(const ModeDims* dims, const ModeModelWeights* w, const float* cond, int R,
-                   int32_t* topk_idx, float* topk_w, float* probs, float* shifted,
+                   int32_t* topk_idx, float* topk_w, float* probs, float* shifted, float* r_pre /* [L,R,2D] pre-GELU, training */,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* combine weights for HOST-chosen expert ids (training: torch.multinomial per token row, modedit.py:390):
+ * w[n, j] = probs[n / tokens_per_row, idx[n, j]] (/ their sum when normalize). */
+int mode_moe_weights_from_idx(const float* probs, const int32_t* idx, int N, int tokens_per_row, int E, int k, int normalize, float* w,
+                              void* stream);
 
 typedef struct ModeForwardArgs {
   int32_t B; int32_t dtype;
@@ -306,6 +322,60 @@ typedef struct ModeForwardArgs {
 } ModeForwardArgs;
 int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w, const ModeForwardArgs* a,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training chains (score-matching step).  mode_dit_forward_train = MoDeDiT.forward in .train() mode (per-token routing ids chosen by
+ * the host, attention / expert dropout) that keeps every activation the backward needs in `stash`; mode_dit_backward turns dF into
+ * the gradient of every parameter (written, not accumulated) — the HIP counterpart of autograd over modedit.py:741-821.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ModeStashLayout {
+  uint64_t x0, h1, qkv, yattn, x1, ub, P, Hd, Y;     /* byte offsets inside one layer record */
+  uint64_t layer_stride;
+  uint64_t xL, yL, u_tmp, global_bytes;              /* global part (precedes the layer records) */
+  uint64_t total_bytes;
+} ModeStashLayout;
+int mode_dit_train_stash_layout(const ModeDims* dims, int B, int dtype, ModeStashLayout* out);
+size_t mode_dit_train_workspace_bytes(const ModeDims* dims, int B, int dtype);
+
+typedef struct ModeTrainArgs {
+  int32_t B; int32_t dtype;
+  uint32_t seed; float attn_pdrop; float mlp_pdrop;
+  const float* sigma;            /* [B]                                                     */
+  const float* e1;               /* [B, D]  Linear(1,D)(ln sigma / 4)  (mode_sigma_embed)    */
+  const float* emb_t;            /* [B, D]                                                   */
+  const float* cond;             /* [B, D]  additive conditioning = router input             */
+  int32_t goal_in_cond;          /* use_goal_in_routing: cond = emb_t + goal_e               */
+  const float* state_images; const float* goals;          /* raw inputs [B*n_img, O], [B, G] (embedding weight gradients) */
+  const float* goal_e; const float* img_e;                /* hoisted embeddings                                          */
+  const float* actions; const float* c_in; int64_t c_in_stride;   /* un-scaled noisy actions [B, A_len, A]; c_in [B] or NULL      */
+  const float* actions_scaled;                            /* actions * c_in (backward of action_emb)                     */
+  const int32_t* act_rows;                                /* [B*A_len] token row of every action token                    */
+  const int32_t* meta; int64_t meta_layer_stride;         /* L per-token dispatch records                                 */
+  const int32_t* topk_idx; int64_t topk_layer_stride; int32_t idx_per_token;   /* [L][B*T or B][k] expert ids            */
+  const float* probs;            /* [L, B, E] clamped softmax of the router                  */
+  const float* r_pre;            /* [L, B, 2D] router pre-GELU activations                   */
+  float* F;                      /* out: [B, A_len, A]                                       */
+} ModeTrainArgs;
+int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes,
+                           void* stream);
+
+typedef struct ModeLayerGrads {           /* fp32 gradients, same shapes as ModeLayerWeights (packed qkv / stacked experts) */
+  float* ln1_g; float* ln2_g; float* qn_g; float* kn_g; float* wqkv; float* bqkv; float* wo;
+  float* r_w0; float* r_b0; float* r_w3; float* r_b3; float* w1; float* b1; float* w2;
+} ModeLayerGrads;
+typedef struct ModeModelGrads {
+  float* pos; float* w_se; float* b_se; float* w_sl; float* w_tok; float* w_goal; float* w_act; float* ln_g; float* w_out; float* b_out;
+  const ModeLayerGrads* layers;
+} ModeModelGrads;
+typedef struct ModeLayerWeightsT {        /* transposed shadows for the data-gradient GEMMs (compute dtype / fp32 for the router) */
+  const void* wqkvT;  /* [D, 3D] */  const void* woT;   /* [D, D] */
+  const void* w1T;    /* [E][D, 8D] */ const void* w2T;  /* [E][4D, D] */
+  const float* r_w0T; /* [D, 2D] */  const float* r_w3T; /* [2D, E] */
+} ModeLayerWeightsT;
+typedef struct ModeModelWeightsT { const float* w_slT; /* [D, D] */ const float* w_outT; /* [D, A] */ const ModeLayerWeightsT* layers; } ModeModelWeightsT;
+int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w, const ModeModelWeightsT* wt, const ModeTrainArgs* a,
+                      const void* stash, const float* dF, const ModeModelGrads* grads, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 #ifdef __cplusplus
 }

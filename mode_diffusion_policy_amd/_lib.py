@@ -68,6 +68,39 @@ class ModeMetaLayout(C.Structure):
                 ("total_words", c_i32), ("padded_rows", c_i32)]
 
 
+c_u64, c_u32 = C.c_uint64, C.c_uint32
+
+
+class ModeStashLayout(C.Structure):
+    _fields_ = [(n, c_u64) for n in ("x0", "h1", "qkv", "yattn", "x1", "ub", "P", "Hd", "Y", "layer_stride", "xL", "yL", "u_tmp", "global_bytes",
+                                     "total_bytes")]
+
+
+class ModeTrainArgs(C.Structure):
+    _fields_ = [("B", c_i32), ("dtype", c_i32), ("seed", c_u32), ("attn_pdrop", c_f32), ("mlp_pdrop", c_f32), ("sigma", c_vp), ("e1", c_vp),
+                ("emb_t", c_vp), ("cond", c_vp), ("goal_in_cond", c_i32), ("state_images", c_vp), ("goals", c_vp), ("goal_e", c_vp),
+                ("img_e", c_vp), ("actions", c_vp), ("c_in", c_vp), ("c_in_stride", c_i64), ("actions_scaled", c_vp), ("act_rows", c_vp),
+                ("meta", c_vp), ("meta_layer_stride", c_i64), ("topk_idx", c_vp), ("topk_layer_stride", c_i64), ("idx_per_token", c_i32),
+                ("probs", c_vp), ("r_pre", c_vp), ("F", c_vp)]
+
+
+class ModeLayerGrads(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("ln1_g", "ln2_g", "qn_g", "kn_g", "wqkv", "bqkv", "wo", "r_w0", "r_b0", "r_w3", "r_b3", "w1", "b1", "w2")]
+
+
+class ModeModelGrads(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("pos", "w_se", "b_se", "w_sl", "w_tok", "w_goal", "w_act", "ln_g", "w_out", "b_out")] + \
+               [("layers", C.POINTER(ModeLayerGrads))]
+
+
+class ModeLayerWeightsT(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("wqkvT", "woT", "w1T", "w2T", "r_w0T", "r_w3T")]
+
+
+class ModeModelWeightsT(C.Structure):
+    _fields_ = [("w_slT", c_vp), ("w_outT", c_vp), ("layers", C.POINTER(ModeLayerWeightsT))]
+
+
 class ModeForwardArgs(C.Structure):
     _fields_ = [("B", c_i32), ("dtype", c_i32), ("emb_t", c_vp), ("emb_row_stride", c_i64), ("cond", c_vp),
                 ("cond_row_stride", c_i64), ("meta", c_vp), ("meta_layer_stride", c_i64), ("goal_e", c_vp), ("img_e", c_vp),
@@ -99,14 +132,25 @@ PROTOTYPES = {
     "mode_colsum": (C.c_int, [c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_vp, c_sz, c_vp]),
     "mode_swiglu_fwd": (C.c_int, [c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_uint32, c_f32, c_vp]),
     "mode_swiglu_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_uint32, c_f32, c_vp]),
-    "mode_rmsnorm_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_f32, c_vp, C.c_int, c_vp, c_vp, c_vp]),
+    "mode_rmsnorm_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_f32, c_vp, C.c_int, c_vp, c_vp, c_vp, C.c_int, c_vp]),
+    "mode_rowcopy_f32": (C.c_int, [c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "mode_gelu_fwd": (C.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "mode_gelu_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "mode_moe_router_bwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
+    "mode_sigma_embed_bwd": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
     "mode_moe_combine_bwd": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
     "mode_moe_meta_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, P(ModeMetaLayout)]),
     "mode_dit_dispatch": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
     "mode_dit_workspace_bytes": (c_sz, [P(ModeDims), C.c_int, C.c_int, C.c_int]),
     "mode_dit_sigma_embed": (C.c_int, [P(ModeDims), P(ModeModelWeights), c_vp, C.c_int, c_vp, c_vp, c_sz, c_vp]),
     "mode_dit_embed_obs": (C.c_int, [P(ModeDims), P(ModeModelWeights), c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
-    "mode_dit_route": (C.c_int, [P(ModeDims), P(ModeModelWeights), c_vp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mode_dit_route": (C.c_int, [P(ModeDims), P(ModeModelWeights), c_vp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mode_moe_weights_from_idx": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
+    "mode_dit_train_stash_layout": (C.c_int, [P(ModeDims), C.c_int, C.c_int, P(ModeStashLayout)]),
+    "mode_dit_train_workspace_bytes": (c_sz, [P(ModeDims), C.c_int, C.c_int]),
+    "mode_dit_forward_train": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeTrainArgs), c_vp, c_sz, c_vp]),
+    "mode_dit_backward": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeModelWeightsT), P(ModeTrainArgs), c_vp, c_vp, P(ModeModelGrads),
+                                    c_vp, c_sz, c_vp]),
     "mode_dit_forward": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeForwardArgs), c_vp, c_sz, c_vp]),
 }
 

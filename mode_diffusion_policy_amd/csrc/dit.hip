@@ -153,7 +153,7 @@ extern "C" int mode_dit_embed_obs(const ModeDims* dims, const ModeModelWeights* 
 }
 
 extern "C" int mode_dit_route(const ModeDims* dims, const ModeModelWeights* w, const float* cond, int R, int32_t* topk_idx, float* topk_w,
-                              float* probs, float* shifted, void* workspace, size_t workspace_bytes, void* stream) {
+                              float* probs, float* shifted, float* r_pre, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_dims(dims);
   if (rc) return rc;
   if (!w || !w->layers || !cond || !topk_idx || !topk_w || !workspace || R <= 0) return MODE_ERR_BAD_ARG;
@@ -165,9 +165,19 @@ extern "C" int mode_dit_route(const ModeDims* dims, const ModeModelWeights* w, c
   const int D = dims->D, E = dims->E, k = dims->k;
   for (int l = 0; l < dims->L; ++l) {
     const ModeLayerWeights& lw = w->layers[l];
-    ModeGemmDesc g = gemm_desc(MODE_F32, MODE_EPI_BIAS_GELU, MODE_F32, R, 2 * D, D, cond, D, lw.r_w0, D, hid, 2 * D);
-    g.bias = lw.r_b0; g.flags = MODE_GEMM_SKINNY_OK;       // R <= 16 distinct sigma rows (sampler): stream the router weights once
-    rc = mode_gemm(&g, stream);
+    ModeGemmDesc g;
+    if (r_pre) {                                              // training: keep the pre-GELU activations for the router backward
+      float* pre = r_pre + (long)l * R * 2 * D;
+      g = gemm_desc(MODE_F32, MODE_EPI_BIAS, MODE_F32, R, 2 * D, D, cond, D, lw.r_w0, D, pre, 2 * D);
+      g.bias = lw.r_b0;
+      rc = mode_gemm(&g, stream);
+      if (rc) return rc;
+      rc = mode_gelu_fwd(pre, hid, (long)R * 2 * D, stream);
+    } else {
+      g = gemm_desc(MODE_F32, MODE_EPI_BIAS_GELU, MODE_F32, R, 2 * D, D, cond, D, lw.r_w0, D, hid, 2 * D);
+      g.bias = lw.r_b0; g.flags = MODE_GEMM_SKINNY_OK;     // R <= 16 distinct sigma rows (sampler): stream the router weights once
+      rc = mode_gemm(&g, stream);
+    }
     if (rc) return rc;
     g = gemm_desc(MODE_F32, MODE_EPI_BIAS, MODE_F32, R, E, 2 * D, hid, 2 * D, lw.r_w3, 2 * D, logits, E);
     g.bias = lw.r_b3; g.flags = MODE_GEMM_SKINNY_OK;

@@ -1,0 +1,363 @@
+// Training launch chains of the MoDE denoiser: forward with an activation stash (per-token routing indices
+// from the host-side multinomial, attention / expert dropout by counter-based hash masks) and the full backward — every gradient of
+// MoDeDiT's parameters — as one C++ launch chain of HIP kernels: no host sync, no floating-point atomics (deterministic).
+//
+// Backward of a Linear y = x W^T reuses the MFMA GEMM twice:  dx = dy @ (W^T)^T  with a pre-transposed weight shadow, and
+// dW = dy^T x as GEMM(A = dy^T, "W" = x^T) on operands produced by mode_transpose (per-expert 64-padded for the grouped GEMMs,
+// contracted with the K-group mode so one launch covers all experts; experts without tokens get exact zeros).
+#include "mode_common.h"
+
+#include <string.h>
+
+using namespace mode;
+
+namespace {
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Take {
+  size_t o = 0;
+  size_t operator()(size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; }
+};
+
+ModeGemmDesc gdesc(int dtype, int epi, int out_dtype, int M, int N, int K, const void* A, long lda, const void* W, long ldw, void* C, long ldc) {
+  ModeGemmDesc g;
+  memset(&g, 0, sizeof(g));
+  g.dtype = dtype; g.epilogue = epi; g.out_dtype = out_dtype; g.M = M; g.N = N; g.K = K;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc;
+  return g;
+}
+
+struct TrainWs {   // backward workspace offsets
+  size_t dxa, dxb, dyl, dys, dhd, dp, dus, dwt, t_big, t_mid, t_d, t_d2, dx1lp, dyattn, dqkv, dh1, dgp, apq, apk, csw, dcond, dlog, dhid, dpre,
+      st1, st2, tmp_rd, demb, de1, dimg, dgoal, total;
+};
+
+TrainWs train_ws(const ModeDims& d, int B, int dtype) {
+  const size_t esz = dtype == MODE_BF16 ? 2 : 4;
+  const size_t N = (size_t)B * d.T, NK = N * d.k, D = d.D;
+  const size_t NKp = (NK + 63) / 64 * 64 + 64 * (size_t)d.E, Np = (N + 63) / 64 * 64;
+  const size_t R = (size_t)B * d.A_len;
+  TrainWs w{};
+  Take t;
+  w.dxa = t(N * D * 4); w.dxb = t(N * D * 4); w.dyl = t(N * D * 4);
+  w.dys = t(NK * D * esz); w.dhd = t(NK * 4 * D * esz); w.dp = t(NK * 8 * D * esz); w.dus = t(NK * D * 4); w.dwt = t(NK * 4);
+  w.t_big = t(8 * D * NKp * esz);            // dP^T  [8D, NKp]   (also dqkv^T [3D, Np])
+  w.t_mid = t(4 * D * NKp * esz);            // Hd^T  [4D, NKp]
+  w.t_d = t(D * NKp * esz);                  // dY^T / u^T / dx1^T / h1^T  [D, NKp]
+  w.t_d2 = t(D * NKp * esz);
+  w.dx1lp = t(N * D * esz); w.dyattn = t(N * D * esz); w.dqkv = t(N * 3 * D * esz); w.dh1 = t(N * D * 4);
+  w.dgp = t(((N + 3) / 4) * D * 4);
+  w.apq = t((size_t)B * d.H * (D / d.H) * 4); w.apk = t((size_t)B * d.H * (D / d.H) * 4);
+  size_t cs = mode_colsum_workspace_bytes((int)NK, 8 * d.D, d.E);
+  const size_t c2 = mode_colsum_workspace_bytes((int)N, 3 * d.D, 1), c3 = mode_colsum_workspace_bytes((int)N, d.D, B);
+  if (c2 > cs) cs = c2;
+  if (c3 > cs) cs = c3;
+  w.csw = t(cs + 4096);
+  w.dcond = t((size_t)B * D * 4); w.dlog = t((size_t)B * d.E * 4); w.dhid = t((size_t)B * 2 * D * 4); w.dpre = t((size_t)B * 2 * D * 4);
+  const size_t smallT = ((size_t)2 * D > (size_t)d.O ? 2 * D : d.O) * (R > 2 * (size_t)B ? R : 2 * B) * 4 + 4096;
+  w.st1 = t(smallT); w.st2 = t(smallT);
+  w.tmp_rd = t(R * D * 4);
+  w.demb = t((size_t)B * D * 4); w.de1 = t((size_t)B * D * 4); w.dimg = t((size_t)B * d.n_img * D * 4); w.dgoal = t((size_t)B * D * 4);
+  w.total = t.o;
+  return w;
+}
+
+int check_train_dims(const ModeDims* d) {
+  if (!d) return MODE_ERR_BAD_ARG;
+  if (d->D <= 0 || d->H <= 0 || d->D % d->H || d->L <= 0 || d->E <= 0 || d->k <= 0 || d->k > d->E || d->k > 8) return MODE_ERR_BAD_ARG;
+  if (d->T != (d->use_noise_token ? 1 : 0) + 1 + d->n_img + d->A_len) return MODE_ERR_UNSUPPORTED;
+  if (d->D % 4 || d->A_dim > 8 || d->T > 16) return MODE_ERR_UNSUPPORTED;
+  return MODE_OK;
+}
+
+}  // namespace
+
+extern "C" int mode_dit_train_stash_layout(const ModeDims* dims, int B, int dtype, ModeStashLayout* out) {
+  int rc = check_train_dims(dims);
+  if (rc) return rc;
+  if (!out || B <= 0) return MODE_ERR_BAD_ARG;
+  const size_t esz = dtype == MODE_BF16 ? 2 : 4;
+  const size_t N = (size_t)B * dims->T, NK = N * dims->k, D = dims->D;
+  Take t;
+  out->x0 = t(N * D * 4); out->h1 = t(N * D * esz); out->qkv = t(N * 3 * D * esz); out->yattn = t(N * D * esz); out->x1 = t(N * D * 4);
+  out->ub = t(N * D * esz); out->P = t(NK * 8 * D * esz); out->Hd = t(NK * 4 * D * esz); out->Y = t(NK * D * esz);
+  out->layer_stride = t.o;
+  Take g;
+  out->xL = g(N * D * 4); out->yL = g(N * D * 4); out->u_tmp = g(N * D * 4);
+  out->global_bytes = g.o;
+  out->total_bytes = out->global_bytes + out->layer_stride * dims->L;
+  return MODE_OK;
+}
+
+extern "C" size_t mode_dit_train_workspace_bytes(const ModeDims* dims, int B, int dtype) {
+  if (check_train_dims(dims) != MODE_OK || B <= 0) return 0;
+  return train_ws(*dims, B, dtype).total;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ forward
+extern "C" int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes,
+                                      void* stream) {
+  int rc = check_train_dims(dims);
+  if (rc) return rc;
+  if (!w || !w->layers || !a || !stash || !a->meta || !a->goal_e || !a->img_e || !a->actions || !a->emb_t || !a->cond || !a->act_rows || !a->F)
+    return MODE_ERR_BAD_ARG;
+  const ModeDims& d = *dims;
+  const int dt = a->dtype, B = a->B, T = d.T, D = d.D, N = B * T, NK = N * d.k;
+  if (dt == MODE_BF16 && (D % 64 || (D / d.H) % 16 || (D / d.H) > 128)) return MODE_ERR_UNSUPPORTED;
+  ModeStashLayout sl;
+  rc = mode_dit_train_stash_layout(dims, B, dt, &sl);
+  if (rc) return rc;
+  if (stash_bytes < sl.total_bytes) return MODE_ERR_WORKSPACE;
+  char* sg = (char*)stash;
+  auto L_ = [&](int l) { return sg + sl.global_bytes + (size_t)l * sl.layer_stride; };
+  float* u_tmp = (float*)(sg + sl.u_tmp);
+  ModeMetaLayout ml;
+  mode_moe_meta_layout(N, d.E, d.k, &ml);
+
+  ModeEmbedDesc e;
+  memset(&e, 0, sizeof(e));
+  e.B = B; e.T = T; e.D = D; e.A_len = d.A_len; e.A_dim = d.A_dim; e.n_img = d.n_img; e.use_noise_token = d.use_noise_token;
+  e.emb_t = a->emb_t; e.emb_row_stride = D; e.goal_e = a->goal_e; e.img_e = a->img_e; e.actions = a->actions;
+  e.c_in = a->c_in; e.c_in_stride = a->c_in_stride; e.w_act = w->w_act; e.pos = w->pos; e.g = w->layers[0].ln1_g;
+  e.cond = a->cond; e.cond_row_stride = D; e.eps = d.eps; e.x = (float*)(L_(0) + sl.x0); e.h = L_(0) + sl.h1; e.h_dtype = dt;
+  rc = mode_embed_tokens_fwd(&e, stream);
+  if (rc) return rc;
+
+  for (int l = 0; l < d.L; ++l) {
+    const ModeLayerWeights& lw = w->layers[l];
+    char* S = L_(l);
+    const int32_t* meta = a->meta + (long)l * a->meta_layer_stride;
+    float* x0 = (float*)(S + sl.x0); float* x1 = (float*)(S + sl.x1);
+    ModeGemmDesc g = gdesc(dt, MODE_EPI_BIAS, dt, N, 3 * D, D, S + sl.h1, D, lw.wqkv, D, S + sl.qkv, 3 * D);
+    g.bias = lw.bqkv;
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    if ((rc = mode_attn_block_fwd(S + sl.qkv, lw.qn_g, lw.kn_g, S + sl.yattn, dt, B, T, d.H, D / d.H, d.eps, a->seed + 2 * l, a->attn_pdrop, stream)))
+      return rc;
+    g = gdesc(dt, MODE_EPI_RESIDUAL, MODE_F32, N, D, D, S + sl.yattn, D, lw.wo, D, x1, D);
+    g.resid = x0; g.ldr = D;
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    if ((rc = mode_rmsnorm_cond_fwd(x1, lw.ln2_g, nullptr, N, D, 1, d.eps, u_tmp, S + sl.ub, dt, stream))) return rc;
+    g = gdesc(dt, MODE_EPI_BIAS, dt, NK, 8 * D, D, S + sl.ub, D, lw.w1, D, S + sl.P, 8 * D);          // pre-activation [value | gate] kept for backward
+    g.bias = lw.b1; g.w_expert_stride = 8L * D * D; g.bias_expert_stride = 8L * D;
+    g.a_rows = meta + ml.perm; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    if ((rc = mode_swiglu_fwd(S + sl.P, S + sl.Hd, NK, 4 * D, dt, a->seed + 2 * l + 1, a->mlp_pdrop, stream))) return rc;
+    g = gdesc(dt, MODE_EPI_NONE, dt, NK, D, 4 * D, S + sl.Hd, 4 * D, lw.w2, 4 * D, S + sl.Y, D);
+    g.w_expert_stride = 4L * D * D; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    const bool last = l + 1 == d.L;
+    float* xn = last ? (float*)(sg + sl.xL) : (float*)(L_(l + 1) + sl.x0);
+    rc = mode_moe_combine_norm_fwd(u_tmp, S + sl.Y, dt, 1, 0, meta + ml.pos, reinterpret_cast<const float*>(meta + ml.posw), N, D, d.k,
+                                   last ? nullptr : w->layers[l + 1].ln1_g, last ? nullptr : a->cond, T, d.eps, xn,
+                                   last ? nullptr : (void*)(L_(l + 1) + sl.h1), dt, stream);
+    if (rc) return rc;
+  }
+  float* yL = (float*)(sg + sl.yL);
+  if ((rc = mode_rmsnorm_cond_fwd((const float*)(sg + sl.xL), w->ln_g, nullptr, N, D, 1, d.eps, yL, nullptr, MODE_F32, stream))) return rc;
+  ModeGemmDesc g = gdesc(MODE_F32, MODE_EPI_BIAS, MODE_F32, B * d.A_len, d.A_dim, D, yL, D, w->w_out, D, a->F, d.A_dim);
+  g.bias = w->b_out; g.a_rows = a->act_rows;
+  return mode_gemm(&g, stream);
+}
+
+// ----------------------------------------------------------------------------------------------------------------- backward
+extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w, const ModeModelWeightsT* wt, const ModeTrainArgs* a,
+                                 const void* stash, const float* dF, const ModeModelGrads* gr, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  int rc = check_train_dims(dims);
+  if (rc) return rc;
+  if (!w || !w->layers || !wt || !wt->layers || !a || !stash || !dF || !gr || !gr->layers || !workspace) return MODE_ERR_BAD_ARG;
+  if (!a->meta || !a->act_rows || !a->probs || !a->r_pre || !a->topk_idx || !a->sigma || !a->state_images || !a->goals || !a->e1) return MODE_ERR_BAD_ARG;
+  const ModeDims& d = *dims;
+  const int dt = a->dtype, B = a->B, T = d.T, D = d.D, N = B * T, NK = N * d.k, E = d.E, R = B * d.A_len, A = d.A_dim, hd = D / d.H;
+  const bool bf = dt == MODE_BF16;
+  const long NKp = ((long)NK + 63) / 64 * 64 + 64L * E, Np = ((long)N + 63) / 64 * 64;
+  const int Ktok = bf ? (int)Np : N;                       // token-dim contraction length (bf16 kernel needs a multiple of 64: zero padded)
+  const size_t esz = bf ? 2 : 4;
+  ModeStashLayout sl;
+  if ((rc = mode_dit_train_stash_layout(dims, B, dt, &sl))) return rc;
+  const TrainWs W = train_ws(d, B, dt);
+  if (workspace_bytes < W.total) return MODE_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  const char* sg = (const char*)stash;
+  auto L_ = [&](int l) { return sg + sl.global_bytes + (size_t)l * sl.layer_stride; };
+  hipStream_t hs = (hipStream_t)stream;
+  ModeMetaLayout ml;
+  mode_moe_meta_layout(N, E, d.k, &ml);
+  float* DXa = (float*)(ws + W.dxa); float* DXb = (float*)(ws + W.dxb);
+  float* dcond = (float*)(ws + W.dcond);
+  void* csw = ws + W.csw; const size_t cswb = mode_colsum_workspace_bytes(NK, 8 * D, E) + 4096;
+  float* dgp = (float*)(ws + W.dgp);
+  const int nblk4 = (N + 3) / 4;
+  auto colsum = [&](const void* X, long ld, int rows, int cols, int xdt, const int32_t* segoff, int seglen, int nseg, float* out, int acc) {
+    return mode_colsum(X, ld, rows, cols, xdt, segoff, seglen, nseg, out, acc, csw, cswb, stream);
+  };
+  if (hipMemsetAsync(dcond, 0, (size_t)B * D * 4, hs) != hipSuccess) return (int)hipGetLastError();
+
+  // ---- output head: F = yL[act_rows] @ w_out^T + b_out ;  yL = RMSNorm(xL; ln.g)
+  {
+    float* tmp = (float*)(ws + W.tmp_rd);                   // d yL on the action rows  [R, D]
+    ModeGemmDesc g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, R, D, A, dF, A, wt->w_outT, A, tmp, D);
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    float* dFT = (float*)(ws + W.st1); float* yT = (float*)(ws + W.st2);
+    if ((rc = mode_transpose(dF, A, R, A, dFT, R, nullptr, nullptr, MODE_F32, stream))) return rc;
+    if ((rc = mode_transpose(sg + sl.yL, D, R, D, yT, R, a->act_rows, nullptr, MODE_F32, stream))) return rc;
+    g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, A, D, R, dFT, R, yT, R, gr->w_out, D);
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    if ((rc = colsum(dF, A, R, A, MODE_F32, nullptr, 0, 1, gr->b_out, 0))) return rc;
+    float* dyl = (float*)(ws + W.dyl);
+    if (hipMemsetAsync(dyl, 0, (size_t)N * D * 4, hs) != hipSuccess) return (int)hipGetLastError();
+    if ((rc = mode_rowcopy_f32(tmp, D, 0, 1, nullptr, dyl, D, 0, 0, a->act_rows, nullptr, 0, R, D, stream))) return rc;
+    if ((rc = mode_rmsnorm_bwd((const float*)(sg + sl.xL), w->ln_g, dyl, nullptr, nullptr, nullptr, 0, N, D, d.eps, DXa, 0, dgp, nullptr, nullptr,
+                               MODE_F32, stream))) return rc;
+    if ((rc = colsum(dgp, D, nblk4, D, MODE_F32, nullptr, 0, 1, gr->ln_g, 0))) return rc;
+  }
+
+  void* dYs = ws + W.dys; void* dHd = ws + W.dhd; void* dP = ws + W.dp; float* dUs = (float*)(ws + W.dus); float* dwt = (float*)(ws + W.dwt);
+  void* Tbig = ws + W.t_big; void* Tmid = ws + W.t_mid; void* Td = ws + W.t_d; void* Td2 = ws + W.t_d2;
+  void* dx1lp = ws + W.dx1lp; void* dyattn = ws + W.dyattn; void* dqkv = ws + W.dqkv; float* dh1 = (float*)(ws + W.dh1);
+  float* apq = (float*)(ws + W.apq); float* apk = (float*)(ws + W.apk);
+  float* dlog = (float*)(ws + W.dlog); float* dhid = (float*)(ws + W.dhid); float* dpre = (float*)(ws + W.dpre);
+  float* st1 = (float*)(ws + W.st1); float* st2 = (float*)(ws + W.st2);
+#define ZERO(ptr, bytes) if (hipMemsetAsync((ptr), 0, (bytes), hs) != hipSuccess) return (int)hipGetLastError();
+
+  for (int l = d.L - 1; l >= 0; --l) {
+    const ModeLayerWeights& lw = w->layers[l];
+    const ModeLayerWeightsT& lt = wt->layers[l];
+    const ModeLayerGrads& lg = gr->layers[l];
+    const char* S = L_(l);
+    const int32_t* meta = a->meta + (long)l * a->meta_layer_stride;
+    const int32_t* offsets = meta + ml.offsets; const int32_t* poff = meta + ml.poffsets; const int32_t* prow = meta + ml.prow;
+    const int32_t* pos = meta + ml.pos; const float* posw = reinterpret_cast<const float*>(meta + ml.posw);
+    // (1) combine backward: dY (sorted rows) and router-weight gradients
+    if ((rc = mode_moe_combine_bwd(DXa, S + sl.Y, dt, pos, posw, N, D, d.k, dYs, dwt, stream))) return rc;
+    // (2) expert down-projection: dH = dY W2 ; dW2_e = dY_e^T H_e
+    ModeGemmDesc g = gdesc(dt, MODE_EPI_NONE, dt, NK, 4 * D, D, dYs, D, lt.w2T, D, dHd, 4 * D);
+    g.w_expert_stride = 4L * D * D; g.expert_offsets = offsets; g.num_experts = E;
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    ZERO(Td, (size_t)D * NKp * esz); ZERO(Tmid, (size_t)4 * D * NKp * esz);
+    if ((rc = mode_transpose(dYs, D, NK, D, Td, NKp, nullptr, prow, dt, stream))) return rc;
+    if ((rc = mode_transpose(S + sl.Hd, 4 * D, NK, 4 * D, Tmid, NKp, nullptr, prow, dt, stream))) return rc;
+    g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, 4 * D, (int)NKp, Td, NKp, Tmid, NKp, lg.w2, 4 * D);
+    g.k_group_offsets = poff; g.num_k_groups = E; g.c_group_stride = 4L * D * D;
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    // (3) SwishGLU (+ dropout) backward, bias gradient
+    if ((rc = mode_swiglu_bwd(S + sl.P, dHd, dP, NK, 4 * D, dt, a->seed + 2 * l + 1, a->mlp_pdrop, stream))) return rc;
+    if ((rc = colsum(dP, 8 * D, NK, 8 * D, dt, offsets, 0, E, lg.b1, 0))) return rc;
+    // (4) expert up-projection: dU (sorted rows, fp32) = dP W1 ; dW1_e = dP_e^T U_e
+    g = gdesc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 8 * D, dP, 8 * D, lt.w1T, 8 * D, dUs, D);
+    g.w_expert_stride = 8L * D * D; g.expert_offsets = offsets; g.num_experts = E;
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    ZERO(Tbig, (size_t)8 * D * NKp * esz); ZERO(Td2, (size_t)D * NKp * esz);
+    if ((rc = mode_transpose(dP, 8 * D, NK, 8 * D, Tbig, NKp, nullptr, prow, dt, stream))) return rc;
+    if ((rc = mode_transpose(S + sl.ub, D, NK, D, Td2, NKp, meta + ml.perm, prow, dt, stream))) return rc;     // gathered u rows
+    g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 8 * D, D, (int)NKp, Tbig, NKp, Td2, NKp, lg.w1, D);
+    g.k_group_offsets = poff; g.num_k_groups = E; g.c_group_stride = 8L * D * D;
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    // (5) ln_2 backward: du = dx_out (residual from the normalised stream) + gather-sum of dU ; -> d x1
+    if ((rc = mode_rmsnorm_bwd((const float*)(S + sl.x1), lw.ln2_g, DXa, nullptr, dUs, pos, d.k, N, D, d.eps, DXb, 0, dgp, nullptr, dx1lp, dt, stream)))
+      return rc;
+    if ((rc = colsum(dgp, D, nblk4, D, MODE_F32, nullptr, 0, 1, lg.ln2_g, 0))) return rc;
+    // (6) c_proj: d yattn = dx1 Wo ; dWo = dx1^T yattn
+    g = gdesc(dt, MODE_EPI_NONE, dt, N, D, D, dx1lp, D, lt.woT, D, dyattn, D);
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    ZERO(Td, (size_t)D * Np * esz); ZERO(Td2, (size_t)D * Np * esz);
+    if ((rc = mode_transpose(dx1lp, D, N, D, Td, Np, nullptr, nullptr, dt, stream))) return rc;
+    if ((rc = mode_transpose(S + sl.yattn, D, N, D, Td2, Np, nullptr, nullptr, dt, stream))) return rc;
+    g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, D, Ktok, Td, Np, Td2, Np, lg.wo, D);
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    // (7) attention backward
+    if ((rc = mode_attn_block_bwd(S + sl.qkv, lw.qn_g, lw.kn_g, dyattn, dqkv, apq, apk, dt, B, T, d.H, hd, d.eps, a->seed + 2 * l, a->attn_pdrop, stream)))
+      return rc;
+    if ((rc = colsum(apq, hd, B * d.H, hd, MODE_F32, nullptr, 0, 1, lg.qn_g, 0))) return rc;
+    if ((rc = colsum(apk, hd, B * d.H, hd, MODE_F32, nullptr, 0, 1, lg.kn_g, 0))) return rc;
+    // (8) QKV projection: dh1 = dqkv Wqkv ; dWqkv = dqkv^T h1 ; db = colsum(dqkv)
+    g = gdesc(dt, MODE_EPI_NONE, MODE_F32, N, D, 3 * D, dqkv, 3 * D, lt.wqkvT, 3 * D, dh1, D);
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    ZERO(Tbig, (size_t)3 * D * Np * esz); ZERO(Td, (size_t)D * Np * esz);
+    if ((rc = mode_transpose(dqkv, 3 * D, N, 3 * D, Tbig, Np, nullptr, nullptr, dt, stream))) return rc;
+    if ((rc = mode_transpose(S + sl.h1, D, N, D, Td, Np, nullptr, nullptr, dt, stream))) return rc;
+    g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 3 * D, D, Ktok, Tbig, Np, Td, Np, lg.wqkv, D);
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    if ((rc = colsum(dqkv, 3 * D, N, 3 * D, dt, nullptr, 0, 1, lg.bqkv, 0))) return rc;
+    // (9) ln_1 (+c) backward: d x0 = d x1 (residual) + RMSNorm'(dh1); dc_b += sum_t dh1[b,t]
+    if ((rc = mode_rmsnorm_bwd((const float*)(S + sl.x0), lw.ln1_g, dh1, nullptr, nullptr, nullptr, 0, N, D, d.eps, DXb, 1, dgp, nullptr, nullptr, MODE_F32,
+                               stream))) return rc;
+    if ((rc = colsum(dgp, D, nblk4, D, MODE_F32, nullptr, 0, 1, lg.ln1_g, 0))) return rc;
+    if ((rc = colsum(dh1, D, N, D, MODE_F32, nullptr, T, B, dcond, 1))) return rc;
+    // (10) router backward (fp32, B distinct conditioning rows)
+    {
+      const float* probs = a->probs + (long)l * B * E;
+      const float* rpre = a->r_pre + (long)l * B * 2 * D;
+      const int32_t* idx = a->topk_idx + (long)l * a->topk_layer_stride;
+      if ((rc = mode_moe_router_bwd(dwt, idx, probs, B, T, E, d.k, d.router_normalize, a->idx_per_token, dlog, stream))) return rc;
+      if ((rc = colsum(dlog, E, B, E, MODE_F32, nullptr, 0, 1, lg.r_b3, 0))) return rc;
+      float* hid = st2 + (size_t)2 * D * B;                                                 // GELU(pre) recomputed  [B, 2D]
+      if ((rc = mode_gelu_fwd(rpre, hid, (long)B * 2 * D, stream))) return rc;
+      // dW3 [E, 2D] = dlog^T hid
+      if ((rc = mode_transpose(dlog, E, B, E, st1, B, nullptr, nullptr, MODE_F32, stream))) return rc;
+      if ((rc = mode_transpose(hid, 2 * D, B, 2 * D, st2, B, nullptr, nullptr, MODE_F32, stream))) return rc;
+      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, E, 2 * D, B, st1, B, st2, B, lg.r_w3, 2 * D);
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      // dhid = dlog W3 ; dpre = dhid * gelu'(pre)
+      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, B, 2 * D, E, dlog, E, lt.r_w3T, E, dhid, 2 * D);
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      if ((rc = mode_gelu_bwd(rpre, dhid, dpre, (long)B * 2 * D, stream))) return rc;
+      if ((rc = colsum(dpre, 2 * D, B, 2 * D, MODE_F32, nullptr, 0, 1, lg.r_b0, 0))) return rc;
+      // dW0 [2D, D] = dpre^T cond ; dcond += dpre W0
+      if ((rc = mode_transpose(dpre, 2 * D, B, 2 * D, st1, B, nullptr, nullptr, MODE_F32, stream))) return rc;
+      if ((rc = mode_transpose(a->cond, D, B, D, st2, B, nullptr, nullptr, MODE_F32, stream))) return rc;
+      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, 2 * D, D, B, st1, B, st2, B, lg.r_w0, D);
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      g = gdesc(MODE_F32, MODE_EPI_RESIDUAL, MODE_F32, B, D, 2 * D, dpre, 2 * D, lt.r_w0T, 2 * D, dcond, D);
+      g.resid = dcond; g.ldr = D;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    }
+    float* t_ = DXa; DXa = DXb; DXb = t_;                    // DXa now holds d x_l
+  }
+
+  // ---- embeddings: x_0 = [emb_t | goal_e + pos0 | img_e + pos1 | act_e + pos(1..A)]
+  {
+    const int t0 = d.use_noise_token ? 1 : 0, t_img = t0 + 1, t_act = t_img + d.n_img;
+    float* demb = (float*)(ws + W.demb); float* de1 = (float*)(ws + W.de1); float* dimg = (float*)(ws + W.dimg); float* dgoal = (float*)(ws + W.dgoal);
+    // conditioning: cond = emb_t (+ goal_e): d emb_t = dcond (+ d x0[:, noise token])
+    if (d.use_noise_token) { if ((rc = mode_rowcopy_f32(DXa, D, 0, T, nullptr, demb, D, 0, 1, nullptr, dcond, D, B, D, stream))) return rc; }
+    else { if ((rc = mode_rowcopy_f32(dcond, D, 0, 1, nullptr, demb, D, 0, 1, nullptr, nullptr, 0, B, D, stream))) return rc; }
+    // goal token (+ routing contribution when the goal embedding feeds the conditioning)
+    if ((rc = mode_rowcopy_f32(DXa, D, t0, T, nullptr, dgoal, D, 0, 1, nullptr, a->goal_in_cond ? dcond : nullptr, D, B, D, stream))) return rc;
+    for (int i = 0; i < d.n_img; ++i)
+      if ((rc = mode_rowcopy_f32(DXa, D, t_img + i, T, nullptr, dimg, D, i, d.n_img, nullptr, nullptr, 0, B, D, stream))) return rc;
+    // pos_emb: row 0 <- goal token; row 1 <- both image tokens + first action; row 1+a <- action a
+    if ((rc = colsum(DXa + (long)t0 * D, (long)T * D, B, D, MODE_F32, nullptr, 0, 1, gr->pos, 0))) return rc;
+    if ((rc = colsum(DXa + (long)t_act * D, (long)T * D, B, D, MODE_F32, nullptr, 0, 1, gr->pos + D, 0))) return rc;
+    for (int i = 0; i < d.n_img; ++i)
+      if ((rc = colsum(DXa + (long)(t_img + i) * D, (long)T * D, B, D, MODE_F32, nullptr, 0, 1, gr->pos + D, 1))) return rc;
+    for (int ai = 1; ai < d.A_len; ++ai)
+      if ((rc = colsum(DXa + (long)(t_act + ai) * D, (long)T * D, B, D, MODE_F32, nullptr, 0, 1, gr->pos + (long)(1 + ai) * D, 0))) return rc;
+    // action_emb: dW_act [D, A] = dX_act^T [D, R] (actions*c_in) [R, A]
+    if ((rc = mode_transpose(DXa, D, R, D, st1, R, a->act_rows, nullptr, MODE_F32, stream))) return rc;
+    if ((rc = mode_transpose(a->actions_scaled, A, R, A, st2, R, nullptr, nullptr, MODE_F32, stream))) return rc;
+    ModeGemmDesc g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, A, R, st1, R, st2, R, gr->w_act, A);
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    // tok_emb / goal_emb: dW = d e^T input
+    const int RI = B * d.n_img;
+    if ((rc = mode_transpose(dimg, D, RI, D, st1, RI, nullptr, nullptr, MODE_F32, stream))) return rc;
+    if ((rc = mode_transpose(a->state_images, d.O, RI, d.O, st2, RI, nullptr, nullptr, MODE_F32, stream))) return rc;
+    g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, d.O, RI, st1, RI, st2, RI, gr->w_tok, d.O);
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    if ((rc = mode_transpose(dgoal, D, B, D, st1, B, nullptr, nullptr, MODE_F32, stream))) return rc;
+    if ((rc = mode_transpose(a->goals, d.G, B, d.G, st2, B, nullptr, nullptr, MODE_F32, stream))) return rc;
+    g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, d.G, B, st1, B, st2, B, gr->w_goal, d.G);
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    // sigma path: emb_t = e1 W_sl^T, e1 = s * w_se + b_se
+    if ((rc = mode_transpose(demb, D, B, D, st1, B, nullptr, nullptr, MODE_F32, stream))) return rc;
+    if ((rc = mode_transpose(a->e1, D, B, D, st2, B, nullptr, nullptr, MODE_F32, stream))) return rc;
+    g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, D, B, st1, B, st2, B, gr->w_sl, D);
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, B, D, D, demb, D, wt->w_slT, D, de1, D);
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    if ((rc = mode_sigma_embed_bwd(de1, a->sigma, B, D, gr->w_se, gr->b_se, stream))) return rc;
+  }
+#undef ZERO
+  return MODE_OK;
+}

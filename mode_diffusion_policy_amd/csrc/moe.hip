@@ -49,6 +49,17 @@ __global__ __launch_bounds__(256) void route_topk_kernel(const float* __restrict
   }
 }
 
+// ---- combine weights for host-chosen expert ids (training multinomial): w[n,j] = probs[row(n), idx[n,j]] (/ sum_j)
+__global__ void weights_from_idx_kernel(const float* __restrict__ probs, const int* __restrict__ idx, int N, int tpr, int E, int k, int normalize,
+                                        float* __restrict__ w) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* p = probs + (long)(n / tpr) * E;
+  float s = 0.f;
+  for (int j = 0; j < k; ++j) s += p[idx[(long)n * k + j]];
+  for (int j = 0; j < k; ++j) { const float v = p[idx[(long)n * k + j]]; w[(long)n * k + j] = normalize ? v / s : v; }
+}
+
 // ---- dispatch metadata: one workgroup per problem (layer); blockDim = 1024
 struct MetaBatch {
   const int* idx; const float* w; long idx_bstride;          // [R,k] per problem
@@ -152,4 +163,13 @@ extern "C" int mode_moe_dispatch_meta(const int32_t* idx, const float* w, int R,
   if (!idx || !w || !counts || !offsets || !perm || !pos || !posw || (!poffsets != !prow)) return MODE_ERR_BAD_ARG;
   MetaBatch mb{idx, w, 0, counts, offsets, perm, pos, posw, poffsets, prow, 0};
   return dispatch_meta_batched(mb, 1, R, tokens_per_row, N, E, k, (hipStream_t)stream);
+}
+
+extern "C" int mode_moe_weights_from_idx(const float* probs, const int32_t* idx, int N, int tokens_per_row, int E, int k, int normalize, float* w,
+                                         void* stream) {
+  if (!probs || !idx || !w || N < 0 || tokens_per_row <= 0 || E <= 0 || k <= 0 || k > E) return MODE_ERR_BAD_ARG;
+  if (N == 0) return MODE_OK;
+  hipLaunchKernelGGL(weights_from_idx_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, probs, idx, N, tokens_per_row, E, k, normalize, w);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
 }

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ P
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* dy_a,
                                                           const float* dy_b, const float* __restrict__ G, const int* __restrict__ pos, int k,
                                                           int rows, int D, float eps, float* dx, int accumulate, float* __restrict__ dgp,
-                                                          float* __restrict__ dy_out) {
+                                                          float* __restrict__ dy_out, void* __restrict__ dx_lp, int lp_bf16) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sx = reinterpret_cast<float*>(smem);                       // [4][D] x rows
   float* sd = sx + 4 * D;                                            // [4][D] dy rows
@@ -169,6 +169,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
       float* dst = dx + (long)row * D + d;
       if (accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
       *reinterpret_cast<float4*>(dst) = o;
+      if (dx_lp) {
+        if (lp_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dx_lp) + (long)row * D + d) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        else *reinterpret_cast<float4*>(reinterpret_cast<float*>(dx_lp) + (long)row * D + d) = o;
+      }
       // stash dy * x / n for the gain gradient in place of dy
       *reinterpret_cast<float4*>(sd + wave * D + d) = make_float4(dv.x * xv.x * rn, dv.y * xv.y * rn, dv.z * xv.z * rn, dv.w * xv.w * rn);
     }
@@ -206,6 +210,76 @@ __global__ __launch_bounds__(256) void combine_bwd_kernel(const float* __restric
     acc = wave_sum(acc);
     if (lane == 0) dw[(long)t * k + j] = acc;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------- small helpers
+// dst[d0 + i*dstride (or didx[i])] (+)= src[s0 + i*sstride (or sidx[i])]  — strided / indexed fp32 row moves (token-type slices of the
+// sequence gradient, scatter of the action-row gradients)
+__global__ void rowcopy_f32_kernel(const float* __restrict__ src, long ld_s, int s0, int sstride, const int* __restrict__ sidx, float* dst,
+                                   long ld_d, int d0, int dstride, const int* __restrict__ didx, const float* __restrict__ add, long ld_a, int n,
+                                   int D) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n * D) return;
+  const int r = i / D, c = i % D;
+  const long sr = sidx ? sidx[r] : (long)s0 + (long)r * sstride;
+  const long dr = didx ? didx[r] : (long)d0 + (long)r * dstride;
+  float v = src[sr * ld_s + c];
+  if (add) v += add[(long)r * ld_a + c];
+  dst[dr * ld_d + c] = v;
+}
+
+__global__ void gelu_fwd_kernel(const float* __restrict__ pre, float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = gelu_erf_f(pre[i]);
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dout, float* __restrict__ dpre, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = pre[i];
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  dpre[i] = dout[i] * (cdf + x * pdf);
+}
+
+// Router backward on distinct conditioning rows (one thread per sample): dw[t,j] (j in ascending expert id) -> dlogits[b,:]
+// w = p[S]/sum(p[S]) (router_normalize) or p[S]; p = clamp(softmax(l), 1e-9, 1-1e-9)   (modedit.py:345-349, 398-399, 418-419)
+__global__ void router_bwd_kernel(const float* __restrict__ dw, const int* __restrict__ idx, const float* __restrict__ probs, int B, int T, int E,
+                                  int k, int normalize, int idx_per_token, float* __restrict__ dlogits) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float dp[64], p[64];
+  for (int e = 0; e < E; ++e) { dp[e] = 0.f; p[e] = probs[(long)b * E + e]; }
+  for (int t = 0; t < T; ++t) {
+    const long tok = (long)b * T + t;
+    const int* id = idx + (idx_per_token ? tok : (long)b) * k;
+    int es[8];
+    for (int j = 0; j < k; ++j) es[j] = id[j];
+    for (int a = 1; a < k; ++a) { const int v = es[a]; int c = a - 1; while (c >= 0 && es[c] > v) { es[c + 1] = es[c]; --c; } es[c + 1] = v; }   // ascending
+    float s = 0.f, wd = 0.f;
+    for (int j = 0; j < k; ++j) s += p[es[j]];
+    if (normalize) {
+      for (int j = 0; j < k; ++j) wd += (p[es[j]] / s) * dw[tok * k + j];
+      for (int j = 0; j < k; ++j) dp[es[j]] += (dw[tok * k + j] - wd) / s;
+    } else {
+      for (int j = 0; j < k; ++j) dp[es[j]] += dw[tok * k + j];
+    }
+  }
+  float dot = 0.f;
+  for (int e = 0; e < E; ++e) {
+    if (p[e] <= 1e-9f || p[e] >= 1.0f - 1e-9f) dp[e] = 0.f;          // clamp passes gradient only strictly inside
+    dot += dp[e] * p[e];
+  }
+  for (int e = 0; e < E; ++e) dlogits[(long)b * E + e] = p[e] * (dp[e] - dot);
+}
+
+// sigma_emb backward: e1[b,d] = s_b * w[d] + bias[d], s_b = ln(sigma_b)/4:  dw[d] = sum_b de1[b,d] s_b, dbias[d] = sum_b de1[b,d]
+__global__ void sigma_embed_bwd_kernel(const float* __restrict__ de1, const float* __restrict__ sigma, int B, int D, float* __restrict__ dw,
+                                       float* __restrict__ db) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float a = 0.f, c = 0.f;
+  for (int b = 0; b < B; ++b) { const float g = de1[(long)b * D + d]; a += g * (logf(sigma[b]) / 4.0f); c += g; }
+  dw[d] = a; db[d] = c;
 }
 
 }  // namespace mode
@@ -287,13 +361,14 @@ extern "C" int mode_swiglu_bwd(const void* P, const void* dHd, void* dP, int64_t
 }
 
 extern "C" int mode_rmsnorm_bwd(const float* x, const float* g, const float* dy_a, const float* dy_b, const float* G, const int32_t* pos, int k,
-                                int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* stream) {
+                                int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* dx_lp,
+                                int lp_dtype, void* stream) {
   if (!x || !g || !dx || rows < 0 || D <= 0 || (D & 3) || (k > 0 && (!G || !pos))) return MODE_ERR_BAD_ARG;
   if (rows == 0) return MODE_OK;
   const size_t lds = (size_t)8 * D * 4;
   if (lds > 64 * 1024) return MODE_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), lds, (hipStream_t)stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx,
-                     accumulate, dg_partial, dy_out);
+                     accumulate, dg_partial, dy_out, dx_lp, lp_dtype == MODE_BF16 ? 1 : 0);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
@@ -306,6 +381,50 @@ extern "C" int mode_moe_combine_bwd(const float* dy, const void* Y, int y_dtype,
     hipLaunchKernelGGL(combine_bwd_kernel<uint16_t>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (const uint16_t*)Y, pos, posw, N, D, k, (uint16_t*)dYs, dw);
   else
     hipLaunchKernelGGL(combine_bwd_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (const float*)Y, pos, posw, N, D, k, (float*)dYs, dw);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_rowcopy_f32(const float* src, int64_t ld_src, int s0, int sstride, const int32_t* sidx, float* dst, int64_t ld_dst, int d0,
+                                int dstride, const int32_t* didx, const float* add, int64_t ld_add, int n, int D, void* stream) {
+  if (!src || !dst || n < 0 || D <= 0) return MODE_ERR_BAD_ARG;
+  const long tot = (long)n * D;
+  if (tot == 0) return MODE_OK;
+  hipLaunchKernelGGL(rowcopy_f32_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, (long)ld_src, s0, sstride, sidx, dst,
+                     (long)ld_dst, d0, dstride, didx, add, (long)ld_add, n, D);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_gelu_fwd(const float* pre, float* out, int64_t n, void* stream) {
+  if (!pre || !out || n < 0) return MODE_ERR_BAD_ARG;
+  if (n == 0) return MODE_OK;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pre, out, (long)n);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_gelu_bwd(const float* pre, const float* dout, float* dpre, int64_t n, void* stream) {
+  if (!pre || !dout || !dpre || n < 0) return MODE_ERR_BAD_ARG;
+  if (n == 0) return MODE_OK;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pre, dout, dpre, (long)n);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_moe_router_bwd(const float* dw, const int32_t* idx, const float* probs, int B, int T, int E, int k, int normalize,
+                                   int idx_per_token, float* dlogits, void* stream) {
+  if (!dw || !idx || !probs || !dlogits || B < 0 || E <= 0 || E > 64 || k <= 0 || k > 8 || k > E) return MODE_ERR_BAD_ARG;
+  if (B == 0) return MODE_OK;
+  hipLaunchKernelGGL(router_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, dw, idx, probs, B, T, E, k, normalize, idx_per_token, dlogits);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_sigma_embed_bwd(const float* de1, const float* sigma, int B, int D, float* dw, float* db, void* stream) {
+  if (!de1 || !sigma || !dw || !db) return MODE_ERR_BAD_ARG;
+  if (D == 0) return MODE_OK;
+  hipLaunchKernelGGL(sigma_embed_bwd_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, de1, sigma, B, D, dw, db);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }

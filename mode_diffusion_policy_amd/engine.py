@@ -119,15 +119,18 @@ class DitEngine:
                                             img_e.data_ptr(), goal_e.data_ptr(), _stream()), "embed_obs")
         return img_e, goal_e
 
-    def route(self, cond: torch.Tensor, want_probs: bool = False):
+    def route(self, cond: torch.Tensor, want_probs: bool = False, want_pre: bool = False):
         R, d = cond.shape[0], self.dims
         idx = torch.empty(d.L, R, d.k, dtype=torch.int32, device=self.device)
         w = torch.empty(d.L, R, d.k, dtype=torch.float32, device=self.device)
         probs = torch.empty(d.L, R, d.E, dtype=torch.float32, device=self.device) if want_probs else None
         shifted = torch.empty(d.L, R, d.E, dtype=torch.float32, device=self.device) if want_probs else None
+        pre = torch.empty(d.L, R, 2 * d.D, dtype=torch.float32, device=self.device) if want_pre else None
         ws, wsn = self.workspace(0, R)
         L.check(self.lib.mode_dit_route(C.byref(d), C.byref(self._mw), cond.data_ptr(), R, idx.data_ptr(), w.data_ptr(),
-                                        _ptr(probs), _ptr(shifted), ws, wsn, _stream()), "route")
+                                        _ptr(probs), _ptr(shifted), _ptr(pre), ws, wsn, _stream()), "route")
+        if want_pre:
+            return idx, w, probs, shifted, pre
         return idx, w, probs, shifted
 
     def dispatch(self, idx: torch.Tensor, w: torch.Tensor, nbatch: int, R: int, tokens_per_row: int, N: int) -> torch.Tensor:

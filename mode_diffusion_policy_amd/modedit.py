@@ -210,9 +210,8 @@ class MoDeDiT(nn.Module):
     def forward(self, states, actions, goals, sigma, uncond: Optional[bool] = False):
         """states: {'state_images': (B, 2, obs_dim)}; actions (B, A_len, A_dim); goals (B,1,G)|(B,G); sigma (B,)|() -> (B, A_len, A_dim)."""
         if self.training:
-            # training (multinomial routing, dropout, autograd through HIP backward kernels) is SURVEY §8 rows 13-17; not in this
-            # round.  Fail loudly rather than fall back to eager PyTorch.
-            raise NotImplementedError("MoDeDiT (HIP): training-mode forward/backward is not implemented yet; call .eval()")
+            from .training import dit_forward_train        # HIP forward with activation stash + HIP backward behind autograd
+            return dit_forward_train(self, states, actions, goals, sigma, uncond)
         eng = self.engine
         dev = eng.device
         B = actions.shape[0]

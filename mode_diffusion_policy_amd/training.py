@@ -1,0 +1,231 @@
+"""Training-mode forward + backward of the MoDE denoiser through the HIP chains.
+
+``MoDeDiT.forward`` in ``.train()`` mode lands here.  The forward runs ``mode_dit_forward_train`` (activation stash, per-token
+expert ids drawn by ``torch.multinomial`` exactly where the reference draws them — modedit.py:390 — or top-k when
+``use_argmax``; attention / expert dropout as counter-based hash masks), and a ``torch.autograd.Function`` hands ``dF`` to
+``mode_dit_backward`` which writes the gradient of every parameter.  PyTorch only wires tensors together; no FLOP of the
+denoiser runs in eager PyTorch.
+
+Not differentiated this round: the auxiliary load-balancing / z losses (values are exposed for logging exactly like the
+reference — modedit.py:584-593, 898-969 — but carry no graph; their weights are 0.0 in conf/model/mode_agent.yaml:5-6).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from .engine import DitEngine, _ptr, _stream
+
+
+class TrainState:
+    """Per-engine training resources that follow the weights: transposed shadows for the data-gradient GEMMs."""
+
+    def __init__(self, eng: DitEngine):
+        self.eng = eng
+        self.key = None
+        self.keep: Dict[str, torch.Tensor] = {}
+
+    def ensure(self) -> None:
+        eng = self.eng
+        if self.key == eng._wkey:
+            return
+        m, lib, dt, tdt, dev = eng.model, eng.lib, eng.dt, eng.tdt, eng.device
+        D, E = m.embed_dim, m.num_experts
+        keep: Dict[str, torch.Tensor] = {}
+
+        def tr(src: torch.Tensor, rows: int, cols: int, dtype_code: int) -> torch.Tensor:
+            dst = torch.empty(cols, rows, dtype=src.dtype, device=dev)
+            L.check(lib.mode_transpose(src.data_ptr(), cols, rows, cols, dst.data_ptr(), rows, None, None, dtype_code, _stream()), "transpose")
+            return dst
+        layers = (L.ModeLayerWeightsT * m.num_layers)()
+        for i in range(m.num_layers):
+            k = f"l{i}."
+            kp = eng._keep
+            keep[k + "wqkvT"] = tr(kp[k + "wqkv"], 3 * D, D, dt)
+            keep[k + "woT"] = tr(kp[k + "wo"], D, D, dt)
+            keep[k + "w1T"] = torch.stack([tr(kp[k + "w1"][e], 8 * D, D, dt) for e in range(E)])
+            keep[k + "w2T"] = torch.stack([tr(kp[k + "w2"][e], D, 4 * D, dt) for e in range(E)])
+            keep[k + "rw0T"] = tr(kp[k + "rw0"], 2 * D, D, L.MODE_F32)
+            keep[k + "rw3T"] = tr(kp[k + "rw3"], E, 2 * D, L.MODE_F32)
+            lt = layers[i]
+            lt.wqkvT, lt.woT, lt.w1T, lt.w2T = (_ptr(keep[k + n]) for n in ("wqkvT", "woT", "w1T", "w2T"))
+            lt.r_w0T, lt.r_w3T = _ptr(keep[k + "rw0T"]), _ptr(keep[k + "rw3T"])
+        keep["w_slT"] = tr(eng._keep["w_sl"], D, D, L.MODE_F32)
+        keep["w_outT"] = tr(eng._keep["w_out"], m.action_dim, D, L.MODE_F32)
+        wt = L.ModeModelWeightsT()
+        wt.w_slT, wt.w_outT = _ptr(keep["w_slT"]), _ptr(keep["w_outT"])
+        wt.layers = C.cast(layers, C.POINTER(L.ModeLayerWeightsT))
+        self.keep, self.layersT, self.wt, self.key = keep, layers, wt, eng._wkey
+
+
+def _grad_layout(m) -> List[tuple]:
+    """(key, shape) of the packed fp32 gradient buffers the backward chain writes, in backward-friendly order."""
+    D, E, A = m.embed_dim, m.num_experts, m.action_dim
+    hd = D // m.n_heads
+    out = [("pos", (m.pos_emb.shape[1], D)), ("w_se", (D,)), ("b_se", (D,)), ("w_sl", (D, D)), ("w_tok", (D, m.obs_dim)),
+           ("w_goal", (D, m.goal_dim)), ("w_act", (D, A)), ("ln_g", (D,)), ("w_out", (A, D)), ("b_out", (A,))]
+    for i in range(m.num_layers):
+        k = f"l{i}."
+        out += [(k + "ln1_g", (D,)), (k + "ln2_g", (D,)), (k + "qn_g", (hd,)), (k + "kn_g", (hd,)), (k + "wqkv", (3 * D, D)), (k + "bqkv", (3 * D,)),
+                (k + "wo", (D, D)), (k + "r_w0", (2 * D, D)), (k + "r_b0", (2 * D,)), (k + "r_w3", (E, 2 * D)), (k + "r_b3", (E,)),
+                (k + "w1", (E, 8 * D, D)), (k + "b1", (E, 8 * D)), (k + "w2", (E, D, 4 * D))]
+    return out
+
+
+def _param_grad_views(m, g: Dict[str, torch.Tensor]) -> Dict[str, Optional[torch.Tensor]]:
+    """Map the packed gradient buffers back onto the reference's parameter names (state_dict layout)."""
+    D = m.embed_dim
+    v: Dict[str, Optional[torch.Tensor]] = {
+        "pos_emb": g["pos"].unsqueeze(0), "sigma_emb.weight": g["w_se"].unsqueeze(1), "sigma_emb.bias": g["b_se"],
+        "sigma_linear.weight": g["w_sl"], "tok_emb.weight": g["w_tok"], "gripper_embed.weight": None, "goal_emb.weight": g["w_goal"],
+        "action_emb.weight": g["w_act"], "ln.g": g["ln_g"], "out.weight": g["w_out"], "out.bias": g["b_out"]}
+    for i in range(m.num_layers):
+        k, p = f"l{i}.", f"blocks.{i}."
+        v[p + "ln_1.g"], v[p + "ln_2.g"] = g[k + "ln1_g"], g[k + "ln2_g"]
+        v[p + "attn.q_norm.g"], v[p + "attn.k_norm.g"] = g[k + "qn_g"], g[k + "kn_g"]
+        for j, nm in enumerate(("query", "key", "value")):                       # packed rows = [query; key; value]
+            v[p + f"attn.{nm}.weight"] = g[k + "wqkv"][j * D:(j + 1) * D]
+            v[p + f"attn.{nm}.bias"] = g[k + "bqkv"][j * D:(j + 1) * D]
+        v[p + "attn.c_proj.weight"] = g[k + "wo"]
+        v[p + "router.router.mlp.0.weight"], v[p + "router.router.mlp.0.bias"] = g[k + "r_w0"], g[k + "r_b0"]
+        v[p + "router.router.mlp.3.weight"], v[p + "router.router.mlp.3.bias"] = g[k + "r_w3"], g[k + "r_b3"]
+        for e in range(m.num_experts):
+            q = p + f"experts.expert_{e}.mlp."
+            v[q + "0.project.weight"], v[q + "0.project.bias"], v[q + "2.weight"] = g[k + "w1"][e], g[k + "b1"][e], g[k + "w2"][e]
+    return v
+
+
+class _Run:
+    """Everything one training forward leaves behind for its backward."""
+    pass
+
+
+class _DitTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, run, *params):
+        ctx.run = run
+        ctx.n = len(params)
+        return run.F
+
+    @staticmethod
+    def backward(ctx, dF):
+        run = ctx.run
+        grads = run.backward(dF.contiguous().float())
+        return (None, *grads)
+
+
+def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
+    eng: DitEngine = model.engine
+    if not hasattr(eng, "_train") or eng._train is None:
+        eng._train = TrainState(eng)
+    ts: TrainState = eng._train
+    ts.ensure()
+    lib, dev, d = eng.lib, eng.device, eng.dims
+    B, T, D, E, k, Ly = actions.shape[0], model.seq_len, model.embed_dim, model.num_experts, model.top_k, model.num_layers
+    N, A_len, A = B * T, model.action_seq_len, model.action_dim
+    f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    img = f(states["state_images"])
+    if img.dim() != 3 or img.shape[1] != model.n_img_tokens or img.shape[2] != model.obs_dim:
+        raise ValueError(f"state_images must be (B, {model.n_img_tokens}, {model.obs_dim}), got {tuple(img.shape)}")
+    gl = f(model.preprocess_goals(goals, 1, uncond=bool(uncond))).reshape(B, -1).contiguous()      # incl. the Bernoulli goal mask
+    acts = f(actions)
+    sig = f(sigma).reshape(-1)
+    if sig.numel() == 1:
+        sig = sig.expand(B).contiguous()
+    if sig.numel() != B:
+        raise ValueError("sigma must be a scalar or have one entry per sample")
+
+    run = _Run()
+    # sigma embedding in two visible steps (e1 is needed by the backward)
+    e1 = torch.empty(B, D, device=dev)
+    L.check(lib.mode_sigma_embed(sig.data_ptr(), eng._keep["w_se"].data_ptr(), eng._keep["b_se"].data_ptr(), e1.data_ptr(), B, D, _stream()), "sigma_embed")
+    emb_t = torch.empty(B, D, device=dev)
+    g = L.ModeGemmDesc(dtype=L.MODE_F32, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=B, N=D, K=D, A=e1.data_ptr(), lda=D,
+                       W=eng._keep["w_sl"].data_ptr(), ldw=D, C=emb_t.data_ptr(), ldc=D)
+    L.check(lib.mode_gemm(C.byref(g), _stream()), "sigma_linear")
+    img_e, goal_e = eng.embed_obs(img, gl)
+    cond = (emb_t + goal_e).contiguous() if model.use_goal_in_routing else emb_t
+    idx_top, w_top, probs, shifted, r_pre = eng.route(cond, want_probs=True, want_pre=True)          # [L,B,*]
+    if model.use_argmax:
+        idx, w, per_tok, tpr, Rr = idx_top, w_top, 0, T, B                                           # top-k also in training (modedit.py:389)
+    else:
+        # expert ids are SAMPLED per token row without replacement (modedit.py:390); the draw stays on the host side of the ABI
+        pt = probs.unsqueeze(2).expand(Ly, B, T, E).reshape(Ly * N, E)
+        idx = torch.multinomial(pt, k, replacement=False).to(torch.int32).view(Ly, N, k).contiguous()
+        w = torch.empty(Ly, N, k, device=dev)
+        for l in range(Ly):
+            L.check(lib.mode_moe_weights_from_idx(probs[l].data_ptr(), idx[l].data_ptr(), N, T, E, k, int(model.router_normalize),
+                                                  w[l].data_ptr(), _stream()), "weights_from_idx")
+        per_tok, tpr, Rr = 1, 1, N
+    meta = eng.dispatch(idx, w, Ly, Rr, tpr, N)
+    ml = eng.meta_layout(N)
+    act_rows = (torch.arange(B, device=dev).repeat_interleave(A_len) * T + (T - A_len) + torch.arange(A_len, device=dev).repeat(B)).to(torch.int32)
+    sl = L.ModeStashLayout()
+    L.check(lib.mode_dit_train_stash_layout(C.byref(d), B, eng.dt, C.byref(sl)), "stash_layout")
+    stash = torch.empty(sl.total_bytes, dtype=torch.uint8, device=dev)
+    F = torch.empty(B, A_len, A, device=dev)
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    args = L.ModeTrainArgs(B=B, dtype=eng.dt, seed=seed, attn_pdrop=float(model.attn_pdrop), mlp_pdrop=float(model.mlp_pdrop),
+                           sigma=sig.data_ptr(), e1=e1.data_ptr(), emb_t=emb_t.data_ptr(), cond=cond.data_ptr(),
+                           goal_in_cond=int(model.use_goal_in_routing), state_images=img.data_ptr(), goals=gl.data_ptr(),
+                           goal_e=goal_e.data_ptr(), img_e=img_e.data_ptr(), actions=acts.data_ptr(), c_in=None, c_in_stride=0,
+                           actions_scaled=acts.data_ptr(), act_rows=act_rows.data_ptr(), meta=meta.data_ptr(), meta_layer_stride=ml.total_words,
+                           topk_idx=idx.data_ptr(), topk_layer_stride=idx.stride(0), idx_per_token=per_tok, probs=probs.data_ptr(),
+                           r_pre=r_pre.data_ptr(), F=F.data_ptr())
+    L.check(lib.mode_dit_forward_train(C.byref(d), C.byref(eng._mw), C.byref(args), stash.data_ptr(), stash.numel(), _stream()), "forward_train")
+
+    # ---- reference side channels (training only, modedit.py:584-593, 816-820); values for logging, no graph
+    with torch.no_grad():
+        idx64 = (idx if per_tok else idx.unsqueeze(2).expand(Ly, B, T, k).reshape(Ly, N, k)).long()
+        wtok = w if per_tok else w.unsqueeze(2).expand(Ly, B, T, k).reshape(Ly, N, k)
+        model.logits_per_layer, model.probs_per_layer = [], []
+        for l, blk in enumerate(model.blocks):
+            mask = torch.zeros(N, E, device=dev).scatter_(1, idx64[l], 1.0)
+            rp = torch.zeros(N, E, device=dev).scatter_(1, idx64[l], wtok[l])
+            blk.logits = shifted[l].unsqueeze(1).expand(B, T, E).reshape(N, E)
+            blk.probs = {"probs": probs[l].unsqueeze(1).expand(B, T, E), "top_k_hot": mask.view(B, T, E),
+                         "load_balancing_term": E * (rp.mean(0) * (mask.sum(0) / N)).sum()}
+            blk.total_tokens_processed += N
+            model.logits_per_layer.append(blk.logits); model.probs_per_layer.append(blk.probs)
+        counts = meta[:, ml.counts: ml.counts + E]
+        if getattr(model, "_train_usage_dev", None) is None or model._train_usage_dev.device != counts.device:
+            model._train_usage_dev = torch.zeros(Ly, E, dtype=torch.int64, device=dev)
+        model._train_usage_dev += counts
+    model._last_topk = idx
+
+    keep_alive = (img, gl, acts, sig, e1, emb_t, img_e, goal_e, cond, idx, w, probs, shifted, r_pre, meta, act_rows, stash)
+    params = list(model.parameters())
+    names = [n for n, _ in model.named_parameters()]
+
+    def backward(dF: torch.Tensor):
+        ts.ensure()
+        layout = _grad_layout(model)
+        total = sum(int(torch.Size(s).numel()) for _, s in layout)
+        flat = torch.empty(total, device=dev)
+        gb: Dict[str, torch.Tensor] = {}
+        o = 0
+        for key, shp in layout:
+            n = int(torch.Size(shp).numel())
+            gb[key] = flat[o:o + n].view(shp)
+            o += n
+        lgr = (L.ModeLayerGrads * Ly)()
+        for i in range(Ly):
+            for fld, _ in L.ModeLayerGrads._fields_:
+                setattr(lgr[i], fld, gb[f"l{i}.{fld}"].data_ptr())
+        mg = L.ModeModelGrads()
+        for fld in ("pos", "w_se", "b_se", "w_sl", "w_tok", "w_goal", "w_act", "ln_g", "w_out", "b_out"):
+            setattr(mg, fld, gb[fld].data_ptr())
+        mg.layers = C.cast(lgr, C.POINTER(L.ModeLayerGrads))
+        wsb = lib.mode_dit_train_workspace_bytes(C.byref(d), B, eng.dt)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        L.check(lib.mode_dit_backward(C.byref(d), C.byref(eng._mw), C.byref(ts.wt), C.byref(args), stash.data_ptr(), dF.data_ptr(), C.byref(mg),
+                                      ws.data_ptr(), wsb, _stream()), "backward")
+        views = _param_grad_views(model, gb)
+        run.flat_grad = flat
+        return [views[n].reshape(p.shape) if (p.requires_grad and views[n] is not None) else None for n, p in zip(names, params)]
+
+    run.F, run.backward, run.keep = F, backward, keep_alive
+    return _DitTrainFn.apply(run, *params)

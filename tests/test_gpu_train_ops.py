@@ -106,10 +106,11 @@ def test_rmsnorm_bwd_with_gather(rows, D, k):
     Gm = rnd(NK, D, seed=10); pos = torch.randperm(NK, generator=torch.Generator().manual_seed(11)).int()
     dx0 = rnd(rows, D, seed=12)
     dx = dx0.clone().to(dev()); nb = (rows + 3) // 4
-    dgp = torch.empty(nb, D, device=dev()); dyo = torch.empty(rows, D, device=dev())
+    dgp = torch.empty(nb, D, device=dev()); dyo = torch.empty(rows, D, device=dev()); dxlp = torch.empty(rows, D, dtype=torch.bfloat16, device=dev())
     xd, gd, dad, dbd, Gd, pd = (t.to(dev()) for t in (x, g, da, db, Gm, pos))
     L.check(lib.mode_rmsnorm_bwd(xd.data_ptr(), gd.data_ptr(), dad.data_ptr(), dbd.data_ptr(), Gd.data_ptr() if k else None,
-                                 pd.data_ptr() if k else None, k, rows, D, 1e-6, dx.data_ptr(), 1, dgp.data_ptr(), dyo.data_ptr(), H.stream()))
+                                 pd.data_ptr() if k else None, k, rows, D, 1e-6, dx.data_ptr(), 1, dgp.data_ptr(), dyo.data_ptr(), dxlp.data_ptr(),
+                                 L.MODE_BF16, H.stream()))
     xr = x.clone().requires_grad_(True); gr = g.clone().requires_grad_(True)
     dy = da + db
     if k:
@@ -117,6 +118,7 @@ def test_rmsnorm_bwd_with_gather(rows, D, k):
     O.rmsnorm(xr, gr).backward(dy)
     assert rel(dyo, dy) < 1e-6
     assert rel(dx, dx0 + xr.grad) < 1e-5
+    assert rel(dxlp.float(), dx0 + xr.grad) < 5e-3
     assert rel(dgp.sum(0), gr.grad) < 1e-5
 
 
