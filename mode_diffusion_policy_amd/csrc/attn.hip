@@ -187,38 +187,40 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
   }
 }
 
-// ---- backward (training): one wave per (sample, head), everything in LDS, plain fp32 VALU in the forward's order.
+// ---- backward (training): one 256-thread workgroup per (sample, head), everything in LDS, fp32 VALU in the forward's order.
 // dY [B*T, D] (T2 = bf16/f32) -> dqkv [B*T, 3D]; per-workgroup partial gradients of the qk-norm gains: dgq/dgk [B*H, HD].
 template <typename T2>
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const T2* __restrict__ qkv, const float* __restrict__ qg, const float* __restrict__ kg,
-                                                      const T2* __restrict__ dY, T2* __restrict__ dqkv, float* __restrict__ dgq_part,
-                                                      float* __restrict__ dgk_part, int B, int T, int H, int HD, float eps, uint32_t seed,
-                                                      uint32_t thresh, float inv_keep) {
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qkv, const float* __restrict__ qg, const float* __restrict__ kg,
+                                                       const T2* __restrict__ dY, T2* __restrict__ dqkv, float* __restrict__ dgq_part,
+                                                       float* __restrict__ dgk_part, int B, int T, int H, int HD, float eps, uint32_t seed,
+                                                       uint32_t thresh, float inv_keep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sq = reinterpret_cast<float*>(smem);          // raw q  [T][HD]
-  float* sk = sq + T * HD;                             // raw k
-  float* sv = sk + T * HD;                             // v
-  float* sdo = sv + T * HD;                            // dO
-  float* sdq = sdo + T * HD;                           // d q_hat
-  float* sdk = sdq + T * HD;                           // d k_hat
-  float* sp = sdk + T * HD;                            // P (after dropout scaling: Pd)   [T][T]
-  float* sds = sp + T * T;                             // dS                               [T][T]
-  float* srq = sds + T * T;                            // 1/norm per token (q)             [T]
+  const int HP = HD + 1;                               // padded row (bank-conflict-free column walks)
+  float* sq = reinterpret_cast<float*>(smem);          // raw q  [T][HP]
+  float* sk = sq + T * HP;                             // raw k
+  float* sv = sk + T * HP;                             // v
+  float* sdo = sv + T * HP;                            // dO
+  float* sqh = sdo + T * HP;                           // q_hat, later d q_hat
+  float* skh = sqh + T * HP;                           // k_hat, later d k_hat
+  float* sp = skh + T * HP;                            // P                                 [T][T]
+  float* sds = sp + T * T;                             // dPd, then dS                      [T][T]
+  float* srq = sds + T * T;                            // 1/norm per token (q)              [T]
   float* srk = srq + T;                                // (k)
-  const int lane = threadIdx.x, prob = blockIdx.x, b = prob / H, h = prob % H, D = H * HD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int prob = blockIdx.x, b = prob / H, h = prob % H, D = H * HD;
   const long ld = 3L * D;
   auto LD = [](const T2* p) -> float { if constexpr (sizeof(T2) == 2) return bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(p)); else return *reinterpret_cast<const float*>(p); };
   auto ST = [](T2* p, float v) { if constexpr (sizeof(T2) == 2) *reinterpret_cast<uint16_t*>(p) = f32_to_bf16_bits(v); else *reinterpret_cast<float*>(p) = v; };
-  for (int i = lane; i < T * HD; i += 64) {
+  for (int i = tid; i < T * HD; i += 256) {
     const int t = i / HD, d = i % HD;
     const T2* r = qkv + ((long)b * T + t) * ld + h * HD + d;
-    sq[i] = LD(r); sk[i] = LD(r + D); sv[i] = LD(r + 2 * D);
-    sdo[i] = LD(dY + ((long)b * T + t) * D + h * HD + d);
+    sq[t * HP + d] = LD(r); sk[t * HP + d] = LD(r + D); sv[t * HP + d] = LD(r + 2 * D);
+    sdo[t * HP + d] = LD(dY + ((long)b * T + t) * D + h * HD + d);
   }
   __syncthreads();
-  for (int t = 0; t < T; ++t) {
+  for (int t = wave; t < T; t += 4) {                  // one wave per token: row norms
     float a = 0.f, c = 0.f;
-    for (int d = lane; d < HD; d += 64) { a += sq[t * HD + d] * sq[t * HD + d]; c += sk[t * HD + d] * sk[t * HD + d]; }
+    for (int d = lane; d < HD; d += 64) { a += sq[t * HP + d] * sq[t * HP + d]; c += sk[t * HP + d] * sk[t * HP + d]; }
     a = wave_sum(a); c = wave_sum(c);
     if (lane == 0) {
       srq[t] = 1.0f / fmaxf(sqrtf(a) * rsqrtf((float)HD), eps);
@@ -226,75 +228,85 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const T2* __restrict__ qkv
     }
   }
   __syncthreads();
+  for (int i = tid; i < T * HD; i += 256) {
+    const int t = i / HD, d = i % HD;
+    sqh[t * HP + d] = sq[t * HP + d] * srq[t] * qg[d];
+    skh[t * HP + d] = sk[t * HP + d] * srk[t] * kg[d];
+  }
+  __syncthreads();
   const float scale = rsqrtf((float)HD);
-  // S = q_hat k_hat^T * scale (causal) and dPd = dO V^T
-  for (int i = lane; i < T * T; i += 64) {
+  for (int i = tid; i < T * T; i += 256) {             // S = q_hat k_hat^T * scale (causal) and dPd = dO V^T
     const int qi = i / T, ki = i % T;
     float s = -INFINITY, dp = 0.f;
     if (ki <= qi) {
       s = 0.f;
-      for (int d = 0; d < HD; ++d) {
-        s = fmaf(sq[qi * HD + d] * srq[qi] * qg[d], sk[ki * HD + d] * srk[ki] * kg[d], s);
-        dp = fmaf(sdo[qi * HD + d], sv[ki * HD + d], dp);
-      }
+      for (int d = 0; d < HD; ++d) { s = fmaf(sqh[qi * HP + d], skh[ki * HP + d], s); dp = fmaf(sdo[qi * HP + d], sv[ki * HP + d], dp); }
       s *= scale;
     }
     sp[i] = s; sds[i] = dp;
   }
   __syncthreads();
-  if (lane < T) {                                       // softmax row, dropout, dS = P * (dP - sum(dP*P)) * scale
-    const int qi = lane;
+  if (tid < T) {                                        // softmax row, dropout, dS = P * (dP - sum(dP*P)) * scale
+    const int qi = tid;
     float mx = -INFINITY;
     for (int ki = 0; ki <= qi; ++ki) mx = fmaxf(mx, sp[qi * T + ki]);
     float sum = 0.f;
     for (int ki = 0; ki <= qi; ++ki) sum += expf(sp[qi * T + ki] - mx);
     float rs = 0.f;
     for (int ki = 0; ki < T; ++ki) {
-      float pv = (ki <= qi) ? expf(sp[qi * T + ki] - mx) / sum : 0.f;
+      const float pv = (ki <= qi) ? expf(sp[qi * T + ki] - mx) / sum : 0.f;
       float m = 1.0f;
       if (thresh) m = attn_keep(seed, prob, T, qi, ki, thresh) ? inv_keep : 0.f;
-      const float dP = sds[qi * T + ki] * m;          // gradient wrt the un-dropped probability
+      const float dP = sds[qi * T + ki] * m;           // gradient wrt the un-dropped probability
       rs += dP * pv;
-      sp[qi * T + ki] = pv;                            // keep P; Pd = P*m is re-derived below
+      sp[qi * T + ki] = pv;
       sds[qi * T + ki] = dP;
     }
     for (int ki = 0; ki < T; ++ki) sds[qi * T + ki] = sp[qi * T + ki] * (sds[qi * T + ki] - rs) * scale;
   }
   __syncthreads();
   // dV[j][d] = sum_{i>=j} Pd[i][j] dO[i][d];  dq_hat[i][d] = sum_{j<=i} dS[i][j] k_hat[j][d];  dk_hat[j][d] = sum_{i>=j} dS[i][j] q_hat[i][d]
-  for (int i = lane; i < T * HD; i += 64) {
+  float dqr[8], dkr[8];                                 // results for this thread's (t, d) slots, written after the barrier (in-place reuse)
+  int nslot = 0;
+  for (int i = tid; i < T * HD; i += 256, ++nslot) {
     const int t = i / HD, d = i % HD;
     float dv = 0.f, dq = 0.f, dk = 0.f;
     for (int u = 0; u < T; ++u) {
       if (u >= t) {
         float pd = sp[u * T + t];
         if (thresh) pd = attn_keep(seed, prob, T, u, t, thresh) ? pd * inv_keep : 0.f;
-        dv = fmaf(pd, sdo[u * HD + d], dv);
-        dk = fmaf(sds[u * T + t], sq[u * HD + d] * srq[u] * qg[d], dk);
+        dv = fmaf(pd, sdo[u * HP + d], dv);
+        dk = fmaf(sds[u * T + t], sqh[u * HP + d], dk);
       }
-      if (u <= t) dq = fmaf(sds[t * T + u], sk[u * HD + d] * srk[u] * kg[d], dq);
+      if (u <= t) dq = fmaf(sds[t * T + u], skh[u * HP + d], dq);
     }
-    sdq[i] = dq; sdk[i] = dk;
+    if (nslot < 8) { dqr[nslot] = dq; dkr[nslot] = dk; }
     ST(dqkv + ((long)b * T + t) * ld + 2 * D + h * HD + d, dv);
   }
   __syncthreads();
+  nslot = 0;
+  for (int i = tid; i < T * HD; i += 256, ++nslot) {    // overwrite q_hat / k_hat with their gradients
+    const int t = i / HD, d = i % HD;
+    if (nslot < 8) { sqh[t * HP + d] = dqr[nslot]; skh[t * HP + d] = dkr[nslot]; }
+  }
+  __syncthreads();
   // qk-RMSNorm backward (x_hat = x * r * g): dx = g*dxh*r - x * <g*dxh, x> * r^3 / HD  (clamped rows: dx = g*dxh/eps)
-  for (int t = 0; t < T; ++t) {
+  for (int t = wave; t < T; t += 4) {
     float cq = 0.f, ck = 0.f;
-    for (int d = lane; d < HD; d += 64) { cq += qg[d] * sdq[t * HD + d] * sq[t * HD + d]; ck += kg[d] * sdk[t * HD + d] * sk[t * HD + d]; }
+    for (int d = lane; d < HD; d += 64) { cq += qg[d] * sqh[t * HP + d] * sq[t * HP + d]; ck += kg[d] * skh[t * HP + d] * sk[t * HP + d]; }
     cq = wave_sum(cq); ck = wave_sum(ck);
     const float rq = srq[t], rk = srk[t];
     const bool clq = rq >= 1.0f / eps, clk = rk >= 1.0f / eps;
     for (int d = lane; d < HD; d += 64) {
-      const float dq = qg[d] * sdq[t * HD + d] * rq - (clq ? 0.f : sq[t * HD + d] * cq * rq * rq * rq / (float)HD);
-      const float dk = kg[d] * sdk[t * HD + d] * rk - (clk ? 0.f : sk[t * HD + d] * ck * rk * rk * rk / (float)HD);
+      const float dq = qg[d] * sqh[t * HP + d] * rq - (clq ? 0.f : sq[t * HP + d] * cq * rq * rq * rq / (float)HD);
+      const float dk = kg[d] * skh[t * HP + d] * rk - (clk ? 0.f : sk[t * HP + d] * ck * rk * rk * rk / (float)HD);
       ST(dqkv + ((long)b * T + t) * ld + h * HD + d, dq);
       ST(dqkv + ((long)b * T + t) * ld + D + h * HD + d, dk);
     }
   }
-  for (int d = lane; d < HD; d += 64) {                 // gain-gradient partials of this (sample, head)
+  for (int d = tid; d < HD; d += 256) {                 // gain-gradient partials of this (sample, head)
     float a = 0.f, c = 0.f;
-    for (int t = 0; t < T; ++t) { a += sdq[t * HD + d] * sq[t * HD + d] * srq[t]; c += sdk[t * HD + d] * sk[t * HD + d] * srk[t]; }
+    for (int t = 0; t < T; ++t) { a += sqh[t * HP + d] * sq[t * HP + d] * srq[t]; c += skh[t * HP + d] * sk[t * HP + d] * srk[t]; }
     dgq_part[(long)prob * HD + d] = a; dgk_part[(long)prob * HD + d] = c;
   }
 }
@@ -338,15 +350,15 @@ extern "C" int mode_attn_block_bwd(const void* qkv, const float* q_gain, const f
   if (!qkv || !q_gain || !k_gain || !dy || !dqkv || !dgq_partial || !dgk_partial || B < 0 || T <= 0 || H <= 0) return MODE_ERR_BAD_ARG;
   if (p_drop < 0.f || p_drop >= 1.f) return MODE_ERR_BAD_ARG;
   if (B == 0) return MODE_OK;
-  const size_t lds = ((size_t)6 * T * head_dim + 2 * (size_t)T * T + 2 * T) * 4;
-  if (lds > 64 * 1024) return MODE_ERR_UNSUPPORTED;
+  const size_t lds = ((size_t)6 * T * (head_dim + 1) + 2 * (size_t)T * T + 2 * T) * 4;
+  if (lds > 64 * 1024 || (size_t)T * head_dim > 8 * 256) return MODE_ERR_UNSUPPORTED;
   const uint32_t th = attn_thresh(p_drop); const float ik = 1.0f / (1.0f - p_drop);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MODE_BF16)
-    hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, dim3(B * H), dim3(64), lds, s, (const uint16_t*)qkv, q_gain, k_gain, (const uint16_t*)dy, (uint16_t*)dqkv,
+    hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, dim3(B * H), dim3(256), lds, s, (const uint16_t*)qkv, q_gain, k_gain, (const uint16_t*)dy, (uint16_t*)dqkv,
                        dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik);
   else
-    hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B * H), dim3(64), lds, s, (const float*)qkv, q_gain, k_gain, (const float*)dy, (float*)dqkv,
+    hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B * H), dim3(256), lds, s, (const float*)qkv, q_gain, k_gain, (const float*)dy, (float*)dqkv,
                        dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik);
   MODE_LAUNCH_CHECK();
   return MODE_OK;

@@ -186,7 +186,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
   mode_moe_meta_layout(N, E, d.k, &ml);
   float* DXa = (float*)(ws + W.dxa); float* DXb = (float*)(ws + W.dxb);
   float* dcond = (float*)(ws + W.dcond);
-  void* csw = ws + W.csw; const size_t cswb = mode_colsum_workspace_bytes(NK, 8 * D, E) + 4096;
+  void* csw = ws + W.csw; const size_t cswb = W.dcond - W.csw;        // everything up to the next carve
   float* dgp = (float*)(ws + W.dgp);
   const int nblk4 = (N + 3) / 4;
   auto colsum = [&](const void* X, long ld, int rows, int cols, int xdt, const int32_t* segoff, int seglen, int nseg, float* out, int acc) {
