@@ -147,6 +147,64 @@ def cpu_baseline():
                       f"oracle/mode_oracle.py with torch.set_num_threads({cores}); cpu: {model}"}
 
 
+def train_bench(args, world, rank, device, dist):
+    """BASELINE configs 3/4: score-matching training step of the full model, B=128 per GPU (global 128*N), AdamW included,
+    gradients averaged over ranks through the static-bucket reducer (RCCL reduce-scatter + all-gather)."""
+    import math
+    from mode_diffusion_policy_amd.ddp import BucketedGradReducer, optimizer_param_groups
+    from mode_diffusion_policy_amd.utils import rand_log_logistic
+    M, den = build_model(device, args.dtype)
+    m = den.inner_model
+    den.train()
+    B = B_PER_GPU
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)                 # every rank gets its own shard of the synthetic batch
+    img = torch.randn(B, 2, C2["obs_dim"], generator=g).to(device); goal = torch.randn(B, 1, C2["goal_dim"], generator=g).to(device)
+    acts = torch.randn(B, 10, 7, generator=g).to(device); noise = torch.randn(B, 10, 7, generator=g).to(device)
+    opt = torch.optim.AdamW(optimizer_param_groups(m, 0.05), lr=1e-4, betas=(0.9, 0.95), fused=True)   # mode_agent.yaml:24-29
+    red = BucketedGradReducer(m, bucket_mb=256.0) if world > 1 else None
+
+    def step():
+        sig = rand_log_logistic((B,), loc=math.log(SIGMA_DATA), scale=0.5, min_value=SIGMA_MIN, max_value=SIGMA_MAX, device=device)
+        opt.zero_grad(set_to_none=True)
+        loss, _ = den.loss({"state_images": img}, acts, goal, noise, sig)
+        loss.backward()
+        if red is not None:
+            red.finish()
+        opt.step()
+        return loss
+    for _ in range(max(args.warmup, 1)):
+        loss = step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss.detach()).all()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        fl = 3.0 * flops_per_denoise_step(B)                                   # fwd + bwd ~ 3x forward (BASELINE.md §4)
+        res = {"metric": "train-samples/sec (score-matching step, B=128 per GPU, AdamW)", "value": round(world * B * args.steps / elapsed, 1),
+               "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "configs[2]/[3]: score-matching training step of the full MoDE denoiser (12 layers, d=1024, 4 experts top-2), "
+                                      "B=128 per GPU, log-logistic sigma, multinomial routing, dropouts on, fused AdamW, router unfrozen",
+                          "global_batch": B * world, "parallelism": f"dp{world}"},
+               "train_tflops_per_gpu": round(fl * args.steps / elapsed / 1e12, 1)}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +212,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
+                    help="sample (default, BASELINE metric): 10-step DDIM chunks; train: config-3/4 score-matching steps (fwd+bwd+AdamW, DP all-reduce)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,6 +229,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
+    if args.mode == "train":
+        return train_bench(args, world, rank, device, dist)
     M, den = build_model(device, args.dtype)
     img, goal, x0 = synthetic_inputs(device, B_PER_GPU)
     sig = M.get_sigmas_exponential(N_SAMPLING_STEPS, SIGMA_MIN, SIGMA_MAX).to(device)
