@@ -79,7 +79,7 @@ def dominant_kernel_roofline(den, device, reps=60):
     Hb = torch.empty(N * k, 4 * D, dtype=torch.bfloat16, device=device)
     descs = []
     for l in range(m.num_layers):
-        kp = eng._keep
+        kp = {**eng.arena.w, **eng.arena.wl}
         d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_SWIGLU, out_dtype=L.MODE_BF16, M=N * k, N=4 * D, K=D, A=u.data_ptr(), lda=D,
                            W=kp[f"l{l}.w1"].data_ptr(), ldw=D, w_expert_stride=8 * D * D, bias=kp[f"l{l}.b1"].data_ptr(),
                            bias_expert_stride=8 * D, resid=None, ldr=0, C=Hb.data_ptr(), ldc=4 * D, a_rows=mp + 4 * ml.perm,
@@ -149,9 +149,10 @@ def cpu_baseline():
 
 def train_bench(args, world, rank, device, dist):
     """BASELINE configs 3/4: score-matching training step of the full model, B=128 per GPU (global 128*N), AdamW included,
-    gradients averaged over ranks through the static-bucket reducer (RCCL reduce-scatter + all-gather)."""
+    gradient arena summed over ranks in flat slices (RCCL), 1/world folded into the fused AdamW pass."""
     import math
-    from mode_diffusion_policy_amd.ddp import BucketedGradReducer, optimizer_param_groups
+    from mode_diffusion_policy_amd.ddp import ArenaGradReducer
+    from mode_diffusion_policy_amd.optim import FusedAdamW
     from mode_diffusion_policy_amd.utils import rand_log_logistic
     M, den = build_model(device, args.dtype)
     m = den.inner_model
@@ -160,17 +161,14 @@ def train_bench(args, world, rank, device, dist):
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)                 # every rank gets its own shard of the synthetic batch
     img = torch.randn(B, 2, C2["obs_dim"], generator=g).to(device); goal = torch.randn(B, 1, C2["goal_dim"], generator=g).to(device)
     acts = torch.randn(B, 10, 7, generator=g).to(device); noise = torch.randn(B, 10, 7, generator=g).to(device)
-    opt = torch.optim.AdamW(optimizer_param_groups(m, 0.05), lr=1e-4, betas=(0.9, 0.95), fused=True)   # mode_agent.yaml:24-29
-    red = BucketedGradReducer(m, bucket_mb=256.0) if world > 1 else None
+    opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)         # mode_agent.yaml:24-29, two groups as mode_agent.py:365-384
+    red = ArenaGradReducer.for_model(m) if world > 1 else None
 
     def step():
         sig = rand_log_logistic((B,), loc=math.log(SIGMA_DATA), scale=0.5, min_value=SIGMA_MIN, max_value=SIGMA_MAX, device=device)
-        opt.zero_grad(set_to_none=True)
         loss, _ = den.loss({"state_images": img}, acts, goal, noise, sig)
         loss.backward()
-        if red is not None:
-            red.finish()
-        opt.step()
+        opt.step(grad_scale=red.reduce() if red is not None else 1.0)
         return loss
     for _ in range(max(args.warmup, 1)):
         loss = step()

@@ -245,6 +245,12 @@ int mode_gelu_bwd(const float* pre, const float* dout, float* dpre, int64_t n, v
 int mode_moe_router_bwd(const float* dw, const int32_t* idx, const float* probs, int B, int T, int E, int k, int normalize,
                         int idx_per_token, float* dlogits, void* stream);
 int mode_sigma_embed_bwd(const float* de1, const float* sigma, int B, int D, float* dw, float* db, void* stream);
+/* Fused AdamW over a flat fp32 slice (p, g, m, v: n elements, n % 4 == 0, 16-byte aligned).  Replaces torch.optim.AdamW as configured by
+ * MoDEAgent.configure_optimizers (mode/models/mode_agent.py:365-392): decoupled weight decay, bias correction by `step` (1-based),
+ * g is scaled by grad_scale first (1/world for a summed data-parallel gradient).  lp_bf16 (nullable) receives the updated weights
+ * rounded to bf16 — the compute shadow of the next forward. */
+int mode_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, float grad_scale, void* lp_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Whole-denoiser forward: the launch chain of one MoDeDiT.forward (modedit.py:741-821) [+ GCDenoiser.forward scalings

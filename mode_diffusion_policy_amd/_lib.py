@@ -149,6 +149,7 @@ PROTOTYPES = {
     "mode_dit_train_stash_layout": (C.c_int, [P(ModeDims), C.c_int, C.c_int, P(ModeStashLayout)]),
     "mode_dit_train_workspace_bytes": (c_sz, [P(ModeDims), C.c_int, C.c_int]),
     "mode_dit_forward_train": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeTrainArgs), c_vp, c_sz, c_vp]),
+    "mode_adamw_step": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i32, C.c_float, c_vp, c_vp]),
     "mode_dit_backward": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeModelWeightsT), P(ModeTrainArgs), c_vp, c_vp, P(ModeModelGrads),
                                     c_vp, c_sz, c_vp]),
     "mode_dit_forward": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeForwardArgs), c_vp, c_sz, c_vp]),

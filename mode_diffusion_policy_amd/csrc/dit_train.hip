@@ -203,6 +203,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     if ((rc = mode_transpose(dF, A, R, A, dFT, R, nullptr, nullptr, MODE_F32, stream))) return rc;
     if ((rc = mode_transpose(sg + sl.yL, D, R, D, yT, R, a->act_rows, nullptr, MODE_F32, stream))) return rc;
     g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, A, D, R, dFT, R, yT, R, gr->w_out, D);
+    g.flags = MODE_GEMM_SKINNY_OK;
     if ((rc = mode_gemm(&g, stream))) return rc;
     if ((rc = colsum(dF, A, R, A, MODE_F32, nullptr, 0, 1, gr->b_out, 0))) return rc;
     float* dyl = (float*)(ws + W.dyl);
@@ -298,6 +299,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       if ((rc = mode_transpose(dlog, E, B, E, st1, B, nullptr, nullptr, MODE_F32, stream))) return rc;
       if ((rc = mode_transpose(hid, 2 * D, B, 2 * D, st2, B, nullptr, nullptr, MODE_F32, stream))) return rc;
       g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, E, 2 * D, B, st1, B, st2, B, lg.r_w3, 2 * D);
+      g.flags = MODE_GEMM_SKINNY_OK;                                                        // M = E rows: stream hid^T once
       if ((rc = mode_gemm(&g, stream))) return rc;
       // dhid = dlog W3 ; dpre = dhid * gelu'(pre)
       g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, B, 2 * D, E, dlog, E, lt.r_w3T, E, dhid, 2 * D);

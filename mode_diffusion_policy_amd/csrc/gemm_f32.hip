@@ -199,6 +199,50 @@ __global__ __launch_bounds__(256) void linear_f32_skinny_kernel(const float* __r
   }
 }
 
+// ---- small-N path (N <= 16: router logits [B, E], output head [R, A]): one wave per output element, both rows streamed with float4
+// loads, xor-butterfly reduction.  Chosen by N only (never by the batch size), so results do not depend on how many rows are batched.
+template <int EPI>
+__global__ __launch_bounds__(256) void linear_f32_dot_kernel(const float* __restrict__ X, long ldx, const int* __restrict__ x_rows,
+                                                              const float* __restrict__ W, long ldw, const float* __restrict__ bias,
+                                                              const float* resid, long ldr, float* Y, long ldy, int M, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= (long)M * N) return;
+  const int m = o / N, n = o % N;
+  const float* x = X + (x_rows ? (long)x_rows[m] : (long)m) * ldx;
+  const float* w = W + (long)n * ldw;
+  float acc = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + k);
+    const float4 wv = *reinterpret_cast<const float4*>(w + k);
+    acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    if constexpr (EPI == MODE_EPI_BIAS || EPI == MODE_EPI_BIAS_GELU) acc += bias[n];
+    if constexpr (EPI == MODE_EPI_BIAS_GELU) acc = gelu_erf_f(acc);
+    if constexpr (EPI == MODE_EPI_RESIDUAL) acc += resid[(long)m * ldr + n];
+    Y[(long)m * ldy + n] = acc;
+  }
+}
+
+static int launch_dot(const ModeGemmDesc* d, hipStream_t s) {
+  const long outs = (long)d->M * d->N;
+  const dim3 grid((outs + 3) / 4), blk(256);
+  const float* X = (const float*)d->A; const float* W = (const float*)d->W; float* Y = (float*)d->C;
+#define MODE_DOT(E) hipLaunchKernelGGL(linear_f32_dot_kernel<E>, grid, blk, 0, s, X, d->lda, d->a_rows, W, d->ldw, d->bias, d->resid, d->ldr, Y, d->ldc, d->M, d->N, d->K)
+  switch (d->epilogue) {
+    case MODE_EPI_NONE: MODE_DOT(MODE_EPI_NONE); break;
+    case MODE_EPI_BIAS: MODE_DOT(MODE_EPI_BIAS); break;
+    case MODE_EPI_BIAS_GELU: MODE_DOT(MODE_EPI_BIAS_GELU); break;
+    case MODE_EPI_RESIDUAL: MODE_DOT(MODE_EPI_RESIDUAL); break;
+    default: return MODE_ERR_BAD_ARG;
+  }
+#undef MODE_DOT
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
 static int launch_skinny(const ModeGemmDesc* d, hipStream_t s) {
   const dim3 grid((d->N + 3) / 4), blk(256);
   const float* X = (const float*)d->A; const float* W = (const float*)d->W; float* Y = (float*)d->C;
@@ -226,7 +270,10 @@ int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s) {
     return MODE_ERR_BAD_ARG;
   if (d->epilogue == MODE_EPI_RESIDUAL && !d->resid) return MODE_ERR_BAD_ARG;
   if (d->M <= 0) return MODE_OK;
-  if ((d->flags & MODE_GEMM_SKINNY_OK) && d->M <= 16 && !d->a_rows && !d->expert_offsets && d->out_dtype == MODE_F32 && d->K % 4 == 0 && d->lda % 4 == 0 && d->ldw % 4 == 0 &&
+  if (d->N <= 16 && d->K >= 64 && d->K % 4 == 0 && !d->expert_offsets && !d->k_group_offsets && d->out_dtype == MODE_F32 && d->lda % 4 == 0 &&
+      d->ldw % 4 == 0 && d->epilogue != MODE_EPI_SWIGLU && (((uintptr_t)d->A | (uintptr_t)d->W) % 16 == 0))
+    return launch_dot(d, s);
+  if ((d->flags & MODE_GEMM_SKINNY_OK) && d->M <= 16 && !d->a_rows && !d->expert_offsets && !d->k_group_offsets && d->out_dtype == MODE_F32 && d->K % 4 == 0 && d->lda % 4 == 0 && d->ldw % 4 == 0 &&
       (d->epilogue == MODE_EPI_NONE || d->epilogue == MODE_EPI_BIAS || d->epilogue == MODE_EPI_BIAS_GELU) &&
       (((uintptr_t)d->A | (uintptr_t)d->W) % 16 == 0))
     return launch_skinny(d, s);

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
 // stage 1: block (x = 64-column group, y = row split, z = segment) -> partial[z][y][col]
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(const T* __restrict__ X, long ld, int rows, int cols, const int* __restrict__ seg_off,
-                                                            int seg_len, int nsplit, float* __restrict__ partial) {
+                                                            int seg_len, int nsplit, float* __restrict__ partial, float* out, int accumulate) {
   __shared__ float red[4][64];
   const int seg = blockIdx.z, sp = blockIdx.y;
   int o0, o1;
@@ -69,8 +69,11 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const T* __restrict_
     for (int r = ra + ty; r < rb; r += 4) acc += ld1<T>(X + (long)r * ld + c);
   red[ty][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (ty == 0 && c < cols)
-    partial[((long)seg * nsplit + sp) * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (ty == 0 && c < cols) {
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (out) { float* o = out + (long)seg * cols + c; *o = accumulate ? *o + v : v; }            // single stage (nsplit == 1)
+    else partial[((long)seg * nsplit + sp) * cols + c] = v;
+  }
 }
 // stage 2: out[seg][col] (+)= sum over splits in order
 __global__ void colsum_stage2_kernel(const float* __restrict__ partial, int nseg, int nsplit, int cols, float* __restrict__ out, int accumulate) {
@@ -301,30 +304,35 @@ extern "C" int mode_transpose(const void* src, int64_t ld_src, int rows, int col
   return MODE_OK;
 }
 
-extern "C" size_t mode_colsum_workspace_bytes(int rows, int cols, int nseg) {
-  if (nseg < 1) nseg = 1;
+static int colsum_nsplit(int rows, int cols, int nseg) {
+  if (rows <= 512) return 1;                                      // one stage: every column group walks its rows itself
   int nsplit = 1;
   const long per = (long)((cols + 63) / 64) * nseg;
   while (per * nsplit < 1024 && nsplit * 64 < rows) nsplit *= 2;
-  return (size_t)nseg * nsplit * cols * 4;
+  return nsplit;
+}
+
+extern "C" size_t mode_colsum_workspace_bytes(int rows, int cols, int nseg) {
+  if (nseg < 1) nseg = 1;
+  return (size_t)nseg * colsum_nsplit(rows, cols, nseg) * cols * 4 + 256;
 }
 
 extern "C" int mode_colsum(const void* X, int64_t ld, int rows, int cols, int dtype, const int32_t* seg_offsets, int seg_len, int nseg,
                            float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   if (!X || !out || !workspace || rows < 0 || cols <= 0) return MODE_ERR_BAD_ARG;
   if (nseg < 1) nseg = 1;
-  int nsplit = 1;
-  const long per = (long)((cols + 63) / 64) * nseg;
-  while (per * nsplit < 1024 && nsplit * 64 < rows) nsplit *= 2;
+  const int nsplit = colsum_nsplit(rows, cols, nseg);
   if (workspace_bytes < (size_t)nseg * nsplit * cols * 4) return MODE_ERR_WORKSPACE;
   float* partial = (float*)workspace;
   const dim3 grid((cols + 63) / 64, nsplit, nseg);
   hipStream_t s = (hipStream_t)stream;
+  float* direct = nsplit == 1 ? out : nullptr;
   if (dtype == MODE_BF16)
-    hipLaunchKernelGGL(colsum_stage1_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)X, (long)ld, rows, cols, seg_offsets, seg_len, nsplit, partial);
+    hipLaunchKernelGGL(colsum_stage1_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)X, (long)ld, rows, cols, seg_offsets, seg_len, nsplit, partial, direct, accumulate);
   else
-    hipLaunchKernelGGL(colsum_stage1_kernel<float>, grid, dim3(256), 0, s, (const float*)X, (long)ld, rows, cols, seg_offsets, seg_len, nsplit, partial);
+    hipLaunchKernelGGL(colsum_stage1_kernel<float>, grid, dim3(256), 0, s, (const float*)X, (long)ld, rows, cols, seg_offsets, seg_len, nsplit, partial, direct, accumulate);
   MODE_LAUNCH_CHECK();
+  if (nsplit == 1) return MODE_OK;
   const long n = (long)nseg * cols;
   hipLaunchKernelGGL(colsum_stage2_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, nseg, nsplit, cols, out, accumulate);
   MODE_LAUNCH_CHECK();
@@ -425,6 +433,53 @@ extern "C" int mode_sigma_embed_bwd(const float* de1, const float* sigma, int B,
   if (!de1 || !sigma || !dw || !db) return MODE_ERR_BAD_ARG;
   if (D == 0) return MODE_OK;
   hipLaunchKernelGGL(sigma_embed_bwd_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, de1, sigma, B, D, dw, db);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused AdamW over a flat fp32 arena slice (replaces torch.optim.AdamW's multi-tensor loop for mode_agent.py:365-384's two groups).
+// One pass: reads p, g, m, v (16 B/elem), writes p, m, v (12 B/elem) and, when asked, the bf16 compute shadow (2 B/elem) — so the
+// low-precision weights the next forward reads never need a separate cast pass.  Arithmetic follows torch's single-tensor AdamW order.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    long n4, float decay, float b1, float b2, float eps, float step_size, float inv_bc2_sqrt,
+                                                    float gscale, uint16_t* __restrict__ lp) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 P = reinterpret_cast<float4*>(p)[i];
+    const float4 G = reinterpret_cast<const float4*>(g)[i];
+    float4 M = reinterpret_cast<float4*>(m)[i];
+    float4 V = reinterpret_cast<float4*>(v)[i];
+    float* pp = &P.x; const float* gg = &G.x; float* mm = &M.x; float* vv = &V.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = gg[j] * gscale;
+      float w = pp[j] * decay;
+      mm[j] = mm[j] + (gr - mm[j]) * (1.f - b1);
+      vv[j] = vv[j] * b2 + (1.f - b2) * gr * gr;
+      const float denom = sqrtf(vv[j]) * inv_bc2_sqrt + eps;
+      w -= step_size * (mm[j] / denom);
+      pp[j] = w;
+    }
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(m)[i] = M;
+    reinterpret_cast<float4*>(v)[i] = V;
+    if (lp) {
+      uint2 o; o.x = pack_bf16x2(P.x, P.y); o.y = pack_bf16x2(P.z, P.w);
+      reinterpret_cast<uint2*>(lp)[i] = o;
+    }
+  }
+}
+
+extern "C" int mode_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int step, float grad_scale, void* lp_bf16, void* stream) {
+  if (n == 0) return MODE_OK;
+  if (!p || !g || !m || !v || n < 0 || n % 4 || step < 1 || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) || ((uintptr_t)lp_bf16 & 7))
+    return MODE_ERR_BAD_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const long n4 = n / 4;
+  const int blocks = (int)std::min<long>((n4 + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, 1.f - lr * weight_decay, beta1, beta2, eps,
+                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, (uint16_t*)lp_bf16);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }

@@ -165,6 +165,68 @@ class BucketedGradReducer:
             h.remove()
 
 
+class ArenaGradReducer:
+    """Data-parallel gradient exchange for a MoDeDiT whose gradients live in the flat gradient arena (``arena.py``).
+
+    The backward chain writes gradients straight into the arena in backward order (per-layer slices, last layer first), so the
+    exchange is a handful of large collectives over static flat slices — no bucket copies at all.  ``reduce()`` is called once after
+    ``loss.backward()``; slices are issued in arena order on a side stream so the collective of slice i overlaps the mean / copy
+    epilogue of slice i-1.  The SUM is left in place; the division by ``world`` is folded into ``FusedAdamW.step(grad_scale=1/world)``
+    (or applied here with ``average=True`` for foreign optimizers).  xGMI is point-to-point: slices of ``slice_mb`` (default 256 MB,
+    ~ one transformer block) keep each ring step large enough to run at link rate.
+    """
+
+    def __init__(self, grad_flat: torch.Tensor, n_reduce: int, process_group=None, slice_mb: float = 256.0, mode: str = "auto",
+                 average: bool = False):
+        self.grad = grad_flat
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.average = average
+        dev = grad_flat.device
+        if mode == "auto":
+            mode = "allreduce"                              # RCCL picks ring/tree for the xGMI mesh itself; "rs_ag" = explicit in-place halves
+        self.mode = mode
+        per = max(self.world, int(slice_mb * 1024 * 1024 / grad_flat.element_size()) // self.world * self.world)
+        self.slices = []
+        o = 0
+        while o < n_reduce:
+            e = min(n_reduce, o + per)
+            self.slices.append((o, e))
+            o = e
+        self._comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+
+    @classmethod
+    def for_model(cls, model, **kw) -> "ArenaGradReducer":
+        ar = model.engine.arena
+        ar.ensure_grad(model)
+        return cls(ar.grad, ar.bounds["no_decay"], **kw)
+
+    def reduce(self) -> float:
+        """Sum (or average) the gradient arena over ranks; returns the scale the optimizer still has to apply."""
+        if self.world == 1:
+            return 1.0
+        if self._comm_stream is not None:
+            self._comm_stream.wait_stream(torch.cuda.current_stream())
+            ctx = torch.cuda.stream(self._comm_stream)
+        else:
+            from contextlib import nullcontext
+            ctx = nullcontext()
+        with ctx:
+            for lo, hi in self.slices:
+                g = self.grad[lo:hi]
+                if self.mode == "rs_ag" and (hi - lo) % self.world == 0:
+                    shard = g.view(self.world, -1)[dist.get_rank(self.pg)]
+                    dist.reduce_scatter_tensor(shard, g, op=dist.ReduceOp.SUM, group=self.pg)      # in place: shard aliases its own slot
+                    dist.all_gather_into_tensor(g, shard, group=self.pg)
+                else:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+                if self.average:
+                    g.div_(self.world)
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        return 1.0 if self.average else 1.0 / self.world
+
+
 def optimizer_param_groups(model: torch.nn.Module, weight_decay: float):
     """AdamW grouping rule of MoDEAgent.get_optim_groups (mode/models/mode_agent.py:365-384): decay every denoiser parameter whose
     NAME contains none of 'bias' / 'LayerNorm' / 'embedding' (so RMSNorm gains, pos_emb and *_emb.weight ARE decayed)."""

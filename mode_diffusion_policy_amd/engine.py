@@ -1,9 +1,10 @@
 """Host-side driver of the HIP denoiser: weight shadows, workspaces and the launch chain.
 
 PyTorch is plumbing here (device memory, streams); all arithmetic of the hot path runs in libmode_hip.so.
-Weight shadows are plain casts of the reference-layout tensors (q/k/v concatenated, experts stacked) — the on-disk
-``state_dict`` layout is never changed; shadows are rebuilt when any parameter's (data_ptr, _version) changes
-(optimizer step, ``load_state_dict``, EMA swap — SURVEY.md §7 "weight-layout staleness").
+Parameters live in one flat HBM arena (``arena.py``): the module's Parameters are views into it, q/k/v and the experts of a
+block are adjacent (packed operands without copies) and the bf16 compute shadow is one cast of the arena.  The ``state_dict``
+layout is never changed; the shadow is refreshed when a parameter version changes (optimizer step, ``load_state_dict``, EMA
+swap — SURVEY.md §7 "weight-layout staleness").
 """
 from __future__ import annotations
 
@@ -34,7 +35,9 @@ class DitEngine:
         self.dt, self.tdt = _DT[compute_dtype]
         self.lib = L.load()
         self._wkey = None
-        self._keep: Dict[str, torch.Tensor] = {}
+        self._pv = None
+        self._structs_for = None
+        self.arena = None
         self._ws: Optional[torch.Tensor] = None
         m = model
         self.dims = L.ModeDims(D=m.embed_dim, H=m.n_heads, L=m.num_layers, E=m.num_experts, k=m.top_k, T=m.seq_len,
@@ -44,49 +47,60 @@ class DitEngine:
 
     # ------------------------------------------------------------------ weights
     def _key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        ar = self.arena
+        return (id(ar), ar.version, tuple(p._version for p in self.model.parameters()))
 
     def ensure_weights(self) -> None:
+        """Adopt the module's parameters into the flat arena (once) and keep the compute shadow current.
+
+        Staleness: an in-place update through the Parameter views (torch optimizers, ``load_state_dict``, EMA swap) bumps
+        their version counters -> the bf16 shadow is re-cast; ``FusedAdamW`` writes the shadow itself and bumps ``arena.version``;
+        ``.to()`` / ``.half()`` re-allocate parameters -> they no longer alias the arena and it is rebuilt."""
+        m = self.model
+        ar = self.arena
+        if ar is None or not ar.owns(m):
+            dev = m.pos_emb.device
+            if dev.type != "cuda":
+                raise L.ModeHipUnavailable("MoDeDiT parameters must live on a ROCm device: the denoising path has no CPU implementation")
+            from .arena import ParamArena
+            ar = self.arena = ParamArena(m, dev)
+            self.device = dev
+            self._wkey = self._pv = None
+            self._structs_for = None
         key = self._key()
         if key == self._wkey:
             return
-        m, tdt = self.model, self.tdt
-        dev = m.pos_emb.device
-        if dev.type != "cuda":
-            raise L.ModeHipUnavailable("MoDeDiT parameters must live on a ROCm device: the denoising path has no CPU implementation")
-        f32 = lambda t: t.detach().to(torch.float32).contiguous()
-        keep: Dict[str, torch.Tensor] = {}
+        if self._pv is not None and key[2] != self._pv:
+            ar.lp_synced = False                                    # somebody wrote through the Parameter views
+        if self.compute_dtype == "bf16":
+            ar.ensure_lp()
+        if self._structs_for != (id(ar), ar.lp is not None):
+            self._build_structs()
+        self._wkey, self._pv = key, key[2]
+
+    def _build_structs(self) -> None:
+        m, ar = self.model, self.arena
+        mat = ar.wl if self.compute_dtype == "bf16" else ar.w      # GEMM operands in the compute dtype; everything else fp32
+        w = ar.w
         layers = (L.ModeLayerWeights * m.num_layers)()
-        with torch.no_grad():
-            for i, blk in enumerate(m.blocks):
-                a = blk.attn
-                k = f"l{i}."
-                keep[k + "wqkv"] = torch.cat([a.query.weight, a.key.weight, a.value.weight], 0).to(tdt).contiguous()
-                keep[k + "bqkv"] = torch.cat([a.query.bias, a.key.bias, a.value.bias], 0).float().contiguous()
-                keep[k + "wo"] = a.c_proj.weight.detach().to(tdt).contiguous()
-                ex = [blk.experts[f"expert_{e}"].mlp for e in range(m.num_experts)]
-                keep[k + "w1"] = torch.stack([x[0].project.weight for x in ex]).to(tdt).contiguous()
-                keep[k + "b1"] = torch.stack([x[0].project.bias for x in ex]).float().contiguous()
-                keep[k + "w2"] = torch.stack([x[2].weight for x in ex]).to(tdt).contiguous()
-                r = blk.router.router.mlp
-                for nm, t in (("ln1", blk.ln_1.g), ("ln2", blk.ln_2.g), ("qn", a.q_norm.g), ("kn", a.k_norm.g),
-                              ("rw0", r[0].weight), ("rb0", r[0].bias), ("rw3", r[3].weight), ("rb3", r[3].bias)):
-                    keep[k + nm] = f32(t)
-                lw = layers[i]
-                lw.ln1_g, lw.ln2_g, lw.qn_g, lw.kn_g = (_ptr(keep[k + n]) for n in ("ln1", "ln2", "qn", "kn"))
-                lw.wqkv, lw.bqkv, lw.wo = _ptr(keep[k + "wqkv"]), _ptr(keep[k + "bqkv"]), _ptr(keep[k + "wo"])
-                lw.r_w0, lw.r_b0, lw.r_w3, lw.r_b3 = (_ptr(keep[k + n]) for n in ("rw0", "rb0", "rw3", "rb3"))
-                lw.w1, lw.b1, lw.w2 = _ptr(keep[k + "w1"]), _ptr(keep[k + "b1"]), _ptr(keep[k + "w2"])
-            for nm, t in (("pos", m.pos_emb[0]), ("w_se", m.sigma_emb.weight), ("b_se", m.sigma_emb.bias),
-                          ("w_sl", m.sigma_linear.weight), ("w_tok", m.tok_emb.weight), ("w_goal", m.goal_emb.weight),
-                          ("w_act", m.action_emb.weight), ("ln_g", m.ln.g), ("w_out", m.out.weight), ("b_out", m.out.bias)):
-                keep[nm] = f32(t)
+        for i in range(m.num_layers):
+            k = f"l{i}."
+            lw = layers[i]
+            lw.ln1_g, lw.ln2_g, lw.qn_g, lw.kn_g = (_ptr(w[k + n]) for n in ("ln1_g", "ln2_g", "qn_g", "kn_g"))
+            lw.wqkv, lw.bqkv, lw.wo = _ptr(mat[k + "wqkv"]), _ptr(w[k + "bqkv"]), _ptr(mat[k + "wo"])
+            lw.r_w0, lw.r_b0, lw.r_w3, lw.r_b3 = _ptr(w["r_w0"][i]), _ptr(w["r_b0"][i]), _ptr(w["r_w3"][i]), _ptr(w["r_b3"][i])
+            lw.w1, lw.b1, lw.w2 = _ptr(mat[k + "w1"]), _ptr(w[k + "b1"]), _ptr(mat[k + "w2"])
         mw = L.ModeModelWeights()
         for nm in ("pos", "w_se", "b_se", "w_sl", "w_tok", "w_goal", "w_act", "ln_g", "w_out", "b_out"):
-            setattr(mw, nm, _ptr(keep[nm]))
+            setattr(mw, nm, _ptr(w[nm]))
         mw.layers = C.cast(layers, C.POINTER(L.ModeLayerWeights))
-        self._keep, self._layers, self._mw, self._wkey = keep, layers, mw, key
-        self.device = dev
+        self._layers, self._mw = layers, mw
+        self._structs_for = (id(ar), ar.lp is not None)
+
+    def weights_updated(self, lp_synced: bool) -> None:
+        """Called by an optimizer that wrote the arena directly (no autograd version bump)."""
+        self.arena.version += 1
+        self.arena.lp_synced = bool(lp_synced) and self.arena.lp is not None
 
     # ------------------------------------------------------------------ workspace
     def workspace(self, B: int, R: int) -> Tuple[int, int]:

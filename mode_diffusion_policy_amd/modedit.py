@@ -327,7 +327,7 @@ class MoDeDiT(nn.Module):
             idx, meta, ml = self._ddim_chain(eng, img, goals, x, sig, sigma_data)
             self._last_topk = idx
             return x
-        key = (B, sig.numel(), eng.compute_dtype, eng._wkey, str(dev), float(sigma_data))
+        key = (B, sig.numel(), eng.compute_dtype, eng._structs_for, str(dev), float(sigma_data))   # arena pointers are static: weight updates keep graphs valid
         ent = self._route_cache.get("graph")
         if ent is None or ent["key"] != key:
             st = dict(key=key, img=img.clone(), goals=goals.clone(), x=x0.clone().contiguous(), sig=sig.clone())

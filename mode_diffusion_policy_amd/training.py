@@ -21,81 +21,90 @@ from .engine import DitEngine, _ptr, _stream
 
 
 class TrainState:
-    """Per-engine training resources that follow the weights: transposed shadows for the data-gradient GEMMs."""
+    """Per-engine training resources that follow the weights: transposed shadows for the data-gradient GEMMs (allocated once,
+    re-filled in place whenever the weights change) and the pointer tables of the gradient arena."""
 
     def __init__(self, eng: DitEngine):
         self.eng = eng
         self.key = None
         self.keep: Dict[str, torch.Tensor] = {}
+        self.built_for = None
+        self.grads_for = None
+        self._ws = None
 
-    def ensure(self) -> None:
+    def _build(self) -> None:
         eng = self.eng
-        if self.key == eng._wkey:
-            return
-        m, lib, dt, tdt, dev = eng.model, eng.lib, eng.dt, eng.tdt, eng.device
-        D, E = m.embed_dim, m.num_experts
+        m, dev, tdt = eng.model, eng.device, eng.tdt
+        D, E, A, Ly = m.embed_dim, m.num_experts, m.action_dim, m.num_layers
         keep: Dict[str, torch.Tensor] = {}
-
-        def tr(src: torch.Tensor, rows: int, cols: int, dtype_code: int) -> torch.Tensor:
-            dst = torch.empty(cols, rows, dtype=src.dtype, device=dev)
-            L.check(lib.mode_transpose(src.data_ptr(), cols, rows, cols, dst.data_ptr(), rows, None, None, dtype_code, _stream()), "transpose")
-            return dst
-        layers = (L.ModeLayerWeightsT * m.num_layers)()
-        for i in range(m.num_layers):
+        layers = (L.ModeLayerWeightsT * Ly)()
+        keep["r_w0T"] = torch.empty(Ly, D, 2 * D, device=dev)
+        keep["r_w3T"] = torch.empty(Ly, 2 * D, E, device=dev)
+        for i in range(Ly):
             k = f"l{i}."
-            kp = eng._keep
-            keep[k + "wqkvT"] = tr(kp[k + "wqkv"], 3 * D, D, dt)
-            keep[k + "woT"] = tr(kp[k + "wo"], D, D, dt)
-            keep[k + "w1T"] = torch.stack([tr(kp[k + "w1"][e], 8 * D, D, dt) for e in range(E)])
-            keep[k + "w2T"] = torch.stack([tr(kp[k + "w2"][e], D, 4 * D, dt) for e in range(E)])
-            keep[k + "rw0T"] = tr(kp[k + "rw0"], 2 * D, D, L.MODE_F32)
-            keep[k + "rw3T"] = tr(kp[k + "rw3"], E, 2 * D, L.MODE_F32)
+            keep[k + "wqkvT"] = torch.empty(D, 3 * D, dtype=tdt, device=dev)
+            keep[k + "woT"] = torch.empty(D, D, dtype=tdt, device=dev)
+            keep[k + "w1T"] = torch.empty(E, D, 8 * D, dtype=tdt, device=dev)
+            keep[k + "w2T"] = torch.empty(E, 4 * D, D, dtype=tdt, device=dev)
             lt = layers[i]
             lt.wqkvT, lt.woT, lt.w1T, lt.w2T = (_ptr(keep[k + n]) for n in ("wqkvT", "woT", "w1T", "w2T"))
-            lt.r_w0T, lt.r_w3T = _ptr(keep[k + "rw0T"]), _ptr(keep[k + "rw3T"])
-        keep["w_slT"] = tr(eng._keep["w_sl"], D, D, L.MODE_F32)
-        keep["w_outT"] = tr(eng._keep["w_out"], m.action_dim, D, L.MODE_F32)
+            lt.r_w0T, lt.r_w3T = _ptr(keep["r_w0T"][i]), _ptr(keep["r_w3T"][i])
+        keep["w_slT"] = torch.empty(D, D, device=dev)
+        keep["w_outT"] = torch.empty(D, A, device=dev)
         wt = L.ModeModelWeightsT()
         wt.w_slT, wt.w_outT = _ptr(keep["w_slT"]), _ptr(keep["w_outT"])
         wt.layers = C.cast(layers, C.POINTER(L.ModeLayerWeightsT))
-        self.keep, self.layersT, self.wt, self.key = keep, layers, wt, eng._wkey
+        self.keep, self.layersT, self.wt = keep, layers, wt
+        self.built_for = eng._structs_for
 
+    def ensure(self) -> None:
+        eng = self.eng
+        if self.built_for != eng._structs_for:
+            self._build()
+            self.key = None
+        if self.key == eng._wkey:
+            return
+        m, lib, dt = eng.model, eng.lib, eng.dt
+        ar = eng.arena
+        mat = ar.wl if eng.compute_dtype == "bf16" else ar.w
+        D, E, A = m.embed_dim, m.num_experts, m.action_dim
+        keep = self.keep
 
-def _grad_layout(m) -> List[tuple]:
-    """(key, shape) of the packed fp32 gradient buffers the backward chain writes, in backward-friendly order."""
-    D, E, A = m.embed_dim, m.num_experts, m.action_dim
-    hd = D // m.n_heads
-    out = [("pos", (m.pos_emb.shape[1], D)), ("w_se", (D,)), ("b_se", (D,)), ("w_sl", (D, D)), ("w_tok", (D, m.obs_dim)),
-           ("w_goal", (D, m.goal_dim)), ("w_act", (D, A)), ("ln_g", (D,)), ("w_out", (A, D)), ("b_out", (A,))]
-    for i in range(m.num_layers):
-        k = f"l{i}."
-        out += [(k + "ln1_g", (D,)), (k + "ln2_g", (D,)), (k + "qn_g", (hd,)), (k + "kn_g", (hd,)), (k + "wqkv", (3 * D, D)), (k + "bqkv", (3 * D,)),
-                (k + "wo", (D, D)), (k + "r_w0", (2 * D, D)), (k + "r_b0", (2 * D,)), (k + "r_w3", (E, 2 * D)), (k + "r_b3", (E,)),
-                (k + "w1", (E, 8 * D, D)), (k + "b1", (E, 8 * D)), (k + "w2", (E, D, 4 * D))]
-    return out
+        def tr(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, dtype_code: int) -> None:
+            L.check(lib.mode_transpose(src.data_ptr(), cols, rows, cols, dst.data_ptr(), rows, None, None, dtype_code, _stream()), "transpose")
+        for i in range(m.num_layers):
+            k = f"l{i}."
+            tr(mat[k + "wqkv"], keep[k + "wqkvT"], 3 * D, D, dt)
+            tr(mat[k + "wo"], keep[k + "woT"], D, D, dt)
+            for e in range(E):
+                tr(mat[k + "w1"][e], keep[k + "w1T"][e], 8 * D, D, dt)
+                tr(mat[k + "w2"][e], keep[k + "w2T"][e], D, 4 * D, dt)
+            tr(ar.w["r_w0"][i], keep["r_w0T"][i], 2 * D, D, L.MODE_F32)
+            tr(ar.w["r_w3"][i], keep["r_w3T"][i], E, 2 * D, L.MODE_F32)
+        tr(ar.w["w_sl"], keep["w_slT"], D, D, L.MODE_F32)
+        tr(ar.w["w_out"], keep["w_outT"], A, D, L.MODE_F32)
+        self.key = eng._wkey
 
-
-def _param_grad_views(m, g: Dict[str, torch.Tensor]) -> Dict[str, Optional[torch.Tensor]]:
-    """Map the packed gradient buffers back onto the reference's parameter names (state_dict layout)."""
-    D = m.embed_dim
-    v: Dict[str, Optional[torch.Tensor]] = {
-        "pos_emb": g["pos"].unsqueeze(0), "sigma_emb.weight": g["w_se"].unsqueeze(1), "sigma_emb.bias": g["b_se"],
-        "sigma_linear.weight": g["w_sl"], "tok_emb.weight": g["w_tok"], "gripper_embed.weight": None, "goal_emb.weight": g["w_goal"],
-        "action_emb.weight": g["w_act"], "ln.g": g["ln_g"], "out.weight": g["w_out"], "out.bias": g["b_out"]}
-    for i in range(m.num_layers):
-        k, p = f"l{i}.", f"blocks.{i}."
-        v[p + "ln_1.g"], v[p + "ln_2.g"] = g[k + "ln1_g"], g[k + "ln2_g"]
-        v[p + "attn.q_norm.g"], v[p + "attn.k_norm.g"] = g[k + "qn_g"], g[k + "kn_g"]
-        for j, nm in enumerate(("query", "key", "value")):                       # packed rows = [query; key; value]
-            v[p + f"attn.{nm}.weight"] = g[k + "wqkv"][j * D:(j + 1) * D]
-            v[p + f"attn.{nm}.bias"] = g[k + "bqkv"][j * D:(j + 1) * D]
-        v[p + "attn.c_proj.weight"] = g[k + "wo"]
-        v[p + "router.router.mlp.0.weight"], v[p + "router.router.mlp.0.bias"] = g[k + "r_w0"], g[k + "r_b0"]
-        v[p + "router.router.mlp.3.weight"], v[p + "router.router.mlp.3.bias"] = g[k + "r_w3"], g[k + "r_b3"]
-        for e in range(m.num_experts):
-            q = p + f"experts.expert_{e}.mlp."
-            v[q + "0.project.weight"], v[q + "0.project.bias"], v[q + "2.weight"] = g[k + "w1"][e], g[k + "b1"][e], g[k + "w2"][e]
-    return v
+    def grad_tables(self):
+        """ctypes tables pointing the backward chain at the gradient arena (built once per arena)."""
+        eng = self.eng
+        ar = eng.arena
+        m = eng.model
+        ar.ensure_grad(m)
+        if self.grads_for != id(ar.grad):
+            g = ar.g
+            lgr = (L.ModeLayerGrads * m.num_layers)()
+            for i in range(m.num_layers):
+                for fld, _ in L.ModeLayerGrads._fields_:
+                    t = g[fld][i] if fld.startswith("r_") else g[f"l{i}.{fld}"]
+                    setattr(lgr[i], fld, t.data_ptr())
+            mg = L.ModeModelGrads()
+            for fld in ("pos", "w_se", "b_se", "w_sl", "w_tok", "w_goal", "w_act", "ln_g", "w_out", "b_out"):
+                setattr(mg, fld, g[fld].data_ptr())
+            mg.layers = C.cast(lgr, C.POINTER(L.ModeLayerGrads))
+            self._lgr, self._mg = lgr, mg
+            self.grads_for = id(ar.grad)
+        return self._mg
 
 
 class _Run:
@@ -141,10 +150,10 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     run = _Run()
     # sigma embedding in two visible steps (e1 is needed by the backward)
     e1 = torch.empty(B, D, device=dev)
-    L.check(lib.mode_sigma_embed(sig.data_ptr(), eng._keep["w_se"].data_ptr(), eng._keep["b_se"].data_ptr(), e1.data_ptr(), B, D, _stream()), "sigma_embed")
+    L.check(lib.mode_sigma_embed(sig.data_ptr(), eng.arena.w["w_se"].data_ptr(), eng.arena.w["b_se"].data_ptr(), e1.data_ptr(), B, D, _stream()), "sigma_embed")
     emb_t = torch.empty(B, D, device=dev)
     g = L.ModeGemmDesc(dtype=L.MODE_F32, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=B, N=D, K=D, A=e1.data_ptr(), lda=D,
-                       W=eng._keep["w_sl"].data_ptr(), ldw=D, C=emb_t.data_ptr(), ldc=D)
+                       W=eng.arena.w["w_sl"].data_ptr(), ldw=D, C=emb_t.data_ptr(), ldc=D)
     L.check(lib.mode_gemm(C.byref(g), _stream()), "sigma_linear")
     img_e, goal_e = eng.embed_obs(img, gl)
     cond = (emb_t + goal_e).contiguous() if model.use_goal_in_routing else emb_t
@@ -201,31 +210,22 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     names = [n for n, _ in model.named_parameters()]
 
     def backward(dF: torch.Tensor):
+        """Writes every parameter gradient straight into the gradient arena and points ``p.grad`` at its slice (gradients are
+        OVERWRITTEN, not accumulated: one backward per optimizer step, as in the reference's training loop)."""
         ts.ensure()
-        layout = _grad_layout(model)
-        total = sum(int(torch.Size(s).numel()) for _, s in layout)
-        flat = torch.empty(total, device=dev)
-        gb: Dict[str, torch.Tensor] = {}
-        o = 0
-        for key, shp in layout:
-            n = int(torch.Size(shp).numel())
-            gb[key] = flat[o:o + n].view(shp)
-            o += n
-        lgr = (L.ModeLayerGrads * Ly)()
-        for i in range(Ly):
-            for fld, _ in L.ModeLayerGrads._fields_:
-                setattr(lgr[i], fld, gb[f"l{i}.{fld}"].data_ptr())
-        mg = L.ModeModelGrads()
-        for fld in ("pos", "w_se", "b_se", "w_sl", "w_tok", "w_goal", "w_act", "ln_g", "w_out", "b_out"):
-            setattr(mg, fld, gb[fld].data_ptr())
-        mg.layers = C.cast(lgr, C.POINTER(L.ModeLayerGrads))
+        mg = ts.grad_tables()
+        ar = eng.arena
         wsb = lib.mode_dit_train_workspace_bytes(C.byref(d), B, eng.dt)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        if ts._ws is None or ts._ws.numel() < wsb:
+            ts._ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         L.check(lib.mode_dit_backward(C.byref(d), C.byref(eng._mw), C.byref(ts.wt), C.byref(args), stash.data_ptr(), dF.data_ptr(), C.byref(mg),
-                                      ws.data_ptr(), wsb, _stream()), "backward")
-        views = _param_grad_views(model, gb)
-        run.flat_grad = flat
-        return [views[n].reshape(p.shape) if (p.requires_grad and views[n] is not None) else None for n, p in zip(names, params)]
+                                      ts._ws.data_ptr(), ts._ws.numel(), _stream()), "backward")
+        gv = ar.g_by_name
+        for n, p in zip(names, params):
+            if p.requires_grad and n != "gripper_embed.weight":               # dead in the reference too (modedit.py:684): grad stays None
+                if p.grad is None or p.grad.data_ptr() != gv[n].data_ptr():
+                    p.grad = gv[n].view(p.shape)
+        return [None] * len(params)
 
     run.F, run.backward, run.keep = F, backward, keep_alive
     return _DitTrainFn.apply(run, *params)

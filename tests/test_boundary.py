@@ -172,3 +172,39 @@ def test_forward_has_no_cpu_fallback():
     src = "".join(open(os.path.join(ROOT, "mode_diffusion_policy_amd", f)).read()
                   for f in os.listdir(os.path.join(ROOT, "mode_diffusion_policy_amd")) if f.endswith(".py"))
     assert "oracle" not in src.replace("oracle/", "")                               # product never imports the oracle
+
+
+def test_arena_layout_regions_and_names():
+    """Flat parameter arena: every reference parameter has a slot, slots are 256-byte aligned, the decay / no-decay split is
+    MoDEAgent.get_optim_groups' name rule (mode_agent.py:365-384) and adoption keeps values + state_dict order (CPU tensors suffice)."""
+    from mode_diffusion_policy_amd.arena import ParamArena, arena_layout
+    from mode_diffusion_policy_amd.ddp import optimizer_param_groups
+    cfg = get_config("tiny")
+    m = M.MoDeDiT(obs_dim=cfg.obs_dim, goal_dim=cfg.goal_dim, device="cpu", goal_conditioned=True, action_dim=7, embed_dim=cfg.embed_dim,
+                  embed_pdrob=0, attn_pdrop=0.0, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=1, obs_seq_len=1, action_seq_len=10,
+                  mlp_pdrop=0.0, goal_drop=0.0, num_experts=cfg.num_experts, top_k=cfg.top_k)
+    sd = make_state_dict(cfg, 3)
+    m.load_state_dict(sd)
+    layout, bounds = arena_layout(m)
+    assert all(off % 64 == 0 for _, _, off in layout) and bounds["decay"] < bounds["no_decay"] < bounds["total"]
+    ar = ParamArena(m, torch.device("cpu"))
+    assert ar.owns(m) and list(m.state_dict().keys()) == list(sd.keys())
+    base = ar.flat.data_ptr()
+    groups = optimizer_param_groups(m, 0.05)
+    decay_ids = {id(p) for p in groups[0]["params"]}
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), sd[n]), n
+        off = (p.data_ptr() - base) // 4
+        if n == "gripper_embed.weight":
+            assert off >= bounds["no_decay"]
+        elif id(p) in decay_ids:
+            assert off < bounds["decay"], n
+        else:
+            assert bounds["decay"] <= off < bounds["no_decay"], n
+    total = sum(p.numel() for p in m.parameters())
+    assert total <= bounds["total"] < total + 64 * len(layout)
+    with torch.no_grad():
+        m.out.bias.add_(1.0)
+    assert abs(float(ar.w["b_out"][0]) - (float(sd["out.bias"][0]) + 1.0)) < 1e-6            # Parameters ARE arena views
+    m.double()
+    assert not ar.owns(m)

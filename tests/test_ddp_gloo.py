@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from mode_diffusion_policy_amd.ddp import BucketedGradReducer, optimizer_param_groups
+from mode_diffusion_policy_amd.ddp import ArenaGradReducer, BucketedGradReducer, optimizer_param_groups
 from oracle import mode_oracle as O
 
 
@@ -105,3 +105,36 @@ def test_single_process_passthrough_and_param_groups():
     for n, p in model.named_parameters():
         assert (id(p) in decayed) == O.uses_weight_decay(n)
     assert groups[0]["weight_decay"] == 0.05 and groups[1]["weight_decay"] == 0.0
+
+
+def _arena_worker(rank, world, port, mode, average, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, n_reduce = 1000, 896                                   # tail = the arena's dead region: must not be exchanged
+        base = torch.arange(n, dtype=torch.float32)
+        flat = base * (rank + 1)
+        red = ArenaGradReducer(flat, n_reduce, slice_mb=0.001, mode=mode, average=average)   # 262 elements per slice -> 4 slices, ragged tail
+        scale = red.reduce()
+        want = base * 3.0 * (0.5 if average else 1.0)
+        ok = torch.allclose(flat[:n_reduce], want[:n_reduce]) and torch.equal(flat[n_reduce:], base[n_reduce:] * (rank + 1))
+        q.put((rank, bool(ok), scale, len(red.slices)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,average", [("allreduce", False), ("allreduce", True), ("rs_ag", False)])
+def test_arena_reducer_world2(mode, average):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_arena_worker, args=(r, 2, port, mode, average, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, scale, nsl in res:
+        assert ok, f"rank {rank}: arena slices not summed correctly"
+        assert scale == (1.0 if average else 0.5)
+        assert nsl == 4

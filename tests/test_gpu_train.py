@@ -89,3 +89,70 @@ def test_training_step_decreases_loss_and_refreshes_shadows():
         losses.append(float(loss))
     assert all(np.isfinite(losses)) and np.mean(losses[-3:]) < 0.8 * np.mean(losses[:3]), losses
     assert m.blocks[0].probs["top_k_hot"].shape == (16, cfg.seq_len, cfg.num_experts)
+
+
+def test_parameters_live_in_one_arena_and_state_dict_is_untouched():
+    cfg, sd, m = build_train("c1e4", 7, "bf16")
+    eng = m.engine
+    ar = eng.arena
+    lo, hi = ar.flat.data_ptr(), ar.flat.data_ptr() + ar.flat.numel() * 4
+    for n, p in m.named_parameters():
+        assert lo <= p.data_ptr() < hi and p.data_ptr() % 16 == 0, n
+        assert torch.equal(p.detach().cpu(), sd[n]), n                           # adoption does not change a single value
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    # q/k/v of a block are adjacent rows of one packed operand; experts are stacked; routers of all layers are adjacent
+    a = m.blocks[1].attn
+    assert a.key.weight.data_ptr() == a.query.weight.data_ptr() + a.query.weight.numel() * 4
+    assert m.blocks[1].router.router.mlp[0].weight.data_ptr() == m.blocks[0].router.router.mlp[0].weight.data_ptr() + 2 * cfg.embed_dim * cfg.embed_dim * 4
+    # staleness: an in-place update through a Parameter view must reach the bf16 compute shadow
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, 4, 1).items()}
+    m.eval()
+    s = torch.full((4,), 0.7, device="cuda")
+    F0 = m({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], s).clone()
+    with torch.no_grad():
+        m.out.weight.mul_(2.0); m.out.bias.mul_(2.0)
+    F1 = m({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], s)
+    assert rel(F1, 2.0 * F0) < 1e-6
+    with torch.no_grad():
+        m.blocks[0].attn.c_proj.weight.zero_()                                    # a bf16-shadowed GEMM operand
+    F2 = m({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], s)
+    assert rel(F2, F1) > 1e-4
+    # re-allocation (module.to(dtype) and back) breaks aliasing -> the arena is rebuilt transparently
+    m.double().float()
+    F3 = m({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], s)
+    assert m.engine.arena is not ar and rel(F3, F2) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fused_adamw_matches_torch_adamw(dtype):
+    """FusedAdamW over the arena == torch.optim.AdamW with MoDEAgent.get_optim_groups' two groups (mode_agent.py:365-392)."""
+    from mode_diffusion_policy_amd.ddp import optimizer_param_groups
+    from mode_diffusion_policy_amd.optim import FusedAdamW
+    cfg, sd, m = build_train("c1e4", 11, dtype)
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, 8, 3).items()}
+    den = M.GCDenoiser(m, 0.5).train()
+    sig = torch.full((8,), 0.9, device="cuda")
+    opt = FusedAdamW(m, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    # shadow copy driven by torch's optimizer with the SAME gradients
+    ref = {n: p.detach().clone().requires_grad_(True) for n, p in m.named_parameters()}
+
+    class _Holder(torch.nn.Module):
+        def named_parameters(self_inner, *a, **k):
+            return iter(ref.items())
+    topt = torch.optim.AdamW(optimizer_param_groups(_Holder(), 0.05), lr=1e-3, betas=(0.9, 0.95))
+    for step in range(3):
+        loss, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
+        loss.backward()
+        for n, p in m.named_parameters():
+            ref[n].grad = None if p.grad is None else p.grad.detach().clone()
+        opt.step()
+        topt.step()
+        for n, p in m.named_parameters():
+            assert rel(p.detach(), ref[n].detach()) < 2e-6, (step, n)
+    assert torch.equal(m.gripper_embed.weight.detach().cpu(), sd["gripper_embed.weight"])          # dead parameter: never updated
+    if dtype == "bf16":                                                                              # shadow written by the optimizer itself
+        ar = m.engine.arena
+        assert ar.lp_synced and torch.equal(ar.lp[: ar.bounds["no_decay"]], ar.flat[: ar.bounds["no_decay"]].to(torch.bfloat16))
+    # the loss keeps moving: the next forward reads the updated weights (transposed shadows refreshed as well)
+    l2, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
+    assert float(l2) != float(loss)
