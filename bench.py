@@ -100,7 +100,10 @@ def dominant_kernel_roofline(den, device, reps=60):
     ach = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "kernel": "gemm_bf16_kernel<SWIGLU> (grouped expert up-projection, M=3584 K=1024 N=2x4096)",
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            "traffic": None, "avg_launch_us": round(us, 2), "flops_per_launch": flops}
+            # HBM bytes per launch from the committed PMC passes (profiles/r01_gemm_pmc.md): FETCH_SIZE 61 350 KB x2 (gfx950 correction,
+            # MI355X_MICROARCH.md "HBM") + WRITE_SIZE 28 672 KB; algorithmic bytes per launch are 100.2 MB
+            "traffic": 155.0e6, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_gemm_pmc.md)",
+            "algorithmic_bytes": 100.2e6, "avg_launch_us": round(us, 2), "flops_per_launch": flops}
 
 
 def cpu_baseline():
