@@ -83,8 +83,19 @@ typedef struct ModeGemmDesc {
   int64_t c_group_stride;         /* C + z*c_group_stride (elements); an empty range yields an all-zero C_z                                */
   int32_t flags;                  /* MODE_GEMM_SKINNY_OK: fp32, M <= 16 may use the weight-streaming GEMV kernel (wave-tree reduction
                                      instead of the MFMA k-ordered chain: same fp32 accuracy, different rounding)                   */
+  const int32_t* w_rows;          /* MODE_GEMM_A_KM only: optional gather of W's K rows (row r of the reduction reads W[w_rows[r]])  */
 } ModeGemmDesc;
 #define MODE_GEMM_SKINNY_OK 1
+/* Backward-pass operand layouts (bf16, epilogue NONE; replace autograd's mm_backward for nn.Linear, i.e. the `grad @ W` and
+ * `grad.T @ x` GEMMs PyTorch launches for every Linear of modedit.py in loss.backward()).  No transposed copies are made: the row-major
+ * tiles are gathered into MFMA fragments by the LDS transpose read ds_read_b64_tr_b16.
+ *   MODE_GEMM_W_KN            W is [K, N] row-major (ldw = row stride): C[M,N] = A[M,K] @ W   — data gradient dX = dY @ W_linear.
+ *                             K % 64 == 0; expert_offsets / w_expert_stride group the rows as in the forward.
+ *   MODE_GEMM_W_KN | A_KM     A is [K, M] row-major too: C[M,N] = A^T @ W — weight gradient dW = dY^T @ X from row-major activations.
+ *                             k_group_offsets are then ARBITRARY row ranges [off[z], off[z+1]) (per-expert segments, no padding), K is
+ *                             the row count when no groups are given; M % 8 == 0. */
+#define MODE_GEMM_W_KN 2
+#define MODE_GEMM_A_KM 4
 int mode_gemm(const ModeGemmDesc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -373,7 +384,8 @@ typedef struct ModeModelGrads {
   float* pos; float* w_se; float* b_se; float* w_sl; float* w_tok; float* w_goal; float* w_act; float* ln_g; float* w_out; float* b_out;
   const ModeLayerGrads* layers;
 } ModeModelGrads;
-typedef struct ModeLayerWeightsT {        /* transposed shadows for the data-gradient GEMMs (compute dtype / fp32 for the router) */
+typedef struct ModeLayerWeightsT {        /* transposed shadows for the data-gradient GEMMs: fp32 router always; wqkvT/woT/w1T/w2T only in
+                                             fp32 compute mode (bf16 reads the [out,in] weights directly, MODE_GEMM_W_KN) — may be NULL there */
   const void* wqkvT;  /* [D, 3D] */  const void* woT;   /* [D, D] */
   const void* w1T;    /* [E][D, 8D] */ const void* w2T;  /* [E][4D, D] */
   const float* r_w0T; /* [D, 2D] */  const float* r_w3T; /* [2D, E] */

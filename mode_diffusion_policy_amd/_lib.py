@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MODE_HIP_LIB", os.path.join(_HERE, "libmode_hip.so"))
 MODE_BF16, MODE_F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3, 4
 ABI_VERSION = 1
-GEMM_SKINNY_OK = 1
+GEMM_SKINNY_OK, GEMM_W_KN, GEMM_A_KM = 1, 2, 4
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -29,7 +29,7 @@ class ModeGemmDesc(C.Structure):
                 ("A", c_vp), ("lda", c_i64), ("W", c_vp), ("ldw", c_i64), ("w_expert_stride", c_i64),
                 ("bias", c_vp), ("bias_expert_stride", c_i64), ("resid", c_vp), ("ldr", c_i64), ("C", c_vp), ("ldc", c_i64),
                 ("a_rows", c_vp), ("expert_offsets", c_vp), ("num_experts", c_i32), ("split_k", c_i32), ("split_stride", c_i64), ("k_group_offsets", c_vp), ("num_k_groups", c_i32),
-                ("c_group_stride", c_i64), ("flags", c_i32)]
+                ("c_group_stride", c_i64), ("flags", c_i32), ("w_rows", c_vp)]
 
 
 class ModeEmbedDesc(C.Structure):

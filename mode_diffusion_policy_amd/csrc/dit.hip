@@ -8,6 +8,7 @@
 namespace mode {
 int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s);
 int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s);
+int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s);
 struct MetaBatch {
   const int* idx; const float* w; long idx_bstride;
   int* counts; int* offsets; int* perm; int* pos; float* posw; int* poffsets; int* prow; long out_bstride;
@@ -15,6 +16,7 @@ struct MetaBatch {
 int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N, int E, int k, hipStream_t s);
 
 extern int g_gemm_cfg;
+extern int g_tr_cfg;
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
@@ -71,12 +73,14 @@ extern "C" const char* mode_hip_status_string(int status) {
 extern "C" int mode_set_option(const char* key, int value) {
   if (!key) return MODE_ERR_BAD_ARG;
   if (!strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return MODE_OK; }
+  if (!strcmp(key, "gemm_tr_cfg")) { g_tr_cfg = value; return MODE_OK; }
   return MODE_ERR_UNSUPPORTED;
 }
 
 extern "C" int mode_gemm(const ModeGemmDesc* d, void* stream) {
   if (!d || !d->A || !d->W || !d->C || d->M < 0 || d->N <= 0) return MODE_ERR_BAD_ARG;
   if (d->expert_offsets && d->num_experts <= 0) return MODE_ERR_BAD_ARG;
+  if (d->flags & (MODE_GEMM_W_KN | MODE_GEMM_A_KM)) return gemm_bf16_tr_launch(d, (hipStream_t)stream);
   if (d->dtype == MODE_BF16) return gemm_bf16_launch(d, (hipStream_t)stream);
   if (d->dtype == MODE_F32) return gemm_f32_launch(d, (hipStream_t)stream);
   return MODE_ERR_BAD_ARG;

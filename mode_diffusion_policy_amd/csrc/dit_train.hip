@@ -170,6 +170,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
   if (!a->meta || !a->act_rows || !a->probs || !a->r_pre || !a->topk_idx || !a->sigma || !a->state_images || !a->goals || !a->e1) return MODE_ERR_BAD_ARG;
   const ModeDims& d = *dims;
   const int dt = a->dtype, B = a->B, T = d.T, D = d.D, N = B * T, NK = N * d.k, E = d.E, R = B * d.A_len, A = d.A_dim, hd = D / d.H;
+  const bool tr = dt == MODE_BF16 && D % 8 == 0;      // bf16: backward GEMMs read row-major operands directly (gemm_bf16_tr.hip); no transposed copies
   const bool bf = dt == MODE_BF16;
   const long NKp = ((long)NK + 63) / 64 * 64 + 64L * E, Np = ((long)N + 63) / 64 * 64;
   const int Ktok = bf ? (int)Np : N;                       // token-dim contraction length (bf16 kernel needs a multiple of 64: zero padded)
@@ -224,7 +225,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
 
   for (int l = d.L - 1; l >= 0; --l) {
     const ModeLayerWeights& lw = w->layers[l];
-    const ModeLayerWeightsT& lt = wt->layers[l];
+    const ModeLayerWeightsT* lt = &wt->layers[l];
     const ModeLayerGrads& lg = gr->layers[l];
     const char* S = L_(l);
     const int32_t* meta = a->meta + (long)l * a->meta_layer_stride;
@@ -233,53 +234,91 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     // (1) combine backward: dY (sorted rows) and router-weight gradients
     if ((rc = mode_moe_combine_bwd(DXa, S + sl.Y, dt, pos, posw, N, D, d.k, dYs, dwt, stream))) return rc;
     // (2) expert down-projection: dH = dY W2 ; dW2_e = dY_e^T H_e
-    ModeGemmDesc g = gdesc(dt, MODE_EPI_NONE, dt, NK, 4 * D, D, dYs, D, lt.w2T, D, dHd, 4 * D);
-    g.w_expert_stride = 4L * D * D; g.expert_offsets = offsets; g.num_experts = E;
-    if ((rc = mode_gemm(&g, stream))) return rc;
-    ZERO(Td, (size_t)D * NKp * esz); ZERO(Tmid, (size_t)4 * D * NKp * esz);
-    if ((rc = mode_transpose(dYs, D, NK, D, Td, NKp, nullptr, prow, dt, stream))) return rc;
-    if ((rc = mode_transpose(S + sl.Hd, 4 * D, NK, 4 * D, Tmid, NKp, nullptr, prow, dt, stream))) return rc;
-    g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, 4 * D, (int)NKp, Td, NKp, Tmid, NKp, lg.w2, 4 * D);
-    g.k_group_offsets = poff; g.num_k_groups = E; g.c_group_stride = 4L * D * D;
-    if ((rc = mode_gemm(&g, stream))) return rc;
+    ModeGemmDesc g;
+    if (tr) {                                        // bf16: operands as they lie in memory, fragments by LDS transpose reads
+      g = gdesc(dt, MODE_EPI_NONE, dt, NK, 4 * D, D, dYs, D, lw.w2, 4 * D, dHd, 4 * D);
+      g.w_expert_stride = 4L * D * D; g.expert_offsets = offsets; g.num_experts = E; g.flags = MODE_GEMM_W_KN;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, 4 * D, NK, dYs, D, S + sl.Hd, 4 * D, lg.w2, 4 * D);
+      g.k_group_offsets = offsets; g.num_k_groups = E; g.c_group_stride = 4L * D * D; g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    } else {
+      g = gdesc(dt, MODE_EPI_NONE, dt, NK, 4 * D, D, dYs, D, lt->w2T, D, dHd, 4 * D);
+      g.w_expert_stride = 4L * D * D; g.expert_offsets = offsets; g.num_experts = E;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      ZERO(Td, (size_t)D * NKp * esz); ZERO(Tmid, (size_t)4 * D * NKp * esz);
+      if ((rc = mode_transpose(dYs, D, NK, D, Td, NKp, nullptr, prow, dt, stream))) return rc;
+      if ((rc = mode_transpose(S + sl.Hd, 4 * D, NK, 4 * D, Tmid, NKp, nullptr, prow, dt, stream))) return rc;
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, 4 * D, (int)NKp, Td, NKp, Tmid, NKp, lg.w2, 4 * D);
+      g.k_group_offsets = poff; g.num_k_groups = E; g.c_group_stride = 4L * D * D;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    }
     // (3) SwishGLU (+ dropout) backward, bias gradient
     if ((rc = mode_swiglu_bwd(S + sl.P, dHd, dP, NK, 4 * D, dt, a->seed + 2 * l + 1, a->mlp_pdrop, stream))) return rc;
     if ((rc = colsum(dP, 8 * D, NK, 8 * D, dt, offsets, 0, E, lg.b1, 0))) return rc;
     // (4) expert up-projection: dU (sorted rows, fp32) = dP W1 ; dW1_e = dP_e^T U_e
-    g = gdesc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 8 * D, dP, 8 * D, lt.w1T, 8 * D, dUs, D);
-    g.w_expert_stride = 8L * D * D; g.expert_offsets = offsets; g.num_experts = E;
-    if ((rc = mode_gemm(&g, stream))) return rc;
-    ZERO(Tbig, (size_t)8 * D * NKp * esz); ZERO(Td2, (size_t)D * NKp * esz);
-    if ((rc = mode_transpose(dP, 8 * D, NK, 8 * D, Tbig, NKp, nullptr, prow, dt, stream))) return rc;
-    if ((rc = mode_transpose(S + sl.ub, D, NK, D, Td2, NKp, meta + ml.perm, prow, dt, stream))) return rc;     // gathered u rows
-    g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 8 * D, D, (int)NKp, Tbig, NKp, Td2, NKp, lg.w1, D);
-    g.k_group_offsets = poff; g.num_k_groups = E; g.c_group_stride = 8L * D * D;
-    if ((rc = mode_gemm(&g, stream))) return rc;
+    if (tr) {
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 8 * D, dP, 8 * D, lw.w1, D, dUs, D);
+      g.w_expert_stride = 8L * D * D; g.expert_offsets = offsets; g.num_experts = E; g.flags = MODE_GEMM_W_KN;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 8 * D, D, NK, dP, 8 * D, S + sl.ub, D, lg.w1, D);          // u rows gathered through perm
+      g.k_group_offsets = offsets; g.num_k_groups = E; g.c_group_stride = 8L * D * D; g.w_rows = meta + ml.perm;
+      g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    } else {
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 8 * D, dP, 8 * D, lt->w1T, 8 * D, dUs, D);
+      g.w_expert_stride = 8L * D * D; g.expert_offsets = offsets; g.num_experts = E;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      ZERO(Tbig, (size_t)8 * D * NKp * esz); ZERO(Td2, (size_t)D * NKp * esz);
+      if ((rc = mode_transpose(dP, 8 * D, NK, 8 * D, Tbig, NKp, nullptr, prow, dt, stream))) return rc;
+      if ((rc = mode_transpose(S + sl.ub, D, NK, D, Td2, NKp, meta + ml.perm, prow, dt, stream))) return rc;     // gathered u rows
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 8 * D, D, (int)NKp, Tbig, NKp, Td2, NKp, lg.w1, D);
+      g.k_group_offsets = poff; g.num_k_groups = E; g.c_group_stride = 8L * D * D;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    }
     // (5) ln_2 backward: du = dx_out (residual from the normalised stream) + gather-sum of dU ; -> d x1
     if ((rc = mode_rmsnorm_bwd((const float*)(S + sl.x1), lw.ln2_g, DXa, nullptr, dUs, pos, d.k, N, D, d.eps, DXb, 0, dgp, nullptr, dx1lp, dt, stream)))
       return rc;
     if ((rc = colsum(dgp, D, nblk4, D, MODE_F32, nullptr, 0, 1, lg.ln2_g, 0))) return rc;
     // (6) c_proj: d yattn = dx1 Wo ; dWo = dx1^T yattn
-    g = gdesc(dt, MODE_EPI_NONE, dt, N, D, D, dx1lp, D, lt.woT, D, dyattn, D);
-    if ((rc = mode_gemm(&g, stream))) return rc;
-    ZERO(Td, (size_t)D * Np * esz); ZERO(Td2, (size_t)D * Np * esz);
-    if ((rc = mode_transpose(dx1lp, D, N, D, Td, Np, nullptr, nullptr, dt, stream))) return rc;
-    if ((rc = mode_transpose(S + sl.yattn, D, N, D, Td2, Np, nullptr, nullptr, dt, stream))) return rc;
-    g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, D, Ktok, Td, Np, Td2, Np, lg.wo, D);
-    if ((rc = mode_gemm(&g, stream))) return rc;
+    if (tr) {
+      g = gdesc(dt, MODE_EPI_NONE, dt, N, D, D, dx1lp, D, lw.wo, D, dyattn, D);
+      g.flags = MODE_GEMM_W_KN;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, D, N, dx1lp, D, S + sl.yattn, D, lg.wo, D);
+      g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    } else {
+      g = gdesc(dt, MODE_EPI_NONE, dt, N, D, D, dx1lp, D, lt->woT, D, dyattn, D);
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      ZERO(Td, (size_t)D * Np * esz); ZERO(Td2, (size_t)D * Np * esz);
+      if ((rc = mode_transpose(dx1lp, D, N, D, Td, Np, nullptr, nullptr, dt, stream))) return rc;
+      if ((rc = mode_transpose(S + sl.yattn, D, N, D, Td2, Np, nullptr, nullptr, dt, stream))) return rc;
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, D, Ktok, Td, Np, Td2, Np, lg.wo, D);
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    }
     // (7) attention backward
     if ((rc = mode_attn_block_bwd(S + sl.qkv, lw.qn_g, lw.kn_g, dyattn, dqkv, apq, apk, dt, B, T, d.H, hd, d.eps, a->seed + 2 * l, a->attn_pdrop, stream)))
       return rc;
     if ((rc = colsum(apq, hd, B * d.H, hd, MODE_F32, nullptr, 0, 1, lg.qn_g, 0))) return rc;
     if ((rc = colsum(apk, hd, B * d.H, hd, MODE_F32, nullptr, 0, 1, lg.kn_g, 0))) return rc;
     // (8) QKV projection: dh1 = dqkv Wqkv ; dWqkv = dqkv^T h1 ; db = colsum(dqkv)
-    g = gdesc(dt, MODE_EPI_NONE, MODE_F32, N, D, 3 * D, dqkv, 3 * D, lt.wqkvT, 3 * D, dh1, D);
-    if ((rc = mode_gemm(&g, stream))) return rc;
-    ZERO(Tbig, (size_t)3 * D * Np * esz); ZERO(Td, (size_t)D * Np * esz);
-    if ((rc = mode_transpose(dqkv, 3 * D, N, 3 * D, Tbig, Np, nullptr, nullptr, dt, stream))) return rc;
-    if ((rc = mode_transpose(S + sl.h1, D, N, D, Td, Np, nullptr, nullptr, dt, stream))) return rc;
-    g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 3 * D, D, Ktok, Tbig, Np, Td, Np, lg.wqkv, D);
-    if ((rc = mode_gemm(&g, stream))) return rc;
+    if (tr) {
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, N, D, 3 * D, dqkv, 3 * D, lw.wqkv, D, dh1, D);
+      g.flags = MODE_GEMM_W_KN;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 3 * D, D, N, dqkv, 3 * D, S + sl.h1, D, lg.wqkv, D);
+      g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    } else {
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, N, D, 3 * D, dqkv, 3 * D, lt->wqkvT, 3 * D, dh1, D);
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      ZERO(Tbig, (size_t)3 * D * Np * esz); ZERO(Td, (size_t)D * Np * esz);
+      if ((rc = mode_transpose(dqkv, 3 * D, N, 3 * D, Tbig, Np, nullptr, nullptr, dt, stream))) return rc;
+      if ((rc = mode_transpose(S + sl.h1, D, N, D, Td, Np, nullptr, nullptr, dt, stream))) return rc;
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 3 * D, D, Ktok, Tbig, Np, Td, Np, lg.wqkv, D);
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    }
     if ((rc = colsum(dqkv, 3 * D, N, 3 * D, dt, nullptr, 0, 1, lg.bqkv, 0))) return rc;
     // (9) ln_1 (+c) backward: d x0 = d x1 (residual) + RMSNorm'(dh1); dc_b += sum_t dh1[b,t]
     if ((rc = mode_rmsnorm_bwd((const float*)(S + sl.x0), lw.ln1_g, dh1, nullptr, nullptr, nullptr, 0, N, D, d.eps, DXb, 1, dgp, nullptr, nullptr, MODE_F32,
@@ -302,7 +341,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       g.flags = MODE_GEMM_SKINNY_OK;                                                        // M = E rows: stream hid^T once
       if ((rc = mode_gemm(&g, stream))) return rc;
       // dhid = dlog W3 ; dpre = dhid * gelu'(pre)
-      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, B, 2 * D, E, dlog, E, lt.r_w3T, E, dhid, 2 * D);
+      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, B, 2 * D, E, dlog, E, lt->r_w3T, E, dhid, 2 * D);
       if ((rc = mode_gemm(&g, stream))) return rc;
       if ((rc = mode_gelu_bwd(rpre, dhid, dpre, (long)B * 2 * D, stream))) return rc;
       if ((rc = colsum(dpre, 2 * D, B, 2 * D, MODE_F32, nullptr, 0, 1, lg.r_b0, 0))) return rc;
@@ -311,7 +350,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       if ((rc = mode_transpose(a->cond, D, B, D, st2, B, nullptr, nullptr, MODE_F32, stream))) return rc;
       g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, 2 * D, D, B, st1, B, st2, B, lg.r_w0, D);
       if ((rc = mode_gemm(&g, stream))) return rc;
-      g = gdesc(MODE_F32, MODE_EPI_RESIDUAL, MODE_F32, B, D, 2 * D, dpre, 2 * D, lt.r_w0T, 2 * D, dcond, D);
+      g = gdesc(MODE_F32, MODE_EPI_RESIDUAL, MODE_F32, B, D, 2 * D, dpre, 2 * D, lt->r_w0T, 2 * D, dcond, D);
       g.resid = dcond; g.ldr = D;
       if ((rc = mode_gemm(&g, stream))) return rc;
     }

@@ -1,0 +1,363 @@
+// bf16 MFMA GEMMs for the BACKWARD pass on gfx950, fed by the LDS transpose-read `ds_read_b64_tr_b16`:
+//
+//   data gradient    dX[M,N] = dY[M,K] @ W[K,N]          (MODE_GEMM_W_KN)            W = nn.Linear's [out,in] weight as stored
+//   weight gradient  dW[M,N] = dY[K,M]^T @ X[K,N]        (MODE_GEMM_W_KN | A_KM)     both operands row-major activations [rows, features]
+//
+// The forward kernel (gemm_bf16.hip) wants both operands K-contiguous.  In the backward pass the reduction index is the *row* index of
+// at least one row-major operand, i.e. its MFMA fragment (8 consecutive k for one m/n) is strided in memory.  Instead of materialising
+// transposed copies in HBM (2 x 1.4 GB of weight shadows per optimizer step + 8 activation transposes per layer, ~4 ms of a 23 ms
+// training step on MI355X), the row-major tile [64 k][128 n] is DMA'd into LDS as it lies in memory and the fragment is gathered by
+// the CDNA4 transpose read: lane (i = l&15, g = l>>4) supplies the address of 4 contiguous elements of row g*8 + (i>>2) and receives
+// column i of the 4x16 block its 16-lane group addressed (semantics pinned on hardware by scripts/probe/tr_probe.hip).  Two reads
+// (k..k+3, k+4..k+7) make the 8-element operand of v_mfma_f32_16x16x32_bf16.
+//
+// LDS image of a [64 k][128 n] tile: 256-byte rows, 32-byte column groups XOR-swizzled by f(k) = (k & 3) | ((k >> 3) & 1) << 2, so the 32
+// lanes of one LDS cycle (2 groups x 4 rows x 32 B) cover all 64 banks exactly once.  The image is written lane-linearly by
+// `global_load_lds_dwordx4` with the inverse swizzle applied to the per-lane SOURCE address, as in the forward kernel.
+//
+// Weight-gradient K ranges are arbitrary row ranges (per-expert segments of the sorted dispatch order, no padding): rows past the end of
+// a range read a zero row for the A operand and a clamped (finite) row for the W operand, so they contribute exactly 0.
+#include "mode_common.h"
+#include <type_traits>
+
+namespace mode {
+
+__device__ __attribute__((aligned(256))) uint16_t g_zero_row[128];      // 256 B of zeros: DMA source of masked K rows
+
+struct TrParams {
+  const uint16_t* A; long lda;
+  const uint16_t* W; long ldw; long w_estride;
+  void* C; long ldc;
+  const int* offsets; int E;              // data gradient, grouped rows (MoE): expert e owns rows [offsets[e], offsets[e+1])
+  const int* koffs; long c_gstride;       // weight gradient: blockIdx.z = group, K rows [koffs[z], koffs[z+1])
+  const int* w_rows;                      // weight gradient: gather of W's K rows (dispatch permutation)
+  int M, N, K, m_tiles, n_tiles;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// LDS reads the compiler does not track (it would otherwise put `s_waitcnt vmcnt(0)` — i.e. the just-issued LDS-DMA of the NEXT tile —
+// in front of every compiler-visible LDS read): hand-counted lgkmcnt waits + sched_barriers, as in the forward kernel.
+template <int OFF>
+__device__ __forceinline__ void lds_tr64(s16x4& dst, uint32_t addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_b128(bf16x8& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int N>
+__device__ __forceinline__ void tr_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// f(k): 32-byte column-group swizzle of a [64 k][COLS] tile (COLS = 128: 8 groups per 256-B row; COLS = 64: 4 groups per 128-B row, odd
+// rows already sit on the other half of the banks)
+template <int COLS>
+__device__ __forceinline__ int kn_swz(int row) {
+  if constexpr (COLS == 128) return (row & 3) | (((row >> 3) & 1) << 2);
+  else return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+}
+
+// BN = 128 | 64 output columns per workgroup (64: twice the workgroups for problems that would not fill 256 CUs); NS = LDS ring depth
+// (2: vmcnt(0) per K-step, 2 workgroups/CU hide each other's fill latency; 3: two tiles in flight under counted waits, for long-K
+// problems with <= 1 workgroup per CU).  The gathered-W weight gradient (w_rows) needs NS == 2.
+template <bool A_KM, bool OUT_BF16, int BN, int NS>
+__global__ __launch_bounds__(256, 2) void gemm_tr_kernel(const TrParams p) {
+  constexpr int BM = 128, BKT = 64, TM = 64, TN = BN / 2, FM = 4, FN = TN / 16;
+  constexpr int W_ROW = BN * 2, W_BYTES = BKT * W_ROW;                 // bytes per k-row / per tile of the [k][n] operand
+  constexpr int RPP = 1024 / W_ROW, NPW = (BKT / RPP) / 4, CHW = BN / 8; // rows per 1-KiB DMA piece, pieces per wave, 16-B chunks per row
+  constexpr int A_BYTES = BM * BKT * 2, STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int LOADS = 4 + NPW;
+  constexpr int GROUP_M = 8;
+  constexpr int ESZ = OUT_BF16 ? 2 : 4;
+  constexpr int CROW = BN * ESZ, CPR = CROW / 16, CSWZ = (CPR < 16 ? CPR : 16) - 1;
+  static_assert(BM * CROW <= NS * STAGE_BYTES, "output tile must fit the operand ring");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nblk = p.m_tiles * p.n_tiles;
+  const int sb = xcd_remap(blockIdx.x, nblk);
+  const int per_group = GROUP_M * p.n_tiles;
+  const int grp = sb / per_group, first_m = grp * GROUP_M;
+  const int gsz = min(p.m_tiles - first_m, GROUP_M);
+  const int rem = sb - grp * per_group;
+  const int mt = first_m + rem % gsz, nt = rem / gsz;
+
+  int row0 = 0, row_end = 0, expert = 0;
+  if (!A_KM && p.offsets) {
+    int t = mt;
+    bool found = false;
+    for (int e = 0; e < p.E && !found; ++e) {
+      const int o0 = p.offsets[e], o1 = p.offsets[e + 1];
+      const int nt_e = (o1 - o0 + BM - 1) / BM;
+      if (t < nt_e) { row0 = o0 + t * BM; row_end = min(o1, row0 + BM); expert = e; found = true; }
+      else t -= nt_e;
+    }
+    if (!found) return;
+  } else {
+    row0 = mt * BM; row_end = min(p.M, row0 + BM);
+  }
+  const int n0 = nt * BN;
+  int kb = 0, ke = p.K;
+  if (A_KM && p.koffs) { kb = p.koffs[blockIdx.z]; ke = p.koffs[blockIdx.z + 1]; }
+  const int nk = (ke - kb + BKT - 1) / BKT;
+  const uint16_t* W = p.W + (long)expert * p.w_estride;
+
+  // ---- DMA sources.  [k][cols] tiles: piece P covers RPP tile rows; lane l -> row P*RPP + l / chunks_per_row, physical chunk l % chunks_per_row
+  const int kra = lane >> 4, pca = lane & 15;          // [k][128] A tile (weight gradient)
+  const int krw = lane / CHW, pcw = lane % CHW;        // [k][BN] W tile
+  int kn_col_a[4], kn_col_w[NPW];                      // logical column (elements) of this lane's 16-B chunk, per piece
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = pca ^ (kn_swz<128>((wave * 4 + q) * 4 + kra) << 1);
+    kn_col_a[q] = min(row0 + c * 8, p.M - 8);          // (A_KM only) clamped: columns past M are never stored
+  }
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) {
+    const int c = pcw ^ (kn_swz<BN>((wave * NPW + q) * RPP + krw) << 1);
+    kn_col_w[q] = min(n0 + c * 8, p.N - 8);
+  }
+  // [rows][64 k] A tile of the data gradient (same image as the forward kernel): 8-row pieces, chunk ^ (row & 7)
+  const uint16_t* a_src[4];
+  if constexpr (!A_KM) {
+    const int r8 = lane >> 3, lchunk = (lane & 7) ^ r8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int tr = (wave * 4 + q) * 8 + r8;
+      const int s = min(row0 + tr, row_end - 1);
+      a_src[q] = p.A + (long)s * p.lda + lchunk * 8;
+    }
+  }
+
+  int widx[NPW];                                       // gathered W rows of the NEXT tile to stage (weight gradient with w_rows, NS == 2)
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) widx[q] = 0;
+  auto load_widx = [&](int kt) {
+    if (A_KM && NS == 2 && p.w_rows) {
+#pragma unroll
+      for (int q = 0; q < NPW; ++q) {
+        const int r = kb + kt * BKT + (wave * NPW + q) * RPP + krw;
+        widx[q] = p.w_rows[min(r, ke - 1)];
+      }
+    }
+  };
+  auto stage = [&](int slot, int kt) {
+    char* base = smem + slot * STAGE_BYTES;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int P = wave * 4 + q;
+      const uint16_t* src;
+      if constexpr (A_KM) {
+        const int r = kb + kt * BKT + P * 4 + kra;
+        src = r < ke ? p.A + (long)r * p.lda + kn_col_a[q] : g_zero_row;
+      } else {
+        src = a_src[q] + kt * BKT;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + P * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) {
+      const int P = wave * NPW + q;
+      long r = kb + kt * BKT + P * RPP + krw;
+      if constexpr (A_KM) {
+        r = min(r, (long)ke - 1);
+        if (NS == 2 && p.w_rows) r = widx[q];
+      }
+      const uint16_t* src = W + r * p.ldw + kn_col_w[q];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + P * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment addressing
+  const int fr = lane & 15, fq = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  // transpose-read base addresses of this lane, one per 16-column tile of the wave: row fq*8 + (fr>>2), cols T*16 + (fr&3)*4
+  const int fsw_a = (fr >> 2) | ((fq & 1) << 2);
+  const int fsw_w = BN == 128 ? fsw_a : (((fr >> 3) & 1) | ((fq & 1) << 1));
+  uint32_t tr_a[FM], tr_w[FN];
+#pragma unroll
+  for (int t = 0; t < FM; ++t)
+    tr_a[t] = lds0 + (fq * 8 + (fr >> 2)) * 256 + (fr & 1) * 8 + ((((((wm * 4 + t) ^ fsw_a) << 1) | ((fr >> 1) & 1))) << 4);
+#pragma unroll
+  for (int t = 0; t < FN; ++t)
+    tr_w[t] = lds0 + A_BYTES + (fq * 8 + (fr >> 2)) * W_ROW + (fr & 1) * 8 + ((((((wn * FN + t) ^ fsw_w) << 1) | ((fr >> 1) & 1))) << 4);
+  // K-contiguous A tile (data gradient): lane -> row fr of fragment i, 16-B chunk (fq [+4]) ^ (fr & 7)
+  const int sw = fr & 7;
+  const uint32_t a_off = (wm * TM + fr) * 128;
+
+  constexpr int PRE = NS - 1;
+  if (nk > 0) load_widx(0);
+#pragma unroll
+  for (int s = 0; s < PRE; ++s)
+    if (s < nk) { stage(s, s); load_widx(s + 1); }
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt landed for this wave's pieces; (NS == 3) one younger tile stays in flight across the barrier
+    if (NS >= 3 && kt + 1 < nk) tr_wait_vmcnt<LOADS>();
+    else tr_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NS - 1 < nk) {
+      stage((slot + NS - 1) % NS, kt + NS - 1);
+      load_widx(kt + NS);
+    }
+    const uint32_t so = slot * STAGE_BYTES;
+    s16x4 alo[2][FM], ahi[2][FM], wlo[2][FN], whi[2][FN];
+    bf16x8 fa[2][FM];
+    auto read_half = [&](auto KH) {
+      constexpr int kh = decltype(KH)::value;
+      if constexpr (A_KM) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          lds_tr64<kh * 8192>(alo[kh][i], tr_a[i] + so);
+          lds_tr64<kh * 8192 + 1024>(ahi[kh][i], tr_a[i] + so);
+        }
+      } else {
+        const uint32_t ab = lds0 + a_off + so + (((fq + kh * 4) ^ sw) * 16);
+        lds_b128<0>(fa[kh][0], ab); lds_b128<2048>(fa[kh][1], ab); lds_b128<4096>(fa[kh][2], ab); lds_b128<6144>(fa[kh][3], ab);
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        lds_tr64<kh * 32 * W_ROW>(wlo[kh][j], tr_w[j] + so);
+        lds_tr64<kh * 32 * W_ROW + 4 * W_ROW>(whi[kh][j], tr_w[j] + so);
+      }
+    };
+    auto mma_half = [&](auto KH) {
+      constexpr int kh = decltype(KH)::value;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        bf16x8 a;
+        if constexpr (A_KM) a = join8(alo[kh][i], ahi[kh][i]);
+        else a = fa[kh][i];
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join8(wlo[kh][j], whi[kh][j]), a, acc[i][j], 0, 0, 0);   // swapped: D[n][m]
+      }
+    };
+    read_half(std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    read_half(std::integral_constant<int, 1>{});                   // second half's LDS round trip runs under the first half's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    slot = (slot + 1 == NS) ? 0 : slot + 1;
+  }
+
+  // ---- epilogue: accumulators -> swizzled LDS tile -> coalesced 16-byte stores
+  char* Cout = reinterpret_cast<char*>(p.C) + (long)blockIdx.z * p.c_gstride * ESZ;
+  const int rows_valid = row_end - row0;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int rl = wm * TM + i * 16 + fr;
+    char* crow = smem + rl * CROW;
+    const int rsw = rl & CSWZ;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int nl = wn * TN + j * 16 + fq * 4;
+      const int b = nl * ESZ;
+      char* dst = crow + ((((b >> 4) ^ rsw) << 4) | (b & 15));
+      const f32x4 v = acc[i][j];
+      if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      else *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  constexpr int EPC = 16 / ESZ;
+  for (int c = tid; c < BM * CPR; c += 256) {
+    const int rl = c / CPR, ch = c % CPR;
+    const int n = n0 + ch * EPC;
+    if (rl >= rows_valid || n >= p.N) continue;
+    const long m = row0 + rl;
+    const uint4 v = *reinterpret_cast<const uint4*>(smem + rl * CROW + ((ch ^ (rl & CSWZ)) << 4));
+    if constexpr (OUT_BF16) {
+      *reinterpret_cast<uint4*>(Cout + (m * p.ldc + n) * 2) = v;
+    } else {
+      *reinterpret_cast<uint4*>(Cout + (m * p.ldc + n) * 4) = v;
+    }
+  }
+}
+
+template <bool KM, bool OB, int BN, int NS>
+static int tr_launch(TrParams p, const ModeGemmDesc* d, hipStream_t s) {
+  p.n_tiles = (d->N + BN - 1) / BN;
+  p.m_tiles = (d->M + 127) / 128 + (d->expert_offsets ? d->num_experts : 0);
+  const dim3 grid(p.m_tiles * p.n_tiles, 1, (KM && d->k_group_offsets) ? d->num_k_groups : 1);
+  constexpr size_t lds = (size_t)NS * (128 * 64 * 2 + 64 * BN * 2);
+  auto kern = gemm_tr_kernel<KM, OB, BN, NS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+int g_tr_cfg = 0;   // "gemm_tr_cfg" option: 0 auto, 1 = 128-wide NS2, 2 = 64-wide NS3, 3 = 128-wide NS3, 4 = 64-wide NS2
+
+int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
+  const bool a_km = (d->flags & MODE_GEMM_A_KM) != 0;
+  if (!(d->flags & MODE_GEMM_W_KN)) return MODE_ERR_BAD_ARG;
+  if (d->dtype != MODE_BF16 || d->epilogue != MODE_EPI_NONE || d->split_k > 1 || d->a_rows) return MODE_ERR_UNSUPPORTED;
+  if (d->N % 8 != 0 || d->N < 8 || d->lda % 8 != 0 || d->ldw % 8 != 0 || d->ldc % (d->out_dtype == MODE_BF16 ? 8 : 4) != 0) return MODE_ERR_UNSUPPORTED;
+  if (a_km) {
+    if (d->M % 8 != 0 || d->M < 8 || d->expert_offsets) return MODE_ERR_UNSUPPORTED;
+    if (d->k_group_offsets && d->num_k_groups <= 0) return MODE_ERR_BAD_ARG;
+  } else {
+    if (d->K % 64 != 0 || d->K <= 0 || d->k_group_offsets || d->w_rows) return MODE_ERR_UNSUPPORTED;
+  }
+  if (d->M <= 0) return MODE_OK;
+  TrParams p;
+  p.A = (const uint16_t*)d->A; p.lda = d->lda; p.W = (const uint16_t*)d->W; p.ldw = d->ldw; p.w_estride = d->w_expert_stride;
+  p.C = d->C; p.ldc = d->ldc; p.offsets = d->expert_offsets; p.E = d->num_experts;
+  p.koffs = d->k_group_offsets; p.c_gstride = d->c_group_stride; p.w_rows = d->w_rows;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.m_tiles = p.n_tiles = 0;
+  // geometry: enough 128x128 workgroups to put two on every CU -> NS2 ring (they hide each other's fill latency); otherwise 128x64
+  // tiles (twice the workgroups) with a 3-slot ring so one workgroup keeps two tiles in flight
+  const long groups = (a_km && d->k_group_offsets) ? d->num_k_groups : 1;
+  const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * groups;
+  int cfg = g_tr_cfg;
+  if (cfg == 0) cfg = (t128 >= 512 || d->w_rows) ? 1 : 2;
+  if (d->w_rows && (cfg == 2 || cfg == 3)) cfg = 1;
+  const bool ob = d->out_dtype == MODE_BF16;
+#define MODE_TR_CFG(BN, NS)                                                                     \
+  {                                                                                             \
+    if (a_km) return ob ? tr_launch<true, true, BN, NS>(p, d, s) : tr_launch<true, false, BN, NS>(p, d, s);   \
+    return ob ? tr_launch<false, true, BN, NS>(p, d, s) : tr_launch<false, false, BN, NS>(p, d, s);           \
+  }
+  switch (cfg) {
+    case 1: MODE_TR_CFG(128, 2)
+    case 2: MODE_TR_CFG(64, 3)
+    case 3: MODE_TR_CFG(128, 3)
+    case 4: MODE_TR_CFG(64, 2)
+    default: return MODE_ERR_BAD_ARG;
+  }
+#undef MODE_TR_CFG
+}
+
+}  // namespace mode

@@ -40,14 +40,16 @@ class TrainState:
         layers = (L.ModeLayerWeightsT * Ly)()
         keep["r_w0T"] = torch.empty(Ly, D, 2 * D, device=dev)
         keep["r_w3T"] = torch.empty(Ly, 2 * D, E, device=dev)
+        lp = eng.compute_dtype == "bf16"                        # bf16 backward GEMMs read the [out,in] weights directly (MODE_GEMM_W_KN)
         for i in range(Ly):
             k = f"l{i}."
-            keep[k + "wqkvT"] = torch.empty(D, 3 * D, dtype=tdt, device=dev)
-            keep[k + "woT"] = torch.empty(D, D, dtype=tdt, device=dev)
-            keep[k + "w1T"] = torch.empty(E, D, 8 * D, dtype=tdt, device=dev)
-            keep[k + "w2T"] = torch.empty(E, 4 * D, D, dtype=tdt, device=dev)
             lt = layers[i]
-            lt.wqkvT, lt.woT, lt.w1T, lt.w2T = (_ptr(keep[k + n]) for n in ("wqkvT", "woT", "w1T", "w2T"))
+            if not lp:
+                keep[k + "wqkvT"] = torch.empty(D, 3 * D, dtype=tdt, device=dev)
+                keep[k + "woT"] = torch.empty(D, D, dtype=tdt, device=dev)
+                keep[k + "w1T"] = torch.empty(E, D, 8 * D, dtype=tdt, device=dev)
+                keep[k + "w2T"] = torch.empty(E, 4 * D, D, dtype=tdt, device=dev)
+                lt.wqkvT, lt.woT, lt.w1T, lt.w2T = (_ptr(keep[k + n]) for n in ("wqkvT", "woT", "w1T", "w2T"))
             lt.r_w0T, lt.r_w3T = _ptr(keep["r_w0T"][i]), _ptr(keep["r_w3T"][i])
         keep["w_slT"] = torch.empty(D, D, device=dev)
         keep["w_outT"] = torch.empty(D, A, device=dev)
@@ -74,11 +76,12 @@ class TrainState:
             L.check(lib.mode_transpose(src.data_ptr(), cols, rows, cols, dst.data_ptr(), rows, None, None, dtype_code, _stream()), "transpose")
         for i in range(m.num_layers):
             k = f"l{i}."
-            tr(mat[k + "wqkv"], keep[k + "wqkvT"], 3 * D, D, dt)
-            tr(mat[k + "wo"], keep[k + "woT"], D, D, dt)
-            for e in range(E):
-                tr(mat[k + "w1"][e], keep[k + "w1T"][e], 8 * D, D, dt)
-                tr(mat[k + "w2"][e], keep[k + "w2T"][e], D, 4 * D, dt)
+            if eng.compute_dtype != "bf16":
+                tr(mat[k + "wqkv"], keep[k + "wqkvT"], 3 * D, D, dt)
+                tr(mat[k + "wo"], keep[k + "woT"], D, D, dt)
+                for e in range(E):
+                    tr(mat[k + "w1"][e], keep[k + "w1T"][e], 8 * D, D, dt)
+                    tr(mat[k + "w2"][e], keep[k + "w2T"][e], D, 4 * D, dt)
             tr(ar.w["r_w0"][i], keep["r_w0T"][i], 2 * D, D, L.MODE_F32)
             tr(ar.w["r_w3"][i], keep["r_w3T"][i], E, 2 * D, L.MODE_F32)
         tr(ar.w["w_sl"], keep["w_slT"], D, D, L.MODE_F32)

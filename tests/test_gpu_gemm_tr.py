@@ -1,0 +1,94 @@
+"""GPU parity of the backward-pass GEMMs fed by the LDS transpose read (gemm_bf16_tr.hip) against plain fp32 torch matmuls of the same
+bf16 operands: data gradient dX = dY @ W (W row-major [K, N] = nn.Linear's [out, in]) and weight gradient dW = dY^T @ X (row-major
+activations), plain / grouped by expert / arbitrary K ranges / gathered rows.  Inputs are random (not symmetric), so an operand or
+output transpose cannot pass."""
+import ctypes as C
+
+import pytest
+import torch
+
+from mode_diffusion_policy_amd import _lib as L
+from hip_helpers import p, stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _desc(**kw):
+    return L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, **kw)
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N", [(256, 128, 128), (1792, 3072, 1024), (300, 64, 64), (130, 256, 4096), (17, 192, 200)])
+def test_dgrad_plain(M, K, N, out_dtype):
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = torch.randn(K, N, generator=g).to(torch.bfloat16).cuda()
+    Cc = torch.full((M, N), float("nan"), dtype=out_dtype, device="cuda")
+    d = _desc(out_dtype=L.MODE_BF16 if out_dtype == torch.bfloat16 else L.MODE_F32, M=M, N=N, K=K, A=p(A), lda=K, W=p(W), ldw=N,
+              C=p(Cc), ldc=N, flags=L.GEMM_W_KN)
+    L.check(L.load().mode_gemm(C.byref(d), stream()), "dgrad")
+    ref = A.float() @ W.float()
+    assert torch.isfinite(Cc.float()).all()
+    assert rel(Cc.float(), ref) < (1e-5 if out_dtype == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("counts", [[896, 896, 896, 896], [0, 1000, 3, 517], [129, 0, 0, 0]])
+def test_dgrad_grouped_by_expert(counts):
+    E, K, N = len(counts), 256, 384
+    M = sum(counts)
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = torch.randn(E, K, N, generator=g).to(torch.bfloat16).cuda()
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).cuda()
+    Cc = torch.full((M, N), float("nan"), device="cuda")
+    d = _desc(out_dtype=L.MODE_F32, M=M, N=N, K=K, A=p(A), lda=K, W=p(W), ldw=N, w_expert_stride=K * N, C=p(Cc), ldc=N,
+              expert_offsets=p(off), num_experts=E, flags=L.GEMM_W_KN)
+    L.check(L.load().mode_gemm(C.byref(d), stream()), "dgrad grouped")
+    o = 0
+    for e, c in enumerate(counts):
+        if c:
+            assert rel(Cc[o:o + c], A[o:o + c].float() @ W[e].float()) < 1e-5, e
+        o += c
+
+
+@pytest.mark.parametrize("R,M,N", [(1792, 1024, 1024), (1792, 3072, 1024), (100, 64, 64), (77, 136, 200), (64, 128, 128)])
+def test_wgrad_plain(R, M, N):
+    g = torch.Generator().manual_seed(R + M)
+    A = torch.randn(R, M, generator=g).to(torch.bfloat16).cuda()
+    X = torch.randn(R, N, generator=g).to(torch.bfloat16).cuda()
+    Cc = torch.full((M, N), float("nan"), device="cuda")
+    d = _desc(out_dtype=L.MODE_F32, M=M, N=N, K=R, A=p(A), lda=M, W=p(X), ldw=N, C=p(Cc), ldc=N, flags=L.GEMM_W_KN | L.GEMM_A_KM)
+    L.check(L.load().mode_gemm(C.byref(d), stream()), "wgrad")
+    assert rel(Cc, A.float().t() @ X.float()) < 1e-5
+
+
+@pytest.mark.parametrize("gather", [False, True])
+@pytest.mark.parametrize("counts", [[896, 896, 896, 896], [0, 1001, 3, 517], [5, 0, 70, 0]])
+def test_wgrad_expert_segments(counts, gather):
+    """Per-expert weight gradients over the sorted dispatch order: arbitrary (unpadded, possibly empty) row ranges; X rows optionally gathered
+    through the dispatch permutation; stale LDS / rows past a segment must contribute exactly nothing (poisoned neighbours)."""
+    E, M, N = len(counts), 256, 128
+    R = sum(counts)
+    g = torch.Generator().manual_seed(9)
+    A = torch.randn(R, M, generator=g).to(torch.bfloat16).cuda()
+    ntok = R // 2 + 3
+    X = torch.randn(ntok if gather else R, N, generator=g).to(torch.bfloat16).cuda()
+    perm = torch.randint(0, ntok, (R,), generator=g, dtype=torch.int32).cuda() if gather else None
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).cuda()
+    Cc = torch.full((E, M, N), float("nan"), device="cuda")
+    d = _desc(out_dtype=L.MODE_F32, M=M, N=N, K=R, A=p(A), lda=M, W=p(X), ldw=N, C=p(Cc), ldc=N, k_group_offsets=p(off), num_k_groups=E,
+              c_group_stride=M * N, w_rows=p(perm), flags=L.GEMM_W_KN | L.GEMM_A_KM)
+    L.check(L.load().mode_gemm(C.byref(d), stream()), "wgrad groups")
+    Xs = X[perm.long()] if gather else X
+    o = 0
+    for e, c in enumerate(counts):
+        ref = A[o:o + c].float().t() @ Xs[o:o + c].float()
+        if c == 0:
+            assert float(Cc[e].abs().max()) == 0.0
+        else:
+            assert rel(Cc[e], ref) < 1e-5, e
+        o += c
