@@ -256,6 +256,14 @@ int mode_gelu_bwd(const float* pre, const float* dout, float* dpre, int64_t n, v
 int mode_moe_router_bwd(const float* dw, const int32_t* idx, const float* probs, int B, int T, int E, int k, int normalize,
                         int idx_per_token, float* dlogits, void* stream);
 int mode_sigma_embed_bwd(const float* de1, const float* sigma, int B, int D, float* dw, float* db, void* stream);
+/* Router MLP (RouterCond.router: Linear(D,2D) -> GELU -> Linear(2D,E), modedit.py:190-200) for ALL L layers in one launch each:
+ * mode_router_logits:  logits[l][r][e] = b3[l][e] + sum_n hid[r][l*K + n] * w3[l][e][n]   (hid row stride ld_hid, K = 2D);
+ * mode_router_mlp_bwd: dpre[b][l][n] = (sum_e dlog[l][b][e] w3[l][e][n]) * gelu'(pre[b][l][n]);  dw3[l][e][n] = sum_b dlog[l][b][e] gelu(pre[b][l][n]).
+ * pre / dpre are [B][L][2D] (what mode_dit_route writes to r_pre), dlog [L][B][E], w3 / dw3 [L][E][2D] contiguous over layers. */
+int mode_router_logits(const float* hid, int64_t ld_hid, const float* w3, int64_t w3_layer_stride, const float* b3, int64_t b3_layer_stride,
+                       int L, int R, int E, int K, float* logits, void* stream);
+int mode_router_mlp_bwd(const float* dlog, const float* r_pre, const float* w3, int L, int B, int E, int H2, float* dpre, float* dw3, void* stream);
+int mode_iota_i32(int32_t* out, int n, int step, void* stream);                               /* out[i] = i * step (K-group offsets) */
 /* Fused AdamW over a flat fp32 slice (p, g, m, v: n elements, n % 4 == 0, 16-byte aligned).  Replaces torch.optim.AdamW as configured by
  * MoDEAgent.configure_optimizers (mode/models/mode_agent.py:365-392): decoupled weight decay, bias correction by `step` (1-based),
  * g is scaled by grad_scale first (1/world for a summed data-parallel gradient).  lp_bf16 (nullable) receives the updated weights
@@ -319,7 +327,7 @@ int mode_dit_embed_obs(const ModeDims* dims, const ModeModelWeights* w, const fl
  * per layer Linear(D,2D)+GELU -> Linear(2D,E) -> softmax/clamp/top-k.   (modedit.py:194-202, 336, 345-349, 392)
  * Outputs (device, caller-owned): topk_idx int32 [L, R, k]; topk_w fp32 [L, R, k]; probs / shifted fp32 [L, R, E] or NULL. */
 int mode_dit_route(const ModeDims* dims, const ModeModelWeights* w, const float* cond, int R,
-                   int32_t* topk_idx, float* topk_w, float* probs, float* shifted, float* r_pre /* [L,R,2D] pre-GELU, training */,
+                   int32_t* topk_idx, float* topk_w, float* probs, float* shifted, float* r_pre /* [R,L,2D] pre-GELU, training */,
                    void* workspace, size_t workspace_bytes, void* stream);
 /* combine weights for HOST-chosen expert ids (training: torch.multinomial per token row, modedit.py:390):
  * w[n, j] = probs[n / tokens_per_row, idx[n, j]] (/ their sum when normalize). */
@@ -370,7 +378,7 @@ typedef struct ModeTrainArgs {
   const int32_t* meta; int64_t meta_layer_stride;         /* L per-token dispatch records                                 */
   const int32_t* topk_idx; int64_t topk_layer_stride; int32_t idx_per_token;   /* [L][B*T or B][k] expert ids            */
   const float* probs;            /* [L, B, E] clamped softmax of the router                  */
-  const float* r_pre;            /* [L, B, 2D] router pre-GELU activations                   */
+  const float* r_pre;            /* [B, L, 2D] router pre-GELU activations (mode_dit_route)  */
   float* F;                      /* out: [B, A_len, A]                                       */
 } ModeTrainArgs;
 int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes,
@@ -384,13 +392,14 @@ typedef struct ModeModelGrads {
   float* pos; float* w_se; float* b_se; float* w_sl; float* w_tok; float* w_goal; float* w_act; float* ln_g; float* w_out; float* b_out;
   const ModeLayerGrads* layers;
 } ModeModelGrads;
-typedef struct ModeLayerWeightsT {        /* transposed shadows for the data-gradient GEMMs: fp32 router always; wqkvT/woT/w1T/w2T only in
-                                             fp32 compute mode (bf16 reads the [out,in] weights directly, MODE_GEMM_W_KN) — may be NULL there */
+typedef struct ModeLayerWeightsT {        /* transposed shadows for the data-gradient GEMMs of the fp32 compute mode only: in bf16 the backward
+                                             GEMMs read the [out,in] weights directly (MODE_GEMM_W_KN) and these may be NULL */
   const void* wqkvT;  /* [D, 3D] */  const void* woT;   /* [D, D] */
   const void* w1T;    /* [E][D, 8D] */ const void* w2T;  /* [E][4D, D] */
-  const float* r_w0T; /* [D, 2D] */  const float* r_w3T; /* [2D, E] */
 } ModeLayerWeightsT;
-typedef struct ModeModelWeightsT { const float* w_slT; /* [D, D] */ const float* w_outT; /* [D, A] */ const ModeLayerWeightsT* layers; } ModeModelWeightsT;
+typedef struct ModeModelWeightsT { const float* w_outT; /* [D, A] */ const ModeLayerWeightsT* layers; } ModeModelWeightsT;
+/* Router weights AND router gradients of the L layers must be contiguous ([L,2D,D], [L,2D], [L,E,2D], [L,E]: layers[l].r_w0 ==
+ * layers[0].r_w0 + l*2D*D, ...): the router MLPs of all layers are back-propagated as one batch (MODE_ERR_UNSUPPORTED otherwise). */
 int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w, const ModeModelWeightsT* wt, const ModeTrainArgs* a,
                       const void* stash, const float* dF, const ModeModelGrads* grads, void* workspace, size_t workspace_bytes,
                       void* stream);

@@ -94,11 +94,11 @@ class ModeModelGrads(C.Structure):
 
 
 class ModeLayerWeightsT(C.Structure):
-    _fields_ = [(n, c_vp) for n in ("wqkvT", "woT", "w1T", "w2T", "r_w0T", "r_w3T")]
+    _fields_ = [(n, c_vp) for n in ("wqkvT", "woT", "w1T", "w2T")]
 
 
 class ModeModelWeightsT(C.Structure):
-    _fields_ = [("w_slT", c_vp), ("w_outT", c_vp), ("layers", C.POINTER(ModeLayerWeightsT))]
+    _fields_ = [("w_outT", c_vp), ("layers", C.POINTER(ModeLayerWeightsT))]
 
 
 class ModeForwardArgs(C.Structure):
@@ -149,6 +149,9 @@ PROTOTYPES = {
     "mode_dit_train_stash_layout": (C.c_int, [P(ModeDims), C.c_int, C.c_int, P(ModeStashLayout)]),
     "mode_dit_train_workspace_bytes": (c_sz, [P(ModeDims), C.c_int, C.c_int]),
     "mode_dit_forward_train": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeTrainArgs), c_vp, c_sz, c_vp]),
+    "mode_router_logits": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mode_router_mlp_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "mode_iota_i32": (C.c_int, [c_vp, c_i32, c_i32, c_vp]),
     "mode_adamw_step": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i32, C.c_float, c_vp, c_vp]),
     "mode_dit_backward": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeModelWeightsT), P(ModeTrainArgs), c_vp, c_vp, P(ModeModelGrads),
                                     c_vp, c_sz, c_vp]),

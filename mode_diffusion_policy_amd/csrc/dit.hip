@@ -40,8 +40,8 @@ static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
   w.meta = take((size_t)d.L * ml.total_words * 4);
   const size_t Rr = R > 0 ? R : 1;
   w.e1 = take(Rr * D * 4);
-  w.hid = take(Rr * 2 * D * 4);
-  w.logits = take(Rr * d.E * 4);
+  w.hid = take(Rr * 2 * D * 4 * d.L);          // router hidden activations of all layers [R][L][2D]
+  w.logits = take(Rr * d.E * 4 * d.L);
   w.total = o;
   return w;
 }
@@ -80,7 +80,7 @@ extern "C" int mode_set_option(const char* key, int value) {
 extern "C" int mode_gemm(const ModeGemmDesc* d, void* stream) {
   if (!d || !d->A || !d->W || !d->C || d->M < 0 || d->N <= 0) return MODE_ERR_BAD_ARG;
   if (d->expert_offsets && d->num_experts <= 0) return MODE_ERR_BAD_ARG;
-  if (d->flags & (MODE_GEMM_W_KN | MODE_GEMM_A_KM)) return gemm_bf16_tr_launch(d, (hipStream_t)stream);
+  if (d->dtype == MODE_BF16 && (d->flags & (MODE_GEMM_W_KN | MODE_GEMM_A_KM))) return gemm_bf16_tr_launch(d, (hipStream_t)stream);
   if (d->dtype == MODE_BF16) return gemm_bf16_launch(d, (hipStream_t)stream);
   if (d->dtype == MODE_F32) return gemm_f32_launch(d, (hipStream_t)stream);
   return MODE_ERR_BAD_ARG;
@@ -164,34 +164,40 @@ extern "C" int mode_dit_route(const ModeDims* dims, const ModeModelWeights* w, c
   const WsLayout L = ws_layout(*dims, 0, R, MODE_F32);
   if (workspace_bytes < L.total) return MODE_ERR_WORKSPACE;
   char* ws = (char*)workspace;
-  float* hid = (float*)(ws + L.hid);
-  float* logits = (float*)(ws + L.logits);
-  const int D = dims->D, E = dims->E, k = dims->k;
-  for (int l = 0; l < dims->L; ++l) {
-    const ModeLayerWeights& lw = w->layers[l];
-    ModeGemmDesc g;
-    if (r_pre) {                                              // training: keep the pre-GELU activations for the router backward
-      float* pre = r_pre + (long)l * R * 2 * D;
-      g = gemm_desc(MODE_F32, MODE_EPI_BIAS, MODE_F32, R, 2 * D, D, cond, D, lw.r_w0, D, pre, 2 * D);
-      g.bias = lw.r_b0;
-      rc = mode_gemm(&g, stream);
-      if (rc) return rc;
-      rc = mode_gelu_fwd(pre, hid, (long)R * 2 * D, stream);
-    } else {
-      g = gemm_desc(MODE_F32, MODE_EPI_BIAS_GELU, MODE_F32, R, 2 * D, D, cond, D, lw.r_w0, D, hid, 2 * D);
-      g.bias = lw.r_b0; g.flags = MODE_GEMM_SKINNY_OK;     // R <= 16 distinct sigma rows (sampler): stream the router weights once
-      rc = mode_gemm(&g, stream);
-    }
-    if (rc) return rc;
-    g = gemm_desc(MODE_F32, MODE_EPI_BIAS, MODE_F32, R, E, 2 * D, hid, 2 * D, lw.r_w3, 2 * D, logits, E);
-    g.bias = lw.r_b3; g.flags = MODE_GEMM_SKINNY_OK;
-    rc = mode_gemm(&g, stream);
-    if (rc) return rc;
-    rc = mode_moe_route_topk_f32(logits, R, E, k, dims->router_normalize, shifted ? shifted + (long)l * R * E : nullptr,
-                                 probs ? probs + (long)l * R * E : nullptr, topk_idx + (long)l * R * k, topk_w + (long)l * R * k, stream);
-    if (rc) return rc;
+  float* hid = (float*)(ws + L.hid);                 // [R][L][2D]
+  float* logits = (float*)(ws + L.logits);           // [L][R][E]
+  const int D = dims->D, E = dims->E, k = dims->k, Ly = dims->L, H2 = 2 * D;
+  // The router only sees the conditioning rows, so ALL layers are routed up front.  When the router weights of the layers are adjacent
+  // in memory (the parameter arena lays them out as r_w0 [L,2D,D], r_b0 [L,2D], r_w3 [L,E,2D], r_b3 [L,E]) the first Linear of every
+  // layer is ONE GEMM with N = L*2D, the second one launch of router_logits, the softmax/top-k one launch over L*R rows.
+  bool packed = true;
+  for (int l = 1; l < Ly; ++l) {
+    const ModeLayerWeights& a = w->layers[l]; const ModeLayerWeights& z = w->layers[0];
+    packed = packed && a.r_w0 == z.r_w0 + (long)l * H2 * D && a.r_b0 == z.r_b0 + (long)l * H2 && a.r_w3 == z.r_w3 + (long)l * E * H2 &&
+             a.r_b3 == z.r_b3 + (long)l * E;
   }
-  return MODE_OK;
+  const int nb = packed ? 1 : Ly, lb = packed ? Ly : 1;      // launches x layers per launch
+  for (int i = 0; i < nb; ++i) {
+    const ModeLayerWeights& lw = w->layers[i];
+    const long col = (long)i * H2;
+    ModeGemmDesc g;
+    if (r_pre) {                                              // training: keep the pre-GELU activations [R][L][2D] for the router backward
+      g = gemm_desc(MODE_F32, MODE_EPI_BIAS, MODE_F32, R, lb * H2, D, cond, D, lw.r_w0, D, r_pre + col, (long)Ly * H2);
+      g.bias = lw.r_b0;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    } else {
+      g = gemm_desc(MODE_F32, MODE_EPI_BIAS_GELU, MODE_F32, R, lb * H2, D, cond, D, lw.r_w0, D, hid + col, (long)Ly * H2);
+      g.bias = lw.r_b0; g.flags = MODE_GEMM_SKINNY_OK;     // R <= 16 distinct sigma rows (sampler): stream the router weights once
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    }
+  }
+  if (r_pre && (rc = mode_gelu_fwd(r_pre, hid, (long)R * Ly * H2, stream))) return rc;
+  for (int i = 0; i < nb; ++i) {
+    const ModeLayerWeights& lw = w->layers[i];
+    if ((rc = mode_router_logits(hid + (long)i * H2, (long)Ly * H2, lw.r_w3, (long)E * H2, lw.r_b3, E, lb, R, E, H2, logits + (long)i * R * E, stream)))
+      return rc;
+  }
+  return mode_moe_route_topk_f32(logits, Ly * R, E, k, dims->router_normalize, shifted, probs, topk_idx, topk_w, stream);
 }
 
 extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w, const ModeForwardArgs* a, void* workspace,

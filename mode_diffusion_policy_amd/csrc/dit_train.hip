@@ -54,7 +54,9 @@ TrainWs train_ws(const ModeDims& d, int B, int dtype) {
   if (c2 > cs) cs = c2;
   if (c3 > cs) cs = c3;
   w.csw = t(cs + 4096);
-  w.dcond = t((size_t)B * D * 4); w.dlog = t((size_t)B * d.E * 4); w.dhid = t((size_t)B * 2 * D * 4); w.dpre = t((size_t)B * 2 * D * 4);
+  w.dcond = t((size_t)B * D * 4); w.dlog = t((size_t)d.L * B * d.E * 4);           // dlogits of ALL layers [L][B][E]
+  w.dhid = t((size_t)d.L * B * D * 4 + 256 * 4);                                   // per-layer partial dcond [L][B][D] + K-group offsets
+  w.dpre = t((size_t)B * d.L * 2 * D * 4);                                         // dpre of ALL layers [B][L][2D]
   const size_t smallT = ((size_t)2 * D > (size_t)d.O ? 2 * D : d.O) * (R > 2 * (size_t)B ? R : 2 * B) * 4 + 4096;
   w.st1 = t(smallT); w.st2 = t(smallT);
   w.tmp_rd = t(R * D * 4);
@@ -170,6 +172,13 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
   if (!a->meta || !a->act_rows || !a->probs || !a->r_pre || !a->topk_idx || !a->sigma || !a->state_images || !a->goals || !a->e1) return MODE_ERR_BAD_ARG;
   const ModeDims& d = *dims;
   const int dt = a->dtype, B = a->B, T = d.T, D = d.D, N = B * T, NK = N * d.k, E = d.E, R = B * d.A_len, A = d.A_dim, hd = D / d.H;
+  for (int l = 1; l < d.L; ++l) {                      // the batched router backward needs layer-contiguous router weights / gradients
+    const ModeLayerWeights& wl = w->layers[l]; const ModeLayerWeights& w0 = w->layers[0];
+    const ModeLayerGrads& gl = gr->layers[l]; const ModeLayerGrads& g0 = gr->layers[0];
+    if (wl.r_w0 != w0.r_w0 + (long)l * 2 * D * D || wl.r_w3 != w0.r_w3 + (long)l * E * 2 * D || gl.r_w0 != g0.r_w0 + (long)l * 2 * D * D ||
+        gl.r_b0 != g0.r_b0 + (long)l * 2 * D || gl.r_w3 != g0.r_w3 + (long)l * E * 2 * D || gl.r_b3 != g0.r_b3 + (long)l * E)
+      return MODE_ERR_UNSUPPORTED;
+  }
   const bool tr = dt == MODE_BF16 && D % 8 == 0;      // bf16: backward GEMMs read row-major operands directly (gemm_bf16_tr.hip); no transposed copies
   const bool bf = dt == MODE_BF16;
   const long NKp = ((long)NK + 63) / 64 * 64 + 64L * E, Np = ((long)N + 63) / 64 * 64;
@@ -325,36 +334,36 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
                                stream))) return rc;
     if ((rc = colsum(dgp, D, nblk4, D, MODE_F32, nullptr, 0, 1, lg.ln1_g, 0))) return rc;
     if ((rc = colsum(dh1, D, N, D, MODE_F32, nullptr, T, B, dcond, 1))) return rc;
-    // (10) router backward (fp32, B distinct conditioning rows)
+    // (10) router: only dlogits here (through renormalisation / clamp / softmax); the router MLPs of all layers are back-propagated
+    //      in one batch after the loop
     {
       const float* probs = a->probs + (long)l * B * E;
-      const float* rpre = a->r_pre + (long)l * B * 2 * D;
       const int32_t* idx = a->topk_idx + (long)l * a->topk_layer_stride;
-      if ((rc = mode_moe_router_bwd(dwt, idx, probs, B, T, E, d.k, d.router_normalize, a->idx_per_token, dlog, stream))) return rc;
-      if ((rc = colsum(dlog, E, B, E, MODE_F32, nullptr, 0, 1, lg.r_b3, 0))) return rc;
-      float* hid = st2 + (size_t)2 * D * B;                                                 // GELU(pre) recomputed  [B, 2D]
-      if ((rc = mode_gelu_fwd(rpre, hid, (long)B * 2 * D, stream))) return rc;
-      // dW3 [E, 2D] = dlog^T hid
-      if ((rc = mode_transpose(dlog, E, B, E, st1, B, nullptr, nullptr, MODE_F32, stream))) return rc;
-      if ((rc = mode_transpose(hid, 2 * D, B, 2 * D, st2, B, nullptr, nullptr, MODE_F32, stream))) return rc;
-      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, E, 2 * D, B, st1, B, st2, B, lg.r_w3, 2 * D);
-      g.flags = MODE_GEMM_SKINNY_OK;                                                        // M = E rows: stream hid^T once
-      if ((rc = mode_gemm(&g, stream))) return rc;
-      // dhid = dlog W3 ; dpre = dhid * gelu'(pre)
-      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, B, 2 * D, E, dlog, E, lt->r_w3T, E, dhid, 2 * D);
-      if ((rc = mode_gemm(&g, stream))) return rc;
-      if ((rc = mode_gelu_bwd(rpre, dhid, dpre, (long)B * 2 * D, stream))) return rc;
-      if ((rc = colsum(dpre, 2 * D, B, 2 * D, MODE_F32, nullptr, 0, 1, lg.r_b0, 0))) return rc;
-      // dW0 [2D, D] = dpre^T cond ; dcond += dpre W0
-      if ((rc = mode_transpose(dpre, 2 * D, B, 2 * D, st1, B, nullptr, nullptr, MODE_F32, stream))) return rc;
-      if ((rc = mode_transpose(a->cond, D, B, D, st2, B, nullptr, nullptr, MODE_F32, stream))) return rc;
-      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, 2 * D, D, B, st1, B, st2, B, lg.r_w0, D);
-      if ((rc = mode_gemm(&g, stream))) return rc;
-      g = gdesc(MODE_F32, MODE_EPI_RESIDUAL, MODE_F32, B, D, 2 * D, dpre, 2 * D, lt->r_w0T, 2 * D, dcond, D);
-      g.resid = dcond; g.ldr = D;
-      if ((rc = mode_gemm(&g, stream))) return rc;
+      if ((rc = mode_moe_router_bwd(dwt, idx, probs, B, T, E, d.k, d.router_normalize, a->idx_per_token, dlog + (long)l * B * E, stream))) return rc;
     }
     float* t_ = DXa; DXa = DXb; DXb = t_;                    // DXa now holds d x_l
+  }
+
+  // ---- router MLPs of all layers in one batch (fp32).  r_pre / dpre are [B][L][2D]; weights and gradients [L][...] contiguous.
+  {
+    const int Ly = d.L, H2 = 2 * D;
+    const ModeLayerWeights& w0 = w->layers[0];
+    const ModeLayerGrads& g0 = gr->layers[0];
+    float* cpart = dhid;                                                          // [L][B][D] partial dcond per layer
+    int32_t* koffs = reinterpret_cast<int32_t*>(dhid + (size_t)Ly * B * D);       // [L+1] K-group offsets 0, 2D, 4D, ...
+    if ((rc = colsum(dlog, E, Ly * B, E, MODE_F32, nullptr, B, Ly, g0.r_b3, 0))) return rc;                    // db3 [L][E]
+    if ((rc = mode_router_mlp_bwd(dlog, a->r_pre, w0.r_w3, Ly, B, E, H2, dpre, g0.r_w3, stream))) return rc;  // dpre, dW3
+    if ((rc = colsum(dpre, (long)Ly * H2, B, Ly * H2, MODE_F32, nullptr, 0, 1, g0.r_b0, 0))) return rc;        // db0 [L][2D]
+    // dW0 [L*2D, D] = dpre^T [L*2D x B] cond [B x D]
+    ModeGemmDesc g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, Ly * H2, D, B, dpre, (long)Ly * H2, a->cond, D, g0.r_w0, D);
+    g.flags = MODE_GEMM_A_KM | MODE_GEMM_W_KN;
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    // dcond += dpre [B, L*2D] W0 [L*2D, D]: one K-group per layer (parallelism), partial results summed in layer order
+    if ((rc = mode_iota_i32(koffs, Ly + 1, H2, stream))) return rc;
+    g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, B, D, Ly * H2, dpre, (long)Ly * H2, w0.r_w0, D, cpart, D);
+    g.flags = MODE_GEMM_W_KN; g.k_group_offsets = koffs; g.num_k_groups = Ly; g.c_group_stride = (long)B * D;
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    if ((rc = colsum(cpart, (long)B * D, Ly, B * D, MODE_F32, nullptr, 0, 1, dcond, 1))) return rc;
   }
 
   // ---- embeddings: x_0 = [emb_t | goal_e + pos0 | img_e + pos1 | act_e + pos(1..A)]
@@ -382,20 +391,30 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     if ((rc = mode_gemm(&g, stream))) return rc;
     // tok_emb / goal_emb: dW = d e^T input
     const int RI = B * d.n_img;
-    if ((rc = mode_transpose(dimg, D, RI, D, st1, RI, nullptr, nullptr, MODE_F32, stream))) return rc;
-    if ((rc = mode_transpose(a->state_images, d.O, RI, d.O, st2, RI, nullptr, nullptr, MODE_F32, stream))) return rc;
-    g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, d.O, RI, st1, RI, st2, RI, gr->w_tok, d.O);
-    if ((rc = mode_gemm(&g, stream))) return rc;
-    if ((rc = mode_transpose(dgoal, D, B, D, st1, B, nullptr, nullptr, MODE_F32, stream))) return rc;
-    if ((rc = mode_transpose(a->goals, d.G, B, d.G, st2, B, nullptr, nullptr, MODE_F32, stream))) return rc;
-    g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, d.G, B, st1, B, st2, B, gr->w_goal, d.G);
-    if ((rc = mode_gemm(&g, stream))) return rc;
+    const bool kn_ok = d.O % 4 == 0 && d.G % 4 == 0;               // [K][M] / [K][N] operand layouts need 16-byte aligned rows
+    if (kn_ok) {
+      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, d.O, RI, dimg, D, a->state_images, d.O, gr->w_tok, d.O);
+      g.flags = MODE_GEMM_A_KM | MODE_GEMM_W_KN;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, d.G, B, dgoal, D, a->goals, d.G, gr->w_goal, d.G);
+      g.flags = MODE_GEMM_A_KM | MODE_GEMM_W_KN;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    } else {
+      if ((rc = mode_transpose(dimg, D, RI, D, st1, RI, nullptr, nullptr, MODE_F32, stream))) return rc;
+      if ((rc = mode_transpose(a->state_images, d.O, RI, d.O, st2, RI, nullptr, nullptr, MODE_F32, stream))) return rc;
+      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, d.O, RI, st1, RI, st2, RI, gr->w_tok, d.O);
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      if ((rc = mode_transpose(dgoal, D, B, D, st1, B, nullptr, nullptr, MODE_F32, stream))) return rc;
+      if ((rc = mode_transpose(a->goals, d.G, B, d.G, st2, B, nullptr, nullptr, MODE_F32, stream))) return rc;
+      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, d.G, B, st1, B, st2, B, gr->w_goal, d.G);
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    }
     // sigma path: emb_t = e1 W_sl^T, e1 = s * w_se + b_se
-    if ((rc = mode_transpose(demb, D, B, D, st1, B, nullptr, nullptr, MODE_F32, stream))) return rc;
-    if ((rc = mode_transpose(a->e1, D, B, D, st2, B, nullptr, nullptr, MODE_F32, stream))) return rc;
-    g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, D, B, st1, B, st2, B, gr->w_sl, D);
+    g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, D, B, demb, D, a->e1, D, gr->w_sl, D);
+    g.flags = MODE_GEMM_A_KM | MODE_GEMM_W_KN;
     if ((rc = mode_gemm(&g, stream))) return rc;
-    g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, B, D, D, demb, D, wt->w_slT, D, de1, D);
+    g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, B, D, D, demb, D, w->w_sl, D, de1, D);
+    g.flags = MODE_GEMM_W_KN;
     if ((rc = mode_gemm(&g, stream))) return rc;
     if ((rc = mode_sigma_embed_bwd(de1, a->sigma, B, D, gr->w_se, gr->b_se, stream))) return rc;
   }

@@ -18,6 +18,7 @@ struct GemmF32Params {
   const int* a_rows; const int* offsets; int E;
   const int* koffs; long c_gstride;
   int M, N, K, m_tiles, n_tiles;
+  int a_km, w_kn;                         // operand given as [K][M] / [K][N] row-major (backward-pass layouts, see MODE_GEMM_A_KM / W_KN)
 };
 
 template <int EPI, bool OUT_BF16, bool VEC>
@@ -80,9 +81,39 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
   if (p.koffs) { kbeg = p.koffs[blockIdx.z]; kend = p.koffs[blockIdx.z + 1]; }
   const int nk = (kend - kbeg + FBK - 1) / FBK;
   float4 ra, rb;
+  // [K][cols] operands: thread -> k row (tid>>4), column quad (tid&15)*4; stored transposed into the same [row][k] LDS image
+  const int krow = tid >> 4, q4 = (tid & 15) * 4;
+  auto kn_load = [&](const float* base, long ld, int k, int c, int climit) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < kend) {
+      const float* src = base + (long)k * ld + c;
+      if (VEC && c + 3 < climit) v = *reinterpret_cast<const float4*>(src);
+      else {
+        if (c + 0 < climit) v.x = src[0];
+        if (c + 1 < climit) v.y = src[1];
+        if (c + 2 < climit) v.z = src[2];
+        if (c + 3 < climit) v.w = src[3];
+      }
+    }
+    return v;
+  };
   auto gload = [&](int kt) {
     const int k = kbeg + kt * FBK + kq;
-    if constexpr (VEC) {
+    if (p.a_km || p.w_kn) {
+      const int kr = kbeg + kt * FBK + krow;
+      if (p.a_km) ra = kn_load(p.A, p.lda, kr, row0 + q4, p.M);
+      else if (k + 3 < kend) ra = *reinterpret_cast<const float4*>(a_src + kbeg + kt * FBK);
+      else {
+        const float* a = a_src + kbeg + kt * FBK;
+        ra.x = (k + 0 < kend) ? a[0] : 0.f; ra.y = (k + 1 < kend) ? a[1] : 0.f; ra.z = (k + 2 < kend) ? a[2] : 0.f; ra.w = (k + 3 < kend) ? a[3] : 0.f;
+      }
+      if (p.w_kn) rb = kn_load(W, p.ldw, kr, n0 + q4, p.N);
+      else if (k + 3 < kend) rb = *reinterpret_cast<const float4*>(b_src + kbeg + kt * FBK);
+      else {
+        const float* b = b_src + kbeg + kt * FBK;
+        rb.x = (k + 0 < kend) ? b[0] : 0.f; rb.y = (k + 1 < kend) ? b[1] : 0.f; rb.z = (k + 2 < kend) ? b[2] : 0.f; rb.w = (k + 3 < kend) ? b[3] : 0.f;
+      }
+    } else if constexpr (VEC) {
       ra = *reinterpret_cast<const float4*>(a_src + kbeg + kt * FBK);
       rb = *reinterpret_cast<const float4*>(b_src + kbeg + kt * FBK);
     } else {
@@ -94,9 +125,20 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
     }
   };
   auto commit = [&](int buf) {
-    float* a = &sA[buf][tr * FLD + kq]; float* b = &sB[buf][tr * FLD + kq];
-    a[0] = ra.x; a[1] = ra.y; a[2] = ra.z; a[3] = ra.w;
-    b[0] = rb.x; b[1] = rb.y; b[2] = rb.z; b[3] = rb.w;
+    if (p.a_km) {
+      float* a = &sA[buf][q4 * FLD + krow];
+      a[0] = ra.x; a[FLD] = ra.y; a[2 * FLD] = ra.z; a[3 * FLD] = ra.w;
+    } else {
+      float* a = &sA[buf][tr * FLD + kq];
+      a[0] = ra.x; a[1] = ra.y; a[2] = ra.z; a[3] = ra.w;
+    }
+    if (p.w_kn) {
+      float* b = &sB[buf][q4 * FLD + krow];
+      b[0] = rb.x; b[FLD] = rb.y; b[2 * FLD] = rb.z; b[3 * FLD] = rb.w;
+    } else {
+      float* b = &sB[buf][tr * FLD + kq];
+      b[0] = rb.x; b[1] = rb.y; b[2] = rb.z; b[3] = rb.w;
+    }
   };
 
   if (nk > 0) { gload(0); commit(0); }
@@ -270,14 +312,21 @@ int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s) {
     return MODE_ERR_BAD_ARG;
   if (d->epilogue == MODE_EPI_RESIDUAL && !d->resid) return MODE_ERR_BAD_ARG;
   if (d->M <= 0) return MODE_OK;
-  if (d->N <= 16 && d->K >= 64 && d->K % 4 == 0 && !d->expert_offsets && !d->k_group_offsets && d->out_dtype == MODE_F32 && d->lda % 4 == 0 &&
+  if (!(d->flags & (MODE_GEMM_A_KM | MODE_GEMM_W_KN)) && d->N <= 16 && d->K >= 64 && d->K % 4 == 0 && !d->expert_offsets && !d->k_group_offsets && d->out_dtype == MODE_F32 && d->lda % 4 == 0 &&
       d->ldw % 4 == 0 && d->epilogue != MODE_EPI_SWIGLU && (((uintptr_t)d->A | (uintptr_t)d->W) % 16 == 0))
     return launch_dot(d, s);
-  if ((d->flags & MODE_GEMM_SKINNY_OK) && d->M <= 16 && !d->a_rows && !d->expert_offsets && !d->k_group_offsets && d->out_dtype == MODE_F32 && d->K % 4 == 0 && d->lda % 4 == 0 && d->ldw % 4 == 0 &&
+  if ((d->flags & MODE_GEMM_SKINNY_OK) && !(d->flags & (MODE_GEMM_A_KM | MODE_GEMM_W_KN)) && d->M <= 16 && !d->a_rows && !d->expert_offsets && !d->k_group_offsets && d->out_dtype == MODE_F32 && d->K % 4 == 0 && d->lda % 4 == 0 && d->ldw % 4 == 0 &&
       (d->epilogue == MODE_EPI_NONE || d->epilogue == MODE_EPI_BIAS || d->epilogue == MODE_EPI_BIAS_GELU) &&
       (((uintptr_t)d->A | (uintptr_t)d->W) % 16 == 0))
     return launch_skinny(d, s);
+  const bool a_km = (d->flags & MODE_GEMM_A_KM) != 0, w_kn = (d->flags & MODE_GEMM_W_KN) != 0;
+  if (a_km || w_kn) {      // backward-pass operand layouts: plain or K-grouped only; the "a_src/b_src + k" fast path needs 16-B aligned rows
+    if (d->a_rows || d->expert_offsets || d->epilogue == MODE_EPI_SWIGLU || d->out_dtype != MODE_F32) return MODE_ERR_UNSUPPORTED;
+    if (d->lda % 4 || d->ldw % 4 || (((uintptr_t)d->A | (uintptr_t)d->W) % 16)) return MODE_ERR_UNSUPPORTED;
+    if (!a_km && d->K % 4) return MODE_ERR_UNSUPPORTED;
+  }
   GemmF32Params p;
+  p.a_km = a_km; p.w_kn = w_kn;
   p.A = (const float*)d->A; p.lda = d->lda;
   p.W = (const float*)d->W; p.ldw = d->ldw; p.w_estride = d->w_expert_stride;
   p.bias = d->bias; p.bias_estride = d->bias_expert_stride;
@@ -288,8 +337,9 @@ int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.n_tiles = (d->N + nout - 1) / nout;
   p.m_tiles = (d->M + FBM - 1) / FBM + (d->expert_offsets ? d->num_experts : 0);
   const int nblk = p.m_tiles * p.n_tiles;
-  const bool vec = (d->K % FBK == 0) && (d->lda % 4 == 0) && (d->ldw % 4 == 0) && (d->w_expert_stride % 4 == 0) &&
-                   (((uintptr_t)d->A | (uintptr_t)d->W) % 16 == 0);
+  const bool vec = (a_km || w_kn) ? true
+                                  : (d->K % FBK == 0) && (d->lda % 4 == 0) && (d->ldw % 4 == 0) && (d->w_expert_stride % 4 == 0) &&
+                                        (((uintptr_t)d->A | (uintptr_t)d->W) % 16 == 0);
   const bool ob = d->out_dtype == MODE_BF16;
   p.koffs = d->k_group_offsets; p.c_gstride = d->c_group_stride;
   const int ng = d->k_group_offsets ? d->num_k_groups : 1;

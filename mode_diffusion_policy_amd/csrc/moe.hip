@@ -129,9 +129,42 @@ __global__ __launch_bounds__(1024) void dispatch_meta_kernel(MetaBatch mb, int R
   }
 }
 
+// Router output layer for all layers at once: logits[l][r][e] = b3[l][e] + sum_n hid[r][l*K + n] * W3[l][e][n]  (Linear(2D, E), modedit.py:199).
+// One wave per output element, float4 loads, fixed per-lane partial order + xor butterfly: deterministic and independent of R.
+__global__ __launch_bounds__(256) void router_logits_kernel(const float* __restrict__ hid, long ld_hid, const float* __restrict__ w3, long w3_ls,
+                                                            const float* __restrict__ b3, long b3_ls, int L, int R, int E, int K,
+                                                            float* __restrict__ logits) {
+  const int lane = threadIdx.x & 63;
+  const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= (long)L * R * E) return;
+  const int e = (int)(o % E), r = (int)((o / E) % R), l = (int)(o / ((long)E * R));
+  const float* x = hid + (long)r * ld_hid + (long)l * K;
+  const float* w = w3 + (long)l * w3_ls + (long)e * K;
+  float acc = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + k);
+    const float4 wv = *reinterpret_cast<const float4*>(w + k);
+    acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) logits[o] = acc + b3[(long)l * b3_ls + e];
+}
+
 }  // namespace mode
 
 using namespace mode;
+
+extern "C" int mode_router_logits(const float* hid, int64_t ld_hid, const float* w3, int64_t w3_layer_stride, const float* b3, int64_t b3_layer_stride,
+                                  int L, int R, int E, int K, float* logits, void* stream) {
+  if (!hid || !w3 || !b3 || !logits || L <= 0 || R < 0 || E <= 0 || K <= 0) return MODE_ERR_BAD_ARG;
+  if (K % 4 || ld_hid % 4 || w3_layer_stride % 4 || (((uintptr_t)hid | (uintptr_t)w3) & 15)) return MODE_ERR_UNSUPPORTED;
+  if (R == 0) return MODE_OK;
+  const long outs = (long)L * R * E;
+  hipLaunchKernelGGL(router_logits_kernel, dim3((outs + 3) / 4), dim3(256), 0, (hipStream_t)stream, hid, (long)ld_hid, w3, (long)w3_layer_stride, b3,
+                     (long)b3_layer_stride, L, R, E, K, logits);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
 
 extern "C" int mode_moe_route_topk_f32(const float* logits, int R, int E, int k, int normalize, float* shifted, float* probs,
                                        int32_t* topk_idx, float* topk_w, void* stream) {

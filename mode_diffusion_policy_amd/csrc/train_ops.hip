@@ -244,6 +244,60 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ pre, const float* __re
   dpre[i] = dout[i] * (cdf + x * pdf);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Router MLP backward for ALL layers at once (RouterCond.router = Linear(D,2D) -> GELU -> Dropout(0) -> Linear(2D,E), modedit.py:190-200):
+//   dpre[b][l][n] = (sum_e dlog[l][b][e] * W3[l][e][n]) * gelu'(pre[b][l][n])          (one thread per 4 n)
+//   dW3[l][e][n]  = sum_b dlog[l][b][e] * gelu(pre[b][l][n])                           (one thread per n, fixed b order -> deterministic)
+// pre / dpre are [B][L][2D] so that dpre is directly the A operand of the batched weight/data-gradient GEMMs of the first Linear.
+__global__ __launch_bounds__(256) void router_mlp_dpre_kernel(const float* __restrict__ dlog, const float* __restrict__ pre, const float* __restrict__ w3,
+                                                              int L, int B, int E, int H2, float* __restrict__ dpre) {
+  const long i4 = (long)blockIdx.x * 256 + threadIdx.x;              // index of a 4-element group in [B][L][H2]
+  const long total4 = (long)B * L * H2 / 4;
+  if (i4 >= total4) return;
+  const long i = i4 * 4;
+  const int n = (int)(i % H2);
+  const int l = (int)((i / H2) % L);
+  const int b = (int)(i / ((long)H2 * L));
+  const float4 x = *reinterpret_cast<const float4*>(pre + i);
+  float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = 0; e < E; ++e) {
+    const float dl = dlog[((long)l * B + b) * E + e];
+    const float4 w = *reinterpret_cast<const float4*>(w3 + ((long)l * E + e) * H2 + n);
+    dh.x = fmaf(dl, w.x, dh.x); dh.y = fmaf(dl, w.y, dh.y); dh.z = fmaf(dl, w.z, dh.z); dh.w = fmaf(dl, w.w, dh.w);
+  }
+  auto gp = [](float v) {
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+    return cdf + v * pdf;
+  };
+  *reinterpret_cast<float4*>(dpre + i) = make_float4(dh.x * gp(x.x), dh.y * gp(x.y), dh.z * gp(x.z), dh.w * gp(x.w));
+}
+
+template <int EMAX>
+__global__ __launch_bounds__(256) void router_w3_grad_kernel(const float* __restrict__ dlog, const float* __restrict__ pre, int L, int B, int E, int H2,
+                                                             float* __restrict__ dw3) {
+  const int n = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
+  if (n >= H2) return;
+  float acc[EMAX];
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) acc[e] = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float h = gelu_erf_f(pre[((long)b * L + l) * H2 + n]);
+    const float* dl = dlog + ((long)l * B + b) * E;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e)
+      if (e < E) acc[e] = fmaf(dl[e], h, acc[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e)
+    if (e < E) dw3[((long)l * E + e) * H2 + n] = acc[e];
+}
+
+__global__ void iota_scale_kernel(int* out, int n, int step) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = i * step;
+}
+
 // Router backward on distinct conditioning rows (one thread per sample): dw[t,j] (j in ascending expert id) -> dlogits[b,:]
 // w = p[S]/sum(p[S]) (router_normalize) or p[S]; p = clamp(softmax(l), 1e-9, 1-1e-9)   (modedit.py:345-349, 398-399, 418-419)
 __global__ void router_bwd_kernel(const float* __restrict__ dw, const int* __restrict__ idx, const float* __restrict__ probs, int B, int T, int E,
@@ -319,10 +373,10 @@ extern "C" size_t mode_colsum_workspace_bytes(int rows, int cols, int nseg) {
 
 extern "C" int mode_colsum(const void* X, int64_t ld, int rows, int cols, int dtype, const int32_t* seg_offsets, int seg_len, int nseg,
                            float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!X || !out || !workspace || rows < 0 || cols <= 0) return MODE_ERR_BAD_ARG;
+  if (!X || !out || rows < 0 || cols <= 0) return MODE_ERR_BAD_ARG;
   if (nseg < 1) nseg = 1;
   const int nsplit = colsum_nsplit(rows, cols, nseg);
-  if (workspace_bytes < (size_t)nseg * nsplit * cols * 4) return MODE_ERR_WORKSPACE;
+  if (nsplit > 1 && (!workspace || workspace_bytes < (size_t)nseg * nsplit * cols * 4)) return MODE_ERR_WORKSPACE;   // single-stage sums need none
   float* partial = (float*)workspace;
   const dim3 grid((cols + 63) / 64, nsplit, nseg);
   hipStream_t s = (hipStream_t)stream;
@@ -480,6 +534,29 @@ extern "C" int mode_adamw_step(float* p, const float* g, float* m, float* v, int
   const int blocks = (int)std::min<long>((n4 + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, 1.f - lr * weight_decay, beta1, beta2, eps,
                      (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, (uint16_t*)lp_bf16);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_router_mlp_bwd(const float* dlog, const float* r_pre, const float* w3, int L, int B, int E, int H2, float* dpre, float* dw3,
+                                   void* stream) {
+  if (!dlog || !r_pre || !w3 || !dpre || !dw3 || L <= 0 || B <= 0 || E <= 0 || H2 <= 0) return MODE_ERR_BAD_ARG;
+  if (H2 % 4 || E > 16) return MODE_ERR_UNSUPPORTED;
+  const long total4 = (long)B * L * H2 / 4;
+  hipLaunchKernelGGL(router_mlp_dpre_kernel, dim3((total4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, dlog, r_pre, w3, L, B, E, H2, dpre);
+  MODE_LAUNCH_CHECK();
+  const dim3 grid((H2 + 255) / 256, L);
+  if (E <= 4) hipLaunchKernelGGL(router_w3_grad_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dlog, r_pre, L, B, E, H2, dw3);
+  else if (E <= 8) hipLaunchKernelGGL(router_w3_grad_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, dlog, r_pre, L, B, E, H2, dw3);
+  else hipLaunchKernelGGL(router_w3_grad_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, dlog, r_pre, L, B, E, H2, dw3);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_iota_i32(int32_t* out, int n, int step, void* stream) {
+  if (!out || n < 0) return MODE_ERR_BAD_ARG;
+  if (n == 0) return MODE_OK;
+  hipLaunchKernelGGL(iota_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, n, step);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }

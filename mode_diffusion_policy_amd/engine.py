@@ -139,7 +139,7 @@ class DitEngine:
         w = torch.empty(d.L, R, d.k, dtype=torch.float32, device=self.device)
         probs = torch.empty(d.L, R, d.E, dtype=torch.float32, device=self.device) if want_probs else None
         shifted = torch.empty(d.L, R, d.E, dtype=torch.float32, device=self.device) if want_probs else None
-        pre = torch.empty(d.L, R, 2 * d.D, dtype=torch.float32, device=self.device) if want_pre else None
+        pre = torch.empty(R, d.L, 2 * d.D, dtype=torch.float32, device=self.device) if want_pre else None      # [R][L][2D]
         ws, wsn = self.workspace(0, R)
         L.check(self.lib.mode_dit_route(C.byref(d), C.byref(self._mw), cond.data_ptr(), R, idx.data_ptr(), w.data_ptr(),
                                         _ptr(probs), _ptr(shifted), _ptr(pre), ws, wsn, _stream()), "route")

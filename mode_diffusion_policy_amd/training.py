@@ -38,8 +38,6 @@ class TrainState:
         D, E, A, Ly = m.embed_dim, m.num_experts, m.action_dim, m.num_layers
         keep: Dict[str, torch.Tensor] = {}
         layers = (L.ModeLayerWeightsT * Ly)()
-        keep["r_w0T"] = torch.empty(Ly, D, 2 * D, device=dev)
-        keep["r_w3T"] = torch.empty(Ly, 2 * D, E, device=dev)
         lp = eng.compute_dtype == "bf16"                        # bf16 backward GEMMs read the [out,in] weights directly (MODE_GEMM_W_KN)
         for i in range(Ly):
             k = f"l{i}."
@@ -50,11 +48,9 @@ class TrainState:
                 keep[k + "w1T"] = torch.empty(E, D, 8 * D, dtype=tdt, device=dev)
                 keep[k + "w2T"] = torch.empty(E, 4 * D, D, dtype=tdt, device=dev)
                 lt.wqkvT, lt.woT, lt.w1T, lt.w2T = (_ptr(keep[k + n]) for n in ("wqkvT", "woT", "w1T", "w2T"))
-            lt.r_w0T, lt.r_w3T = _ptr(keep["r_w0T"][i]), _ptr(keep["r_w3T"][i])
-        keep["w_slT"] = torch.empty(D, D, device=dev)
         keep["w_outT"] = torch.empty(D, A, device=dev)
         wt = L.ModeModelWeightsT()
-        wt.w_slT, wt.w_outT = _ptr(keep["w_slT"]), _ptr(keep["w_outT"])
+        wt.w_outT = _ptr(keep["w_outT"])
         wt.layers = C.cast(layers, C.POINTER(L.ModeLayerWeightsT))
         self.keep, self.layersT, self.wt = keep, layers, wt
         self.built_for = eng._structs_for
@@ -82,9 +78,6 @@ class TrainState:
                 for e in range(E):
                     tr(mat[k + "w1"][e], keep[k + "w1T"][e], 8 * D, D, dt)
                     tr(mat[k + "w2"][e], keep[k + "w2T"][e], D, 4 * D, dt)
-            tr(ar.w["r_w0"][i], keep["r_w0T"][i], 2 * D, D, L.MODE_F32)
-            tr(ar.w["r_w3"][i], keep["r_w3T"][i], E, 2 * D, L.MODE_F32)
-        tr(ar.w["w_sl"], keep["w_slT"], D, D, L.MODE_F32)
         tr(ar.w["w_out"], keep["w_outT"], A, D, L.MODE_F32)
         self.key = eng._wkey
 

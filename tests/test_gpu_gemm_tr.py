@@ -92,3 +92,34 @@ def test_wgrad_expert_segments(counts, gather):
         else:
             assert rel(Cc[e], ref) < 1e-5, e
         o += c
+
+
+@pytest.mark.parametrize("M,K,N", [(128, 2048, 1024), (70, 36, 52), (128, 24576, 256)])
+def test_f32_dgrad_layout(M, K, N):
+    """fp32 (router) data gradient straight from the [out, in] weight: C = A @ W with W row-major [K, N]."""
+    g = torch.Generator().manual_seed(K)
+    A = torch.randn(M, K, generator=g).cuda(); W = torch.randn(K, N, generator=g).cuda()
+    Cc = torch.full((M, N), float("nan"), device="cuda")
+    d = L.ModeGemmDesc(dtype=L.MODE_F32, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=M, N=N, K=K, A=p(A), lda=K, W=p(W), ldw=N, C=p(Cc), ldc=N,
+                       flags=L.GEMM_W_KN)
+    L.check(L.load().mode_gemm(C.byref(d), stream()), "f32 dgrad")
+    assert rel(Cc, A.double() @ W.double()) < (2e-6 if K <= 4096 else 3e-5)      # one k-ordered fp32 chain: error ~ sqrt(K) * 2^-24
+
+
+@pytest.mark.parametrize("R,M,N,groups", [(128, 2048, 1024, None), (77, 36, 52, None), (300, 64, 128, [0, 100, 100, 171, 300])])
+def test_f32_wgrad_layout(R, M, N, groups):
+    g = torch.Generator().manual_seed(R)
+    A = torch.randn(R, M, generator=g).cuda(); X = torch.randn(R, N, generator=g).cuda()
+    ng = len(groups) - 1 if groups else 1
+    Cc = torch.full((ng, M, N), float("nan"), device="cuda")
+    off = torch.tensor(groups, dtype=torch.int32).cuda() if groups else None
+    d = L.ModeGemmDesc(dtype=L.MODE_F32, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=M, N=N, K=R, A=p(A), lda=M, W=p(X), ldw=N, C=p(Cc), ldc=N,
+                       k_group_offsets=p(off), num_k_groups=ng if groups else 0, c_group_stride=M * N, flags=L.GEMM_W_KN | L.GEMM_A_KM)
+    L.check(L.load().mode_gemm(C.byref(d), stream()), "f32 wgrad")
+    gr = groups or [0, R]
+    for z in range(ng):
+        ref = A[gr[z]:gr[z + 1]].double().t() @ X[gr[z]:gr[z + 1]].double()
+        if gr[z] == gr[z + 1]:
+            assert float(Cc[z].abs().max()) == 0.0
+        else:
+            assert rel(Cc[z], ref) < 2e-6
