@@ -25,8 +25,7 @@ _ALIGN = 64                                   # elements (256 B of fp32, 128 B o
 
 
 def _layer_keys(D: int, E: int, hd: int):
-    decay = [("ln1_g", (D,)), ("ln2_g", (D,)), ("qn_g", (hd,)), ("kn_g", (hd,)), ("wqkv", (3 * D, D)), ("wo", (D, D)),
-             ("w1", (E, 8 * D, D)), ("w2", (E, D, 4 * D))]
+    decay = [("wqkv", (3 * D, D)), ("wo", (D, D)), ("w1", (E, 8 * D, D)), ("w2", (E, D, 4 * D))]
     no_decay = [("bqkv", (3 * D,)), ("b1", (E, 8 * D))]
     return decay, no_decay
 
@@ -36,7 +35,9 @@ def arena_layout(m) -> Tuple[List[Tuple[str, tuple, int]], Dict[str, int]]:
     D, E, L, A = m.embed_dim, m.num_experts, m.num_layers, m.action_dim
     hd = D // m.n_heads
     ld, lnd = _layer_keys(D, E, hd)
-    decay = [("r_w0", (L, 2 * D, D)), ("r_w3", (L, E, 2 * D))]
+    # small per-layer tensors are stacked over layers ([L, ...]): the router of every layer is routed / back-propagated as one batch and the
+    # norm-gain gradients of all layers are reduced by one segmented column sum each
+    decay = [("r_w0", (L, 2 * D, D)), ("r_w3", (L, E, 2 * D)), ("ln1_g", (L, D)), ("ln2_g", (L, D)), ("qn_g", (L, hd)), ("kn_g", (L, hd))]
     # per-layer blocks in BACKWARD order (last layer first) so gradient slices complete front-to-back during the backward pass
     for i in reversed(range(L)):
         decay += [(f"l{i}.{k}", s) for k, s in ld]
@@ -67,8 +68,8 @@ def param_views(m, g: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         "action_emb.weight": g["w_act"], "ln.g": g["ln_g"], "out.weight": g["w_out"], "out.bias": g["b_out"]}
     for i in range(m.num_layers):
         k, p = f"l{i}.", f"blocks.{i}."
-        v[p + "ln_1.g"], v[p + "ln_2.g"] = g[k + "ln1_g"], g[k + "ln2_g"]
-        v[p + "attn.q_norm.g"], v[p + "attn.k_norm.g"] = g[k + "qn_g"], g[k + "kn_g"]
+        v[p + "ln_1.g"], v[p + "ln_2.g"] = g["ln1_g"][i], g["ln2_g"][i]
+        v[p + "attn.q_norm.g"], v[p + "attn.k_norm.g"] = g["qn_g"][i], g["kn_g"][i]
         for j, nm in enumerate(("query", "key", "value")):                       # packed rows = [query; key; value]
             v[p + f"attn.{nm}.weight"] = g[k + "wqkv"][j * D:(j + 1) * D]
             v[p + f"attn.{nm}.bias"] = g[k + "bqkv"][j * D:(j + 1) * D]

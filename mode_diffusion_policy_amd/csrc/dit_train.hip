@@ -47,8 +47,8 @@ TrainWs train_ws(const ModeDims& d, int B, int dtype) {
   w.t_d = t(D * NKp * esz);                  // dY^T / u^T / dx1^T / h1^T  [D, NKp]
   w.t_d2 = t(D * NKp * esz);
   w.dx1lp = t(N * D * esz); w.dyattn = t(N * D * esz); w.dqkv = t(N * 3 * D * esz); w.dh1 = t(N * D * 4);
-  w.dgp = t(((N + 3) / 4) * D * 4);
-  w.apq = t((size_t)B * d.H * (D / d.H) * 4); w.apk = t((size_t)B * d.H * (D / d.H) * 4);
+  w.dgp = t(((N + 3) / 4) * D * 4 * (2 * (size_t)d.L + 1));            // per-block gain-gradient partials: ln_1 / ln_2 of every layer + final ln
+  w.apq = t((size_t)d.L * B * d.H * (D / d.H) * 4); w.apk = t((size_t)d.L * B * d.H * (D / d.H) * 4);   // q/k-norm gain partials of every layer
   size_t cs = mode_colsum_workspace_bytes((int)NK, 8 * d.D, d.E);
   const size_t c2 = mode_colsum_workspace_bytes((int)N, 3 * d.D, 1), c3 = mode_colsum_workspace_bytes((int)N, d.D, B);
   if (c2 > cs) cs = c2;
@@ -286,9 +286,11 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       if ((rc = mode_gemm(&g, stream))) return rc;
     }
     // (5) ln_2 backward: du = dx_out (residual from the normalised stream) + gather-sum of dU ; -> d x1
-    if ((rc = mode_rmsnorm_bwd((const float*)(S + sl.x1), lw.ln2_g, DXa, nullptr, dUs, pos, d.k, N, D, d.eps, DXb, 0, dgp, nullptr, dx1lp, dt, stream)))
+    float* dgp2 = dgp + (size_t)(1 + d.L + l) * nblk4 * D;                  // gain partials are reduced for all layers after the loop
+    float* dgp1 = dgp + (size_t)(1 + l) * nblk4 * D;
+    float* apq_l = apq + (size_t)l * B * D; float* apk_l = apk + (size_t)l * B * D;
+    if ((rc = mode_rmsnorm_bwd((const float*)(S + sl.x1), lw.ln2_g, DXa, nullptr, dUs, pos, d.k, N, D, d.eps, DXb, 0, dgp2, nullptr, dx1lp, dt, stream)))
       return rc;
-    if ((rc = colsum(dgp, D, nblk4, D, MODE_F32, nullptr, 0, 1, lg.ln2_g, 0))) return rc;
     // (6) c_proj: d yattn = dx1 Wo ; dWo = dx1^T yattn
     if (tr) {
       g = gdesc(dt, MODE_EPI_NONE, dt, N, D, D, dx1lp, D, lw.wo, D, dyattn, D);
@@ -307,10 +309,8 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       if ((rc = mode_gemm(&g, stream))) return rc;
     }
     // (7) attention backward
-    if ((rc = mode_attn_block_bwd(S + sl.qkv, lw.qn_g, lw.kn_g, dyattn, dqkv, apq, apk, dt, B, T, d.H, hd, d.eps, a->seed + 2 * l, a->attn_pdrop, stream)))
+    if ((rc = mode_attn_block_bwd(S + sl.qkv, lw.qn_g, lw.kn_g, dyattn, dqkv, apq_l, apk_l, dt, B, T, d.H, hd, d.eps, a->seed + 2 * l, a->attn_pdrop, stream)))
       return rc;
-    if ((rc = colsum(apq, hd, B * d.H, hd, MODE_F32, nullptr, 0, 1, lg.qn_g, 0))) return rc;
-    if ((rc = colsum(apk, hd, B * d.H, hd, MODE_F32, nullptr, 0, 1, lg.kn_g, 0))) return rc;
     // (8) QKV projection: dh1 = dqkv Wqkv ; dWqkv = dqkv^T h1 ; db = colsum(dqkv)
     if (tr) {
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, N, D, 3 * D, dqkv, 3 * D, lw.wqkv, D, dh1, D);
@@ -330,9 +330,8 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     }
     if ((rc = colsum(dqkv, 3 * D, N, 3 * D, dt, nullptr, 0, 1, lg.bqkv, 0))) return rc;
     // (9) ln_1 (+c) backward: d x0 = d x1 (residual) + RMSNorm'(dh1); dc_b += sum_t dh1[b,t]
-    if ((rc = mode_rmsnorm_bwd((const float*)(S + sl.x0), lw.ln1_g, dh1, nullptr, nullptr, nullptr, 0, N, D, d.eps, DXb, 1, dgp, nullptr, nullptr, MODE_F32,
+    if ((rc = mode_rmsnorm_bwd((const float*)(S + sl.x0), lw.ln1_g, dh1, nullptr, nullptr, nullptr, 0, N, D, d.eps, DXb, 1, dgp1, nullptr, nullptr, MODE_F32,
                                stream))) return rc;
-    if ((rc = colsum(dgp, D, nblk4, D, MODE_F32, nullptr, 0, 1, lg.ln1_g, 0))) return rc;
     if ((rc = colsum(dh1, D, N, D, MODE_F32, nullptr, T, B, dcond, 1))) return rc;
     // (10) router: only dlogits here (through renormalisation / clamp / softmax); the router MLPs of all layers are back-propagated
     //      in one batch after the loop
@@ -342,6 +341,26 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       if ((rc = mode_moe_router_bwd(dwt, idx, probs, B, T, E, d.k, d.router_normalize, a->idx_per_token, dlog + (long)l * B * E, stream))) return rc;
     }
     float* t_ = DXa; DXa = DXb; DXb = t_;                    // DXa now holds d x_l
+  }
+
+  // ---- RMSNorm gain gradients of all layers: one segmented column sum per kind when the gradient slots are layer-contiguous
+  {
+    const int Ly = d.L;
+    const ModeLayerGrads& g0 = gr->layers[0];
+    bool packed = true;
+    for (int l = 1; l < Ly; ++l) {
+      const ModeLayerGrads& gl = gr->layers[l];
+      packed = packed && gl.ln1_g == g0.ln1_g + (long)l * D && gl.ln2_g == g0.ln2_g + (long)l * D && gl.qn_g == g0.qn_g + (long)l * hd &&
+               gl.kn_g == g0.kn_g + (long)l * hd;
+    }
+    const int nb = packed ? 1 : Ly, lb = packed ? Ly : 1;
+    for (int i = 0; i < nb; ++i) {
+      const ModeLayerGrads& gi = gr->layers[i];
+      if ((rc = colsum(dgp + (size_t)(1 + i) * nblk4 * D, D, lb * nblk4, D, MODE_F32, nullptr, nblk4, lb, gi.ln1_g, 0))) return rc;
+      if ((rc = colsum(dgp + (size_t)(1 + Ly + i) * nblk4 * D, D, lb * nblk4, D, MODE_F32, nullptr, nblk4, lb, gi.ln2_g, 0))) return rc;
+      if ((rc = colsum(apq + (size_t)i * B * D, hd, lb * B * d.H, hd, MODE_F32, nullptr, B * d.H, lb, gi.qn_g, 0))) return rc;
+      if ((rc = colsum(apk + (size_t)i * B * D, hd, lb * B * d.H, hd, MODE_F32, nullptr, B * d.H, lb, gi.kn_g, 0))) return rc;
+    }
   }
 
   // ---- router MLPs of all layers in one batch (fp32).  r_pre / dpre are [B][L][2D]; weights and gradients [L][...] contiguous.

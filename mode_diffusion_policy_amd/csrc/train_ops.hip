@@ -498,28 +498,43 @@ extern "C" int mode_sigma_embed_bwd(const float* de1, const float* sigma, int B,
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     long n4, float decay, float b1, float b2, float eps, float step_size, float inv_bc2_sqrt,
                                                     float gscale, uint16_t* __restrict__ lp) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    float4 P = reinterpret_cast<float4*>(p)[i];
-    const float4 G = reinterpret_cast<const float4*>(g)[i];
-    float4 M = reinterpret_cast<float4*>(m)[i];
-    float4 V = reinterpret_cast<float4*>(v)[i];
-    float* pp = &P.x; const float* gg = &G.x; float* mm = &M.x; float* vv = &V.x;
+  // pure stream: every byte is touched once per step -> non-temporal accesses, two float4 groups in flight per thread and stream
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const long stride = (long)gridDim.x * 256;
+  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+    f4 P[2], G[2], M[2], V[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float gr = gg[j] * gscale;
-      float w = pp[j] * decay;
-      mm[j] = mm[j] + (gr - mm[j]) * (1.f - b1);
-      vv[j] = vv[j] * b2 + (1.f - b2) * gr * gr;
-      const float denom = sqrtf(vv[j]) * inv_bc2_sqrt + eps;
-      w -= step_size * (mm[j] / denom);
-      pp[j] = w;
+    for (int u = 0; u < 2; ++u) {
+      const long i = i0 + u * stride;
+      if (i < n4) {
+        P[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p) + i);
+        G[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(g) + i);
+        M[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(m) + i);
+        V[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(v) + i);
+      }
     }
-    reinterpret_cast<float4*>(p)[i] = P;
-    reinterpret_cast<float4*>(m)[i] = M;
-    reinterpret_cast<float4*>(v)[i] = V;
-    if (lp) {
-      uint2 o; o.x = pack_bf16x2(P.x, P.y); o.y = pack_bf16x2(P.z, P.w);
-      reinterpret_cast<uint2*>(lp)[i] = o;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long i = i0 + u * stride;
+      if (i >= n4) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gr = G[u][j] * gscale;
+        float w = P[u][j] * decay;
+        M[u][j] = M[u][j] + (gr - M[u][j]) * (1.f - b1);
+        V[u][j] = V[u][j] * b2 + (1.f - b2) * gr * gr;
+        const float denom = sqrtf(V[u][j]) * inv_bc2_sqrt + eps;
+        w -= step_size * (M[u][j] / denom);
+        P[u][j] = w;
+      }
+      __builtin_nontemporal_store(P[u], reinterpret_cast<f4*>(p) + i);
+      __builtin_nontemporal_store(M[u], reinterpret_cast<f4*>(m) + i);
+      __builtin_nontemporal_store(V[u], reinterpret_cast<f4*>(v) + i);
+      if (lp) {
+        u2 o; o[0] = pack_bf16x2(P[u][0], P[u][1]); o[1] = pack_bf16x2(P[u][2], P[u][3]);
+        *(reinterpret_cast<u2*>(lp) + i) = o;           // the bf16 shadow is re-read by the next forward: normal (cached) store
+      }
     }
   }
 }
@@ -531,7 +546,7 @@ extern "C" int mode_adamw_step(float* p, const float* g, float* m, float* v, int
     return MODE_ERR_BAD_ARG;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const long n4 = n / 4;
-  const int blocks = (int)std::min<long>((n4 + 255) / 256, 256 * 16);
+  const int blocks = (int)std::min<long>((n4 + 511) / 512, 256 * 8);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, 1.f - lr * weight_decay, beta1, beta2, eps,
                      (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, (uint16_t*)lp_bf16);
   MODE_LAUNCH_CHECK();

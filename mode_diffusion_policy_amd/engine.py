@@ -86,7 +86,7 @@ class DitEngine:
         for i in range(m.num_layers):
             k = f"l{i}."
             lw = layers[i]
-            lw.ln1_g, lw.ln2_g, lw.qn_g, lw.kn_g = (_ptr(w[k + n]) for n in ("ln1_g", "ln2_g", "qn_g", "kn_g"))
+            lw.ln1_g, lw.ln2_g, lw.qn_g, lw.kn_g = (_ptr(w[n][i]) for n in ("ln1_g", "ln2_g", "qn_g", "kn_g"))
             lw.wqkv, lw.bqkv, lw.wo = _ptr(mat[k + "wqkv"]), _ptr(w[k + "bqkv"]), _ptr(mat[k + "wo"])
             lw.r_w0, lw.r_b0, lw.r_w3, lw.r_b3 = _ptr(w["r_w0"][i]), _ptr(w["r_b0"][i]), _ptr(w["r_w3"][i]), _ptr(w["r_b3"][i])
             lw.w1, lw.b1, lw.w2 = _ptr(mat[k + "w1"]), _ptr(w[k + "b1"]), _ptr(mat[k + "w2"])

@@ -92,7 +92,7 @@ class TrainState:
             lgr = (L.ModeLayerGrads * m.num_layers)()
             for i in range(m.num_layers):
                 for fld, _ in L.ModeLayerGrads._fields_:
-                    t = g[fld][i] if fld.startswith("r_") else g[f"l{i}.{fld}"]
+                    t = g[fld][i] if fld in g else g[f"l{i}.{fld}"]          # routers / norm gains are stacked over layers
                     setattr(lgr[i], fld, t.data_ptr())
             mg = L.ModeModelGrads()
             for fld in ("pos", "w_se", "b_se", "w_sl", "w_tok", "w_goal", "w_act", "ln_g", "w_out", "b_out"):
