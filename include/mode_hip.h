@@ -380,6 +380,10 @@ typedef struct ModeTrainArgs {
   const float* probs;            /* [L, B, E] clamped softmax of the router                  */
   const float* r_pre;            /* [B, L, 2D] router pre-GELU activations (mode_dit_route)  */
   float* F;                      /* out: [B, A_len, A]                                       */
+  void* const* layer_events;     /* optional hipEvent_t[L] (backward only): event l is recorded on the stream as soon as ALL weight
+                                    gradients of block l (wqkv, bqkv, wo, w1, b1, w2) are written — blocks finish in the order L-1 … 0,
+                                    so a data-parallel reducer can exchange block l's gradient slice while earlier blocks are still
+                                    back-propagating (replaces DDP's autograd-hook bucketing, mode/training_calvin.py:92-103) */
 } ModeTrainArgs;
 int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes,
                            void* stream);

@@ -81,7 +81,7 @@ class ModeTrainArgs(C.Structure):
                 ("emb_t", c_vp), ("cond", c_vp), ("goal_in_cond", c_i32), ("state_images", c_vp), ("goals", c_vp), ("goal_e", c_vp),
                 ("img_e", c_vp), ("actions", c_vp), ("c_in", c_vp), ("c_in_stride", c_i64), ("actions_scaled", c_vp), ("act_rows", c_vp),
                 ("meta", c_vp), ("meta_layer_stride", c_i64), ("topk_idx", c_vp), ("topk_layer_stride", c_i64), ("idx_per_token", c_i32),
-                ("probs", c_vp), ("r_pre", c_vp), ("F", c_vp)]
+                ("probs", c_vp), ("r_pre", c_vp), ("F", c_vp), ("layer_events", c_vp)]
 
 
 class ModeLayerGrads(C.Structure):

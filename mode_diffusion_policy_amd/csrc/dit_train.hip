@@ -340,6 +340,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       const int32_t* idx = a->topk_idx + (long)l * a->topk_layer_stride;
       if ((rc = mode_moe_router_bwd(dwt, idx, probs, B, T, E, d.k, d.router_normalize, a->idx_per_token, dlog + (long)l * B * E, stream))) return rc;
     }
+    if (a->layer_events && a->layer_events[l] && hipEventRecord((hipEvent_t)a->layer_events[l], hs) != hipSuccess) return (int)hipGetLastError();
     float* t_ = DXa; DXa = DXb; DXb = t_;                    // DXa now holds d x_l
   }
 

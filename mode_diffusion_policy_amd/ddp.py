@@ -170,8 +170,8 @@ class ArenaGradReducer:
 
     The backward chain writes gradients straight into the arena in backward order (per-layer slices, last layer first), so the
     exchange is a handful of large collectives over static flat slices — no bucket copies at all.  ``reduce()`` is called once after
-    ``loss.backward()``; slices are issued in arena order on a side stream so the collective of slice i overlaps the mean / copy
-    epilogue of slice i-1.  The SUM is left in place; the division by ``world`` is folded into ``FusedAdamW.step(grad_scale=1/world)``
+    ``loss.backward()`` returns (the backward kernels are still running): every block's slice is queued on a side stream behind the
+    event the backward chain records when that block's gradients are complete, so communication overlaps the rest of the backward.  The SUM is left in place; the division by ``world`` is folded into ``FusedAdamW.step(grad_scale=1/world)``
     (or applied here with ``average=True`` for foreign optimizers).  xGMI is point-to-point: slices of ``slice_mb`` (default 256 MB,
     ~ one transformer block) keep each ring step large enough to run at link rate.
     """
@@ -196,23 +196,47 @@ class ArenaGradReducer:
         self._comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
 
     @classmethod
-    def for_model(cls, model, **kw) -> "ArenaGradReducer":
-        ar = model.engine.arena
+    def for_model(cls, model, overlap: bool = True, **kw) -> "ArenaGradReducer":
+        """Reducer over the model's gradient arena.  With ``overlap`` the slices follow the arena's per-block layout (blocks are stored in
+        backward order) and each block slice waits only on the event the backward chain records when that block's gradients are complete,
+        so its collective runs while the earlier blocks are still back-propagating."""
+        eng = model.engine
+        ar = eng.arena
         ar.ensure_grad(model)
-        return cls(ar.grad, ar.bounds["no_decay"], **kw)
+        red = cls(ar.grad, ar.bounds["no_decay"], **kw)
+        if overlap and ar.grad.device.type == "cuda":
+            from .training import TrainState
+            if getattr(eng, "_train", None) is None:
+                eng._train = TrainState(eng)
+            eng._train.layer_events()
+            evs = eng._train.events
+            L = model.num_layers
+            starts = [ar.offset(f"l{i}.wqkv") for i in range(L)]
+            first, last_end = starts[L - 1], ar.offset("pos")                   # blocks are laid out L-1 ... 0, then the embeddings
+            bounds = sorted(starts) + [last_end]
+            block = {lo: hi for lo, hi in zip(bounds[:-1], bounds[1:])}
+            red.slices = [(starts[i], block[starts[i]], evs[i]) for i in reversed(range(L))]
+            red.slices += [(0, first, None), (last_end, ar.bounds["no_decay"], None)]   # stacked routers / gains; embeddings, head, biases
+        return red
 
     def reduce(self) -> float:
-        """Sum (or average) the gradient arena over ranks; returns the scale the optimizer still has to apply."""
+        """Sum (or average) the gradient arena over ranks; returns the scale the optimizer still has to apply.  Call right after
+        ``loss.backward()`` returned: the backward kernels are still executing, the collectives queue up behind their events."""
         if self.world == 1:
             return 1.0
-        if self._comm_stream is not None:
-            self._comm_stream.wait_stream(torch.cuda.current_stream())
-            ctx = torch.cuda.stream(self._comm_stream)
-        else:
-            from contextlib import nullcontext
-            ctx = nullcontext()
-        with ctx:
-            for lo, hi in self.slices:
+        cur = torch.cuda.current_stream() if self._comm_stream is not None else None
+        for sl in self.slices:
+            lo, hi, ev = sl if len(sl) == 3 else (sl[0], sl[1], None)
+            if self._comm_stream is not None:
+                if ev is not None:
+                    self._comm_stream.wait_event(ev)
+                else:
+                    self._comm_stream.wait_stream(cur)
+                ctx = torch.cuda.stream(self._comm_stream)
+            else:
+                from contextlib import nullcontext
+                ctx = nullcontext()
+            with ctx:
                 g = self.grad[lo:hi]
                 if self.mode == "rs_ag" and (hi - lo) % self.world == 0:
                     shard = g.view(self.world, -1)[dist.get_rank(self.pg)]
@@ -223,7 +247,7 @@ class ArenaGradReducer:
                 if self.average:
                     g.div_(self.world)
         if self._comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
+            cur.wait_stream(self._comm_stream)
         return 1.0 if self.average else 1.0 / self.world
 
 

@@ -31,6 +31,8 @@ class TrainState:
         self.built_for = None
         self.grads_for = None
         self._ws = None
+        self.events = None                 # one event per block: "all weight gradients of block l are written" (data-parallel overlap)
+        self._ev_arr = None
 
     def _build(self) -> None:
         eng = self.eng
@@ -80,6 +82,16 @@ class TrainState:
                     tr(mat[k + "w2"][e], keep[k + "w2T"][e], D, 4 * D, dt)
         tr(ar.w["w_out"], keep["w_outT"], A, D, L.MODE_F32)
         self.key = eng._wkey
+
+    def layer_events(self):
+        """hipEvent handles the backward chain records after each block (created once; see ModeTrainArgs.layer_events)."""
+        if self.events is None:
+            n = self.eng.model.num_layers
+            self.events = [torch.cuda.Event() for _ in range(n)]
+            for ev in self.events:
+                ev.record()                                                     # forces creation of the underlying hipEvent
+            self._ev_arr = (C.c_void_p * n)(*[ev.cuda_event for ev in self.events])
+        return C.cast(self._ev_arr, C.c_void_p)
 
     def grad_tables(self):
         """ctypes tables pointing the backward chain at the gradient arena (built once per arena)."""
@@ -179,7 +191,7 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
                            goal_e=goal_e.data_ptr(), img_e=img_e.data_ptr(), actions=acts.data_ptr(), c_in=None, c_in_stride=0,
                            actions_scaled=acts.data_ptr(), act_rows=act_rows.data_ptr(), meta=meta.data_ptr(), meta_layer_stride=ml.total_words,
                            topk_idx=idx.data_ptr(), topk_layer_stride=idx.stride(0), idx_per_token=per_tok, probs=probs.data_ptr(),
-                           r_pre=r_pre.data_ptr(), F=F.data_ptr())
+                           r_pre=r_pre.data_ptr(), F=F.data_ptr(), layer_events=ts.layer_events())
     L.check(lib.mode_dit_forward_train(C.byref(d), C.byref(eng._mw), C.byref(args), stash.data_ptr(), stash.numel(), _stream()), "forward_train")
 
     # ---- reference side channels (training only, modedit.py:584-593, 816-820); values for logging, no graph

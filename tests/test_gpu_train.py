@@ -156,3 +156,41 @@ def test_fused_adamw_matches_torch_adamw(dtype):
     # the loss keeps moving: the next forward reads the updated weights (transposed shadows refreshed as well)
     l2, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
     assert float(l2) != float(loss)
+
+
+def test_arena_reducer_overlap_slices_and_events():
+    """Data-parallel exchange on the gradient arena (ddp.ArenaGradReducer): per-block slices in backward order, each gated by the event the
+    backward chain records for that block; the slices tile the optimised part of the arena exactly once.  Runs the real stream / event /
+    RCCL code path on one GPU (process group of size 1; the reducer is told it has 2 ranks so it does not short-circuit)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from mode_diffusion_policy_amd.ddp import ArenaGradReducer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        cfg, sd, m = build_train("c1e4", 31, "bf16")
+        inp = {k: v.cuda() for k, v in make_inputs(cfg, 8, 3).items()}
+        den = M.GCDenoiser(m, 0.5).train()
+        sig = torch.full((8,), 0.9, device="cuda")
+        red = ArenaGradReducer.for_model(m)
+        ar = m.engine.arena
+        cover = sorted((lo, hi) for lo, hi, _ in red.slices)
+        assert cover[0][0] == 0 and cover[-1][1] == ar.bounds["no_decay"]
+        assert all(a[1] == b[0] for a, b in zip(cover[:-1], cover[1:]))                   # contiguous, no overlap, nothing missing
+        evs = [ev for _, _, ev in red.slices]
+        assert sum(e is not None for e in evs) == cfg.n_layers and evs[0] is not None      # block L-1 first: it finishes first
+        assert red.slices[0][0] == ar.offset(f"l{cfg.n_layers - 1}.wqkv")
+        loss, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
+        loss.backward()
+        red.world = 2                                                                       # exercise the collective path
+        scale = red.reduce()
+        torch.cuda.synchronize()
+        want = ar.grad.clone()
+        loss, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert scale == 0.5 and torch.equal(ar.grad, want)                                  # sum over the single rank = identity, deterministic backward
+    finally:
+        dist.destroy_process_group()
