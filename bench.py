@@ -228,7 +228,18 @@ def main():
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:       # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        # RCCL prints a version banner to STDOUT when the communicator comes up; keep stdout = the one JSON line of the contract
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=device)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     if args.mode == "train":
         return train_bench(args, world, rank, device, dist)
