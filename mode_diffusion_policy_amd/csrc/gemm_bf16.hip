@@ -73,7 +73,7 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16>
-__global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (NS == 1 ? 3 : 2))) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;         // 1-KiB DMA pieces (8 rows x 128 B) per wave per operand tile
@@ -218,6 +218,20 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
       if (kt + NS - 1 < nk) stage((slot + NS - 1) % NS, kt0 + kt + NS - 1);   // refill the slot tile kt-1 just vacated
     }
     const uint32_t so = slot * STAGE_BYTES;
+    if constexpr (NW >= 16) {
+      // 16 waves share one 256x256 tile (4 per SIMD, <= 128 VGPRs each): one k32 half of fragments at a time; the LDS round trip of a
+      // wave is covered by the MFMAs of the three other waves on its SIMD
+      read_frags(fa0, fb0, so, c0);
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(fa0, fb0, so, c1);
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     read_frags(fa0, fb0, so, c0);
     read_frags(fa1, fb1, so, c1);
     wait_lgkmcnt<FM + FN>();                                       // first half arrived, second half still in flight
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
     __builtin_amdgcn_sched_barrier(0);
     mma(fa1, fb1);
     __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (NS == 1) {
       if (kt + 1 < nk) {
         __builtin_amdgcn_s_barrier();                              // single buffer: every wave is done reading before the refill
@@ -318,7 +333,8 @@ __global__ __launch_bounds__(WM* WN * 64, (NS == 1 ? 3 : 2)) void gemm_bf16_kern
 // ------------------------------------------------------------------------------------------------------------ host side
 // geometry ids (also the values of the "gemm_cfg" option; 0 = auto)
 enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x128_NS3 = 2, CFG_256x128_NS3 = 3, CFG_128x64_NS3 = 4, CFG_128x64_NS4 = 5,
-       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10 };
+       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10, CFG_256x256_W16 = 11, CFG_P256 = 12 };
+int gemm_bf16_p256_launch(const ModeGemmDesc* d, hipStream_t s);   // gemm_bf16_p256.hip: persistent 256x256 with cross-tile operand prefetch
 int g_gemm_cfg = CFG_AUTO;
 
 template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16>
@@ -353,6 +369,7 @@ static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipSt
     case CFG_128x64_NS2: return launch_cfg<128, 64, 2, 2, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_256x256_NS2: return launch_cfg<256, 256, 2, 4, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_256x128_NS2: return launch_cfg<256, 128, 4, 2, 2, EPI, OUT_BF16>(p, d, s);
+    case CFG_256x256_W16: return launch_cfg<256, 256, 4, 4, 2, EPI, OUT_BF16>(p, d, s);
     default: return MODE_ERR_BAD_ARG;
   }
 }
@@ -391,6 +408,10 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.koffs = d->k_group_offsets; p.c_gstride = d->c_group_stride;
   if (p.koffs && (d->num_k_groups <= 0 || p.split_k > 1 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
   const int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d);
+  if (cfg == CFG_P256) {
+    if (p.split_k > 1 || p.koffs) return MODE_ERR_UNSUPPORTED;
+    return gemm_bf16_p256_launch(d, s);
+  }
   const bool ob = d->out_dtype == MODE_BF16;
 #define MODE_CASE(E) \
   case E: return ob ? launch_epi<E, true>(p, d, cfg, s) : launch_epi<E, false>(p, d, cfg, s);

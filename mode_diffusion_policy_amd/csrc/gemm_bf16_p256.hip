@@ -1,0 +1,347 @@
+// Persistent 256x256 bf16 MFMA GEMM for gfx950 (forward layout: C[M,N] = epilogue(A[M,K] @ W[N,K]^T), plain / gathered / grouped).
+//
+// Why a second forward kernel: a K-sweep of gemm_bf16.hip on the expert up-projection (M=3584, N=2x4096, K=1024) shows that the 256x256
+// tile has the better per-K-step slope (2.77 us vs 3.43 us per 64-deep K-step over the whole grid: half the L2->LDS bytes per flop,
+// the L2->LDS fill of a 128x128 tile alone takes longer than its MFMAs) but twice the fixed cost per output tile (22.6 us vs 11.7 us:
+// with one 128-KiB workgroup per CU nothing overlaps a tile's first-fill latency and its epilogue).  With K = 1024 (16 K-steps) the fixed
+// part decides.  This kernel removes it: one PERSISTENT workgroup per CU walks its output tiles, and the operand stream never stops —
+// while a tile's epilogue (bias / SwiGLU / LDS transpose / stores) runs out of one ring slot, the first K-tile of the NEXT output tile
+// is already landing in the other slot (global_load_lds, counted in the same vmcnt stream).
+//
+// Geometry: 8 wave64 (2 x 4), wave tile 128 x 64 (8 x 4 accumulators of v_mfma_f32_16x16x32_bf16), BK = 64, 2-slot ring of 64 KiB.  LDS
+// image, fragment addressing, swapped MFMA operands and the epilogue are those of gemm_bf16.hip; the output tile goes through the slot
+// the last K-tile just vacated, in passes of 64 KiB.
+#include "mode_common.h"
+#include <type_traits>
+
+namespace mode {
+
+struct GemmParams {   // identical to gemm_bf16.hip's
+  const uint16_t* A; long lda;
+  const uint16_t* W; long ldw; long w_estride;
+  const float* bias; long bias_estride;
+  const float* resid; long ldr;
+  void* C; long ldc;
+  const int* a_rows; const int* offsets; int E;
+  int M, N, K, m_tiles, n_tiles;
+  int split_k; long split_stride;
+  const int* koffs; long c_gstride;
+};
+
+template <int N>
+__device__ __forceinline__ void p_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N>
+__device__ __forceinline__ void p_wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ void p_lds_read128(bf16x8& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int STRIDE, int CNT, int I = 0>
+__device__ __forceinline__ void p_lds_read_seq(bf16x8* dst, uint32_t addr) {
+  if constexpr (I < CNT) {
+    p_lds_read128<I * STRIDE>(dst[I], addr);
+    p_lds_read_seq<STRIDE, CNT, I + 1>(dst, addr);
+  }
+}
+
+template <int EPI, bool OUT_BF16>
+__global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, BKK = 64, WM = 2, WN = 4, NW = 8, NT = 512;
+  constexpr int TM = 128, TN = 64, FM = 8, FN = 4;
+  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;           // 4 + 4 one-KiB DMA pieces per wave per K-tile
+  constexpr int A_BYTES = BM * BKK * 2, STAGE_BYTES = (BM + BN) * BKK * 2;
+  constexpr int GROUP_M = 4;
+  constexpr int NOUT = (EPI == MODE_EPI_SWIGLU) ? BN / 2 : BN;
+  constexpr int ESZ = OUT_BF16 ? 2 : 4;
+  constexpr int CROW = NOUT * ESZ, CPR = CROW / 16, CSWZ = (CPR < 16 ? CPR : 16) - 1;
+  constexpr int RP = STAGE_BYTES / CROW < BM ? STAGE_BYTES / CROW : BM;      // output rows per epilogue pass (one ring slot)
+  constexpr int EPASS = BM / RP;
+  static_assert(RP % 16 == 0 && BM % RP == 0, "epilogue passes must split the tile into whole fragment rows");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nblk = p.m_tiles * p.n_tiles;
+  const int nk = p.K / BKK;
+
+  // ---- output tile -> (rows, expert, columns)
+  struct Tile { int row0, row_end, expert, n0; };
+  auto map_tile = [&](int vb, Tile& t) -> bool {
+    if (vb >= nblk) return false;
+    const int sb = xcd_remap(vb, nblk);
+    const int per_group = GROUP_M * p.n_tiles;
+    const int grp = sb / per_group, first_m = grp * GROUP_M;
+    const int gsz = min(p.m_tiles - first_m, GROUP_M);
+    const int rem = sb - grp * per_group;
+    const int mt = first_m + rem % gsz, nt = rem / gsz;
+    t.expert = 0;
+    if (p.offsets) {
+      int tt = mt;
+      bool found = false;
+      for (int e = 0; e < p.E && !found; ++e) {
+        const int o0 = p.offsets[e], o1 = p.offsets[e + 1];
+        const int nt_e = (o1 - o0 + BM - 1) / BM;
+        if (tt < nt_e) { t.row0 = o0 + tt * BM; t.row_end = min(o1, t.row0 + BM); t.expert = e; found = true; }
+        else tt -= nt_e;
+      }
+      if (!found) return false;
+    } else {
+      t.row0 = mt * BM; t.row_end = min(p.M, t.row0 + BM);
+    }
+    t.n0 = nt * NOUT;
+    return true;
+  };
+  auto next_valid = [&](int vb, Tile& t) -> int {          // first valid tile at or after vb in this workgroup's stride sequence
+    while (vb < nblk && !map_tile(vb, t)) vb += gridDim.x;
+    return vb;
+  };
+
+  // ---- per-thread DMA sources of a tile: lane i -> row (i>>3) of an 8-row piece, physical 16-B chunk (i&7), logical chunk (i&7)^(i>>3)
+  const int r8 = lane >> 3, lchunk = (lane & 7) ^ r8;
+  // Sources are kept as 32-bit BYTE offsets from the (uniform) operand bases: half the address registers of 64-bit pointers — the
+  // kernel lives at the 256-VGPR limit (128 accumulators + 96 fragment registers).  Host side guarantees the operands span < 4 GiB.
+  auto make_src = [&](const Tile& t, uint32_t* a_off, uint32_t* b_off) {
+    const long wbase = (long)t.expert * p.w_estride;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int tr = (wave * PA + q) * 8 + r8;
+      const int s = min(t.row0 + tr, t.row_end - 1);
+      const long arow = p.a_rows ? (long)p.a_rows[s] : (long)s;
+      a_off[q] = (uint32_t)((arow * p.lda + lchunk * 8) * 2);
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int tr = (wave * PB + q) * 8 + r8;
+      long brow;
+      if constexpr (EPI == MODE_EPI_SWIGLU) brow = (long)min(t.n0 + (tr % (BN / 2)), p.N - 1) + ((tr >= BN / 2) ? p.N : 0);
+      else brow = min(t.n0 + tr, p.N - 1);
+      b_off[q] = (uint32_t)((wbase + brow * p.ldw + lchunk * 8) * 2);
+    }
+  };
+  auto stage = [&](int slot, int kt, const uint32_t* a_off, const uint32_t* b_off) {
+    char* base = smem + slot * STAGE_BYTES;
+    const uint32_t koff = kt * BKK * 2;
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+#pragma unroll
+    for (int q = 0; q < PA; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ab + (size_t)(a_off[q] + koff)),
+                                       (__attribute__((address_space(3))) void*)(base + (wave * PA + q) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wb + (size_t)(b_off[q] + koff)),
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave * PB + q) * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment addressing (as gemm_bf16.hip)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = fr & 7;
+  const int c0 = (fq ^ sw) * 16, c1 = ((fq + 4) ^ sw) * 16;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t a_base = lds0 + (wm * TM + fr) * 128;
+  constexpr int BJ = (EPI == MODE_EPI_SWIGLU) ? FN / 2 : FN;
+  const uint32_t b_base = lds0 + A_BYTES + ((EPI == MODE_EPI_SWIGLU ? wn * (TN / 2) : wn * TN) + fr) * 128;
+
+  Tile cur, nxt;
+  int vb = next_valid(blockIdx.x, cur);
+  if (vb >= nblk) return;
+  uint32_t a_src[PA], b_src[PB], na_src[PA], nb_src[PB];
+  make_src(cur, a_src, b_src);
+  stage(0, 0, a_src, b_src);                                  // K-tile 0 of the first output tile
+  int slot = 0;
+
+  while (true) {
+    const int nvb = next_valid(vb + gridDim.x, nxt);
+    const bool has_next = nvb < nblk;
+    if (has_next) make_src(nxt, na_src, nb_src);              // gather indices / pointers resolved long before they are needed
+    const float* bias = p.bias ? p.bias + (long)cur.expert * p.bias_estride : nullptr;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      // everything this wave issued so far has landed: K-tile kt (and, on a tile's first K-step, the previous tile's output stores,
+      // which share the vmcnt stream)
+      p_wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                            // K-tile kt visible to all waves; the other slot is free
+      if (kt + 1 < nk) stage(slot ^ 1, kt + 1, a_src, b_src);
+      else if (has_next) stage(slot ^ 1, 0, na_src, nb_src);   // the operand stream continues into the next output tile
+      const uint32_t so = slot * STAGE_BYTES;
+      // Four 16-MFMA batches per K-tile: (k32 half, 64-row half of the wave tile).  Fragments are double-buffered per batch (2 x 4 A
+      // + 2 x 4 B registers-quads = 64 VGPRs instead of 96 for a whole K-tile), every batch's LDS reads are issued one batch ahead.
+      bf16x8 fa[2][4], fb[2][FN];
+      auto read_a = [&](bf16x8* dst, int mh, uint32_t co) { p_lds_read_seq<2048, 4>(dst, a_base + so + mh * (64 * 128) + co); };
+      auto read_b = [&](bf16x8* dst, uint32_t co) {
+        p_lds_read_seq<2048, BJ>(dst, b_base + so + co);
+        if constexpr (EPI == MODE_EPI_SWIGLU) p_lds_read_seq<2048, BJ>(dst + BJ, b_base + so + co + (BN / 2) * 128);
+      };
+      auto mma = [&](const bf16x8* a, const bf16x8* b, auto MH) {
+        constexpr int mh = decltype(MH)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[mh * 4 + i][j], 0, 0, 0);   // swapped: D[n][m]
+      };
+      read_a(fa[0], 0, c0); read_b(fb[0], c0);                 // batch 0 operands (8 reads)
+      read_a(fa[1], 1, c0);                                    // batch 1 (4)
+      p_wait_lgkmcnt<4>();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(fa[0], fb[0], std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(fa[0], 0, c1); read_b(fb[1], c1);                 // batch 2 (8): A set 0 was consumed by batch 0
+      p_wait_lgkmcnt<8>();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(fa[1], fb[0], std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(fa[1], 1, c1);                                    // batch 3 (4)
+      p_wait_lgkmcnt<4>();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(fa[0], fb[1], std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      p_wait_lgkmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(fa[1], fb[1], std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      slot ^= 1;
+    }
+
+    // ---- epilogue through the slot the last K-tile occupied (slot ^ 1 after the loop); `slot` is receiving the next tile's K-tile 0
+    char* cbuf = smem + (slot ^ 1) * STAGE_BYTES;
+    char* Cout = reinterpret_cast<char*>(p.C);
+    const int rows_valid = cur.row_end - cur.row0;
+    const int n0 = cur.n0;
+#pragma unroll 1
+    for (int g = 0; g < EPASS; ++g) {
+      __builtin_amdgcn_s_barrier();                            // all waves are done with the slot (operand reads / previous pass)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int rt = wm * TM + i * 16;                       // first tile row of this fragment row
+        if (rt / RP != g) continue;
+        const int rl = rt % RP + fr;
+        char* crow = cbuf + rl * CROW;
+        const int rsw = rl & CSWZ;
+        auto cpos = [&](int nl) { const int b = nl * ESZ; return crow + ((((b >> 4) ^ rsw) << 4) | (b & 15)); };
+        if constexpr (EPI == MODE_EPI_SWIGLU) {
+#pragma unroll
+          for (int j = 0; j < FN / 2; ++j) {
+            const int nl = wn * (TN / 2) + j * 16 + fq * 4;
+            const int n = min(n0 + nl, p.N - 4);
+            const float4 bp = *reinterpret_cast<const float4*>(bias + n);
+            const float4 bg = *reinterpret_cast<const float4*>(bias + p.N + n);
+            const f32x4 v = acc[i][j], gt = acc[i][j + FN / 2];
+            const float o0 = (v[0] + bp.x) * silu_f(gt[0] + bg.x), o1 = (v[1] + bp.y) * silu_f(gt[1] + bg.y);
+            const float o2 = (v[2] + bp.z) * silu_f(gt[2] + bg.z), o3 = (v[3] + bp.w) * silu_f(gt[3] + bg.w);
+            if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(cpos(nl)) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+            else *reinterpret_cast<float4*>(cpos(nl)) = make_float4(o0, o1, o2, o3);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const int nl = wn * TN + j * 16 + fq * 4;
+            f32x4 v = acc[i][j];
+            if constexpr (EPI == MODE_EPI_BIAS || EPI == MODE_EPI_BIAS_GELU) {
+              const float4 b = *reinterpret_cast<const float4*>(bias + min(n0 + nl, p.N - 4));
+              v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+              if constexpr (EPI == MODE_EPI_BIAS_GELU) {
+                v[0] = gelu_erf_f(v[0]); v[1] = gelu_erf_f(v[1]); v[2] = gelu_erf_f(v[2]); v[3] = gelu_erf_f(v[3]);
+              }
+            }
+            if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(cpos(nl)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            else *reinterpret_cast<float4*>(cpos(nl)) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      constexpr int EPC = 16 / ESZ;
+      for (int c = tid; c < RP * CPR; c += NT) {
+        const int rl = c / CPR, ch = c % CPR;
+        const int ml = g * RP + rl;
+        const int n = n0 + ch * EPC;
+        if (ml >= rows_valid || n >= p.N) continue;
+        const long m = cur.row0 + ml;
+        uint4 v = *reinterpret_cast<const uint4*>(cbuf + rl * CROW + ((ch ^ (rl & CSWZ)) << 4));
+        if constexpr (EPI == MODE_EPI_RESIDUAL && !OUT_BF16) {
+          const float4 r = *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n);
+          float4 f = *reinterpret_cast<float4*>(&v);
+          f.x += r.x; f.y += r.y; f.z += r.z; f.w += r.w;
+          v = *reinterpret_cast<uint4*>(&f);
+        }
+        if constexpr (OUT_BF16) {
+          if (n + 8 <= p.N) *reinterpret_cast<uint4*>(Cout + (m * p.ldc + n) * 2) = v;
+          else *reinterpret_cast<uint2*>(Cout + (m * p.ldc + n) * 2) = make_uint2(v.x, v.y);
+        } else {
+          *reinterpret_cast<uint4*>(Cout + (m * p.ldc + n) * 4) = v;
+        }
+      }
+    }
+    if (!has_next) break;
+    cur = nxt; vb = nvb;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) a_src[q] = na_src[q];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) b_src[q] = nb_src[q];
+  }
+}
+
+template <int EPI, bool OUT_BF16>
+static int p256_launch(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
+  constexpr int NOUT = (EPI == MODE_EPI_SWIGLU) ? 128 : 256;
+  p.n_tiles = (d->N + NOUT - 1) / NOUT;
+  p.m_tiles = (d->M + 255) / 256 + (d->expert_offsets ? d->num_experts : 0);
+  const int nblk = p.m_tiles * p.n_tiles;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int grid = nblk < ncu ? nblk : ncu;                    // one persistent workgroup per CU (128 KiB of LDS each)
+  constexpr size_t LDS = 2 * (256 + 256) * 64 * 2;
+  auto kern = gemm_p256_kernel<EPI, OUT_BF16>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, p);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+// entered from gemm_bf16_launch (cfg 12 / heuristic) with an already validated descriptor
+int gemm_bf16_p256_launch(const ModeGemmDesc* d, hipStream_t s) {
+  if (d->split_k > 1 || d->k_group_offsets || d->K % 64) return MODE_ERR_UNSUPPORTED;
+  const long rows_a = d->a_rows ? (1L << 20) : d->M;          // gathered rows: bounded by the caller's token count (checked below via lda)
+  const long wrows = (d->epilogue == MODE_EPI_SWIGLU ? 2L : 1L) * d->N;
+  const long wspan = ((d->expert_offsets ? (long)(d->num_experts - 1) * d->w_expert_stride : 0) + wrows * d->ldw) * 2;
+  if (wspan >= (1L << 32) || rows_a * d->lda * 2 >= (1L << 32)) return MODE_ERR_UNSUPPORTED;
+  GemmParams p;
+  p.A = (const uint16_t*)d->A; p.lda = d->lda;
+  p.W = (const uint16_t*)d->W; p.ldw = d->ldw; p.w_estride = d->w_expert_stride;
+  p.bias = d->bias; p.bias_estride = d->bias_expert_stride;
+  p.resid = d->resid; p.ldr = d->ldr; p.C = d->C; p.ldc = d->ldc;
+  p.a_rows = d->a_rows; p.offsets = d->expert_offsets; p.E = d->num_experts;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.m_tiles = p.n_tiles = 0; p.split_k = 1; p.split_stride = 0; p.koffs = nullptr; p.c_gstride = 0;
+  const bool ob = d->out_dtype == MODE_BF16;
+#define MODE_CASE(E) \
+  case E: return ob ? p256_launch<E, true>(p, d, s) : p256_launch<E, false>(p, d, s);
+  switch (d->epilogue) {
+    MODE_CASE(MODE_EPI_NONE)
+    MODE_CASE(MODE_EPI_BIAS)
+    MODE_CASE(MODE_EPI_BIAS_GELU)
+    MODE_CASE(MODE_EPI_RESIDUAL)
+    MODE_CASE(MODE_EPI_SWIGLU)
+    default: return MODE_ERR_BAD_ARG;
+  }
+#undef MODE_CASE
+}
+
+}  // namespace mode
