@@ -41,7 +41,7 @@ TrainWs train_ws(const ModeDims& d, int B, int dtype) {
   TrainWs w{};
   Take t;
   w.dxa = t(N * D * 4); w.dxb = t(N * D * 4); w.dyl = t(N * D * 4);
-  w.dys = t(NK * D * esz); w.dhd = t(NK * 4 * D * esz); w.dp = t(NK * 8 * D * esz); w.dus = t(NK * D * 4); w.dwt = t(NK * 4);
+  w.dys = t(NK * D * esz); w.dhd = t(NK * 4 * D * esz); w.dp = t(NK * 8 * D * esz); w.dus = t(NK * D * 4); w.dwt = t(NK * 4 * (size_t)d.L);      // router-weight gradients of ALL layers [L][N*k]
   w.t_big = t(8 * D * NKp * esz);            // dP^T  [8D, NKp]   (also dqkv^T [3D, Np])
   w.t_mid = t(4 * D * NKp * esz);            // Hd^T  [4D, NKp]
   w.t_d = t(D * NKp * esz);                  // dY^T / u^T / dx1^T / h1^T  [D, NKp]
@@ -241,7 +241,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     const int32_t* offsets = meta + ml.offsets; const int32_t* poff = meta + ml.poffsets; const int32_t* prow = meta + ml.prow;
     const int32_t* pos = meta + ml.pos; const float* posw = reinterpret_cast<const float*>(meta + ml.posw);
     // (1) combine backward: dY (sorted rows) and router-weight gradients
-    if ((rc = mode_moe_combine_bwd(DXa, S + sl.Y, dt, pos, posw, N, D, d.k, dYs, dwt, stream))) return rc;
+    if ((rc = mode_moe_combine_bwd(DXa, S + sl.Y, dt, pos, posw, N, D, d.k, dYs, dwt + (size_t)l * NK, stream))) return rc;
     // (2) expert down-projection: dH = dY W2 ; dW2_e = dY_e^T H_e
     ModeGemmDesc g;
     if (tr) {                                        // bf16: operands as they lie in memory, fragments by LDS transpose reads
@@ -333,13 +333,6 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     if ((rc = mode_rmsnorm_bwd((const float*)(S + sl.x0), lw.ln1_g, dh1, nullptr, nullptr, nullptr, 0, N, D, d.eps, DXb, 1, dgp1, nullptr, nullptr, MODE_F32,
                                stream))) return rc;
     if ((rc = colsum(dh1, D, N, D, MODE_F32, nullptr, T, B, dcond, 1))) return rc;
-    // (10) router: only dlogits here (through renormalisation / clamp / softmax); the router MLPs of all layers are back-propagated
-    //      in one batch after the loop
-    {
-      const float* probs = a->probs + (long)l * B * E;
-      const int32_t* idx = a->topk_idx + (long)l * a->topk_layer_stride;
-      if ((rc = mode_moe_router_bwd(dwt, idx, probs, B, T, E, d.k, d.router_normalize, a->idx_per_token, dlog + (long)l * B * E, stream))) return rc;
-    }
     if (a->layer_events && a->layer_events[l] && hipEventRecord((hipEvent_t)a->layer_events[l], hs) != hipSuccess) return (int)hipGetLastError();
     float* t_ = DXa; DXa = DXb; DXb = t_;                    // DXa now holds d x_l
   }
@@ -371,6 +364,15 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     const ModeLayerGrads& g0 = gr->layers[0];
     float* cpart = dhid;                                                          // [L][B][D] partial dcond per layer
     int32_t* koffs = reinterpret_cast<int32_t*>(dhid + (size_t)Ly * B * D);       // [L+1] K-group offsets 0, 2D, 4D, ...
+    // dlogits through renormalisation / clamp / softmax: all layers in one launch when the expert ids of the layers are adjacent
+    const long idx_rows = a->idx_per_token ? (long)N : (long)B;
+    if (a->topk_layer_stride == idx_rows * d.k) {
+      if ((rc = mode_moe_router_bwd(dwt, a->topk_idx, a->probs, Ly * B, T, E, d.k, d.router_normalize, a->idx_per_token, dlog, stream))) return rc;
+    } else {
+      for (int l = 0; l < Ly; ++l)
+        if ((rc = mode_moe_router_bwd(dwt + (size_t)l * NK, a->topk_idx + (long)l * a->topk_layer_stride, a->probs + (long)l * B * E, B, T, E, d.k,
+                                      d.router_normalize, a->idx_per_token, dlog + (long)l * B * E, stream))) return rc;
+    }
     if ((rc = colsum(dlog, E, Ly * B, E, MODE_F32, nullptr, B, Ly, g0.r_b3, 0))) return rc;                    // db3 [L][E]
     if ((rc = mode_router_mlp_bwd(dlog, a->r_pre, w0.r_w3, Ly, B, E, H2, dpre, g0.r_w3, stream))) return rc;  // dpre, dW3
     if ((rc = colsum(dpre, (long)Ly * H2, B, Ly * H2, MODE_F32, nullptr, 0, 1, g0.r_b0, 0))) return rc;        // db0 [L][2D]

@@ -300,33 +300,59 @@ __global__ void iota_scale_kernel(int* out, int n, int step) {
 
 // Router backward on distinct conditioning rows (one thread per sample): dw[t,j] (j in ascending expert id) -> dlogits[b,:]
 // w = p[S]/sum(p[S]) (router_normalize) or p[S]; p = clamp(softmax(l), 1e-9, 1-1e-9)   (modedit.py:345-349, 398-399, 418-419)
+template <int EMAX>
 __global__ void router_bwd_kernel(const float* __restrict__ dw, const int* __restrict__ idx, const float* __restrict__ probs, int B, int T, int E,
                                   int k, int normalize, int idx_per_token, float* __restrict__ dlogits) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  float dp[64], p[64];
-  for (int e = 0; e < E; ++e) { dp[e] = 0.f; p[e] = probs[(long)b * E + e]; }
+  float dp[EMAX], p[EMAX];                                             // compile-time indexed only: stays in registers
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) { dp[e] = 0.f; p[e] = e < E ? probs[(long)b * E + e] : 0.f; }
+  auto pick = [&](const float* arr, int e) { float r = 0.f;
+#pragma unroll
+    for (int q = 0; q < EMAX; ++q) r = (q == e) ? arr[q] : r;
+    return r; };
   for (int t = 0; t < T; ++t) {
     const long tok = (long)b * T + t;
     const int* id = idx + (idx_per_token ? tok : (long)b) * k;
     int es[8];
-    for (int j = 0; j < k; ++j) es[j] = id[j];
-    for (int a = 1; a < k; ++a) { const int v = es[a]; int c = a - 1; while (c >= 0 && es[c] > v) { es[c + 1] = es[c]; --c; } es[c + 1] = v; }   // ascending
+    float pe[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) es[j] = j < k ? id[j] : 0x7fffffff;
+    // ascending expert id: slot j of dw belongs to the j-th smallest id (combine_bwd's convention); k <= 8 -> fixed compare-exchange network
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int c = 0; c + 1 < 8 - a; ++c) { const int lo = min(es[c], es[c + 1]), hi = max(es[c], es[c + 1]); es[c] = lo; es[c + 1] = hi; }
     float s = 0.f, wd = 0.f;
-    for (int j = 0; j < k; ++j) s += p[es[j]];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { pe[j] = j < k ? pick(p, es[j]) : 0.f; s += pe[j]; }
+    float add[8];
     if (normalize) {
-      for (int j = 0; j < k; ++j) wd += (p[es[j]] / s) * dw[tok * k + j];
-      for (int j = 0; j < k; ++j) dp[es[j]] += (dw[tok * k + j] - wd) / s;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (j < k) wd += (pe[j] / s) * dw[tok * k + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) add[j] = j < k ? (dw[tok * k + j] - wd) / s : 0.f;
     } else {
-      for (int j = 0; j < k; ++j) dp[es[j]] += dw[tok * k + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) add[j] = j < k ? dw[tok * k + j] : 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < EMAX; ++e) dp[e] += (j < k && es[j] == e) ? add[j] : 0.f;
   }
   float dot = 0.f;
-  for (int e = 0; e < E; ++e) {
-    if (p[e] <= 1e-9f || p[e] >= 1.0f - 1e-9f) dp[e] = 0.f;          // clamp passes gradient only strictly inside
-    dot += dp[e] * p[e];
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) {
+    if (e < E) {
+      if (p[e] <= 1e-9f || p[e] >= 1.0f - 1e-9f) dp[e] = 0.f;          // clamp passes gradient only strictly inside
+      dot += dp[e] * p[e];
+    }
   }
-  for (int e = 0; e < E; ++e) dlogits[(long)b * E + e] = p[e] * (dp[e] - dot);
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e)
+    if (e < E) dlogits[(long)b * E + e] = p[e] * (dp[e] - dot);
 }
 
 // sigma_emb backward: e1[b,d] = s_b * w[d] + bias[d], s_b = ln(sigma_b)/4:  dw[d] = sum_b de1[b,d] s_b, dbias[d] = sum_b de1[b,d]
@@ -478,7 +504,9 @@ extern "C" int mode_moe_router_bwd(const float* dw, const int32_t* idx, const fl
                                    int idx_per_token, float* dlogits, void* stream) {
   if (!dw || !idx || !probs || !dlogits || B < 0 || E <= 0 || E > 64 || k <= 0 || k > 8 || k > E) return MODE_ERR_BAD_ARG;
   if (B == 0) return MODE_OK;
-  hipLaunchKernelGGL(router_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, dw, idx, probs, B, T, E, k, normalize, idx_per_token, dlogits);
+#define MODE_RB(EM) hipLaunchKernelGGL(router_bwd_kernel<EM>, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, dw, idx, probs, B, T, E, k, normalize, idx_per_token, dlogits)
+  if (E <= 4) MODE_RB(4); else if (E <= 8) MODE_RB(8); else if (E <= 16) MODE_RB(16); else MODE_RB(64);
+#undef MODE_RB
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
