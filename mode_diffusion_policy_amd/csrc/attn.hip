@@ -193,7 +193,7 @@ template <typename T2>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qkv, const float* __restrict__ qg, const float* __restrict__ kg,
                                                        const T2* __restrict__ dY, T2* __restrict__ dqkv, float* __restrict__ dgq_part,
                                                        float* __restrict__ dgk_part, int B, int T, int H, int HD, float eps, uint32_t seed,
-                                                       uint32_t thresh, float inv_keep) {
+                                                       uint32_t thresh, float inv_keep, int stop_after) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HP = HD + 1;                               // padded row (bank-conflict-free column walks)
   float* sq = reinterpret_cast<float*>(smem);          // raw q  [T][HP]
@@ -204,20 +204,37 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
   float* skh = sqh + T * HP;                           // k_hat, later d k_hat
   float* sp = skh + T * HP;                            // P                                 [T][T]
   float* sds = sp + T * T;                             // dPd, then dS                      [T][T]
-  float* srq = sds + T * T;                            // 1/norm per token (q)              [T]
+  float* spd = sds + T * T;                            // dropped probabilities Pd          [T][T]
+  float* srq = spd + T * T;                            // 1/norm per token (q)              [T]
   float* srk = srq + T;                                // (k)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int prob = blockIdx.x, b = prob / H, h = prob % H, D = H * HD;
   const long ld = 3L * D;
-  auto LD = [](const T2* p) -> float { if constexpr (sizeof(T2) == 2) return bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(p)); else return *reinterpret_cast<const float*>(p); };
-  auto ST = [](T2* p, float v) { if constexpr (sizeof(T2) == 2) *reinterpret_cast<uint16_t*>(p) = f32_to_bf16_bits(v); else *reinterpret_cast<float*>(p) = v; };
-  for (int i = tid; i < T * HD; i += 256) {
-    const int t = i / HD, d = i % HD;
+  // 16-byte global loads, all four tensors of a thread's chunk requested before the first use (one memory round trip per workgroup —
+  // a per-element loop serialises T*HD/256 dependent round trips and was 80 % of this kernel's time)
+  constexpr int VE = 16 / (int)sizeof(T2);              // elements per 16-byte chunk
+  const int cpr = HD / VE;                              // chunks per token row
+  auto unpack = [&](const uint4& u, float* dst) {
+    if constexpr (sizeof(T2) == 2) {
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dst[2 * j] = bf16_bits_to_f32(w[j] & 0xffff); dst[2 * j + 1] = bf16_bits_to_f32(w[j] >> 16); }
+    } else {
+      dst[0] = __uint_as_float(u.x); dst[1] = __uint_as_float(u.y); dst[2] = __uint_as_float(u.z); dst[3] = __uint_as_float(u.w);
+    }
+  };
+  for (int i = tid; i < T * cpr; i += 256) {
+    const int t = i / cpr, d = (i % cpr) * VE;
     const T2* r = qkv + ((long)b * T + t) * ld + h * HD + d;
-    sq[t * HP + d] = LD(r); sk[t * HP + d] = LD(r + D); sv[t * HP + d] = LD(r + 2 * D);
-    sdo[t * HP + d] = LD(dY + ((long)b * T + t) * D + h * HD + d);
+    const uint4 uq = *reinterpret_cast<const uint4*>(r), uk = *reinterpret_cast<const uint4*>(r + D), uv = *reinterpret_cast<const uint4*>(r + 2 * D);
+    const uint4 ud = *reinterpret_cast<const uint4*>(dY + ((long)b * T + t) * D + h * HD + d);
+    float fq_[VE], fk_[VE], fv_[VE], fd_[VE];
+    unpack(uq, fq_); unpack(uk, fk_); unpack(uv, fv_); unpack(ud, fd_);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { sq[t * HP + d + j] = fq_[j]; sk[t * HP + d + j] = fk_[j]; sv[t * HP + d + j] = fv_[j]; sdo[t * HP + d + j] = fd_[j]; }
   }
   __syncthreads();
+  if (stop_after == 1) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   for (int t = wave; t < T; t += 4) {                  // one wave per token: row norms
     float a = 0.f, c = 0.f;
     for (int d = lane; d < HD; d += 64) { a += sq[t * HP + d] * sq[t * HP + d]; c += sk[t * HP + d] * sk[t * HP + d]; }
@@ -228,24 +245,36 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
     }
   }
   __syncthreads();
+  if (stop_after == 2) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   for (int i = tid; i < T * HD; i += 256) {
     const int t = i / HD, d = i % HD;
     sqh[t * HP + d] = sq[t * HP + d] * srq[t] * qg[d];
     skh[t * HP + d] = sk[t * HP + d] * srk[t] * kg[d];
   }
   __syncthreads();
+  if (stop_after == 3) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   const float scale = rsqrtf((float)HD);
-  for (int i = tid; i < T * T; i += 256) {             // S = q_hat k_hat^T * scale (causal) and dPd = dO V^T
-    const int qi = i / T, ki = i % T;
-    float s = -INFINITY, dp = 0.f;
+  // S = q_hat k_hat^T * scale (causal) and dPd = dO V^T: four lanes per (query, key) pair, each a quarter of the head dim with two
+  // independent accumulator pairs (the one-thread-per-pair loop was a 128-deep chain of dependent LDS reads), xor-shuffle combine
+  for (int i = tid >> 2; i < T * T; i += 64) {
+    const int qi = i / T, ki = i % T, part = tid & 3;
+    float s0 = 0.f, s1 = 0.f, p0 = 0.f, p1 = 0.f;
     if (ki <= qi) {
-      s = 0.f;
-      for (int d = 0; d < HD; ++d) { s = fmaf(sqh[qi * HP + d], skh[ki * HP + d], s); dp = fmaf(sdo[qi * HP + d], sv[ki * HP + d], dp); }
-      s *= scale;
+      const float* qr = sqh + qi * HP; const float* kr = skh + ki * HP; const float* orow = sdo + qi * HP; const float* vr = sv + ki * HP;
+      int d = part;
+      for (; d + 4 < HD; d += 8) {                          // lanes interleave d: consecutive banks
+        s0 = fmaf(qr[d], kr[d], s0); s1 = fmaf(qr[d + 4], kr[d + 4], s1);
+        p0 = fmaf(orow[d], vr[d], p0); p1 = fmaf(orow[d + 4], vr[d + 4], p1);
+      }
+      for (; d < HD; d += 4) { s0 = fmaf(qr[d], kr[d], s0); p0 = fmaf(orow[d], vr[d], p0); }
     }
-    sp[i] = s; sds[i] = dp;
+    float sa = s0 + s1, pa = p0 + p1;
+    sa += __shfl_xor(sa, 1, 64); sa += __shfl_xor(sa, 2, 64);
+    pa += __shfl_xor(pa, 1, 64); pa += __shfl_xor(pa, 2, 64);
+    if (part == 0) { sp[i] = (ki <= qi) ? sa * scale : -INFINITY; sds[i] = pa; }
   }
   __syncthreads();
+  if (stop_after == 4) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   if (tid < T) {                                        // softmax row, dropout, dS = P * (dP - sum(dP*P)) * scale
     const int qi = tid;
     float mx = -INFINITY;
@@ -260,37 +289,63 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
       const float dP = sds[qi * T + ki] * m;           // gradient wrt the un-dropped probability
       rs += dP * pv;
       sp[qi * T + ki] = pv;
+      spd[qi * T + ki] = pv * m;                         // dropped probabilities (dV needs them)
       sds[qi * T + ki] = dP;
     }
     for (int ki = 0; ki < T; ++ki) sds[qi * T + ki] = sp[qi * T + ki] * (sds[qi * T + ki] - rs) * scale;
   }
   __syncthreads();
-  // dV[j][d] = sum_{i>=j} Pd[i][j] dO[i][d];  dq_hat[i][d] = sum_{j<=i} dS[i][j] k_hat[j][d];  dk_hat[j][d] = sum_{i>=j} dS[i][j] q_hat[i][d]
-  float dqr[8], dkr[8];                                 // results for this thread's (t, d) slots, written after the barrier (in-place reuse)
-  int nslot = 0;
-  for (int i = tid; i < T * HD; i += 256, ++nslot) {
-    const int t = i / HD, d = i % HD;
-    float dv = 0.f, dq = 0.f, dk = 0.f;
-    for (int u = 0; u < T; ++u) {
-      if (u >= t) {
-        float pd = sp[u * T + t];
-        if (thresh) pd = attn_keep(seed, prob, T, u, t, thresh) ? pd * inv_keep : 0.f;
-        dv = fmaf(pd, sdo[u * HP + d], dv);
-        dk = fmaf(sds[u * T + t], sqh[u * HP + d], dk);
-      }
-      if (u <= t) dq = fmaf(sds[t * T + u], skh[u * HP + d], dq);
+  if (stop_after == 5) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
+  // dV[j][d] = sum_{i>=j} Pd[i][j] dO[i][d];  dq_hat[i][d] = sum_{j<=i} dS[i][j] k_hat[j][d];  dk_hat[j][d] = sum_{i>=j} dS[i][j] q_hat[i][d].
+  // One thread per (role, head-dim column) — role 0: dq_hat, role 1: dV and dk_hat.  The T column values a thread needs are read from
+  // LDS once into registers, the P / dS coefficients are wave-uniform broadcast reads, so the FMAs are independent of LDS latency.
+  // Results stay in registers across the barrier: they overwrite q_hat / k_hat / v in place.   (host side guarantees 2*HD <= 256, T <= 16)
+  {
+    constexpr int TMAX = 16;
+    const int role = tid / HD, d = tid % HD;
+    const bool act = tid < 2 * HD;
+    float o0[TMAX], o1[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
+    if (act && role == 0) {
+      float kc[TMAX];
+#pragma unroll
+      for (int u = 0; u < TMAX; ++u) kc[u] = u < T ? skh[u * HP + d] : 0.f;
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int u = 0; u <= t; ++u)
+          if (t < T) o0[t] = fmaf(sds[t * T + u], kc[u], o0[t]);
+    } else if (act) {
+      float oc[TMAX], qc[TMAX];
+#pragma unroll
+      for (int u = 0; u < TMAX; ++u) { oc[u] = u < T ? sdo[u * HP + d] : 0.f; qc[u] = u < T ? sqh[u * HP + d] : 0.f; }
+#pragma unroll
+      for (int j = 0; j < TMAX; ++j)
+#pragma unroll
+        for (int i = j; i < TMAX; ++i)
+          if (i < T) { o0[j] = fmaf(spd[i * T + j], oc[i], o0[j]); o1[j] = fmaf(sds[i * T + j], qc[i], o1[j]); }
     }
-    if (nslot < 8) { dqr[nslot] = dq; dkr[nslot] = dk; }
-    ST(dqkv + ((long)b * T + t) * ld + 2 * D + h * HD + d, dv);
+    __syncthreads();
+  if (stop_after == 6) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
+    if (act && role == 0) {
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) if (t < T) sqh[t * HP + d] = o0[t];
+    } else if (act) {
+#pragma unroll
+      for (int j = 0; j < TMAX; ++j) if (j < T) { sv[j * HP + d] = o0[j]; skh[j * HP + d] = o1[j]; }
+    }
   }
   __syncthreads();
-  nslot = 0;
-  for (int i = tid; i < T * HD; i += 256, ++nslot) {    // overwrite q_hat / k_hat with their gradients
-    const int t = i / HD, d = i % HD;
-    if (nslot < 8) { sqh[t * HP + d] = dqr[nslot]; skh[t * HP + d] = dkr[nslot]; }
+  if (stop_after == 7) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
+  for (int d = tid; d < HD; d += 256) {                 // gain-gradient partials of this (sample, head)
+    float a = 0.f, c = 0.f;
+    for (int t = 0; t < T; ++t) { a += sqh[t * HP + d] * sq[t * HP + d] * srq[t]; c += skh[t * HP + d] * sk[t * HP + d] * srk[t]; }
+    dgq_part[(long)prob * HD + d] = a; dgk_part[(long)prob * HD + d] = c;
   }
   __syncthreads();
-  // qk-RMSNorm backward (x_hat = x * r * g): dx = g*dxh*r - x * <g*dxh, x> * r^3 / HD  (clamped rows: dx = g*dxh/eps)
+  if (stop_after == 8) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
+  // qk-RMSNorm backward (x_hat = x * r * g): dx = g*dxh*r - x * <g*dxh, x> * r^3 / HD  (clamped rows: dx = g*dxh/eps); in place over d x_hat
   for (int t = wave; t < T; t += 4) {
     float cq = 0.f, ck = 0.f;
     for (int d = lane; d < HD; d += 64) { cq += qg[d] * sqh[t * HP + d] * sq[t * HP + d]; ck += kg[d] * skh[t * HP + d] * sk[t * HP + d]; }
@@ -298,21 +353,33 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
     const float rq = srq[t], rk = srk[t];
     const bool clq = rq >= 1.0f / eps, clk = rk >= 1.0f / eps;
     for (int d = lane; d < HD; d += 64) {
-      const float dq = qg[d] * sqh[t * HP + d] * rq - (clq ? 0.f : sq[t * HP + d] * cq * rq * rq * rq / (float)HD);
-      const float dk = kg[d] * skh[t * HP + d] * rk - (clk ? 0.f : sk[t * HP + d] * ck * rk * rk * rk / (float)HD);
-      ST(dqkv + ((long)b * T + t) * ld + h * HD + d, dq);
-      ST(dqkv + ((long)b * T + t) * ld + D + h * HD + d, dk);
+      sqh[t * HP + d] = qg[d] * sqh[t * HP + d] * rq - (clq ? 0.f : sq[t * HP + d] * cq * rq * rq * rq / (float)HD);
+      skh[t * HP + d] = kg[d] * skh[t * HP + d] * rk - (clk ? 0.f : sk[t * HP + d] * ck * rk * rk * rk / (float)HD);
     }
   }
-  for (int d = tid; d < HD; d += 256) {                 // gain-gradient partials of this (sample, head)
-    float a = 0.f, c = 0.f;
-    for (int t = 0; t < T; ++t) { a += sqh[t * HP + d] * sq[t * HP + d] * srq[t]; c += skh[t * HP + d] * sk[t * HP + d] * srk[t]; }
-    dgq_part[(long)prob * HD + d] = a; dgk_part[(long)prob * HD + d] = c;
+  __syncthreads();
+  if (stop_after == 9) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
+  auto pack = [&](const float* src) -> uint4 {
+    uint4 u;
+    if constexpr (sizeof(T2) == 2) {
+      u.x = pack_bf16x2(src[0], src[1]); u.y = pack_bf16x2(src[2], src[3]); u.z = pack_bf16x2(src[4], src[5]); u.w = pack_bf16x2(src[6], src[7]);
+    } else {
+      u.x = __float_as_uint(src[0]); u.y = __float_as_uint(src[1]); u.z = __float_as_uint(src[2]); u.w = __float_as_uint(src[3]);
+    }
+    return u;
+  };
+  for (int i = tid; i < T * cpr; i += 256) {            // 16-byte stores of dq | dk | dv
+    const int t = i / cpr, d = (i % cpr) * VE;
+    T2* o = dqkv + ((long)b * T + t) * ld + h * HD + d;
+    *reinterpret_cast<uint4*>(o) = pack(sqh + t * HP + d);
+    *reinterpret_cast<uint4*>(o + D) = pack(skh + t * HP + d);
+    *reinterpret_cast<uint4*>(o + 2 * D) = pack(sv + t * HP + d);
   }
 }
 
 }  // namespace mode
 
+namespace mode { int g_attn_bwd_stop = 0; }
 using namespace mode;
 
 static inline uint32_t attn_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)((double)p * 4294967296.0); }
@@ -350,16 +417,16 @@ extern "C" int mode_attn_block_bwd(const void* qkv, const float* q_gain, const f
   if (!qkv || !q_gain || !k_gain || !dy || !dqkv || !dgq_partial || !dgk_partial || B < 0 || T <= 0 || H <= 0) return MODE_ERR_BAD_ARG;
   if (p_drop < 0.f || p_drop >= 1.f) return MODE_ERR_BAD_ARG;
   if (B == 0) return MODE_OK;
-  const size_t lds = ((size_t)6 * T * (head_dim + 1) + 2 * (size_t)T * T + 2 * T) * 4;
-  if (lds > 64 * 1024 || (size_t)T * head_dim > 8 * 256) return MODE_ERR_UNSUPPORTED;
+  const size_t lds = ((size_t)6 * T * (head_dim + 1) + 3 * (size_t)T * T + 2 * T) * 4;
+  if (lds > 64 * 1024 || head_dim > 128 || T > 16 || head_dim % (dtype == MODE_BF16 ? 8 : 4)) return MODE_ERR_UNSUPPORTED;
   const uint32_t th = attn_thresh(p_drop); const float ik = 1.0f / (1.0f - p_drop);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MODE_BF16)
     hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, dim3(B * H), dim3(256), lds, s, (const uint16_t*)qkv, q_gain, k_gain, (const uint16_t*)dy, (uint16_t*)dqkv,
-                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik);
+                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik, g_attn_bwd_stop);
   else
     hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B * H), dim3(256), lds, s, (const float*)qkv, q_gain, k_gain, (const float*)dy, (float*)dqkv,
-                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik);
+                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik, g_attn_bwd_stop);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
