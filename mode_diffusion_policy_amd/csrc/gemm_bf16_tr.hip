@@ -67,7 +67,7 @@ __device__ __forceinline__ int kn_swz(int row) {
 // (2: vmcnt(0) per K-step, 2 workgroups/CU hide each other's fill latency; 3: two tiles in flight under counted waits, for long-K
 // problems with <= 1 workgroup per CU).  The gathered-W weight gradient (w_rows) needs NS == 2.
 template <bool A_KM, bool OUT_BF16, int BN, int NS>
-__global__ __launch_bounds__(256, 2) void gemm_tr_kernel(const TrParams p) {
+__global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const TrParams p) {
   constexpr int BM = 128, BKT = 64, TM = 64, TN = BN / 2, FM = 4, FN = TN / 16;
   constexpr int W_ROW = BN * 2, W_BYTES = BKT * W_ROW;                 // bytes per k-row / per tile of the [k][n] operand
   constexpr int RPP = 1024 / W_ROW, NPW = (BKT / RPP) / 4, CHW = BN / 8; // rows per 1-KiB DMA piece, pieces per wave, 16-B chunks per row
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tr_kernel(const TrParams p) {
   constexpr int GROUP_M = 8;
   constexpr int ESZ = OUT_BF16 ? 2 : 4;
   constexpr int CROW = BN * ESZ, CPR = CROW / 16, CSWZ = (CPR < 16 ? CPR : 16) - 1;
-  static_assert(BM * CROW <= NS * STAGE_BYTES, "output tile must fit the operand ring");
+  static_assert(BM * CROW <= 2 * NS * STAGE_BYTES, "half the output tile must fit the operand ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tr_kernel(const TrParams p) {
 #pragma unroll
   for (int q = 0; q < NPW; ++q) widx[q] = 0;
   auto load_widx = [&](int kt) {
-    if (A_KM && NS == 2 && p.w_rows) {
+    if (A_KM && NS <= 2 && p.w_rows) {
 #pragma unroll
       for (int q = 0; q < NPW; ++q) {
         const int r = kb + kt * BKT + (wave * NPW + q) * RPP + krw;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tr_kernel(const TrParams p) {
       long r = kb + kt * BKT + P * RPP + krw;
       if constexpr (A_KM) {
         r = min(r, (long)ke - 1);
-        if (NS == 2 && p.w_rows) r = widx[q];
+        if (NS <= 2 && p.w_rows) r = widx[q];
       }
       const uint16_t* src = W + r * p.ldw + kn_col_w[q];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tr_kernel(const TrParams p) {
   const int sw = fr & 7;
   const uint32_t a_off = (wm * TM + fr) * 128;
 
-  constexpr int PRE = NS - 1;
+  constexpr int PRE = (NS == 1) ? 1 : NS - 1;
   if (nk > 0) load_widx(0);
 #pragma unroll
   for (int s = 0; s < PRE; ++s)
@@ -211,9 +211,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tr_kernel(const TrParams p) {
     if (NS >= 3 && kt + 1 < nk) tr_wait_vmcnt<LOADS>();
     else tr_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (kt + NS - 1 < nk) {
-      stage((slot + NS - 1) % NS, kt + NS - 1);
-      load_widx(kt + NS);
+    if constexpr (NS >= 2) {
+      if (kt + NS - 1 < nk) {
+        stage((slot + NS - 1) % NS, kt + NS - 1);
+        load_widx(kt + NS);
+      }
     }
     const uint32_t so = slot * STAGE_BYTES;
     s16x4 alo[2][FM], ahi[2][FM], wlo[2][FN], whi[2][FN];
@@ -259,42 +261,57 @@ __global__ __launch_bounds__(256, 2) void gemm_tr_kernel(const TrParams p) {
     __builtin_amdgcn_sched_barrier(0);
     mma_half(std::integral_constant<int, 1>{});
     __builtin_amdgcn_sched_barrier(0);
-    slot = (slot + 1 == NS) ? 0 : slot + 1;
-  }
-
-  // ---- epilogue: accumulators -> swizzled LDS tile -> coalesced 16-byte stores
-  char* Cout = reinterpret_cast<char*>(p.C) + (long)blockIdx.z * p.c_gstride * ESZ;
-  const int rows_valid = row_end - row0;
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int rl = wm * TM + i * 16 + fr;
-    char* crow = smem + rl * CROW;
-    const int rsw = rl & CSWZ;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int nl = wn * TN + j * 16 + fq * 4;
-      const int b = nl * ESZ;
-      char* dst = crow + ((((b >> 4) ^ rsw) << 4) | (b & 15));
-      const f32x4 v = acc[i][j];
-      if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-      else *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    if constexpr (NS == 1) {
+      // single buffer (32-48 KiB: three workgroups per CU hide each other's fill latency): everyone must be done reading before the refill
+      if (kt + 1 < nk) {
+        __builtin_amdgcn_s_barrier();
+        stage(0, kt + 1);
+        load_widx(kt + 2);
+      }
+    } else {
+      slot = (slot + 1 == NS) ? 0 : slot + 1;
     }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  constexpr int EPC = 16 / ESZ;
-  for (int c = tid; c < BM * CPR; c += 256) {
-    const int rl = c / CPR, ch = c % CPR;
-    const int n = n0 + ch * EPC;
-    if (rl >= rows_valid || n >= p.N) continue;
-    const long m = row0 + rl;
-    const uint4 v = *reinterpret_cast<const uint4*>(smem + rl * CROW + ((ch ^ (rl & CSWZ)) << 4));
-    if constexpr (OUT_BF16) {
-      *reinterpret_cast<uint4*>(Cout + (m * p.ldc + n) * 2) = v;
-    } else {
-      *reinterpret_cast<uint4*>(Cout + (m * p.ldc + n) * 4) = v;
+
+  // ---- epilogue: accumulators -> swizzled LDS tile -> coalesced 16-byte stores; one pass when the tile fits the operand ring, else one
+  //      pass per wave-row group (64 rows), so a single-buffered (NS == 1) workgroup keeps its small LDS footprint
+  char* Cout = reinterpret_cast<char*>(p.C) + (long)blockIdx.z * p.c_gstride * ESZ;
+  const int rows_valid = row_end - row0;
+  constexpr int EPASS = (BM * CROW <= NS * STAGE_BYTES) ? 1 : 2;
+  constexpr int RP = BM / EPASS;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+  for (int g = 0; g < EPASS; ++g) {
+    __builtin_amdgcn_s_barrier();
+    if (EPASS == 1 || wm == g) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int rl = (EPASS == 1 ? wm * TM : 0) + i * 16 + fr;
+        char* crow = smem + rl * CROW;
+        const int rsw = rl & CSWZ;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int nl = wn * TN + j * 16 + fq * 4;
+          const int bb = nl * ESZ;
+          char* dst = crow + ((((bb >> 4) ^ rsw) << 4) | (bb & 15));
+          const f32x4 v = acc[i][j];
+          if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          else *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int EPC = 16 / ESZ;
+    for (int c = tid; c < RP * CPR; c += 256) {
+      const int rl = c / CPR, ch = c % CPR;
+      const int ml = g * RP + rl;
+      const int n = n0 + ch * EPC;
+      if (ml >= rows_valid || n >= p.N) continue;
+      const long m = row0 + ml;
+      const uint4 v = *reinterpret_cast<const uint4*>(smem + rl * CROW + ((ch ^ (rl & CSWZ)) << 4));
+      if constexpr (OUT_BF16) *reinterpret_cast<uint4*>(Cout + (m * p.ldc + n) * 2) = v;
+      else *reinterpret_cast<uint4*>(Cout + (m * p.ldc + n) * 4) = v;
     }
   }
 }
@@ -304,7 +321,7 @@ static int tr_launch(TrParams p, const ModeGemmDesc* d, hipStream_t s) {
   p.n_tiles = (d->N + BN - 1) / BN;
   p.m_tiles = (d->M + 127) / 128 + (d->expert_offsets ? d->num_experts : 0);
   const dim3 grid(p.m_tiles * p.n_tiles, 1, (KM && d->k_group_offsets) ? d->num_k_groups : 1);
-  constexpr size_t lds = (size_t)NS * (128 * 64 * 2 + 64 * BN * 2);
+  constexpr size_t lds = (size_t)NS * (128 * 64 * 2 + 64 * BN * 2);       // the output tile goes through the ring (one or two passes)
   auto kern = gemm_tr_kernel<KM, OB, BN, NS>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -317,7 +334,7 @@ static int tr_launch(TrParams p, const ModeGemmDesc* d, hipStream_t s) {
   return MODE_OK;
 }
 
-int g_tr_cfg = 0;   // "gemm_tr_cfg" option: 0 auto, 1 = 128-wide NS2, 2 = 64-wide NS3, 3 = 128-wide NS3, 4 = 64-wide NS2
+int g_tr_cfg = 0;   // "gemm_tr_cfg" option: 0 auto, 1 = 128-wide NS2, 2 = 64-wide NS3, 3 = 128-wide NS3, 4 = 64-wide NS2, 5 = 128-wide NS1
 
 int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
   const bool a_km = (d->flags & MODE_GEMM_A_KM) != 0;
@@ -342,7 +359,8 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
   const long groups = (a_km && d->k_group_offsets) ? d->num_k_groups : 1;
   const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * groups;
   int cfg = g_tr_cfg;
-  if (cfg == 0) cfg = (t128 >= 512 || d->w_rows) ? 1 : 2;
+  // measured (profiles/): weight gradients (short K per tile, >= 3 workgroups per CU) are 4 % faster single-buffered; data gradients are not
+  if (cfg == 0) cfg = (a_km && t128 >= 768) ? 5 : ((t128 >= 512 || d->w_rows) ? 1 : 2);
   if (d->w_rows && (cfg == 2 || cfg == 3)) cfg = 1;
   const bool ob = d->out_dtype == MODE_BF16;
 #define MODE_TR_CFG(BN, NS)                                                                     \
@@ -355,6 +373,7 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
     case 2: MODE_TR_CFG(64, 3)
     case 3: MODE_TR_CFG(128, 3)
     case 4: MODE_TR_CFG(64, 2)
+    case 5: MODE_TR_CFG(128, 1)
     default: return MODE_ERR_BAD_ARG;
   }
 #undef MODE_TR_CFG
