@@ -216,3 +216,54 @@ def test_expert_weight_gradient_gemm(dtype):
             assert float(dW[e].abs().max()) == 0.0
         else:
             assert rel(dW[e], ref) < (3e-3 if dtype == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("Ly,R,E,D", [(12, 128, 4, 256), (2, 10, 2, 64), (3, 1, 8, 128)])
+def test_router_mlp_all_layers_fwd_bwd(Ly, R, E, D):
+    """Layer-batched router MLP (RouterCond.router, modedit.py:190-200): logits of every layer in one launch and the batched backward
+    (dpre, dW3) against fp32 autograd of the per-layer Linear -> GELU -> Linear."""
+    lib = L.load()
+    H2 = 2 * D
+    pre = rnd(R, Ly, H2, seed=1).to(dev()).requires_grad_(True)                     # [R][L][2D] pre-GELU activations
+    w3 = (rnd(Ly, E, H2, seed=2) * H2 ** -0.5).to(dev()).requires_grad_(True)
+    b3 = rnd(Ly, E, seed=3).to(dev())
+    hid = torch.nn.functional.gelu(pre)
+    ref_logits = torch.einsum("rln,len->lre", hid, w3) + b3[:, None, :]
+    hid_c = hid.detach().contiguous()
+    logits = torch.full((Ly, R, E), float("nan"), device=dev())
+    L.check(lib.mode_router_logits(hid_c.data_ptr(), Ly * H2, w3.data_ptr(), E * H2, b3.data_ptr(), E, Ly, R, E, H2, logits.data_ptr(), H.stream()))
+    assert rel(logits, ref_logits.detach()) < 2e-6
+    dlog = rnd(Ly, R, E, seed=4).to(dev())
+    ref_logits.backward(dlog)
+    dpre = torch.full((R, Ly, H2), float("nan"), device=dev()); dw3 = torch.full((Ly, E, H2), float("nan"), device=dev())
+    L.check(lib.mode_router_mlp_bwd(dlog.data_ptr(), pre.detach().data_ptr(), w3.detach().data_ptr(), Ly, R, E, H2, dpre.data_ptr(), dw3.data_ptr(),
+                                    H.stream()))
+    assert rel(dpre, pre.grad) < 2e-6 and rel(dw3, w3.grad) < 2e-6
+
+
+@pytest.mark.parametrize("with_lp", [False, True])
+def test_adamw_kernel_matches_torch(with_lp):
+    """mode_adamw_step on a flat slice == torch.optim.AdamW (decoupled decay, bias correction) over several steps; n not a multiple of the
+    kernel's unroll width; optional bf16 shadow output; grad_scale folds the data-parallel mean."""
+    lib = L.load()
+    n = 4 * 100003
+    p0 = rnd(n, seed=1); g = [rnd(n, seed=10 + i) for i in range(3)]
+    p = p0.clone().to(dev()); m = torch.zeros(n, device=dev()); v = torch.zeros(n, device=dev())
+    lp = torch.zeros(n, dtype=torch.bfloat16, device=dev()) if with_lp else None
+    pt = p0.clone().to(dev()).requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    for step in range(1, 4):
+        gd = (g[step - 1] * 2.0).to(dev())                                          # "summed over 2 ranks"
+        L.check(lib.mode_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 3e-3, 0.9, 0.95, 1e-8, 0.05, step, 0.5,
+                                    None if lp is None else lp.data_ptr(), H.stream()))
+        pt.grad = g[step - 1].to(dev())
+        opt.step()
+        assert rel(p, pt.detach()) < 1e-6, step
+    if with_lp:
+        assert torch.equal(lp, p.to(torch.bfloat16))
+
+
+def test_iota_offsets():
+    out = torch.full((13,), -1, dtype=torch.int32, device=dev())
+    L.check(L.load().mode_iota_i32(out.data_ptr(), 13, 2048, H.stream()))
+    assert torch.equal(out.cpu(), torch.arange(13, dtype=torch.int32) * 2048)
