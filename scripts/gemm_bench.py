@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--only", default="")
     ap.add_argument("--splitk", type=int, default=1)
+    ap.add_argument("--nogather", action="store_true", help="gemm1 reads pre-sorted rows (no a_rows gather)")
     a = ap.parse_args()
     lib = L.load()
     for o in a.opt:
@@ -41,6 +42,7 @@ def main():
     qkv = torch.empty(N, 3 * D, dtype=bf, device=dev); xr = torch.randn(N, D, device=dev); xo = torch.empty(N, D, device=dev)
     Hb = torch.empty(NK, 4 * D, dtype=bf, device=dev); Y = torch.empty(max(a.splitk, 1), NK, D, device=dev)
     hin = torch.randn(NK, 4 * D, device=dev).to(bf)
+    xs = torch.randn(NK, D, device=dev).to(bf)           # pre-sorted (duplicated) expert inputs
 
     def desc(**kw):
         base = dict(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=N, N=D, K=D, A=x.data_ptr(), lda=D, W=None, ldw=D,
@@ -55,7 +57,8 @@ def main():
                                                  C=xo.data_ptr()) for i in range(nl)], 2.0 * N * D * D),
         "gemm1 grouped swiglu [3584x1024]x[2x8192x1024]": ([desc(epilogue=L.EPI_SWIGLU, M=NK, N=4 * D, W=w1[i].data_ptr(), w_expert_stride=8 * D * D,
                                                                    bias=b1.data_ptr(), bias_expert_stride=8 * D, C=Hb.data_ptr(), ldc=4 * D,
-                                                                   a_rows=mp + 4 * ml.perm, expert_offsets=mp + 4 * ml.offsets, num_experts=E) for i in range(nl)], 2.0 * NK * D * 8 * D),
+                                                                   a_rows=(None if a.nogather else mp + 4 * ml.perm), expert_offsets=mp + 4 * ml.offsets, num_experts=E,
+                                                                   **(dict(A=xs.data_ptr()) if a.nogather else {})) for i in range(nl)], 2.0 * NK * D * 8 * D),
         "gemm2 grouped [3584x4096]x[2x1024x4096]": ([desc(out_dtype=L.MODE_F32, M=NK, N=D, K=4 * D, A=hin.data_ptr(), lda=4 * D, W=w2[i].data_ptr(), ldw=4 * D,
                                                             w_expert_stride=4 * D * D, C=Y.data_ptr(), expert_offsets=mp + 4 * ml.offsets, num_experts=E, split_k=a.splitk,
                                                             split_stride=NK * D) for i in range(nl)], 2.0 * NK * 4 * D * D),
@@ -67,12 +70,14 @@ def main():
         for d in ds:
             L.check(lib.mode_gemm(C.byref(d), st))
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(a.reps):
-            lib.mode_gemm(C.byref(ds[i % nl]), st)
-        e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / a.reps
+        if True:
+            evs = []
+            for i in range(a.reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); lib.mode_gemm(C.byref(ds[i % nl]), st); e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            us = sum(x.elapsed_time(y) for x, y in evs) * 1e3 / a.reps
         tot_us += us
         print(f"{name:52s} {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
     print(f"sum {tot_us:.1f} us/layer  opts={a.opt}")
