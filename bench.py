@@ -213,8 +213,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
-                    help="sample (default, BASELINE metric): 10-step DDIM chunks; train: config-3/4 score-matching steps (fwd+bwd+AdamW, DP all-reduce)")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train", "rollout"],
+                    help="sample (default, BASELINE metric): 10-step DDIM chunks at B=128; train: configs[2]/[3] score-matching steps "
+                         "(fwd+bwd+AdamW, DP all-reduce); rollout: configs[4], B=32 environments, router pre-cached per noise level")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -244,9 +245,14 @@ def main():
     if args.mode == "train":
         return train_bench(args, world, rank, device, dist)
     M, den = build_model(device, args.dtype)
-    img, goal, x0 = synthetic_inputs(device, B_PER_GPU)
+    rollout = args.mode == "rollout"
+    batch = 32 if rollout else B_PER_GPU
+    img, goal, x0 = synthetic_inputs(device, batch)
     sig = M.get_sigmas_exponential(N_SAMPLING_STEPS, SIGMA_MIN, SIGMA_MAX).to(device)
     state = {"state_images": img}
+    if rollout:                                     # MoDEAgent's inference setup: routing decisions cached per noise level (mode_agent.py:318-341)
+        for s_ in sig[:-1]:
+            den.inner_model.precompute_experts_for_inference(s_)
 
     def chunk():
         return M.sample_ddim(den, state, x0, goal, sig, disable=True)
@@ -274,6 +280,22 @@ def main():
     n_gpus = world
     denoise_steps = n_gpus * args.steps * N_SAMPLING_STEPS
     value = denoise_steps / elapsed
+    if rollout:
+        if rank == 0:
+            print(json.dumps({
+                "metric": "action-chunks/sec (B=32 envs, 10-step DDIM per chunk)", "value": round(n_gpus * args.steps * batch / elapsed, 1),
+                "unit": "action-chunks/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": "configs[4]: inference rollout, 32 environments x one 10-action chunk x 10 denoise steps per call, hipGraph-captured "
+                                       "sampler, routing pre-cached per noise level, full MoDE denoiser", "global_batch": batch * n_gpus,
+                           "parallelism": f"replicas x{n_gpus} (no data-path collective)"},
+                "latency_ms_per_chunk_call": round(elapsed / args.steps * 1e3, 3),
+                "e2e_tflops_per_gpu": round(flops_per_denoise_step(batch) * args.steps * N_SAMPLING_STEPS / elapsed / 1e12, 1)}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     res = {
         "metric": "denoise-steps/sec (B=128, 10-step chunk)", "value": round(value, 2), "unit": "denoise-steps/s", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (NS == 1 ? 3 : 2)
 // ------------------------------------------------------------------------------------------------------------ host side
 // geometry ids (also the values of the "gemm_cfg" option; 0 = auto)
 enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x128_NS3 = 2, CFG_256x128_NS3 = 3, CFG_128x64_NS3 = 4, CFG_128x64_NS4 = 5,
-       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10, CFG_256x256_W16 = 11, CFG_P256 = 12 };
+       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10, CFG_256x256_W16 = 11, CFG_P256 = 12, CFG_256x64_NS3 = 13, CFG_256x64_NS2 = 14 };
 int gemm_bf16_p256_launch(const ModeGemmDesc* d, hipStream_t s);   // gemm_bf16_p256.hip: persistent 256x256 with cross-tile operand prefetch
 int g_gemm_cfg = CFG_AUTO;
 
@@ -370,21 +370,24 @@ static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipSt
     case CFG_256x256_NS2: return launch_cfg<256, 256, 2, 4, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_256x128_NS2: return launch_cfg<256, 128, 4, 2, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_256x256_W16: return launch_cfg<256, 256, 4, 4, 2, EPI, OUT_BF16>(p, d, s);
+    case CFG_256x64_NS3: return launch_cfg<256, 64, 4, 1, 3, EPI, OUT_BF16>(p, d, s);
+    case CFG_256x64_NS2: return launch_cfg<256, 64, 4, 1, 2, EPI, OUT_BF16>(p, d, s);
     default: return MODE_ERR_BAD_ARG;
   }
 }
 
-// Tile-geometry heuristic for 256 CUs, from scripts/gemm_bench.py / gemm_ksweep.py on the config-2 layer shapes:
-//   >= 1024 tiles of 128x128 : single-buffered 128x128 at 3 workgroups/CU (other workgroups hide the fill latency)   [expert up-projection]
-//   >= 256                   : double-buffered 128x128 ring                                                          [QKV]
-//   fewer                    : 128x64 tiles so that >= 1 workgroup lands on every CU; deeper ring for long K          [c_proj, expert down-proj]
+// Tile-geometry heuristic for 256 CUs, from scripts/gemm_bench.py (--batch 32 / 64 / 128) / gemm_ksweep.py on the config-2 layer shapes:
+//   >= 384 tiles of 128x128 : single-buffered 128x128 at 3 workgroups/CU (other workgroups hide the fill latency)   [expert up-projection]
+//   >= 256                  : double-buffered 128x128 ring                                                          [QKV at B=128]
+//   fewer                   : 128x64 tiles so that more CUs get a workgroup, 3-slot ring (two K-tiles in flight per workgroup: with
+//                             <= 1 workgroup per CU nothing else hides the fill latency)                 [c_proj, expert down-proj, small batches]
 static int pick_cfg(const ModeGemmDesc* d) {
   const long rows = d->M;
   const int nout128 = (d->epilogue == MODE_EPI_SWIGLU) ? 64 : 128;
   const long t128 = ((rows + 127) / 128) * ((d->N + nout128 - 1) / nout128);
-  if (t128 >= 1024) return CFG_128x128_NS1;
+  if (t128 >= 384) return CFG_128x128_NS1;
   if (t128 >= 256) return CFG_128x128_NS2;
-  return d->K >= 2048 ? CFG_128x64_NS3 : CFG_128x64_NS2;
+  return CFG_128x64_NS3;
 }
 
 int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {

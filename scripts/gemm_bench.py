@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--only", default="")
     ap.add_argument("--splitk", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=128, help="samples (tokens = 14 x batch)")
     ap.add_argument("--nogather", action="store_true", help="gemm1 reads pre-sorted rows (no a_rows gather)")
     a = ap.parse_args()
     lib = L.load()
@@ -24,15 +25,15 @@ def main():
         k, v = o.split("=")
         assert lib.mode_set_option(k.encode(), int(v)) == 0, o
     dev = torch.device("cuda:0")
-    D, N, E, k = 1024, 1792, 4, 2
+    D, N, E, k = 1024, 14 * a.batch, 4, 2
     NK = N * k
     bf = torch.bfloat16
     x = torch.randn(N, D, device=dev).to(bf)
-    idx = torch.tensor([[1, 2]], dtype=torch.int32, device=dev); w = torch.tensor([[0.6, 0.4]], device=dev)
+    idx = torch.tensor([[1, 2], [0, 3]] * (a.batch // 2), dtype=torch.int32, device=dev); w = torch.tensor([[0.6, 0.4]] * a.batch, device=dev)   # all 4 experts loaded evenly
     ml = L.ModeMetaLayout(); lib.mode_moe_meta_layout(N, E, k, C.byref(ml))
     meta = torch.empty(ml.total_words, dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    L.check(lib.mode_dit_dispatch(idx.data_ptr(), w.data_ptr(), 1, k, 1, N, N, E, k, meta.data_ptr(), st))
+    L.check(lib.mode_dit_dispatch(idx.data_ptr(), w.data_ptr(), 1, a.batch * k, a.batch, 14, N, E, k, meta.data_ptr(), st))
     mp = meta.data_ptr()
     nl = 6   # cycle through several weight sets so weights are not L2-hot between launches (as in the real layer loop)
     wqkv = [torch.randn(3 * D, D, device=dev).to(bf) * 0.03 for _ in range(nl)]; bqkv = torch.randn(3 * D, device=dev)
