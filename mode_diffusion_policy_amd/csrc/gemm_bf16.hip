@@ -31,18 +31,6 @@ namespace mode {
 
 constexpr int BK = 64;
 
-struct GemmParams {
-  const uint16_t* A; long lda;
-  const uint16_t* W; long ldw; long w_estride;
-  const float* bias; long bias_estride;
-  const float* resid; long ldr;
-  void* C; long ldc;
-  const int* a_rows; const int* offsets; int E;
-  int M, N, K, m_tiles, n_tiles;
-  int split_k; long split_stride;     // split-K: blockIdx.y = K-slice, output slab = C + slice*split_stride elements
-  const int* koffs; long c_gstride;   // K-groups (weight gradients per expert): blockIdx.z = group, K range [koffs[z], koffs[z+1])
-};
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

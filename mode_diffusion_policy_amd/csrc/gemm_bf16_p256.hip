@@ -16,18 +16,6 @@
 
 namespace mode {
 
-struct GemmParams {   // identical to gemm_bf16.hip's
-  const uint16_t* A; long lda;
-  const uint16_t* W; long ldw; long w_estride;
-  const float* bias; long bias_estride;
-  const float* resid; long ldr;
-  void* C; long ldc;
-  const int* a_rows; const int* offsets; int E;
-  int M, N, K, m_tiles, n_tiles;
-  int split_k; long split_stride;
-  const int* koffs; long c_gstride;
-};
-
 template <int N>
 __device__ __forceinline__ void p_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int N>

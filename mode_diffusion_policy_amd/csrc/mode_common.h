@@ -51,6 +51,19 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
   return base + (b >> 3);
 }
 
+// Kernel argument block shared by the forward bf16 GEMM kernels (gemm_bf16.hip, gemm_bf16_p256.hip)
+struct GemmParams {
+  const uint16_t* A; long lda;
+  const uint16_t* W; long ldw; long w_estride;
+  const float* bias; long bias_estride;
+  const float* resid; long ldr;
+  void* C; long ldc;
+  const int* a_rows; const int* offsets; int E;
+  int M, N, K, m_tiles, n_tiles;
+  int split_k; long split_stride;     // split-K: blockIdx.y = K-slice, output slab = C + slice*split_stride elements
+  const int* koffs; long c_gstride;   // K-groups: blockIdx.z = group, K range [koffs[z], koffs[z+1])
+};
+
 #define MODE_LAUNCH_CHECK()                                  \
   do {                                                       \
     hipError_t e__ = hipGetLastError();                      \
