@@ -165,13 +165,15 @@ def train_bench(args, world, rank, device, dist):
     img = torch.randn(B, 2, C2["obs_dim"], generator=g).to(device); goal = torch.randn(B, 1, C2["goal_dim"], generator=g).to(device)
     acts = torch.randn(B, 10, 7, generator=g).to(device); noise = torch.randn(B, 10, 7, generator=g).to(device)
     opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)         # mode_agent.yaml:24-29, two groups as mode_agent.py:365-384
+    if os.environ.get("MODE_ADAMW_BLOCKS"):
+        m.engine.lib.mode_set_option(b"adamw_blocks", int(os.environ["MODE_ADAMW_BLOCKS"]))
     red = ArenaGradReducer.for_model(m) if world > 1 else None
 
     def step():
         sig = rand_log_logistic((B,), loc=math.log(SIGMA_DATA), scale=0.5, min_value=SIGMA_MIN, max_value=SIGMA_MAX, device=device)
         loss, _ = den.loss({"state_images": img}, acts, goal, noise, sig)
         loss.backward()
-        opt.step(grad_scale=red.reduce() if red is not None else 1.0)
+        opt.step(reducer=red, overlap=os.environ.get("MODE_OPT_OVERLAP", "0") == "1")   # per-block: exchange (RCCL) -> AdamW underneath the remaining backward
         return loss
     for _ in range(max(args.warmup, 1)):
         loss = step()

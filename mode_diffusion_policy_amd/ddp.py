@@ -219,6 +219,34 @@ class ArenaGradReducer:
             red.slices += [(0, first, None), (last_end, ar.bounds["no_decay"], None)]   # stacked routers / gains; embeddings, head, biases
         return red
 
+    def reduce_async(self):
+        """Queue every slice's collective on the communication stream (each behind its block event) WITHOUT joining the current stream;
+        returns {(lo, hi): torch.cuda.Event recorded after that slice's exchange} so that an optimizer can chain per-slice updates
+        (``FusedAdamW.step(reducer=...)``).  The caller is responsible for the final join."""
+        assert self._comm_stream is not None, "reduce_async needs CUDA streams"
+        cur = torch.cuda.current_stream()
+        done = {}
+        for sl in self.slices:
+            lo, hi, ev = sl if len(sl) == 3 else (sl[0], sl[1], None)
+            if ev is not None:
+                self._comm_stream.wait_event(ev)
+            else:
+                self._comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self._comm_stream):
+                g = self.grad[lo:hi]
+                if self.mode == "rs_ag" and (hi - lo) % self.world == 0:
+                    shard = g.view(self.world, -1)[dist.get_rank(self.pg)]
+                    dist.reduce_scatter_tensor(shard, g, op=dist.ReduceOp.SUM, group=self.pg)
+                    dist.all_gather_into_tensor(g, shard, group=self.pg)
+                else:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+                if self.average:
+                    g.div_(self.world)
+                e = torch.cuda.Event()
+                e.record(self._comm_stream)
+                done[(lo, hi)] = e
+        return done
+
     def reduce(self) -> float:
         """Sum (or average) the gradient arena over ranks; returns the scale the optimizer still has to apply.  Call right after
         ``loss.backward()`` returned: the backward kernels are still executing, the collectives queue up behind their events."""

@@ -123,8 +123,8 @@ def test_parameters_live_in_one_arena_and_state_dict_is_untouched():
     assert m.engine.arena is not ar and rel(F3, F2) < 1e-6
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_fused_adamw_matches_torch_adamw(dtype):
+@pytest.mark.parametrize("dtype,overlap", [("fp32", False), ("bf16", False), ("bf16", True)])
+def test_fused_adamw_matches_torch_adamw(dtype, overlap):
     """FusedAdamW over the arena == torch.optim.AdamW with MoDEAgent.get_optim_groups' two groups (mode_agent.py:365-392)."""
     from mode_diffusion_policy_amd.ddp import optimizer_param_groups
     from mode_diffusion_policy_amd.optim import FusedAdamW
@@ -145,7 +145,7 @@ def test_fused_adamw_matches_torch_adamw(dtype):
         loss.backward()
         for n, p in m.named_parameters():
             ref[n].grad = None if p.grad is None else p.grad.detach().clone()
-        opt.step()
+        opt.step(overlap=overlap)                           # overlap: per-block updates on a side stream behind the backward's block events
         topt.step()
         for n, p in m.named_parameters():
             assert rel(p.detach(), ref[n].detach()) < 2e-6, (step, n)
