@@ -256,6 +256,38 @@ int mode_gelu_bwd(const float* pre, const float* dout, float* dpre, int64_t n, v
 int mode_moe_router_bwd(const float* dw, const int32_t* idx, const float* probs, int B, int T, int E, int k, int normalize,
                         int idx_per_token, float* dlogits, void* stream);
 int mode_sigma_embed_bwd(const float* de1, const float* sigma, int B, int D, float* dw, float* db, void* stream);
+/* ------------------------------------------------------------------------------------------------------------------
+ * mode_moe_grouped_mlp_fwd / _bwd — the expert MLP of one MoE block on the SORTED dispatch order (SURVEY §8b minimum exports).
+ * Replaces NoiseBlockMoE's per-expert Python loop `for idx in range(E): x[token_indices] -> expert(...)` (modedit.py:557-566) with
+ * FusedMLPV2 = Linear(D,8D) -> SwishGLU -> Dropout -> Linear(4D,D) (modedit.py:21-60, 83-90), and autograd's backward of it.
+ *   fwd:  y[s] = W2_e ( swiglu(W1_e x[perm[s]] + b1_e) * dropmask ),  s in expert e's segment [offsets[e], offsets[e+1])
+ *         p (optional, training) receives the pre-activation [NK, 8D] = [value | gate]; h the post-SwishGLU(+dropout) [NK, 4D].
+ *   bwd:  dy [NK, D] (compute dtype) -> dxs [NK, D] fp32 (gradient wrt the GATHERED rows: the caller scatters/gather-sums it back
+ *         to tokens, e.g. mode_rmsnorm_bwd's G/pos input), dw1 [E,8D,D], db1 [E,8D], dw2 [E,D,4D] fp32 (overwritten).
+ * x [N, D], w1 [E,8D,D], w2 [E,D,4D], p, h, dy in the compute dtype (bf16 | fp32); perm / offsets from mode_moe_dispatch_meta.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ModeGroupedMlpDesc {
+  int32_t dtype; int32_t N, D, E, k;
+  const void* x; const int32_t* perm; const int32_t* offsets;
+  const void* w1; const float* b1; const void* w2;
+  void* p;                        /* [NK, 8D] pre-activation: out of fwd when non-NULL (then h = swiglu(p)), in of bwd              */
+  void* h;                        /* [NK, 4D] out of fwd, in of bwd                                                                  */
+  void* y; int32_t y_dtype;       /* [NK, D]  out of fwd (bf16 | fp32)                                                               */
+  uint32_t seed; float p_drop;    /* expert dropout (hash mask; 0 = off)                                                             */
+  const void* dy;                 /* bwd: [NK, D] compute dtype                                                                      */
+  float* dxs; float* dw1; float* db1; float* dw2;      /* bwd outputs                                                               */
+} ModeGroupedMlpDesc;
+size_t mode_moe_grouped_mlp_workspace_bytes(int N, int D, int E, int k, int dtype);          /* backward scratch (dH, dP, column sums) */
+int mode_moe_grouped_mlp_fwd(const ModeGroupedMlpDesc* d, void* stream);
+int mode_moe_grouped_mlp_bwd(const ModeGroupedMlpDesc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* mode_rmsnorm_cond_bwd — complete backward of y = RMSNorm(x; g) (+ cond[row / rows_per_cond]) (modedit.py:72-80, 532): dx [rows, D],
+ * dg [D] and (when dcond != NULL) dcond [rows / rows_per_cond, D] = sum of dy over the rows sharing a conditioning vector.  Thin
+ * composite of mode_rmsnorm_bwd + mode_colsum (both deterministic). */
+size_t mode_rmsnorm_cond_bwd_workspace_bytes(int rows, int D, int rows_per_cond);
+int mode_rmsnorm_cond_bwd(const float* x, const float* g, const float* dy, int rows, int D, int rows_per_cond, float eps, float* dx,
+                          float* dg, float* dcond, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Router MLP (RouterCond.router: Linear(D,2D) -> GELU -> Linear(2D,E), modedit.py:190-200) for ALL L layers in one launch each:
  * mode_router_logits:  logits[l][r][e] = b3[l][e] + sum_n hid[r][l*K + n] * w3[l][e][n]   (hid row stride ld_hid, K = 2D);
  * mode_router_mlp_bwd: dpre[b][l][n] = (sum_e dlog[l][b][e] w3[l][e][n]) * gelu'(pre[b][l][n]);  dw3[l][e][n] = sum_b dlog[l][b][e] gelu(pre[b][l][n]).

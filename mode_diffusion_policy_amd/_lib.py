@@ -76,6 +76,12 @@ class ModeStashLayout(C.Structure):
                                      "total_bytes")]
 
 
+class ModeGroupedMlpDesc(C.Structure):
+    _fields_ = [("dtype", c_i32), ("N", c_i32), ("D", c_i32), ("E", c_i32), ("k", c_i32), ("x", c_vp), ("perm", c_vp), ("offsets", c_vp),
+                ("w1", c_vp), ("b1", c_vp), ("w2", c_vp), ("p", c_vp), ("h", c_vp), ("y", c_vp), ("y_dtype", c_i32), ("seed", c_u32),
+                ("p_drop", c_f32), ("dy", c_vp), ("dxs", c_vp), ("dw1", c_vp), ("db1", c_vp), ("dw2", c_vp)]
+
+
 class ModeTrainArgs(C.Structure):
     _fields_ = [("B", c_i32), ("dtype", c_i32), ("seed", c_u32), ("attn_pdrop", c_f32), ("mlp_pdrop", c_f32), ("sigma", c_vp), ("e1", c_vp),
                 ("emb_t", c_vp), ("cond", c_vp), ("goal_in_cond", c_i32), ("state_images", c_vp), ("goals", c_vp), ("goal_e", c_vp),
@@ -149,6 +155,11 @@ PROTOTYPES = {
     "mode_dit_train_stash_layout": (C.c_int, [P(ModeDims), C.c_int, C.c_int, P(ModeStashLayout)]),
     "mode_dit_train_workspace_bytes": (c_sz, [P(ModeDims), C.c_int, C.c_int]),
     "mode_dit_forward_train": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeTrainArgs), c_vp, c_sz, c_vp]),
+    "mode_moe_grouped_mlp_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "mode_moe_grouped_mlp_fwd": (C.c_int, [P(ModeGroupedMlpDesc), c_vp]),
+    "mode_moe_grouped_mlp_bwd": (C.c_int, [P(ModeGroupedMlpDesc), c_vp, c_sz, c_vp]),
+    "mode_rmsnorm_cond_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
+    "mode_rmsnorm_cond_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mode_router_logits": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mode_router_mlp_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "mode_iota_i32": (C.c_int, [c_vp, c_i32, c_i32, c_vp]),

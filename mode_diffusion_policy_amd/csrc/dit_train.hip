@@ -443,3 +443,115 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
 #undef ZERO
   return MODE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stand-alone composites named in the scope contract (SURVEY §8b "minimum exports"): the same kernels the whole-model chains use,
+// callable (and testable against torch.autograd) on one MoE block / one norm.
+namespace {
+struct MlpWs { size_t dh, dp, csw, total; size_t csw_bytes; };
+MlpWs mlp_ws(int N, int D, int E, int k, int dtype) {
+  const size_t esz = dtype == MODE_BF16 ? 2 : 4, NK = (size_t)N * k;
+  MlpWs w{};
+  Take t;
+  w.dh = t(NK * 4 * D * esz); w.dp = t(NK * 8 * D * esz);
+  w.csw_bytes = mode_colsum_workspace_bytes((int)NK, 8 * D, E) + 4096;
+  w.csw = t(w.csw_bytes);
+  w.total = t.o;
+  return w;
+}
+int mlp_check(const ModeGroupedMlpDesc* d) {
+  if (!d || !d->x || !d->perm || !d->offsets || !d->w1 || !d->b1 || !d->w2 || !d->h) return MODE_ERR_BAD_ARG;
+  if (d->N < 0 || d->D <= 0 || d->E <= 0 || d->k <= 0 || d->k > d->E) return MODE_ERR_BAD_ARG;
+  if (d->dtype != MODE_BF16 && d->dtype != MODE_F32) return MODE_ERR_BAD_ARG;
+  return MODE_OK;
+}
+}  // namespace
+
+extern "C" size_t mode_moe_grouped_mlp_workspace_bytes(int N, int D, int E, int k, int dtype) {
+  if (N < 0 || D <= 0 || E <= 0 || k <= 0) return 0;
+  return mlp_ws(N, D, E, k, dtype).total;
+}
+
+extern "C" int mode_moe_grouped_mlp_fwd(const ModeGroupedMlpDesc* d, void* stream) {
+  int rc = mlp_check(d);
+  if (rc) return rc;
+  if (!d->y) return MODE_ERR_BAD_ARG;
+  const int D = d->D, NK = d->N * d->k, dt = d->dtype;
+  if (NK == 0) return MODE_OK;
+  ModeGemmDesc g;
+  if (d->p) {                                          // training: keep the pre-activation, SwishGLU (+dropout) as its own pass
+    g = gdesc(dt, MODE_EPI_BIAS, dt, NK, 8 * D, D, d->x, D, d->w1, D, d->p, 8 * D);
+    g.bias = d->b1; g.bias_expert_stride = 8L * D; g.w_expert_stride = 8L * D * D; g.a_rows = d->perm; g.expert_offsets = d->offsets;
+    g.num_experts = d->E;
+    if ((rc = mode_gemm(&g, stream))) return rc;
+    if ((rc = mode_swiglu_fwd(d->p, d->h, NK, 4 * D, dt, d->seed, d->p_drop, stream))) return rc;
+  } else {                                             // inference: bias + SwishGLU fused into the GEMM epilogue
+    if (d->p_drop != 0.f) return MODE_ERR_BAD_ARG;
+    g = gdesc(dt, MODE_EPI_SWIGLU, dt, NK, 4 * D, D, d->x, D, d->w1, D, d->h, 4 * D);
+    g.bias = d->b1; g.bias_expert_stride = 8L * D; g.w_expert_stride = 8L * D * D; g.a_rows = d->perm; g.expert_offsets = d->offsets;
+    g.num_experts = d->E;
+    if ((rc = mode_gemm(&g, stream))) return rc;
+  }
+  g = gdesc(dt, MODE_EPI_NONE, d->y_dtype, NK, D, 4 * D, d->h, 4 * D, d->w2, 4 * D, d->y, D);
+  g.w_expert_stride = 4L * D * D; g.expert_offsets = d->offsets; g.num_experts = d->E;
+  return mode_gemm(&g, stream);
+}
+
+extern "C" int mode_moe_grouped_mlp_bwd(const ModeGroupedMlpDesc* d, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = mlp_check(d);
+  if (rc) return rc;
+  if (!d->p || !d->dy || !d->dxs || !d->dw1 || !d->db1 || !d->dw2 || !workspace) return MODE_ERR_BAD_ARG;
+  if (d->dtype != MODE_BF16 || d->D % 8) return MODE_ERR_UNSUPPORTED;       // fp32 parity mode goes through mode_dit_backward's transpose path
+  const int D = d->D, E = d->E, NK = d->N * d->k, dt = d->dtype;
+  const MlpWs W = mlp_ws(d->N, D, E, d->k, dt);
+  if (workspace_bytes < W.total) return MODE_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  void* dH = ws + W.dh; void* dP = ws + W.dp;
+  // down-projection: dH = dY W2 ; dW2_e = dY_e^T H_e
+  ModeGemmDesc g = gdesc(dt, MODE_EPI_NONE, dt, NK, 4 * D, D, d->dy, D, d->w2, 4 * D, dH, 4 * D);
+  g.w_expert_stride = 4L * D * D; g.expert_offsets = d->offsets; g.num_experts = E; g.flags = MODE_GEMM_W_KN;
+  if ((rc = mode_gemm(&g, stream))) return rc;
+  g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, 4 * D, NK, d->dy, D, d->h, 4 * D, d->dw2, 4 * D);
+  g.k_group_offsets = d->offsets; g.num_k_groups = E; g.c_group_stride = 4L * D * D; g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
+  if ((rc = mode_gemm(&g, stream))) return rc;
+  // SwishGLU (+dropout) backward and the bias gradient
+  if ((rc = mode_swiglu_bwd(d->p, dH, dP, NK, 4 * D, dt, d->seed, d->p_drop, stream))) return rc;
+  if ((rc = mode_colsum(dP, 8 * D, NK, 8 * D, dt, d->offsets, 0, E, d->db1, 0, ws + W.csw, W.csw_bytes, stream))) return rc;
+  // up-projection: dX (sorted rows) = dP W1 ; dW1_e = dP_e^T X_e (rows gathered through perm)
+  g = gdesc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 8 * D, dP, 8 * D, d->w1, D, d->dxs, D);
+  g.w_expert_stride = 8L * D * D; g.expert_offsets = d->offsets; g.num_experts = E; g.flags = MODE_GEMM_W_KN;
+  if ((rc = mode_gemm(&g, stream))) return rc;
+  g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 8 * D, D, NK, dP, 8 * D, d->x, D, d->dw1, D);
+  g.k_group_offsets = d->offsets; g.num_k_groups = E; g.c_group_stride = 8L * D * D; g.w_rows = d->perm;
+  g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
+  return mode_gemm(&g, stream);
+}
+
+extern "C" size_t mode_rmsnorm_cond_bwd_workspace_bytes(int rows, int D, int rows_per_cond) {
+  if (rows < 0 || D <= 0) return 0;
+  const size_t nblk4 = ((size_t)rows + 3) / 4;
+  size_t cs = mode_colsum_workspace_bytes((int)nblk4, D, 1);
+  const size_t c2 = rows_per_cond > 0 ? mode_colsum_workspace_bytes(rows, D, (rows + rows_per_cond - 1) / rows_per_cond) : 0;
+  if (c2 > cs) cs = c2;
+  return align_up(nblk4 * D * 4, 256) + cs + 4096;
+}
+
+extern "C" int mode_rmsnorm_cond_bwd(const float* x, const float* g, const float* dy, int rows, int D, int rows_per_cond, float eps, float* dx,
+                                     float* dg, float* dcond, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !g || !dy || !dx || !dg || !workspace || rows < 0 || D <= 0) return MODE_ERR_BAD_ARG;
+  if (dcond && rows_per_cond <= 0) return MODE_ERR_BAD_ARG;
+  if (workspace_bytes < mode_rmsnorm_cond_bwd_workspace_bytes(rows, D, rows_per_cond)) return MODE_ERR_WORKSPACE;
+  if (rows == 0) return MODE_OK;
+  const int nblk4 = (rows + 3) / 4;
+  float* dgp = (float*)workspace;
+  char* csw = (char*)workspace + align_up((size_t)nblk4 * D * 4, 256);
+  const size_t cswb = workspace_bytes - align_up((size_t)nblk4 * D * 4, 256);
+  int rc = mode_rmsnorm_bwd(x, g, dy, nullptr, nullptr, nullptr, 0, rows, D, eps, dx, 0, dgp, nullptr, nullptr, MODE_F32, stream);
+  if (rc) return rc;
+  if ((rc = mode_colsum(dgp, D, nblk4, D, MODE_F32, nullptr, 0, 1, dg, 0, csw, cswb, stream))) return rc;
+  if (dcond) {
+    const int nseg = (rows + rows_per_cond - 1) / rows_per_cond;
+    if ((rc = mode_colsum(dy, D, rows, D, MODE_F32, nullptr, rows_per_cond, nseg, dcond, 0, csw, cswb, stream))) return rc;
+  }
+  return MODE_OK;
+}

@@ -267,3 +267,82 @@ def test_iota_offsets():
     out = torch.full((13,), -1, dtype=torch.int32, device=dev())
     L.check(L.load().mode_iota_i32(out.data_ptr(), 13, 2048, H.stream()))
     assert torch.equal(out.cpu(), torch.arange(13, dtype=torch.int32) * 2048)
+
+
+@pytest.mark.parametrize("N_tok,E,k,D,p_drop", [(448, 4, 2, 256, 0.0), (70, 4, 2, 64, 0.0), (1792, 4, 2, 128, 0.0), (112, 2, 1, 256, 0.0)])
+def test_moe_grouped_mlp_fwd_bwd(N_tok, E, k, D, p_drop):
+    """SURVEY §8b export `moe_grouped_mlp_fwd/_bwd`: the expert MLP of one block on the sorted dispatch order vs fp32 autograd of the
+    reference's per-expert loop (modedit.py:557-566 with FusedMLPV2 / SwishGLU) on the same bf16-rounded operands."""
+    lib = L.load()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(N_tok + D)
+    x = rnd(N_tok, D, seed=1).to(bf)
+    w1 = (rnd(E, 8 * D, D, seed=2) * D ** -0.5).to(bf); b1 = rnd(E, 8 * D, seed=3) * 0.1
+    w2 = (rnd(E, D, 4 * D, seed=4) * (4 * D) ** -0.5).to(bf)
+    logits = torch.randn(N_tok, E, generator=g)
+    _, _, idx, w = H.route_topk(logits.to(dev()), k)
+    meta = H.dispatch_meta(idx, w, 1, N_tok, E)
+    perm, offsets = meta["perm"], meta["offsets"]
+    NK = N_tok * k
+    xd, w1d, b1d, w2d = x.to(dev()), w1.to(dev()), b1.to(dev()), w2.to(dev())
+    pbuf = torch.empty(NK, 8 * D, dtype=bf, device=dev()); hbuf = torch.empty(NK, 4 * D, dtype=bf, device=dev())
+    y = torch.full((NK, D), float("nan"), device=dev())
+    dy = rnd(NK, D, seed=5).to(bf).to(dev())
+    dxs = torch.full((NK, D), float("nan"), device=dev()); dw1 = torch.full((E, 8 * D, D), float("nan"), device=dev())
+    db1 = torch.full((E, 8 * D), float("nan"), device=dev()); dw2 = torch.full((E, D, 4 * D), float("nan"), device=dev())
+    d = L.ModeGroupedMlpDesc(dtype=L.MODE_BF16, N=N_tok, D=D, E=E, k=k, x=xd.data_ptr(), perm=perm.data_ptr(), offsets=offsets.data_ptr(),
+                             w1=w1d.data_ptr(), b1=b1d.data_ptr(), w2=w2d.data_ptr(), p=pbuf.data_ptr(), h=hbuf.data_ptr(), y=y.data_ptr(),
+                             y_dtype=L.MODE_F32, seed=0, p_drop=p_drop, dy=dy.data_ptr(), dxs=dxs.data_ptr(), dw1=dw1.data_ptr(),
+                             db1=db1.data_ptr(), dw2=dw2.data_ptr())
+    L.check(lib.mode_moe_grouped_mlp_fwd(C.byref(d), H.stream()), "mlp fwd")
+    # inference form (fused SwiGLU epilogue, no pre-activation kept) must agree with the training form
+    y2 = torch.full((NK, D), float("nan"), device=dev()); h2 = torch.empty_like(hbuf)
+    d2 = L.ModeGroupedMlpDesc(dtype=L.MODE_BF16, N=N_tok, D=D, E=E, k=k, x=xd.data_ptr(), perm=perm.data_ptr(), offsets=offsets.data_ptr(),
+                              w1=w1d.data_ptr(), b1=b1d.data_ptr(), w2=w2d.data_ptr(), p=None, h=h2.data_ptr(), y=y2.data_ptr(), y_dtype=L.MODE_F32)
+    L.check(lib.mode_moe_grouped_mlp_fwd(C.byref(d2), H.stream()), "mlp fwd (fused)")
+    wsb = lib.mode_moe_grouped_mlp_workspace_bytes(N_tok, D, E, k, L.MODE_BF16)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    L.check(lib.mode_moe_grouped_mlp_bwd(C.byref(d), ws.data_ptr(), wsb, H.stream()), "mlp bwd")
+    # fp32 autograd reference on the sorted rows
+    xs = x.float()[perm.cpu().long()].requires_grad_(True)
+    W1 = w1.float().requires_grad_(True); B1 = b1.clone().requires_grad_(True); W2 = w2.float().requires_grad_(True)
+    off = offsets.cpu().tolist()
+    outs = []
+    for e in range(E):
+        seg = xs[off[e]:off[e + 1]]
+        pre = seg @ W1[e].t() + B1[e]
+        val, gate = pre.tensor_split(2, dim=-1)
+        outs.append((val * torch.nn.functional.silu(gate)) @ W2[e].t())
+    ref = torch.cat(outs)
+    ref.backward(dy.float().cpu())
+    assert rel(y, ref.detach()) < 1e-2 and rel(y2, ref.detach()) < 1e-2 and rel(y2, y) < 6e-3
+    assert rel(dxs, xs.grad) < 1.5e-2
+    for got, want, name in ((dw1, W1.grad, "dw1"), (db1, B1.grad, "db1"), (dw2, W2.grad, "dw2")):
+        for e in range(E):
+            if off[e + 1] > off[e]:
+                assert rel(got[e], want[e]) < 1.5e-2, (name, e)
+            else:
+                assert float(got[e].abs().max()) == 0.0, (name, e)            # un-routed expert: exact zeros, not garbage
+
+
+@pytest.mark.parametrize("rows,D,rpc", [(1792, 1024, 14), (70, 64, 14), (33, 128, 0)])
+def test_rmsnorm_cond_bwd_composite(rows, D, rpc):
+    lib = L.load()
+    x = rnd(rows, D, seed=1, scale=2.0).requires_grad_(True); g = (1 + 0.1 * rnd(D, seed=2)).requires_grad_(True)
+    nc = (rows + rpc - 1) // rpc if rpc else 0
+    cond = rnd(nc, D, seed=3).requires_grad_(True) if rpc else None
+    y = O.rmsnorm(x, g)
+    if rpc:
+        y = y + cond[torch.arange(rows) // rpc]
+    dy = rnd(rows, D, seed=4)
+    y.backward(dy)
+    xd, gd, dyd = x.detach().to(dev()), g.detach().to(dev()), dy.to(dev())
+    dx = torch.full((rows, D), float("nan"), device=dev()); dg = torch.full((D,), float("nan"), device=dev())
+    dc = torch.full((nc, D), float("nan"), device=dev()) if rpc else None
+    wsb = lib.mode_rmsnorm_cond_bwd_workspace_bytes(rows, D, rpc)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    L.check(lib.mode_rmsnorm_cond_bwd(xd.data_ptr(), gd.data_ptr(), dyd.data_ptr(), rows, D, rpc, 1e-6, dx.data_ptr(), dg.data_ptr(),
+                                      None if dc is None else dc.data_ptr(), ws.data_ptr(), wsb, H.stream()), "rmsnorm_cond_bwd")
+    assert rel(dx, x.grad) < 1e-5 and rel(dg, g.grad) < 1e-5
+    if rpc:
+        assert rel(dc, cond.grad) < 1e-5
