@@ -299,9 +299,11 @@ int mode_iota_i32(int32_t* out, int n, int step, void* stream);                 
 /* Fused AdamW over a flat fp32 slice (p, g, m, v: n elements, n % 4 == 0, 16-byte aligned).  Replaces torch.optim.AdamW as configured by
  * MoDEAgent.configure_optimizers (mode/models/mode_agent.py:365-392): decoupled weight decay, bias correction by `step` (1-based),
  * g is scaled by grad_scale first (1/world for a summed data-parallel gradient).  lp_bf16 (nullable) receives the updated weights
- * rounded to bf16 — the compute shadow of the next forward. */
+ * rounded to bf16 — the compute shadow of the next forward.  ema (nullable): exponential moving average of the weights, updated in the
+ * same pass with the updated weight, e -= ema_rate * (e - w), ema_rate = 1 - decay (EMA callback, mode/callbacks/ema.py:83-126). */
 int mode_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, int step, float grad_scale, void* lp_bf16, void* stream);
+                    float weight_decay, int step, float grad_scale, void* lp_bf16, float* ema, float ema_rate, void* stream);
+int mode_ema_update(float* ema, const float* p, int64_t n, float rate, void* stream);      /* stand-alone EMA pass (foreign optimizers) */
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Whole-denoiser forward: the launch chain of one MoDeDiT.forward (modedit.py:741-821) [+ GCDenoiser.forward scalings

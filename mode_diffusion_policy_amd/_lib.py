@@ -163,7 +163,9 @@ PROTOTYPES = {
     "mode_router_logits": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mode_router_mlp_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "mode_iota_i32": (C.c_int, [c_vp, c_i32, c_i32, c_vp]),
-    "mode_adamw_step": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i32, C.c_float, c_vp, c_vp]),
+    "mode_adamw_step": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i32, C.c_float, c_vp, c_vp,
+                                  C.c_float, c_vp]),
+    "mode_ema_update": (C.c_int, [c_vp, c_vp, c_i64, C.c_float, c_vp]),
     "mode_dit_backward": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeModelWeightsT), P(ModeTrainArgs), c_vp, c_vp, P(ModeModelGrads),
                                     c_vp, c_sz, c_vp]),
     "mode_dit_forward": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeForwardArgs), c_vp, c_sz, c_vp]),

@@ -525,7 +525,7 @@ extern "C" int mode_sigma_embed_bwd(const float* de1, const float* sigma, int B,
 // low-precision weights the next forward reads never need a separate cast pass.  Arithmetic follows torch's single-tensor AdamW order.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     long n4, float decay, float b1, float b2, float eps, float step_size, float inv_bc2_sqrt,
-                                                    float gscale, uint16_t* __restrict__ lp) {
+                                                    float gscale, uint16_t* __restrict__ lp, float* __restrict__ ema, float ema_rate) {
   // pure stream: every byte is touched once per step -> non-temporal accesses, two float4 groups in flight per thread and stream
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
@@ -559,6 +559,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       __builtin_nontemporal_store(P[u], reinterpret_cast<f4*>(p) + i);
       __builtin_nontemporal_store(M[u], reinterpret_cast<f4*>(m) + i);
       __builtin_nontemporal_store(V[u], reinterpret_cast<f4*>(v) + i);
+      if (ema) {                                       // EMA of the weights (mode/callbacks/ema.py:119-126): e -= (1 - decay) * (e - w)
+        f4 Ev = __builtin_nontemporal_load(reinterpret_cast<const f4*>(ema) + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ev[j] = Ev[j] - ema_rate * (Ev[j] - P[u][j]);
+        __builtin_nontemporal_store(Ev, reinterpret_cast<f4*>(ema) + i);
+      }
       if (lp) {
         u2 o; o[0] = pack_bf16x2(P[u][0], P[u][1]); o[1] = pack_bf16x2(P[u][2], P[u][3]);
         *(reinterpret_cast<u2*>(lp) + i) = o;           // the bf16 shadow is re-read by the next forward: normal (cached) store
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 namespace mode { int g_adamw_blocks = 0; }   // "adamw_blocks" option: cap on the workgroups of one AdamW launch (0 = 2048)
 
 extern "C" int mode_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                               float weight_decay, int step, float grad_scale, void* lp_bf16, void* stream) {
+                               float weight_decay, int step, float grad_scale, void* lp_bf16, float* ema, float ema_rate, void* stream) {
   if (n == 0) return MODE_OK;
   if (!p || !g || !m || !v || n < 0 || n % 4 || step < 1 || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) || ((uintptr_t)lp_bf16 & 7))
     return MODE_ERR_BAD_ARG;
@@ -578,7 +584,7 @@ extern "C" int mode_adamw_step(float* p, const float* g, float* m, float* v, int
   const long n4 = n / 4;
   const int blocks = (int)std::min<long>((n4 + 511) / 512, g_adamw_blocks > 0 ? g_adamw_blocks : 256 * 8);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, 1.f - lr * weight_decay, beta1, beta2, eps,
-                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, (uint16_t*)lp_bf16);
+                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, (uint16_t*)lp_bf16, ema, ema_rate);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
@@ -602,6 +608,26 @@ extern "C" int mode_iota_i32(int32_t* out, int n, int step, void* stream) {
   if (!out || n < 0) return MODE_ERR_BAD_ARG;
   if (n == 0) return MODE_OK;
   hipLaunchKernelGGL(iota_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, n, step);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+namespace mode {
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, long n4, float rate) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 e = reinterpret_cast<float4*>(ema)[i];
+    const float4 w = reinterpret_cast<const float4*>(p)[i];
+    e.x -= rate * (e.x - w.x); e.y -= rate * (e.y - w.y); e.z -= rate * (e.z - w.z); e.w -= rate * (e.w - w.w);
+    reinterpret_cast<float4*>(ema)[i] = e;
+  }
+}
+}  // namespace mode
+
+extern "C" int mode_ema_update(float* ema, const float* p, int64_t n, float rate, void* stream) {
+  if (n == 0) return MODE_OK;
+  if (!ema || !p || n < 0 || n % 4 || (((uintptr_t)ema | (uintptr_t)p) & 15)) return MODE_ERR_BAD_ARG;
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(mode::ema_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, ema, p, n4, rate);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }

@@ -30,6 +30,7 @@ class FusedAdamW:
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=eng.device)
         self.step_count = 0
         self._side = None
+        self._ema_now = (None, 0.0)
         self.param_groups = [dict(name="decay", lr=lr, betas=betas, eps=eps, weight_decay=weight_decay),
                              dict(name="no_decay", lr=lr, betas=betas, eps=eps, weight_decay=0.0)]
 
@@ -38,10 +39,12 @@ class FusedAdamW:
 
     def _launch(self, lo: int, hi: int, gp, lp, grad_scale: float) -> None:
         ar = self.arena
+        ema, rate = self._ema_now
         L.check(self.eng.lib.mode_adamw_step(ar.flat[lo:hi].data_ptr(), ar.grad[lo:hi].data_ptr(), self.exp_avg[lo:hi].data_ptr(),
                                              self.exp_avg_sq[lo:hi].data_ptr(), hi - lo, float(gp["lr"]), float(gp["betas"][0]),
                                              float(gp["betas"][1]), float(gp["eps"]), float(gp["weight_decay"]), self.step_count,
-                                             float(grad_scale), None if lp is None else lp[lo:hi].data_ptr(), _stream()), "adamw_step")
+                                             float(grad_scale), None if lp is None else lp[lo:hi].data_ptr(),
+                                             None if ema is None else ema.flat[lo:hi].data_ptr(), float(rate), _stream()), "adamw_step")
 
     def _block_slices(self):
         """[(lo, hi, layer)] of the per-block weight slices (arena order = backward order) and the remaining decay-region ranges."""
@@ -54,7 +57,7 @@ class FusedAdamW:
         return blocks, rest
 
     @torch.no_grad()
-    def step(self, grad_scale: float = 1.0, overlap: bool = False, reducer=None) -> None:
+    def step(self, grad_scale: float = 1.0, overlap: bool = False, reducer=None, ema=None) -> None:
         """One AdamW update of the whole arena.
 
         Default: (exchange gradients through ``reducer`` — its collectives overlap the backward —, then) two launches over the decay / no-decay
@@ -66,7 +69,10 @@ class FusedAdamW:
         backward only reads block l's weights, so updating later blocks early is safe).  Measured on MI355X: 16.1-16.7 ms per step at best
         (AdamW capped to 128-256 workgroups, ``mode_set_option("adamw_blocks", n)``) against 17.0-18.0 ms serial, but run-to-run spread up to
         21 ms — the streaming pass raises the memory latency the fill-bound GEMMs are sensitive to — hence not the default.  ``reducer`` (an ``ArenaGradReducer``)
-        chains the data-parallel exchange in front of each slice's update on the same events; its 1/world scale is applied here."""
+        chains the data-parallel exchange in front of each slice's update on the same events; its 1/world scale is applied here.
+
+        ``ema`` (an ``ArenaEMA``): the moving average of the weights is updated in the same pass whenever the callback's schedule says so
+        for this step (the reference's EMA callback runs right after every optimizer step, mode/callbacks/ema.py:128-142)."""
         eng = self.model.engine
         ar = eng.arena
         if ar is not self.arena:
@@ -74,6 +80,11 @@ class FusedAdamW:
         if ar.grad is None:
             raise RuntimeError("no gradients: run a training forward + backward first")
         self.step_count += 1
+        self._ema_now = (None, 0.0)
+        if ema is not None and ema.should_apply(self.step_count):
+            ema.ensure(ar)
+            self._ema_now = (ema, 1.0 - ema.get_decay(self.step_count))
+            ema.mark_applied(self.step_count)
         lp = ar.lp if eng.compute_dtype == "bf16" else None
         gd, gn = self.param_groups
         train = getattr(eng, "_train", None)
@@ -115,3 +126,97 @@ class FusedAdamW:
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
+
+
+class ArenaEMA:
+    """Exponential moving average of the denoiser weights over the flat arena (replaces the ``EMA`` Lightning callback,
+    mode/callbacks/ema.py:36-141, for the denoiser's parameters): ``e -= (1 - decay_t) * (e - w)`` with the callback's warm-up schedule
+    ``decay_t = clamp(1 - (1 + max(0, t - start_step - 1) / inv_gamma) ** -power, min_value, max_value)`` (its non-apex path — the apex
+    multi-tensor path with a constant decay does not exist on ROCm).  Fused into ``FusedAdamW.step(ema=...)`` (+8 B/element on the
+    optimizer stream) or applied on its own with ``update(step)`` after a foreign optimizer.  ``swap()`` exchanges live and averaged
+    weights in place (the callback's ``swap_model_weights`` around validation) — both directions keep the bf16 shadow coherent."""
+
+    def __init__(self, model, decay: float = 0.999, apply_ema_every_n_steps: int = 1, start_step: int = 0, inv_gamma: float = 1.0,
+                 power: float = 2 / 3, min_value: float = 0.0, max_value: float = 0.9999):
+        if not 0.0 <= decay <= 1.0:
+            raise ValueError("EMA decay value must be between 0 and 1")
+        self.model = model
+        self.decay, self.every, self.start_step = decay, apply_ema_every_n_steps, start_step
+        self.inv_gamma, self.power, self.min_value, self.max_value = inv_gamma, power, min_value, max_value
+        self.flat = None
+        self._cur_step = None
+
+    def get_decay(self, optimization_step: int) -> float:
+        step = max(0, optimization_step - self.start_step - 1)
+        value = 1 - (1 + step / self.inv_gamma) ** -self.power
+        return max(min(value, self.max_value), self.min_value)
+
+    def should_apply(self, step: int) -> bool:
+        return step != self._cur_step and step >= self.start_step and step % self.every == 0
+
+    def mark_applied(self, step: int) -> None:
+        self._cur_step = step
+
+    def ensure(self, arena) -> None:
+        if self.flat is None or self.flat.numel() != arena.flat.numel() or self.flat.device != arena.flat.device:
+            self.flat = arena.flat.detach().clone()                       # starts as a copy of the weights (on_train_start)
+
+    @torch.no_grad()
+    def update(self, step: int) -> None:
+        """Stand-alone EMA pass (when the optimizer is not FusedAdamW)."""
+        if not self.should_apply(step):
+            return
+        eng = self.model.engine
+        self.ensure(eng.arena)
+        n = eng.arena.bounds["total"]
+        L.check(eng.lib.mode_ema_update(self.flat.data_ptr(), eng.arena.flat.data_ptr(), n, 1.0 - self.get_decay(step), _stream()), "ema_update")
+        self.mark_applied(step)
+
+    @torch.no_grad()
+    def swap(self) -> None:
+        """Exchange the live weights with the averaged ones (call again to swap back)."""
+        eng = self.model.engine
+        self.ensure(eng.arena)
+        tmp = eng.arena.flat.clone()
+        eng.arena.flat.copy_(self.flat)
+        self.flat.copy_(tmp)
+        eng.weights_updated(lp_synced=False)
+
+
+class TriStageLR:
+    """Warm-up / hold / cosine-decay learning-rate schedule of the reference (mode/utils/lr_schedulers/tri_stage_scheduler.py:69-147, as
+    configured by conf/model/mode_agent.yaml lr_scheduler): linear from ``init_lr_scale * lr`` to ``lr`` over ``phase_ratio[0] * total_steps``,
+    hold for ``phase_ratio[1]``, cosine to ``final_lr_scale * lr`` over ``phase_ratio[2]``, then constant.  Works on any optimizer exposing
+    ``param_groups`` (``FusedAdamW`` or torch's)."""
+
+    def __init__(self, optimizer, lr: float, init_lr_scale: float = 0.01, final_lr_scale: float = 0.01, phase_ratio=(0.1, 0.4, 0.5),
+                 total_steps: int = 400000):
+        if isinstance(phase_ratio, str):
+            phase_ratio = tuple(float(x) for x in phase_ratio.strip("()[] ").split(","))
+        self.optimizer = optimizer
+        self.warmup_steps, self.hold_steps, self.decay_steps = (int(total_steps * r) for r in phase_ratio)
+        self.peak_lr, self.init_lr, self.final_lr = lr, init_lr_scale * lr, final_lr_scale * lr
+        self.update_step = 0
+        self.lr = self.init_lr
+
+    def lr_at(self, t: int) -> float:
+        import math
+        if t < self.warmup_steps:
+            return self.init_lr + (self.peak_lr - self.init_lr) / self.warmup_steps * t
+        t -= self.warmup_steps
+        if t < self.hold_steps:
+            return self.peak_lr
+        t -= self.hold_steps
+        if t <= self.decay_steps:
+            return self.final_lr + 0.5 * (self.peak_lr - self.final_lr) * (1 + math.cos(t / self.decay_steps * math.pi))
+        return self.final_lr
+
+    def step(self, val_loss=None) -> float:
+        self.lr = self.lr_at(self.update_step)
+        for g in self.optimizer.param_groups:
+            g["lr"] = self.lr
+        self.update_step += 1
+        return self.lr
+
+    def get_lr(self) -> float:
+        return self.lr

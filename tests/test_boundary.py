@@ -208,3 +208,21 @@ def test_arena_layout_regions_and_names():
     assert abs(float(ar.w["b_out"][0]) - (float(sd["out.bias"][0]) + 1.0)) < 1e-6            # Parameters ARE arena views
     m.double()
     assert not ar.owns(m)
+
+
+def test_tri_stage_lr_schedule():
+    """TriStageLR == the reference's warm-up / hold / cosine schedule (tri_stage_scheduler.py:100-147) at its stage boundaries."""
+    import math
+    from mode_diffusion_policy_amd.optim import TriStageLR
+
+    class _Opt:
+        param_groups = [{"lr": 0.0}, {"lr": 0.0}]
+    sch = TriStageLR(_Opt(), lr=1e-4, init_lr_scale=0.1, final_lr_scale=0.5, phase_ratio="(0.02, 0.08, 0.9)", total_steps=1000)
+    assert (sch.warmup_steps, sch.hold_steps, sch.decay_steps) == (20, 80, 900)
+    lrs = [sch.step() for _ in range(1100)]
+    assert abs(lrs[0] - 1e-5) < 1e-15 and abs(lrs[10] - (1e-5 + 9e-5 / 20 * 10)) < 1e-15        # linear warm-up from init_lr_scale * lr
+    assert lrs[20] == 1e-4 and lrs[99] == 1e-4                                                      # hold
+    assert abs(lrs[100] - 1e-4) < 1e-15                                                             # cosine starts at the peak
+    assert abs(lrs[100 + 450] - (5e-5 + 0.5 * 5e-5 * (1 + math.cos(0.5 * math.pi)))) < 1e-15
+    assert abs(lrs[1000] - 5e-5) < 1e-15 and lrs[1001] == 5e-5 and lrs[-1] == 5e-5                  # floor at final_lr_scale * lr
+    assert _Opt.param_groups[0]["lr"] == lrs[-1] == _Opt.param_groups[1]["lr"]

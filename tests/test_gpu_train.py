@@ -194,3 +194,42 @@ def test_arena_reducer_overlap_slices_and_events():
         assert scale == 0.5 and torch.equal(ar.grad, want)                                  # sum over the single rank = identity, deterministic backward
     finally:
         dist.destroy_process_group()
+
+
+def test_arena_ema_fused_standalone_and_swap():
+    """ArenaEMA == the EMA callback's non-apex update rule (mode/callbacks/ema.py:83-126: e -= (1 - decay_t)(e - w), warm-up decay schedule)
+    restated with torch on clones of the weights; fused into FusedAdamW.step and as a stand-alone pass; swap() round-trips bit-exactly."""
+    from mode_diffusion_policy_amd.optim import ArenaEMA, FusedAdamW
+    cfg, sd, m = build_train("c1e4", 41, "bf16")
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, 8, 3).items()}
+    den = M.GCDenoiser(m, 0.5).train()
+    sig = torch.full((8,), 0.9, device="cuda")
+    opt = FusedAdamW(m, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    ema = ArenaEMA(m, decay=0.999, apply_ema_every_n_steps=1, start_step=0)
+    ref = {n: p.detach().clone() for n, p in m.named_parameters()}                       # on_train_start: a copy of the weights
+    for step in range(1, 5):
+        loss, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
+        loss.backward()
+        if step % 2:
+            opt.step(ema=ema)                                                             # fused into the optimizer pass
+        else:
+            opt.step()
+            ema.update(step)                                                              # stand-alone pass after a (foreign) optimizer step
+        d = ema.get_decay(step)
+        for n, p in m.named_parameters():
+            ref[n] = ref[n] - (1.0 - d) * (ref[n] - p.detach())
+    assert abs(ema.get_decay(1) - 0.0) < 1e-12 and abs(ema.get_decay(3) - (1 - 3.0 ** (-2 / 3))) < 1e-12
+    from mode_diffusion_policy_amd.arena import param_views
+    views = param_views(m, {k: ema.flat[off: off + int(torch.Size(shp).numel())].view(shp) for k, shp, off in m.engine.arena.layout})
+    for n in ref:
+        assert rel(views[n], ref[n].reshape(views[n].shape)) < 1e-6, n
+    # swap(): evaluate with the averaged weights, then restore the live ones bit-exactly
+    m.eval()
+    live = m.engine.arena.flat.clone(); avg = ema.flat.clone()
+    F0 = m({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], sig).clone()
+    ema.swap()
+    assert torch.equal(m.engine.arena.flat, avg) and torch.equal(ema.flat, live)          # arena now holds the average, the EMA object the live weights
+    F1 = m({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], sig).clone()
+    ema.swap()
+    F2 = m({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], sig)
+    assert torch.equal(m.engine.arena.flat, live) and torch.equal(F2, F0) and not torch.equal(F1, F0)

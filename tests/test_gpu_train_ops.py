@@ -255,7 +255,7 @@ def test_adamw_kernel_matches_torch(with_lp):
     for step in range(1, 4):
         gd = (g[step - 1] * 2.0).to(dev())                                          # "summed over 2 ranks"
         L.check(lib.mode_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 3e-3, 0.9, 0.95, 1e-8, 0.05, step, 0.5,
-                                    None if lp is None else lp.data_ptr(), H.stream()))
+                                    None if lp is None else lp.data_ptr(), None, 0.0, H.stream()))
         pt.grad = g[step - 1].to(dev())
         opt.step()
         assert rel(p, pt.detach()) < 1e-6, step
