@@ -1,4 +1,5 @@
-"""Mirror of the schedule + DDIM parts of ``mode.models.edm_diffusion.gc_sampling`` on the HIP denoiser.
+"""Mirror of ``mode.models.edm_diffusion.gc_sampling`` on the HIP denoiser: schedules, the default DDIM sampler (fused + hipGraph) and, from
+``samplers.py``, the other samplers behind the reference signatures.
 
 ``sample_ddim`` keeps the reference signature (gc_sampling.py:922-951).  When the model is our ``GCDenoiser(MoDeDiT)`` the whole
 sampler runs as one launch chain: observation embeddings hoisted out of the step loop, routing for ALL steps resolved up front
@@ -21,6 +22,8 @@ except Exception:  # pragma: no cover
 
 from .score_wrappers import GCDenoiser
 from .modedit import MoDeDiT
+from .samplers import *  # noqa: F401,F403  the other samplers / schedules MoDEAgent.sample_loop and get_noise_schedule dispatch to
+from .samplers import __all__ as _sampler_names
 
 
 def append_zero(action):

@@ -1,0 +1,324 @@
+"""The other score-based samplers and noise schedules of ``mode.models.edm_diffusion.gc_sampling`` behind the same signatures
+(``MoDEAgent.sample_loop`` dispatches on ``sampler_type``, mode_agent.py:798-839; ``get_noise_schedule`` on
+``noise_scheduler``, :841-861).
+
+Every sampler is a host-side recurrence over tiny (B, 10, 7) tensors around 1-2 denoiser calls per step; the denoiser call is the HIP
+launch chain (``GCDenoiser.forward`` -> ``MoDeDiT.denoise``: EDM scalings fused, routing resolved per noise level), so these need no
+kernels of their own.  They are written against two primitives:
+
+* the Karras ODE derivative  d = (x - D(x; sigma)) / sigma                              (Karras et al. 2022, eq. 3 / Alg. 1-2)
+* the exponential-integrator step of DPM-Solver++  x' = (s'/s) x - expm1(-h) D,  h = ln(s/s')       (Lu et al. 2022, eq. 8)
+
+and keep the reference's observable behaviour: argument names and defaults, the callback payload keys of each sampler (``'x'`` vs
+``'action'``), the ``scaler.clip_output`` hook, Euler fallback on the final ``sigma = 0`` step, and the noise-"churn" of Algorithm 2.
+Not provided (raise ``NotImplementedError`` naming the missing dependency): ``sample_dpmpp_sde`` (needs ``torchsde``'s Brownian tree),
+``sample_dpm_fast`` / ``sample_dpm_adaptive`` (the adaptive-step DPM-Solver class).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from scipy import integrate
+
+
+# ------------------------------------------------------------------------------------------------------------------ schedules
+def _with_zero(s: torch.Tensor) -> torch.Tensor:
+    return torch.cat([s, s.new_zeros([1])])
+
+
+def get_sigmas_vp(n, beta_d=19.9, beta_min=0.1, eps_s=1e-3, device="cpu"):
+    """Continuous VP schedule sigma(t) = sqrt(exp(beta_d t^2 / 2 + beta_min t) - 1), t from 1 to eps_s (gc_sampling.py:84-88)."""
+    t = torch.linspace(1, eps_s, n, device=device)
+    return _with_zero(torch.sqrt(torch.exp(beta_d * t ** 2 / 2 + beta_min * t) - 1))
+
+
+def get_sigmas_ve(n, sigma_min=0.02, sigma_max=100, device="cpu"):
+    """Geometric variance schedule as the reference computes it (gc_sampling.py:61-68; note its index ramp runs to n+1, not n-1)."""
+    t = torch.linspace(0, n + 1, n, device=device)
+    var = (sigma_max ** 2) * ((sigma_min ** 2 / sigma_max ** 2) ** (t / (n - 1)))
+    return _with_zero(torch.sqrt(var))
+
+
+def cosine_beta_schedule(n, s=0.008, device="cpu"):
+    """Nichol & Dhariwal cosine schedule, returned as the reversed clipped betas (gc_sampling.py:47-58)."""
+    grid = np.linspace(0, n + 1, n + 1)
+    acp = np.cos(((grid / (n + 1)) + s) / (1 + s) * np.pi * 0.5) ** 2
+    acp = acp / acp[0]
+    betas = np.clip(1 - acp[1:] / acp[:-1], 0, 0.999)
+    return _with_zero(torch.tensor(betas[::-1].copy(), device=device, dtype=torch.float32))
+
+
+def get_iddpm_sigmas(n, sigma_min=0.02, sigma_max=100, M=1000, j_0=0, C_1=0.001, C_2=0.008, device="cpu"):
+    """iDDPM discretisation (Karras et al. 2022, Table 1; gc_sampling.py:71-81): u_{j-1} = sqrt((u_j^2 + 1) / max(ab(j-1)/ab(j), C_1) - 1),
+    keep the levels inside [sigma_min, sigma_max], pick n of them at equal index spacing."""
+    # alpha_bar is evaluated in fp32 (an int64 index tensor times a Python float promotes to the default dtype) while the recurrence
+    # runs in fp64: the mixed precision is part of the reference's observable output, so it is reproduced here
+    idx = torch.arange(0, M + 1, dtype=torch.int64)
+    ab = (0.5 * np.pi * idx / M / (C_2 + 1)).sin() ** 2                       # fp32 [M+1]
+    u = torch.zeros(M + 1, dtype=torch.float64)
+    for j in range(M, j_0, -1):
+        u[j - 1] = ((u[j] ** 2 + 1) / (ab[j - 1] / ab[j]).clip(min=C_1) - 1).sqrt()
+    kept = u[torch.logical_and(u >= sigma_min, u <= sigma_max)].numpy()
+    pick = np.round((len(kept) - 1) / (n - 1) * np.arange(n, dtype=np.float64)).astype(np.int64)
+    return _with_zero(torch.tensor(kept[pick], dtype=torch.float64, device=device)).to(torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------------------------ primitives
+def to_d(action, sigma, denoised):
+    """Karras ODE derivative (gc_sampling.py:91-93)."""
+    sigma = torch.as_tensor(sigma, device=action.device, dtype=action.dtype)
+    return (action - denoised) / sigma.reshape(sigma.shape + (1,) * (action.ndim - sigma.ndim))
+
+
+def default_noise_sampler(x):
+    return lambda sigma, sigma_next: torch.randn_like(x)
+
+
+def get_ancestral_step(sigma_from, sigma_to, eta=1.0):
+    """(sigma_down, sigma_up) of an ancestral step (gc_sampling.py:102-109)."""
+    if not eta:
+        return sigma_to, 0.0
+    sigma_up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+    return sigma_down, sigma_up
+
+
+def _exp_step(x, denoised, s_from, s_to):
+    """x(s_to) of the data-prediction exponential integrator with D frozen: (s_to/s_from) x - expm1(-h) D, h = ln(s_from/s_to)."""
+    h = s_from.log() - s_to.log()
+    return (s_to / s_from) * x - (-h).expm1() * denoised
+
+
+def _churn(x, sigmas, i, s_churn, s_tmin, s_tmax, s_noise):
+    """Algorithm 2's stochastic 'churn': raise the noise level to sigma_hat = sigma_i (1 + gamma) by adding fresh noise."""
+    gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.0
+    eps = torch.randn_like(x) * s_noise
+    sigma_hat = sigmas[i] * (gamma + 1)
+    if gamma > 0:
+        x = x + eps * (sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5
+    return x, sigma_hat
+
+
+class _Run:
+    """Shared per-call plumbing: the batched sigma vector, extra args, callback and output clipping."""
+
+    def __init__(self, model, state, goal, action, extra_args, callback, scaler, x_key):
+        self.model, self.state, self.goal = model, state, goal
+        self.kw = {} if extra_args is None else extra_args
+        self.ones = action.new_ones([action.shape[0]])
+        self.callback, self.scaler, self.x_key = callback, scaler, x_key
+
+    def denoise(self, x, sigma):
+        return self.model(self.state, x, self.goal, sigma * self.ones, **self.kw)
+
+    def report(self, x, i, sigma, sigma_hat, denoised):
+        if self.callback is not None:
+            self.callback({self.x_key: x, "i": i, "sigma": sigma, "sigma_hat": sigma_hat, "denoised": denoised})
+
+    def clip(self, x):
+        return x if self.scaler is None else self.scaler.clip_output(x)
+
+
+# ------------------------------------------------------------------------------------------------------------------ samplers
+@torch.no_grad()
+def sample_euler(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, s_churn=0.0, s_tmin=0.0,
+                 s_tmax=float("inf"), s_noise=1.0):
+    """Euler steps of Karras et al. (2022) Algorithm 2 (gc_sampling.py:165-211); an ODE solver for s_churn = 0."""
+    run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
+    for i in range(len(sigmas) - 1):
+        action, sigma_hat = _churn(action, sigmas, i, s_churn, s_tmin, s_tmax, s_noise)
+        denoised = run.denoise(action, sigma_hat)
+        d = to_d(action, sigma_hat, denoised)
+        run.report(action, i, sigmas[i], sigma_hat, denoised)
+        action = run.clip(action + d * (sigmas[i + 1] - sigma_hat))
+    return action
+
+
+@torch.no_grad()
+def sample_euler_ancestral(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, eta=1.0):
+    """Euler step to sigma_down, then fresh noise of scale sigma_up (gc_sampling.py:214-254)."""
+    run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
+    for i in range(len(sigmas) - 1):
+        denoised = run.denoise(action, sigmas[i])
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        run.report(action, i, sigmas[i], sigmas[i], denoised)
+        action = action + to_d(action, sigmas[i], denoised) * (sigma_down - sigmas[i])
+        if sigma_down > 0:
+            action = action + torch.randn_like(action) * sigma_up
+        action = run.clip(action)
+    return action
+
+
+@torch.no_grad()
+def sample_heun(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, s_churn=0.0, s_tmin=0.0,
+                s_tmax=float("inf"), s_noise=1.0):
+    """Heun (2nd-order) steps of Algorithm 2: Euler predictor, trapezoidal corrector, plain Euler into sigma = 0 (gc_sampling.py:257-312)."""
+    run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
+    for i in range(len(sigmas) - 1):
+        action, sigma_hat = _churn(action, sigmas, i, s_churn, s_tmin, s_tmax, s_noise)
+        denoised = run.denoise(action, sigma_hat)
+        d = to_d(action, sigma_hat, denoised)
+        run.report(action, i, sigmas[i], sigma_hat, denoised)
+        dt = sigmas[i + 1] - sigma_hat
+        if sigmas[i + 1] == 0:
+            action = action + d * dt
+        else:
+            probe = action + d * dt
+            d_probe = to_d(probe, sigmas[i + 1], run.denoise(probe, sigmas[i + 1]))
+            action = action + (d + d_probe) / 2 * dt
+        action = run.clip(action)
+    return action
+
+
+@torch.no_grad()
+def sample_dpm_2(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, s_churn=0.0, s_tmin=0.0,
+                 s_tmax=float("inf"), s_noise=1.0):
+    """Midpoint method in log-sigma (DPM-Solver-2 flavoured), Euler into sigma = 0 (gc_sampling.py:315-373)."""
+    run = _Run(model, state, goal, action, extra_args, callback, scaler, "action")
+    for i in range(len(sigmas) - 1):
+        action, sigma_hat = _churn(action, sigmas, i, s_churn, s_tmin, s_tmax, s_noise)
+        denoised = run.denoise(action, sigma_hat)
+        d = to_d(action, sigma_hat, denoised)
+        run.report(action, i, sigmas[i], sigma_hat, denoised)
+        if sigmas[i + 1] == 0:
+            action = action + d * (sigmas[i + 1] - sigma_hat)
+        else:
+            sigma_mid = sigma_hat.log().lerp(sigmas[i + 1].log(), 0.5).exp()
+            mid = action + d * (sigma_mid - sigma_hat)
+            d_mid = to_d(mid, sigma_mid, run.denoise(mid, sigma_mid))
+            action = action + d_mid * (sigmas[i + 1] - sigma_hat)
+        action = run.clip(action)
+    return action
+
+
+@torch.no_grad()
+def sample_dpm_2_ancestral(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, eta=1.0):
+    """Midpoint step to sigma_down plus ancestral noise (gc_sampling.py:376-410)."""
+    run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
+    for i in range(len(sigmas) - 1):
+        denoised = run.denoise(action, sigmas[i])
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        run.report(action, i, sigmas[i], sigmas[i], denoised)
+        d = to_d(action, sigmas[i], denoised)
+        if sigma_down == 0:
+            action = action + d * (sigma_down - sigmas[i])
+        else:
+            sigma_mid = sigmas[i].log().lerp(sigma_down.log(), 0.5).exp()
+            mid = action + d * (sigma_mid - sigmas[i])
+            d_mid = to_d(mid, sigma_mid, run.denoise(mid, sigma_mid))
+            action = action + d_mid * (sigma_down - sigmas[i])
+            action = action + torch.randn_like(action) * sigma_up
+        action = run.clip(action)
+    return action
+
+
+def linear_multistep_coeff(order, t, i, j):
+    """Integral over [t_i, t_{i+1}] of the j-th Lagrange basis polynomial through the last `order` nodes (gc_sampling.py:413-427)."""
+    if order - 1 > i:
+        raise ValueError(f"Order {order} too high for step {i}")
+
+    def basis(tau):
+        prod = 1.0
+        for k in range(order):
+            if k != j:
+                prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return prod
+    return integrate.quad(basis, t[i], t[i + 1], epsrel=1e-4)[0]
+
+
+@torch.no_grad()
+def sample_lms(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, order=4):
+    """Adams-Bashforth style linear multistep sampler on the Karras ODE (gc_sampling.py:430-466)."""
+    run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
+    nodes = sigmas.detach().cpu().numpy()
+    history = []
+    for i in range(len(sigmas) - 1):
+        denoised = run.denoise(action, sigmas[i])
+        history.append(to_d(action, sigmas[i], denoised))
+        if len(history) > order:
+            history.pop(0)
+        run.report(action, i, sigmas[i], sigmas[i], denoised)
+        cur = min(i + 1, order)
+        weights = [linear_multistep_coeff(cur, nodes, i, j) for j in range(cur)]
+        action = run.clip(action + sum(w * d for w, d in zip(weights, reversed(history))))
+    return action
+
+
+@torch.no_grad()
+def sample_dpmpp_2m(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None):
+    """DPM-Solver++(2M): exponential-integrator steps with a two-point extrapolation of the denoised prediction (gc_sampling.py:700-734)."""
+    run = _Run(model, state, goal, action, extra_args, callback, None, "action")
+    previous = None
+    for i in range(len(sigmas) - 1):
+        denoised = run.denoise(action, sigmas[i])
+        run.report(action, i, sigmas[i], sigmas[i], denoised)
+        if previous is None or sigmas[i + 1] == 0:
+            action = _exp_step(action, denoised, sigmas[i], sigmas[i + 1])
+        else:
+            h = sigmas[i].log() - sigmas[i + 1].log()
+            h_last = sigmas[i - 1].log() - sigmas[i].log()
+            r = h_last / h
+            action = _exp_step(action, (1 + 1 / (2 * r)) * denoised - (1 / (2 * r)) * previous, sigmas[i], sigmas[i + 1])
+        previous = denoised
+    return action
+
+
+def _dpmpp_2s_core(run, action, denoised, s_from, s_to):
+    """One DPM-Solver++(2S) step s_from -> s_to (s_to > 0): half step in log-sigma with D(x), full step with D at the midpoint."""
+    s_mid = (0.5 * (s_from.log() + s_to.log())).exp()                      # t + h/2 in t = -ln sigma
+    h = s_from.log() - s_to.log()
+    x_mid = (s_mid / s_from) * action - (-h * 0.5).expm1() * denoised
+    return (s_to / s_from) * action - (-h).expm1() * run.denoise(x_mid, s_mid)
+
+
+@torch.no_grad()
+def sample_dpmpp_2s_ancestral(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, eta=1.0,
+                              s_noise=1.0, noise_sampler=None):
+    """DPM-Solver++(2S) steps to sigma_down plus ancestral noise (gc_sampling.py:874-920)."""
+    run = _Run(model, state, goal, action, extra_args, callback, scaler, "action")
+    noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+    for i in range(len(sigmas) - 1):
+        denoised = run.denoise(action, sigmas[i])
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        run.report(action, i, sigmas[i], sigmas[i], denoised)
+        if sigma_down == 0:
+            action = action + to_d(action, sigmas[i], denoised) * (sigma_down - sigmas[i])
+        else:
+            action = _dpmpp_2s_core(run, action, denoised, sigmas[i], sigma_down)
+        action = run.clip(action + noise_sampler(sigmas[i], sigmas[i + 1]) * s_noise * sigma_up)
+    return action
+
+
+@torch.no_grad()
+def sample_dpmpp_2s(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, eta=1.0):
+    """Deterministic DPM-Solver++(2S) (gc_sampling.py:956-994)."""
+    run = _Run(model, state, goal, action, extra_args, callback, scaler, "action")
+    for i in range(len(sigmas) - 1):
+        denoised = run.denoise(action, sigmas[i])
+        run.report(action, i, sigmas[i], sigmas[i], denoised)
+        if sigmas[i + 1] == 0:
+            action = action + to_d(action, sigmas[i], denoised) * (sigmas[i + 1] - sigmas[i])
+        else:
+            action = _dpmpp_2s_core(run, action, denoised, sigmas[i], sigmas[i + 1])
+        action = run.clip(action)
+    return action
+
+
+def _missing(name, why):
+    def fn(*a, **k):
+        raise NotImplementedError(f"{name} is not provided by the MI355X build: {why}")
+    fn.__name__ = name
+    return fn
+
+
+sample_dpmpp_sde = _missing("sample_dpmpp_sde", "it needs torchsde's BrownianTree noise sampler (absent from this image)")
+sample_dpm_fast = _missing("sample_dpm_fast", "the adaptive DPM-Solver class is outside the round-1 scope")
+sample_dpm_adaptive = _missing("sample_dpm_adaptive", "the adaptive DPM-Solver class is outside the round-1 scope")
+sample_dpmpp_2_with_lms = _missing("sample_dpmpp_2_with_lms", "debugging sampler of the reference, outside the round-1 scope")
+
+__all__ = ["get_sigmas_vp", "get_sigmas_ve", "cosine_beta_schedule", "get_iddpm_sigmas", "to_d", "default_noise_sampler", "get_ancestral_step",
+           "sample_euler", "sample_euler_ancestral", "sample_heun", "sample_dpm_2", "sample_dpm_2_ancestral", "linear_multistep_coeff",
+           "sample_lms", "sample_dpmpp_2m", "sample_dpmpp_2s_ancestral", "sample_dpmpp_2s", "sample_dpmpp_sde", "sample_dpm_fast",
+           "sample_dpm_adaptive", "sample_dpmpp_2_with_lms"]
