@@ -1,0 +1,154 @@
+"""Inference-side harness around the HIP sampler: what ``MoDEAgent`` does between "perceptual
+embeddings + goal embedding" and "action for this control step" — noise-schedule / sampler dispatch, the initial noise draw, action
+chunking with replanning every ``multistep`` steps, routing pre-cache per noise level, and loading the denoiser's weights from a
+published checkpoint.  The reference agent (mode/models/mode_agent.py) is a LightningModule that also owns the ResNet / CLIP encoders;
+those producers are out of scope here, so this harness starts at their outputs and — unlike the reference's ``step`` which is B = 1
+(``pred_action_seq[0, ...]``, mode_agent.py:630) — serves a BATCH of environments per call (BASELINE configs[4]: 32 envs).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import gc_sampling as gs
+
+
+def get_noise_schedule(n_sampling_steps: int, noise_schedule_type: str, sigma_min: float, sigma_max: float, device="cpu") -> torch.Tensor:
+    """``MoDEAgent.get_noise_schedule`` (mode_agent.py:841-861): same names, same defaults (Karras rho = 7), same error."""
+    if noise_schedule_type == "karras":
+        return gs.get_sigmas_karras(n_sampling_steps, sigma_min, sigma_max, 7, device)
+    if noise_schedule_type == "exponential":
+        return gs.get_sigmas_exponential(n_sampling_steps, sigma_min, sigma_max, device)
+    if noise_schedule_type == "vp":
+        return gs.get_sigmas_vp(n_sampling_steps, device=device)
+    if noise_schedule_type == "linear":
+        return gs.get_sigmas_linear(n_sampling_steps, sigma_min, sigma_max, device=device)
+    if noise_schedule_type == "cosine_beta":
+        return gs.cosine_beta_schedule(n_sampling_steps, device=device)
+    if noise_schedule_type == "ve":
+        return gs.get_sigmas_ve(n_sampling_steps, sigma_min, sigma_max, device=device)
+    if noise_schedule_type == "iddpm":
+        return gs.get_iddpm_sigmas(n_sampling_steps, sigma_min, sigma_max, device=device)
+    raise ValueError("Unknown noise schedule type")
+
+
+def sample_loop(model, sigmas, x_t, state, goal, sampler_type: str = "ddim", extra_args: Optional[dict] = None, scaler=None):
+    """``MoDEAgent.sample_loop`` (mode_agent.py:779-839): sampler names -> functions, ``s_churn`` / ``s_min`` / ``use_scaler`` taken from
+    ``extra_args`` the way the agent does, ``ValueError`` for an unknown name."""
+    extra_args = extra_args or {}
+    s_churn = extra_args.get("s_churn", 0)
+    s_min = extra_args.get("s_min", 0)
+    sc = scaler if extra_args.get("use_scaler", False) else None
+    reduced = {k: extra_args[k] for k in ("s_churn", "keep_last_actions")} if extra_args else {}
+    table = {
+        "lms": lambda: gs.sample_lms(model, state, x_t, goal, sigmas, scaler=sc, disable=True, extra_args=reduced),
+        "heun": lambda: gs.sample_heun(model, state, x_t, goal, sigmas, scaler=sc, s_churn=s_churn, s_tmin=s_min, disable=True),
+        "euler": lambda: gs.sample_euler(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
+        "ancestral": lambda: gs.sample_dpm_2_ancestral(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
+        "euler_ancestral": lambda: gs.sample_euler_ancestral(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
+        "dpm": lambda: gs.sample_dpm_2(model, state, x_t, goal, sigmas, disable=True),
+        "dpm_adaptive": lambda: gs.sample_dpm_adaptive(model, state, x_t, goal, sigmas[-2].item(), sigmas[0].item(), disable=True),
+        "dpm_fast": lambda: gs.sample_dpm_fast(model, state, x_t, goal, sigmas[-2].item(), sigmas[0].item(), len(sigmas), disable=True),
+        "dpmpp_2s_ancestral": lambda: gs.sample_dpmpp_2s_ancestral(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
+        "dpmpp_2m": lambda: gs.sample_dpmpp_2m(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
+        "dpmpp_2m_sde": lambda: gs.sample_dpmpp_sde(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
+        "ddim": lambda: gs.sample_ddim(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
+        "dpmpp_2s": lambda: gs.sample_dpmpp_2s(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
+        "dpmpp_2_with_lms": lambda: gs.sample_dpmpp_2_with_lms(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
+    }
+    if sampler_type not in table:
+        raise ValueError("desired sampler type not found!")
+    return table[sampler_type]()
+
+
+class ChunkedRolloutPolicy:
+    """Action-chunking policy for a batch of environments: plan ``act_window_size`` actions with the sampler, emit one per control step,
+    replan every ``multistep`` steps (``MoDEAgent.forward`` / ``step`` / ``denoise_actions`` / ``precompute_expert_for_inference``,
+    mode_agent.py:584-644, 733-760).
+
+    ``step(perceptual_emb, latent_goal)``: ``perceptual_emb = {'state_images': (B, 2, obs_dim)}`` (the encoders' output), ``latent_goal``
+    (B, G) or (B, 1, G); returns the actions of this control step, (B, action_dim).  With the default DDIM sampler a replanning call is one
+    hipGraph replay; the routing decisions of every noise level are resolved once (``precompute_experts_for_inference``) like the agent does
+    on its first inference call."""
+
+    def __init__(self, denoiser, num_sampling_steps: int = 10, sigma_min: float = 0.001, sigma_max: float = 80.0,
+                 noise_scheduler: str = "exponential", sampler_type: str = "ddim", act_window_size: int = 10, multistep: int = 10,
+                 action_dim: int = 7, generator: Optional[torch.Generator] = None):
+        if multistep > act_window_size:
+            raise ValueError("multistep cannot exceed the planned window")
+        self.model = denoiser
+        self.num_sampling_steps, self.sigma_min, self.sigma_max = num_sampling_steps, sigma_min, sigma_max
+        self.noise_scheduler, self.sampler_type = noise_scheduler, sampler_type
+        self.act_window_size, self.multistep, self.action_dim = act_window_size, multistep, action_dim
+        self.generator = generator
+        self.need_precompute_experts_for_inference = True
+        self.reset()
+
+    def reset(self) -> None:
+        """Start of an episode (the reference agent's ``reset``): replan at the next ``step``."""
+        self.rollout_step_counter = 0
+        self.pred_action_seq: Optional[torch.Tensor] = None
+
+    def precompute_expert_for_inference(self, goal=None) -> None:
+        inner = self.model.inner_model
+        dev = next(inner.parameters()).device
+        for sigma in get_noise_schedule(self.num_sampling_steps, self.noise_scheduler, self.sigma_min, self.sigma_max, dev)[:-1]:
+            inner.precompute_experts_for_inference(sigma, goal)
+
+    @torch.no_grad()
+    def denoise_actions(self, perceptual_emb: Dict[str, torch.Tensor], latent_goal: torch.Tensor, extra_args: Optional[dict] = None) -> torch.Tensor:
+        self.model.eval()
+        dev = perceptual_emb["state_images"].device
+        if latent_goal.dim() < perceptual_emb["state_images"].dim():
+            latent_goal = latent_goal.unsqueeze(1)
+        if self.need_precompute_experts_for_inference:
+            self.precompute_expert_for_inference(latent_goal[:1] if self.model.inner_model.use_goal_in_routing else None)
+            self.need_precompute_experts_for_inference = False
+        sigmas = get_noise_schedule(self.num_sampling_steps, self.noise_scheduler, self.sigma_min, self.sigma_max, dev)
+        x = torch.randn((len(latent_goal), self.act_window_size, self.action_dim), device=dev, generator=self.generator) * self.sigma_max
+        return sample_loop(self.model, sigmas, x, perceptual_emb, latent_goal, self.sampler_type, extra_args)
+
+    @torch.no_grad()
+    def step(self, perceptual_emb: Dict[str, torch.Tensor], latent_goal: torch.Tensor) -> torch.Tensor:
+        if self.rollout_step_counter % self.multistep == 0:
+            self.pred_action_seq = self.denoise_actions(perceptual_emb, latent_goal)
+        current = self.pred_action_seq[:, self.rollout_step_counter]
+        self.rollout_step_counter += 1
+        if self.rollout_step_counter == self.multistep:
+            self.rollout_step_counter = 0
+        return current
+
+
+def load_denoiser_checkpoint(model, source, prefix: str = "model.inner_model.", strict: bool = False):
+    """Load the denoiser's tensors from an agent checkpoint: a ``.safetensors`` file (the published HF weights), a ``torch.save``d
+    ``state_dict`` / Lightning checkpoint, or an in-memory mapping.  Keys are matched by name after stripping the agent's prefix
+    (``model.inner_model.`` — mode_agent.py:209-251 loads by key and skips the CLIP / ResNet tensors, which belong to the out-of-scope
+    encoders); the kernel-side layout is untouched because the Parameters are arena views.  Returns (missing, unexpected, skipped_shape)."""
+    if isinstance(source, (str, bytes)):
+        path = source if isinstance(source, str) else source.decode()
+        if path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(path)
+        else:
+            sd = torch.load(path, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+    else:
+        sd = dict(source)
+    own = model.state_dict()
+    picked, skipped = {}, []
+    for key, t in sd.items():
+        if "visual" in key or "clip" in key.lower():
+            continue
+        name = key[len(prefix):] if key.startswith(prefix) else key
+        if name not in own:
+            continue
+        if tuple(own[name].shape) != tuple(t.shape):
+            if own[name].numel() == t.numel():
+                t = t.reshape(own[name].shape)
+            else:
+                skipped.append(name)
+                continue
+        picked[name] = t
+    res = model.load_state_dict(picked, strict=strict)
+    return list(res.missing_keys), list(res.unexpected_keys), skipped

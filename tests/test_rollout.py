@@ -1,0 +1,100 @@
+"""Inference harness (mode_diffusion_policy_amd/rollout.py): schedule / sampler dispatch with the agent's names and errors (mode_agent.py:779-861),
+checkpoint loading by key, and the batched action-chunking policy (mode_agent.py:584-637)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mode_diffusion_policy_amd as M
+from mode_diffusion_policy_amd import gc_sampling, rollout
+from oracle.weights import get_config, make_inputs, make_state_dict
+
+
+def _model(cfg, device, dtype="fp32"):
+    return M.MoDeDiT(obs_dim=cfg.obs_dim, goal_dim=cfg.goal_dim, device=device, goal_conditioned=True, action_dim=7, embed_dim=cfg.embed_dim,
+                     embed_pdrob=0, attn_pdrop=0.3, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=1, obs_seq_len=1, action_seq_len=10,
+                     num_experts=cfg.num_experts, top_k=cfg.top_k, compute_dtype=dtype)
+
+
+def test_dispatch_names_and_errors(golden):
+    g = golden("F10_schedules")
+    for name in ("karras", "linear", "vp", "cosine_beta", "iddpm"):
+        got = rollout.get_noise_schedule(10, name, 1e-3, 80.0)
+        np.testing.assert_allclose(got.numpy(), g[f"{name}_n10"], rtol=2e-6, atol=1e-9)
+    assert torch.equal(rollout.get_noise_schedule(10, "exponential", 1e-3, 80.0), gc_sampling.get_sigmas_exponential(10, 1e-3, 80.0))
+    with pytest.raises(ValueError, match="Unknown noise schedule type"):
+        rollout.get_noise_schedule(10, "nope", 1e-3, 80.0)
+
+    def toy(state, action, goal, sigma, **kw):
+        return 0.5 * action
+    x0 = torch.randn(2, 10, 7, generator=torch.Generator().manual_seed(0))
+    sig = gc_sampling.get_sigmas_exponential(5, 1e-3, 80.0)
+    for name in ("lms", "heun", "euler", "ancestral", "euler_ancestral", "dpm", "dpmpp_2s_ancestral", "dpmpp_2m", "ddim", "dpmpp_2s"):
+        out = rollout.sample_loop(toy, sig, x0, None, None, name)
+        assert out.shape == x0.shape and torch.isfinite(out).all(), name
+    with pytest.raises(ValueError, match="desired sampler type not found"):
+        rollout.sample_loop(toy, sig, x0, None, None, "nope")
+    with pytest.raises(NotImplementedError):
+        rollout.sample_loop(toy, sig, x0, None, None, "dpmpp_2m_sde")
+
+
+def test_checkpoint_loader_by_key(tmp_path):
+    from safetensors.torch import save_file
+    cfg = get_config("tiny")
+    sd = make_state_dict(cfg, 5)
+    ck = {"model.inner_model." + k: v.clone() for k, v in sd.items()}
+    ck["model.inner_model.sigma_emb.weight"] = ck["model.inner_model.sigma_emb.weight"].reshape(-1)     # same numel, other shape: reshaped on load
+    ck["static_resnet.resnet.conv1.weight"] = torch.zeros(4, 3, 3, 3)                                  # encoder tensors: not ours
+    ck["clip_model.visual.proj"] = torch.zeros(4, 4)
+    path = os.path.join(tmp_path, "agent.safetensors")
+    save_file(ck, path)
+    m = _model(cfg, "cpu")
+    missing, unexpected, skipped = rollout.load_denoiser_checkpoint(m, path)
+    assert not missing and not unexpected and not skipped
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # a plain mapping without the prefix, one tensor absent, one incompatible
+    part = {k: v for k, v in sd.items() if k != "out.bias"}
+    part["pos_emb"] = torch.zeros(3)
+    m2 = _model(cfg, "cpu")
+    missing, unexpected, skipped = rollout.load_denoiser_checkpoint(m2, part)
+    assert "out.bias" in missing and "pos_emb" in missing and skipped == ["pos_emb"] and not unexpected
+
+
+@pytest.mark.gpu
+def test_chunked_rollout_policy_batch_of_envs():
+    cfg = get_config("c1e4")
+    sd = make_state_dict(cfg, 210)
+    m = _model(cfg, "cuda", "bf16")
+    m.load_state_dict(sd)
+    den = M.GCDenoiser(m.cuda().eval(), 0.5).eval()
+    B = 6
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, B, 3).items()}
+    obs = {"state_images": inp["state_images"]}
+    pol = rollout.ChunkedRolloutPolicy(den, num_sampling_steps=10, multistep=4, act_window_size=10,
+                                       generator=torch.Generator(device="cuda").manual_seed(7))
+    acts = [pol.step(obs, inp["goals"].squeeze(1)).clone() for _ in range(9)]            # replans at control steps 0, 4, 8
+    assert all(a.shape == (B, 7) and torch.isfinite(a).all() for a in acts)
+    assert pol.rollout_step_counter == 1 and not pol.need_precompute_experts_for_inference
+    # the emitted actions are consecutive rows of the planned chunk; the plan is what sample_ddim produces from the same noise
+    ref = rollout.ChunkedRolloutPolicy(den, multistep=4, generator=torch.Generator(device="cuda").manual_seed(7))
+    plan0 = ref.denoise_actions(obs, inp["goals"])
+    for t in range(4):
+        assert torch.equal(acts[t], plan0[:, t])
+    plan1 = ref.denoise_actions(obs, inp["goals"])
+    assert torch.equal(acts[4], plan1[:, 0]) and not torch.equal(plan1, plan0)             # fresh noise per replanning call
+    sig = rollout.get_noise_schedule(10, "exponential", 1e-3, 80.0, "cuda")
+    x0 = torch.randn((B, 10, 7), device="cuda", generator=torch.Generator(device="cuda").manual_seed(7)) * 80.0
+    assert torch.equal(plan0, M.sample_ddim(den, obs, x0, inp["goals"], sig, disable=True))
+    # environments are independent: the plan of env 2 does not depend on who else is in the batch
+    solo = rollout.ChunkedRolloutPolicy(den, multistep=4)
+    sub = {"state_images": inp["state_images"][2:3]}
+    x_solo = M.sample_ddim(den, sub, x0[2:3], inp["goals"][2:3], sig, disable=True)
+    assert float((x_solo - plan0[2:3]).abs().max()) < 2e-2 * float(plan0.abs().max())
+    pol.reset()
+    assert pol.rollout_step_counter == 0 and pol.pred_action_seq is None and solo.rollout_step_counter == 0
+    # another sampler through the same policy
+    pol2 = rollout.ChunkedRolloutPolicy(den, sampler_type="dpmpp_2m", noise_scheduler="karras", multistep=10)
+    a = pol2.step(obs, inp["goals"])
+    assert a.shape == (B, 7) and torch.isfinite(a).all()
