@@ -226,3 +226,40 @@ def test_tri_stage_lr_schedule():
     assert abs(lrs[100 + 450] - (5e-5 + 0.5 * 5e-5 * (1 + math.cos(0.5 * math.pi)))) < 1e-15
     assert abs(lrs[1000] - 5e-5) < 1e-15 and lrs[1001] == 5e-5 and lrs[-1] == 5e-5                  # floor at final_lr_scale * lr
     assert _Opt.param_groups[0]["lr"] == lrs[-1] == _Opt.param_groups[1]["lr"]
+
+
+def test_noise_level_densities_reproduce_reference_rng_stream():
+    """The sigma densities of MoDEAgent.make_sample_density (mode_agent.py:691-730) against closed-form restatements driven by the same seeded
+    torch RNG stream: identical draws in identical order -> bit-identical samples (the reference functions are edm_diffusion/utils.py:154-203)."""
+    import math
+    shape = (257,)
+
+    def stream(seed):
+        torch.manual_seed(seed)
+
+    stream(1); got = utils.rand_log_normal(shape, loc=-1.2, scale=1.2)
+    stream(1); assert torch.equal(got, (torch.randn(shape) * 1.2 + -1.2).exp())
+    stream(2); got = utils.rand_log_uniform(shape, 1e-3, 80.0)
+    stream(2); assert torch.equal(got, (torch.rand(shape) * (math.log(80.0) - math.log(1e-3)) + math.log(1e-3)).exp())
+    stream(3); got = utils.rand_uniform(shape, 1e-3, 80.0)
+    stream(3); assert torch.equal(got, torch.rand(shape) * (80.0 - 1e-3) + 1e-3)
+    stream(4); got = utils.rand_v_diffusion(shape, 0.5, 1e-3, 80.0)
+    lo, hi = math.atan(1e-3 / 0.5) * 2 / math.pi, math.atan(80.0 / 0.5) * 2 / math.pi
+    stream(4); assert torch.equal(got, torch.tan((torch.rand(shape) * (hi - lo) + lo) * math.pi / 2) * 0.5)
+    assert float(got.min()) >= 1e-3 * 0.999 and float(got.max()) <= 80.0 * 1.001
+    stream(5); got = utils.rand_split_log_normal(shape, -1.0, 0.5, 1.5)
+    stream(5); n = torch.randn(shape).abs(); u = torch.rand(shape)
+    assert torch.equal(got, torch.where(u < 0.25, n * -0.5 - 1.0, n * 1.5 - 1.0).exp())
+    vals = torch.tensor([0.1, 0.2, 0.3])
+    stream(6); got = utils.rand_discrete(shape, vals)
+    stream(6); assert torch.equal(got, vals[torch.randint(0, 3, shape)])
+    # factory: names, defaults (loglogistic = the shipped default) and the agent's error
+    stream(7); a = utils.make_sample_density("loglogistic", sigma_data=0.5, sigma_min=1e-3, sigma_max=80.0)(shape=shape, device="cpu")
+    stream(7); b = utils.rand_log_logistic(shape, loc=math.log(0.5), scale=0.5, min_value=1e-3, max_value=80.0)
+    assert torch.equal(a, b)
+    for kind in ("lognormal", "loguniform", "uniform", "v-diffusion"):
+        s = utils.make_sample_density(kind)(shape=(16,), device="cpu")
+        assert s.shape == (16,) and torch.isfinite(s).all() and float(s.min()) > 0
+    assert utils.make_sample_density("split-lognormal", loc=-1.0, scale_1=0.5, scale_2=1.5)(shape=(4,)).shape == (4,)
+    with pytest.raises(ValueError, match="Unknown sample density type"):
+        utils.make_sample_density("nope")
