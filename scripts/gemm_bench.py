@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--splitk", type=int, default=1)
     ap.add_argument("--batch", type=int, default=128, help="samples (tokens = 14 x batch)")
+    ap.add_argument("--experts", type=int, default=2, help="active experts: 2 = uniform-sigma inference (all samples route alike), 4 = training-like")
     ap.add_argument("--nogather", action="store_true", help="gemm1 reads pre-sorted rows (no a_rows gather)")
     a = ap.parse_args()
     lib = L.load()
@@ -29,7 +30,8 @@ def main():
     NK = N * k
     bf = torch.bfloat16
     x = torch.randn(N, D, device=dev).to(bf)
-    idx = torch.tensor([[1, 2], [0, 3]] * (a.batch // 2), dtype=torch.int32, device=dev); w = torch.tensor([[0.6, 0.4]] * a.batch, device=dev)   # all 4 experts loaded evenly
+    pairs = [[1, 2], [0, 3]] if a.experts == 4 else [[1, 2], [1, 2]]
+    idx = torch.tensor(pairs * (a.batch // 2), dtype=torch.int32, device=dev); w = torch.tensor([[0.6, 0.4]] * a.batch, device=dev)
     ml = L.ModeMetaLayout(); lib.mode_moe_meta_layout(N, E, k, C.byref(ml))
     meta = torch.empty(ml.total_words, dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
