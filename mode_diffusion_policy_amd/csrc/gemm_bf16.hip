@@ -321,7 +321,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (NS == 1 ? 3 : 2)
 // ------------------------------------------------------------------------------------------------------------ host side
 // geometry ids (also the values of the "gemm_cfg" option; 0 = auto)
 enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x128_NS3 = 2, CFG_256x128_NS3 = 3, CFG_128x64_NS3 = 4, CFG_128x64_NS4 = 5,
-       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10, CFG_256x256_W16 = 11, CFG_P256 = 12, CFG_256x64_NS3 = 13, CFG_256x64_NS2 = 14 };
+       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10, CFG_256x256_W16 = 11, CFG_P256 = 12 };
 int gemm_bf16_p256_launch(const ModeGemmDesc* d, hipStream_t s);   // gemm_bf16_p256.hip: persistent 256x256 with cross-tile operand prefetch
 int g_gemm_cfg = CFG_AUTO;
 
@@ -358,8 +358,6 @@ static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipSt
     case CFG_256x256_NS2: return launch_cfg<256, 256, 2, 4, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_256x128_NS2: return launch_cfg<256, 128, 4, 2, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_256x256_W16: return launch_cfg<256, 256, 4, 4, 2, EPI, OUT_BF16>(p, d, s);
-    case CFG_256x64_NS3: return launch_cfg<256, 64, 4, 1, 3, EPI, OUT_BF16>(p, d, s);
-    case CFG_256x64_NS2: return launch_cfg<256, 64, 4, 1, 2, EPI, OUT_BF16>(p, d, s);
     default: return MODE_ERR_BAD_ARG;
   }
 }
