@@ -202,10 +202,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
   float* sdo = sv + T * HP;                            // dO
   float* sqh = sdo + T * HP;                           // q_hat, later d q_hat
   float* skh = sqh + T * HP;                           // k_hat, later d k_hat
-  float* sp = skh + T * HP;                            // P                                 [T][T]
-  float* sds = sp + T * T;                             // dPd, then dS                      [T][T]
-  float* spd = sds + T * T;                            // dropped probabilities Pd          [T][T]
-  float* srq = spd + T * T;                            // 1/norm per token (q)              [T]
+  // probability-sized tiles are zero-padded to 16 x 16 (row stride 16): branch-free 16-term dot products, float4 broadcast reads
+  float* sp = skh + T * HP + ((4 - ((6 * T * HP) & 3)) & 3);   // P [query][key]                    (16-byte aligned)
+  float* sds = sp + 256;                               // dPd, then dS   [query][key]
+  float* spdT = sds + 256;                             // dropped probabilities, transposed [key][query]
+  float* sdsT = spdT + 256;                            // dS transposed                     [key][query]
+  float* srq = sdsT + 256;                             // 1/norm per token (q)              [T]
   float* srk = srq + T;                                // (k)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int prob = blockIdx.x, b = prob / H, h = prob % H, D = H * HD;
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
       dst[0] = __uint_as_float(u.x); dst[1] = __uint_as_float(u.y); dst[2] = __uint_as_float(u.z); dst[3] = __uint_as_float(u.w);
     }
   };
+  for (int i = tid; i < 4 * 256; i += 256) sp[i] = 0.f;   // zero padding of the four 16x16 tiles (written sparsely below)
   for (int i = tid; i < T * cpr; i += 256) {
     const int t = i / cpr, d = (i % cpr) * VE;
     const T2* r = qkv + ((long)b * T + t) * ld + h * HD + d;
@@ -256,43 +259,63 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
   const float scale = rsqrtf((float)HD);
   // S = q_hat k_hat^T * scale (causal) and dPd = dO V^T: four lanes per (query, key) pair, each a quarter of the head dim with two
   // independent accumulator pairs (the one-thread-per-pair loop was a 128-deep chain of dependent LDS reads), xor-shuffle combine
-  for (int i = tid >> 2; i < T * T; i += 64) {
-    const int qi = i / T, ki = i % T, part = tid & 3;
-    float s0 = 0.f, s1 = 0.f, p0 = 0.f, p1 = 0.f;
-    if (ki <= qi) {
-      const float* qr = sqh + qi * HP; const float* kr = skh + ki * HP; const float* orow = sdo + qi * HP; const float* vr = sv + ki * HP;
-      int d = part;
-      for (; d + 4 < HD; d += 8) {                          // lanes interleave d: consecutive banks
-        s0 = fmaf(qr[d], kr[d], s0); s1 = fmaf(qr[d + 4], kr[d + 4], s1);
-        p0 = fmaf(orow[d], vr[d], p0); p1 = fmaf(orow[d + 4], vr[d + 4], p1);
+  {
+    // thread = (query qi, group of 4 keys, quarter of the head dim): the q / dO values are loaded once per 4 keys (10 LDS reads per 8 FMAs),
+    // 14 x 4 x 4 = 224 threads cover the whole [T][T] tile in one pass; quarter sums are combined by xor-shuffles
+    const int part = tid & 3, kgrp = (tid >> 2) & 3, qi = tid >> 4;
+    float sa[4] = {0.f, 0.f, 0.f, 0.f}, pa[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool act = qi < T && kgrp * 4 <= qi;
+    if (act) {
+      const float* qr = sqh + qi * HP; const float* orow = sdo + qi * HP;
+      const int k0 = kgrp * 4;
+      const float* kr[4]; const float* vr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int kk = min(k0 + j, T - 1); kr[j] = skh + kk * HP; vr[j] = sv + kk * HP; }
+#pragma unroll 4
+      for (int d = part; d < HD; d += 4) {                  // lanes interleave d: consecutive banks; unrolled: 40 LDS reads in flight
+        const float qv = qr[d], ov = orow[d];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sa[j] = fmaf(qv, kr[j][d], sa[j]); pa[j] = fmaf(ov, vr[j][d], pa[j]); }
       }
-      for (; d < HD; d += 4) { s0 = fmaf(qr[d], kr[d], s0); p0 = fmaf(orow[d], vr[d], p0); }
     }
-    float sa = s0 + s1, pa = p0 + p1;
-    sa += __shfl_xor(sa, 1, 64); sa += __shfl_xor(sa, 2, 64);
-    pa += __shfl_xor(pa, 1, 64); pa += __shfl_xor(pa, 2, 64);
-    if (part == 0) { sp[i] = (ki <= qi) ? sa * scale : -INFINITY; sds[i] = pa; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sa[j] += __shfl_xor(sa[j], 1, 64); sa[j] += __shfl_xor(sa[j], 2, 64);
+      pa[j] += __shfl_xor(pa[j], 1, 64); pa[j] += __shfl_xor(pa[j], 2, 64);
+    }
+    if (act && part == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ki = kgrp * 4 + j;
+        if (ki <= qi) { sp[qi * 16 + ki] = sa[j] * scale; sds[qi * 16 + ki] = pa[j]; }
+      }
+    }
   }
   __syncthreads();
   if (stop_after == 4) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
-  if (tid < T) {                                        // softmax row, dropout, dS = P * (dP - sum(dP*P)) * scale
-    const int qi = tid;
-    float mx = -INFINITY;
-    for (int ki = 0; ki <= qi; ++ki) mx = fmaxf(mx, sp[qi * T + ki]);
-    float sum = 0.f;
-    for (int ki = 0; ki <= qi; ++ki) sum += expf(sp[qi * T + ki] - mx);
-    float rs = 0.f;
-    for (int ki = 0; ki < T; ++ki) {
-      const float pv = (ki <= qi) ? expf(sp[qi * T + ki] - mx) / sum : 0.f;
-      float m = 1.0f;
-      if (thresh) m = attn_keep(seed, prob, T, qi, ki, thresh) ? inv_keep : 0.f;
-      const float dP = sds[qi * T + ki] * m;           // gradient wrt the un-dropped probability
-      rs += dP * pv;
-      sp[qi * T + ki] = pv;
-      spd[qi * T + ki] = pv * m;                         // dropped probabilities (dV needs them)
-      sds[qi * T + ki] = dP;
+  {                                                     // softmax rows, dropout, dS = P * (dP - sum(dP*P)) * scale: 16 lanes per query row
+    const int qi = wave * 4 + (lane >> 4), ki = lane & 15;
+    const bool valid = qi < T && ki <= qi;
+    const float sv_ = valid ? sp[qi * 16 + ki] : -INFINITY;
+    float mx = sv_;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float e = valid ? expf(sv_ - mx) : 0.f;
+    float sum = e;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+    const float pv = valid ? e / sum : 0.f;
+    float m = 1.0f;
+    if (thresh && valid) m = attn_keep(seed, prob, T, qi, ki, thresh) ? inv_keep : 0.f;
+    const float dP = valid ? sds[qi * 16 + ki] * m : 0.f;   // gradient wrt the un-dropped probability
+    float rs = dP * pv;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) rs += __shfl_xor(rs, o, 64);
+    const float dS = pv * (dP - rs) * scale;
+    if (qi < T && ki < T) {
+      sp[qi * 16 + ki] = pv; sds[qi * 16 + ki] = dS;
+      spdT[ki * 16 + qi] = pv * m; sdsT[ki * 16 + qi] = dS;
     }
-    for (int ki = 0; ki < T; ++ki) sds[qi * T + ki] = sp[qi * T + ki] * (sds[qi * T + ki] - rs) * scale;
   }
   __syncthreads();
   if (stop_after == 5) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
@@ -307,24 +330,27 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
     float o0[TMAX], o1[TMAX];
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
+    auto dot16 = [](const float* row, const float* col) {   // row: 16 floats in LDS (wave-uniform address -> broadcast), col: registers
+      const float4 a = *reinterpret_cast<const float4*>(row), b4 = *reinterpret_cast<const float4*>(row + 4);
+      const float4 c = *reinterpret_cast<const float4*>(row + 8), e = *reinterpret_cast<const float4*>(row + 12);
+      float r0 = a.x * col[0], r1 = a.y * col[1], r2 = a.z * col[2], r3 = a.w * col[3];
+      r0 = fmaf(b4.x, col[4], r0); r1 = fmaf(b4.y, col[5], r1); r2 = fmaf(b4.z, col[6], r2); r3 = fmaf(b4.w, col[7], r3);
+      r0 = fmaf(c.x, col[8], r0); r1 = fmaf(c.y, col[9], r1); r2 = fmaf(c.z, col[10], r2); r3 = fmaf(c.w, col[11], r3);
+      r0 = fmaf(e.x, col[12], r0); r1 = fmaf(e.y, col[13], r1); r2 = fmaf(e.z, col[14], r2); r3 = fmaf(e.w, col[15], r3);
+      return (r0 + r1) + (r2 + r3);
+    };
     if (act && role == 0) {
       float kc[TMAX];
 #pragma unroll
       for (int u = 0; u < TMAX; ++u) kc[u] = u < T ? skh[u * HP + d] : 0.f;
 #pragma unroll
-      for (int t = 0; t < TMAX; ++t)
-#pragma unroll
-        for (int u = 0; u <= t; ++u)
-          if (t < T) o0[t] = fmaf(sds[t * T + u], kc[u], o0[t]);
+      for (int t = 0; t < TMAX; ++t) o0[t] = dot16(sds + t * 16, kc);          // causal zeros are in the tile
     } else if (act) {
       float oc[TMAX], qc[TMAX];
 #pragma unroll
       for (int u = 0; u < TMAX; ++u) { oc[u] = u < T ? sdo[u * HP + d] : 0.f; qc[u] = u < T ? sqh[u * HP + d] : 0.f; }
 #pragma unroll
-      for (int j = 0; j < TMAX; ++j)
-#pragma unroll
-        for (int i = j; i < TMAX; ++i)
-          if (i < T) { o0[j] = fmaf(spd[i * T + j], oc[i], o0[j]); o1[j] = fmaf(sds[i * T + j], qc[i], o1[j]); }
+      for (int j = 0; j < TMAX; ++j) { o0[j] = dot16(spdT + j * 16, oc); o1[j] = dot16(sdsT + j * 16, qc); }
     }
     __syncthreads();
   if (stop_after == 6) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
@@ -346,19 +372,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
   __syncthreads();
   if (stop_after == 8) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   // qk-RMSNorm backward (x_hat = x * r * g): dx = g*dxh*r - x * <g*dxh, x> * r^3 / HD  (clamped rows: dx = g*dxh/eps); in place over d x_hat
-  for (int t = wave; t < T; t += 4) {
+  {                                                     // 16 lanes per token: all T tokens in one pass, 4-step xor-shuffle reductions
+    const int t = tid >> 4, l16 = tid & 15;
     float cq = 0.f, ck = 0.f;
-    for (int d = lane; d < HD; d += 64) { cq += qg[d] * sqh[t * HP + d] * sq[t * HP + d]; ck += kg[d] * skh[t * HP + d] * sk[t * HP + d]; }
-    cq = wave_sum(cq); ck = wave_sum(ck);
-    const float rq = srq[t], rk = srk[t];
-    const bool clq = rq >= 1.0f / eps, clk = rk >= 1.0f / eps;
-    for (int d = lane; d < HD; d += 64) {
-      sqh[t * HP + d] = qg[d] * sqh[t * HP + d] * rq - (clq ? 0.f : sq[t * HP + d] * cq * rq * rq * rq / (float)HD);
-      skh[t * HP + d] = kg[d] * skh[t * HP + d] * rk - (clk ? 0.f : sk[t * HP + d] * ck * rk * rk * rk / (float)HD);
+    if (t < T) {
+#pragma unroll 4
+      for (int d = l16; d < HD; d += 16) { cq += qg[d] * sqh[t * HP + d] * sq[t * HP + d]; ck += kg[d] * skh[t * HP + d] * sk[t * HP + d]; }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { cq += __shfl_xor(cq, o, 64); ck += __shfl_xor(ck, o, 64); }
+    if (t < T) {
+      const float rq = srq[t], rk = srk[t];
+      const bool clq = rq >= 1.0f / eps, clk = rk >= 1.0f / eps;
+#pragma unroll 4
+      for (int d = l16; d < HD; d += 16) {
+        sqh[t * HP + d] = qg[d] * sqh[t * HP + d] * rq - (clq ? 0.f : sq[t * HP + d] * cq * rq * rq * rq / (float)HD);
+        skh[t * HP + d] = kg[d] * skh[t * HP + d] * rk - (clk ? 0.f : sk[t * HP + d] * ck * rk * rk * rk / (float)HD);
+      }
     }
   }
   __syncthreads();
-  if (stop_after == 9) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   auto pack = [&](const float* src) -> uint4 {
     uint4 u;
     if constexpr (sizeof(T2) == 2) {
@@ -417,7 +450,7 @@ extern "C" int mode_attn_block_bwd(const void* qkv, const float* q_gain, const f
   if (!qkv || !q_gain || !k_gain || !dy || !dqkv || !dgq_partial || !dgk_partial || B < 0 || T <= 0 || H <= 0) return MODE_ERR_BAD_ARG;
   if (p_drop < 0.f || p_drop >= 1.f) return MODE_ERR_BAD_ARG;
   if (B == 0) return MODE_OK;
-  const size_t lds = ((size_t)6 * T * (head_dim + 1) + 3 * (size_t)T * T + 2 * T) * 4;
+  const size_t lds = ((size_t)6 * T * (head_dim + 1) + 4 + 4 * 256 + 2 * T) * 4;
   if (lds > 64 * 1024 || head_dim > 128 || T > 16 || head_dim % (dtype == MODE_BF16 ? 8 : 4)) return MODE_ERR_UNSUPPORTED;
   const uint32_t th = attn_thresh(p_drop); const float ik = 1.0f / (1.0f - p_drop);
   hipStream_t s = (hipStream_t)stream;
