@@ -237,6 +237,13 @@ int mode_swiglu_fwd(const void* P, void* Hd, int64_t rows, int Hdim, int dtype, 
 int mode_swiglu_bwd(const void* P, const void* dHd, void* dP, int64_t rows, int Hdim, int dtype, uint32_t seed, float p_drop,
                     void* stream);
 
+/* mode_swiglu_bwd_bias — mode_swiglu_bwd fused with the per-expert bias gradient of the up-projection (bf16 only): db[e, 0:2*Hdim] =
+ * column sums of dP over expert e's sorted rows [expert_offsets[e], expert_offsets[e+1]) (autograd's `grad.sum(0)` of
+ * FusedMLPV2's first Linear, modedit.py:52-56), accumulated in registers while dP is produced; db is overwritten. */
+size_t mode_swiglu_bwd_bias_workspace_bytes(int64_t rows, int Hdim, int E);
+int mode_swiglu_bwd_bias(const void* P, const void* dHd, void* dP, int64_t rows, int Hdim, int dtype, uint32_t seed, float p_drop,
+                         const int32_t* expert_offsets, int E, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 /* mode_rmsnorm_bwd — backward of RMSNorm (modedit.py:72-80).  dy[row] = dy_a[row] + dy_b[row] + sum_j G[pos[row*k + j]] (any may be
  * NULL / k = 0; the gather-sum is the MoE dispatch backward); dx (+)= d/dx; dg_partial [ceil(rows/4), D] per-workgroup partial gain
  * gradients (reduce with mode_colsum); dy_out (optional) receives the assembled dy (the conditioning gradient needs it). */

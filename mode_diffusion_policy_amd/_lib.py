@@ -160,6 +160,8 @@ PROTOTYPES = {
     "mode_moe_grouped_mlp_bwd": (C.c_int, [P(ModeGroupedMlpDesc), c_vp, c_sz, c_vp]),
     "mode_rmsnorm_cond_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "mode_rmsnorm_cond_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mode_swiglu_bwd_bias_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
+    "mode_swiglu_bwd_bias": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_u32, c_f32, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "mode_router_logits": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mode_router_mlp_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "mode_iota_i32": (C.c_int, [c_vp, c_i32, c_i32, c_vp]),

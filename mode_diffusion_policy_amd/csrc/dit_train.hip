@@ -53,6 +53,8 @@ TrainWs train_ws(const ModeDims& d, int B, int dtype) {
   const size_t c2 = mode_colsum_workspace_bytes((int)N, 3 * d.D, 1), c3 = mode_colsum_workspace_bytes((int)N, d.D, B);
   if (c2 > cs) cs = c2;
   if (c3 > cs) cs = c3;
+  const size_t c4 = mode_swiglu_bwd_bias_workspace_bytes((int64_t)NK, 4 * d.D, d.E);     // fused SwishGLU backward + bias sums
+  if (c4 > cs) cs = c4;
   w.csw = t(cs + 4096);
   w.dcond = t((size_t)B * D * 4); w.dlog = t((size_t)d.L * B * d.E * 4);           // dlogits of ALL layers [L][B][E]
   w.dhid = t((size_t)d.L * B * D * 4 + 256 * 4);                                   // per-layer partial dcond [L][B][D] + K-group offsets
@@ -263,8 +265,12 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       if ((rc = mode_gemm(&g, stream))) return rc;
     }
     // (3) SwishGLU (+ dropout) backward, bias gradient
-    if ((rc = mode_swiglu_bwd(S + sl.P, dHd, dP, NK, 4 * D, dt, a->seed + 2 * l + 1, a->mlp_pdrop, stream))) return rc;
-    if ((rc = colsum(dP, 8 * D, NK, 8 * D, dt, offsets, 0, E, lg.b1, 0))) return rc;
+    if (dt == MODE_BF16 && D % 2 == 0 && E <= 16) {                  // one pass: dP and the per-expert column sums of dP
+      if ((rc = mode_swiglu_bwd_bias(S + sl.P, dHd, dP, NK, 4 * D, dt, a->seed + 2 * l + 1, a->mlp_pdrop, offsets, E, lg.b1, csw, cswb, stream))) return rc;
+    } else {
+      if ((rc = mode_swiglu_bwd(S + sl.P, dHd, dP, NK, 4 * D, dt, a->seed + 2 * l + 1, a->mlp_pdrop, stream))) return rc;
+      if ((rc = colsum(dP, 8 * D, NK, 8 * D, dt, offsets, 0, E, lg.b1, 0))) return rc;
+    }
     // (4) expert up-projection: dU (sorted rows, fp32) = dP W1 ; dW1_e = dP_e^T U_e
     if (tr) {
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 8 * D, dP, 8 * D, lw.w1, D, dUs, D);
@@ -455,6 +461,8 @@ MlpWs mlp_ws(int N, int D, int E, int k, int dtype) {
   Take t;
   w.dh = t(NK * 4 * D * esz); w.dp = t(NK * 8 * D * esz);
   w.csw_bytes = mode_colsum_workspace_bytes((int)NK, 8 * D, E) + 4096;
+  const size_t fb = mode_swiglu_bwd_bias_workspace_bytes((int64_t)NK, 4 * D, E);
+  if (fb > w.csw_bytes) w.csw_bytes = fb;
   w.csw = t(w.csw_bytes);
   w.total = t.o;
   return w;
@@ -515,8 +523,7 @@ extern "C" int mode_moe_grouped_mlp_bwd(const ModeGroupedMlpDesc* d, void* works
   g.k_group_offsets = d->offsets; g.num_k_groups = E; g.c_group_stride = 4L * D * D; g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
   if ((rc = mode_gemm(&g, stream))) return rc;
   // SwishGLU (+dropout) backward and the bias gradient
-  if ((rc = mode_swiglu_bwd(d->p, dH, dP, NK, 4 * D, dt, d->seed, d->p_drop, stream))) return rc;
-  if ((rc = mode_colsum(dP, 8 * D, NK, 8 * D, dt, d->offsets, 0, E, d->db1, 0, ws + W.csw, W.csw_bytes, stream))) return rc;
+  if ((rc = mode_swiglu_bwd_bias(d->p, dH, dP, NK, 4 * D, dt, d->seed, d->p_drop, d->offsets, E, d->db1, ws + W.csw, W.csw_bytes, stream))) return rc;
   // up-projection: dX (sorted rows) = dP W1 ; dW1_e = dP_e^T X_e (rows gathered through perm)
   g = gdesc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 8 * D, dP, 8 * D, d->w1, D, d->dxs, D);
   g.w_expert_stride = 8L * D * D; g.expert_offsets = d->offsets; g.num_experts = E; g.flags = MODE_GEMM_W_KN;

@@ -346,3 +346,48 @@ def test_rmsnorm_cond_bwd_composite(rows, D, rpc):
     assert rel(dx, x.grad) < 1e-5 and rel(dg, g.grad) < 1e-5
     if rpc:
         assert rel(dc, cond.grad) < 1e-5
+
+
+@pytest.mark.parametrize("rows,Hdim,E,p_drop", [(3584, 4096, 4, 0.1), (70, 64, 4, 0.0), (900, 256, 2, 0.0), (33, 128, 8, 0.25)])
+def test_swiglu_bwd_bias_fused_matches_separate_kernels(rows, Hdim, E, p_drop):
+    """mode_swiglu_bwd_bias == mode_swiglu_bwd followed by the segmented column sum (dP to one bf16 ulp, bias sums to fp32 reduction-order noise),
+    incl. empty experts and segment boundaries that fall inside a row block."""
+    lib = L.load()
+    bf = torch.bfloat16
+    P = rnd(rows, 2 * Hdim, seed=1).to(bf).to(dev()); dH = rnd(rows, Hdim, seed=2).to(bf).to(dev())
+    g = torch.Generator().manual_seed(rows)
+    cuts = sorted(torch.randint(0, rows + 1, (E - 1,), generator=g).tolist())
+    if E >= 4:
+        cuts[1] = cuts[0]                                                    # an empty expert
+    off = torch.tensor([0] + cuts + [rows], dtype=torch.int32, device=dev())
+    dP0 = torch.empty(rows, 2 * Hdim, dtype=bf, device=dev())
+    L.check(lib.mode_swiglu_bwd(P.data_ptr(), dH.data_ptr(), dP0.data_ptr(), rows, Hdim, L.MODE_BF16, 77, p_drop, H.stream()))
+    ref_db = torch.zeros(E, 2 * Hdim)
+    o = off.cpu().tolist()
+    for e in range(E):
+        ref_db[e] = dP0[o[e]:o[e + 1]].float().sum(0).cpu()
+    dP1 = torch.full((rows, 2 * Hdim), float("nan"), dtype=bf, device=dev()); db = torch.full((E, 2 * Hdim), float("nan"), device=dev())
+    wsb = lib.mode_swiglu_bwd_bias_workspace_bytes(rows, Hdim, E)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    L.check(lib.mode_swiglu_bwd_bias(P.data_ptr(), dH.data_ptr(), dP1.data_ptr(), rows, Hdim, L.MODE_BF16, 77, p_drop, off.data_ptr(), E, db.data_ptr(),
+                                     ws.data_ptr(), wsb, H.stream()))
+    # same arithmetic, different instruction selection (fma contraction): equal up to one bf16 ulp on isolated elements
+    assert rel(dP1.float(), dP0.float()) < 1e-3 and float((dP1 != dP0).float().mean()) < 0.02
+    for e in range(E):                                                       # the fused sums are the column sums of the dP it wrote
+        ref_db[e] = dP1[o[e]:o[e + 1]].float().sum(0).cpu()
+    assert torch.isfinite(db).all() and float((db.cpu() - ref_db).abs().max()) <= 1e-4 * max(1.0, float(ref_db.abs().max()))
+    for e in range(E):
+        if o[e] == o[e + 1]:
+            assert float(db[e].abs().max()) == 0.0
+    # the vectorised forward agrees with the element kernel's arithmetic (same hash mask)
+    Hd = torch.empty(rows, Hdim, dtype=bf, device=dev())
+    L.check(lib.mode_swiglu_fwd(P.data_ptr(), Hd.data_ptr(), rows, Hdim, L.MODE_BF16, 77, p_drop, H.stream()))
+    v, gt = P.float().tensor_split(2, dim=-1)
+    ref_h = v * torch.nn.functional.silu(gt)
+    keep = Hd.float() != 0
+    if p_drop > 0:
+        frac = 1.0 - float(keep.float().mean())
+        assert abs(frac - p_drop) < 0.02 + 2.0 / (rows * Hdim) ** 0.5
+        assert rel(Hd.float()[keep], (ref_h / (1 - p_drop))[keep]) < 6e-3
+    else:
+        assert rel(Hd.float(), ref_h) < 6e-3
