@@ -57,7 +57,7 @@ TrainWs train_ws(const ModeDims& d, int B, int dtype) {
   if (c4 > cs) cs = c4;
   w.csw = t(cs + 4096);
   w.dcond = t((size_t)B * D * 4); w.dlog = t((size_t)d.L * B * d.E * 4);           // dlogits of ALL layers [L][B][E]
-  w.dhid = t((size_t)d.L * B * D * 4 + 256 * 4);                                   // per-layer partial dcond [L][B][D] + K-group offsets
+  w.dhid = t((size_t)d.L * 4 * B * D * 4 + 256 * 4);                               // partial dcond [4L][B][D] (4 K-slices per layer) + K-group offsets
   w.dpre = t((size_t)B * d.L * 2 * D * 4);                                         // dpre of ALL layers [B][L][2D]
   const size_t smallT = ((size_t)2 * D > (size_t)d.O ? 2 * D : d.O) * (R > 2 * (size_t)B ? R : 2 * B) * 4 + 4096;
   w.st1 = t(smallT); w.st2 = t(smallT);
@@ -368,8 +368,9 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     const int Ly = d.L, H2 = 2 * D;
     const ModeLayerWeights& w0 = w->layers[0];
     const ModeLayerGrads& g0 = gr->layers[0];
-    float* cpart = dhid;                                                          // [L][B][D] partial dcond per layer
-    int32_t* koffs = reinterpret_cast<int32_t*>(dhid + (size_t)Ly * B * D);       // [L+1] K-group offsets 0, 2D, 4D, ...
+    const int KS = (H2 % 64 == 0) ? 4 : 1;                                        // K-slices per layer: 4x the workgroups, 4x shorter serial K loops
+    float* cpart = dhid;                                                          // [KS*L][B][D] partial dcond
+    int32_t* koffs = reinterpret_cast<int32_t*>(dhid + (size_t)Ly * 4 * B * D);   // [KS*L+1] K-group offsets 0, 2D/KS, ...
     // dlogits through renormalisation / clamp / softmax: all layers in one launch when the expert ids of the layers are adjacent
     const long idx_rows = a->idx_per_token ? (long)N : (long)B;
     if (a->topk_layer_stride == idx_rows * d.k) {
@@ -386,12 +387,12 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     ModeGemmDesc g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, Ly * H2, D, B, dpre, (long)Ly * H2, a->cond, D, g0.r_w0, D);
     g.flags = MODE_GEMM_A_KM | MODE_GEMM_W_KN;
     if ((rc = mode_gemm(&g, stream))) return rc;
-    // dcond += dpre [B, L*2D] W0 [L*2D, D]: one K-group per layer (parallelism), partial results summed in layer order
-    if ((rc = mode_iota_i32(koffs, Ly + 1, H2, stream))) return rc;
+    // dcond += dpre [B, L*2D] W0 [L*2D, D]: KS K-groups per layer (parallelism), partial results summed in a fixed order
+    if ((rc = mode_iota_i32(koffs, KS * Ly + 1, H2 / KS, stream))) return rc;
     g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, B, D, Ly * H2, dpre, (long)Ly * H2, w0.r_w0, D, cpart, D);
-    g.flags = MODE_GEMM_W_KN; g.k_group_offsets = koffs; g.num_k_groups = Ly; g.c_group_stride = (long)B * D;
+    g.flags = MODE_GEMM_W_KN; g.k_group_offsets = koffs; g.num_k_groups = KS * Ly; g.c_group_stride = (long)B * D;
     if ((rc = mode_gemm(&g, stream))) return rc;
-    if ((rc = colsum(cpart, (long)B * D, Ly, B * D, MODE_F32, nullptr, 0, 1, dcond, 1))) return rc;
+    if ((rc = colsum(cpart, (long)B * D, KS * Ly, B * D, MODE_F32, nullptr, 0, 1, dcond, 1))) return rc;
   }
 
   // ---- embeddings: x_0 = [emb_t | goal_e + pos0 | img_e + pos1 | act_e + pos(1..A)]
