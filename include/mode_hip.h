@@ -265,6 +265,9 @@ int mode_gelu_bwd(const float* pre, const float* dout, float* dpre, int64_t n, v
  * idx [B or B*T, k] top-k ids, probs [B, E] -> dlogits [B, E]; through renormalisation, clamp and softmax (SURVEY §8 a-bis). */
 int mode_moe_router_bwd(const float* dw, const int32_t* idx, const float* probs, int B, int T, int E, int k, int normalize,
                         int idx_per_token, float* dlogits, void* stream);
+/* pos_emb gradient (modedit.py:760-790): dx0 [B, T, D] gradient of the embedded token sequence -> dpos [1 + A_len, D]; row 0 <- goal token,
+ * row 1 <- the n_img image tokens + first action token, row 1+a <- action token a.  t0 = 1 when the sigma token is part of the sequence. */
+int mode_pos_emb_bwd(const float* dx0, int B, int T, int D, int t0, int n_img, int A_len, float* dpos, void* stream);
 int mode_sigma_embed_bwd(const float* de1, const float* sigma, int B, int D, float* dw, float* db, void* stream);
 /* ------------------------------------------------------------------------------------------------------------------
  * mode_moe_grouped_mlp_fwd / _bwd — the expert MLP of one MoE block on the SORTED dispatch order (SURVEY §8b minimum exports).

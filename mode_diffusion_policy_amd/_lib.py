@@ -162,6 +162,7 @@ PROTOTYPES = {
     "mode_rmsnorm_cond_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mode_swiglu_bwd_bias_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
     "mode_swiglu_bwd_bias": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_u32, c_f32, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "mode_pos_emb_bwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mode_router_logits": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mode_router_mlp_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "mode_iota_i32": (C.c_int, [c_vp, c_i32, c_i32, c_vp]),

@@ -407,12 +407,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     for (int i = 0; i < d.n_img; ++i)
       if ((rc = mode_rowcopy_f32(DXa, D, t_img + i, T, nullptr, dimg, D, i, d.n_img, nullptr, nullptr, 0, B, D, stream))) return rc;
     // pos_emb: row 0 <- goal token; row 1 <- both image tokens + first action; row 1+a <- action a
-    if ((rc = colsum(DXa + (long)t0 * D, (long)T * D, B, D, MODE_F32, nullptr, 0, 1, gr->pos, 0))) return rc;
-    if ((rc = colsum(DXa + (long)t_act * D, (long)T * D, B, D, MODE_F32, nullptr, 0, 1, gr->pos + D, 0))) return rc;
-    for (int i = 0; i < d.n_img; ++i)
-      if ((rc = colsum(DXa + (long)(t_img + i) * D, (long)T * D, B, D, MODE_F32, nullptr, 0, 1, gr->pos + D, 1))) return rc;
-    for (int ai = 1; ai < d.A_len; ++ai)
-      if ((rc = colsum(DXa + (long)(t_act + ai) * D, (long)T * D, B, D, MODE_F32, nullptr, 0, 1, gr->pos + (long)(1 + ai) * D, 0))) return rc;
+    if ((rc = mode_pos_emb_bwd(DXa, B, T, D, t0, d.n_img, d.A_len, gr->pos, stream))) return rc;
     // action_emb: dW_act [D, A] = dX_act^T [D, R] (actions*c_in) [R, A]
     if ((rc = mode_transpose(DXa, D, R, D, st1, R, a->act_rows, nullptr, MODE_F32, stream))) return rc;
     if ((rc = mode_transpose(a->actions_scaled, A, R, A, st2, R, nullptr, nullptr, MODE_F32, stream))) return rc;

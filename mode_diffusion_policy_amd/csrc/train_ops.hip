@@ -443,6 +443,26 @@ __global__ void router_bwd_kernel(const float* __restrict__ dw, const int* __res
     if (e < E) dlogits[(long)b * E + e] = p[e] * (dp[e] - dot);
 }
 
+// pos_emb backward (modedit.py:760-790: row 0 is added to the goal token, row 1 to BOTH image tokens and the first action token, row 1+a
+// to action token a): dpos[r][d] = sum over samples of the token gradients that row fed.  One thread per (row, d), fixed b order.
+__global__ __launch_bounds__(256) void pos_emb_bwd_kernel(const float* __restrict__ dx0, int B, int T, int D, int t0, int n_img, int A_len,
+                                                          float* __restrict__ dpos) {
+  const int d = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (d >= D) return;
+  const int t_img = t0 + 1, t_act = t_img + n_img;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* row = dx0 + (long)b * T * D + d;
+    if (r == 0) acc += row[(long)t0 * D];
+    else if (r == 1) {
+      float v = row[(long)t_act * D];
+      for (int i = 0; i < n_img; ++i) v += row[(long)(t_img + i) * D];
+      acc += v;
+    } else acc += row[(long)(t_act + r - 1) * D];
+  }
+  dpos[(long)r * D + d] = acc;
+}
+
 // sigma_emb backward: e1[b,d] = s_b * w[d] + bias[d], s_b = ln(sigma_b)/4:  dw[d] = sum_b de1[b,d] s_b, dbias[d] = sum_b de1[b,d]
 __global__ void sigma_embed_bwd_kernel(const float* __restrict__ de1, const float* __restrict__ sigma, int B, int D, float* __restrict__ dw,
                                        float* __restrict__ db) {
@@ -750,4 +770,11 @@ extern "C" int mode_swiglu_bwd_bias(const void* P, const void* dHd, void* dP, in
   MODE_LAUNCH_CHECK();
   // db[e][c] = sum over row blocks of partial[rb][e][c]: rows = nrb, cols = E * 2 * Hdim
   return mode_colsum(partial, (int64_t)E * 2 * Hdim, nrb, E * 2 * Hdim, MODE_F32, nullptr, 0, 1, db, 0, (char*)workspace + (size_t)nrb * E * 2 * Hdim * 4, 0, stream);
+}
+
+extern "C" int mode_pos_emb_bwd(const float* dx0, int B, int T, int D, int t0, int n_img, int A_len, float* dpos, void* stream) {
+  if (!dx0 || !dpos || B < 0 || T <= 0 || D <= 0 || t0 < 0 || n_img < 0 || A_len <= 0 || t0 + 1 + n_img + A_len > T) return MODE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pos_emb_bwd_kernel, dim3((D + 255) / 256, 1 + A_len), dim3(256), 0, (hipStream_t)stream, dx0, B, T, D, t0, n_img, A_len, dpos);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
 }
