@@ -59,7 +59,7 @@ def synthetic_inputs(device, B):
     return img, goal, x0
 
 
-def dominant_kernel_roofline(den, device, reps=60):
+def dominant_kernel_roofline(den, device, reps=240):
     """Dominant kernel = grouped bf16 MFMA GEMM with SwishGLU epilogue (expert up-projection: 47 % of all FLOPs).  Launch it in
     isolation at the benchmark's exact shape (3584 gathered rows = 1792 tokens x top-2, K = 1024, 2 x 4096 weight rows per expert),
     cycling through the 12 layers' weights, timed with HIP events on the stream it is launched on."""
@@ -86,8 +86,9 @@ def dominant_kernel_roofline(den, device, reps=60):
                            expert_offsets=mp + 4 * ml.offsets, num_experts=E)
         descs.append(d)
     st = torch.cuda.current_stream().cuda_stream
-    for d in descs:
-        L.check(lib.mode_gemm(C.byref(d), st))
+    for _ in range(4):                                        # warm-up: clocks, code objects, L2/MALL state of a steady layer loop
+        for d in descs:
+            L.check(lib.mode_gemm(C.byref(d), st))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -100,10 +101,11 @@ def dominant_kernel_roofline(den, device, reps=60):
     ach = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "kernel": "gemm_bf16_kernel<SWIGLU> (grouped expert up-projection, M=3584 K=1024 N=2x4096)",
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            # HBM bytes per launch from the committed PMC passes (profiles/r01_gemm_pmc.md): FETCH_SIZE 61 350 KB x2 (gfx950 correction,
-            # MI355X_MICROARCH.md "HBM") + WRITE_SIZE 28 672 KB; algorithmic bytes per launch are 100.2 MB
-            "traffic": 155.0e6, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_gemm_pmc.md)",
-            "algorithmic_bytes": 100.2e6, "avg_launch_us": round(us, 2), "flops_per_launch": flops}
+            # HBM bytes per launch from the committed PMC passes (profiles/r01_gemm_pmc.md): FETCH_SIZE 60 671 KB x2 (gfx950 correction,
+            # MI355X_MICROARCH.md "HBM") + WRITE_SIZE 28 672 KB; algorithmic bytes per launch (2 of 4 experts active under uniform sigma):
+            # A 3.7 MB + W1 33.6 MB + H 29.4 MB = 66.6 MB
+            "traffic": 153.7e6, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_gemm_pmc.md)",
+            "algorithmic_bytes": 66.6e6, "avg_launch_us": round(us, 2), "flops_per_launch": flops}
 
 
 def cpu_baseline():

@@ -17,6 +17,7 @@ int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N
 
 extern int g_gemm_cfg;
 extern int g_tr_cfg;
+extern int g_gemm_group_m;
 extern int g_attn_bwd_stop;
 extern int g_adamw_blocks;
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -76,6 +77,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!key) return MODE_ERR_BAD_ARG;
   if (!strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return MODE_OK; }
   if (!strcmp(key, "gemm_tr_cfg")) { g_tr_cfg = value; return MODE_OK; }
+  if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return MODE_OK; }
   if (!strcmp(key, "attn_bwd_stop")) { g_attn_bwd_stop = value; return MODE_OK; }
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }
   return MODE_ERR_UNSUPPORTED;

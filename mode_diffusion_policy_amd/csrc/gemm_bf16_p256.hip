@@ -317,6 +317,7 @@ int gemm_bf16_p256_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.resid = d->resid; p.ldr = d->ldr; p.C = d->C; p.ldc = d->ldc;
   p.a_rows = d->a_rows; p.offsets = d->expert_offsets; p.E = d->num_experts;
   p.M = d->M; p.N = d->N; p.K = d->K;
+  p.group_m = 0;
   p.m_tiles = p.n_tiles = 0; p.split_k = 1; p.split_stride = 0; p.koffs = nullptr; p.c_gstride = 0;
   const bool ob = d->out_dtype == MODE_BF16;
 #define MODE_CASE(E) \

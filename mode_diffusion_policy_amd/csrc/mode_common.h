@@ -62,6 +62,7 @@ struct GemmParams {
   int M, N, K, m_tiles, n_tiles;
   int split_k; long split_stride;     // split-K: blockIdx.y = K-slice, output slab = C + slice*split_stride elements
   const int* koffs; long c_gstride;   // K-groups: blockIdx.z = group, K range [koffs[z], koffs[z+1])
+  int group_m;                        // m-tiles per rasterisation group (0 = kernel default)
 };
 
 #define MODE_LAUNCH_CHECK()                                  \
