@@ -9,7 +9,7 @@ swap — SURVEY.md §7 "weight-layout staleness").
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional, Tuple
+from typing import Optional, Tuple
 
 import torch
 

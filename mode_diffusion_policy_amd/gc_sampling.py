@@ -23,7 +23,6 @@ except Exception:  # pragma: no cover
 from .score_wrappers import GCDenoiser
 from .modedit import MoDeDiT
 from .samplers import *  # noqa: F401,F403  the other samplers / schedules MoDEAgent.sample_loop and get_noise_schedule dispatch to
-from .samplers import __all__ as _sampler_names
 
 
 def append_zero(action):

@@ -16,8 +16,6 @@ Not provided (raise ``NotImplementedError`` naming the missing dependency): ``sa
 """
 from __future__ import annotations
 
-import math
-
 import numpy as np
 import torch
 from scipy import integrate

@@ -12,7 +12,7 @@ reference — modedit.py:584-593, 898-969 — but carry no graph; their weights 
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional
+from typing import Dict
 
 import torch
 
