@@ -19,9 +19,6 @@ from .engine import _stream
 
 class FusedAdamW:
     def __init__(self, model, lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05):
-        frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
-        if frozen:
-            raise NotImplementedError(f"FusedAdamW updates the whole arena; frozen parameters are not supported: {frozen[:3]}")
         self.model = model
         eng = model.engine                                   # adopts the parameters into the arena
         self.eng, self.arena = eng, eng.arena
@@ -31,13 +28,42 @@ class FusedAdamW:
         self.step_count = 0
         self._side = None
         self._ema_now = (None, 0.0)
+        self._frozen = []
         self.param_groups = [dict(name="decay", lr=lr, betas=betas, eps=eps, weight_decay=weight_decay),
                              dict(name="no_decay", lr=lr, betas=betas, eps=eps, weight_decay=0.0)]
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         """Gradients are overwritten by every backward; nothing to clear (kept for optimizer-API compatibility)."""
 
+    def _frozen_ranges(self):
+        """Arena element ranges of parameters with ``requires_grad == False`` (``freeze_router()`` for fine-tuning, mode_agent.py:762-766):
+        torch's AdamW skips tensors without a gradient, so these slices are left untouched."""
+        ar = self.arena
+        base = ar.flat.data_ptr()
+        spans = sorted(((p.data_ptr() - base) // 4, (p.data_ptr() - base) // 4 + p.numel()) for p in self.model.parameters() if not p.requires_grad)
+        merged = []
+        for lo, hi in spans:
+            if merged and lo <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], hi)
+            else:
+                merged.append([lo, hi])
+        for lo, hi in merged:
+            if lo % 4 or hi % 4:
+                raise NotImplementedError("frozen parameter ranges must start and end on 16-byte boundaries of the arena")
+        return merged
+
     def _launch(self, lo: int, hi: int, gp, lp, grad_scale: float) -> None:
+        for flo, fhi in self._frozen:                          # carve frozen slices out of [lo, hi)
+            if flo < hi and fhi > lo:
+                if lo < flo:
+                    self._launch_raw(lo, flo, gp, lp, grad_scale)
+                lo = max(lo, fhi)
+                if lo >= hi:
+                    return
+        if lo < hi:
+            self._launch_raw(lo, hi, gp, lp, grad_scale)
+
+    def _launch_raw(self, lo: int, hi: int, gp, lp, grad_scale: float) -> None:
         ar = self.arena
         ema, rate = self._ema_now
         L.check(self.eng.lib.mode_adamw_step(ar.flat[lo:hi].data_ptr(), ar.grad[lo:hi].data_ptr(), self.exp_avg[lo:hi].data_ptr(),
@@ -80,6 +106,7 @@ class FusedAdamW:
         if ar.grad is None:
             raise RuntimeError("no gradients: run a training forward + backward first")
         self.step_count += 1
+        self._frozen = self._frozen_ranges()
         self._ema_now = (None, 0.0)
         if ema is not None and ema.should_apply(self.step_count):
             ema.ensure(ar)

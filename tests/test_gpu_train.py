@@ -233,3 +233,27 @@ def test_arena_ema_fused_standalone_and_swap():
     ema.swap()
     F2 = m({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], sig)
     assert torch.equal(m.engine.arena.flat, live) and torch.equal(F2, F0) and not torch.equal(F1, F0)
+
+
+def test_fused_adamw_respects_frozen_router():
+    """Fine-tuning mode (MoDEAgent.prepare_model_for_finetuning -> inner_model.freeze_router(), mode_agent.py:762-766): router tensors have
+    requires_grad False, get no gradient and must not move (torch's AdamW skips them; decoupled weight decay included)."""
+    from mode_diffusion_policy_amd.optim import FusedAdamW
+    cfg, sd, m = build_train("c1e4", 51, "bf16")
+    m.freeze_router()
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, 8, 3).items()}
+    den = M.GCDenoiser(m, 0.5).train()
+    sig = torch.full((8,), 0.9, device="cuda")
+    opt = FusedAdamW(m, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    for _ in range(2):
+        loss, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
+        loss.backward()
+        opt.step()
+    moved = 0
+    for n, p in m.named_parameters():
+        if "router" in n:
+            assert p.grad is None and torch.equal(p.detach(), before[n]), n
+        elif n != "gripper_embed.weight":
+            moved += int(not torch.equal(p.detach(), before[n]))
+    assert moved > 50
