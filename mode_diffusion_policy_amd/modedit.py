@@ -215,6 +215,8 @@ class MoDeDiT(nn.Module):
         eng = self.engine
         dev = eng.device
         B = actions.shape[0]
+        if B == 0:                                                       # empty batch: empty prediction, no launches
+            return torch.empty(0, self.action_seq_len, self.action_dim, dtype=torch.float32, device=dev)
         T, D = self.seq_len, self.embed_dim
         f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         img = f(states["state_images"])
@@ -259,6 +261,8 @@ class MoDeDiT(nn.Module):
         """GCDenoiser.forward (score_wrappers.py:65-80) with c_in / c_out / c_skip fused into the HIP chain."""
         eng = self.engine
         dev, B, T, D = eng.device, action.shape[0], self.seq_len, self.embed_dim
+        if B == 0:
+            return action.detach().to(device=dev, dtype=torch.float32).clone()
         img, goals = self._prep_obs(eng, states, goals)
         x = action.detach().to(device=dev, dtype=torch.float32).contiguous()
         sig = sigma.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
@@ -311,6 +315,8 @@ class MoDeDiT(nn.Module):
         import os
         eng = self.engine
         dev, B = eng.device, action.shape[0]
+        if B == 0:                                                       # empty batch: nothing to denoise
+            return action.detach().to(device=dev, dtype=torch.float32).clone()
         img, goals = self._prep_obs(eng, states, goals)
         sig = sigmas.detach().to(device=dev, dtype=torch.float32).contiguous()
         x0 = action.detach().to(device=dev, dtype=torch.float32)

@@ -142,6 +142,8 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     ts.ensure()
     lib, dev, d = eng.lib, eng.device, eng.dims
     B, T, D, E, k, Ly = actions.shape[0], model.seq_len, model.embed_dim, model.num_experts, model.top_k, model.num_layers
+    if B == 0:
+        raise ValueError("training forward needs at least one sample")
     N, A_len, A = B * T, model.action_seq_len, model.action_dim
     f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
     img = f(states["state_images"])

@@ -259,3 +259,15 @@ def test_c2_block_oracle_large_batch(golden):
     with torch.no_grad():
         out32 = m({"state_images": c["state_images"]}, c["actions"], c["goals"], sig.cuda())
     assert rel(out32, ref) < 2e-5
+
+
+def test_empty_batch_is_a_no_op():
+    """B = 0 (an evaluation loop whose last shard is empty): empty outputs of the right shape, no kernel launched, no error."""
+    cfg, sd, m = build("c1e4", 3, "bf16")
+    den = M.GCDenoiser(m, 0.5).eval()
+    st = {"state_images": torch.zeros(0, 2, cfg.obs_dim, device="cuda")}
+    a = torch.zeros(0, 10, 7, device="cuda"); g = torch.zeros(0, 1, cfg.goal_dim, device="cuda")
+    sig = M.get_sigmas_exponential(10, 1e-3, 80.0).cuda()
+    assert m(st, a, g, torch.zeros(0, device="cuda")).shape == (0, 10, 7)
+    assert den(st, a, g, torch.zeros(0, device="cuda")).shape == (0, 10, 7)
+    assert M.sample_ddim(den, st, a, g, sig, disable=True).shape == (0, 10, 7)
