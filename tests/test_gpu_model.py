@@ -271,3 +271,22 @@ def test_empty_batch_is_a_no_op():
     assert m(st, a, g, torch.zeros(0, device="cuda")).shape == (0, 10, 7)
     assert den(st, a, g, torch.zeros(0, device="cuda")).shape == (0, 10, 7)
     assert M.sample_ddim(den, st, a, g, sig, disable=True).shape == (0, 10, 7)
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 37, 129])
+def test_ragged_batch_sizes_vs_oracle(B):
+    """Batch sizes that are no multiple of any tile edge (N = 14 B tokens: 14 … 1806): partial GEMM tiles, partially filled expert
+    segments, attention problem counts that do not fill a workgroup — fp32 mode against the oracle, per-sample sigma, router indices exact."""
+    cfg, sd, m = build("c1e4", 210, "fp32")
+    inp = make_inputs(cfg, B, 40 + B)
+    sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(B))
+    ref, aux = O.dit_forward(sd, cfg, inp["state_images"], inp["actions"], inp["goals"], sig, return_aux=True)
+    c = cuda_inputs(inp)
+    with torch.no_grad():
+        out = m({"state_images": c["state_images"]}, c["actions"], c["goals"], sig.cuda())
+    assert torch.equal(m._last_topk.cpu().long(), torch.stack(aux.topk_idx)[:, :, 0, :])
+    assert rel(out, ref) < 1e-4
+    den = M.GCDenoiser(m, 0.5).eval()
+    sched = M.get_sigmas_exponential(5, 1e-3, 80.0)
+    x = M.sample_ddim(den, {"state_images": c["state_images"]}, c["x0"], c["goals"], sched.cuda(), disable=True)
+    assert rel(x, O.sample_ddim(sd, cfg, 0.5, inp["state_images"], inp["x0"], inp["goals"], sched)) < 1e-4
