@@ -60,8 +60,8 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
   else wait_vmcnt<0>();
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (NS == 1 ? 3 : 2))) void gemm_bf16_kernel(const GemmParams p) {
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16, int LR = 0>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? 4 : (NS == 1 ? 3 : 2)))) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;         // 1-KiB DMA pieces (8 rows x 128 B) per wave per operand tile
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (NS == 1 ? 3 : 2)
       if (kt + NS - 1 < nk) stage((slot + NS - 1) % NS, kt0 + kt + NS - 1);   // refill the slot tile kt-1 just vacated
     }
     const uint32_t so = slot * STAGE_BYTES;
-    if constexpr (NW >= 16) {
+    if constexpr (NW >= 16 || LR) {
       // 16 waves share one 256x256 tile (4 per SIMD, <= 128 VGPRs each): one k32 half of fragments at a time; the LDS round trip of a
       // wave is covered by the MFMAs of the three other waves on its SIMD
       read_frags(fa0, fb0, so, c0);
@@ -321,19 +321,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (NS == 1 ? 3 : 2)
 // ------------------------------------------------------------------------------------------------------------ host side
 // geometry ids (also the values of the "gemm_cfg" option; 0 = auto)
 enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x128_NS3 = 2, CFG_256x128_NS3 = 3, CFG_128x64_NS3 = 4, CFG_128x64_NS4 = 5,
-       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10, CFG_256x256_W16 = 11, CFG_P256 = 12 };
+       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10, CFG_256x256_W16 = 11, CFG_P256 = 12, CFG_128x128_NS1_4WG = 13 };
 int gemm_bf16_p256_launch(const ModeGemmDesc* d, hipStream_t s);   // gemm_bf16_p256.hip: persistent 256x256 with cross-tile operand prefetch
 int g_gemm_cfg = CFG_AUTO;
 int g_gemm_group_m = 0;   // "gemm_group_m" option: m-tiles per rasterisation group (0 = default 8; >= m_tiles = n-major partition over the XCDs)
 
-template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16, int LR = 0>
 static int launch_cfg(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   constexpr int NOUT = (EPI == MODE_EPI_SWIGLU) ? BN / 2 : BN;
   constexpr size_t RING = (size_t)NS * (BM + BN) * BK * 2, OUTT = (size_t)(BM / WM) * NOUT * (OUT_BF16 ? 2 : 4);
   constexpr size_t LDS = RING > OUTT ? RING : OUTT;   // whole tile in one pass when it fits the ring, else TM rows per pass
   p.n_tiles = (d->N + NOUT - 1) / NOUT;
   p.m_tiles = (d->M + BM - 1) / BM + (d->expert_offsets ? d->num_experts : 0);
-  auto kern = gemm_bf16_kernel<BM, BN, WM, WN, NS, EPI, OUT_BF16>;
+  auto kern = gemm_bf16_kernel<BM, BN, WM, WN, NS, EPI, OUT_BF16, LR>;
   static bool attr_set = false;
   if (!attr_set && LDS > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
@@ -359,12 +359,14 @@ static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipSt
     case CFG_256x256_NS2: return launch_cfg<256, 256, 2, 4, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_256x128_NS2: return launch_cfg<256, 128, 4, 2, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_256x256_W16: return launch_cfg<256, 256, 4, 4, 2, EPI, OUT_BF16>(p, d, s);
+    case CFG_128x128_NS1_4WG: return launch_cfg<128, 128, 2, 2, 1, EPI, OUT_BF16, 1>(p, d, s);   // <= 128 VGPRs: four 32-KiB workgroups per CU
     default: return MODE_ERR_BAD_ARG;
   }
 }
 
 // Tile-geometry heuristic for 256 CUs, from scripts/gemm_bench.py (--batch 32 / 64 / 128) / gemm_ksweep.py on the config-2 layer shapes:
-//   >= 384 tiles of 128x128 : single-buffered 128x128 at 3 workgroups/CU (other workgroups hide the fill latency)   [expert up-projection]
+//   >= 768 tiles of 128x128 : single-buffered 128x128, <= 128 VGPRs, 4 workgroups/CU (72 vs 76 us at B=128, 41 vs 47 us at B=64)   [expert up-projection]
+//   >= 384                  : single-buffered 128x128 at 3 workgroups/CU (other workgroups hide the fill latency)   [up-projection at B=32]
 //   >= 256                  : double-buffered 128x128 ring                                                          [QKV at B=128]
 //   fewer                   : 128x64 tiles so that more CUs get a workgroup, 3-slot ring (two K-tiles in flight per workgroup: with
 //                             <= 1 workgroup per CU nothing else hides the fill latency)                 [c_proj, expert down-proj, small batches]
@@ -372,6 +374,7 @@ static int pick_cfg(const ModeGemmDesc* d) {
   const long rows = d->M;
   const int nout128 = (d->epilogue == MODE_EPI_SWIGLU) ? 64 : 128;
   const long t128 = ((rows + 127) / 128) * ((d->N + nout128 - 1) / nout128);
+  if (t128 >= 768) return CFG_128x128_NS1_4WG;   // >= 3 tiles per CU: four low-register workgroups per CU interleave fill / LDS / MFMA phases best
   if (t128 >= 384) return CFG_128x128_NS1;
   if (t128 >= 256) return CFG_128x128_NS2;
   return CFG_128x64_NS3;
