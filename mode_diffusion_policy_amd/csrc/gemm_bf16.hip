@@ -61,7 +61,7 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16, int LR = 0>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? 4 : (NS == 1 ? 3 : 2)))) void gemm_bf16_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS == 1 ? 3 : 2)))) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;         // 1-KiB DMA pieces (8 rows x 128 B) per wave per operand tile
@@ -359,7 +359,7 @@ static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipSt
     case CFG_256x256_NS2: return launch_cfg<256, 256, 2, 4, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_256x128_NS2: return launch_cfg<256, 128, 4, 2, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_256x256_W16: return launch_cfg<256, 256, 4, 4, 2, EPI, OUT_BF16>(p, d, s);
-    case CFG_128x128_NS1_4WG: return launch_cfg<128, 128, 2, 2, 1, EPI, OUT_BF16, 1>(p, d, s);   // <= 128 VGPRs: four 32-KiB workgroups per CU
+    case CFG_128x128_NS1_4WG: return launch_cfg<128, 128, 2, 2, 1, EPI, OUT_BF16, 4>(p, d, s);   // <= 128 VGPRs: four 32-KiB workgroups per CU
     default: return MODE_ERR_BAD_ARG;
   }
 }
