@@ -39,7 +39,7 @@ static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
   w.qkv = take(N * 3 * D * esz);
   w.y = take(N * D * esz);
   w.hbuf = take(NK * 4 * D * esz);
-  w.ybuf = take(NK * D * 4);        // expert outputs (compute dtype; sized for fp32)
+  w.ybuf = take(NK * D * 16);       // expert outputs (compute dtype): up to 8 bf16 split-K slabs of the down-projection (or one fp32 slab)
   w.meta = take((size_t)d.L * ml.total_words * 4);
   const size_t Rr = R > 0 ? R : 1;
   w.e1 = take(Rr * D * 4);
@@ -47,6 +47,21 @@ static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
   w.logits = take(Rr * d.E * 4 * d.L);
   w.total = o;
   return w;
+}
+
+int g_dn_split_k = 0;   // "dn_split_k" option: K-slices of the inference-path expert down-projection (0 = default 2, 1 = off, <= 8)
+
+// The expert down-projection [NK, 4D] x [D, 4D]^T has few output tiles (NK*D / 128^2 = 224 at B=128, 56 at B=32) and a long K, so the
+// 256 CUs are not covered by whole-K tiles.  K is cut into TWO slices whose bf16 partial slabs the combine / head kernel adds in slice
+// order (scripts/gemm_bench.py --only gemm2 --y-bf16 --splitk 2: B=128 44.6 -> 38.2 us with 128x128 tiles, B=64 31.9 -> 26.6 us and
+// B=32 29.4 -> 21.9 us with 128x64 tiles; in the chain 466 -> 486 denoise-steps/s).  The slice count is the same for EVERY batch size —
+// 4 slices would be faster still at B=32 (19.0 us) — so that a sample's result does not depend on how many samples share its batch
+// (bit-exact batch-slice consistency, tests/test_gpu_model.py::test_c2_full_size_properties).
+static int down_proj_split(int dt, int K) {
+  if (dt != MODE_BF16) return 1;
+  int s = g_dn_split_k > 0 ? g_dn_split_k : 2;
+  while (s > 1 && K % (64 * s)) s /= 2;
+  return s;
 }
 
 static int check_dims(const ModeDims* d) {
@@ -80,6 +95,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return MODE_OK; }
   if (!strcmp(key, "attn_bwd_stop")) { g_attn_bwd_stop = value; return MODE_OK; }
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }
+  if (!strcmp(key, "dn_split_k")) { if (value < 0 || value > 8) return MODE_ERR_BAD_ARG; g_dn_split_k = value; return MODE_OK; }
   return MODE_ERR_UNSUPPORTED;
 }
 
@@ -224,6 +240,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
   void* ybuf = ws + L.ybuf;
   ModeMetaLayout ml;
   mode_moe_meta_layout(N, d.E, d.k, &ml);
+  const int ysplit = down_proj_split(dt, 4 * D);
   const int cond_rpc = T;   // one conditioning row per sample
   // cond addressing: row b at cond + b*cond_row_stride.  rmsnorm/combine kernels index cond by (row / rows_per_cond) * D, so a
   // shared row (stride 0) is expressed as rows_per_cond = N (every token maps to row 0).
@@ -267,18 +284,19 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     g = gemm_desc(dt, MODE_EPI_NONE, dt, NK, D, 4 * D, hbuf, 4 * D, lw.w2, 4 * D, ybuf, D);   // bf16 Y like the reference's autocast Linear
     g.w_expert_stride = 4L * D * D;
     g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
+    g.split_k = ysplit; g.split_stride = (long)NK * D;
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
     if (l + 1 < d.L) {
       // weighted combine + residual (from the normalised stream) + next block's ln_1 + c
-      rc = mode_moe_combine_norm_fwd(x, ybuf, dt, 1, 0, meta + ml.pos, reinterpret_cast<const float*>(meta + ml.posw), N, D, d.k,
+      rc = mode_moe_combine_norm_fwd(x, ybuf, dt, ysplit, (long)NK * D, meta + ml.pos, reinterpret_cast<const float*>(meta + ml.posw), N, D, d.k,
                                      w->layers[l + 1].ln1_g, a->cond, rpc, d.eps, x, h, dt, stream);
       if (rc) return rc;
     } else {
       ModeHeadDesc hd;
       memset(&hd, 0, sizeof(hd));
       hd.B = B; hd.T = T; hd.D = D; hd.A_len = d.A_len; hd.A_dim = d.A_dim; hd.k = d.k;
-      hd.u = x; hd.Y = ybuf; hd.y_dtype = dt; hd.y_splits = 1; hd.y_split_stride = 0; hd.pos = meta + ml.pos; hd.posw = reinterpret_cast<const float*>(meta + ml.posw);
+      hd.u = x; hd.Y = ybuf; hd.y_dtype = dt; hd.y_splits = ysplit; hd.y_split_stride = (long)NK * D; hd.pos = meta + ml.pos; hd.posw = reinterpret_cast<const float*>(meta + ml.posw);
       hd.g = w->ln_g; hd.eps = d.eps; hd.w_out = w->w_out; hd.b_out = w->b_out;
       hd.x_a = a->actions; hd.scal = a->scal; hd.scal_stride = a->scal_stride;
       hd.F = a->F; hd.denoised = a->denoised; hd.x_next = a->x_next;

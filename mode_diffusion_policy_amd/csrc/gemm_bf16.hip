@@ -374,6 +374,7 @@ static int pick_cfg(const ModeGemmDesc* d) {
   const long rows = d->M;
   const int nout128 = (d->epilogue == MODE_EPI_SWIGLU) ? 64 : 128;
   const long t128 = ((rows + 127) / 128) * ((d->N + nout128 - 1) / nout128);
+  if (d->split_k > 1) return t128 * d->split_k >= 448 ? CFG_128x128_NS2 : CFG_128x64_NS3;   // split-K (down-projection, dit.hip down_proj_split): slices are extra workgroups
   if (t128 >= 768) return CFG_128x128_NS1_4WG;   // >= 3 tiles per CU: four low-register workgroups per CU interleave fill / LDS / MFMA phases best
   if (t128 >= 384) return CFG_128x128_NS1;
   if (t128 >= 256) return CFG_128x128_NS2;

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--splitk", type=int, default=1)
     ap.add_argument("--batch", type=int, default=128, help="samples (tokens = 14 x batch)")
     ap.add_argument("--experts", type=int, default=2, help="active experts: 2 = uniform-sigma inference (all samples route alike), 4 = training-like")
+    ap.add_argument("--y-bf16", action="store_true", help="gemm2 writes bf16 (the product path) instead of fp32")
     ap.add_argument("--nogather", action="store_true", help="gemm1 reads pre-sorted rows (no a_rows gather)")
     a = ap.parse_args()
     lib = L.load()
@@ -62,7 +63,7 @@ def main():
                                                                    bias=b1.data_ptr(), bias_expert_stride=8 * D, C=Hb.data_ptr(), ldc=4 * D,
                                                                    a_rows=(None if a.nogather else mp + 4 * ml.perm), expert_offsets=mp + 4 * ml.offsets, num_experts=E,
                                                                    **(dict(A=xs.data_ptr()) if a.nogather else {})) for i in range(nl)], 2.0 * NK * D * 8 * D),
-        "gemm2 grouped [3584x4096]x[2x1024x4096]": ([desc(out_dtype=L.MODE_F32, M=NK, N=D, K=4 * D, A=hin.data_ptr(), lda=4 * D, W=w2[i].data_ptr(), ldw=4 * D,
+        "gemm2 grouped [3584x4096]x[2x1024x4096]": ([desc(out_dtype=(L.MODE_BF16 if a.y_bf16 else L.MODE_F32), M=NK, N=D, K=4 * D, A=hin.data_ptr(), lda=4 * D, W=w2[i].data_ptr(), ldw=4 * D,
                                                             w_expert_stride=4 * D * D, C=Y.data_ptr(), expert_offsets=mp + 4 * ml.offsets, num_experts=E, split_k=a.splitk,
                                                             split_stride=NK * D) for i in range(nl)], 2.0 * NK * 4 * D * D),
     }

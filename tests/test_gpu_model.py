@@ -290,3 +290,30 @@ def test_ragged_batch_sizes_vs_oracle(B):
     sched = M.get_sigmas_exponential(5, 1e-3, 80.0)
     x = M.sample_ddim(den, {"state_images": c["state_images"]}, c["x0"], c["goals"], sched.cuda(), disable=True)
     assert rel(x, O.sample_ddim(sd, cfg, 0.5, inp["state_images"], inp["x0"], inp["goals"], sched)) < 1e-4
+
+
+@pytest.mark.parametrize("B", [4, 37])
+def test_down_projection_split_k_slices(B):
+    """The inference path cuts the expert down-projection's K into 1-8 slices (dit.hip down_proj_split; bf16 partial slabs summed in slice
+    order by the combine / head kernels): every slice count stays inside the bf16 tolerance against the fp32 oracle, routes identically, and
+    agrees with the unsplit path to bf16 rounding of the partial sums."""
+    from mode_diffusion_policy_amd import _lib as L
+    cfg, sd, m = build("c1e4", 77, "bf16")
+    inp = make_inputs(cfg, B, 90 + B)
+    sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(B))
+    ref, aux = O.dit_forward(sd, cfg, inp["state_images"], inp["actions"], inp["goals"], sig, return_aux=True)
+    c = cuda_inputs(inp)
+    lib = L.load()
+    outs = {}
+    try:
+        for s in (1, 2, 4, 8, 0):
+            assert lib.mode_set_option(b"dn_split_k", s) == 0
+            with torch.no_grad():
+                outs[s] = m({"state_images": c["state_images"]}, c["actions"], c["goals"], sig.cuda()).float().cpu()
+            assert torch.equal(m._last_topk.cpu().long(), torch.stack(aux.topk_idx)[:, :, 0, :])
+            assert rel(outs[s], ref) < 1e-2, s
+    finally:
+        lib.mode_set_option(b"dn_split_k", 0)
+    for s in (2, 4, 8, 0):
+        assert rel(outs[s], outs[1]) < 4e-3, s
+    assert lib.mode_set_option(b"dn_split_k", 9) != 0
