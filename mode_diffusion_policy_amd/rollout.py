@@ -55,6 +55,7 @@ def sample_loop(model, sigmas, x_t, state, goal, sampler_type: str = "ddim", ext
         "dpmpp_2m_sde": lambda: gs.sample_dpmpp_sde(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
         "ddim": lambda: gs.sample_ddim(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
         "dpmpp_2s": lambda: gs.sample_dpmpp_2s(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
+        "debugging": lambda: gs.sample_dpmpp_2_with_lms(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
         "dpmpp_2_with_lms": lambda: gs.sample_dpmpp_2_with_lms(model, state, x_t, goal, sigmas, scaler=sc, disable=True),
     }
     if sampler_type not in table:

@@ -11,8 +11,8 @@ kernels of their own.  They are written against two primitives:
 
 and keep the reference's observable behaviour: argument names and defaults, the callback payload keys of each sampler (``'x'`` vs
 ``'action'``), the ``scaler.clip_output`` hook, Euler fallback on the final ``sigma = 0`` step, and the noise-"churn" of Algorithm 2.
-Not provided (raise ``NotImplementedError`` naming the missing dependency): ``sample_dpmpp_sde`` (needs ``torchsde``'s Brownian tree),
-``sample_dpm_fast`` / ``sample_dpm_adaptive`` (the adaptive-step DPM-Solver class).
+``sample_dpmpp_sde`` runs with any ``noise_sampler=`` callable; its default Brownian-tree sampler needs the optional ``torchsde``.
+``sample_dpm_adaptive`` raises ``NotImplementedError``: the reference function itself fails on every call (see its docstring).
 """
 from __future__ import annotations
 
@@ -304,19 +304,157 @@ def sample_dpmpp_2s(model, state, action, goal, sigmas, scaler=None, extra_args=
     return action
 
 
-def _missing(name, why):
-    def fn(*a, **k):
-        raise NotImplementedError(f"{name} is not provided by the MI355X build: {why}")
-    fn.__name__ = name
-    return fn
+@torch.no_grad()
+def sample_dpmpp_2_with_lms(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None):
+    """The agent's ``'debugging'`` / ``'dpmpp_2_with_lms'`` sampler (gc_sampling.py:797-830): the DPM-Solver++(2M) recurrence again —
+    the reference carries the same update under two names; ``scaler`` is accepted and unused there as well."""
+    return sample_dpmpp_2m(model, state, action, goal, sigmas, scaler=scaler, extra_args=extra_args, callback=callback, disable=disable)
 
 
-sample_dpmpp_sde = _missing("sample_dpmpp_sde", "it needs torchsde's BrownianTree noise sampler (absent from this image)")
-sample_dpm_fast = _missing("sample_dpm_fast", "the adaptive DPM-Solver class is outside the round-1 scope")
-sample_dpm_adaptive = _missing("sample_dpm_adaptive", "the adaptive DPM-Solver class is outside the round-1 scope")
-sample_dpmpp_2_with_lms = _missing("sample_dpmpp_2_with_lms", "debugging sampler of the reference, outside the round-1 scope")
+class BrownianTreeNoiseSampler:
+    """Noise for the SDE sampler drawn from one Brownian path per call site, so that refining the step grid refines the SAME sample
+    path: ``W(t0, t1) / sqrt(|t1 - t0|)`` is a unit normal for every interval (gc_sampling.py:112-162).  Needs ``torchsde`` (imported
+    here, not at module import: the package is optional).  ``seed`` may be a list with one entry per batch item."""
+
+    def __init__(self, x, sigma_min, sigma_max, seed=None, transform=lambda v: v):
+        try:
+            import torchsde
+        except ImportError as e:  # pragma: no cover - depends on the image
+            raise ImportError("sample_dpmpp_sde's default noise sampler needs the optional package 'torchsde'; pass noise_sampler= "
+                              "(a callable (sigma, sigma_next) -> noise like x) to run without it") from e
+        self.transform = transform
+        lo, hi = transform(torch.as_tensor(sigma_min)), transform(torch.as_tensor(sigma_max))
+        self.flip = 1.0
+        if not lo < hi:
+            lo, hi, self.flip = hi, lo, -1.0
+        if seed is None:
+            seed = torch.randint(0, 2 ** 63 - 1, []).item()
+        self.per_item = isinstance(seed, (list, tuple))
+        seeds = list(seed) if self.per_item else [seed]
+        if self.per_item and len(seeds) != x.shape[0]:
+            raise ValueError("one seed per batch item expected")
+        w0 = torch.zeros_like(x[0] if self.per_item else x)
+        self.trees = [torchsde.BrownianTree(lo, w0, hi, entropy=sd) for sd in seeds]
+
+    def __call__(self, sigma, sigma_next):
+        t0, t1 = self.transform(torch.as_tensor(sigma)), self.transform(torch.as_tensor(sigma_next))
+        a, b, sign = (t0, t1, 1.0) if t0 < t1 else (t1, t0, -1.0)
+        w = torch.stack([tree(a, b) for tree in self.trees]) * (self.flip * sign)
+        return (w if self.per_item else w[0]) / (t1 - t0).abs().sqrt()
+
+
+@torch.no_grad()
+def sample_dpmpp_sde(model, state, action, goal, sigmas, extra_args=None, callback=None, disable=None, eta=1.0, s_noise=1.0, scaler=None,
+                     noise_sampler=None, r=1 / 2):
+    """Stochastic DPM-Solver++ (the agent's ``'dpmpp_2m_sde'``, gc_sampling.py:737-793): per step a 2S-style pair of exponential-integrator
+    moves (to the intermediate level t + r h, then to t_next with the two predictions blended by 1/(2r)), each split into a deterministic
+    move to sigma_down and fresh noise of scale sigma_up (``get_ancestral_step``); plain Euler on the final sigma = 0 step."""
+    run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
+    if noise_sampler is None:
+        noise_sampler = BrownianTreeNoiseSampler(action, sigmas[sigmas > 0].min(), sigmas.max())
+    x = action
+    for i in range(len(sigmas) - 1):
+        denoised = run.denoise(x, sigmas[i])
+        run.report(x, i, sigmas[i], sigmas[i], denoised)
+        if sigmas[i + 1] == 0:
+            x = x + to_d(x, sigmas[i], denoised) * (sigmas[i + 1] - sigmas[i])
+            continue
+        t, t_next = sigmas[i].log().neg(), sigmas[i + 1].log().neg()
+        s_mid = (t + (t_next - t) * r).neg().exp()                       # sigma at the intermediate level
+        w = 1 / (2 * r)
+        down, up = get_ancestral_step(sigmas[i], s_mid, eta)
+        x_mid = (down / sigmas[i]) * x - (down.log() - sigmas[i].log()).expm1() * denoised
+        x_mid = x_mid + noise_sampler(sigmas[i], s_mid) * s_noise * up
+        denoised_mid = run.denoise(x_mid, s_mid)
+        down, up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta)
+        blend = (1 - w) * denoised + w * denoised_mid
+        x = (down / sigmas[i]) * x - (down.log() - sigmas[i].log()).expm1() * blend
+        x = run.clip(x + noise_sampler(sigmas[i], sigmas[i + 1]) * s_noise * up)
+    return x
+
+
+class _EpsSolver:
+    """DPM-Solver (Lu et al. 2022, Alg. 1-2) single steps of order 1-3 in the noise-prediction view eps = (x - D(x; sigma)) / sigma on the
+    half-log-SNR axis t = -ln sigma (gc_sampling.py:524-588).  ``e`` is eps at the start of the step, evaluated once by the caller."""
+
+    def __init__(self, run):
+        self.run = run
+
+    @staticmethod
+    def sigma(t):
+        return t.neg().exp()
+
+    def eps(self, x, t):
+        s = self.sigma(t)
+        return (x - self.run.denoise(x, s)) / s
+
+    def step1(self, x, t, t_next, e):
+        return x - self.sigma(t_next) * (t_next - t).expm1() * e
+
+    def step2(self, x, t, t_next, e, r1=1 / 2):
+        h = t_next - t
+        s1 = t + r1 * h
+        e1 = self.eps(x - self.sigma(s1) * (r1 * h).expm1() * e, s1)
+        return x - self.sigma(t_next) * h.expm1() * e - self.sigma(t_next) / (2 * r1) * h.expm1() * (e1 - e)
+
+    def step3(self, x, t, t_next, e, r1=1 / 3, r2=2 / 3):
+        h = t_next - t
+        s1, s2 = t + r1 * h, t + r2 * h
+        e1 = self.eps(x - self.sigma(s1) * (r1 * h).expm1() * e, s1)
+        u2 = x - self.sigma(s2) * (r2 * h).expm1() * e - self.sigma(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1) * (e1 - e)
+        e2 = self.eps(u2, s2)
+        return x - self.sigma(t_next) * h.expm1() * e - self.sigma(t_next) / r2 * (h.expm1() / h - 1) * (e2 - e)
+
+
+@torch.no_grad()
+def sample_dpm_fast(model, state, action, goal, sigma_min, sigma_max, n, scaler=None, extra_args=None, callback=None, disable=None, eta=0.0,
+                    s_noise=1.0, noise_sampler=None):
+    """DPM-Solver-fast: ``n`` denoiser evaluations spent on a uniform grid in t = -ln sigma from sigma_max to sigma_min, third-order steps
+    with a lower-order tail so that the budget is met exactly (gc_sampling.py:589-627, 673-697).  Callback payload: ``x, i, t, t_up,
+    denoised, sigma, sigma_hat``.
+
+    Deviation, stated: with ``noise_sampler=None`` the reference dereferences an undefined name (``default_noise_sampler(x)``,
+    gc_sampling.py:590) and raises ``NameError`` — so does ``MoDEAgent.sample_loop('dpm_fast')``.  Here None means
+    ``default_noise_sampler(action)``, the evident intent; with an explicit sampler both agree (tests/golden/F11)."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError("sigma_min and sigma_max must not be 0")
+    run = _Run(model, state, goal, action, extra_args, None, scaler, "x")
+    solver = _EpsSolver(run)
+    noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+    t_start, t_end = -torch.tensor(sigma_max).log(), -torch.tensor(sigma_min, device=action.device).log()
+    m = n // 3 + 1
+    ts = torch.linspace(t_start, t_end.cpu(), m + 1, device=action.device)
+    orders = [3] * (m - 2) + [2, 1] if n % 3 == 0 else [3] * (m - 1) + [n % 3]
+    x = action
+    for i, order in enumerate(orders):
+        t, t_next = ts[i], ts[i + 1]
+        if eta:
+            down, _ = get_ancestral_step(solver.sigma(t), solver.sigma(t_next), eta)
+            t_to = torch.minimum(t_end, -down.log())
+            up = (solver.sigma(t_next) ** 2 - solver.sigma(t_to) ** 2) ** 0.5
+        else:
+            t_to, up = t_next, 0.0
+        e = solver.eps(x, t)
+        if callback is not None:
+            callback({"sigma": solver.sigma(t), "sigma_hat": solver.sigma(t), "x": x, "i": i, "t": t, "t_up": t, "denoised": x - solver.sigma(t) * e})
+        x = (solver.step1, solver.step2, solver.step3)[order - 1](x, t, t_to, e)
+        x = x + up * s_noise * noise_sampler(solver.sigma(t), solver.sigma(t_next))
+    return x
+
+
+def sample_dpm_adaptive(model, state, action, goal, sigma_min, sigma_max, extra_args=None, callback=None, disable=None, order=3, rtol=0.05,
+                        atol=0.0078, h_init=0.05, pcoeff=0.0, icoeff=1.0, dcoeff=0.0, accept_safety=0.81, eta=0.0, s_noise=1.0,
+                        return_info=False):
+    """Not provided.  In the reference every call fails before the first denoiser evaluation: ``dpm_solver_adaptive`` reads its local
+    ``noise_sampler`` before assigning it (gc_sampling.py:630, ``UnboundLocalError``), so ``MoDEAgent.sample_loop('dpm_adaptive')`` has no
+    behaviour to match and no output to pin an implementation against."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError("sigma_min and sigma_max must not be 0")
+    raise NotImplementedError("sample_dpm_adaptive: the reference implementation raises UnboundLocalError on every call "
+                              "(gc_sampling.py:630); there is no reference behaviour to reproduce")
+
 
 __all__ = ["get_sigmas_vp", "get_sigmas_ve", "cosine_beta_schedule", "get_iddpm_sigmas", "to_d", "default_noise_sampler", "get_ancestral_step",
            "sample_euler", "sample_euler_ancestral", "sample_heun", "sample_dpm_2", "sample_dpm_2_ancestral", "linear_multistep_coeff",
            "sample_lms", "sample_dpmpp_2m", "sample_dpmpp_2s_ancestral", "sample_dpmpp_2s", "sample_dpmpp_sde", "sample_dpm_fast",
-           "sample_dpm_adaptive", "sample_dpmpp_2_with_lms"]
+           "sample_dpm_adaptive", "sample_dpmpp_2_with_lms", "BrownianTreeNoiseSampler"]

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-for b in 32 64; do for sk in 1 2 4 8; do for cfg in 0 1 4 13; do
-echo "== batch=$b splitk=$sk cfg=$cfg"; timeout 120 python scripts/gemm_bench.py --batch $b --only gemm2 --y-bf16 --splitk $sk --opt gemm_cfg=$cfg --reps 60 2>&1 | grep -v "^sum\|amdgpu.ids" ; done; done; done
+for cfg in 0 14 2 4 13; do echo "== cfg=$cfg"; timeout 120 python scripts/gemm_bench.py --only qkv --opt gemm_cfg=$cfg --reps 60 2>&1 | grep -v "^sum\|amdgpu.ids"; done
+python -m pytest tests/test_gpu_kernels.py -q -m gpu -x 2>&1 | tail -2

@@ -30,13 +30,20 @@ def test_dispatch_names_and_errors(golden):
         return 0.5 * action
     x0 = torch.randn(2, 10, 7, generator=torch.Generator().manual_seed(0))
     sig = gc_sampling.get_sigmas_exponential(5, 1e-3, 80.0)
-    for name in ("lms", "heun", "euler", "ancestral", "euler_ancestral", "dpm", "dpmpp_2s_ancestral", "dpmpp_2m", "ddim", "dpmpp_2s"):
+    for name in ("lms", "heun", "euler", "ancestral", "euler_ancestral", "dpm", "dpmpp_2s_ancestral", "dpmpp_2m", "ddim", "dpmpp_2s", "dpm_fast",
+                 "debugging", "dpmpp_2_with_lms"):
         out = rollout.sample_loop(toy, sig, x0, None, None, name)
         assert out.shape == x0.shape and torch.isfinite(out).all(), name
     with pytest.raises(ValueError, match="desired sampler type not found"):
         rollout.sample_loop(toy, sig, x0, None, None, "nope")
-    with pytest.raises(NotImplementedError):
-        rollout.sample_loop(toy, sig, x0, None, None, "dpmpp_2m_sde")
+    with pytest.raises(NotImplementedError):                       # fails on every call in the reference as well (gc_sampling.py:630)
+        rollout.sample_loop(toy, sig, x0, None, None, "dpm_adaptive")
+    try:
+        import torchsde  # noqa: F401
+        assert torch.isfinite(rollout.sample_loop(toy, sig, x0, None, None, "dpmpp_2m_sde")).all()
+    except ImportError:
+        with pytest.raises(ImportError, match="torchsde"):
+            rollout.sample_loop(toy, sig, x0, None, None, "dpmpp_2m_sde")
 
 
 def test_checkpoint_loader_by_key(tmp_path):
