@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MODE_HIP_ABI_VERSION 1
+#define MODE_HIP_ABI_VERSION 2
 
 typedef enum ModeStatus {
   MODE_OK = 0,
@@ -41,7 +41,10 @@ typedef enum ModeEpilogue {
   MODE_EPI_BIAS = 1,      /* C = acc + bias[n]                (nn.Linear with bias)      */
   MODE_EPI_BIAS_GELU = 2, /* C = gelu_erf(acc + bias[n])      (router mlp.0 + GELU)      */
   MODE_EPI_RESIDUAL = 3,  /* C = acc + resid[m, n] (fp32)     (c_proj + residual)        */
-  MODE_EPI_SWIGLU = 4     /* W is [2*N, K]; C[m,n] = (acc[m,n]+b[n]) * silu(acc[m,N+n]+b[N+n])   (SwishGLU) */
+  MODE_EPI_SWIGLU = 4,    /* W is [2*N, K]; C[m,n] = (acc[m,n]+b[n]) * silu(acc[m,N+n]+b[N+n])   (SwishGLU) */
+  MODE_EPI_RESIDUAL_NORM = 5 /* RESIDUAL plus the first half of the NEXT RMSNorm (ln_2, modedit.py:539): v = acc + resid goes to C (fp32),
+                                bf16(v * gain[n]) to C2 and sum_n v^2 over each 64-column group to row_ss_out[m][n/64]; the consumer
+                                (MODE_EPI_SWIGLU with row_ss, the combine / head kernels with u_ss) applies 1/max(|v| D^-1/2, eps) per row */
 } ModeEpilogue;
 
 int mode_hip_version(void);
@@ -88,6 +91,14 @@ typedef struct ModeGemmDesc {
   int32_t flags;                  /* MODE_GEMM_SKINNY_OK: fp32, M <= 16 may use the weight-streaming GEMV kernel (wave-tree reduction
                                      instead of the MFMA k-ordered chain: same fp32 accuracy, different rounding)                   */
   const int32_t* w_rows;          /* MODE_GEMM_A_KM only: optional gather of W's K rows (row r of the reduction reads W[w_rows[r]])  */
+  /* fused ln_2 (bf16 only).  Producer, MODE_EPI_RESIDUAL_NORM (N % 64 == 0): */
+  void* C2; int64_t ldc2;         /* bf16 [M, N]: (acc + resid) * gain[n] — the un-normalised, gain-scaled input of the next GEMM       */
+  const float* gain;              /* fp32 [N]: the RMSNorm gain                                                                          */
+  float* row_ss_out;              /* fp32 [M, N/64]: per-row sums of squares of (acc + resid), one per 64 output columns (fixed order)     */
+  /* Consumer, MODE_EPI_SWIGLU: when row_ss != NULL every accumulator row m (token a_rows[m], or m) is multiplied by                      */
+  const float* row_ss;            /* 1 / max(sqrt(sum_j row_ss[token][j]) * K^-1/2, row_eps) before bias and activation, i.e. the GEMM   */
+  int32_t row_ss_n;               /* reads A = x*gain and produces RMSNorm(x) @ W^T (K = the normalised width D)                          */
+  float row_eps;
 } ModeGemmDesc;
 #define MODE_GEMM_SKINNY_OK 1
 /* Backward-pass operand layouts (bf16, epilogue NONE; replace autograd's mm_backward for nn.Linear, i.e. the `grad @ W` and
@@ -165,6 +176,13 @@ int mode_moe_dispatch_meta(const int32_t* idx, const float* w, int R, int tokens
 int mode_moe_combine_norm_fwd(const float* u, const void* Y, int y_dtype, int y_splits, int64_t y_split_stride,
                               const int32_t* pos, const float* posw, int N, int D, int k, const float* g, const float* cond,
                               int rows_per_cond, float eps, float* x_next, void* h, int h_dtype, void* stream);
+/* Same with ln_2 fused in: u is the UN-normalised residual stream written by a MODE_EPI_RESIDUAL_NORM GEMM and u_ss [N, u_ss_n] its
+ * per-64-column sums of squares; the kernel uses u / max(sqrt(sum u_ss[row]) * D^-1/2, eps) * u_gain in place of u (modedit.py:539 moved
+ * out of a kernel of its own).  u_ss == NULL: identical to mode_moe_combine_norm_fwd. */
+int mode_moe_combine_norm_fused_fwd(const float* u, const float* u_ss, int u_ss_n, const float* u_gain, const void* Y, int y_dtype,
+                                    int y_splits, int64_t y_split_stride, const int32_t* pos, const float* posw, int N, int D, int k,
+                                    const float* g, const float* cond, int rows_per_cond, float eps, float* x_next, void* h, int h_dtype,
+                                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * mode_embed_tokens_fwd — builds the input sequence and the first block's conditioned norm in one pass:
@@ -208,6 +226,7 @@ typedef struct ModeHeadDesc {
   float* F;                                    /* [B, A_len, A_dim] raw network output (may be NULL) */
   float* denoised;                             /* may be NULL */
   float* x_next;                               /* may be NULL; may alias x_a */
+  const float* u_ss; int32_t u_ss_n; const float* u_gain;   /* fused ln_2: u is un-normalised, see mode_moe_combine_norm_fused_fwd (NULL = u as is) */
 } ModeHeadDesc;
 int mode_head_ddim_fwd(const ModeHeadDesc* d, void* stream);
 

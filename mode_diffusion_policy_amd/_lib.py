@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MODE_HIP_LIB", os.path.join(_HERE, "libmode_hip.so"))
 
 MODE_BF16, MODE_F32 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3, 4
-ABI_VERSION = 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_RESIDUAL_NORM = 0, 1, 2, 3, 4, 5
+ABI_VERSION = 2
 GEMM_SKINNY_OK, GEMM_W_KN, GEMM_A_KM = 1, 2, 4
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -29,7 +29,8 @@ class ModeGemmDesc(C.Structure):
                 ("A", c_vp), ("lda", c_i64), ("W", c_vp), ("ldw", c_i64), ("w_expert_stride", c_i64),
                 ("bias", c_vp), ("bias_expert_stride", c_i64), ("resid", c_vp), ("ldr", c_i64), ("C", c_vp), ("ldc", c_i64),
                 ("a_rows", c_vp), ("expert_offsets", c_vp), ("num_experts", c_i32), ("split_k", c_i32), ("split_stride", c_i64), ("k_group_offsets", c_vp), ("num_k_groups", c_i32),
-                ("c_group_stride", c_i64), ("flags", c_i32), ("w_rows", c_vp)]
+                ("c_group_stride", c_i64), ("flags", c_i32), ("w_rows", c_vp),
+                ("C2", c_vp), ("ldc2", c_i64), ("gain", c_vp), ("row_ss_out", c_vp), ("row_ss", c_vp), ("row_ss_n", c_i32), ("row_eps", c_f32)]
 
 
 class ModeEmbedDesc(C.Structure):
@@ -43,7 +44,7 @@ class ModeHeadDesc(C.Structure):
     _fields_ = [("B", c_i32), ("T", c_i32), ("D", c_i32), ("A_len", c_i32), ("A_dim", c_i32), ("k", c_i32),
                 ("u", c_vp), ("Y", c_vp), ("y_dtype", c_i32), ("y_splits", c_i32), ("y_split_stride", c_i64), ("pos", c_vp), ("posw", c_vp), ("g", c_vp), ("eps", c_f32),
                 ("w_out", c_vp), ("b_out", c_vp), ("x_a", c_vp), ("scal", c_vp), ("scal_stride", c_i64),
-                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp)]
+                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp), ("u_ss", c_vp), ("u_ss_n", c_i32), ("u_gain", c_vp)]
 
 
 class ModeDims(C.Structure):
@@ -111,7 +112,7 @@ class ModeForwardArgs(C.Structure):
     _fields_ = [("B", c_i32), ("dtype", c_i32), ("emb_t", c_vp), ("emb_row_stride", c_i64), ("cond", c_vp),
                 ("cond_row_stride", c_i64), ("meta", c_vp), ("meta_layer_stride", c_i64), ("goal_e", c_vp), ("img_e", c_vp),
                 ("actions", c_vp), ("c_in", c_vp), ("c_in_stride", c_i64), ("scal", c_vp), ("scal_stride", c_i64),
-                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp)]
+                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp), ("u_ss", c_vp), ("u_ss_n", c_i32), ("u_gain", c_vp)]
 
 
 P = C.POINTER
@@ -130,6 +131,8 @@ PROTOTYPES = {
     "mode_moe_dispatch_meta": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mode_moe_combine_norm_fwd": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, c_i64, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp, C.c_int,
                                             c_f32, c_vp, c_vp, C.c_int, c_vp]),
+    "mode_moe_combine_norm_fused_fwd": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, C.c_int, C.c_int, c_i64, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp,
+                                                  c_vp, C.c_int, c_f32, c_vp, c_vp, C.c_int, c_vp]),
     "mode_embed_tokens_fwd": (C.c_int, [P(ModeEmbedDesc), c_vp]),
     "mode_head_ddim_fwd": (C.c_int, [P(ModeHeadDesc), c_vp]),
     "mode_ddim_edm_step": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
@@ -198,6 +201,10 @@ def load() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     if lib.mode_hip_version() != ABI_VERSION:
         raise ModeHipUnavailable(f"ABI version mismatch: library {lib.mode_hip_version()} != binding {ABI_VERSION}")
+    for kv in filter(None, os.environ.get("MODE_HIP_OPTS", "").split(",")):     # tuning knobs of mode_set_option, e.g. "fuse_ln2=0,dn_split_k=1"
+        key, _, val = kv.partition("=")
+        if lib.mode_set_option(key.strip().encode(), int(val)) != 0:
+            raise ValueError(f"MODE_HIP_OPTS: unknown or invalid option {kv!r}")
     _lib = lib
     return lib
 

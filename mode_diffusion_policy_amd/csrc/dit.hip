@@ -23,7 +23,7 @@ extern int g_adamw_blocks;
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t x, h, qkv, y, hbuf, ybuf, meta, e1, hid, logits, total;
+  size_t x, h, qkv, y, hbuf, ybuf, rowss, meta, e1, hid, logits, total;
 };
 
 static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
@@ -40,6 +40,7 @@ static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
   w.y = take(N * D * esz);
   w.hbuf = take(NK * 4 * D * esz);
   w.ybuf = take(NK * D * 16);       // expert outputs (compute dtype): up to 8 bf16 split-K slabs of the down-projection (or one fp32 slab)
+  w.rowss = take(N * ((D + 63) / 64) * 4);   // fused ln_2: per-64-column sums of squares of the residual stream
   w.meta = take((size_t)d.L * ml.total_words * 4);
   const size_t Rr = R > 0 ? R : 1;
   w.e1 = take(Rr * D * 4);
@@ -49,6 +50,7 @@ static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
   return w;
 }
 
+int g_fuse_ln2 = 1;     // "fuse_ln2" option: 1 = ln_2 folded into the c_proj epilogue / up-projection epilogue / combine (bf16 path), 0 = its own kernel
 int g_dn_split_k = 0;   // "dn_split_k" option: K-slices of the inference-path expert down-projection (0 = default 2, 1 = off, <= 8)
 
 // The expert down-projection [NK, 4D] x [D, 4D]^T has few output tiles (NK*D / 128^2 = 224 at B=128, 56 at B=32) and a long K, so the
@@ -95,6 +97,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return MODE_OK; }
   if (!strcmp(key, "attn_bwd_stop")) { g_attn_bwd_stop = value; return MODE_OK; }
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }
+  if (!strcmp(key, "fuse_ln2")) { g_fuse_ln2 = value != 0; return MODE_OK; }
   if (!strcmp(key, "dn_split_k")) { if (value < 0 || value > 8) return MODE_ERR_BAD_ARG; g_dn_split_k = value; return MODE_OK; }
   return MODE_ERR_UNSUPPORTED;
 }
@@ -238,6 +241,9 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
   float* x = (float*)(ws + L.x);
   void* h = ws + L.h; void* qkv = ws + L.qkv; void* yat = ws + L.y; void* hbuf = ws + L.hbuf;
   void* ybuf = ws + L.ybuf;
+  float* rowss = (float*)(ws + L.rowss);
+  const bool fuse = g_fuse_ln2 && dt == MODE_BF16 && D % 64 == 0;
+  const int ssn = D / 64;
   ModeMetaLayout ml;
   mode_moe_meta_layout(N, d.E, d.k, &ml);
   const int ysplit = down_proj_split(dt, 4 * D);
@@ -268,17 +274,24 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     rc = mode_attn_block_fwd(qkv, lw.qn_g, lw.kn_g, yat, dt, B, T, d.H, D / d.H, d.eps, 0u, 0.0f, stream);
     if (rc) return rc;
     // c_proj (no bias) + residual, in place on the fp32 stream   (modedit.py:111, 166, 532)
-    g = gemm_desc(dt, MODE_EPI_RESIDUAL, MODE_F32, N, D, D, yat, D, lw.wo, D, x, D);
+    // ln_2 (modedit.py:539) has no kernel of its own on the bf16 path: the c_proj epilogue also writes bf16(x * g) and per-64-column sums of
+    // squares of x, the up-projection scales its accumulator rows by 1 / max(|x| D^-1/2, eps) — (x g / n) W^T == ((x g) W^T) / n — and the
+    // combine / head kernel rebuilds the normalised fp32 residual from x, the sums and g.
+    g = gemm_desc(dt, fuse ? MODE_EPI_RESIDUAL_NORM : MODE_EPI_RESIDUAL, MODE_F32, N, D, D, yat, D, lw.wo, D, x, D);
     g.resid = x; g.ldr = D;
+    if (fuse) { g.C2 = h; g.ldc2 = D; g.gain = lw.ln2_g; g.row_ss_out = rowss; }
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
-    // x = ln_2(x): overwrites the stream (modedit.py:539); low-precision copy feeds the experts
-    rc = mode_rmsnorm_cond_fwd(x, lw.ln2_g, nullptr, N, D, 1, d.eps, x, h, dt, stream);
-    if (rc) return rc;
+    if (!fuse) {
+      // x = ln_2(x): overwrites the stream (modedit.py:539); low-precision copy feeds the experts
+      rc = mode_rmsnorm_cond_fwd(x, lw.ln2_g, nullptr, N, D, 1, d.eps, x, h, dt, stream);
+      if (rc) return rc;
+    }
     // experts: gather -> grouped GEMM (SwishGLU epilogue) -> grouped GEMM   (modedit.py:561-566, 83-90, 247-255)
     g = gemm_desc(dt, MODE_EPI_SWIGLU, dt, NK, 4 * D, D, h, D, lw.w1, D, hbuf, 4 * D);
     g.bias = lw.b1; g.w_expert_stride = 8L * D * D; g.bias_expert_stride = 8L * D;
     g.a_rows = meta + ml.perm; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
+    if (fuse) { g.row_ss = rowss; g.row_ss_n = ssn; g.row_eps = d.eps; }
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
     g = gemm_desc(dt, MODE_EPI_NONE, dt, NK, D, 4 * D, hbuf, 4 * D, lw.w2, 4 * D, ybuf, D);   // bf16 Y like the reference's autocast Linear
@@ -289,15 +302,16 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     if (rc) return rc;
     if (l + 1 < d.L) {
       // weighted combine + residual (from the normalised stream) + next block's ln_1 + c
-      rc = mode_moe_combine_norm_fwd(x, ybuf, dt, ysplit, (long)NK * D, meta + ml.pos, reinterpret_cast<const float*>(meta + ml.posw), N, D, d.k,
-                                     w->layers[l + 1].ln1_g, a->cond, rpc, d.eps, x, h, dt, stream);
+      rc = mode_moe_combine_norm_fused_fwd(x, fuse ? rowss : nullptr, ssn, lw.ln2_g, ybuf, dt, ysplit, (long)NK * D, meta + ml.pos,
+                                           reinterpret_cast<const float*>(meta + ml.posw), N, D, d.k, w->layers[l + 1].ln1_g, a->cond, rpc, d.eps,
+                                           x, h, dt, stream);
       if (rc) return rc;
     } else {
       ModeHeadDesc hd;
       memset(&hd, 0, sizeof(hd));
       hd.B = B; hd.T = T; hd.D = D; hd.A_len = d.A_len; hd.A_dim = d.A_dim; hd.k = d.k;
       hd.u = x; hd.Y = ybuf; hd.y_dtype = dt; hd.y_splits = ysplit; hd.y_split_stride = (long)NK * D; hd.pos = meta + ml.pos; hd.posw = reinterpret_cast<const float*>(meta + ml.posw);
-      hd.g = w->ln_g; hd.eps = d.eps; hd.w_out = w->w_out; hd.b_out = w->b_out;
+      hd.g = w->ln_g; hd.eps = d.eps; hd.u_ss = fuse ? rowss : nullptr; hd.u_ss_n = ssn; hd.u_gain = lw.ln2_g; hd.w_out = w->w_out; hd.b_out = w->b_out;
       hd.x_a = a->actions; hd.scal = a->scal; hd.scal_stride = a->scal_stride;
       hd.F = a->F; hd.denoised = a->denoised; hd.x_next = a->x_next;
       rc = mode_head_ddim_fwd(&hd, stream);

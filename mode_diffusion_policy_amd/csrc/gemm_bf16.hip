@@ -128,12 +128,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
   const int r8 = lane >> 3, lchunk = (lane & 7) ^ r8;
   const uint16_t* a_src[PA];
   const uint16_t* b_src[PB];
+  [[maybe_unused]] long a_tok[PA];                                 // token row behind each DMA row (fused ln_2 consumer)
 #pragma unroll
   for (int q = 0; q < PA; ++q) {
     const int tr = (wave * PA + q) * 8 + r8;
     const int s = min(row0 + tr, row_end - 1);                   // rows past the segment re-read a valid row (never stored)
     const long arow = p.a_rows ? (long)p.a_rows[s] : (long)s;
     a_src[q] = p.A + arow * p.lda + lchunk * 8;
+    a_tok[q] = arow;
   }
 #pragma unroll
   for (int q = 0; q < PB; ++q) {
@@ -144,6 +146,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
     b_src[q] = W + brow * p.ldw + lchunk * 8;
   }
 
+  // fused ln_2 consumer: 1 / max(|x_row| K^-1/2, eps) of this tile's rows from the producer's per-64-column partial sums -> LDS strip past
+  // the ring (read again in the epilogue; the loads overlap the first operand tile's fill)
+  constexpr int RING_BYTES = NS * STAGE_BYTES, OUT_BYTES = (BM / WM) * NOUT * ESZ;
+  float* inv_nrm = reinterpret_cast<float*>(smem + (RING_BYTES > OUT_BYTES ? RING_BYTES : OUT_BYTES));
   auto stage = [&](int slot, int kt) {
     char* base = smem + slot * STAGE_BYTES;
     const int koff = kt * BK;
@@ -197,6 +203,36 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
 #pragma unroll
   for (int s = 0; s < PRE; ++s)
     if (s < nk) stage(s, kt0 + s);
+  if constexpr (EPI == MODE_EPI_SWIGLU) {
+    // fused ln_2 consumer: 1 / max(|x_row| K^-1/2, eps) of this tile's rows -> LDS strip past the ring (read in the epilogue).  The 8 lanes that
+    // DMA one A row share its token id (a_tok): each fetches every 8th partial sum, a 3-step shuffle adds them — issued right behind the first
+    // operand tile, no second dependent a_rows load.
+    if (p.ss_in) {
+      const int j0 = lane & 7, nss = p.ss_n;
+      float part[PA];
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {                                // all 2*PA loads in flight together (clamped index + select: no branches)
+        const float* sp = p.ss_in + a_tok[q] * nss;
+        const float v0 = sp[min(j0, nss - 1)], v1 = sp[min(j0 + 8, nss - 1)];
+        part[q] = (j0 < nss ? v0 : 0.f) + (j0 + 8 < nss ? v1 : 0.f);
+      }
+      if (nss > 16) {                                                // D > 1024
+#pragma unroll
+        for (int q = 0; q < PA; ++q)
+          for (int j = j0 + 16; j < nss; j += 8) part[q] += p.ss_in[a_tok[q] * nss + j];
+      }
+#pragma unroll
+      for (int sh = 1; sh < 8; sh <<= 1) {
+#pragma unroll
+        for (int q = 0; q < PA; ++q) part[q] += __shfl_xor(part[q], sh, 64);
+      }
+      const float rk = rsqrtf((float)p.K);
+#pragma unroll
+      for (int q = 0; q < PA; ++q)
+        if (j0 == 0) inv_nrm[(wave * PA + q) * 8 + r8] = __frcp_rn(fmaxf(__fsqrt_rn(part[q]) * rk, p.ss_eps));
+    }
+  }
+
   int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt landed for this wave's pieces; younger tiles stay in flight across the barrier
@@ -248,6 +284,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
   __builtin_amdgcn_s_barrier();                                    // all waves are done reading operand tiles
   constexpr int EPASS = (BM * CROW <= NS * STAGE_BYTES) ? 1 : WM;   // epilogue passes
   constexpr int RP = BM / EPASS;                                   // rows per pass
+  [[maybe_unused]] float rs[FM];                                   // fused ln_2: inverse row norms of this lane's rows, read once (x 1.0f is exact)
+  if constexpr (EPI == MODE_EPI_SWIGLU) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) rs[i] = p.ss_in ? inv_nrm[wm * TM + i * 16 + fr] : 1.0f;
+  }
 #pragma unroll 1
   for (int g = 0; g < EPASS; ++g) {
     if (EPASS == 1 || wm == g) {
@@ -264,7 +305,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
             const int n = min(n0 + nl, p.N - 4);
             const float4 bp = *reinterpret_cast<const float4*>(bias + n);
             const float4 bg = *reinterpret_cast<const float4*>(bias + p.N + n);
-            const f32x4 v = acc[i][j], gt = acc[i][j + FN / 2];
+            const f32x4 v = acc[i][j] * rs[i], gt = acc[i][j + FN / 2] * rs[i];
             const float o0 = (v[0] + bp.x) * silu_f(gt[0] + bg.x), o1 = (v[1] + bp.y) * silu_f(gt[1] + bg.y);
             const float o2 = (v[2] + bp.z) * silu_f(gt[2] + bg.z), o3 = (v[3] + bp.w) * silu_f(gt[3] + bg.w);
             if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(cpos(nl)) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
@@ -291,6 +332,41 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     constexpr int EPC = 16 / ESZ;                                  // elements per 16-byte chunk
+    if constexpr (EPI == MODE_EPI_RESIDUAL_NORM && !OUT_BF16) {
+      // v = acc + resid -> C (fp32); bf16(v * gain) -> C2; sum of v^2 over this row's 64-column group -> ss_out (16 lanes = 64 columns, fixed
+      // shuffle order: deterministic).  Four chunks per batch: the residual / gain loads of a batch are all in flight before the first use;
+      // every lane takes part in the shuffles, out-of-range lanes contribute zeros.
+      constexpr int ITERS = RP * CPR / NT, BATCH = ITERS % 4 == 0 ? 4 : 1;
+      static_assert((RP * CPR) % NT == 0, "output tile must split evenly over the workgroup");
+#pragma unroll 1
+      for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+        float4 rr[BATCH], gq[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+          const int c = tid + (it0 + u) * NT, rl = c / CPR, ch = c % CPR, ml = g * RP + rl, n = n0 + ch * 4;
+          const bool ok = ml < rows_valid && n < p.N;
+          rr[u] = ok ? *reinterpret_cast<const float4*>(p.resid + (long)(row0 + ml) * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+          gq[u] = ok ? *reinterpret_cast<const float4*>(p.gain + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+          const int c = tid + (it0 + u) * NT, rl = c / CPR, ch = c % CPR, ml = g * RP + rl, n = n0 + ch * 4;
+          const bool ok = ml < rows_valid && n < p.N;
+          const long m = row0 + (ok ? ml : 0);
+          float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) {
+            f = *reinterpret_cast<const float4*>(smem + rl * CROW + ((ch ^ (rl & CSWZ)) << 4));
+            f.x += rr[u].x; f.y += rr[u].y; f.z += rr[u].z; f.w += rr[u].w;
+            *reinterpret_cast<float4*>(Cout + (m * p.ldc + n) * 4) = f;
+            *reinterpret_cast<uint2*>(p.C2 + m * p.ldc2 + n) =
+                make_uint2(pack_bf16x2(f.x * gq[u].x, f.y * gq[u].y), pack_bf16x2(f.z * gq[u].z, f.w * gq[u].w));
+          }
+          float ss = f.x * f.x + f.y * f.y + f.z * f.z + f.w * f.w;
+          ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 1, 64);
+          if (ok && (lane & 15) == 0) p.ss_out[m * (p.N >> 6) + (n >> 6)] = ss;
+        }
+      }
+    } else
     for (int c = tid; c < RP * CPR; c += NT) {
       const int rl = c / CPR, ch = c % CPR;
       const int ml = g * RP + rl;
@@ -330,7 +406,7 @@ template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16, int LR
 static int launch_cfg(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   constexpr int NOUT = (EPI == MODE_EPI_SWIGLU) ? BN / 2 : BN;
   constexpr size_t RING = (size_t)NS * (BM + BN) * BK * 2, OUTT = (size_t)(BM / WM) * NOUT * (OUT_BF16 ? 2 : 4);
-  constexpr size_t LDS = RING > OUTT ? RING : OUTT;   // whole tile in one pass when it fits the ring, else TM rows per pass
+  constexpr size_t LDS = (RING > OUTT ? RING : OUTT) + (EPI == MODE_EPI_SWIGLU ? BM * 4 : 0);   // whole tile in one pass when it fits the ring, else TM rows per pass; + the inverse row norms of the fused ln_2
   p.n_tiles = (d->N + NOUT - 1) / NOUT;
   p.m_tiles = (d->M + BM - 1) / BM + (d->expert_offsets ? d->num_experts : 0);
   auto kern = gemm_bf16_kernel<BM, BN, WM, WN, NS, EPI, OUT_BF16, LR>;
@@ -386,7 +462,10 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
   if (d->N % 4 != 0 || d->lda % 8 != 0 || d->ldw % 8 != 0 || d->ldc % 4 != 0) return MODE_ERR_UNSUPPORTED;
   if ((d->epilogue == MODE_EPI_BIAS || d->epilogue == MODE_EPI_BIAS_GELU || d->epilogue == MODE_EPI_SWIGLU) && !d->bias)
     return MODE_ERR_BAD_ARG;
-  if (d->epilogue == MODE_EPI_RESIDUAL && (!d->resid || d->out_dtype != MODE_F32 || d->ldr % 4)) return MODE_ERR_BAD_ARG;
+  if ((d->epilogue == MODE_EPI_RESIDUAL || d->epilogue == MODE_EPI_RESIDUAL_NORM) && (!d->resid || d->out_dtype != MODE_F32 || d->ldr % 4))
+    return MODE_ERR_BAD_ARG;
+  if (d->epilogue == MODE_EPI_RESIDUAL_NORM && (!d->C2 || !d->gain || !d->row_ss_out || d->N % 64 || d->ldc2 % 4 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
+  if (d->row_ss && (d->epilogue != MODE_EPI_SWIGLU || d->row_ss_n <= 0)) return MODE_ERR_BAD_ARG;
   if (d->M <= 0) return MODE_OK;
   GemmParams p;
   p.A = (const uint16_t*)d->A; p.lda = d->lda;
@@ -406,10 +485,12 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
   const long a_elems = (long)d->M * d->K, w_elems = (long)(d->epilogue == MODE_EPI_SWIGLU ? 2 : 1) * d->N * d->K * (d->expert_offsets ? d->num_experts : 1);
   p.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : (2 * a_elems <= w_elems ? (1 << 20) : 0);
   p.koffs = d->k_group_offsets; p.c_gstride = d->c_group_stride;
+  p.C2 = (uint16_t*)d->C2; p.ldc2 = d->ldc2; p.gain = d->gain; p.ss_out = d->row_ss_out;
+  p.ss_in = d->row_ss; p.ss_n = d->row_ss_n; p.ss_eps = d->row_eps;
   if (p.koffs && (d->num_k_groups <= 0 || p.split_k > 1 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
   const int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d);
   if (cfg == CFG_P256) {
-    if (p.split_k > 1 || p.koffs) return MODE_ERR_UNSUPPORTED;
+    if (p.split_k > 1 || p.koffs || p.ss_in || d->epilogue == MODE_EPI_RESIDUAL_NORM) return MODE_ERR_UNSUPPORTED;
     return gemm_bf16_p256_launch(d, s);
   }
   const bool ob = d->out_dtype == MODE_BF16;
@@ -421,6 +502,7 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
     MODE_CASE(MODE_EPI_BIAS_GELU)
     MODE_CASE(MODE_EPI_RESIDUAL)
     MODE_CASE(MODE_EPI_SWIGLU)
+    case MODE_EPI_RESIDUAL_NORM: return ob ? MODE_ERR_BAD_ARG : launch_epi<MODE_EPI_RESIDUAL_NORM, false>(p, d, cfg, s);
     default: return MODE_ERR_BAD_ARG;
   }
 #undef MODE_CASE

@@ -307,7 +307,7 @@ static int launch_f32(const GemmF32Params& p, int nblk, bool vec, int ngroups, h
 }
 
 int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s) {
-  if (d->K <= 0 || d->split_k > 1) return MODE_ERR_UNSUPPORTED;
+  if (d->K <= 0 || d->split_k > 1 || d->row_ss || d->epilogue == MODE_EPI_RESIDUAL_NORM) return MODE_ERR_UNSUPPORTED;
   if ((d->epilogue == MODE_EPI_BIAS || d->epilogue == MODE_EPI_BIAS_GELU || d->epilogue == MODE_EPI_SWIGLU) && !d->bias)
     return MODE_ERR_BAD_ARG;
   if (d->epilogue == MODE_EPI_RESIDUAL && !d->resid) return MODE_ERR_BAD_ARG;

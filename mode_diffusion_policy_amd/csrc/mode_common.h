@@ -63,7 +63,23 @@ struct GemmParams {
   int split_k; long split_stride;     // split-K: blockIdx.y = K-slice, output slab = C + slice*split_stride elements
   const int* koffs; long c_gstride;   // K-groups: blockIdx.z = group, K range [koffs[z], koffs[z+1])
   int group_m;                        // m-tiles per rasterisation group (0 = kernel default)
+  // fused ln_2 (MODE_EPI_RESIDUAL_NORM producer / MODE_EPI_SWIGLU consumer): see include/mode_hip.h
+  uint16_t* C2; long ldc2; const float* gain; float* ss_out;   // producer: bf16((acc+resid)*gain[n]) and per-64-column row sums of squares
+  const float* ss_in; int ss_n; float ss_eps;                   // consumer: acc rows scaled by 1/max(sqrt(sum ss_in[row][0..ss_n)) * K^-1/2, eps)
 };
+
+// Sum of the per-64-column partial sums of squares of one row (fused ln_2), ascending j.  The first 16 (D <= 1024) are fetched by independent
+// (index-clamped) loads so that one memory round trip covers them; producer: gemm_bf16.hip MODE_EPI_RESIDUAL_NORM.
+__device__ __forceinline__ float sum_row_partials(const float* __restrict__ sp, int n) {
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = sp[min(j, n - 1)];      // clamped index + select below: branch-free, all loads in flight together
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += j < n ? v[j] : 0.f;
+  for (int j = 16; j < n; ++j) s += sp[j];
+  return s;
+}
 
 #define MODE_LAUNCH_CHECK()                                  \
   do {                                                       \

@@ -48,6 +48,12 @@ __device__ __forceinline__ void norm_store(const float* row, int D, float ssq, c
   });
 }
 
+// Fused ln_2: the residual operand u arrives un-normalised together with per-64-column sums of squares (MODE_EPI_RESIDUAL_NORM); the
+// normalised row is u / max(sqrt(sum) * D^-1/2, eps) * gain, the expression of norm_store, evaluated on the fly.
+__device__ __forceinline__ float row_norm_from_partials(const float* ss, int n, int D, float eps) {
+  return fmaxf(sqrtf(sum_row_partials(ss, n)) * rsqrtf((float)D), eps);   // same order as the GEMM-side consumer (gemm_bf16.hip)
+}
+
 __device__ __forceinline__ float4 load_y4(const void* Y, bool y_bf16, long off) {
   if (y_bf16) {
     const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(Y) + off);
@@ -81,19 +87,22 @@ __global__ __launch_bounds__(256) void rmsnorm_cond_kernel(const float* x, const
 }
 
 // ------------------------------------------------------------------------------------------------------- combine + norm
-template <bool LP_BF16, int NCH, int KK>   // KK = top_k when known at compile time (1, 2), else 0
+template <bool LP_BF16, int NCH, int KK, bool FUSED>   // KK = top_k when known at compile time (1, 2), else 0; FUSED = ln_2 applied to u here
 __global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const void* __restrict__ Y, int y_bf16, int y_splits,
                                                            long y_split_stride, const int* __restrict__ pos,
                                                            const float* __restrict__ posw, int N, int D, int k,
                                                            const float* __restrict__ g,
                                                            const float* __restrict__ cond, int rpc, float eps, float* x_next,
-                                                           void* h) {
+                                                           void* h, const float* __restrict__ u_ss, int u_ss_n,
+                                                           const float* __restrict__ u_gain) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * ROWS_PER_BLOCK + wave;
   if (row >= N) return;
   float* cache = reinterpret_cast<float*>(smem) + (size_t)wave * D;
   const float* ur = u + (long)row * D;
+  float u_nrm = 1.0f;
+  if constexpr (FUSED) u_nrm = row_norm_from_partials(u_ss + (long)row * u_ss_n, u_ss_n, D, eps);
   const int kk = KK ? KK : k;
   long prow[KK ? KK : 8]; float pw[KK ? KK : 8];
 #pragma unroll
@@ -102,7 +111,11 @@ __global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const
   }
   float ssq = 0.f;
   for_chunks<NCH>(D, lane, [&](int d) {
-    const float4 uu = *reinterpret_cast<const float4*>(ur + d);
+    float4 uu = *reinterpret_cast<const float4*>(ur + d);
+    if constexpr (FUSED) {                                // ln_2 applied here instead of in a kernel of its own
+      const float4 gg = *reinterpret_cast<const float4*>(u_gain + d);
+      uu = make_float4(uu.x / u_nrm * gg.x, uu.y / u_nrm * gg.y, uu.z / u_nrm * gg.z, uu.w / u_nrm * gg.w);
+    }
     float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < (KK ? KK : 8); ++j) {           // ascending expert id: next += w * expert(x)   (modedit.py:566)
@@ -193,9 +206,14 @@ __global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
   float* cache = reinterpret_cast<float*>(smem) + (size_t)wave * D;
   const float* ur = h.u + row * D;
   const bool ybf = h.y_dtype == MODE_BF16;
+  const float u_nrm = h.u_ss ? row_norm_from_partials(h.u_ss + row * h.u_ss_n, h.u_ss_n, D, h.eps) : 1.0f;
   float ssq = 0.f;
   for (int d = lane * 4; d < D; d += 256) {
-    const float4 uu = *reinterpret_cast<const float4*>(ur + d);
+    float4 uu = *reinterpret_cast<const float4*>(ur + d);
+    if (h.u_ss) {
+      const float4 gg = *reinterpret_cast<const float4*>(h.u_gain + d);
+      uu = make_float4(uu.x / u_nrm * gg.x, uu.y / u_nrm * gg.y, uu.z / u_nrm * gg.z, uu.w / u_nrm * gg.w);
+    }
     float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < h.k; ++j) {
       const long p = h.pos[row * h.k + j];
@@ -297,28 +315,32 @@ extern "C" int mode_rmsnorm_cond_fwd(const float* x, const float* g, const float
 template <bool LP, int NCH>
 static void launch_combine_k(dim3 grid, size_t lds, hipStream_t st, const float* u, const void* Y, int ybf, int ys, long yss, const int* pos,
                              const float* posw, int N, int D, int k, const float* g, const float* cond, int rpc, float eps, float* x_next,
-                             void* h) {
-  if (k == 2) hipLaunchKernelGGL((combine_norm_kernel<LP, NCH, 2>), grid, dim3(256), lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h);
-  else if (k == 1) hipLaunchKernelGGL((combine_norm_kernel<LP, NCH, 1>), grid, dim3(256), lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h);
-  else hipLaunchKernelGGL((combine_norm_kernel<LP, NCH, 0>), grid, dim3(256), lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h);
+                             void* h, const float* u_ss, int u_ss_n, const float* u_gain) {
+#define MODE_COMBINE(KK, F) hipLaunchKernelGGL((combine_norm_kernel<LP, NCH, KK, F>), grid, dim3(256), lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h, u_ss, u_ss_n, u_gain)
+  if (u_ss) { if (k == 2) MODE_COMBINE(2, true); else if (k == 1) MODE_COMBINE(1, true); else MODE_COMBINE(0, true); }
+  else { if (k == 2) MODE_COMBINE(2, false); else if (k == 1) MODE_COMBINE(1, false); else MODE_COMBINE(0, false); }
+#undef MODE_COMBINE
 }
 
 template <bool LP>
 static void launch_combine(dim3 grid, size_t lds, hipStream_t st, const float* u, const void* Y, int ybf, int ys, long yss, const int* pos,
-                           const float* posw, int N, int D, int k, const float* g, const float* cond, int rpc, float eps, float* x_next, void* h) {
+                           const float* posw, int N, int D, int k, const float* g, const float* cond, int rpc, float eps, float* x_next, void* h,
+                           const float* u_ss, int u_ss_n, const float* u_gain) {
   switch (D) {
-    case 256: launch_combine_k<LP, 1>(grid, lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h); break;
-    case 512: launch_combine_k<LP, 2>(grid, lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h); break;
-    case 1024: launch_combine_k<LP, 4>(grid, lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h); break;
-    default: launch_combine_k<LP, 0>(grid, lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h);
+    case 256: launch_combine_k<LP, 1>(grid, lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h, u_ss, u_ss_n, u_gain); break;
+    case 512: launch_combine_k<LP, 2>(grid, lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h, u_ss, u_ss_n, u_gain); break;
+    case 1024: launch_combine_k<LP, 4>(grid, lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h, u_ss, u_ss_n, u_gain); break;
+    default: launch_combine_k<LP, 0>(grid, lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h, u_ss, u_ss_n, u_gain);
   }
 }
 
-extern "C" int mode_moe_combine_norm_fwd(const float* u, const void* Y, int y_dtype, int y_splits, int64_t y_split_stride, const int32_t* pos,
-                                         const float* posw, int N, int D, int k, const float* g, const float* cond, int rows_per_cond,
-                                         float eps, float* x_next, void* h, int h_dtype, void* stream) {
+extern "C" int mode_moe_combine_norm_fused_fwd(const float* u, const float* u_ss, int u_ss_n, const float* u_gain, const void* Y, int y_dtype,
+                                               int y_splits, int64_t y_split_stride, const int32_t* pos, const float* posw, int N, int D, int k,
+                                               const float* g, const float* cond, int rows_per_cond, float eps, float* x_next, void* h,
+                                               int h_dtype, void* stream) {
   if (!u || !Y || !pos || !posw || N < 0 || D <= 0 || (D & 3) || k <= 0 || k > 8) return MODE_ERR_BAD_ARG;
   if (h && !g) return MODE_ERR_BAD_ARG;
+  if (u_ss && (!u_gain || u_ss_n <= 0)) return MODE_ERR_BAD_ARG;
   if (N == 0) return MODE_OK;
   if (rows_per_cond <= 0) rows_per_cond = 1;
   if (y_splits < 1) y_splits = 1;
@@ -326,11 +348,20 @@ extern "C" int mode_moe_combine_norm_fwd(const float* u, const void* Y, int y_dt
   const size_t lds = (size_t)ROWS_PER_BLOCK * D * 4;
   const int ybf = y_dtype == MODE_BF16;
   if (h_dtype == MODE_BF16)
-    launch_combine<true>(grid, lds, (hipStream_t)stream, u, Y, ybf, y_splits, (long)y_split_stride, pos, posw, N, D, k, g, cond, rows_per_cond, eps, x_next, h);
+    launch_combine<true>(grid, lds, (hipStream_t)stream, u, Y, ybf, y_splits, (long)y_split_stride, pos, posw, N, D, k, g, cond, rows_per_cond, eps, x_next, h,
+                         u_ss, u_ss_n, u_gain);
   else
-    launch_combine<false>(grid, lds, (hipStream_t)stream, u, Y, ybf, y_splits, (long)y_split_stride, pos, posw, N, D, k, g, cond, rows_per_cond, eps, x_next, h);
+    launch_combine<false>(grid, lds, (hipStream_t)stream, u, Y, ybf, y_splits, (long)y_split_stride, pos, posw, N, D, k, g, cond, rows_per_cond, eps, x_next, h,
+                          u_ss, u_ss_n, u_gain);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
+}
+
+extern "C" int mode_moe_combine_norm_fwd(const float* u, const void* Y, int y_dtype, int y_splits, int64_t y_split_stride, const int32_t* pos,
+                                         const float* posw, int N, int D, int k, const float* g, const float* cond, int rows_per_cond,
+                                         float eps, float* x_next, void* h, int h_dtype, void* stream) {
+  return mode_moe_combine_norm_fused_fwd(u, nullptr, 0, nullptr, Y, y_dtype, y_splits, y_split_stride, pos, posw, N, D, k, g, cond, rows_per_cond,
+                                         eps, x_next, h, h_dtype, stream);
 }
 
 extern "C" int mode_embed_tokens_fwd(const ModeEmbedDesc* d, void* stream) {
@@ -350,6 +381,7 @@ extern "C" int mode_embed_tokens_fwd(const ModeEmbedDesc* d, void* stream) {
 extern "C" int mode_head_ddim_fwd(const ModeHeadDesc* d, void* stream) {
   if (!d || !d->u || !d->Y || !d->pos || !d->posw || !d->g || !d->w_out || !d->b_out) return MODE_ERR_BAD_ARG;
   if (d->scal && !d->x_a) return MODE_ERR_BAD_ARG;
+  if (d->u_ss && (!d->u_gain || d->u_ss_n <= 0)) return MODE_ERR_BAD_ARG;
   if ((d->D & 3) || d->A_dim > 8) return MODE_ERR_UNSUPPORTED;
   const int rows = d->B * d->A_len;
   if (rows == 0) return MODE_OK;

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="samples (tokens = 14 x batch)")
     ap.add_argument("--experts", type=int, default=2, help="active experts: 2 = uniform-sigma inference (all samples route alike), 4 = training-like")
     ap.add_argument("--y-bf16", action="store_true", help="gemm2 writes bf16 (the product path) instead of fp32")
+    ap.add_argument("--rowss", action="store_true", help="gemm1 consumes per-row partial sums of squares (fused ln_2)")
     ap.add_argument("--nogather", action="store_true", help="gemm1 reads pre-sorted rows (no a_rows gather)")
     a = ap.parse_args()
     lib = L.load()
@@ -48,10 +49,15 @@ def main():
     hin = torch.randn(NK, 4 * D, device=dev).to(bf)
     xs = torch.randn(NK, D, device=dev).to(bf)           # pre-sorted (duplicated) expert inputs
 
+    ssb = torch.rand(N, D // 64, device=dev) + 0.5
+    ss_kw = dict(row_ss=ssb.data_ptr(), row_ss_n=D // 64, row_eps=1e-6) if a.rowss else {}
+
     def desc(**kw):
         base = dict(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=N, N=D, K=D, A=x.data_ptr(), lda=D, W=None, ldw=D,
                     w_expert_stride=0, bias=None, bias_expert_stride=0, resid=None, ldr=0, C=None, ldc=D, a_rows=None, expert_offsets=None,
                     num_experts=0, split_k=1, split_stride=0, flags=0)
+        if kw.get("epilogue") == L.EPI_SWIGLU:
+            base.update(ss_kw)
         base.update(kw)
         return L.ModeGemmDesc(**base)
     shapes = {

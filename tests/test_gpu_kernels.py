@@ -243,3 +243,63 @@ def test_dispatch_meta_bit_exact(R, tpr, E, k):
     wtok = w.repeat_interleave(tpr, 0).gather(1, srt.indices)
     assert torch.equal(perm[pos.reshape(-1)], torch.arange(N).repeat_interleave(k))
     assert torch.equal(posw, wtok)
+
+
+# ------------------------------------------------------------------------------------------------- fused ln_2 (c_proj -> experts -> combine)
+@pytest.mark.parametrize("cfg", [0, 1, 4, 6, 13])
+@pytest.mark.parametrize("N_tok,D,E,k", [(70, 128, 4, 2), (1792, 256, 4, 2), (37, 64, 2, 1)])
+def test_fused_ln2_chain_matches_separate_kernels(N_tok, D, E, k, cfg):
+    """MODE_EPI_RESIDUAL_NORM producer + MODE_EPI_SWIGLU(row_ss) consumer + combine(u_ss) against the three-kernel formulation
+    (c_proj+residual -> rmsnorm -> up-projection -> combine): the same mathematics with ln_2's division moved behind the GEMM."""
+    import ctypes as C
+    lib = L.load()
+    p, st = H.p, H.stream()
+    bf = torch.bfloat16
+    ya = rnd(N_tok, D, seed=1).to(bf).to(dev()); wo = rnd(D, D, seed=2, scale=D ** -0.5).to(bf).to(dev())
+    x0 = rnd(N_tok, D, seed=3).to(dev()); g2 = (1.0 + 0.2 * rnd(D, seed=4)).to(dev())
+    W1 = rnd(E, 8 * D, D, seed=5, scale=D ** -0.5).to(bf).to(dev()); b1 = rnd(E, 8 * D, seed=6, scale=0.1).to(dev())
+    logits = rnd(N_tok, E, seed=7).to(dev())
+    _, _, idx, w = H.route_topk(logits, k)
+    meta = H.dispatch_meta(idx, w, 1, N_tok, E)
+    NK = N_tok * k
+    eps = 1e-6
+    lib.mode_set_option(b"gemm_cfg", cfg)
+    try:
+        # --- separate kernels
+        x_ref = H.gemm(ya, wo, L.EPI_RESIDUAL, resid=x0, out_dtype=torch.float32)
+        xn_ref, h_ref = H.rmsnorm(x_ref, g2, eps=eps)
+        hid_ref = H.gemm(h_ref, W1, L.EPI_SWIGLU, bias=b1, out_dtype=bf, a_rows=meta["perm"], offsets=meta["offsets"], num_experts=E, M=NK,
+                         w_estride=8 * D * D, b_estride=8 * D)
+        # --- fused
+        x = torch.full((N_tok, D), float("nan"), device=dev()); xg = torch.zeros(N_tok, D, dtype=bf, device=dev())
+        ss = torch.full((N_tok, D // 64), float("nan"), device=dev())
+        d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_RESIDUAL_NORM, out_dtype=L.MODE_F32, M=N_tok, N=D, K=D, A=p(ya), lda=D, W=p(wo), ldw=D,
+                           resid=p(x0), ldr=D, C=p(x), ldc=D, C2=p(xg), ldc2=D, gain=p(g2), row_ss_out=p(ss))
+        L.check(lib.mode_gemm(C.byref(d), st), "c_proj fused")
+        assert torch.equal(x, x_ref)                                                   # the residual stream itself is unchanged
+        assert rel(ss.sum(1), x_ref.double().pow(2).sum(1).float()) < 1e-6
+        assert rel(xg.float(), x_ref * g2) < 4e-3
+        hid = torch.full((NK, 4 * D), float("nan"), dtype=bf, device=dev())
+        d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_SWIGLU, out_dtype=L.MODE_BF16, M=NK, N=4 * D, K=D, A=p(xg), lda=D, W=p(W1), ldw=D,
+                           w_expert_stride=8 * D * D, bias=p(b1), bias_expert_stride=8 * D, C=p(hid), ldc=4 * D, a_rows=p(meta["perm"]),
+                           expert_offsets=p(meta["offsets"]), num_experts=E, row_ss=p(ss), row_ss_n=D // 64, row_eps=eps)
+        L.check(lib.mode_gemm(C.byref(d), st), "up-projection fused")
+        assert rel(hid.float(), hid_ref.float()) < 8e-3                                 # bf16 rounding of x*g instead of x*g/n
+        # exact check of the consumer's arithmetic against fp32 torch fed the same bf16 operand
+        nrm = (x_ref.double().pow(2).sum(1).sqrt() * D ** -0.5).clamp_min(eps)
+        pre = torch.zeros(NK, 8 * D, dtype=torch.float64)
+        perm = meta["perm"].cpu().long(); offs = meta["offsets"].cpu().long()
+        for e in range(E):
+            rows = perm[offs[e]:offs[e + 1]]
+            pre[offs[e]:offs[e + 1]] = (xg[rows].double().cpu() @ W1[e].double().cpu().t()) / nrm.cpu()[rows, None] + b1[e].double().cpu()
+        want = pre[:, :4 * D] * torch.nn.functional.silu(pre[:, 4 * D:])
+        assert rel(hid.float(), want.float()) < 4e-3
+    finally:
+        lib.mode_set_option(b"gemm_cfg", 0)
+    # --- combine: un-normalised u + partial sums + gain == normalised u
+    Y = rnd(NK, D, seed=8).to(bf).to(dev()); g1 = (1.0 + 0.1 * rnd(D, seed=9)).to(dev()); cond = rnd(N_tok, D, seed=10).to(dev())
+    xn_a, h_a = H.combine_norm(xn_ref, Y, meta["pos"], meta["posw"], k, g1, cond, 1, eps=eps)
+    xn_b = torch.empty_like(x); h_b = torch.empty(N_tok, D, dtype=bf, device=dev())
+    L.check(lib.mode_moe_combine_norm_fused_fwd(p(x), p(ss), D // 64, p(g2), p(Y), L.MODE_BF16, 1, 0, p(meta["pos"]), p(meta["posw"]), N_tok, D, k,
+                                                p(g1), p(cond), 1, eps, p(xn_b), p(h_b), L.MODE_BF16, st), "combine fused")
+    assert rel(xn_b, xn_a) < 1e-6 and rel(h_b.float(), h_a.float()) < 4e-3
