@@ -175,7 +175,7 @@ def train_bench(args, world, rank, device, dist):
         sig = rand_log_logistic((B,), loc=math.log(SIGMA_DATA), scale=0.5, min_value=SIGMA_MIN, max_value=SIGMA_MAX, device=device)
         loss, _ = den.loss({"state_images": img}, acts, goal, noise, sig)
         loss.backward()
-        opt.step(reducer=red, overlap=os.environ.get("MODE_OPT_OVERLAP", "0") == "1")   # per-block: exchange (RCCL) -> AdamW underneath the remaining backward
+        opt.step(reducer=red, overlap=os.environ.get("MODE_OPT_OVERLAP", "1") == "1")   # per-block: exchange (RCCL) -> AdamW underneath the remaining backward
         return loss
     for _ in range(max(args.warmup, 1)):
         loss = step()

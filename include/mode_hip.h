@@ -53,7 +53,7 @@ const char* mode_hip_status_string(int status);
  * 3 = 256x128 ring-3, 4 = 128x64 ring-3, 5 = 128x64 ring-4, 6 = 128x128 single-buffered (3 workgroups/CU), 7 = 128x64 single-buffered,
  * 8 = 128x64 ring-2, 9 = 256x256 ring-2 (8 waves), 10 = 256x128 ring-2, 11 = 256x256 ring-2 (16 waves), 12 = persistent 256x256 with
  * cross-tile operand prefetch, 13 = 128x128 single-buffered with <= 128 VGPRs (4 workgroups/CU).  "gemm_tr_cfg": backward (transpose-read) GEMM geometry, 0 = auto, 1 = 128-wide ring-2, 2 = 64-wide ring-3,
- * 3 = 128-wide ring-3, 4 = 64-wide ring-2, 5 = 128-wide single-buffered.  "adamw_blocks": workgroup cap of one AdamW launch (0 = 2048).
+ * 3 = 128-wide ring-3, 4 = 64-wide ring-2, 5 = 128-wide single-buffered.  "adamw_blocks": workgroup cap of one AdamW launch (0 = 256, one streaming workgroup per CU).
  * "dn_split_k": K-slices of the inference path's expert down-projection, 0 = default (2, for every batch size), 1 = off, <= 8.
  * "attn_bwd_stop": profiling aid, attention backward returns after phase n (0 = off).  Unknown keys return MODE_ERR_BAD_ARG. */
 int mode_set_option(const char* key, int value);

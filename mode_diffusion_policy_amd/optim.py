@@ -89,13 +89,16 @@ class FusedAdamW:
         Default: (exchange gradients through ``reducer`` — its collectives overlap the backward —, then) two launches over the decay / no-decay
         regions on the current stream.
 
-        ``overlap=True`` (experimental): call right after ``loss.backward()`` returned.  The backward kernels are still executing; the update
-        of block l's 228 MB weight slice is queued on a side stream behind the event the backward chain records when block l's gradients are
-        complete, so the HBM-bound optimizer pass (25 % of a serial step) runs underneath the backward of the earlier blocks (block l's
-        backward only reads block l's weights, so updating later blocks early is safe).  Measured on MI355X: 16.1-16.7 ms per step at best
-        (AdamW capped to 128-256 workgroups, ``mode_set_option("adamw_blocks", n)``) against 17.0-18.0 ms serial, but run-to-run spread up to
-        21 ms — the streaming pass raises the memory latency the fill-bound GEMMs are sensitive to — hence not the default.  ``reducer`` (an ``ArenaGradReducer``)
-        chains the data-parallel exchange in front of each slice's update on the same events; its 1/world scale is applied here.
+        ``overlap=True``: call right after ``loss.backward()`` returned and do not touch the gradients in between (clipping goes through
+        ``grad_scale``).  The backward kernels are still executing; the update of block l's 228 MB weight slice is queued on a side stream
+        behind the event the backward chain records when block l's gradients are complete, so the HBM-bound optimizer pass (a quarter of a
+        serial step) runs underneath the backward of the earlier blocks (block l's backward only reads block l's weights, so updating later
+        blocks early is safe).  Measured on MI355X inside one process, interleaved rounds (scripts/train_overlap_probe.py): 14.65-14.75 ms
+        per step against 15.35-15.45 ms serial with one AdamW workgroup per CU (``adamw_blocks`` = 256, the default), 15.2-15.7 ms
+        overlapped / 15.8 ms serial with 2048 workgroups — a streaming pass that oversubscribes the CUs raises the memory latency the
+        fill-bound backward GEMMs are sensitive to.  ``bench.py --mode train`` uses it; the keyword default stays False because an
+        overlapped update must not be preceded by in-place gradient edits.  ``reducer`` (an ``ArenaGradReducer``) chains the data-parallel
+        exchange in front of each slice's update on the same events; its 1/world scale is applied here.
 
         ``ema`` (an ``ArenaEMA``): the moving average of the weights is updated in the same pass whenever the callback's schedule says so
         for this step (the reference's EMA callback runs right after every optimizer step, mode/callbacks/ema.py:128-142)."""
