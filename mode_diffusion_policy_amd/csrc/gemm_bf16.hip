@@ -442,8 +442,8 @@ static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipSt
 
 // Tile-geometry heuristic for 256 CUs, from scripts/gemm_bench.py (--batch 32 / 64 / 128) / gemm_ksweep.py on the config-2 layer shapes:
 //   >= 768 tiles of 128x128 : single-buffered 128x128, <= 128 VGPRs, 4 workgroups/CU (72 vs 76 us at B=128, 41 vs 47 us at B=64)   [expert up-projection]
-//   >= 384                  : single-buffered 128x128 at 3 workgroups/CU (other workgroups hide the fill latency)   [up-projection at B=32]
-//   >= 256                  : double-buffered 128x128 ring                                                          [QKV at B=128]
+//   >= 576                  : single-buffered 128x128 at 3 workgroups/CU (other workgroups hide the fill latency)
+//   >= 256                  : double-buffered 128x128 ring            [QKV at B=128; up-projection at B=32: 448 tiles, 26.6 vs 29.5 us single-buffered]
 //   fewer                   : 128x64 tiles so that more CUs get a workgroup, 3-slot ring (two K-tiles in flight per workgroup: with
 //                             <= 1 workgroup per CU nothing else hides the fill latency)                 [c_proj, expert down-proj, small batches]
 static int pick_cfg(const ModeGemmDesc* d) {
@@ -452,7 +452,7 @@ static int pick_cfg(const ModeGemmDesc* d) {
   const long t128 = ((rows + 127) / 128) * ((d->N + nout128 - 1) / nout128);
   if (d->split_k > 1) return t128 * d->split_k >= 448 ? CFG_128x128_NS2 : CFG_128x64_NS3;   // split-K (down-projection, dit.hip down_proj_split): slices are extra workgroups
   if (t128 >= 768) return CFG_128x128_NS1_4WG;   // >= 3 tiles per CU: four low-register workgroups per CU interleave fill / LDS / MFMA phases best
-  if (t128 >= 384) return CFG_128x128_NS1;
+  if (t128 >= 576) return CFG_128x128_NS1;
   if (t128 >= 256) return CFG_128x128_NS2;
   return CFG_128x64_NS3;
 }
