@@ -77,13 +77,14 @@ def dominant_kernel_roofline(den, device, reps=240):
     mp = meta.data_ptr()
     u = torch.randn(N, D, device=device).to(torch.bfloat16)
     Hb = torch.empty(N * k, 4 * D, dtype=torch.bfloat16, device=device)
+    ss = torch.rand(N, D // 64, device=device) + 0.5          # per-64-column sums of squares of the fused ln_2 (the chain's variant of the kernel)
     descs = []
     for l in range(m.num_layers):
         kp = {**eng.arena.w, **eng.arena.wl}
         d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_SWIGLU, out_dtype=L.MODE_BF16, M=N * k, N=4 * D, K=D, A=u.data_ptr(), lda=D,
                            W=kp[f"l{l}.w1"].data_ptr(), ldw=D, w_expert_stride=8 * D * D, bias=kp[f"l{l}.b1"].data_ptr(),
                            bias_expert_stride=8 * D, resid=None, ldr=0, C=Hb.data_ptr(), ldc=4 * D, a_rows=mp + 4 * ml.perm,
-                           expert_offsets=mp + 4 * ml.offsets, num_experts=E)
+                           expert_offsets=mp + 4 * ml.offsets, num_experts=E, row_ss=ss.data_ptr(), row_ss_n=D // 64, row_eps=1e-6)
         descs.append(d)
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(4):                                        # warm-up: clocks, code objects, L2/MALL state of a steady layer loop
@@ -101,10 +102,10 @@ def dominant_kernel_roofline(den, device, reps=240):
     ach = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "kernel": "gemm_bf16_kernel<SWIGLU> (grouped expert up-projection, M=3584 K=1024 N=2x4096)",
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            # HBM bytes per launch from the committed PMC passes (profiles/r01_gemm_pmc.md): FETCH_SIZE 46 368 KB x2 (gfx950 correction,
+            # HBM bytes per launch from the committed PMC passes (profiles/r01_gemm_pmc.md): FETCH_SIZE 47 047 KB x2 (gfx950 correction,
             # MI355X_MICROARCH.md "HBM") + WRITE_SIZE 28 672 KB; algorithmic bytes per launch (2 of 4 experts active under uniform sigma):
             # A 3.7 MB + W1 33.6 MB + H 29.4 MB = 66.6 MB
-            "traffic": 124.4e6, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_gemm_pmc.md)",
+            "traffic": 125.7e6, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_gemm_pmc.md)",
             "algorithmic_bytes": 66.6e6, "avg_launch_us": round(us, 2), "flops_per_launch": flops}
 
 
