@@ -136,6 +136,33 @@ __global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const
     ssq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   });
   if (!h) return;
+  if constexpr (NCH > 0) {
+    // the gain / conditioning rows do not depend on the reduction: fetch them before it so that their round trip overlaps the wave reduction
+    // instead of following it (one dependent L2 round trip less per row)
+    const float* cr = cond ? cond + (long)(row / rpc) * D : nullptr;
+    float4 gq[NCH], cq[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      gq[c] = *reinterpret_cast<const float4*>(g + lane * 4 + c * 256);
+      cq[c] = cr ? *reinterpret_cast<const float4*>(cr + lane * 4 + c * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    ssq = wave_sum(ssq);
+    const float nrm = fmaxf(sqrtf(ssq) * rsqrtf((float)D), eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int d = lane * 4 + c * 256;
+      const float4 v = *reinterpret_cast<const float4*>(cache + d);
+      float4 o = make_float4(v.x / nrm * gq[c].x, v.y / nrm * gq[c].y, v.z / nrm * gq[c].z, v.w / nrm * gq[c].w);
+      if (cr) { o.x += cq[c].x; o.y += cq[c].y; o.z += cq[c].z; o.w += cq[c].w; }
+      if constexpr (LP_BF16) {
+        uint2 pk; pk.x = pack_bf16x2(o.x, o.y); pk.y = pack_bf16x2(o.z, o.w);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(h) + (long)row * D + d) = pk;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(h) + (long)row * D + d) = o;
+      }
+    }
+    return;
+  }
   ssq = wave_sum(ssq);
   norm_store<LP_BF16, NCH>(cache, D, ssq, g, cond ? cond + (long)(row / rpc) * D : nullptr, eps, nullptr,
                            (void*)((char*)h + (long)row * D * (LP_BF16 ? 2 : 4)), lane);

@@ -175,9 +175,9 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         pt = probs.unsqueeze(2).expand(Ly, B, T, E).reshape(Ly * N, E)
         idx = torch.multinomial(pt, k, replacement=False).to(torch.int32).view(Ly, N, k).contiguous()
         w = torch.empty(Ly, N, k, device=dev)
-        for l in range(Ly):
-            L.check(lib.mode_moe_weights_from_idx(probs[l].data_ptr(), idx[l].data_ptr(), N, T, E, k, int(model.router_normalize),
-                                                  w[l].data_ptr(), _stream()), "weights_from_idx")
+        # all layers in one launch: token row n of layer l reads probs row (l*N + n) / T = l*B + b
+        L.check(lib.mode_moe_weights_from_idx(probs.data_ptr(), idx.data_ptr(), Ly * N, T, E, k, int(model.router_normalize),
+                                              w.data_ptr(), _stream()), "weights_from_idx")
         per_tok, tpr, Rr = 1, 1, N
     meta = eng.dispatch(idx, w, Ly, Rr, tpr, N)
     ml = eng.meta_layout(N)
@@ -200,13 +200,15 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     with torch.no_grad():
         idx64 = (idx if per_tok else idx.unsqueeze(2).expand(Ly, B, T, k).reshape(Ly, N, k)).long()
         wtok = w if per_tok else w.unsqueeze(2).expand(Ly, B, T, k).reshape(Ly, N, k)
+        # batched over the layers (a dozen launches per step instead of ~120), then handed out as per-block views
+        mask = torch.zeros(Ly, N, E, device=dev).scatter_(2, idx64, 1.0)
+        rp = torch.zeros(Ly, N, E, device=dev).scatter_(2, idx64, wtok)
+        lb = E * (rp.mean(1) * (mask.sum(1) / N)).sum(-1)                                       # [L]
+        logits_tok = shifted.unsqueeze(2).expand(Ly, B, T, E).reshape(Ly, N, E)
         model.logits_per_layer, model.probs_per_layer = [], []
         for l, blk in enumerate(model.blocks):
-            mask = torch.zeros(N, E, device=dev).scatter_(1, idx64[l], 1.0)
-            rp = torch.zeros(N, E, device=dev).scatter_(1, idx64[l], wtok[l])
-            blk.logits = shifted[l].unsqueeze(1).expand(B, T, E).reshape(N, E)
-            blk.probs = {"probs": probs[l].unsqueeze(1).expand(B, T, E), "top_k_hot": mask.view(B, T, E),
-                         "load_balancing_term": E * (rp.mean(0) * (mask.sum(0) / N)).sum()}
+            blk.logits = logits_tok[l]
+            blk.probs = {"probs": probs[l].unsqueeze(1).expand(B, T, E), "top_k_hot": mask[l].view(B, T, E), "load_balancing_term": lb[l]}
             blk.total_tokens_processed += N
             model.logits_per_layer.append(blk.logits); model.probs_per_layer.append(blk.probs)
         counts = meta[:, ml.counts: ml.counts + E]
