@@ -47,6 +47,15 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
     vv[db][0] = v[0] | (v[1] << 16); vv[db][1] = v[2] | (v[3] << 16);
   }
 
+  // ---- qk-norm gains: independent of everything else, fetched up front (their round trip used to follow the row-norm reduction)
+  float4 gq4[NKS][2], gk4[NKS][2];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int dg = (ks * 32 + fq * 8 < HD) ? ks * 32 + fq * 8 : 0;      // padded k-slots carry zeros; any valid gain address works
+    gq4[ks][0] = *reinterpret_cast<const float4*>(qg + dg); gq4[ks][1] = *reinterpret_cast<const float4*>(qg + dg + 4);
+    gk4[ks][0] = *reinterpret_cast<const float4*>(kg + dg); gk4[ks][1] = *reinterpret_cast<const float4*>(kg + dg + 4);
+  }
+
   // ---- load q / k fragments: token row fr, dims ks*32 + fq*8 + [0,8)
   float qf[NKS][8], kf[NKS][8];
   float qss = 0.f, kss = 0.f;
@@ -74,9 +83,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
   bf16x8 qfrag[NKS], kfrag[NKS];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
-    const int dg = (ks * 32 + fq * 8 < HD) ? ks * 32 + fq * 8 : 0;      // padded k-slots carry zeros; any valid gain address works
-    const float4 g0 = *reinterpret_cast<const float4*>(qg + dg), g1 = *reinterpret_cast<const float4*>(qg + dg + 4);
-    const float4 h0 = *reinterpret_cast<const float4*>(kg + dg), h1 = *reinterpret_cast<const float4*>(kg + dg + 4);
+    const float4 g0 = gq4[ks][0], g1 = gq4[ks][1], h0 = gk4[ks][0], h1 = gk4[ks][1];
     const float gq[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, gk[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
     uint32_t pq[4], pk[4];
 #pragma unroll

@@ -97,6 +97,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return MODE_OK; }
   if (!strcmp(key, "attn_bwd_stop")) { g_attn_bwd_stop = value; return MODE_OK; }
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }
+  if (!strcmp(key, "gemm_skinny_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_skinny_rows = value; return MODE_OK; }
   if (!strcmp(key, "fuse_ln2")) { g_fuse_ln2 = value != 0; return MODE_OK; }
   if (!strcmp(key, "dn_split_k")) { if (value < 0 || value > 8) return MODE_ERR_BAD_ARG; g_dn_split_k = value; return MODE_OK; }
   return MODE_ERR_UNSUPPORTED;
@@ -242,7 +243,8 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
   void* h = ws + L.h; void* qkv = ws + L.qkv; void* yat = ws + L.y; void* hbuf = ws + L.hbuf;
   void* ybuf = ws + L.ybuf;
   float* rowss = (float*)(ws + L.rowss);
-  const bool fuse = g_fuse_ln2 && dt == MODE_BF16 && D % 64 == 0;
+  // (a handful of token rows take the weight-streaming GEMM, which has no fused-ln_2 epilogue: ln_2 stays a kernel of its own there)
+  const bool fuse = g_fuse_ln2 && dt == MODE_BF16 && D % 64 == 0 && N > g_gemm_skinny_rows;
   const int ssn = D / 64;
   ModeMetaLayout ml;
   mode_moe_meta_layout(N, d.E, d.k, &ml);

@@ -81,6 +81,9 @@ __device__ __forceinline__ float sum_row_partials(const float* __restrict__ sp, 
   return s;
 }
 
+// Rows up to which the bf16 GEMM uses the weight-streaming kernel of gemm_bf16_skinny.hip ("gemm_skinny_rows" option; 0 = off)
+extern int g_gemm_skinny_rows;
+
 #define MODE_LAUNCH_CHECK()                                  \
   do {                                                       \
     hipError_t e__ = hipGetLastError();                      \

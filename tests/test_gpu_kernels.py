@@ -264,6 +264,7 @@ def test_fused_ln2_chain_matches_separate_kernels(N_tok, D, E, k, cfg):
     NK = N_tok * k
     eps = 1e-6
     lib.mode_set_option(b"gemm_cfg", cfg)
+    lib.mode_set_option(b"gemm_skinny_rows", 0)          # both formulations on the tiled kernel: the residual stream must then be bit-identical
     try:
         # --- separate kernels
         x_ref = H.gemm(ya, wo, L.EPI_RESIDUAL, resid=x0, out_dtype=torch.float32)
@@ -296,6 +297,7 @@ def test_fused_ln2_chain_matches_separate_kernels(N_tok, D, E, k, cfg):
         assert rel(hid.float(), want.float()) < 4e-3
     finally:
         lib.mode_set_option(b"gemm_cfg", 0)
+        lib.mode_set_option(b"gemm_skinny_rows", 64)
     # --- combine: un-normalised u + partial sums + gain == normalised u
     Y = rnd(NK, D, seed=8).to(bf).to(dev()); g1 = (1.0 + 0.1 * rnd(D, seed=9)).to(dev()); cond = rnd(N_tok, D, seed=10).to(dev())
     xn_a, h_a = H.combine_norm(xn_ref, Y, meta["pos"], meta["posw"], k, g1, cond, 1, eps=eps)
@@ -303,3 +305,74 @@ def test_fused_ln2_chain_matches_separate_kernels(N_tok, D, E, k, cfg):
     L.check(lib.mode_moe_combine_norm_fused_fwd(p(x), p(ss), D // 64, p(g2), p(Y), L.MODE_BF16, 1, 0, p(meta["pos"]), p(meta["posw"]), N_tok, D, k,
                                                 p(g1), p(cond), 1, eps, p(xn_b), p(h_b), L.MODE_BF16, st), "combine fused")
     assert rel(xn_b, xn_a) < 1e-6 and rel(h_b.float(), h_a.float()) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------------- weight-streaming GEMM for a handful of rows
+def _both_paths(fn):
+    """fn() with the weight-streaming kernel (default only for M <= 64; forced here up to 128 rows) and with the tiled kernel; returns (skinny, tiled)."""
+    lib = L.load()
+    lib.mode_set_option(b"gemm_skinny_rows", 128)
+    a = fn()
+    lib.mode_set_option(b"gemm_skinny_rows", 0)
+    try:
+        b = fn()
+    finally:
+        lib.mode_set_option(b"gemm_skinny_rows", 64)
+    return a, b
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 128), (14, 3072, 1024), (28, 64, 256), (56, 1024, 1024), (100, 192, 384), (128, 1024, 4096), (17, 20, 128)])
+def test_skinny_gemm_epilogues(M, N, K):
+    A = rnd(M, K, seed=1).to(torch.bfloat16).to(dev()); W = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16).to(dev())
+    b = rnd(N, seed=3).to(dev()); r = rnd(M, N, seed=4).to(dev())
+    ref = A.float() @ W.float().t()
+    for epi, kw, want in ((L.EPI_NONE, {}, ref), (L.EPI_BIAS, dict(bias=b), ref + b), (L.EPI_RESIDUAL, dict(resid=r), ref + r),
+                          (L.EPI_BIAS_GELU, dict(bias=b), torch.nn.functional.gelu(ref + b))):
+        s32, t32 = _both_paths(lambda: H.gemm(A, W, epi, out_dtype=torch.float32, **kw))
+        assert rel(s32, want) < 2e-3 and rel(s32, t32) < 1e-5, epi       # same products, another fp32 summation order
+        if epi != L.EPI_RESIDUAL:
+            s16, _ = _both_paths(lambda: H.gemm(A, W, epi, out_dtype=torch.bfloat16, **kw))
+            assert rel(s16.float(), want) < 6e-3, epi
+    if N % 8 == 0:                                                       # SwiGLU: W is [2*(N/2), K]
+        bb = rnd(N, seed=5, scale=0.1).to(dev())
+        s, t = _both_paths(lambda: H.gemm(A, W, L.EPI_SWIGLU, bias=bb, out_dtype=torch.float32))
+        h = ref + bb
+        assert rel(s, h[:, : N // 2] * torch.nn.functional.silu(h[:, N // 2:])) < 3e-3 and rel(s, t) < 1e-5
+
+
+@pytest.mark.parametrize("N_tok,E,k,D", [(14, 4, 2, 128), (56, 4, 2, 256), (5, 4, 2, 128), (64, 2, 1, 128), (28, 4, 2, 1024)])
+def test_skinny_grouped_gather_and_split_k(N_tok, E, k, D):
+    """Grouped + gathered up-projection (SwiGLU) and the K-sliced down-projection through the weight-streaming kernel: against the tiled kernel
+    and fp32 torch, with ragged expert segments (some experts empty)."""
+    import ctypes as C
+    lib = L.load(); p, st = H.p, H.stream()
+    bf = torch.bfloat16
+    x = rnd(N_tok, D, seed=1).to(bf).to(dev())
+    W1 = rnd(E, 8 * D, D, seed=2, scale=D ** -0.5).to(bf).to(dev()); b1 = rnd(E, 8 * D, seed=3, scale=0.1).to(dev())
+    W2 = rnd(E, D, 4 * D, seed=4, scale=(4 * D) ** -0.5).to(bf).to(dev())
+    logits = rnd(N_tok, E, seed=5).to(dev()); logits[:, 0] -= 100.0          # expert 0 stays empty
+    _, _, idx, w = H.route_topk(logits, k)
+    meta = H.dispatch_meta(idx, w, 1, N_tok, E)
+    NK = N_tok * k
+    hid_s, hid_t = _both_paths(lambda: H.gemm(x, W1, L.EPI_SWIGLU, bias=b1, out_dtype=bf, a_rows=meta["perm"], offsets=meta["offsets"], num_experts=E,
+                                              M=NK, w_estride=8 * D * D, b_estride=8 * D))
+    assert rel(hid_s.float(), hid_t.float()) < 4e-3
+    perm = meta["perm"].cpu().long(); offs = meta["offsets"].cpu().long()
+    pre = torch.zeros(NK, 8 * D)
+    for e in range(E):
+        rows = perm[offs[e]:offs[e + 1]]
+        pre[offs[e]:offs[e + 1]] = x[rows].float().cpu() @ W1[e].float().cpu().t() + b1[e].cpu()
+    assert rel(hid_s.float(), pre[:, :4 * D] * torch.nn.functional.silu(pre[:, 4 * D:])) < 4e-3
+
+    def down(split):
+        Y = torch.full((split, NK, D), float("nan"), dtype=bf, device=dev())
+        d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=NK, N=D, K=4 * D, A=p(hid_t), lda=4 * D, W=p(W2), ldw=4 * D,
+                           w_expert_stride=4 * D * D, C=p(Y), ldc=D, expert_offsets=p(meta["offsets"]), num_experts=E, split_k=split, split_stride=NK * D)
+        L.check(lib.mode_gemm(C.byref(d), st), "down")
+        return Y.float().sum(0)
+    want = torch.zeros(NK, D)
+    for e in range(E):
+        want[offs[e]:offs[e + 1]] = hid_t[offs[e]:offs[e + 1]].float().cpu() @ W2[e].float().cpu().t()
+    for split in (1, 2):
+        s, t = _both_paths(lambda: down(split))
+        assert rel(s, want) < 6e-3 and rel(s, t) < 6e-3, split
