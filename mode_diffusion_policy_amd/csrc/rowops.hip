@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const
 }
 
 // --------------------------------------------------------------------------------------------------------------- embed
-template <bool LP_BF16>
+template <bool LP_BF16, int NCH>
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const ModeEmbedDesc e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const ModeEmbedDesc e
     for (int j = 0; j < 8; ++j) a[j] = (j < e.A_dim) ? e.actions[((long)b * e.A_len + ai) * e.A_dim + j] * cin : 0.f;
   }
   float ssq = 0.f;
-  for (int d = lane * 4; d < D; d += 256) {
+  for_chunks<NCH>(D, lane, [&](int d) {
     float4 v;
     if (t < t0) {
       v = *reinterpret_cast<const float4*>(e.emb_t + (long)b * e.emb_row_stride + d);
@@ -203,26 +203,45 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const ModeEmbedDesc e
     } else {
       const float4 pp = *reinterpret_cast<const float4*>(e.pos + (long)(1 + ai) * D + d);
       float o[4];
+      if (e.A_dim == 7) {
+        // rows d..d+3 of w_act [D, 7] are 28 contiguous floats starting at a 16-byte boundary (d % 4 == 0): 7 vector loads instead of 28
+        // scalar ones; same fma order as the generic path
+        float wv[28];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float* wr = e.w_act + (long)(d + c) * e.A_dim;
-        float s = 0.f;
+        for (int q = 0; q < 7; ++q) {
+          const float4 t4 = *reinterpret_cast<const float4*>(e.w_act + (long)d * 7 + q * 4);
+          wv[4 * q] = t4.x; wv[4 * q + 1] = t4.y; wv[4 * q + 2] = t4.z; wv[4 * q + 3] = t4.w;
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (j < e.A_dim) s = fmaf(a[j], wr[j], s);
-        o[c] = s;
+        for (int c = 0; c < 4; ++c) {
+          float s_ = 0.f;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) s_ = fmaf(a[j], wv[c * 7 + j], s_);
+          o[c] = s_;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float* wr = e.w_act + (long)(d + c) * e.A_dim;
+          float s_ = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (j < e.A_dim) s_ = fmaf(a[j], wr[j], s_);
+          o[c] = s_;
+        }
       }
       v = make_float4(o[0] + pp.x, o[1] + pp.y, o[2] + pp.z, o[3] + pp.w);
     }
     *reinterpret_cast<float4*>(cache + d) = v;
     *reinterpret_cast<float4*>(e.x + (long)row * D + d) = v;
     ssq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-  }
+  });
   ssq = wave_sum(ssq);
-  norm_store<LP_BF16, 0>(cache, D, ssq, e.g, e.cond ? e.cond + (long)b * e.cond_row_stride : nullptr, e.eps, nullptr,
+  norm_store<LP_BF16, NCH>(cache, D, ssq, e.g, e.cond ? e.cond + (long)b * e.cond_row_stride : nullptr, e.eps, nullptr,
                       (void*)((char*)e.h + (long)row * D * (LP_BF16 ? 2 : 4)), lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- head
+template <int NCH>   // NCH > 0: D == 256*NCH, chunk loops fully unrolled (all loads of a phase in flight together)
 __global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -234,8 +253,15 @@ __global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
   const float* ur = h.u + row * D;
   const bool ybf = h.y_dtype == MODE_BF16;
   const float u_nrm = h.u_ss ? row_norm_from_partials(h.u_ss + row * h.u_ss_n, h.u_ss_n, D, h.eps) : 1.0f;
+  // epilogue operands do not depend on the row math: fetch them first
+  const bool act_lane = lane < h.A_dim;
+  const long oidx = (long)ar * h.A_dim + lane;
+  const float bo = act_lane ? h.b_out[lane] : 0.f;
+  const float* scp = h.scal ? h.scal + (long)b * h.scal_stride : nullptr;
+  const float sc0 = scp ? scp[0] : 0.f, sc1 = scp ? scp[1] : 0.f, sc2 = scp ? scp[2] : 0.f;
+  const float xa = (scp && act_lane) ? h.x_a[oidx] : 0.f;
   float ssq = 0.f;
-  for (int d = lane * 4; d < D; d += 256) {
+  for_chunks<NCH>(D, lane, [&](int d) {
     float4 uu = *reinterpret_cast<const float4*>(ur + d);
     if (h.u_ss) {
       const float4 gg = *reinterpret_cast<const float4*>(h.u_gain + d);
@@ -256,39 +282,59 @@ __global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
     const float4 v = make_float4(uu.x + nx.x, uu.y + nx.y, uu.z + nx.z, uu.w + nx.w);
     *reinterpret_cast<float4*>(cache + d) = v;
     ssq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-  }
-  ssq = wave_sum(ssq);
-  const float nrm = fmaxf(sqrtf(ssq) * rsqrtf((float)D), h.eps);
+  });
   float accv[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) accv[j] = 0.f;
-  for (int d = lane * 4; d < D; d += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(cache + d);
-    const float4 gg = *reinterpret_cast<const float4*>(h.g + d);
-    const float4 n = make_float4(v.x / nrm * gg.x, v.y / nrm * gg.y, v.z / nrm * gg.z, v.w / nrm * gg.w);
+  if constexpr (NCH > 0) {
+    // final-norm gain and the 7 head rows for all chunks are requested BEFORE the row reduction (their round trip overlaps it)
+    float4 gq[NCH], wq[NCH][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j < h.A_dim) {
-        const float4 w = *reinterpret_cast<const float4*>(h.w_out + (long)j * D + d);
-        accv[j] += n.x * w.x + n.y * w.y + n.z * w.z + n.w * w.w;
+    for (int c = 0; c < NCH; ++c) {
+      const int d = lane * 4 + c * 256;
+      gq[c] = *reinterpret_cast<const float4*>(h.g + d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        wq[c][j] = j < h.A_dim ? *reinterpret_cast<const float4*>(h.w_out + (long)j * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    ssq = wave_sum(ssq);
+    const float nrm = fmaxf(sqrtf(ssq) * rsqrtf((float)D), h.eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(cache + lane * 4 + c * 256);
+      const float4 n = make_float4(v.x / nrm * gq[c].x, v.y / nrm * gq[c].y, v.z / nrm * gq[c].z, v.w / nrm * gq[c].w);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < h.A_dim) accv[j] += n.x * wq[c][j].x + n.y * wq[c][j].y + n.z * wq[c][j].z + n.w * wq[c][j].w;
+    }
+  } else {
+    ssq = wave_sum(ssq);
+    const float nrm = fmaxf(sqrtf(ssq) * rsqrtf((float)D), h.eps);
+    for (int d = lane * 4; d < D; d += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(cache + d);
+      const float4 gg = *reinterpret_cast<const float4*>(h.g + d);
+      const float4 n = make_float4(v.x / nrm * gg.x, v.y / nrm * gg.y, v.z / nrm * gg.z, v.w / nrm * gg.w);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < h.A_dim) {
+          const float4 w = *reinterpret_cast<const float4*>(h.w_out + (long)j * D + d);
+          accv[j] += n.x * w.x + n.y * w.y + n.z * w.z + n.w * w.w;
+        }
       }
     }
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) accv[j] = wave_sum(accv[j]);
-  if (lane < h.A_dim) {
+  if (act_lane) {
     float F = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) if (lane == j) F = accv[j];
-    F += h.b_out[lane];
-    const long o = (long)ar * h.A_dim + lane;
-    if (h.F) h.F[o] = F;
-    if (h.scal) {
-      const float* sc = h.scal + (long)b * h.scal_stride;
-      const float xa = h.x_a[o];
-      const float den = F * sc[1] + xa * sc[0];           // F*c_out + x*c_skip      (score_wrappers.py:79-80)
-      if (h.denoised) h.denoised[o] = den;
-      if (h.x_next) h.x_next[o] = sc[2] * xa + (1.0f - sc[2]) * den;   // r*x + (1-r)*denoised (gc_sampling.py:948-950)
+    F += bo;
+    if (h.F) h.F[oidx] = F;
+    if (scp) {
+      const float den = F * sc1 + xa * sc0;               // F*c_out + x*c_skip      (score_wrappers.py:79-80)
+      if (h.denoised) h.denoised[oidx] = den;
+      if (h.x_next) h.x_next[oidx] = sc2 * xa + (1.0f - sc2) * den;   // r*x + (1-r)*denoised (gc_sampling.py:948-950)
     }
   }
 }
@@ -399,8 +445,13 @@ extern "C" int mode_embed_tokens_fwd(const ModeEmbedDesc* d, void* stream) {
   if (rows == 0) return MODE_OK;
   const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   const size_t lds = (size_t)ROWS_PER_BLOCK * d->D * 4;
-  if (d->h_dtype == MODE_BF16) hipLaunchKernelGGL(embed_tokens_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, *d);
-  else hipLaunchKernelGGL(embed_tokens_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, *d);
+  if (d->D == 1024) {
+    if (d->h_dtype == MODE_BF16) hipLaunchKernelGGL((embed_tokens_kernel<true, 4>), grid, dim3(256), lds, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL((embed_tokens_kernel<false, 4>), grid, dim3(256), lds, (hipStream_t)stream, *d);
+  } else {
+    if (d->h_dtype == MODE_BF16) hipLaunchKernelGGL((embed_tokens_kernel<true, 0>), grid, dim3(256), lds, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL((embed_tokens_kernel<false, 0>), grid, dim3(256), lds, (hipStream_t)stream, *d);
+  }
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
@@ -414,7 +465,8 @@ extern "C" int mode_head_ddim_fwd(const ModeHeadDesc* d, void* stream) {
   if (rows == 0) return MODE_OK;
   const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   const size_t lds = (size_t)ROWS_PER_BLOCK * d->D * 4;
-  hipLaunchKernelGGL(head_ddim_kernel, grid, dim3(256), lds, (hipStream_t)stream, *d);
+  if (d->D == 1024) hipLaunchKernelGGL(head_ddim_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(head_ddim_kernel<0>, grid, dim3(256), lds, (hipStream_t)stream, *d);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
