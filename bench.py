@@ -62,7 +62,7 @@ def synthetic_inputs(device, B):
 def dominant_kernel_roofline(den, device, reps=240):
     """Dominant kernel = grouped bf16 MFMA GEMM with SwishGLU epilogue (expert up-projection: 47 % of all FLOPs).  Launch it in
     isolation at the benchmark's exact shape (3584 gathered rows = 1792 tokens x top-2, K = 1024, 2 x 4096 weight rows per expert),
-    cycling through the 12 layers' weights, timed with HIP events on the stream it is launched on."""
+    cycling through the 12 layers' weights, as one hipGraph replay timed with HIP events on the stream it is launched on."""
     import ctypes as C
     from mode_diffusion_policy_amd import _lib as L
     m = den.inner_model
@@ -91,10 +91,18 @@ def dominant_kernel_roofline(den, device, reps=240):
         for d in descs:
             L.check(lib.mode_gemm(C.byref(d), st))
     torch.cuda.synchronize()
+    # the `reps` launches are recorded into one hipGraph and replayed between two events on the replay stream: back-to-back launches like in
+    # the sampler's chain, no host launch gaps inside the timed region
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cst = torch.cuda.current_stream().cuda_stream
+        for i in range(reps):
+            L.check(lib.mode_gemm(C.byref(descs[i % len(descs)]), cst))
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for i in range(reps):
-        lib.mode_gemm(C.byref(descs[i % len(descs)]), st)
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
@@ -102,10 +110,10 @@ def dominant_kernel_roofline(den, device, reps=240):
     ach = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "kernel": "gemm_bf16_kernel<SWIGLU> (grouped expert up-projection, M=3584 K=1024 N=2x4096)",
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            # HBM bytes per launch from the committed PMC passes (profiles/r01_gemm_pmc.md): FETCH_SIZE 47 047 KB x2 (gfx950 correction,
+            # HBM bytes per launch from the committed PMC passes (profiles/r01_gemm_pmc.md): FETCH_SIZE 47 391 KB x2 (gfx950 correction,
             # MI355X_MICROARCH.md "HBM") + WRITE_SIZE 28 672 KB; algorithmic bytes per launch (2 of 4 experts active under uniform sigma):
             # A 3.7 MB + W1 33.6 MB + H 29.4 MB = 66.6 MB
-            "traffic": 125.7e6, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_gemm_pmc.md)",
+            "traffic": 126.4e6, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_gemm_pmc.md)",
             "algorithmic_bytes": 66.6e6, "avg_launch_us": round(us, 2), "flops_per_launch": flops}
 
 
