@@ -34,6 +34,23 @@ def test_header_symbols_all_exported():
     assert lib.mode_hip_version() == L.ABI_VERSION
     assert lib.mode_hip_status_string(-2).decode().startswith("unsupported")
     assert lib.mode_set_option(b"gemm_cfg", 0) == 0 and lib.mode_set_option(b"nope", 1) == -2
+    for key, default, bad in ((b"dn_split_k", 0, 9), (b"gemm_skinny_rows", 64, -1), (b"fuse_ln2", 1, None), (b"adamw_blocks", 0, None)):
+        assert lib.mode_set_option(key, default) == 0, key                                  # documented knobs exist (include/mode_hip.h)
+        if bad is not None:
+            assert lib.mode_set_option(key, bad) != 0, key
+
+
+def test_mode_hip_opts_env(monkeypatch):
+    """MODE_HIP_OPTS="key=value,..." is applied when the library is loaded; unknown keys fail loudly."""
+    lib = L.load()
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setenv("MODE_HIP_OPTS", "fuse_ln2=1,dn_split_k=0")
+    assert L.load() is not None
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setenv("MODE_HIP_OPTS", "no_such_knob=1")
+    with pytest.raises(ValueError, match="MODE_HIP_OPTS"):
+        L.load()
+    monkeypatch.setattr(L, "_lib", lib)
 
 
 def test_ctypes_struct_sizes_match_header_layout():
