@@ -55,6 +55,8 @@ const char* mode_hip_status_string(int status);
  * cross-tile operand prefetch, 13 = 128x128 single-buffered with <= 128 VGPRs (4 workgroups/CU).  "gemm_tr_cfg": backward (transpose-read) GEMM geometry, 0 = auto, 1 = 128-wide ring-2, 2 = 64-wide ring-3,
  * 3 = 128-wide ring-3, 4 = 64-wide ring-2, 5 = 128-wide single-buffered.  "adamw_blocks": workgroup cap of one AdamW launch (0 = 256, one streaming workgroup per CU).
  * "gemm_skinny_rows": bf16 GEMMs with M <= this many rows use the weight-streaming kernel (default 64, 0 = off).
+ * "gemm_setprio": 1 (default) = s_setprio 1 around the MFMA clusters of the tiled bf16 GEMM (waves of co-resident workgroups that are in their
+ * MFMA phase win arbitration over waves issuing LDS / DMA work: +0.5 % on the up-projection, same-box A/B), 0 = off.
  * "fuse_ln2": 1 (default) = ln_2 folded into the c_proj / up-projection / combine kernels on the bf16 path, 0 = its own kernel.
  * "dn_split_k": K-slices of the inference path's expert down-projection, 0 = default (2, for every batch size), 1 = off, <= 8.
  * "attn_bwd_stop": profiling aid, attention backward returns after phase n (0 = off).  Unknown keys return MODE_ERR_BAD_ARG. */

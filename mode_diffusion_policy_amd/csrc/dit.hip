@@ -98,6 +98,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "attn_bwd_stop")) { g_attn_bwd_stop = value; return MODE_OK; }
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }
   if (!strcmp(key, "gemm_skinny_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_skinny_rows = value; return MODE_OK; }
+  if (!strcmp(key, "gemm_setprio")) { g_gemm_setprio = value != 0; return MODE_OK; }
   if (!strcmp(key, "fuse_ln2")) { g_fuse_ln2 = value != 0; return MODE_OK; }
   if (!strcmp(key, "dn_split_k")) { if (value < 0 || value > 8) return MODE_ERR_BAD_ARG; g_dn_split_k = value; return MODE_OK; }
   return MODE_ERR_UNSUPPORTED;

@@ -185,11 +185,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
     if constexpr (EPI == MODE_EPI_SWIGLU) lds_read_seq<2048, BJ>(fb + BJ, b_base + slot_off + co + (BN / 2) * 128);
   };
   auto mma = [&](const bf16x8(&fa)[FM], const bf16x8(&fb)[FN]) {
+    if (p.setprio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // swapped operands: D[n][m]
+    if (p.setprio) __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- main loop
@@ -401,6 +403,7 @@ enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x128_NS3 = 2, CFG_256x128_NS3 =
 int gemm_bf16_p256_launch(const ModeGemmDesc* d, hipStream_t s);   // gemm_bf16_p256.hip: persistent 256x256 with cross-tile operand prefetch
 int gemm_bf16_skinny_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_skinny.hip: weight streamer for a handful of rows
 int g_gemm_cfg = CFG_AUTO;
+int g_gemm_setprio = 1;
 int g_gemm_skinny_rows = 64;   // measured (scripts/rollout_batch_probe.py): chunk latency B=1 9.4 -> 7.7 ms, B=2 9.4 -> 9.0, B=4 9.7 -> 9.5; slower than the tiled kernel from ~100 rows on
 int g_gemm_group_m = 0;   // "gemm_group_m" option: m-tiles per rasterisation group (0 = default 8; >= m_tiles = n-major partition over the XCDs)
 
@@ -489,6 +492,7 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.koffs = d->k_group_offsets; p.c_gstride = d->c_group_stride;
   p.C2 = (uint16_t*)d->C2; p.ldc2 = d->ldc2; p.gain = d->gain; p.ss_out = d->row_ss_out;
   p.ss_in = d->row_ss; p.ss_n = d->row_ss_n; p.ss_eps = d->row_eps;
+  p.setprio = g_gemm_setprio;
   if (p.koffs && (d->num_k_groups <= 0 || p.split_k > 1 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
   if (g_gemm_cfg == CFG_AUTO && d->M <= g_gemm_skinny_rows) {
     const int rc = gemm_bf16_skinny_launch(d, p, s);
