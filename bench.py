@@ -178,7 +178,9 @@ def train_bench(args, world, rank, device, dist):
     opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)         # mode_agent.yaml:24-29, two groups as mode_agent.py:365-384
     if os.environ.get("MODE_ADAMW_BLOCKS"):
         m.engine.lib.mode_set_option(b"adamw_blocks", int(os.environ["MODE_ADAMW_BLOCKS"]))
-    red = ArenaGradReducer.for_model(m) if world > 1 else None
+    # gradient exchange dtype: fp32 like the reference's DDP (default), or MODE_DP_COMM=bf16 = half the bytes on the xGMI links
+    comm = torch.bfloat16 if os.environ.get("MODE_DP_COMM", "fp32") == "bf16" else torch.float32
+    red = ArenaGradReducer.for_model(m, comm_dtype=comm) if world > 1 else None
 
     def step():
         sig = rand_log_logistic((B,), loc=math.log(SIGMA_DATA), scale=0.5, min_value=SIGMA_MIN, max_value=SIGMA_MAX, device=device)
@@ -211,7 +213,7 @@ def train_bench(args, world, rank, device, dist):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "configs[2]/[3]: score-matching training step of the full MoDE denoiser (12 layers, d=1024, 4 experts top-2), "
                                       "B=128 per GPU, log-logistic sigma, multinomial routing, dropouts on, fused AdamW, router unfrozen",
-                          "global_batch": B * world, "parallelism": f"dp{world}"},
+                          "global_batch": B * world, "parallelism": f"dp{world}" + (" (bf16 gradient exchange)" if world > 1 and comm == torch.bfloat16 else "")},
                "train_tflops_per_gpu": round(fl * args.steps / elapsed / 1e12, 1)}
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -177,7 +177,11 @@ class ArenaGradReducer:
     """
 
     def __init__(self, grad_flat: torch.Tensor, n_reduce: int, process_group=None, slice_mb: float = 256.0, mode: str = "auto",
-                 average: bool = False):
+                 average: bool = False, comm_dtype: torch.dtype = torch.float32):
+        if comm_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("comm_dtype must be torch.float32 or torch.bfloat16")
+        self.comm_dtype = comm_dtype
+        self._stage = None                                  # bf16 staging buffer of the largest slice (comm_dtype=bfloat16)
         self.grad = grad_flat
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -219,6 +223,25 @@ class ArenaGradReducer:
             red.slices += [(0, first, None), (last_end, ar.bounds["no_decay"], None)]   # stacked routers / gains; embeddings, head, biases
         return red
 
+    def _exchange(self, g: torch.Tensor) -> None:
+        """Sum one flat slice over the ranks, in place (runs on whatever stream is current: the communication stream)."""
+        if self.comm_dtype != torch.float32:
+            if self._stage is None or self._stage.numel() < g.numel():
+                longest = max(hi - lo for lo, hi, *_ in self.slices)
+                self._stage = torch.empty(max(longest, g.numel()), dtype=self.comm_dtype, device=g.device)
+            st = self._stage[: g.numel()]
+            st.copy_(g)                                                      # fp32 -> bf16, one pass
+            dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.pg)
+            g.copy_(st)
+        elif self.mode == "rs_ag" and g.numel() % self.world == 0:
+            shard = g.view(self.world, -1)[dist.get_rank(self.pg)]
+            dist.reduce_scatter_tensor(shard, g, op=dist.ReduceOp.SUM, group=self.pg)      # in place: shard aliases its own slot
+            dist.all_gather_into_tensor(g, shard, group=self.pg)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.average:
+            g.div_(self.world)
+
     def reduce_async(self):
         """Queue every slice's collective on the communication stream (each behind its block event) WITHOUT joining the current stream;
         returns {(lo, hi): torch.cuda.Event recorded after that slice's exchange} so that an optimizer can chain per-slice updates
@@ -234,14 +257,7 @@ class ArenaGradReducer:
                 self._comm_stream.wait_stream(cur)
             with torch.cuda.stream(self._comm_stream):
                 g = self.grad[lo:hi]
-                if self.mode == "rs_ag" and (hi - lo) % self.world == 0:
-                    shard = g.view(self.world, -1)[dist.get_rank(self.pg)]
-                    dist.reduce_scatter_tensor(shard, g, op=dist.ReduceOp.SUM, group=self.pg)
-                    dist.all_gather_into_tensor(g, shard, group=self.pg)
-                else:
-                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
-                if self.average:
-                    g.div_(self.world)
+                self._exchange(g)
                 e = torch.cuda.Event()
                 e.record(self._comm_stream)
                 done[(lo, hi)] = e
@@ -266,14 +282,7 @@ class ArenaGradReducer:
                 ctx = nullcontext()
             with ctx:
                 g = self.grad[lo:hi]
-                if self.mode == "rs_ag" and (hi - lo) % self.world == 0:
-                    shard = g.view(self.world, -1)[dist.get_rank(self.pg)]
-                    dist.reduce_scatter_tensor(shard, g, op=dist.ReduceOp.SUM, group=self.pg)      # in place: shard aliases its own slot
-                    dist.all_gather_into_tensor(g, shard, group=self.pg)
-                else:
-                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
-                if self.average:
-                    g.div_(self.world)
+                self._exchange(g)
         if self._comm_stream is not None:
             cur.wait_stream(self._comm_stream)
         return 1.0 if self.average else 1.0 / self.world

@@ -107,6 +107,42 @@ def test_single_process_passthrough_and_param_groups():
     assert groups[0]["weight_decay"] == 0.05 and groups[1]["weight_decay"] == 0.0
 
 
+def _arena_bf16_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, n_reduce = 1000, 896
+        g = torch.Generator().manual_seed(5)
+        base = torch.randn(n, generator=g)
+        flat = base * (rank + 1)
+        red = ArenaGradReducer(flat, n_reduce, slice_mb=0.001, comm_dtype=torch.bfloat16)
+        scale = red.reduce()
+        want = (base.to(torch.bfloat16) * 1 + (base * 2).to(torch.bfloat16)).float()     # bf16 operands, bf16 sum
+        err = float((flat[:n_reduce] - (base * 3.0)[:n_reduce]).abs().max() / (base * 3.0).abs().max())
+        ok = err < 2 ** -7 and torch.equal(flat[n_reduce:], base[n_reduce:] * (rank + 1)) and flat.dtype == torch.float32
+        ok = ok and float((flat[:n_reduce] - want[:n_reduce]).abs().max()) <= float(want.abs().max()) * 2 ** -7
+        q.put((rank, bool(ok), scale, err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_arena_reducer_bf16_exchange_world2():
+    """comm_dtype=bfloat16: the slices travel as bf16 (half the bytes on the links), the arena stays fp32; the sum is exact to bf16 rounding."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_arena_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, scale, err in res:
+        assert ok and scale == 0.5, (rank, err)
+    with pytest.raises(ValueError):
+        ArenaGradReducer(torch.zeros(8), 8, comm_dtype=torch.float16)
+
+
 def _arena_worker(rank, world, port, mode, average, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
