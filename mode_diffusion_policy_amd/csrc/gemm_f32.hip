@@ -217,8 +217,17 @@ __global__ __launch_bounds__(256) void linear_f32_skinny_kernel(const float* __r
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const float* w = W + (long)n * ldw;
-  for (int k = lane * 4; k < K; k += 256) {
-    const float4 wv = *reinterpret_cast<const float4*>(w + k);
+  // four K-chunks per trip: their weight loads (the HBM stream) are requested together instead of one round trip per chunk; the per-lane
+  // fma order (k ascending) is unchanged
+  for (int k0 = lane * 4; k0 < K; k0 += 1024) {
+    float4 wq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wq[u] = *reinterpret_cast<const float4*>(w + min(k0 + u * 256, K - 4));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+    const int k = k0 + u * 256;
+    if (k >= K) break;
+    const float4 wv = wq[u];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (r < R) {
@@ -226,6 +235,7 @@ __global__ __launch_bounds__(256) void linear_f32_skinny_kernel(const float* __r
         acc[r] = fmaf(xv.x, wv.x, acc[r]); acc[r] = fmaf(xv.y, wv.y, acc[r]);
         acc[r] = fmaf(xv.z, wv.z, acc[r]); acc[r] = fmaf(xv.w, wv.w, acc[r]);
       }
+    }
     }
   }
 #pragma unroll
