@@ -399,7 +399,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
 // ------------------------------------------------------------------------------------------------------------ host side
 // geometry ids (also the values of the "gemm_cfg" option; 0 = auto)
 enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x128_NS3 = 2, CFG_256x128_NS3 = 3, CFG_128x64_NS3 = 4, CFG_128x64_NS4 = 5,
-       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10, CFG_256x256_W16 = 11, CFG_P256 = 12, CFG_128x128_NS1_4WG = 13 };
+       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10, CFG_256x256_W16 = 11, CFG_P256 = 12, CFG_128x128_NS1_4WG = 13, CFG_64x64_NS3 = 14, CFG_64x64_NS2 = 15 };
 int gemm_bf16_p256_launch(const ModeGemmDesc* d, hipStream_t s);   // gemm_bf16_p256.hip: persistent 256x256 with cross-tile operand prefetch
 int gemm_bf16_skinny_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_skinny.hip: weight streamer for a handful of rows
 int g_gemm_cfg = CFG_AUTO;
@@ -441,6 +441,10 @@ static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipSt
     case CFG_256x128_NS2: return launch_cfg<256, 128, 4, 2, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_256x256_W16: return launch_cfg<256, 256, 4, 4, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_128x128_NS1_4WG: return launch_cfg<128, 128, 2, 2, 1, EPI, OUT_BF16, 4>(p, d, s);   // <= 128 VGPRs: four 32-KiB workgroups per CU
+    case CFG_64x64_NS3:
+      if constexpr (EPI == MODE_EPI_SWIGLU) return MODE_ERR_UNSUPPORTED; else return launch_cfg<64, 64, 2, 2, 3, EPI, OUT_BF16>(p, d, s);
+    case CFG_64x64_NS2:
+      if constexpr (EPI == MODE_EPI_SWIGLU) return MODE_ERR_UNSUPPORTED; else return launch_cfg<64, 64, 2, 2, 2, EPI, OUT_BF16>(p, d, s);
     default: return MODE_ERR_BAD_ARG;
   }
 }
@@ -449,6 +453,7 @@ static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipSt
 //   >= 768 tiles of 128x128 : single-buffered 128x128, <= 128 VGPRs, 4 workgroups/CU (72 vs 76 us at B=128, 41 vs 47 us at B=64)   [expert up-projection]
 //   >= 576                  : single-buffered 128x128 at 3 workgroups/CU (other workgroups hide the fill latency)
 //   >= 256                  : double-buffered 128x128 ring            [QKV at B=128; up-projection at B=32: 448 tiles, 26.6 vs 29.5 us single-buffered]
+//   < 256 tiles of 128x64   : 64x64 tiles, 3-slot ring: twice the workgroups, two per CU (c_proj 15.1 -> 13.0 us at B=128, 12.4 -> 9.9 us at B=32)
 //   fewer                   : 128x64 tiles so that more CUs get a workgroup, 3-slot ring (two K-tiles in flight per workgroup: with
 //                             <= 1 workgroup per CU nothing else hides the fill latency)                 [c_proj, expert down-proj, small batches]
 static int pick_cfg(const ModeGemmDesc* d) {
@@ -459,6 +464,8 @@ static int pick_cfg(const ModeGemmDesc* d) {
   if (t128 >= 768) return CFG_128x128_NS1_4WG;   // >= 3 tiles per CU: four low-register workgroups per CU interleave fill / LDS / MFMA phases best
   if (t128 >= 576) return CFG_128x128_NS1;
   if (t128 >= 256) return CFG_128x128_NS2;
+  const long t64 = ((rows + 127) / 128) * ((d->N + 63) / 64);
+  if (t64 < 256 && d->epilogue != MODE_EPI_SWIGLU) return CFG_64x64_NS3;   // c_proj at B <= 128, QKV at B <= 32: two small workgroups per CU overlap each other
   return CFG_128x64_NS3;
 }
 

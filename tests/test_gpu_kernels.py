@@ -30,7 +30,7 @@ def rnd(*shape, seed=0, scale=1.0):
 
 # ----------------------------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1792, 3072, 1024), (100, 192, 64), (257, 1024, 256), (14, 64, 128), (1, 128, 64)])
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
 def test_gemm_bf16_plain_bias(M, N, K, cfg):
     # asymmetric operands: a transposed/permuted C-write cannot pass
     A = rnd(M, K, seed=1).to(torch.bfloat16); W = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
@@ -247,7 +247,7 @@ def test_dispatch_meta_bit_exact(R, tpr, E, k):
 
 # ------------------------------------------------------------------------------------------------- fused ln_2 (c_proj -> experts -> combine)
 @pytest.mark.parametrize("cfg", [0, 1, 4, 6, 13])
-@pytest.mark.parametrize("N_tok,D,E,k", [(70, 128, 4, 2), (1792, 256, 4, 2), (37, 64, 2, 1)])
+@pytest.mark.parametrize("N_tok,D,E,k", [(70, 128, 4, 2), (1792, 256, 4, 2), (1792, 1024, 4, 2), (37, 64, 2, 1)])
 def test_fused_ln2_chain_matches_separate_kernels(N_tok, D, E, k, cfg):
     """MODE_EPI_RESIDUAL_NORM producer + MODE_EPI_SWIGLU(row_ss) consumer + combine(u_ss) against the three-kernel formulation
     (c_proj+residual -> rmsnorm -> up-projection -> combine): the same mathematics with ln_2's division moved behind the GEMM."""
