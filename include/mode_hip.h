@@ -54,7 +54,7 @@ const char* mode_hip_status_string(int status);
  * 8 = 128x64 ring-2, 9 = 256x256 ring-2 (8 waves), 10 = 256x128 ring-2, 11 = 256x256 ring-2 (16 waves), 12 = persistent 256x256 with
  * cross-tile operand prefetch, 13 = 128x128 single-buffered with <= 128 VGPRs (4 workgroups/CU), 14 = 64x64 ring-3, 15 = 64x64 ring-2 (no SwiGLU).  "gemm_tr_cfg": backward (transpose-read) GEMM geometry, 0 = auto, 1 = 128-wide ring-2, 2 = 64-wide ring-3,
  * 3 = 128-wide ring-3, 4 = 64-wide ring-2, 5 = 128-wide single-buffered.  "adamw_blocks": workgroup cap of one AdamW launch (0 = 256, one streaming workgroup per CU).
- * "gemm_skinny_rows": bf16 GEMMs with M <= this many rows use the weight-streaming kernel (default 64, 0 = off).
+ * "gemm_skinny_rows": bf16 GEMMs with M <= this many rows use the weight-streaming kernel (default 32, 0 = off).
  * "gemm_setprio": 1 (default) = s_setprio 1 around the MFMA clusters of the tiled bf16 GEMM (waves of co-resident workgroups that are in their
  * MFMA phase win arbitration over waves issuing LDS / DMA work: +0.5 % on the up-projection, same-box A/B), 0 = off.
  * "fuse_ln2": 1 (default) = ln_2 folded into the c_proj / up-projection / combine kernels on the bf16 path, 0 = its own kernel.

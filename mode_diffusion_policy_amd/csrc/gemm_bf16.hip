@@ -404,7 +404,7 @@ int gemm_bf16_p256_launch(const ModeGemmDesc* d, hipStream_t s);   // gemm_bf16_
 int gemm_bf16_skinny_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_skinny.hip: weight streamer for a handful of rows
 int g_gemm_cfg = CFG_AUTO;
 int g_gemm_setprio = 1;
-int g_gemm_skinny_rows = 64;   // measured (scripts/rollout_batch_probe.py): chunk latency B=1 9.4 -> 7.7 ms, B=2 9.4 -> 9.0, B=4 9.7 -> 9.5; slower than the tiled kernel from ~100 rows on
+int g_gemm_skinny_rows = 32;   // measured (scripts/rollout_batch_probe.py): chunk latency B=1 9.4 -> 7.35 ms, B=2 8.7 -> 8.3 ms; from ~3 environments on the tiled kernel (64x64 tiles) is as fast or faster
 int g_gemm_group_m = 0;   // "gemm_group_m" option: m-tiles per rasterisation group (0 = default 8; >= m_tiles = n-major partition over the XCDs)
 
 template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16, int LR = 0>

@@ -1,4 +1,4 @@
-// Skinny-M bf16 GEMM for gfx950: C[M,N] = epilogue(A[M,K] @ W[N,K]^T) when M is a handful of rows (B <= 4 environments = 14..56 tokens,
+// Skinny-M bf16 GEMM for gfx950: C[M,N] = epilogue(A[M,K] @ W[N,K]^T) when M is a handful of rows (B <= 2 environments = 14..28 tokens,
 // the reference's own rollout is B = 1: mode_agent.py:630).  There the tiled kernel of gemm_bf16.hip launches 16..128 workgroups that each
 // walk K serially with two 24-KiB tiles in flight — 0.4-0.7 TB/s of weight traffic.  This kernel is a weight STREAMER:
 //   * one workgroup per 16 output columns (16 value + 16 gate rows of W1 for SwiGLU) and expert; its waves cut K into NW slices, so a

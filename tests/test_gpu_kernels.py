@@ -297,7 +297,7 @@ def test_fused_ln2_chain_matches_separate_kernels(N_tok, D, E, k, cfg):
         assert rel(hid.float(), want.float()) < 4e-3
     finally:
         lib.mode_set_option(b"gemm_cfg", 0)
-        lib.mode_set_option(b"gemm_skinny_rows", 64)
+        lib.mode_set_option(b"gemm_skinny_rows", 32)
     # --- combine: un-normalised u + partial sums + gain == normalised u
     Y = rnd(NK, D, seed=8).to(bf).to(dev()); g1 = (1.0 + 0.1 * rnd(D, seed=9)).to(dev()); cond = rnd(N_tok, D, seed=10).to(dev())
     xn_a, h_a = H.combine_norm(xn_ref, Y, meta["pos"], meta["posw"], k, g1, cond, 1, eps=eps)
@@ -309,7 +309,7 @@ def test_fused_ln2_chain_matches_separate_kernels(N_tok, D, E, k, cfg):
 
 # ------------------------------------------------------------------------------------------------- weight-streaming GEMM for a handful of rows
 def _both_paths(fn):
-    """fn() with the weight-streaming kernel (default only for M <= 64; forced here up to 128 rows) and with the tiled kernel; returns (skinny, tiled)."""
+    """fn() with the weight-streaming kernel (default only for M <= 32; forced here up to 128 rows) and with the tiled kernel; returns (skinny, tiled)."""
     lib = L.load()
     lib.mode_set_option(b"gemm_skinny_rows", 128)
     a = fn()
@@ -317,7 +317,7 @@ def _both_paths(fn):
     try:
         b = fn()
     finally:
-        lib.mode_set_option(b"gemm_skinny_rows", 64)
+        lib.mode_set_option(b"gemm_skinny_rows", 32)
     return a, b
 
 
