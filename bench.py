@@ -110,10 +110,10 @@ def dominant_kernel_roofline(den, device, reps=240):
     ach = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "kernel": "gemm_bf16_kernel<SWIGLU> (grouped expert up-projection, M=3584 K=1024 N=2x4096)",
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            # HBM bytes per launch from the committed PMC passes (profiles/r01_gemm_pmc.md): FETCH_SIZE 47 391 KB x2 (gfx950 correction,
+            # HBM bytes per launch from the committed PMC passes (profiles/r01_gemm_pmc.md): FETCH_SIZE 47 216 KB x2 (gfx950 correction,
             # MI355X_MICROARCH.md "HBM") + WRITE_SIZE 28 672 KB; algorithmic bytes per launch (2 of 4 experts active under uniform sigma):
             # A 3.7 MB + W1 33.6 MB + H 29.4 MB = 66.6 MB
-            "traffic": 126.4e6, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_gemm_pmc.md)",
+            "traffic": 126.1e6, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_gemm_pmc.md)",
             "algorithmic_bytes": 66.6e6, "avg_launch_us": round(us, 2), "flops_per_launch": flops}
 
 
