@@ -317,3 +317,25 @@ def test_down_projection_split_k_slices(B):
     for s in (2, 4, 8, 0):
         assert rel(outs[s], outs[1]) < 4e-3, s
     assert lib.mode_set_option(b"dn_split_k", 9) != 0
+
+
+@pytest.mark.parametrize("B", [1, 2, 3])
+def test_single_environment_bf16_chain_vs_oracle(B):
+    """The reference's own rollout is ONE environment (mode_agent.py:630): 14-28 token rows take the weight-streaming GEMM, ln_2 stays a kernel of its
+    own, B = 3 crosses back to the tiled kernels with the fused ln_2.  bf16 chain + 10-step DDIM (hipGraph) against the fp32 oracle, routing exact."""
+    cfg, sd, m = build("c1e4", 210, "bf16")
+    inp = make_inputs(cfg, B, 70 + B)
+    sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(B))
+    ref, aux = O.dit_forward(sd, cfg, inp["state_images"], inp["actions"], inp["goals"], sig, return_aux=True)
+    c = cuda_inputs(inp)
+    with torch.no_grad():
+        out = m({"state_images": c["state_images"]}, c["actions"], c["goals"], sig.cuda())
+    assert torch.equal(m._last_topk.cpu().long(), torch.stack(aux.topk_idx)[:, :, 0, :])
+    assert rel(out, ref) < 1e-2
+    den = M.GCDenoiser(m, 0.5).eval()
+    sched = M.get_sigmas_exponential(10, 1e-3, 80.0)
+    st = {"state_images": c["state_images"]}
+    x = M.sample_ddim(den, st, c["x0"], c["goals"], sched.cuda(), disable=True)
+    want = O.sample_ddim(sd, cfg, 0.5, inp["state_images"], inp["x0"], inp["goals"], sched)
+    assert rel(x, want) < 2e-2
+    assert torch.equal(x, M.sample_ddim(den, st, c["x0"], c["goals"], sched.cuda(), disable=True))      # graph replay is deterministic
