@@ -94,7 +94,7 @@ def dominant_kernel_roofline(den, device, reps=240):
     # the `reps` launches are recorded into one hipGraph and replayed between two events on the replay stream: back-to-back launches like in
     # the sampler's chain, no host launch gaps inside the timed region
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
         cst = torch.cuda.current_stream().cuda_stream
         for i in range(reps):
             L.check(lib.mode_gemm(C.byref(descs[i % len(descs)]), cst))

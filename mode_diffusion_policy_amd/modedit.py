@@ -343,7 +343,7 @@ class MoDeDiT(nn.Module):
                 self._ddim_chain(eng, st["img"], st["goals"], st["x"], st["sig"], sigma_data)
             torch.cuda.current_stream(dev).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
                 st["idx"], st["meta"], st["ml"] = self._ddim_chain(eng, st["img"], st["goals"], st["x"], st["sig"], sigma_data)
             st["graph"] = g
             self._route_cache["graph"] = ent = st
