@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_bias_bf16x8_kernel(const uint1
 // One wave per row.  dy[row] = (dy_a ? dy_a[row] : 0) + (dy_b ? dy_b[row] : 0) + sum_j G[pos[row*k+j]]   (all fp32)
 // dx[row] (+)= (g*dy)/n - x * <g*dy, x> / (D n^3)   with n = max(||x||/sqrt(D), eps)  [clamped branch: dx = g*dy/eps]
 // dg partial: dgp[block][d] = sum over the block's 4 rows of dy_d * x_d / n  (reduced by colsum stage 2)
+template <int NCH>   // NCH > 0: D == 256*NCH, chunk loops fully unrolled so that a phase's loads are all in flight together (else generic D % 4 == 0)
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* dy_a,
                                                           const float* dy_b, const float* __restrict__ G, const int* __restrict__ pos, int k,
                                                           int rows, int D, float eps, float* dx, int accumulate, float* __restrict__ dgp,
@@ -240,15 +241,29 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   const int row = blockIdx.x * 4 + wave;
   const bool valid = row < rows;
   float ssq = 0.f, dot = 0.f;
+  long prow[8];                                                      // gathered rows of G (the k expert copies), fetched once per row
+#pragma unroll
+  for (int j = 0; j < 8; ++j) prow[j] = (valid && j < k) ? (long)pos[(long)row * k + j] * D : 0;
+  auto chunks = [&](auto&& f) {
+    if constexpr (NCH > 0) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) f(lane * 4 + c * 256);
+    } else {
+      for (int d = lane * 4; d < D; d += 256) f(d);
+    }
+  };
   if (valid) {
-    for (int d = lane * 4; d < D; d += 256) {
+    chunks([&](int d) {
       const float4 xv = *reinterpret_cast<const float4*>(x + (long)row * D + d);
       float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (dy_a) { const float4 t = *reinterpret_cast<const float4*>(dy_a + (long)row * D + d); dv.x += t.x; dv.y += t.y; dv.z += t.z; dv.w += t.w; }
       if (dy_b) { const float4 t = *reinterpret_cast<const float4*>(dy_b + (long)row * D + d); dv.x += t.x; dv.y += t.y; dv.z += t.z; dv.w += t.w; }
-      for (int j = 0; j < k; ++j) {
-        const float4 t = *reinterpret_cast<const float4*>(G + (long)pos[(long)row * k + j] * D + d);
-        dv.x += t.x; dv.y += t.y; dv.z += t.z; dv.w += t.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < k) {
+          const float4 t = *reinterpret_cast<const float4*>(G + prow[j] + d);
+          dv.x += t.x; dv.y += t.y; dv.z += t.z; dv.w += t.w;
+        }
       }
       const float4 gv = *reinterpret_cast<const float4*>(g + d);
       *reinterpret_cast<float4*>(sx + wave * D + d) = xv;
@@ -256,7 +271,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
       if (dy_out) *reinterpret_cast<float4*>(dy_out + (long)row * D + d) = dv;
       ssq += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
       dot += gv.x * dv.x * xv.x + gv.y * dv.y * xv.y + gv.z * dv.z * xv.z + gv.w * dv.w * xv.w;
-    }
+    });
   }
   ssq = wave_sum(ssq); dot = wave_sum(dot);
   const float rms = sqrtf(ssq) * rsqrtf((float)D);
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   const float rn = 1.0f / n;
   const float coef = clamped ? 0.f : dot * rn * rn * rn / (float)D;
   if (valid) {
-    for (int d = lane * 4; d < D; d += 256) {
+    chunks([&](int d) {
       const float4 xv = *reinterpret_cast<const float4*>(sx + wave * D + d);
       const float4 dv = *reinterpret_cast<const float4*>(sd + wave * D + d);
       const float4 gv = *reinterpret_cast<const float4*>(g + d);
@@ -280,7 +295,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
       }
       // stash dy * x / n for the gain gradient in place of dy
       *reinterpret_cast<float4*>(sd + wave * D + d) = make_float4(dv.x * xv.x * rn, dv.y * xv.y * rn, dv.z * xv.z * rn, dv.w * xv.w * rn);
-    }
+    });
   } else {
     for (int d = lane * 4; d < D; d += 256) *reinterpret_cast<float4*>(sd + wave * D + d) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -305,11 +320,18 @@ __global__ __launch_bounds__(256) void combine_bwd_kernel(const float* __restric
     float acc = 0.f;
     for (int d = lane * 4; d < D; d += 256) {
       const float4 g = *reinterpret_cast<const float4*>(dy + (long)t * D + d);
+      if constexpr (sizeof(T) == 2) {                               // bf16: one 8-byte load / store per lane instead of four 2-byte ones
+        const uint2 y2 = *reinterpret_cast<const uint2*>(Y + p * D + d);
+        acc += g.x * bf16_bits_to_f32(y2.x & 0xffff); acc += g.y * bf16_bits_to_f32(y2.x >> 16);
+        acc += g.z * bf16_bits_to_f32(y2.y & 0xffff); acc += g.w * bf16_bits_to_f32(y2.y >> 16);
+        *reinterpret_cast<uint2*>(dYs + p * D + d) = make_uint2(pack_bf16x2(w * g.x, w * g.y), pack_bf16x2(w * g.z, w * g.w));
+      } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float gv = (&g.x)[c];
-        acc += gv * ld1<T>(Y + p * D + d + c);
-        st1<T>(dYs + p * D + d + c, w * gv);
+        for (int c = 0; c < 4; ++c) {
+          const float gv = (&g.x)[c];
+          acc += gv * ld1<T>(Y + p * D + d + c);
+          st1<T>(dYs + p * D + d + c, w * gv);
+        }
       }
     }
     acc = wave_sum(acc);
@@ -580,8 +602,13 @@ extern "C" int mode_rmsnorm_bwd(const float* x, const float* g, const float* dy_
   if (rows == 0) return MODE_OK;
   const size_t lds = (size_t)8 * D * 4;
   if (lds > 64 * 1024) return MODE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), lds, (hipStream_t)stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx,
-                     accumulate, dg_partial, dy_out, dx_lp, lp_dtype == MODE_BF16 ? 1 : 0);
+  if (k > 8) return MODE_ERR_UNSUPPORTED;
+  if (D == 1024)
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, dim3((rows + 3) / 4), dim3(256), lds, (hipStream_t)stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx,
+                       accumulate, dg_partial, dy_out, dx_lp, lp_dtype == MODE_BF16 ? 1 : 0);
+  else
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<0>, dim3((rows + 3) / 4), dim3(256), lds, (hipStream_t)stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx,
+                       accumulate, dg_partial, dy_out, dx_lp, lp_dtype == MODE_BF16 ? 1 : 0);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
