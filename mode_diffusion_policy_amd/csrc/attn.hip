@@ -6,6 +6,8 @@
 //   * the probabilities are already laid out as the B operand of  O^T = V^T P^T  (k-slots 4..7 of each lane group are zero
 //     padding), so P never moves between lanes; each lane then owns 4 consecutive head-dim outputs of one query -> 8-byte stores.
 // fp32 parity mode: a plain VALU kernel with the same math (one wave per (sample, head), LDS-staged q/k/v).
+#include <type_traits>
+
 #include "mode_common.h"
 
 namespace mode {
@@ -197,25 +199,30 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 // ---- backward (training): one 256-thread workgroup per (sample, head), everything in LDS, fp32 VALU in the forward's order.
 // dY [B*T, D] (T2 = bf16/f32) -> dqkv [B*T, 3D]; per-workgroup partial gradients of the qk-norm gains: dgq/dgk [B*H, HD].
 template <typename T2>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qkv, const float* __restrict__ qg, const float* __restrict__ kg,
+__global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__ qkv, const float* __restrict__ qg, const float* __restrict__ kg,
                                                        const T2* __restrict__ dY, T2* __restrict__ dqkv, float* __restrict__ dgq_part,
                                                        float* __restrict__ dgk_part, int B, int T, int H, int HD, float eps, uint32_t seed,
                                                        uint32_t thresh, float inv_keep, int stop_after) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HP = HD + 1;                               // padded row (bank-conflict-free column walks)
+  // v / dO (and dV, which replaces v) are kept in the INPUT dtype: for bf16 that is exact (the inputs are bf16, dV is rounded to bf16 on
+  // its way out anyway) and brings the workgroup under 40 KB of LDS — four workgroups per CU, the whole grid of B*H = 1024 in one round
+  typedef typename std::conditional<sizeof(T2) == 2, uint16_t, float>::type TV;
+  const int HV = sizeof(T2) == 2 ? HD + 8 : HD + 1;     // row stride of the TV tiles (bf16: 16-byte aligned rows, 4 banks of skew)
   float* sq = reinterpret_cast<float*>(smem);          // raw q  [T][HP]
   float* sk = sq + T * HP;                             // raw k
-  float* sv = sk + T * HP;                             // v
-  float* sdo = sv + T * HP;                            // dO
-  float* sqh = sdo + T * HP;                           // q_hat, later d q_hat
+  float* sqh = sk + T * HP;                            // q_hat, later d q_hat
   float* skh = sqh + T * HP;                           // k_hat, later d k_hat
   // probability-sized tiles are zero-padded to 16 x 16 (row stride 16): branch-free 16-term dot products, float4 broadcast reads
-  float* sp = skh + T * HP + ((4 - ((6 * T * HP) & 3)) & 3);   // P [query][key]                    (16-byte aligned)
+  float* sp = skh + T * HP + ((4 - ((4 * T * HP) & 3)) & 3);   // P [query][key]                    (16-byte aligned)
   float* sds = sp + 256;                               // dPd, then dS   [query][key]
   float* spdT = sds + 256;                             // dropped probabilities, transposed [key][query]
   float* sdsT = spdT + 256;                            // dS transposed                     [key][query]
   float* srq = sdsT + 256;                             // 1/norm per token (q)              [T]
   float* srk = srq + T;                                // (k)
+  TV* sv = reinterpret_cast<TV*>(srk + T + ((4 - ((2 * T) & 3)) & 3));   // v, later dV   [T][HV]   (16-byte aligned)
+  TV* sdo = sv + T * HV;                               // dO
+  auto tvf = [](TV x) -> float { if constexpr (sizeof(TV) == 2) return bf16_bits_to_f32(x); else return x; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int prob = blockIdx.x, b = prob / H, h = prob % H, D = H * HD;
   const long ld = 3L * D;
@@ -238,10 +245,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
     const T2* r = qkv + ((long)b * T + t) * ld + h * HD + d;
     const uint4 uq = *reinterpret_cast<const uint4*>(r), uk = *reinterpret_cast<const uint4*>(r + D), uv = *reinterpret_cast<const uint4*>(r + 2 * D);
     const uint4 ud = *reinterpret_cast<const uint4*>(dY + ((long)b * T + t) * D + h * HD + d);
-    float fq_[VE], fk_[VE], fv_[VE], fd_[VE];
-    unpack(uq, fq_); unpack(uk, fk_); unpack(uv, fv_); unpack(ud, fd_);
+    float fq_[VE], fk_[VE];
+    unpack(uq, fq_); unpack(uk, fk_);
 #pragma unroll
-    for (int j = 0; j < VE; ++j) { sq[t * HP + d + j] = fq_[j]; sk[t * HP + d + j] = fk_[j]; sv[t * HP + d + j] = fv_[j]; sdo[t * HP + d + j] = fd_[j]; }
+    for (int j = 0; j < VE; ++j) { sq[t * HP + d + j] = fq_[j]; sk[t * HP + d + j] = fk_[j]; }
+    if constexpr (sizeof(T2) == 2) {                    // bf16: the 16-byte chunks go to LDS as they are
+      *reinterpret_cast<uint4*>(sv + t * HV + d) = uv; *reinterpret_cast<uint4*>(sdo + t * HV + d) = ud;
+    } else {
+      float fv_[VE], fd_[VE];
+      unpack(uv, fv_); unpack(ud, fd_);
+#pragma unroll
+      for (int j = 0; j < VE; ++j) { sv[t * HV + d + j] = fv_[j]; sdo[t * HV + d + j] = fd_[j]; }
+    }
   }
   __syncthreads();
   if (stop_after == 1) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
@@ -273,16 +288,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
     float sa[4] = {0.f, 0.f, 0.f, 0.f}, pa[4] = {0.f, 0.f, 0.f, 0.f};
     const bool act = qi < T && kgrp * 4 <= qi;
     if (act) {
-      const float* qr = sqh + qi * HP; const float* orow = sdo + qi * HP;
+      const float* qr = sqh + qi * HP; const TV* orow = sdo + qi * HV;
       const int k0 = kgrp * 4;
-      const float* kr[4]; const float* vr[4];
+      const float* kr[4]; const TV* vr[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const int kk = min(k0 + j, T - 1); kr[j] = skh + kk * HP; vr[j] = sv + kk * HP; }
+      for (int j = 0; j < 4; ++j) { const int kk = min(k0 + j, T - 1); kr[j] = skh + kk * HP; vr[j] = sv + kk * HV; }
 #pragma unroll 4
       for (int d = part; d < HD; d += 4) {                  // lanes interleave d: consecutive banks; unrolled: 40 LDS reads in flight
-        const float qv = qr[d], ov = orow[d];
+        const float qv = qr[d], ov = tvf(orow[d]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { sa[j] = fmaf(qv, kr[j][d], sa[j]); pa[j] = fmaf(ov, vr[j][d], pa[j]); }
+        for (int j = 0; j < 4; ++j) { sa[j] = fmaf(qv, kr[j][d], sa[j]); pa[j] = fmaf(ov, tvf(vr[j][d]), pa[j]); }
       }
     }
 #pragma unroll
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
     } else if (act) {
       float oc[TMAX], qc[TMAX];
 #pragma unroll
-      for (int u = 0; u < TMAX; ++u) { oc[u] = u < T ? sdo[u * HP + d] : 0.f; qc[u] = u < T ? sqh[u * HP + d] : 0.f; }
+      for (int u = 0; u < TMAX; ++u) { oc[u] = u < T ? tvf(sdo[u * HV + d]) : 0.f; qc[u] = u < T ? sqh[u * HP + d] : 0.f; }
 #pragma unroll
       for (int j = 0; j < TMAX; ++j) { o0[j] = dot16(spdT + j * 16, oc); o1[j] = dot16(sdsT + j * 16, qc); }
     }
@@ -366,7 +381,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
       for (int t = 0; t < TMAX; ++t) if (t < T) sqh[t * HP + d] = o0[t];
     } else if (act) {
 #pragma unroll
-      for (int j = 0; j < TMAX; ++j) if (j < T) { sv[j * HP + d] = o0[j]; skh[j * HP + d] = o1[j]; }
+      for (int j = 0; j < TMAX; ++j) if (j < T) {
+        if constexpr (sizeof(TV) == 2) sv[j * HV + d] = f32_to_bf16_bits(o0[j]); else sv[j * HV + d] = o0[j];
+        skh[j * HP + d] = o1[j];
+      }
     }
   }
   __syncthreads();
@@ -413,7 +431,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T2* __restrict__ qk
     T2* o = dqkv + ((long)b * T + t) * ld + h * HD + d;
     *reinterpret_cast<uint4*>(o) = pack(sqh + t * HP + d);
     *reinterpret_cast<uint4*>(o + D) = pack(skh + t * HP + d);
-    *reinterpret_cast<uint4*>(o + 2 * D) = pack(sv + t * HP + d);
+    if constexpr (sizeof(T2) == 2) *reinterpret_cast<uint4*>(o + 2 * D) = *reinterpret_cast<const uint4*>(sv + t * HV + d);
+    else *reinterpret_cast<uint4*>(o + 2 * D) = pack(reinterpret_cast<const float*>(sv) + t * HV + d);
   }
 }
 
@@ -457,7 +476,8 @@ extern "C" int mode_attn_block_bwd(const void* qkv, const float* q_gain, const f
   if (!qkv || !q_gain || !k_gain || !dy || !dqkv || !dgq_partial || !dgk_partial || B < 0 || T <= 0 || H <= 0) return MODE_ERR_BAD_ARG;
   if (p_drop < 0.f || p_drop >= 1.f) return MODE_ERR_BAD_ARG;
   if (B == 0) return MODE_OK;
-  const size_t lds = ((size_t)6 * T * (head_dim + 1) + 4 + 4 * 256 + 2 * T) * 4;
+  const size_t lds = dtype == MODE_BF16 ? ((size_t)4 * T * (head_dim + 1) + 4 + 4 * 256 + 2 * T + 4) * 4 + (size_t)2 * T * (head_dim + 8) * 2
+                                        : ((size_t)6 * T * (head_dim + 1) + 4 + 4 * 256 + 2 * T + 4) * 4;
   if (lds > 64 * 1024 || head_dim > 128 || T > 16 || head_dim % (dtype == MODE_BF16 ? 8 : 4)) return MODE_ERR_UNSUPPORTED;
   const uint32_t th = attn_thresh(p_drop); const float ik = 1.0f / (1.0f - p_drop);
   hipStream_t s = (hipStream_t)stream;
