@@ -109,7 +109,8 @@ typedef struct ModeGemmDesc {
  * `grad.T @ x` GEMMs PyTorch launches for every Linear of modedit.py in loss.backward()).  No transposed copies are made: the row-major
  * tiles are gathered into MFMA fragments by the LDS transpose read ds_read_b64_tr_b16.
  *   MODE_GEMM_W_KN            W is [K, N] row-major (ldw = row stride): C[M,N] = A[M,K] @ W   — data gradient dX = dY @ W_linear.
- *                             K % 64 == 0; expert_offsets / w_expert_stride group the rows as in the forward.
+ *                             K % 64 == 0; expert_offsets / w_expert_stride group the rows as in the forward; split_k K-slices
+ *                             (K % (64*split_k) == 0) write partial slabs split_stride elements apart that the consumer adds.
  *   MODE_GEMM_W_KN | A_KM     A is [K, M] row-major too: C[M,N] = A^T @ W — weight gradient dW = dY^T @ X from row-major activations.
  *                             k_group_offsets are then ARBITRARY row ranges [off[z], off[z+1]) (per-expert segments, no padding), K is
  *                             the row count when no groups are given; M % 8 == 0. */

@@ -11,6 +11,12 @@
 
 using namespace mode;
 
+namespace mode {
+int rmsnorm_bwd_launch(const float* x, const float* g, const float* dy_a, const float* dy_b, const float* G, int g_splits, long g_split_stride,
+                       const int32_t* pos, int k, int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* dx_lp,
+                       int lp_dtype, hipStream_t stream);   // train_ops.hip
+}
+
 namespace {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -41,7 +47,7 @@ TrainWs train_ws(const ModeDims& d, int B, int dtype) {
   TrainWs w{};
   Take t;
   w.dxa = t(N * D * 4); w.dxb = t(N * D * 4); w.dyl = t(N * D * 4);
-  w.dys = t(NK * D * esz); w.dhd = t(NK * 4 * D * esz); w.dp = t(NK * 8 * D * esz); w.dus = t(NK * D * 4); w.dwt = t(NK * 4 * (size_t)d.L);      // router-weight gradients of ALL layers [L][N*k]
+  w.dys = t(NK * D * esz); w.dhd = t(NK * 4 * D * esz); w.dp = t(NK * 8 * D * esz); w.dus = t(NK * D * 4 * 2);   /* dU: two K-slice slabs of the up-projection data gradient */ w.dwt = t(NK * 4 * (size_t)d.L);      // router-weight gradients of ALL layers [L][N*k]
   w.t_big = t(8 * D * NKp * esz);            // dP^T  [8D, NKp]   (also dqkv^T [3D, Np])
   w.t_mid = t(4 * D * NKp * esz);            // Hd^T  [4D, NKp]
   w.t_d = t(D * NKp * esz);                  // dY^T / u^T / dx1^T / h1^T  [D, NKp]
@@ -182,6 +188,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       return MODE_ERR_UNSUPPORTED;
   }
   const bool tr = dt == MODE_BF16 && D % 8 == 0;      // bf16: backward GEMMs read row-major operands directly (gemm_bf16_tr.hip); no transposed copies
+  const int du_split = (tr && (8 * D) % 128 == 0) ? 2 : 1;   // K-slices of the up-projection data gradient
   const bool bf = dt == MODE_BF16;
   const long NKp = ((long)NK + 63) / 64 * 64 + 64L * E, Np = ((long)N + 63) / 64 * 64;
   const int Ktok = bf ? (int)Np : N;                       // token-dim contraction length (bf16 kernel needs a multiple of 64: zero padded)
@@ -273,8 +280,11 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     }
     // (4) expert up-projection: dU (sorted rows, fp32) = dP W1 ; dW1_e = dP_e^T U_e
     if (tr) {
+      // K = 8D with only NK*D/128^2 = 224 output tiles: two K-slices (fp32 slabs, added by the ln_2 backward's gather-sum) double the workgroups
+      // and allow 128-wide tiles, as for the inference down-projection (112 -> ~80 us)
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 8 * D, dP, 8 * D, lw.w1, D, dUs, D);
       g.w_expert_stride = 8L * D * D; g.expert_offsets = offsets; g.num_experts = E; g.flags = MODE_GEMM_W_KN;
+      g.split_k = du_split; g.split_stride = (long)NK * D;
       if ((rc = mode_gemm(&g, stream))) return rc;
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 8 * D, D, NK, dP, 8 * D, S + sl.ub, D, lg.w1, D);          // u rows gathered through perm
       g.k_group_offsets = offsets; g.num_k_groups = E; g.c_group_stride = 8L * D * D; g.w_rows = meta + ml.perm;
@@ -295,7 +305,8 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     float* dgp2 = dgp + (size_t)(1 + d.L + l) * nblk4 * D;                  // gain partials are reduced for all layers after the loop
     float* dgp1 = dgp + (size_t)(1 + l) * nblk4 * D;
     float* apq_l = apq + (size_t)l * B * D; float* apk_l = apk + (size_t)l * B * D;
-    if ((rc = mode_rmsnorm_bwd((const float*)(S + sl.x1), lw.ln2_g, DXa, nullptr, dUs, pos, d.k, N, D, d.eps, DXb, 0, dgp2, nullptr, dx1lp, dt, stream)))
+    if ((rc = rmsnorm_bwd_launch((const float*)(S + sl.x1), lw.ln2_g, DXa, nullptr, dUs, tr ? du_split : 1, (long)NK * D, pos, d.k, N, D, d.eps, DXb, 0, dgp2,
+                                 nullptr, dx1lp, dt, (hipStream_t)stream)))
       return rc;
     // (6) c_proj: d yattn = dx1 Wo ; dWo = dx1^T yattn
     if (tr) {

@@ -32,6 +32,7 @@ struct TrParams {
   const int* koffs; long c_gstride;       // weight gradient: blockIdx.z = group, K rows [koffs[z], koffs[z+1])
   const int* w_rows;                      // weight gradient: gather of W's K rows (dispatch permutation)
   int M, N, K, m_tiles, n_tiles;
+  int split_k; long split_stride;         // data gradient only: blockIdx.y = K-slice, partial sums to C + slice*split_stride (the consumer adds the slabs)
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const T
   const int n0 = nt * BN;
   int kb = 0, ke = p.K;
   if (A_KM && p.koffs) { kb = p.koffs[blockIdx.z]; ke = p.koffs[blockIdx.z + 1]; }
+  if (!A_KM && p.split_k > 1) { const int ks = p.K / p.split_k; kb = blockIdx.y * ks; ke = kb + ks; }
   const int nk = (ke - kb + BKT - 1) / BKT;
   const uint16_t* W = p.W + (long)expert * p.w_estride;
 
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const T
         const int r = kb + kt * BKT + P * 4 + kra;
         src = r < ke ? p.A + (long)r * p.lda + kn_col_a[q] : g_zero_row;
       } else {
-        src = a_src[q] + kt * BKT;
+        src = a_src[q] + kb + kt * BKT;
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + P * 1024), 16, 0, 0);
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const T
 
   // ---- epilogue: accumulators -> swizzled LDS tile -> coalesced 16-byte stores; one pass when the tile fits the operand ring, else one
   //      pass per wave-row group (64 rows), so a single-buffered (NS == 1) workgroup keeps its small LDS footprint
-  char* Cout = reinterpret_cast<char*>(p.C) + (long)blockIdx.z * p.c_gstride * ESZ;
+  char* Cout = reinterpret_cast<char*>(p.C) + ((long)blockIdx.z * p.c_gstride + (long)blockIdx.y * p.split_stride) * ESZ;
   const int rows_valid = row_end - row0;
   constexpr int EPASS = (BM * CROW <= NS * STAGE_BYTES) ? 1 : 2;
   constexpr int RP = BM / EPASS;
@@ -320,7 +322,7 @@ template <bool KM, bool OB, int BN, int NS>
 static int tr_launch(TrParams p, const ModeGemmDesc* d, hipStream_t s) {
   p.n_tiles = (d->N + BN - 1) / BN;
   p.m_tiles = (d->M + 127) / 128 + (d->expert_offsets ? d->num_experts : 0);
-  const dim3 grid(p.m_tiles * p.n_tiles, 1, (KM && d->k_group_offsets) ? d->num_k_groups : 1);
+  const dim3 grid(p.m_tiles * p.n_tiles, p.split_k, (KM && d->k_group_offsets) ? d->num_k_groups : 1);
   constexpr size_t lds = (size_t)NS * (128 * 64 * 2 + 64 * BN * 2);       // the output tile goes through the ring (one or two passes)
   auto kern = gemm_tr_kernel<KM, OB, BN, NS>;
   static bool attr_set = false;
@@ -339,7 +341,9 @@ int g_tr_cfg = 0;   // "gemm_tr_cfg" option: 0 auto, 1 = 128-wide NS2, 2 = 64-wi
 int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
   const bool a_km = (d->flags & MODE_GEMM_A_KM) != 0;
   if (!(d->flags & MODE_GEMM_W_KN)) return MODE_ERR_BAD_ARG;
-  if (d->dtype != MODE_BF16 || d->epilogue != MODE_EPI_NONE || d->split_k > 1 || d->a_rows) return MODE_ERR_UNSUPPORTED;
+  if (d->dtype != MODE_BF16 || d->epilogue != MODE_EPI_NONE || d->a_rows) return MODE_ERR_UNSUPPORTED;
+  const int split = d->split_k > 1 ? d->split_k : 1;
+  if (split > 1 && (a_km || d->K % (64 * split) != 0)) return MODE_ERR_UNSUPPORTED;      // K-slices: data gradient only
   if (d->N % 8 != 0 || d->N < 8 || d->lda % 8 != 0 || d->ldw % 8 != 0 || d->ldc % (d->out_dtype == MODE_BF16 ? 8 : 4) != 0) return MODE_ERR_UNSUPPORTED;
   if (a_km) {
     if (d->M % 8 != 0 || d->M < 8 || d->expert_offsets) return MODE_ERR_UNSUPPORTED;
@@ -353,6 +357,7 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.C = d->C; p.ldc = d->ldc; p.offsets = d->expert_offsets; p.E = d->num_experts;
   p.koffs = d->k_group_offsets; p.c_gstride = d->c_group_stride; p.w_rows = d->w_rows;
   p.M = d->M; p.N = d->N; p.K = d->K;
+  p.split_k = split; p.split_stride = d->split_stride;
   p.m_tiles = p.n_tiles = 0;
   // geometry: enough 128x128 workgroups to put two on every CU -> NS2 ring (they hide each other's fill latency); otherwise 128x64
   // tiles (twice the workgroups) with a 3-slot ring so one workgroup keeps two tiles in flight
@@ -360,7 +365,7 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
   const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * groups;
   int cfg = g_tr_cfg;
   // measured (profiles/): weight gradients (short K per tile, >= 3 workgroups per CU) are 4 % faster single-buffered; data gradients are not
-  if (cfg == 0) cfg = (a_km && t128 >= 768) ? 5 : ((t128 >= 512 || d->w_rows) ? 1 : 2);
+  if (cfg == 0) cfg = (a_km && t128 >= 768) ? 5 : ((t128 * split >= 448 || d->w_rows) ? 1 : 2);      // K-slices count as workgroups
   if (d->w_rows && (cfg == 2 || cfg == 3)) cfg = 1;
   const bool ob = d->out_dtype == MODE_BF16;
 #define MODE_TR_CFG(BN, NS)                                                                     \

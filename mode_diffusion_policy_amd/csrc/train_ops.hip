@@ -233,7 +233,8 @@ template <int NCH>   // NCH > 0: D == 256*NCH, chunk loops fully unrolled so tha
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* dy_a,
                                                           const float* dy_b, const float* __restrict__ G, const int* __restrict__ pos, int k,
                                                           int rows, int D, float eps, float* dx, int accumulate, float* __restrict__ dgp,
-                                                          float* __restrict__ dy_out, void* __restrict__ dx_lp, int lp_bf16) {
+                                                          float* __restrict__ dy_out, void* __restrict__ dx_lp, int lp_bf16, int g_splits,
+                                                          long g_split_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sx = reinterpret_cast<float*>(smem);                       // [4][D] x rows
   float* sd = sx + 4 * D;                                            // [4][D] dy rows
@@ -263,6 +264,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
         if (j < k) {
           const float4 t = *reinterpret_cast<const float4*>(G + prow[j] + d);
           dv.x += t.x; dv.y += t.y; dv.z += t.z; dv.w += t.w;
+          for (int z = 1; z < g_splits; ++z) {                       // K-slice slabs of the producing data-gradient GEMM
+            const float4 t2 = *reinterpret_cast<const float4*>(G + z * g_split_stride + prow[j] + d);
+            dv.x += t2.x; dv.y += t2.y; dv.z += t2.z; dv.w += t2.w;
+          }
         }
       }
       const float4 gv = *reinterpret_cast<const float4*>(g + d);
@@ -595,22 +600,31 @@ extern "C" int mode_swiglu_bwd(const void* P, const void* dHd, void* dP, int64_t
   return MODE_OK;
 }
 
-extern "C" int mode_rmsnorm_bwd(const float* x, const float* g, const float* dy_a, const float* dy_b, const float* G, const int32_t* pos, int k,
-                                int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* dx_lp,
-                                int lp_dtype, void* stream) {
-  if (!x || !g || !dx || rows < 0 || D <= 0 || (D & 3) || (k > 0 && (!G || !pos))) return MODE_ERR_BAD_ARG;
+namespace mode {
+// G may come as g_splits K-slice slabs (g_split_stride elements apart) of the data-gradient GEMM that produced it (dit_train.hip)
+int rmsnorm_bwd_launch(const float* x, const float* g, const float* dy_a, const float* dy_b, const float* G, int g_splits, long g_split_stride,
+                       const int32_t* pos, int k, int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* dx_lp,
+                       int lp_dtype, hipStream_t stream) {
+  if (!x || !g || !dx || rows < 0 || D <= 0 || (D & 3) || (k > 0 && (!G || !pos)) || g_splits < 1) return MODE_ERR_BAD_ARG;
   if (rows == 0) return MODE_OK;
   const size_t lds = (size_t)8 * D * 4;
   if (lds > 64 * 1024) return MODE_ERR_UNSUPPORTED;
   if (k > 8) return MODE_ERR_UNSUPPORTED;
   if (D == 1024)
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, dim3((rows + 3) / 4), dim3(256), lds, (hipStream_t)stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx,
-                       accumulate, dg_partial, dy_out, dx_lp, lp_dtype == MODE_BF16 ? 1 : 0);
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, dim3((rows + 3) / 4), dim3(256), lds, stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx,
+                       accumulate, dg_partial, dy_out, dx_lp, lp_dtype == MODE_BF16 ? 1 : 0, g_splits, g_split_stride);
   else
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel<0>, dim3((rows + 3) / 4), dim3(256), lds, (hipStream_t)stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx,
-                       accumulate, dg_partial, dy_out, dx_lp, lp_dtype == MODE_BF16 ? 1 : 0);
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<0>, dim3((rows + 3) / 4), dim3(256), lds, stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx,
+                       accumulate, dg_partial, dy_out, dx_lp, lp_dtype == MODE_BF16 ? 1 : 0, g_splits, g_split_stride);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
+}
+}  // namespace mode
+
+extern "C" int mode_rmsnorm_bwd(const float* x, const float* g, const float* dy_a, const float* dy_b, const float* G, const int32_t* pos, int k,
+                                int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* dx_lp,
+                                int lp_dtype, void* stream) {
+  return mode::rmsnorm_bwd_launch(x, g, dy_a, dy_b, G, 1, 0, pos, k, rows, D, eps, dx, accumulate, dg_partial, dy_out, dx_lp, lp_dtype, (hipStream_t)stream);
 }
 
 extern "C" int mode_moe_combine_bwd(const float* dy, const void* Y, int y_dtype, const int32_t* pos, const float* posw, int N, int D, int k,

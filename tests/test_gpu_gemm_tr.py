@@ -55,6 +55,33 @@ def test_dgrad_grouped_by_expert(counts):
         o += c
 
 
+@pytest.mark.parametrize("split", [2, 4])
+@pytest.mark.parametrize("counts,K,N", [([896, 896, 896, 896], 2048, 256), ([0, 1000, 3, 517], 512, 384), ([37], 256, 64)])
+def test_dgrad_k_slices(counts, K, N, split):
+    """Data gradient in K-slices (split_k: fp32 partial slabs split_stride apart, added by the consumer — the training backward's dU): the slabs
+    sum to the unsplit product; weight-gradient layouts refuse the option."""
+    E = len(counts); M = sum(counts)
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = torch.randn(E, K, N, generator=g).to(torch.bfloat16).cuda()
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).cuda()
+    Cc = torch.full((split, M, N), float("nan"), device="cuda")
+    d = _desc(out_dtype=L.MODE_F32, M=M, N=N, K=K, A=p(A), lda=K, W=p(W), ldw=N, w_expert_stride=K * N, C=p(Cc), ldc=N,
+              expert_offsets=p(off), num_experts=E, flags=L.GEMM_W_KN, split_k=split, split_stride=M * N)
+    L.check(L.load().mode_gemm(C.byref(d), stream()), "dgrad slices")
+    tot = Cc.sum(0)
+    o = 0
+    for e, c in enumerate(counts):
+        if c:
+            assert rel(tot[o:o + c], A[o:o + c].float() @ W[e].float()) < 1e-5, e
+            ks = K // split
+            assert rel(Cc[1, o:o + c], A[o:o + c, ks:2 * ks].float() @ W[e, ks:2 * ks].float()) < 1e-5      # slice 1 is exactly its K range
+        o += c
+    d2 = _desc(out_dtype=L.MODE_F32, M=N, N=N, K=M, A=p(A), lda=K, W=p(A), ldw=K, C=p(Cc), ldc=N, flags=L.GEMM_W_KN | L.GEMM_A_KM, split_k=2,
+               split_stride=N * N)
+    assert L.load().mode_gemm(C.byref(d2), stream()) != 0
+
+
 @pytest.mark.parametrize("R,M,N", [(1792, 1024, 1024), (1792, 3072, 1024), (100, 64, 64), (77, 136, 200), (64, 128, 128)])
 def test_wgrad_plain(R, M, N):
     g = torch.Generator().manual_seed(R + M)
