@@ -22,3 +22,34 @@ for B in (128, 32, 1):
             bad += 1
     print(f"B={B}: {n} replays, {bad} mismatching, finite={bool(torch.isfinite(ref).all())}", flush=True)
     assert bad == 0
+
+# training: the same step (same host seed -> same sigma draw, multinomial routing and dropout seed) must give bit-identical gradients
+import math  # noqa: E402
+from mode_diffusion_policy_amd.utils import rand_log_logistic  # noqa: E402
+
+m = den.inner_model
+den.train()
+B = 128
+g = torch.Generator().manual_seed(1)
+img = torch.randn(B, 2, 2048, generator=g).to(dev); goal = torch.randn(B, 1, 512, generator=g).to(dev)
+acts = torch.randn(B, 10, 7, generator=g).to(dev); noise = torch.randn(B, 10, 7, generator=g).to(dev)
+
+
+def grads():
+    torch.manual_seed(123)
+    sg = rand_log_logistic((B,), loc=math.log(0.5), scale=0.5, min_value=1e-3, max_value=80.0, device=dev)
+    loss, _ = den.loss({"state_images": img}, acts, goal, noise, sg)
+    loss.backward()
+    torch.cuda.synchronize()
+    return m.engine.arena.grad.clone(), float(loss)
+
+
+ref_g, ref_l = grads()
+bad = 0
+nt = max(1, n // 20)
+for i in range(nt):
+    gi, li = grads()
+    if not torch.equal(gi, ref_g) or li != ref_l:
+        bad += 1
+print(f"training step: {nt} repeats, {bad} with differing gradients, |g| = {float(ref_g.norm()):.4f}", flush=True)
+assert bad == 0
