@@ -48,6 +48,9 @@ typedef enum ModeEpilogue {
 } ModeEpilogue;
 
 int mode_hip_version(void);
+/* sizeof() of an ABI struct by name ("ModeGemmDesc", "ModeHeadDesc", ...), 0 for an unknown name: lets a binding verify its mirror of the
+ * structs against the library it actually loaded (tests/test_boundary.py does, for every struct of this header). */
+size_t mode_hip_sizeof(const char* struct_name);
 const char* mode_hip_status_string(int status);
 /* Tuning knobs (process-wide).  "gemm_cfg": bf16 GEMM tile geometry, 0 = auto (default), 1 = 128x128 ring-2, 2 = 128x128 ring-3,
  * 3 = 256x128 ring-3, 4 = 128x64 ring-3, 5 = 128x64 ring-4, 6 = 128x128 single-buffered (3 workgroups/CU), 7 = 128x64 single-buffered,

@@ -112,7 +112,7 @@ class ModeForwardArgs(C.Structure):
     _fields_ = [("B", c_i32), ("dtype", c_i32), ("emb_t", c_vp), ("emb_row_stride", c_i64), ("cond", c_vp),
                 ("cond_row_stride", c_i64), ("meta", c_vp), ("meta_layer_stride", c_i64), ("goal_e", c_vp), ("img_e", c_vp),
                 ("actions", c_vp), ("c_in", c_vp), ("c_in_stride", c_i64), ("scal", c_vp), ("scal_stride", c_i64),
-                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp), ("u_ss", c_vp), ("u_ss_n", c_i32), ("u_gain", c_vp)]
+                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp)]
 
 
 P = C.POINTER
@@ -121,6 +121,7 @@ PROTOTYPES = {
     "mode_hip_version": (C.c_int, []),
     "mode_hip_status_string": (C.c_char_p, [C.c_int]),
     "mode_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "mode_hip_sizeof": (c_sz, [C.c_char_p]),
     "mode_gemm": (C.c_int, [P(ModeGemmDesc), c_vp]),
     "mode_rmsnorm_cond_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_f32, c_vp, c_vp, C.c_int, c_vp]),
     "mode_attn_block_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32, C.c_uint32, c_f32, c_vp]),

@@ -80,6 +80,16 @@ using namespace mode;
 
 extern "C" int mode_hip_version(void) { return MODE_HIP_ABI_VERSION; }
 
+extern "C" size_t mode_hip_sizeof(const char* n) {
+  if (!n) return 0;
+#define MODE_SZ(T) if (!strcmp(n, #T)) return sizeof(T);
+  MODE_SZ(ModeGemmDesc) MODE_SZ(ModeEmbedDesc) MODE_SZ(ModeHeadDesc) MODE_SZ(ModeGroupedMlpDesc) MODE_SZ(ModeDims) MODE_SZ(ModeLayerWeights)
+  MODE_SZ(ModeModelWeights) MODE_SZ(ModeMetaLayout) MODE_SZ(ModeForwardArgs) MODE_SZ(ModeStashLayout) MODE_SZ(ModeTrainArgs) MODE_SZ(ModeLayerGrads)
+  MODE_SZ(ModeModelGrads) MODE_SZ(ModeLayerWeightsT) MODE_SZ(ModeModelWeightsT)
+#undef MODE_SZ
+  return 0;
+}
+
 extern "C" const char* mode_hip_status_string(int status) {
   switch (status) {
     case MODE_OK: return "ok";

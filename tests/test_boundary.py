@@ -54,9 +54,15 @@ def test_mode_hip_opts_env(monkeypatch):
 
 
 def test_ctypes_struct_sizes_match_header_layout():
-    """Host-only ABI sanity: layout queries round-trip through the structs."""
+    """Host-only ABI sanity: every ctypes mirror has the size the loaded library compiled the struct with; layout queries round-trip."""
     import ctypes as C
     lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "mode_hip.h")).read()
+    names = set(re.findall(r"typedef struct (Mode\w+)", hdr))
+    assert names and lib.mode_hip_sizeof(b"NoSuchStruct") == 0
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} has no ctypes mirror in _lib.py"
+        assert lib.mode_hip_sizeof(n.encode()) == C.sizeof(getattr(L, n)), n
     ml = L.ModeMetaLayout()
     assert lib.mode_moe_meta_layout(1792, 4, 2, C.byref(ml)) == 0
     assert ml.perm % 4 == 0 and ml.total_words >= 3 * 3584 + 9
