@@ -286,3 +286,16 @@ def test_noise_level_densities_reproduce_reference_rng_stream():
     assert utils.make_sample_density("split-lognormal", loc=-1.0, scale_1=0.5, scale_2=1.5)(shape=(4,)).shape == (4,)
     with pytest.raises(ValueError, match="Unknown sample density type"):
         utils.make_sample_density("nope")
+
+
+def test_binding_constants_match_header():
+    """The enum / flag values the ctypes binding hard-codes are the ones include/mode_hip.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "mode_hip.h")).read()
+    vals = {k: int(v) for k, v in re.findall(r"\b(MODE_[A-Z0-9_]+)\s*=\s*(-?\d+)", hdr)}
+    vals.update({k: int(v) for k, v in re.findall(r"#define\s+(MODE_[A-Z0-9_]+)\s+(-?\d+)\b", hdr)})
+    assert vals["MODE_BF16"] == L.MODE_BF16 and vals["MODE_F32"] == L.MODE_F32
+    for name in ("NONE", "BIAS", "BIAS_GELU", "RESIDUAL", "SWIGLU", "RESIDUAL_NORM"):
+        assert vals[f"MODE_EPI_{name}"] == getattr(L, f"EPI_{name}"), name
+    for name in ("SKINNY_OK", "W_KN", "A_KM"):
+        assert vals[f"MODE_GEMM_{name}"] == getattr(L, f"GEMM_{name}"), name
+    assert vals["MODE_HIP_ABI_VERSION"] == L.ABI_VERSION
