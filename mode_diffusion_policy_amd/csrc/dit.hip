@@ -16,6 +16,10 @@ struct MetaBatch {
 int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N, int E, int k, hipStream_t s);
 
 extern int g_gemm_cfg;
+extern int g_gemm_pp;
+extern int g_pp_flags;
+extern int g_gemm_pp_min_tiles;
+extern unsigned long long g_pp_trace;
 extern int g_tr_cfg;
 extern int g_gemm_group_m;
 extern int g_attn_bwd_stop;
@@ -103,6 +107,11 @@ extern "C" const char* mode_hip_status_string(int status) {
 extern "C" int mode_set_option(const char* key, int value) {
   if (!key) return MODE_ERR_BAD_ARG;
   if (!strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return MODE_OK; }
+  if (!strcmp(key, "gemm_pp")) { g_gemm_pp = value != 0; return MODE_OK; }
+  if (!strcmp(key, "pp_flags")) { g_pp_flags = value; return MODE_OK; }
+  if (!strcmp(key, "gemm_pp_min_tiles")) { g_gemm_pp_min_tiles = value; return MODE_OK; }
+  if (!strcmp(key, "pp_trace_lo")) { g_pp_trace = (g_pp_trace & 0xffffffff00000000ull) | (unsigned)value; return MODE_OK; }   // profiling aid:
+  if (!strcmp(key, "pp_trace_hi")) { g_pp_trace = (g_pp_trace & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); return MODE_OK; }   // device buffer of cycle stamps (gemm_bf16_pp.hip)
   if (!strcmp(key, "gemm_tr_cfg")) { g_tr_cfg = value; return MODE_OK; }
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return MODE_OK; }
   if (!strcmp(key, "attn_bwd_stop")) { g_attn_bwd_stop = value; return MODE_OK; }

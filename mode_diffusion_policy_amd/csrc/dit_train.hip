@@ -142,7 +142,7 @@ extern "C" int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeigh
     ModeGemmDesc g = gdesc(dt, MODE_EPI_BIAS, dt, N, 3 * D, D, S + sl.h1, D, lw.wqkv, D, S + sl.qkv, 3 * D);
     g.bias = lw.bqkv;
     if ((rc = mode_gemm(&g, stream))) return rc;
-    if ((rc = mode_attn_block_fwd(S + sl.qkv, lw.qn_g, lw.kn_g, S + sl.yattn, dt, B, T, d.H, D / d.H, d.eps, a->seed + 2 * l, a->attn_pdrop, stream)))
+    if ((rc = mode_attn_block_fwd(S + sl.qkv, lw.qn_g, lw.kn_g, S + sl.yattn, dt, B, T, d.H, D / d.H, d.eps, mode_stream_seed(a->seed, 2 * l), a->attn_pdrop, stream)))
       return rc;
     g = gdesc(dt, MODE_EPI_RESIDUAL, MODE_F32, N, D, D, S + sl.yattn, D, lw.wo, D, x1, D);
     g.resid = x0; g.ldr = D;
@@ -152,7 +152,7 @@ extern "C" int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeigh
     g.bias = lw.b1; g.w_expert_stride = 8L * D * D; g.bias_expert_stride = 8L * D;
     g.a_rows = meta + ml.perm; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
     if ((rc = mode_gemm(&g, stream))) return rc;
-    if ((rc = mode_swiglu_fwd(S + sl.P, S + sl.Hd, NK, 4 * D, dt, a->seed + 2 * l + 1, a->mlp_pdrop, stream))) return rc;
+    if ((rc = mode_swiglu_fwd(S + sl.P, S + sl.Hd, NK, 4 * D, dt, mode_stream_seed(a->seed, 2 * l + 1), a->mlp_pdrop, stream))) return rc;
     g = gdesc(dt, MODE_EPI_NONE, dt, NK, D, 4 * D, S + sl.Hd, 4 * D, lw.w2, 4 * D, S + sl.Y, D);
     g.w_expert_stride = 4L * D * D; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
     if ((rc = mode_gemm(&g, stream))) return rc;
@@ -273,9 +273,9 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     }
     // (3) SwishGLU (+ dropout) backward, bias gradient
     if (dt == MODE_BF16 && D % 2 == 0 && E <= 16) {                  // one pass: dP and the per-expert column sums of dP
-      if ((rc = mode_swiglu_bwd_bias(S + sl.P, dHd, dP, NK, 4 * D, dt, a->seed + 2 * l + 1, a->mlp_pdrop, offsets, E, lg.b1, csw, cswb, stream))) return rc;
+      if ((rc = mode_swiglu_bwd_bias(S + sl.P, dHd, dP, NK, 4 * D, dt, mode_stream_seed(a->seed, 2 * l + 1), a->mlp_pdrop, offsets, E, lg.b1, csw, cswb, stream))) return rc;
     } else {
-      if ((rc = mode_swiglu_bwd(S + sl.P, dHd, dP, NK, 4 * D, dt, a->seed + 2 * l + 1, a->mlp_pdrop, stream))) return rc;
+      if ((rc = mode_swiglu_bwd(S + sl.P, dHd, dP, NK, 4 * D, dt, mode_stream_seed(a->seed, 2 * l + 1), a->mlp_pdrop, stream))) return rc;
       if ((rc = colsum(dP, 8 * D, NK, 8 * D, dt, offsets, 0, E, lg.b1, 0))) return rc;
     }
     // (4) expert up-projection: dU (sorted rows, fp32) = dP W1 ; dW1_e = dP_e^T U_e
@@ -326,7 +326,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       if ((rc = mode_gemm(&g, stream))) return rc;
     }
     // (7) attention backward
-    if ((rc = mode_attn_block_bwd(S + sl.qkv, lw.qn_g, lw.kn_g, dyattn, dqkv, apq_l, apk_l, dt, B, T, d.H, hd, d.eps, a->seed + 2 * l, a->attn_pdrop, stream)))
+    if ((rc = mode_attn_block_bwd(S + sl.qkv, lw.qn_g, lw.kn_g, dyattn, dqkv, apq_l, apk_l, dt, B, T, d.H, hd, d.eps, mode_stream_seed(a->seed, 2 * l), a->attn_pdrop, stream)))
       return rc;
     // (8) QKV projection: dh1 = dqkv Wqkv ; dWqkv = dqkv^T h1 ; db = colsum(dqkv)
     if (tr) {

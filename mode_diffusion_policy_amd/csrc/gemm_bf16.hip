@@ -399,12 +399,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
 // ------------------------------------------------------------------------------------------------------------ host side
 // geometry ids (also the values of the "gemm_cfg" option; 0 = auto)
 enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x128_NS3 = 2, CFG_256x128_NS3 = 3, CFG_128x64_NS3 = 4, CFG_128x64_NS4 = 5,
-       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10, CFG_256x256_W16 = 11, CFG_P256 = 12, CFG_128x128_NS1_4WG = 13, CFG_64x64_NS3 = 14, CFG_64x64_NS2 = 15 };
+       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10, CFG_256x256_W16 = 11, CFG_P256 = 12, CFG_128x128_NS1_4WG = 13, CFG_64x64_NS3 = 14, CFG_64x64_NS2 = 15, CFG_PP256 = 16, CFG_PP224 = 17 };
+int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p, int rows224, hipStream_t s);   // gemm_bf16_pp.hip: persistent ping-pong 8-phase kernel
 int gemm_bf16_p256_launch(const ModeGemmDesc* d, hipStream_t s);   // gemm_bf16_p256.hip: persistent 256x256 with cross-tile operand prefetch
 int gemm_bf16_skinny_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_skinny.hip: weight streamer for a handful of rows
 int g_gemm_cfg = CFG_AUTO;
 int g_gemm_setprio = 1;
 int g_gemm_skinny_rows = 32;   // measured (scripts/rollout_batch_probe.py): chunk latency B=1 9.4 -> 7.35 ms, B=2 8.7 -> 8.3 ms; from ~3 environments on the tiled kernel (64x64 tiles) is as fast or faster
+int g_gemm_pp_min_tiles = 200;   // "gemm_pp_min_tiles" option
+int g_pp_flags = 0;       // "pp_flags" option (GemmParams::pp_flags)
+int g_gemm_pp = 1;        // "gemm_pp" option: 1 = large problems go to the persistent ping-pong kernel (gemm_bf16_pp.hip), 0 = 128x128 family only
 int g_gemm_group_m = 0;   // "gemm_group_m" option: m-tiles per rasterisation group (0 = default 8; >= m_tiles = n-major partition over the XCDs)
 
 template <int BM, int BN, int WM, int WN, int NS, int EPI, bool OUT_BF16, int LR = 0>
@@ -458,6 +462,14 @@ static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipSt
 //                             <= 1 workgroup per CU nothing else hides the fill latency)                 [c_proj, expert down-proj, small batches]
 static int pick_cfg(const ModeGemmDesc* d) {
   const long rows = d->M;
+  // persistent ping-pong kernel (224 x 256 tiles, one workgroup per CU): whenever its tiles cover most of the chip - the expert up-projection from
+  // B = 64 on (256 / 512 tiles at B = 64 / 128) and the K-sliced down-projection at B = 128 (16 x 4 tiles x 4 slices = 256).  Unsupported shapes
+  // come back from its launcher and fall through to the 128x128 family below.
+  if (g_gemm_pp && (d->epilogue == MODE_EPI_SWIGLU || d->epilogue == MODE_EPI_NONE || d->epilogue == MODE_EPI_BIAS)) {
+    const int nout = d->epilogue == MODE_EPI_SWIGLU ? 128 : 256;
+    const long tpp = ((rows + 223) / 224) * (d->N / nout) * (d->split_k > 1 ? d->split_k : 1);
+    if (d->N % nout == 0 && tpp >= g_gemm_pp_min_tiles) return CFG_PP224;
+  }
   const int nout128 = (d->epilogue == MODE_EPI_SWIGLU) ? 64 : 128;
   const long t128 = ((rows + 127) / 128) * ((d->N + nout128 - 1) / nout128);
   const long t64 = ((rows + 127) / 128) * ((d->N + 63) / 64);
@@ -504,12 +516,19 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.C2 = (uint16_t*)d->C2; p.ldc2 = d->ldc2; p.gain = d->gain; p.ss_out = d->row_ss_out;
   p.ss_in = d->row_ss; p.ss_n = d->row_ss_n; p.ss_eps = d->row_eps;
   p.setprio = g_gemm_setprio;
+  p.pp_flags = g_pp_flags;
   if (p.koffs && (d->num_k_groups <= 0 || p.split_k > 1 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
   if (g_gemm_cfg == CFG_AUTO && d->M <= g_gemm_skinny_rows) {
     const int rc = gemm_bf16_skinny_launch(d, p, s);
     if (rc != MODE_ERR_UNSUPPORTED) return rc;
   }
-  const int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d);
+  int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d);
+  if (cfg == CFG_PP256 || cfg == CFG_PP224) {
+    const int rc = gemm_bf16_pp_launch(d, p, cfg == CFG_PP224, s);
+    if (rc != MODE_ERR_UNSUPPORTED) return rc;
+    const int keep = g_gemm_pp;                                    // shapes / epilogues the ping-pong kernel does not take
+    g_gemm_pp = 0; cfg = pick_cfg(d); g_gemm_pp = keep;
+  }
   if (cfg == CFG_P256) {
     if (p.split_k > 1 || p.koffs || p.ss_in || d->epilogue == MODE_EPI_RESIDUAL_NORM) return MODE_ERR_UNSUPPORTED;
     return gemm_bf16_p256_launch(d, s);

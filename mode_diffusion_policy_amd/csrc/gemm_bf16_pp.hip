@@ -1,0 +1,577 @@
+// Persistent "ping-pong" bf16 MFMA GEMM for gfx950, large-M forward shapes:  C[M,N] = epilogue(A[M,K] @ W[N,K]^T), plain / row-gathered /
+// grouped (MoE) / K-sliced.  This is the kernel of the two expert projections at B = 128 (85 % of the denoiser's FLOPs).
+//
+// Why a second tiled kernel: the 128x128 one-barrier-per-K-step loop of gemm_bf16.hip tops out at ~840 TF/s (33 % of the bf16 MFMA peak): a
+// workgroup's fill / LDS-read / MFMA phases serialise and a 128x128x64 step moves 32 KiB through the vector-memory path per 512 MFMA cycles.
+// This kernel changes the structure, not the tuning:
+//   * (128 + 32*FM1) x 256 output tile (FM1 = 4: 256 rows, FM1 = 3: 224 rows - 3584 sorted rows = 16 x 224 gives 512 tiles = exactly two per CU),
+//     BK = 64, 8 wave64 as 2 (M) x 4 (N): half the L2->LDS bytes per flop of the 128x128 tile.
+//   * The operand tile of a K-step lives in LDS as four 16-KiB HALF-tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255), two K-steps
+//     resident (128 KiB).  A wave's output is the 2 x 2 grid of quadrants {A half} x {W half}; one K-step = four PHASES of 16 MFMAs
+//     (v_mfma_f32_16x16x32_bf16), each phase: {ds_read the operand fragments the phase needs | issue ONE half-tile of global_load_lds for a
+//     K-step 1.5 steps ahead} -> s_barrier -> MFMAs -> s_barrier.  A half-tile is re-filled two phases after its last fragment read.
+//   * Counted waits only: `s_waitcnt vmcnt(6)` once per K-step (three half-tiles stay in flight across every barrier), never vmcnt(0);
+//     a staged half-tile is read one phase after the wait that retires it (the wait sits before a barrier every reader passes).
+//   * The two wave rows run STAGGERED by one barrier: while waves 0-3 issue their 16 MFMAs, waves 4-7 (their SIMD partners) issue fragment
+//     reads and DMA, and vice versa - the matrix pipe of every SIMD always has one wave feeding it (s_setprio around the MFMA cluster).
+//   * PERSISTENT: one workgroup per CU walks its output tiles (consecutive n-tiles of one m-tile, so the gathered A rows and their per-lane
+//     DMA sources never change) and the operand stream never stops: while the last K-steps of a tile run, the first two K-steps of the NEXT
+//     tile are already landing.  K = 1024 is only 16 K-steps, so the first-fill latency of a tile would otherwise cost ~20 % of it.
+//   * Weight rows are assigned to LDS rows through a permutation (free: the DMA source address is per lane) such that, with the swapped
+//     MFMA operands, a lane ends up with EIGHT consecutive output columns of one token row: bias / SwiGLU run in registers and the tile is
+//     stored straight from registers, 16 bytes per lane - no LDS round trip, no barrier in the epilogue.
+//   * SwiGLU: W half 0 = the 128 "value" rows, W half 1 = the matching 128 "gate" rows (rows n and N+n, the reference's tensor_split(2),
+//     modedit.py:89) - quadrant (a, 0) and (a, 1) of a wave hold value and gate of the same outputs.
+//   * XCD-aware tile order: an XCD's 32 workgroups cover 8 m-tiles x 8 n-tiles, so the 4-MiB L2 sees each operand K-slice once.
+//
+// Numerics: every output element is the same k-ordered fp32 MFMA accumulation chain and the same epilogue expression as gemm_bf16.hip, so
+// results are BIT-IDENTICAL to the 128x128 kernels (the batch-slice consistency tests of the sampler rely on it).
+#include "mode_common.h"
+#include <type_traits>
+
+namespace mode {
+
+namespace pp {
+constexpr int BKK = 64;
+constexpr int HALF_BYTES = 128 * BKK * 2;                  // one 128-row half-tile: 16 KiB
+constexpr int LDS_A = 0;                                   // A[t][h] at (t*2+h) * 16 KiB
+constexpr int LDS_B = 4 * HALF_BYTES;                      // W[t][h] at 64 KiB + (t*2+h) * 16 KiB
+constexpr int LDS_BIAS = 8 * HALF_BYTES;                   // 8 x 1 KiB: one bias slot per wave (each wave DMAs and reads its own copy)
+constexpr int LDS_NRM = LDS_BIAS + 8 * 1024;               // 2 x 256 floats: inverse row norms of the fused ln_2 (double-buffered per restart)
+constexpr int LDS_TOTAL = LDS_NRM + 2 * 1024;
+constexpr int GM = 8;                                      // m-tiles per rasterisation band
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ void lds_read128(bf16x8& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int BASE, int STRIDE, int CNT, int I = 0>
+__device__ __forceinline__ void lds_read_seq(bf16x8* dst, uint32_t addr) {
+  if constexpr (I < CNT) {
+    lds_read128<BASE + I * STRIDE>(dst[I], addr);
+    lds_read_seq<BASE, STRIDE, CNT, I + 1>(dst, addr);
+  }
+}
+__device__ __forceinline__ void lds_read_f4(float4& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_read_f1(float& dst, uint32_t addr) {
+  asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+template <int V>
+using IC = std::integral_constant<int, V>;
+}  // namespace pp
+
+template <int EPI, bool OUT_BF16, int FM1>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, unsigned long long* __restrict__ trace) {
+  using namespace pp;
+  constexpr int BM = 128 + 32 * FM1;                         // rows of an output tile: half 0 = 2 x 64, half 1 = 2 x 16*FM1
+  constexpr bool SWI = EPI == MODE_EPI_SWIGLU;
+  constexpr bool HAS_BIAS = EPI == MODE_EPI_BIAS || EPI == MODE_EPI_BIAS_GELU || SWI;
+  constexpr int NOUT = SWI ? 128 : 256;                      // output columns of a tile
+  constexpr int ESZ = OUT_BF16 ? 2 : 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---------------------------------------------------------------------------------------------------- tile space (all scalar)
+  // grouped (MoE): rows are sorted by expert; expert e owns sorted rows [o[e], o[e+1]) and ceil(count / BM) m-tiles (device-side offsets).
+  int o[9];
+  int m_real;
+  if (p.offsets) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) o[e] = p.offsets[min(e, p.E)];
+    m_real = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (e < p.E) m_real += (o[e + 1] - o[e] + BM - 1) / BM;
+  } else {
+    m_real = (p.M + BM - 1) / BM;
+  }
+  const int S = p.split_k, n_tiles = p.n_tiles;
+  const int T = m_real * n_tiles * S;
+  const int G = gridDim.x;
+  const int R = (T + G - 1) / G;                               // tiles per workgroup
+  if (R == 0) return;
+  const int RN = (n_tiles % R == 0) ? R : 1;                   // n-run: a workgroup's consecutive tiles share the m-tile when R | n_tiles
+  const int nwg = (T + R - 1) / R;                             // workgroups that get work
+  if ((int)blockIdx.x >= nwg) return;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  int L = wg * R;
+  const int Lend = min(T, L + R);
+  const int nk = p.K / BKK / S;                                // K-steps per slice (even, >= 2: checked by the launcher)
+
+  struct Tile { int m, n, slice, row0, row_end, expert; };
+  auto map_tile = [&](int l, Tile& t) {
+    const int per_band = GM * n_tiles * S;
+    const int band = l / per_band, first_m = band * GM;
+    const int gsz = min(GM, m_real - first_m);
+    const int rem = l - band * per_band;
+    const int per_slice = gsz * n_tiles;
+    t.slice = rem / per_slice;
+    const int q = rem - t.slice * per_slice;
+    const int run = gsz * RN;
+    const int n_hi = q / run, r2 = q - n_hi * run;
+    t.m = first_m + r2 / RN;
+    t.n = n_hi * RN + r2 % RN;
+    t.expert = 0;
+    if (p.offsets) {
+      int tt = t.m;
+      bool found = false;
+      t.row0 = 0; t.row_end = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (!found && e < p.E) {
+          const int nt_e = (o[e + 1] - o[e] + BM - 1) / BM;
+          if (tt < nt_e) { t.row0 = o[e] + tt * BM; t.row_end = min(o[e + 1], t.row0 + BM); t.expert = e; found = true; }
+          else tt -= nt_e;
+        }
+      }
+    } else {
+      t.row0 = t.m * BM; t.row_end = min(p.M, t.row0 + BM);
+    }
+  };
+  // byte address of a tile's first weight row at K-offset 0 of its slice; half 1 of the W tile sits `w_half` bytes further
+  auto w_tile_base = [&](const Tile& t) -> const char* {
+    return reinterpret_cast<const char*>(p.W) + ((long)t.expert * p.w_estride + (long)t.n * NOUT * p.ldw + (long)t.slice * nk * BKK) * 2;
+  };
+  const long w_half = (long)(SWI ? p.N : 128) * p.ldw * 2;
+
+  // ---------------------------------------------------------------------------------------------------- per-lane constants
+  // DMA: one global_load_lds_dwordx4 fills a 1-KiB piece = 8 rows x 128 B; lane i -> row i>>3, physical 16-B chunk i&7 which holds the
+  // LOGICAL chunk (i&7)^(i>>3) (XOR swizzle on the source address; linear destination; same XOR on the fragment reads).  A half-tile is
+  // 16 pieces: wave w fills pieces 2w and 2w+1.
+  const int r8 = lane >> 3, lchunk = (lane & 7) ^ r8;
+  uint32_t b_off[2];                                           // byte offsets from a W half-tile base (tile independent)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int lrow = (wave * 2 + q) * 8 + r8;                  // LDS row of the half-tile, 0..127
+    // LDS row blk*32 + j*16 + q4*4 + r  holds weight row  blk*32 + q4*8 + j*4 + r : a lane's 2 fragments x 4 accumulator rows = 8 consecutive columns
+    const int blk = lrow >> 5, rho = lrow & 31;
+    const int col = blk * 32 + ((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3);
+    b_off[q] = (uint32_t)(((long)col * p.ldw + lchunk * 8) * 2);
+  }
+  // fragment reads: lane -> row (l&15) of a 16-row fragment, 16-B chunk (l>>4) [+4 for the second k32 half], chunk XOR (row & 7)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int c0 = (fq ^ (fr & 7)) * 16;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  uint32_t a_addr[2][2], b_addr[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    const int c = kh ? (c0 ^ 64) : c0;
+    a_addr[0][kh] = lds0 + LDS_A + (wr * 64 + fr) * 128 + c;
+    a_addr[1][kh] = lds0 + LDS_A + (wr * 16 * FM1 + fr) * 128 + c;
+    b_addr[kh] = lds0 + LDS_B + (wc * 32 + fr) * 128 + c;
+  }
+
+  bf16x8 A_[8], Bf[2][4];                                      // A fragments [k-half*4 + i], W fragments [half][k-half*2 + j]
+  f32x4 acc[2][2][4][2];                                       // [A half][W half][i][j]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bool fresh = true;
+  const bool ab_mma = p.pp_flags & 2, ab_rd = p.pp_flags & 4, ab_dma = p.pp_flags & 8, ab_st = p.pp_flags & 16, ab_act = p.pp_flags & 32;      // timing ablations (results are garbage)
+  auto rdA = [&](auto T_, auto H_) {
+    if (ab_rd) return;
+    constexpr int t = decltype(T_)::value, h = decltype(H_)::value;
+    constexpr int base = (t * 2 + h) * HALF_BYTES, nf = h ? FM1 : 4;
+    lds_read_seq<base, 2048, nf>(&A_[0], a_addr[h][0]);
+    lds_read_seq<base, 2048, nf>(&A_[4], a_addr[h][1]);
+  };
+  auto rdB = [&](auto T_, auto H_) {
+    if (ab_rd) return;
+    constexpr int t = decltype(T_)::value, h = decltype(H_)::value;
+    constexpr int base = (t * 2 + h) * HALF_BYTES;
+    lds_read_seq<base, 2048, 2>(&Bf[h][0], b_addr[0]);
+    lds_read_seq<base, 2048, 2>(&Bf[h][2], b_addr[1]);
+  };
+  auto mma = [&](auto AH_, auto BH_) {
+    constexpr int ah = decltype(AH_)::value, bh = decltype(BH_)::value, nf = ah ? FM1 : 4;
+    if (ab_mma) return;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < nf; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)                              // swapped operands: D[weight row][token]
+          acc[ah][bh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[bh][kh * 2 + j], A_[kh * 4 + i], acc[ah][bh][i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto stage = [&](auto OP_, auto T_, auto H_, const char* g, uint32_t o0, uint32_t o1) {
+    constexpr int op = decltype(OP_)::value, t = decltype(T_)::value, h = decltype(H_)::value;
+    constexpr int base = (op ? LDS_B : LDS_A) + (t * 2 + h) * HALF_BYTES;
+    if (ab_dma && !fresh) return;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + o0),
+                                     (__attribute__((address_space(3))) void*)(smem + base + (wave * 2 + 0) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + o1),
+                                     (__attribute__((address_space(3))) void*)(smem + base + (wave * 2 + 1) * 1024), 16, 0, 0);
+  };
+  // A half 1 of the 224-row tile has 96 rows = 12 pieces: waves 6 and 7 own pieces 12-15 and stage nothing (6 % fewer DMA bytes; the loop is
+  // DMA-rate bound).  Their counted waits are unaffected: the A-half-1 stages (phases 1 / 5) are never among the newest six at a wait.
+  const bool stage_a1 = FM1 == 4 || wave < 6;
+  auto stamp = [&](int slot) {                                  // profiling aid: per-wave cycle stamps ("pp_trace" option), 8 slots per wave
+    if (trace && lane == 0) trace[((long)blockIdx.x * 8 + wave) * 8 + slot] = __builtin_readcyclecounter();
+  };
+  constexpr IC<0> _0{};
+  constexpr IC<1> _1{};
+#define PP_SB() __builtin_amdgcn_sched_barrier(0)
+#define PP_BAR() __builtin_amdgcn_s_barrier()
+  // one phase's compute part: barrier -> (fragments landed) -> 16 MFMAs -> barrier
+#define PP_COMPUTE(AH, BH)        \
+  PP_BAR();                       \
+  wait_lgkmcnt<0>();              \
+  PP_SB();                        \
+  mma(AH, BH);                    \
+  PP_SB();                        \
+  PP_BAR();                       \
+  PP_SB();
+
+  stamp(0);
+  bool staggered = false;                                      // true while wave row 1 runs one barrier behind wave row 0
+
+  Tile cur, nxt;
+  map_tile(L, cur);
+  int nrm_par = 0;
+  uint32_t a_off[2][2] = {{0, 0}, {0, 0}};                     // byte offsets of this lane's A rows (gathered) from p.A, per half / piece
+  const char* Ak = nullptr;
+  const char* Wc = nullptr;
+
+  while (true) {
+    if (fresh) {
+      // ---- (re)start the operand stream for a new m-tile / K-slice: nothing this wave issued is in flight after the wait; other waves'
+      //      DMA only ever writes their own pieces, and every fragment read of the previous tile was consumed by its MFMAs.
+      // Both wave rows run the (re)start CONCURRENTLY: the stagger is taken out first (row 0 passes the barrier row 1 still owes) and put back
+      // at the end.  With the stagger left in, row 1's first barrier here would pair with row 0's LAST one and row 1 would only begin its index
+      // loads after row 0 had finished its whole prologue (measured: 15.5k cycles to the first MFMA instead of ~6k).
+      wait_vmcnt<0>();
+      if (staggered && wr == 0) PP_BAR();
+      PP_BAR();
+      nrm_par ^= 1;
+      const int last = cur.row_end - 1;
+      Ak = reinterpret_cast<const char*>(p.A) + (long)cur.slice * nk * BKK * 2;
+      Wc = w_tile_base(cur);
+      // ONE dependent round trip: the gathered-row indices of this lane's four DMA pieces and of "its" tile row (fused ln_2), together
+      int srow[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) srow[h][q] = min(cur.row0 + h * 128 + (wave * 2 + q) * 8 + r8, last);   // rows past the segment re-read a valid row (never stored)
+      int nrow = min(cur.row0 + (tid & 255), last);
+      if (p.a_rows) {                                              // condition hoisted: five independent loads
+        int tok[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) tok[h][q] = p.a_rows[srow[h][q]];
+        const int ntok = p.a_rows[nrow];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) srow[h][q] = tok[h][q];
+        nrow = ntok;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a_off[h][q] = (uint32_t)(((long)srow[h][q] * p.lda + lchunk * 8) * 2);
+      if (L == wg * R) stamp(6);                                 // gathered-row indices landed
+      // then everything else in flight together: the partial sums of squares (fused ln_2), the W half-tiles, the A half-tiles
+      [[maybe_unused]] float v[16];
+      const bool do_nrm = SWI && p.ss_in && tid < 256;
+      if constexpr (SWI) {
+        if (do_nrm) {
+          const float* sp = p.ss_in + (long)nrow * p.ss_n;
+          const int nss = p.ss_n;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = sp[min(j, nss - 1)];
+        }
+        asm volatile("" ::: "memory");                            // keep the loads above the DMA issue
+      }
+      stage(_1, _0, _0, Wc, b_off[0], b_off[1]);
+      stage(_0, _0, _0, Ak, a_off[0][0], a_off[0][1]);
+      stage(_1, _0, _1, Wc + w_half, b_off[0], b_off[1]);
+      if (stage_a1) stage(_0, _0, _1, Ak, a_off[1][0], a_off[1][1]);
+      stage(_1, _1, _0, Wc + 128, b_off[0], b_off[1]);
+      stage(_0, _1, _0, Ak + 128, a_off[0][0], a_off[0][1]);
+      stage(_1, _1, _1, Wc + w_half + 128, b_off[0], b_off[1]);
+      if constexpr (SWI) {
+        // fused ln_2 consumer: 1 / max(|x_row| K^-1/2, eps) per tile row from the producer's per-64-column partial sums (summation order of
+        // gemm_bf16.hip: p_j = v_j + v_{j+8}, then the xor-shuffle tree ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)))
+        if (do_nrm) {
+          const int nss = p.ss_n;
+          float pj[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pj[j] = (j < nss ? v[j] : 0.f) + (j + 8 < nss ? v[j + 8] : 0.f);
+          const float ssum = ((pj[0] + pj[1]) + (pj[2] + pj[3])) + ((pj[4] + pj[5]) + (pj[6] + pj[7]));
+          const float rk = rsqrtf((float)p.K);
+          reinterpret_cast<float*>(smem + LDS_NRM)[nrm_par * 256 + tid] = __frcp_rn(fmaxf(__fsqrt_rn(ssum) * rk, p.ss_eps));
+        }
+      }
+      if (L == wg * R) stamp(7);                                 // inverse row norms written
+      // K-step 0 complete, K-step 1 without its A half 1 (phase 1 stages it): the steady state of the loop below.  Everything is waited for:
+      // the last DMA issued is read within the first four phases, too early for the loop's counted waits to have retired it.
+      wait_vmcnt<0>();
+      wait_lgkmcnt<0>();
+      PP_BAR();
+      if (wr == 1) PP_BAR();                                     // stagger: wave row 1 runs one barrier behind wave row 0 from here on
+      staggered = true;
+      PP_SB();
+      fresh = false;
+      stamp(1);
+    }
+    const bool has_next = L + 1 < Lend;
+    bool cont = false;
+    if (has_next) {
+      map_tile(L + 1, nxt);
+      cont = nxt.m == cur.m && nxt.slice == cur.slice;
+    }
+    const char* Wn = cont ? w_tile_base(nxt) : Wc;             // no successor on this stream: the tail re-reads valid memory, never consumed
+
+    // ------------------------------------------------------------------------------------------------ K loop: 8 phases = 2 K-steps
+#pragma unroll 1
+    for (int kt = 0; kt < nk; kt += 2) {
+      const bool cross = kt + 2 >= nk;
+      const int k2 = cross ? kt + 2 - nk : kt + 2;             // K-step (kt+2) inside its own output tile
+      const char* A1 = Ak + (long)(kt + 1) * 128;
+      const char* A2 = Ak + (long)k2 * 128;
+      const char* W2 = (cross ? Wn : Wc) + (long)k2 * 128;
+      // phase 1: quadrant (A half 0, W half 0) of K-step kt [buffer 0]
+      rdB(_0, _0);
+      PP_SB();
+      rdA(_0, _0);
+      if constexpr (HAS_BIAS) {
+        if (kt == 0) {                                           // this tile's bias slice -> the wave's own LDS slot (1 KiB = one DMA instruction)
+          const float* bsrc = p.bias + (long)cur.expert * p.bias_estride + (long)cur.n * NOUT;
+          const float* bl = SWI ? (lane < 32 ? bsrc + lane * 4 : bsrc + p.N + (lane - 32) * 4) : bsrc + lane * 4;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bl,
+                                           (__attribute__((address_space(3))) void*)(smem + LDS_BIAS + wave * 1024), 16, 0, 0);
+        }
+      }
+      if (stage_a1) stage(_0, _1, _1, A1, a_off[1][0], a_off[1][1]);
+      wait_lgkmcnt<8>();                                       // the W fragment reads (issued first) are retired: W[0][0] may be refilled next phase
+      PP_COMPUTE(_0, _0)
+      // phase 2: (A0, W1)
+      rdB(_0, _1);
+      stage(_1, _0, _0, W2, b_off[0], b_off[1]);
+      PP_COMPUTE(_0, _1)
+      // phase 3: (A1, W0)
+      rdA(_0, _1);
+      stage(_0, _0, _0, A2, a_off[0][0], a_off[0][1]);
+      PP_COMPUTE(_1, _0)
+      // phase 4: (A1, W1); K-step kt+1 [buffer 1] retired for the next four phases
+      stage(_1, _0, _1, W2 + w_half, b_off[0], b_off[1]);
+      wait_vmcnt<6>();
+      PP_COMPUTE(_1, _1)
+      // phase 5: (A0, W0) of K-step kt+1
+      rdB(_1, _0);
+      PP_SB();
+      rdA(_1, _0);
+      if (stage_a1) stage(_0, _0, _1, A2, a_off[1][0], a_off[1][1]);
+      wait_lgkmcnt<8>();
+      PP_COMPUTE(_0, _0)
+      // phase 6
+      rdB(_1, _1);
+      stage(_1, _1, _0, W2 + 128, b_off[0], b_off[1]);
+      PP_COMPUTE(_0, _1)
+      // phase 7
+      rdA(_1, _1);
+      stage(_0, _1, _0, A2 + 128, a_off[0][0], a_off[0][1]);
+      PP_COMPUTE(_1, _0)
+      // phase 8; K-step kt+2 [buffer 0] retired
+      stage(_1, _1, _1, W2 + w_half + 128, b_off[0], b_off[1]);
+      wait_vmcnt<6>();
+      PP_COMPUTE(_1, _1)
+    }
+    stamp(2 + 2 * min(L - wg * R, 1));
+
+    // ------------------------------------------------------------------------------------------------ epilogue: registers -> global
+    // The two wave rows run it CONCURRENTLY (their VALU / LDS / store work interleaves on the shared SIMDs: measured 3.4k cycles per row when
+    // serialised behind each other by the stagger).  Wave row 0 passes one extra barrier early in its epilogue (after its first fragment row, about when row 1 finishes phase 8) - it pairs with wave row 1's last
+    // phase barrier, so row 1 is released into its epilogue ~one MFMA segment later instead of waiting for row 0's - and wave row 1 passes one
+    // after its epilogue (pairs with row 0's first barrier of the next tile), which restores the one-barrier stagger.  No LDS hazard: the next
+    // tile's first K-steps were waited for by both rows in phase 8, and nothing is staged between the two extra barriers.
+    const bool epi_sync = !(p.pp_flags & 1);
+    {
+      const int rows_valid = cur.row_end - cur.row0;
+      char* Cb = reinterpret_cast<char*>(p.C) + ((long)cur.slice * p.split_stride + (long)cur.row0 * p.ldc + (long)cur.n * NOUT + wc * 32 + fq * 8) * ESZ;
+      [[maybe_unused]] float4 bq[2][2];                        // bias of this lane's 8 columns: [W half][4-column group]
+      [[maybe_unused]] float rs[2][4];
+      if constexpr (HAS_BIAS) {
+        const uint32_t ba = lds0 + LDS_BIAS + wave * 1024 + (wc * 32 + fq * 8) * 4;
+        lds_read_f4(bq[0][0], ba); lds_read_f4(bq[0][1], ba + 16);
+        lds_read_f4(bq[1][0], ba + 512); lds_read_f4(bq[1][1], ba + 528);
+      }
+      if constexpr (SWI) {
+        if (p.ss_in) {
+          const uint32_t na = lds0 + LDS_NRM + nrm_par * 1024;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lds_read_f1(rs[0][i], na + (wr * 64 + i * 16 + fr) * 4);
+#pragma unroll
+          for (int i = 0; i < FM1; ++i) lds_read_f1(rs[1][i], na + (128 + wr * 16 * FM1 + i * 16 + fr) * 4);
+        }
+      }
+      wait_lgkmcnt<0>();
+      PP_SB();
+      if constexpr (SWI) {
+        if (!p.ss_in) {
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rs[a][i] = 1.0f;       // x 1.0f is exact
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int i = 0; i < (a ? FM1 : 4); ++i) {
+          if (a == 0 && i == 1) {
+            if (epi_sync && wr == 0) PP_BAR();
+          }
+          const int trow = a * 128 + (a ? wr * 16 * FM1 : wr * 64) + i * 16 + fr;
+          const bool ok = trow < rows_valid && !ab_st;
+          char* crow = Cb + (long)trow * p.ldc * ESZ;
+          if constexpr (SWI) {
+            float ov[8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const f32x4 v = acc[a][0][i][j] * rs[a][i], gt = acc[a][1][i][j] * rs[a][i];
+              const float4 bp = bq[0][j], bg = bq[1][j];
+              if (ab_act) { ov[j * 4 + 0] = v[0] + gt[0]; ov[j * 4 + 1] = v[1] + gt[1]; ov[j * 4 + 2] = v[2] + gt[2]; ov[j * 4 + 3] = v[3] + gt[3]; continue; }
+              ov[j * 4 + 0] = (v[0] + bp.x) * silu_f(gt[0] + bg.x); ov[j * 4 + 1] = (v[1] + bp.y) * silu_f(gt[1] + bg.y);
+              ov[j * 4 + 2] = (v[2] + bp.z) * silu_f(gt[2] + bg.z); ov[j * 4 + 3] = (v[3] + bp.w) * silu_f(gt[3] + bg.w);
+            }
+            if (ok) {
+              if constexpr (OUT_BF16) {
+                *reinterpret_cast<uint4*>(crow) = make_uint4(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]), pack_bf16x2(ov[4], ov[5]), pack_bf16x2(ov[6], ov[7]));
+              } else {
+                *reinterpret_cast<float4*>(crow) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                *reinterpret_cast<float4*>(crow + 16) = make_float4(ov[4], ov[5], ov[6], ov[7]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              float ov[8];
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                f32x4 v = acc[a][b][i][j];
+                if constexpr (HAS_BIAS) { const float4 bb = bq[b][j]; v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+                if constexpr (EPI == MODE_EPI_BIAS_GELU) { v[0] = gelu_erf_f(v[0]); v[1] = gelu_erf_f(v[1]); v[2] = gelu_erf_f(v[2]); v[3] = gelu_erf_f(v[3]); }
+                ov[j * 4 + 0] = v[0]; ov[j * 4 + 1] = v[1]; ov[j * 4 + 2] = v[2]; ov[j * 4 + 3] = v[3];
+              }
+              if (ok) {
+                char* c = crow + b * 128 * ESZ;
+                if constexpr (OUT_BF16) {
+                  *reinterpret_cast<uint4*>(c) = make_uint4(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]), pack_bf16x2(ov[4], ov[5]), pack_bf16x2(ov[6], ov[7]));
+                } else {
+                  *reinterpret_cast<float4*>(c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                  *reinterpret_cast<float4*>(c + 16) = make_float4(ov[4], ov[5], ov[6], ov[7]);
+                }
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (epi_sync && wr == 1) PP_BAR();
+    stamp(3 + 2 * min(L - wg * R, 1));
+    if (!has_next) break;
+    ++L;
+    cur = nxt;
+    fresh = !cont;
+    Wc = Wn;
+  }
+  wait_vmcnt<0>();                                             // the tail of the operand stream must land before the LDS is released
+  if (staggered && wr == 0) PP_BAR();                                       // balance the stagger barrier of wave row 1
+#undef PP_COMPUTE
+#undef PP_BAR
+#undef PP_SB
+}
+
+// ------------------------------------------------------------------------------------------------------------ host side
+static int pp_num_cus() {
+  static int ncu[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (!ncu[dev]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return ncu[dev];
+}
+
+unsigned long long g_pp_trace = 0;        // "pp_trace_lo" / "pp_trace_hi" options: device buffer of 256 x 8 x 8 cycle stamps (profiling aid), 0 = off
+
+template <int EPI, bool OUT_BF16, int FM1>
+static int pp_launch(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
+  constexpr int BM = 128 + 32 * FM1, NOUT = (EPI == MODE_EPI_SWIGLU) ? 128 : 256;
+  p.n_tiles = d->N / NOUT;
+  p.m_tiles = (d->M + BM - 1) / BM + (d->expert_offsets ? d->num_experts : 0);     // upper bound; the kernel counts the real m-tiles
+  const long t_max = (long)p.m_tiles * p.n_tiles * p.split_k;
+  const int ncu = pp_num_cus();
+  const int grid = (int)(t_max < ncu ? t_max : ncu);           // one persistent workgroup per CU (140 KiB of LDS each)
+  auto kern = gemm_pp_kernel<EPI, OUT_BF16, FM1>;
+  static bool attr_set[16] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16) dev = 0;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_TOTAL);
+    if (e != hipSuccess) return (int)e;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pp::LDS_TOTAL, s, p, reinterpret_cast<unsigned long long*>(g_pp_trace));
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+// Entered from gemm_bf16_launch with a validated descriptor and a filled parameter block; rows224 selects the 224-row tile.  Returns
+// MODE_ERR_UNSUPPORTED for shapes / epilogues this kernel does not take (the caller falls back to the 128x128 family).
+int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, int rows224, hipStream_t s) {
+  const int epi = d->epilogue;
+  if (epi != MODE_EPI_NONE && epi != MODE_EPI_BIAS && epi != MODE_EPI_SWIGLU) return MODE_ERR_UNSUPPORTED;
+  const int nout = epi == MODE_EPI_SWIGLU ? 128 : 256;
+  const int S = p0.split_k;
+  if (d->k_group_offsets || d->N % nout || d->K % (128 * S) || d->K / S < 128) return MODE_ERR_UNSUPPORTED;
+  if (d->expert_offsets && d->num_experts > 8) return MODE_ERR_UNSUPPORTED;
+  if (d->ldc % 8 || (reinterpret_cast<uintptr_t>(d->C) & 15) || (S > 1 && d->split_stride % 8)) return MODE_ERR_UNSUPPORTED;
+  if (d->row_ss && d->row_ss_n > 16) return MODE_ERR_UNSUPPORTED;   // fused ln_2 partial sums: D <= 1024
+  // 32-bit per-lane byte offsets: both operands must span < 4 GiB from their bases
+  const long wrows = (epi == MODE_EPI_SWIGLU ? 2L : 1L) * d->N;   // gathered A rows are token ids < M (M = tokens x top_k sorted rows)
+  if (wrows * d->ldw * 2 >= (1L << 32) || (long)d->M * d->lda * 2 >= (1L << 32)) return MODE_ERR_UNSUPPORTED;
+  if (d->bias && ((reinterpret_cast<uintptr_t>(d->bias) & 15) || d->bias_expert_stride % 4)) return MODE_ERR_UNSUPPORTED;
+  const bool ob = d->out_dtype == MODE_BF16;
+#define PP_CASE(E)                                                                                              \
+  case E:                                                                                                       \
+    if (rows224) return ob ? pp_launch<E, true, 3>(p0, d, s) : pp_launch<E, false, 3>(p0, d, s);              \
+    return ob ? pp_launch<E, true, 4>(p0, d, s) : pp_launch<E, false, 4>(p0, d, s);
+  switch (epi) {
+    PP_CASE(MODE_EPI_NONE)
+    PP_CASE(MODE_EPI_BIAS)
+    PP_CASE(MODE_EPI_SWIGLU)
+    default: return MODE_ERR_UNSUPPORTED;
+  }
+#undef PP_CASE
+}
+
+}  // namespace mode

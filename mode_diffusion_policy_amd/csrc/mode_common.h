@@ -28,6 +28,15 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
+// Independent 32-bit dropout stream per (step seed, stream id).  The keep-masks hash (element index XOR stream seed); with consecutive integers
+// as per-layer seeds the mask of layer l+1 would be the mask of layer l with its element indices XORed by a small constant (a permutation of
+// the same stream).  Stream id = 2*layer (attention dropout) / 2*layer + 1 (expert dropout).  oracle/mode_oracle.py restates this bit for bit.
+__host__ __device__ inline uint32_t mode_stream_seed(uint32_t seed, uint32_t stream) {
+  uint32_t x = seed ^ (0x9e3779b9u * (stream + 1u));
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;   // lowbias32
+  return x;
+}
+
 // ---- wave64 reductions via cross-lane shuffles ----------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -40,7 +49,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float silu_f(float g) { return __fdividef(g, 1.0f + __expf(-g)); }
+// g * sigmoid(g) with the hardware reciprocal (v_rcp_f32, 1 ulp): `__fdividef` compiles to the full IEEE division sequence on gfx950
+// (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup, serialised through VCC) - measured 5.5k cycles for the 56 outputs per lane of a
+// 224x256 SwiGLU tile epilogue against ~2k with this form.  Every kernel of the library shares this function (forward = backward = all tile shapes).
+__device__ __forceinline__ float silu_f(float g) { return g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // XCD-aware, bijective remap of a linear workgroup id: hardware places block b on XCD b % 8 (observed, speed only), so give
@@ -64,6 +76,7 @@ struct GemmParams {
   const int* koffs; long c_gstride;   // K-groups: blockIdx.z = group, K range [koffs[z], koffs[z+1])
   int group_m;                        // m-tiles per rasterisation group (0 = kernel default)
   int setprio;                        // raise the wave priority around the MFMA clusters ("gemm_setprio" option)
+  int pp_flags;                       // gemm_bf16_pp.hip experiment switches ("pp_flags" option): 1 = serial epilogues, 2/4/8 = timing ablations (no MFMA / no fragment reads / no DMA)
   // fused ln_2 (MODE_EPI_RESIDUAL_NORM producer / MODE_EPI_SWIGLU consumer): see include/mode_hip.h
   uint16_t* C2; long ldc2; const float* gain; float* ss_out;   // producer: bf16((acc+resid)*gain[n]) and per-64-column row sums of squares
   const float* ss_in; int ss_n; float ss_eps;                   // consumer: acc rows scaled by 1/max(sqrt(sum ss_in[row][0..ss_n)) * K^-1/2, eps)

@@ -46,6 +46,11 @@ class _Bucket:
 class BucketedGradReducer:
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_mb: float = 64.0, grad_dtype: torch.dtype = torch.float32,
                  mode: str = "auto", dead_params=("gripper_embed",)):
+        if any(type(m).__name__ == "MoDeDiT" and hasattr(m, "engine") for m in module.modules()):
+            # the HIP backward writes gradients straight into the gradient arena and hands autograd None for every parameter: the
+            # post-accumulate hooks this reducer is driven by never fire, and finish() would overwrite the arena-aliased p.grad with zeros
+            raise TypeError("BucketedGradReducer is hook-driven and cannot reduce a HIP MoDeDiT (its gradients live in the gradient arena): "
+                            "use ArenaGradReducer.for_model(model)")
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -136,19 +141,19 @@ class BucketedGradReducer:
                         b.buf[b.offsets[i]: b.offsets[i] + p.numel()].zero_()
                 b.pending = 0
         self._launch_ready()
+        from contextlib import nullcontext
         for b in self.buckets:
             if self.world > 1:
-                b.work.wait()
-                if self.mode == "rs_ag":
-                    if self._comm_stream is not None:
-                        with torch.cuda.stream(self._comm_stream):
-                            b.shard.div_(self.world)
-                            dist.all_gather_into_tensor(b.buf, b.shard, group=self.pg)
-                    else:
+                # everything that touches the bucket after its collective is enqueued on the COMMUNICATION stream, and work.wait() is called
+                # with that stream current: wait() only orders the *current* stream behind the async collective, so waiting on the compute
+                # stream and then dividing on the side stream would let div_ race the reduce_scatter that is still writing the shard
+                with (torch.cuda.stream(self._comm_stream) if self._comm_stream is not None else nullcontext()):
+                    b.work.wait()
+                    if self.mode == "rs_ag":
                         b.shard.div_(self.world)
                         dist.all_gather_into_tensor(b.buf, b.shard, group=self.pg)
-                else:
-                    b.buf.div_(self.world)
+                    else:
+                        b.buf.div_(self.world)
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         for b in self.buckets:

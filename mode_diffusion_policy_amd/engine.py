@@ -39,6 +39,7 @@ class DitEngine:
         self._structs_for = None
         self.arena = None
         self._ws: Optional[torch.Tensor] = None
+        self._ws_pin: Optional[torch.Tensor] = None            # workspace owned by a hipGraph being warmed up / captured (see pinned_workspace)
         m = model
         self.dims = L.ModeDims(D=m.embed_dim, H=m.n_heads, L=m.num_layers, E=m.num_experts, k=m.top_k, T=m.seq_len,
                                A_len=m.action_seq_len, A_dim=m.action_dim, O=m.obs_dim, G=m.goal_dim, n_img=m.n_img_tokens,
@@ -103,13 +104,37 @@ class DitEngine:
         self.arena.lp_synced = bool(lp_synced) and self.arena.lp is not None
 
     # ------------------------------------------------------------------ workspace
-    def workspace(self, B: int, R: int) -> Tuple[int, int]:
+    def workspace_bytes(self, B: int, R: int) -> int:
         need = self.lib.mode_dit_workspace_bytes(C.byref(self.dims), B, R, self.dt)
         if need == 0:
             raise RuntimeError("unsupported MoDeDiT dimensions for the HIP path")
+        return need
+
+    def workspace(self, B: int, R: int) -> Tuple[int, int]:
+        need = self.workspace_bytes(B, R)
+        pin = self._ws_pin
+        if pin is not None:                                     # a captured graph bakes this pointer in: it must never be re-allocated
+            if pin.numel() < need:
+                raise RuntimeError("pinned workspace too small for this launch chain")
+            return pin.data_ptr(), pin.numel()
         if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws.data_ptr(), self._ws.numel()
+
+    def pinned_workspace(self, ws: torch.Tensor):
+        """Context manager: every launch chain issued inside uses ``ws`` (a tensor the caller keeps alive next to its hipGraph) instead of
+        the engine's growable scratch buffer — a replay must not read a pointer that a later, larger request freed."""
+        eng = self
+
+        class _Pin:
+            def __enter__(self_inner):
+                self_inner.prev = eng._ws_pin
+                eng._ws_pin = ws
+
+            def __exit__(self_inner, *exc):
+                eng._ws_pin = self_inner.prev
+                return False
+        return _Pin()
 
     def meta_layout(self, N: int) -> L.ModeMetaLayout:
         ml = L.ModeMetaLayout()

@@ -337,14 +337,19 @@ class MoDeDiT(nn.Module):
         ent = self._route_cache.get("graph")
         if ent is None or ent["key"] != key:
             st = dict(key=key, img=img.clone(), goals=goals.clone(), x=x0.clone().contiguous(), sig=sig.clone())
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):                                # warm-up: sizes the workspace, loads code objects
-                self._ddim_chain(eng, st["img"], st["goals"], st["x"], st["sig"], sigma_data)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
-                st["idx"], st["meta"], st["ml"] = self._ddim_chain(eng, st["img"], st["goals"], st["x"], st["sig"], sigma_data)
+            # the graph owns its workspace: the engine's shared scratch buffer is re-allocated whenever a larger chain (a training step, a
+            # bigger batch) asks for more, and a replay would then read freed memory
+            n_sig = sig.numel() - 1
+            st["ws"] = torch.empty(max(eng.workspace_bytes(B, 0), eng.workspace_bytes(0, n_sig)), dtype=torch.uint8, device=dev)
+            with eng.pinned_workspace(st["ws"]):
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):                            # warm-up: loads code objects
+                    self._ddim_chain(eng, st["img"], st["goals"], st["x"], st["sig"], sigma_data)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
+                    st["idx"], st["meta"], st["ml"] = self._ddim_chain(eng, st["img"], st["goals"], st["x"], st["sig"], sigma_data)
             st["graph"] = g
             self._route_cache["graph"] = ent = st
         ent["img"].copy_(img); ent["goals"].copy_(goals); ent["x"].copy_(x0); ent["sig"].copy_(sig)

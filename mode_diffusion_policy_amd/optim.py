@@ -33,7 +33,9 @@ class FusedAdamW:
                              dict(name="no_decay", lr=lr, betas=betas, eps=eps, weight_decay=0.0)]
 
     def zero_grad(self, set_to_none: bool = False) -> None:
-        """Gradients are overwritten by every backward; nothing to clear (kept for optimizer-API compatibility)."""
+        """The next backward overwrites the gradient arena instead of accumulating into it (no memset pass: the backward chain writes every
+        element of the reducible region, exact zeros for un-routed experts included)."""
+        self.arena.grad_pending = False
 
     def _frozen_ranges(self):
         """Arena element ranges of parameters with ``requires_grad == False`` (``freeze_router()`` for fine-tuning, mode_agent.py:762-766):
@@ -145,6 +147,7 @@ class FusedAdamW:
                 self._launch(ar.bounds["decay"], ar.bounds["no_decay"], gn, lp, grad_scale)
             cur.wait_stream(self._side)
         eng.weights_updated(lp_synced=lp is not None)
+        ar.grad_pending = False                                  # gradients consumed: the next backward starts a fresh sum
 
     # ---- checkpointing (same information as torch's optimizer state, flat)
     def state_dict(self) -> Dict:

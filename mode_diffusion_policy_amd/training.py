@@ -145,6 +145,13 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     if B == 0:
         raise ValueError("training forward needs at least one sample")
     N, A_len, A = B * T, model.action_seq_len, model.action_dim
+    if torch.is_grad_enabled():
+        # The HIP backward produces parameter gradients only.  An upstream module that expects a gradient through one of the inputs (the
+        # reference trains its FiLM-ResNet encoders through state_images, mode_agent.py:548-567) would silently train on zeros: refuse.
+        for nm, t in (("states['state_images']", states["state_images"]), ("goals", goals), ("actions", actions)):
+            if torch.is_tensor(t) and t.requires_grad:
+                raise NotImplementedError(f"MoDeDiT (HIP) training forward: {nm} requires grad, but the backward chain returns no input gradients "
+                                          "(detach the input, or freeze the upstream encoder)")
     f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
     img = f(states["state_images"])
     if img.dim() != 3 or img.shape[1] != model.n_img_tokens or img.shape[2] != model.obs_dim:
@@ -187,6 +194,7 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     stash = torch.empty(sl.total_bytes, dtype=torch.uint8, device=dev)
     F = torch.empty(B, A_len, A, device=dev)
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    model._last_seed = seed                                   # step seed of the hash dropout streams (tests reproduce the masks from it)
     args = L.ModeTrainArgs(B=B, dtype=eng.dt, seed=seed, attn_pdrop=float(model.attn_pdrop), mlp_pdrop=float(model.mlp_pdrop),
                            sigma=sig.data_ptr(), e1=e1.data_ptr(), emb_t=emb_t.data_ptr(), cond=cond.data_ptr(),
                            goal_in_cond=int(model.use_goal_in_routing), state_images=img.data_ptr(), goals=gl.data_ptr(),
@@ -222,16 +230,26 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     names = [n for n, _ in model.named_parameters()]
 
     def backward(dF: torch.Tensor):
-        """Writes every parameter gradient straight into the gradient arena and points ``p.grad`` at its slice (gradients are
-        OVERWRITTEN, not accumulated: one backward per optimizer step, as in the reference's training loop)."""
+        """Writes every parameter gradient straight into the gradient arena and points ``p.grad`` at its slice.  The first backward after an
+        optimizer step (or ``zero_grad``) overwrites; further ones accumulate."""
         ts.ensure()
         mg = ts.grad_tables()
         ar = eng.arena
         wsb = lib.mode_dit_train_workspace_bytes(C.byref(d), B, eng.dt)
         if ts._ws is None or ts._ws.numel() < wsb:
             ts._ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        # A second backward before the optimizer consumed the first one (gradient accumulation; the reference's training_step sums the losses of
+        # several modalities, mode_agent.py:386-440) must ADD, like autograd does.  The chain overwrites the arena, so the earlier sum is parked
+        # in a side buffer around the launch (2.7 GB copy + add: the rare path; one backward per step pays nothing).
+        nred = ar.bounds["no_decay"]
+        carry = None
+        if getattr(ar, "grad_pending", False) and any(p.grad is not None for p in params if p.requires_grad):
+            carry = ar.grad[:nred].clone()
         L.check(lib.mode_dit_backward(C.byref(d), C.byref(eng._mw), C.byref(ts.wt), C.byref(args), stash.data_ptr(), dF.data_ptr(), C.byref(mg),
                                       ts._ws.data_ptr(), ts._ws.numel(), _stream()), "backward")
+        if carry is not None:
+            ar.grad[:nred].add_(carry)
+        ar.grad_pending = True                                                  # cleared by FusedAdamW.step()/zero_grad() or p.grad = None
         gv = ar.g_by_name
         for n, p in zip(names, params):
             if p.requires_grad and n != "gripper_embed.weight":               # dead in the reference too (modedit.py:684): grad stays None

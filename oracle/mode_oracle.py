@@ -21,6 +21,7 @@ import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -136,15 +137,62 @@ def dispatch_permutation(idx: Tensor, num_experts: int) -> Tuple[Tensor, Tensor,
     return counts, tok[order], slot[order]
 
 
-def expert_mlp(sd, layer: int, e: int, x: Tensor) -> Tensor:
-    """SwishGLU(D,4D) -> Linear(4D,D, no bias)   (modedit.py:83-90, 247-255); dropout=identity (eval)."""
+# --------------------------------------------------------------------------- counter-based dropout streams of the HIP training chain
+# The reference draws its dropout masks from torch's RNG (SDPA dropout_p modedit.py:149, nn.Dropout in the expert MLP modedit.py:254); those
+# draws cannot be bit-matched by another implementation.  The HIP chain uses counter-based hash masks instead (a pure function of
+# (step seed, stream, element index), so the backward regenerates them).  Restated here bit for bit so that the STOCHASTIC training path can be
+# checked against this oracle's autograd with shared randomness (mode_common.h: mode_stream_seed; attn.hip: attn_keep; train_ops.hip: drop_keep).
+def _lowbias32(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint32)
+    with np.errstate(over="ignore"):
+        x = x ^ (x >> np.uint32(16)); x = x * np.uint32(0x7feb352d)
+        x = x ^ (x >> np.uint32(15)); x = x * np.uint32(0x846ca68b)
+        x = x ^ (x >> np.uint32(16))
+    return x
+
+
+def stream_seed(seed: int, stream: int) -> int:
+    """mode_stream_seed: stream 2l = attention dropout of layer l, 2l+1 = expert dropout of layer l."""
+    x = np.array([(seed ^ ((0x9e3779b9 * (stream + 1)) & 0xffffffff)) & 0xffffffff], dtype=np.uint32)
+    return int(_lowbias32(x)[0])
+
+
+def _thresh(p: float) -> int:
+    return 0 if p <= 0.0 else int(float(p) * 4294967296.0)
+
+
+def attn_keep_scale(seed: int, B: int, H: int, T: int, p: float) -> Tensor:
+    """(B,H,T,T) multiplier of the softmax probabilities: 1/(1-p) where kept, 0 where dropped (attn.hip attn_keep)."""
+    e = np.arange(B * H * T * T, dtype=np.uint64).astype(np.uint32)             # ((b*H+h)*T + q)*T + k
+    with np.errstate(over="ignore"):
+        hsh = _lowbias32(_lowbias32(e ^ np.uint32(seed)) + np.uint32(0x9e3779b9))
+    keep = hsh >= np.uint32(_thresh(p))
+    return torch.from_numpy(keep.astype(np.float32) / np.float32(1.0 - p)).view(B, H, T, T)
+
+
+def mlp_keep_scale(seed: int, row0: int, rows: int, hdim: int, p: float) -> Tensor:
+    """(rows, hdim) multiplier of the SwishGLU output of SORTED rows row0.. (train_ops.hip drop_keep, element index r*hdim + c)."""
+    idx = (np.arange(row0, row0 + rows, dtype=np.uint64)[:, None] * np.uint64(hdim) + np.arange(hdim, dtype=np.uint64)[None, :])
+    lo, hi = (idx & np.uint64(0xffffffff)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        hsh = _lowbias32(_lowbias32(lo ^ np.uint32(seed)) + hi * np.uint32(0x9e3779b9))
+    keep = hsh >= np.uint32(_thresh(p))
+    return torch.from_numpy(keep.astype(np.float32) / np.float32(1.0 - p))
+
+
+def expert_mlp(sd, layer: int, e: int, x: Tensor, keep_scale: Optional[Tensor] = None) -> Tensor:
+    """SwishGLU(D,4D) -> Dropout -> Linear(4D,D, no bias)   (modedit.py:83-90, 247-255); dropout = identity in eval, or the given
+    keep/scale multiplier (mlp_keep_scale)."""
     p = f"blocks.{layer}.experts.expert_{e}.mlp."
     h = x @ sd[p + "0.project.weight"].t() + sd[p + "0.project.bias"]
     proj, gate = h.tensor_split(2, dim=-1)
-    return (proj * F.silu(gate)) @ sd[p + "2.weight"].t()
+    hh = proj * F.silu(gate)
+    if keep_scale is not None:
+        hh = hh * keep_scale
+    return hh @ sd[p + "2.weight"].t()
 
 
-def causal_attention(sd, layer: int, h: Tensor, n_heads: int) -> Tensor:
+def causal_attention(sd, layer: int, h: Tensor, n_heads: int, keep_scale: Optional[Tensor] = None) -> Tensor:
     """q,k,v Linear(+bias) -> per-head qk-RMSNorm(eps 1e-6) -> causal softmax(QK^T/sqrt(hd)) V -> c_proj (no bias)
     (modedit.py:108-111, 125-127, 141-166).  h (B,T,D) -> (B,T,D)."""
     p = f"blocks.{layer}.attn."
@@ -159,6 +207,8 @@ def causal_attention(sd, layer: int, h: Tensor, n_heads: int) -> Tensor:
     att = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(hd))
     mask = torch.ones(T, T, dtype=torch.bool).tril()
     att = att.masked_fill(~mask, float("-inf")).softmax(dim=-1)
+    if keep_scale is not None:                                           # SDPA dropout_p on the attention weights (modedit.py:149)
+        att = att * keep_scale
     y = (att @ v).transpose(1, 2).reshape(B, T, D)
     return y @ sd[p + "c_proj.weight"].t()
 
@@ -190,11 +240,12 @@ def embed_sequence(sd, cfg: DiTConfig, state_images: Tensor, actions: Tensor, go
 
 
 def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, state_images: Tensor, actions: Tensor, goals: Tensor,
-                sigma: Tensor, topk_idx: Optional[List[Tensor]] = None, return_aux: bool = False):
+                sigma: Tensor, topk_idx: Optional[List[Tensor]] = None, return_aux: bool = False, dropout: Optional[dict] = None):
     """MoDeDiT.forward in eval mode (modedit.py:741-821, 530-595).
 
     ``topk_idx``: optional per-layer (B,T,k) expert ids (training: the reference draws them with
     torch.multinomial per token row, modedit.py:390 — the draw stays on the host side of the ABI).
+    ``dropout``: optional {"seed": step seed, "attn_p": p, "mlp_p": p} — the HIP chain's counter-based masks (see attn_keep_scale).
     """
     B = actions.shape[0]
     T, D, E, k = cfg.seq_len, cfg.embed_dim, cfg.num_experts, cfg.top_k
@@ -208,7 +259,10 @@ def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, state_images: Tensor, act
     aux = Aux(cond=cond)
     for l in range(cfg.n_layers):
         p = f"blocks.{l}."
-        x = x + causal_attention(sd, l, rmsnorm(x, sd[p + "ln_1.g"]) + c, cfg.n_heads)   # :532
+        ak = None
+        if dropout is not None and dropout.get("attn_p", 0.0) > 0.0:
+            ak = attn_keep_scale(stream_seed(int(dropout["seed"]), 2 * l), B, cfg.n_heads, T, float(dropout["attn_p"]))
+        x = x + causal_attention(sd, l, rmsnorm(x, sd[p + "ln_1.g"]) + c, cfg.n_heads, ak)   # :532
         u = rmsnorm(x, sd[p + "ln_2.g"])                                                # :539 (overwrites stream)
         logits, probs = router_probs(sd, l, cond)                                       # distinct rows only
         if topk_idx is None:
@@ -228,7 +282,10 @@ def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, state_images: Tensor, act
             if n_e:
                 rows = perm[off: off + n_e]
                 we = w[rows, slot[off: off + n_e]].unsqueeze(-1)
-                nxt[rows] += we * expert_mlp(sd, l, e, uf[rows])
+                mk = None
+                if dropout is not None and dropout.get("mlp_p", 0.0) > 0.0:
+                    mk = mlp_keep_scale(stream_seed(int(dropout["seed"]), 2 * l + 1), off, n_e, 4 * D, float(dropout["mlp_p"]))
+                nxt[rows] += we * expert_mlp(sd, l, e, uf[rows], mk)
             off += n_e
         x = (uf + nxt).reshape(B, T, D)                                  # residual from the NORMALISED stream (:595)
         if return_aux:
