@@ -108,19 +108,101 @@ def dominant_kernel_roofline(den, device, reps=240):
     us = e0.elapsed_time(e1) * 1e3 / reps
     flops = 2.0 * (N * k) * D * (8 * D)
     ach = flops / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_bf16_kernel<SWIGLU> (grouped expert up-projection, M=3584 K=1024 N=2x4096)",
+    # HBM bytes per launch: NOT a literal - read from the machine-readable summary scripts/pmc_summary.py writes from the separate
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command (FETCH_SIZE doubled: gfx950 correction, MI355X_MICROARCH.md "HBM");
+    # null when the summary is absent or was taken on another kernel.
+    traffic, src = None, None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_gemm_pmc.json")))
+        ent = pj["kernels"].get("expert_up_projection")
+        if ent and ent.get("kernel_substr", "") in "gemm_pp_kernel<4, true, 3>":
+            traffic, src = ent["hbm_bytes_per_launch"], "profiles/r02_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+    except Exception:
+        pass
+    return {"bound": "mfma", "kernel": "gemm_pp_kernel<SWIGLU, bf16, 224x256> (grouped expert up-projection + fused ln_2 scale + SwiGLU, M=3584 K=1024 N=2x4096)",
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            # HBM bytes per launch from the committed PMC passes (profiles/r01_gemm_pmc.md): FETCH_SIZE 47 216 KB x2 (gfx950 correction,
-            # MI355X_MICROARCH.md "HBM") + WRITE_SIZE 28 672 KB; algorithmic bytes per launch (2 of 4 experts active under uniform sigma):
-            # A 3.7 MB + W1 33.6 MB + H 29.4 MB = 66.6 MB
-            "traffic": 126.1e6, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_gemm_pmc.md)",
-            "algorithmic_bytes": 66.6e6, "avg_launch_us": round(us, 2), "flops_per_launch": flops}
+            # algorithmic bytes per launch (2 of 4 experts active under uniform sigma): A 3.7 MB + W1 33.6 MB + H 29.4 MB = 66.6 MB
+            "traffic": traffic, "traffic_source": src, "algorithmic_bytes": 66.6e6, "avg_launch_us": round(us, 2), "flops_per_launch": flops}
 
 
-def cpu_baseline():
-    """The oracle (pure-torch fp32 CPU restatement, parity-pinned to the reference) on this box's host cores, bounded sample."""
-    from oracle import mode_oracle as O
-    from oracle.weights import param_spec
+def layer_kernel_breakdown(den, device, reps=120):
+    """The six kernels of one transformer block at the benchmark shape (B=128, N=1792 tokens), each timed in isolation as a hipGraph of `reps`
+    launches cycling the 12 layers' weights (HIP events on the replay stream): {name: {us, frac, bound}}; frac against the roof that bounds it."""
+    import ctypes as C
+    from mode_diffusion_policy_amd import _lib as L
+    m = den.inner_model
+    eng = m.engine
+    lib = L.load()
+    D, E, k, T, H = 1024, 4, 2, 14, 8
+    B = B_PER_GPU
+    N, NK = B * T, B * T * 2
+    bf = torch.bfloat16
+    idx = torch.tensor([[1, 2]], dtype=torch.int32, device=device); w = torch.tensor([[0.6, 0.4]], dtype=torch.float32, device=device)
+    meta = eng.dispatch(idx, w, 1, 1, N, N); ml = eng.meta_layout(N); mp = meta.data_ptr()
+    kp = {**eng.arena.w, **eng.arena.wl}
+    h = torch.randn(N, D, device=device).to(bf); qkv = torch.empty(N, 3 * D, dtype=bf, device=device); yat = torch.randn(N, D, device=device).to(bf)
+    x = torch.randn(N, D, device=device); xo = torch.empty(N, D, device=device); h2 = torch.empty(N, D, dtype=bf, device=device)
+    ss = torch.rand(N, D // 64, device=device) + 0.5
+    Hb = torch.randn(NK, 4 * D, device=device).to(bf) * 0.1
+    S = 4
+    Y = torch.empty(S, NK, D, dtype=bf, device=device)
+    cond = torch.randn(1, D, device=device)
+    st_of = lambda: torch.cuda.current_stream().cuda_stream
+    Ly = m.num_layers
+
+    def g(**kw):
+        base = dict(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=N, N=D, K=D, A=h.data_ptr(), lda=D, W=None, ldw=D, C=None, ldc=D)
+        base.update(kw)
+        return L.ModeGemmDesc(**base)
+    qkv_d = [g(epilogue=L.EPI_BIAS, N=3 * D, W=kp[f"l{l}.wqkv"].data_ptr(), bias=kp[f"l{l}.bqkv"].data_ptr(), C=qkv.data_ptr(), ldc=3 * D) for l in range(Ly)]
+    cpr_d = [g(epilogue=L.EPI_RESIDUAL_NORM, out_dtype=L.MODE_F32, A=yat.data_ptr(), W=kp[f"l{l}.wo"].data_ptr(), resid=x.data_ptr(), ldr=D, C=xo.data_ptr(),
+               C2=h2.data_ptr(), ldc2=D, gain=kp["ln2_g"][l].data_ptr(), row_ss_out=ss.data_ptr()) for l in range(Ly)]
+    up_d = [g(epilogue=L.EPI_SWIGLU, M=NK, N=4 * D, W=kp[f"l{l}.w1"].data_ptr(), w_expert_stride=8 * D * D, bias=kp[f"l{l}.b1"].data_ptr(),
+              bias_expert_stride=8 * D, C=Hb.data_ptr(), ldc=4 * D, a_rows=mp + 4 * ml.perm, expert_offsets=mp + 4 * ml.offsets, num_experts=E,
+              row_ss=ss.data_ptr(), row_ss_n=D // 64, row_eps=1e-6) for l in range(Ly)]
+    dn_d = [g(M=NK, N=D, K=4 * D, A=Hb.data_ptr(), lda=4 * D, W=kp[f"l{l}.w2"].data_ptr(), ldw=4 * D, w_expert_stride=4 * D * D, C=Y.data_ptr(),
+              expert_offsets=mp + 4 * ml.offsets, num_experts=E, split_k=S, split_stride=NK * D) for l in range(Ly)]
+
+    def gemm(ds):
+        return lambda i, st: L.check(lib.mode_gemm(C.byref(ds[i % Ly]), st))
+
+    def attn(i, st):
+        L.check(lib.mode_attn_block_fwd(qkv.data_ptr(), kp["qn_g"][i % Ly].data_ptr(), kp["kn_g"][i % Ly].data_ptr(), yat.data_ptr(), L.MODE_BF16, B, T, H, D // H,
+                                        1e-6, 0, 0.0, st))
+
+    def comb(i, st):
+        l = i % Ly
+        L.check(lib.mode_moe_combine_norm_fused_fwd(xo.data_ptr(), ss.data_ptr(), D // 64, kp["ln2_g"][l].data_ptr(), Y.data_ptr(), L.MODE_BF16, S, NK * D,
+                                                    mp + 4 * ml.pos, mp + 4 * ml.posw, N, D, k, kp["ln1_g"][(l + 1) % Ly].data_ptr(), cond.data_ptr(), N, 1e-6,
+                                                    x.data_ptr(), h.data_ptr(), L.MODE_BF16, st))
+    MB = 1e6
+    items = [("qkv_gemm", gemm(qkv_d), "mfma", 2.0 * N * D * 3 * D),
+             ("attention", attn, "hbm", (N * 3 * D + N * D) * 2.0),
+             ("c_proj_gemm+resid+ln2", gemm(cpr_d), "mfma", 2.0 * N * D * D),
+             ("expert_up_gemm+swiglu", gemm(up_d), "mfma", 2.0 * NK * D * 8 * D),
+             ("expert_down_gemm_4slices", gemm(dn_d), "mfma", 2.0 * NK * 4 * D * D),
+             ("combine+ln1", comb, "hbm", N * D * (4 + 4 + 2) + S * NK * D * 2.0 + N * 16 * 4)]
+    out = {}
+    for name, fn, bound, work in items:
+        for i in range(Ly):
+            fn(i, st_of())
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+            cst = st_of()
+            for i in range(reps):
+                fn(i, cst)
+        gr.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        peak = MFMA_BF16_PEAK_TFLOPS * 1e12 if bound == "mfma" else HBM_PEAK_GBS * 1e9
+        out[name] = {"us": round(us, 2), "bound": bound, "frac": round(work / (us * 1e-6) / peak, 4)}
+    out["sum_us"] = round(sum(v["us"] for v in out.values()), 1)
+    return out
+
+
+def _cpu_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:                                            # container CPU quota (cgroup v2): "max" or "<quota> <period>"
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -128,37 +210,112 @@ def cpu_baseline():
             cores = max(1, min(cores, int(int(q) / int(per))))
     except Exception:
         pass
+    return cores
+
+
+def cpu_baseline():
+    """BASELINE.md section 3 protocol: the CPU restatement (oracle/mode_oracle.py: pure-torch fp32, parity-pinned to the reference) on this box's
+    host cores, `torch.set_num_threads(cores)`: 1 warm-up + 3 timed runs of the full 10-step DDIM chunk, median, at C1 (B=8) and C2 (B=128).
+    Bounded: if one C2 chunk takes longer than 25 s only ONE timed C2 run follows the warm-up (the protocol line says so)."""
+    from oracle import mode_oracle as O
+    from oracle.weights import param_spec
+    cores = _cpu_cores()
     torch.set_num_threads(cores)
-    cfg = O.DiTConfig(**C2)
-    g = torch.Generator().manual_seed(0)
-    sd = {}
-    for name, shape in param_spec(cfg):
-        if name.endswith(".g"):
-            sd[name] = torch.ones(shape)
-        elif name.endswith("bias") or name == "pos_emb":
-            sd[name] = torch.zeros(shape)
-        else:
-            sd[name] = torch.randn(shape, generator=g) * (shape[-1] ** -0.5)
-    B = B_PER_GPU
-    img = torch.randn(B, 2, cfg.obs_dim, generator=g); goal = torch.randn(B, 1, cfg.goal_dim, generator=g)
-    x = torch.randn(B, 10, 7, generator=g) * SIGMA_MAX
-    sig = O.get_sigmas_exponential(N_SAMPLING_STEPS, SIGMA_MIN, SIGMA_MAX)
-    with torch.no_grad():
-        O.denoiser_forward(sd, cfg, SIGMA_DATA, img, x, goal, sig[0] * torch.ones(B))     # warm-up
-        n, t0 = 0, time.perf_counter()
-        while n < 2 or (time.perf_counter() - t0 < 8.0 and n < 10):
-            x = O.ddim_update(x, O.denoiser_forward(sd, cfg, SIGMA_DATA, img, x, goal, sig[n % 10] * torch.ones(B)),
-                              float(sig[n % 10]), float(sig[n % 10 + 1]))
-            n += 1
-        dt = time.perf_counter() - t0
+    legs = {}
+    for leg, kw, B in (("c1", dict(obs_dim=512, goal_dim=512, embed_dim=256, n_layers=2, n_heads=8, num_experts=2, top_k=1), 8), ("c2", C2, B_PER_GPU)):
+        cfg = O.DiTConfig(**kw)
+        g = torch.Generator().manual_seed(0)
+        sd = {}
+        for name, shape in param_spec(cfg):
+            if name.endswith(".g"):
+                sd[name] = torch.ones(shape)
+            elif name.endswith("bias") or name == "pos_emb":
+                sd[name] = torch.zeros(shape)
+            else:
+                sd[name] = torch.randn(shape, generator=g) * (shape[-1] ** -0.5)
+        img = torch.randn(B, 2, cfg.obs_dim, generator=g); goal = torch.randn(B, 1, cfg.goal_dim, generator=g)
+        x0 = torch.randn(B, 10, 7, generator=g) * SIGMA_MAX
+        sig = O.get_sigmas_exponential(N_SAMPLING_STEPS, SIGMA_MIN, SIGMA_MAX)
+        times = []
+        with torch.no_grad():
+            t0 = time.perf_counter(); O.sample_ddim(sd, cfg, SIGMA_DATA, img, x0, goal, sig); warm = time.perf_counter() - t0
+            for _ in range(3 if warm <= 25.0 else 1):
+                t0 = time.perf_counter(); O.sample_ddim(sd, cfg, SIGMA_DATA, img, x0, goal, sig); times.append(time.perf_counter() - t0)
+        med = sorted(times)[len(times) // 2]
+        legs[leg] = {"denoise_steps_per_s": round(N_SAMPLING_STEPS / med, 4), "ms_per_denoise_step": round(med / N_SAMPLING_STEPS * 1e3, 2),
+                     "timed_chunks": len(times), "warmup_chunk_s": round(warm, 2)}
     model = ""
     try:
         model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         pass
-    return {"value": round(n / dt, 4), "unit": "denoise-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} denoise steps (GCDenoiser.forward + DDIM update) of the full config-2 model at B=128, fp32, "
-                      f"oracle/mode_oracle.py with torch.set_num_threads({cores}); cpu: {model}"}
+    c2 = legs["c2"]
+    return {"value": c2["denoise_steps_per_s"], "unit": "denoise-steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 warm-up + {c2['timed_chunks']} timed full 10-step DDIM chunks (median) of the config-2 model at B=128 (GCDenoiser.forward + DDIM update per step), fp32, "
+                      f"oracle/mode_oracle.py with torch.set_num_threads({cores}); cpu: {model}",
+            "c1_b8": legs["c1"], "c2_b128": c2}
+
+
+def extra_measurements(M, den, device):
+    """Driver-timed numbers of the other configurations, in the same process as the headline run (rank 0, N = 1 only):
+    configs[2] training step (fwd + bwd + fused AdamW, B=128), configs[4] rollout (B=32 environments) and the reference's real rollout case B=1."""
+    import math
+    out = {}
+    sig = M.get_sigmas_exponential(N_SAMPLING_STEPS, SIGMA_MIN, SIGMA_MAX).to(device)
+    m = den.inner_model
+    weight_bytes = 767e6                                             # bf16 weights touched per denoise step under uniform sigma (SURVEY section 8d)
+    for key, batch in (("rollout", 32), ("b1", 1)):
+        img, goal, x0 = synthetic_inputs(device, batch)
+        state = {"state_images": img}
+        if key == "rollout":                                         # MoDEAgent's inference setup: routing cached per noise level (mode_agent.py:639-644)
+            for s_ in sig[:-1]:
+                m.precompute_experts_for_inference(s_)
+        for _ in range(3):
+            out_x = M.sample_ddim(den, state, x0, goal, sig, disable=True)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out_x).all()
+        n = 30
+        t0 = time.perf_counter()
+        for _ in range(n):
+            M.sample_ddim(den, state, x0, goal, sig, disable=True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        out[f"{key}_ms_per_chunk"] = round(ms, 3)
+        out[f"{key}_hbm_frac"] = round(weight_bytes * N_SAMPLING_STEPS / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
+        out[f"{key}_mfma_frac"] = round(flops_per_denoise_step(batch) * N_SAMPLING_STEPS / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4)
+        if key == "rollout":
+            out["rollout_action_chunks_per_s"] = round(batch / (ms * 1e-3), 1)
+    # training step (the sampler graphs own their workspaces: the training chain may grow the shared one)
+    from mode_diffusion_policy_amd.optim import FusedAdamW
+    from mode_diffusion_policy_amd.utils import rand_log_logistic
+    den.train()
+    B = B_PER_GPU
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    img = torch.randn(B, 2, C2["obs_dim"], generator=g).to(device); goal = torch.randn(B, 1, C2["goal_dim"], generator=g).to(device)
+    acts = torch.randn(B, 10, 7, generator=g).to(device); noise = torch.randn(B, 10, 7, generator=g).to(device)
+    opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+
+    def step():
+        s_ = rand_log_logistic((B,), loc=math.log(SIGMA_DATA), scale=0.5, min_value=SIGMA_MIN, max_value=SIGMA_MAX, device=device)
+        loss, _ = den.loss({"state_images": img}, acts, goal, noise, s_)
+        loss.backward()
+        opt.step(overlap=True)
+        return loss
+    for _ in range(3):
+        loss = step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss.detach()).all()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    out["train_ms_per_step"] = round(ms, 3)
+    out["train_samples_per_s"] = round(B / (ms * 1e-3), 1)
+    out["train_mfma_frac"] = round(3.0 * flops_per_denoise_step(B) / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4)
+    den.eval()
+    return out
 
 
 def train_bench(args, world, rank, device, dist):
@@ -228,6 +385,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel breakdown and the train / rollout / B=1 legs of the default run")
     ap.add_argument("--mode", default="sample", choices=["sample", "train", "rollout"],
                     help="sample (default, BASELINE metric): 10-step DDIM chunks at B=128; train: configs[2]/[3] score-matching steps "
                          "(fwd+bwd+AdamW, DP all-reduce); rollout: configs[4], B=32 environments, router pre-cached per noise level")
@@ -329,6 +487,9 @@ def main():
         res["e2e_mfma_frac"] = round(res["e2e_tflops_per_gpu"] / MFMA_BF16_PEAK_TFLOPS, 4)
         if args.dtype == "bf16":
             res["roofline"] = dominant_kernel_roofline(den, device)
+            if n_gpus == 1 and not args.no_extras:
+                res["layer_kernels"] = layer_kernel_breakdown(den, device)
+                res.update(extra_measurements(M, den, device))
         if n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

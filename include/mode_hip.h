@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MODE_HIP_ABI_VERSION 2
+#define MODE_HIP_ABI_VERSION 3
 
 typedef enum ModeStatus {
   MODE_OK = 0,
@@ -293,6 +293,25 @@ int mode_gelu_bwd(const float* pre, const float* dout, float* dpre, int64_t n, v
  * idx [B or B*T, k] top-k ids, probs [B, E] -> dlogits [B, E]; through renormalisation, clamp and softmax (SURVEY §8 a-bis). */
 int mode_moe_router_bwd(const float* dw, const int32_t* idx, const float* probs, int B, int T, int E, int k, int normalize,
                         int idx_per_token, float* dlogits, void* stream);
+/* Same, plus the gradients of the two auxiliary router losses of the reference (MoDeDiT.load_balancing_loss modedit.py:898-928 with the
+ * per-block term of :586-593, and compute_router_z_loss :930-969; composed into the training loss at mode_agent.py:413-419).  The B rows
+ * are `B / rows_per_layer` layers of `rows_per_layer` conditioning rows each.
+ *   lb_coef [layers, E] (device, NULL = off): d(loss)/d(router_probs[n, e]) for every token n that selected expert e - the load-balancing
+ *     term is linear in the (renormalised) combine weights: coefficient = dLB * E * f_e / (layers * N), f_e = fraction of tokens on expert e;
+ *     it is added to dw before the renormalisation / clamp / softmax backward.
+ *   shifted [B, E] max-shifted logits + z_coef (device scalar, NULL = off) = dZ * 2 / (layers * rows_per_layer):
+ *     dlogits += z_coef * z * exp(l) / (sum exp(l) + 1e-6), z = log(sum exp(l) + 1e-6), pushed through the max-shift (the arg-max column
+ *     receives minus the row sum, like autograd through `logits - logits.max()`). */
+int mode_moe_router_bwd_aux(const float* dw, const int32_t* idx, const float* probs, const float* shifted, const float* lb_coef,
+                            const float* z_coef, int B, int rows_per_layer, int T, int E, int k, int normalize, int idx_per_token,
+                            float* dlogits, void* stream);
+/* EDM preconditioning of the score-matching loss (GCDenoiser.loss, score_wrappers.py:45-63) around the training chain, one launch each:
+ *   mode_edm_noise_scale : x_scaled = (action + noise * sigma_b) * c_in(sigma_b)                       [B, n] (n = A_len * A_dim)
+ *   mode_edm_loss        : target = (action - c_skip * noised) / c_out; loss = mean((F - target)^2) (fixed-order reduction, one workgroup);
+ *                          dF = 2 (F - target) / (B n)  (gradient of the loss for a unit upstream gradient) */
+int mode_edm_noise_scale(const float* action, const float* noise, const float* sigma, float sigma_data, int B, int n, float* x_scaled, void* stream);
+int mode_edm_loss(const float* F, const float* action, const float* noise, const float* sigma, float sigma_data, int B, int n, float* loss,
+                  float* dF, void* stream);
 /* pos_emb gradient (modedit.py:760-790): dx0 [B, T, D] gradient of the embedded token sequence -> dpos [1 + A_len, D]; row 0 <- goal token,
  * row 1 <- the n_img image tokens + first action token, row 1+a <- action token a.  t0 = 1 when the sigma token is part of the sequence. */
 int mode_pos_emb_bwd(const float* dx0, int B, int T, int D, int t0, int n_img, int A_len, float* dpos, void* stream);
@@ -459,6 +478,10 @@ typedef struct ModeTrainArgs {
                                     gradients of block l (wqkv, bqkv, wo, w1, b1, w2) are written — blocks finish in the order L-1 … 0,
                                     so a data-parallel reducer can exchange block l's gradient slice while earlier blocks are still
                                     back-propagating (replaces DDP's autograd-hook bucketing, mode/training_calvin.py:92-103) */
+  /* auxiliary router losses (backward only; all NULL = off): see mode_moe_router_bwd_aux */
+  const float* shifted;          /* [L, B, E] max-shifted router logits (mode_dit_route)     */
+  const float* aux_lb_coef;      /* [L, E] device                                            */
+  const float* aux_z_coef;       /* device scalar                                            */
 } ModeTrainArgs;
 int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes,
                            void* stream);

@@ -55,17 +55,17 @@ static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
 }
 
 int g_fuse_ln2 = 1;     // "fuse_ln2" option: 1 = ln_2 folded into the c_proj epilogue / up-projection epilogue / combine (bf16 path), 0 = its own kernel
-int g_dn_split_k = 0;   // "dn_split_k" option: K-slices of the inference-path expert down-projection (0 = default 2, 1 = off, <= 8)
+int g_dn_split_k = 0;   // "dn_split_k" option: K-slices of the inference-path expert down-projection (0 = default 4, 1 = off, <= 8)
 
-// The expert down-projection [NK, 4D] x [D, 4D]^T has few output tiles (NK*D / 128^2 = 224 at B=128, 56 at B=32) and a long K, so the
-// 256 CUs are not covered by whole-K tiles.  K is cut into TWO slices whose bf16 partial slabs the combine / head kernel adds in slice
-// order (scripts/gemm_bench.py --only gemm2 --y-bf16 --splitk 2: B=128 44.6 -> 38.2 us with 128x128 tiles, B=64 31.9 -> 26.6 us and
-// B=32 29.4 -> 21.9 us with 128x64 tiles; in the chain 466 -> 486 denoise-steps/s).  The slice count is the same for EVERY batch size —
-// 4 slices would be faster still at B=32 (19.0 us) — so that a sample's result does not depend on how many samples share its batch
-// (bit-exact batch-slice consistency, tests/test_gpu_model.py::test_c2_full_size_properties).
+// The expert down-projection [NK, 4D] x [D, 4D]^T has few output tiles (16 x 4 tiles of 224 x 256 at B=128) and a long K, so the 256 CUs are
+// not covered by whole-K tiles.  K is cut into FOUR slices whose bf16 partial slabs the combine / head kernel adds in slice order: at B=128 that
+// is exactly one 224x256x1024 tile per CU for the persistent ping-pong kernel (scripts/pp_probe.py: 30.2 us against 33.7 us for two slices of
+// 128x128 tiles; 540 -> 549 denoise-steps/s in the chain), at B=32 twice the workgroups of two slices (19.0 vs 21.9 us).  The slice count is
+// the same for EVERY batch size so that a sample's result does not depend on how many samples share its batch (bit-exact batch-slice
+// consistency, tests/test_gpu_model.py::test_c2_full_size_properties).
 static int down_proj_split(int dt, int K) {
   if (dt != MODE_BF16) return 1;
-  int s = g_dn_split_k > 0 ? g_dn_split_k : 2;
+  int s = g_dn_split_k > 0 ? g_dn_split_k : 4;
   while (s > 1 && K % (64 * s)) s /= 2;
   return s;
 }

@@ -385,11 +385,14 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     // dlogits through renormalisation / clamp / softmax: all layers in one launch when the expert ids of the layers are adjacent
     const long idx_rows = a->idx_per_token ? (long)N : (long)B;
     if (a->topk_layer_stride == idx_rows * d.k) {
-      if ((rc = mode_moe_router_bwd(dwt, a->topk_idx, a->probs, Ly * B, T, E, d.k, d.router_normalize, a->idx_per_token, dlog, stream))) return rc;
+      if ((rc = mode_moe_router_bwd_aux(dwt, a->topk_idx, a->probs, a->shifted, a->aux_lb_coef, a->shifted ? a->aux_z_coef : nullptr, Ly * B, B, T, E, d.k,
+                                        d.router_normalize, a->idx_per_token, dlog, stream))) return rc;
     } else {
       for (int l = 0; l < Ly; ++l)
-        if ((rc = mode_moe_router_bwd(dwt + (size_t)l * NK, a->topk_idx + (long)l * a->topk_layer_stride, a->probs + (long)l * B * E, B, T, E, d.k,
-                                      d.router_normalize, a->idx_per_token, dlog + (long)l * B * E, stream))) return rc;
+        if ((rc = mode_moe_router_bwd_aux(dwt + (size_t)l * NK, a->topk_idx + (long)l * a->topk_layer_stride, a->probs + (long)l * B * E,
+                                          a->shifted ? a->shifted + (long)l * B * E : nullptr, a->aux_lb_coef ? a->aux_lb_coef + (long)l * E : nullptr,
+                                          a->shifted ? a->aux_z_coef : nullptr, B, B, T, E, d.k, d.router_normalize, a->idx_per_token,
+                                          dlog + (long)l * B * E, stream))) return rc;
     }
     if ((rc = colsum(dlog, E, Ly * B, E, MODE_F32, nullptr, B, Ly, g0.r_b3, 0))) return rc;                    // db3 [L][E]
     if ((rc = mode_router_mlp_bwd(dlog, a->r_pre, w0.r_w3, Ly, B, E, H2, dpre, g0.r_w3, stream))) return rc;  // dpre, dW3

@@ -307,9 +307,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
             const int n = min(n0 + nl, p.N - 4);
             const float4 bp = *reinterpret_cast<const float4*>(bias + n);
             const float4 bg = *reinterpret_cast<const float4*>(bias + p.N + n);
-            const f32x4 v = acc[i][j] * rs[i], gt = acc[i][j + FN / 2] * rs[i];
-            const float o0 = (v[0] + bp.x) * silu_f(gt[0] + bg.x), o1 = (v[1] + bp.y) * silu_f(gt[1] + bg.y);
-            const float o2 = (v[2] + bp.z) * silu_f(gt[2] + bg.z), o3 = (v[3] + bp.w) * silu_f(gt[3] + bg.w);
+            const f32x4 v = acc[i][j], gt = acc[i][j + FN / 2];
+            const float o0 = swiglu_f(v[0], gt[0], rs[i], bp.x, bg.x), o1 = swiglu_f(v[1], gt[1], rs[i], bp.y, bg.y);
+            const float o2 = swiglu_f(v[2], gt[2], rs[i], bp.z, bg.z), o3 = swiglu_f(v[3], gt[3], rs[i], bp.w, bg.w);
             if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(cpos(nl)) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
             else *reinterpret_cast<float4*>(cpos(nl)) = make_float4(o0, o1, o2, o3);
           }
@@ -398,10 +398,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
 
 // ------------------------------------------------------------------------------------------------------------ host side
 // geometry ids (also the values of the "gemm_cfg" option; 0 = auto)
-enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x128_NS3 = 2, CFG_256x128_NS3 = 3, CFG_128x64_NS3 = 4, CFG_128x64_NS4 = 5,
-       CFG_128x128_NS1 = 6, CFG_128x64_NS1 = 7, CFG_128x64_NS2 = 8, CFG_256x256_NS2 = 9, CFG_256x128_NS2 = 10, CFG_256x256_W16 = 11, CFG_P256 = 12, CFG_128x128_NS1_4WG = 13, CFG_64x64_NS3 = 14, CFG_64x64_NS2 = 15, CFG_PP256 = 16, CFG_PP224 = 17 };
+// (ids 2, 3, 5, 7, 9-12, 15 were measured-and-rejected geometries of round 1 - deeper rings, 256-wide one-barrier tiles, a persistent 256x256 kernel with
+// a serial epilogue - removed once the ping-pong kernel superseded them; the numbers stay in DESIGN.md)
+enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x64_NS3 = 4, CFG_128x128_NS1 = 6, CFG_128x64_NS2 = 8, CFG_128x128_NS1_4WG = 13, CFG_64x64_NS3 = 14,
+       CFG_PP256 = 16, CFG_PP224 = 17 };
 int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p, int rows224, hipStream_t s);   // gemm_bf16_pp.hip: persistent ping-pong 8-phase kernel
-int gemm_bf16_p256_launch(const ModeGemmDesc* d, hipStream_t s);   // gemm_bf16_p256.hip: persistent 256x256 with cross-tile operand prefetch
 int gemm_bf16_skinny_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_skinny.hip: weight streamer for a handful of rows
 int g_gemm_cfg = CFG_AUTO;
 int g_gemm_setprio = 1;
@@ -434,21 +435,12 @@ template <int EPI, bool OUT_BF16>
 static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipStream_t s) {
   switch (cfg) {
     case CFG_128x128_NS2: return launch_cfg<128, 128, 2, 2, 2, EPI, OUT_BF16>(p, d, s);
-    case CFG_128x128_NS3: return launch_cfg<128, 128, 2, 2, 3, EPI, OUT_BF16>(p, d, s);
-    case CFG_256x128_NS3: return launch_cfg<256, 128, 4, 2, 3, EPI, OUT_BF16>(p, d, s);
     case CFG_128x64_NS3: return launch_cfg<128, 64, 2, 2, 3, EPI, OUT_BF16>(p, d, s);
-    case CFG_128x64_NS4: return launch_cfg<128, 64, 2, 2, 4, EPI, OUT_BF16>(p, d, s);
     case CFG_128x128_NS1: return launch_cfg<128, 128, 2, 2, 1, EPI, OUT_BF16>(p, d, s);
-    case CFG_128x64_NS1: return launch_cfg<128, 64, 2, 2, 1, EPI, OUT_BF16>(p, d, s);
     case CFG_128x64_NS2: return launch_cfg<128, 64, 2, 2, 2, EPI, OUT_BF16>(p, d, s);
-    case CFG_256x256_NS2: return launch_cfg<256, 256, 2, 4, 2, EPI, OUT_BF16>(p, d, s);
-    case CFG_256x128_NS2: return launch_cfg<256, 128, 4, 2, 2, EPI, OUT_BF16>(p, d, s);
-    case CFG_256x256_W16: return launch_cfg<256, 256, 4, 4, 2, EPI, OUT_BF16>(p, d, s);
     case CFG_128x128_NS1_4WG: return launch_cfg<128, 128, 2, 2, 1, EPI, OUT_BF16, 4>(p, d, s);   // <= 128 VGPRs: four 32-KiB workgroups per CU
     case CFG_64x64_NS3:
       if constexpr (EPI == MODE_EPI_SWIGLU) return MODE_ERR_UNSUPPORTED; else return launch_cfg<64, 64, 2, 2, 3, EPI, OUT_BF16>(p, d, s);
-    case CFG_64x64_NS2:
-      if constexpr (EPI == MODE_EPI_SWIGLU) return MODE_ERR_UNSUPPORTED; else return launch_cfg<64, 64, 2, 2, 2, EPI, OUT_BF16>(p, d, s);
     default: return MODE_ERR_BAD_ARG;
   }
 }
@@ -528,10 +520,6 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
     if (rc != MODE_ERR_UNSUPPORTED) return rc;
     const int keep = g_gemm_pp;                                    // shapes / epilogues the ping-pong kernel does not take
     g_gemm_pp = 0; cfg = pick_cfg(d); g_gemm_pp = keep;
-  }
-  if (cfg == CFG_P256) {
-    if (p.split_k > 1 || p.koffs || p.ss_in || d->epilogue == MODE_EPI_RESIDUAL_NORM) return MODE_ERR_UNSUPPORTED;
-    return gemm_bf16_p256_launch(d, s);
   }
   const bool ob = d->out_dtype == MODE_BF16;
 #define MODE_CASE(E) \

@@ -38,7 +38,8 @@ constexpr int LDS_A = 0;                                   // A[t][h] at (t*2+h)
 constexpr int LDS_B = 4 * HALF_BYTES;                      // W[t][h] at 64 KiB + (t*2+h) * 16 KiB
 constexpr int LDS_BIAS = 8 * HALF_BYTES;                   // 8 x 1 KiB: one bias slot per wave (each wave DMAs and reads its own copy)
 constexpr int LDS_NRM = LDS_BIAS + 8 * 1024;               // 2 x 256 floats: inverse row norms of the fused ln_2 (double-buffered per restart)
-constexpr int LDS_TOTAL = LDS_NRM + 2 * 1024;
+constexpr int LDS_SS = LDS_NRM + 2 * 1024;                 // 256 rows x 64 B: per-64-column partial sums of squares of the tile's rows (DMA'd at a restart)
+constexpr int LDS_TOTAL = LDS_SS + 256 * 64;               // 154 KiB of the CU's 160
 constexpr int GM = 8;                                      // m-tiles per rasterisation band
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -60,6 +61,13 @@ __device__ __forceinline__ void lds_read_f4(float4& dst, uint32_t addr) {
 }
 __device__ __forceinline__ void lds_read_f1(float& dst, uint32_t addr) {
   asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_write_u4(uint32_t addr, u32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_read_u4(u32x4& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
 }
 template <int V>
 using IC = std::integral_constant<int, V>;
@@ -180,7 +188,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   bool fresh = true;
-  const bool ab_mma = p.pp_flags & 2, ab_rd = p.pp_flags & 4, ab_dma = p.pp_flags & 8, ab_st = p.pp_flags & 16, ab_act = p.pp_flags & 32;      // timing ablations (results are garbage)
+  const bool ab_mma = p.pp_flags & 2, ab_rd = p.pp_flags & 4, ab_dma = p.pp_flags & 8, ab_st = p.pp_flags & 16;
+  const bool early_resident = !(p.pp_flags & 32);           // A/B switch: 32 = the epilogue's stores are issued without the vmcnt(0) in front (first-pair phase-4 wait kept)      // timing ablations (results are garbage)
   auto rdA = [&](auto T_, auto H_) {
     if (ab_rd) return;
     constexpr int t = decltype(T_)::value, h = decltype(H_)::value;
@@ -261,43 +270,35 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
       const int last = cur.row_end - 1;
       Ak = reinterpret_cast<const char*>(p.A) + (long)cur.slice * nk * BKK * 2;
       Wc = w_tile_base(cur);
-      // ONE dependent round trip: the gathered-row indices of this lane's four DMA pieces and of "its" tile row (fused ln_2), together
-      int srow[2][2];
+      // ONE dependent round trip: the gathered-row indices of this lane's four A pieces and of its two norm-row pieces (fused ln_2), together
+      const bool do_nrm = SWI && p.ss_in;
+      int srow[2][2], nrow[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < 2; ++q) srow[h][q] = min(cur.row0 + h * 128 + (wave * 2 + q) * 8 + r8, last);   // rows past the segment re-read a valid row (never stored)
-      int nrow = min(cur.row0 + (tid & 255), last);
-      if (p.a_rows) {                                              // condition hoisted: five independent loads
-        int tok[2][2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) nrow[q] = min(cur.row0 + (wave * 2 + q) * 16 + (lane >> 2), last);
+      if (p.a_rows) {                                              // condition hoisted: six independent loads
+        int tok[2][2], ntok[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int q = 0; q < 2; ++q) tok[h][q] = p.a_rows[srow[h][q]];
-        const int ntok = p.a_rows[nrow];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ntok[q] = do_nrm ? p.a_rows[nrow[q]] : 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int q = 0; q < 2; ++q) srow[h][q] = tok[h][q];
-        nrow = ntok;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) nrow[q] = ntok[q];
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < 2; ++q) a_off[h][q] = (uint32_t)(((long)srow[h][q] * p.lda + lchunk * 8) * 2);
       if (L == wg * R) stamp(6);                                 // gathered-row indices landed
-      // then everything else in flight together: the partial sums of squares (fused ln_2), the W half-tiles, the A half-tiles
-      [[maybe_unused]] float v[16];
-      const bool do_nrm = SWI && p.ss_in && tid < 256;
-      if constexpr (SWI) {
-        if (do_nrm) {
-          const float* sp = p.ss_in + (long)nrow * p.ss_n;
-          const int nss = p.ss_n;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) v[j] = sp[min(j, nss - 1)];
-        }
-        asm volatile("" ::: "memory");                            // keep the loads above the DMA issue
-      }
       stage(_1, _0, _0, Wc, b_off[0], b_off[1]);
       stage(_0, _0, _0, Ak, a_off[0][0], a_off[0][1]);
       stage(_1, _0, _1, Wc + w_half, b_off[0], b_off[1]);
@@ -305,10 +306,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
       stage(_1, _1, _0, Wc + 128, b_off[0], b_off[1]);
       stage(_0, _1, _0, Ak + 128, a_off[0][0], a_off[0][1]);
       stage(_1, _1, _1, Wc + w_half + 128, b_off[0], b_off[1]);
+      if (stage_a1) stage(_0, _1, _1, Ak + 128, a_off[1][0], a_off[1][1]);
       if constexpr (SWI) {
-        // fused ln_2 consumer: 1 / max(|x_row| K^-1/2, eps) per tile row from the producer's per-64-column partial sums (summation order of
-        // gemm_bf16.hip: p_j = v_j + v_{j+8}, then the xor-shuffle tree ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)))
+        // fused ln_2 consumer: the tile rows' per-64-column partial sums of squares (64 B per token row) come in by DMA as well - 16 rows per
+        // instruction, 4 lanes per row - instead of 16 scattered dword loads per row (measured: those loads, 4096 cache-line requests per
+        // workgroup, queue in front of the operand DMA and cost ~10k cycles of start-up)
         if (do_nrm) {
+          const int chunk = (lane & 3) * 4 < p.ss_n ? (lane & 3) : 0;   // D < 1024: fewer than 16 partials per row; the reader ignores the rest
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ss_in + (long)nrow[q] * p.ss_n + chunk * 4),
+                                             (__attribute__((address_space(3))) void*)(smem + LDS_SS + (wave * 2 + q) * 1024), 16, 0, 0);
+        }
+      }
+      // K-steps 0 and 1 complete and waited for: the state in which every output tile begins (see the epilogue)
+      wait_vmcnt<0>();
+      PP_BAR();
+      if constexpr (SWI) {
+        // 1 / max(|x_row| K^-1/2, eps) per tile row (summation order of gemm_bf16.hip: p_j = v_j + v_{j+8}, then the xor-shuffle tree
+        // ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7))) -> LDS strip read by the epilogues (any number of barriers later)
+        if (do_nrm && tid < 256) {
+          const float4* sp = reinterpret_cast<const float4*>(smem + LDS_SS + tid * 64);
+          const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3];
+          const float v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
           const int nss = p.ss_n;
           float pj[8];
 #pragma unroll
@@ -318,12 +338,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
           reinterpret_cast<float*>(smem + LDS_NRM)[nrm_par * 256 + tid] = __frcp_rn(fmaxf(__fsqrt_rn(ssum) * rk, p.ss_eps));
         }
       }
-      if (L == wg * R) stamp(7);                                 // inverse row norms written
-      // K-step 0 complete, K-step 1 without its A half 1 (phase 1 stages it): the steady state of the loop below.  Everything is waited for:
-      // the last DMA issued is read within the first four phases, too early for the loop's counted waits to have retired it.
-      wait_vmcnt<0>();
+      if (L == wg * R) stamp(7);                                 // operands landed, inverse row norms written
       wait_lgkmcnt<0>();
-      PP_BAR();
       if (wr == 1) PP_BAR();                                     // stagger: wave row 1 runs one barrier behind wave row 0 from here on
       staggered = true;
       PP_SB();
@@ -358,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
                                            (__attribute__((address_space(3))) void*)(smem + LDS_BIAS + wave * 1024), 16, 0, 0);
         }
       }
-      if (stage_a1) stage(_0, _1, _1, A1, a_off[1][0], a_off[1][1]);
+      if (stage_a1 && kt != 0) stage(_0, _1, _1, A1, a_off[1][0], a_off[1][1]);   // (first pair of a tile: K-step 1 is complete already)
       wait_lgkmcnt<8>();                                       // the W fragment reads (issued first) are retired: W[0][0] may be refilled next phase
       PP_COMPUTE(_0, _0)
       // phase 2: (A0, W1)
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
       PP_COMPUTE(_1, _0)
       // phase 4: (A1, W1); K-step kt+1 [buffer 1] retired for the next four phases
       stage(_1, _0, _1, W2 + w_half, b_off[0], b_off[1]);
-      wait_vmcnt<6>();
+      if (kt != 0 || !early_resident) wait_vmcnt<6>();          // (first pair of a tile: K-steps 0 and 1 were resident before it began)
       PP_COMPUTE(_1, _1)
       // phase 5: (A0, W0) of K-step kt+1
       rdB(_1, _0);
@@ -396,15 +412,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
     stamp(2 + 2 * min(L - wg * R, 1));
 
     // ------------------------------------------------------------------------------------------------ epilogue: registers -> global
-    // The two wave rows run it CONCURRENTLY (their VALU / LDS / store work interleaves on the shared SIMDs: measured 3.4k cycles per row when
-    // serialised behind each other by the stagger).  Wave row 0 passes one extra barrier early in its epilogue (after its first fragment row, about when row 1 finishes phase 8) - it pairs with wave row 1's last
-    // phase barrier, so row 1 is released into its epilogue ~one MFMA segment later instead of waiting for row 0's - and wave row 1 passes one
-    // after its epilogue (pairs with row 0's first barrier of the next tile), which restores the one-barrier stagger.  No LDS hazard: the next
-    // tile's first K-steps were waited for by both rows in phase 8, and nothing is staged between the two extra barriers.
-    const bool epi_sync = !(p.pp_flags & 1);
+    // bias / SwiGLU in registers (a lane owns 8 consecutive output columns of a token row), stored straight from registers, 16 bytes per lane.
+    // What makes an epilogue expensive here is not its VALU work but its STORES: CDNA4's vmcnt counts stores, the L2 is write-through, and a
+    // counted wait of the next tile's K loop that is reached before the stores have drained stalls on them (measured: 8.9 us of a 58 us launch;
+    // staging through LDS for whole-row stores cost more in barriers than it saved).  So the order is: (1) the LAST half-tile of the next output
+    // tile's second K-step is requested, (2) all outputs are computed and packed while every DMA still in flight lands, (3) `vmcnt(0)` - by now
+    // free - so K-steps 0 and 1 of the next tile are resident, (4) the stores are issued back to back.  The next tile's first eight phases then
+    // run without any vmcnt wait; the first counted wait (phase 8) comes ~4.5k cycles after the stores were issued.
     {
       const int rows_valid = cur.row_end - cur.row0;
-      char* Cb = reinterpret_cast<char*>(p.C) + ((long)cur.slice * p.split_stride + (long)cur.row0 * p.ldc + (long)cur.n * NOUT + wc * 32 + fq * 8) * ESZ;
+      char* Ct = reinterpret_cast<char*>(p.C) + ((long)cur.slice * p.split_stride + (long)cur.row0 * p.ldc + (long)cur.n * NOUT + wc * 32 + fq * 8) * ESZ;
+      if (cont && stage_a1) stage(_0, _1, _1, Ak + 128, a_off[1][0], a_off[1][1]);      // next tile, K-step 1, A half 1 (its slot was last read in phase 7)
+      // The two wave rows run their epilogues CONCURRENTLY: wave row 0 passes one extra barrier here (it pairs with wave row 1's last phase
+      // barrier, so row 1 is released into its epilogue one MFMA segment later instead of after row 0's whole epilogue) and wave row 1 passes one
+      // after its epilogue (pairs with row 0's first barrier of the next tile), which restores the one-barrier stagger.
+      const bool epi_sync = !(p.pp_flags & 1);
+      if (epi_sync && wr == 0) PP_BAR();
       [[maybe_unused]] float4 bq[2][2];                        // bias of this lane's 8 columns: [W half][4-column group]
       [[maybe_unused]] float rs[2][4];
       if constexpr (HAS_BIAS) {
@@ -431,55 +454,60 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
             for (int i = 0; i < 4; ++i) rs[a][i] = 1.0f;       // x 1.0f is exact
         }
       }
+      // one ROUND = one fragment row (x one 128-column W half when there is no SwiGLU pairing): this lane's 8 outputs of it
+      constexpr int NFR = 4 + FM1, R = SWI ? NFR : 2 * NFR;
+      auto outputs = [&](int r, float (&ov)[8]) {                 // r is a compile-time constant after unrolling
+        const int fi = SWI ? r : r >> 1, a = fi < 4 ? 0 : 1, i = a ? fi - 4 : fi;
+        if constexpr (SWI) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-#pragma unroll
-        for (int i = 0; i < (a ? FM1 : 4); ++i) {
-          if (a == 0 && i == 1) {
-            if (epi_sync && wr == 0) PP_BAR();
+          for (int j = 0; j < 2; ++j) {
+            const f32x4 v = acc[a][0][i][j], gt = acc[a][1][i][j];
+            const float4 bp = bq[0][j], bg = bq[1][j];
+            ov[j * 4 + 0] = swiglu_f(v[0], gt[0], rs[a][i], bp.x, bg.x); ov[j * 4 + 1] = swiglu_f(v[1], gt[1], rs[a][i], bp.y, bg.y);
+            ov[j * 4 + 2] = swiglu_f(v[2], gt[2], rs[a][i], bp.z, bg.z); ov[j * 4 + 3] = swiglu_f(v[3], gt[3], rs[a][i], bp.w, bg.w);
           }
-          const int trow = a * 128 + (a ? wr * 16 * FM1 : wr * 64) + i * 16 + fr;
-          const bool ok = trow < rows_valid && !ab_st;
-          char* crow = Cb + (long)trow * p.ldc * ESZ;
-          if constexpr (SWI) {
-            float ov[8];
+        } else {
+          const int b = r & 1;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const f32x4 v = acc[a][0][i][j] * rs[a][i], gt = acc[a][1][i][j] * rs[a][i];
-              const float4 bp = bq[0][j], bg = bq[1][j];
-              if (ab_act) { ov[j * 4 + 0] = v[0] + gt[0]; ov[j * 4 + 1] = v[1] + gt[1]; ov[j * 4 + 2] = v[2] + gt[2]; ov[j * 4 + 3] = v[3] + gt[3]; continue; }
-              ov[j * 4 + 0] = (v[0] + bp.x) * silu_f(gt[0] + bg.x); ov[j * 4 + 1] = (v[1] + bp.y) * silu_f(gt[1] + bg.y);
-              ov[j * 4 + 2] = (v[2] + bp.z) * silu_f(gt[2] + bg.z); ov[j * 4 + 3] = (v[3] + bp.w) * silu_f(gt[3] + bg.w);
-            }
-            if (ok) {
-              if constexpr (OUT_BF16) {
-                *reinterpret_cast<uint4*>(crow) = make_uint4(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]), pack_bf16x2(ov[4], ov[5]), pack_bf16x2(ov[6], ov[7]));
-              } else {
-                *reinterpret_cast<float4*>(crow) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-                *reinterpret_cast<float4*>(crow + 16) = make_float4(ov[4], ov[5], ov[6], ov[7]);
-              }
-            }
-          } else {
+          for (int j = 0; j < 2; ++j) {
+            f32x4 v = acc[a][b][i][j];
+            if constexpr (HAS_BIAS) { const float4 bb = bq[b][j]; v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+            if constexpr (EPI == MODE_EPI_BIAS_GELU) { v[0] = gelu_erf_f(v[0]); v[1] = gelu_erf_f(v[1]); v[2] = gelu_erf_f(v[2]); v[3] = gelu_erf_f(v[3]); }
+            ov[j * 4 + 0] = v[0]; ov[j * 4 + 1] = v[1]; ov[j * 4 + 2] = v[2]; ov[j * 4 + 3] = v[3];
+          }
+        }
+      };
+      auto round_row = [&](int r) { const int fi = SWI ? r : r >> 1, a = fi < 4 ? 0 : 1, i = a ? fi - 4 : fi;
+                                    return a * 128 + (a ? wr * 16 * FM1 : wr * 64) + i * 16 + fr; };
+      auto round_col = [&](int r) { return SWI ? 0 : (r & 1) * 128; };
+      if constexpr (OUT_BF16) {
+        u32x4 pk[R];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-              float ov[8];
+        for (int r = 0; r < R; ++r) {
+          float ov[8];
+          outputs(r, ov);
+          pk[r] = u32x4{pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]), pack_bf16x2(ov[4], ov[5]), pack_bf16x2(ov[6], ov[7])};
+        }
 #pragma unroll
-              for (int j = 0; j < 2; ++j) {
-                f32x4 v = acc[a][b][i][j];
-                if constexpr (HAS_BIAS) { const float4 bb = bq[b][j]; v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-                if constexpr (EPI == MODE_EPI_BIAS_GELU) { v[0] = gelu_erf_f(v[0]); v[1] = gelu_erf_f(v[1]); v[2] = gelu_erf_f(v[2]); v[3] = gelu_erf_f(v[3]); }
-                ov[j * 4 + 0] = v[0]; ov[j * 4 + 1] = v[1]; ov[j * 4 + 2] = v[2]; ov[j * 4 + 3] = v[3];
-              }
-              if (ok) {
-                char* c = crow + b * 128 * ESZ;
-                if constexpr (OUT_BF16) {
-                  *reinterpret_cast<uint4*>(c) = make_uint4(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]), pack_bf16x2(ov[4], ov[5]), pack_bf16x2(ov[6], ov[7]));
-                } else {
-                  *reinterpret_cast<float4*>(c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-                  *reinterpret_cast<float4*>(c + 16) = make_float4(ov[4], ov[5], ov[6], ov[7]);
-                }
-              }
-            }
+        for (int r = 0; r < R; ++r) asm volatile("" : "+v"(pk[r]));      // every output is computed before the wait below
+        if (early_resident) wait_vmcnt<0>();
+        PP_SB();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int trow = round_row(r);
+          if (trow < rows_valid && !ab_st) *reinterpret_cast<u32x4*>(Ct + ((long)trow * p.ldc + round_col(r)) * 2) = pk[r];
+        }
+      } else {
+        if (early_resident) wait_vmcnt<0>();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float ov[8];
+          outputs(r, ov);
+          const int trow = round_row(r);
+          if (trow < rows_valid && !ab_st) {
+            float* c = reinterpret_cast<float*>(Ct) + (long)trow * p.ldc + round_col(r);
+            *reinterpret_cast<float4*>(c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            *reinterpret_cast<float4*>(c + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
           }
         }
       }
@@ -491,8 +519,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (epi_sync && wr == 1) PP_BAR();
     }
-    if (epi_sync && wr == 1) PP_BAR();
     stamp(3 + 2 * min(L - wg * R, 1));
     if (!has_next) break;
     ++L;
@@ -555,7 +583,7 @@ int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, int rows224
   if (d->k_group_offsets || d->N % nout || d->K % (128 * S) || d->K / S < 128) return MODE_ERR_UNSUPPORTED;
   if (d->expert_offsets && d->num_experts > 8) return MODE_ERR_UNSUPPORTED;
   if (d->ldc % 8 || (reinterpret_cast<uintptr_t>(d->C) & 15) || (S > 1 && d->split_stride % 8)) return MODE_ERR_UNSUPPORTED;
-  if (d->row_ss && d->row_ss_n > 16) return MODE_ERR_UNSUPPORTED;   // fused ln_2 partial sums: D <= 1024
+  if (d->row_ss && (d->row_ss_n > 16 || d->row_ss_n % 4 || (reinterpret_cast<uintptr_t>(d->row_ss) & 15))) return MODE_ERR_UNSUPPORTED;   // fused ln_2 partial sums: D <= 1024, D % 256 == 0
   // 32-bit per-lane byte offsets: both operands must span < 4 GiB from their bases
   const long wrows = (epi == MODE_EPI_SWIGLU ? 2L : 1L) * d->N;   // gathered A rows are token ids < M (M = tokens x top_k sorted rows)
   if (wrows * d->ldw * 2 >= (1L << 32) || (long)d->M * d->lda * 2 >= (1L << 32)) return MODE_ERR_UNSUPPORTED;

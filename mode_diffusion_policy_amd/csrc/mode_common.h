@@ -53,6 +53,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup, serialised through VCC) - measured 5.5k cycles for the 56 outputs per lane of a
 // 224x256 SwiGLU tile epilogue against ~2k with this form.  Every kernel of the library shares this function (forward = backward = all tile shapes).
 __device__ __forceinline__ float silu_f(float g) { return g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)); }
+// One SwiGLU output from the value / gate accumulators: the fused-ln_2 row scale and the bias add are ONE explicit fma each.  Left to the
+// compiler, `acc * rs + b` is contracted or not depending on the surrounding code, and two tile shapes of the same GEMM then round differently
+// (seen: 505 of 14.7 M outputs one bf16 ulp apart) - every forward GEMM kernel must produce bit-identical results (batch-slice consistency).
+__device__ __forceinline__ float swiglu_f(float acc_v, float acc_g, float rs, float bv, float bg) {
+  return __builtin_fmaf(acc_v, rs, bv) * silu_f(__builtin_fmaf(acc_g, rs, bg));
+}
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // XCD-aware, bijective remap of a linear workgroup id: hardware places block b on XCD b % 8 (observed, speed only), so give
@@ -76,7 +82,7 @@ struct GemmParams {
   const int* koffs; long c_gstride;   // K-groups: blockIdx.z = group, K range [koffs[z], koffs[z+1])
   int group_m;                        // m-tiles per rasterisation group (0 = kernel default)
   int setprio;                        // raise the wave priority around the MFMA clusters ("gemm_setprio" option)
-  int pp_flags;                       // gemm_bf16_pp.hip experiment switches ("pp_flags" option): 1 = serial epilogues, 2/4/8 = timing ablations (no MFMA / no fragment reads / no DMA)
+  int pp_flags;                       // gemm_bf16_pp.hip experiment switches ("pp_flags" option): A/B switches 1 = serial epilogues, 32 = stores ahead of the residency wait; timing ablations 2 / 4 / 8 / 16 = no MFMA / no fragment reads / no DMA in the K loop / no global stores
   // fused ln_2 (MODE_EPI_RESIDUAL_NORM producer / MODE_EPI_SWIGLU consumer): see include/mode_hip.h
   uint16_t* C2; long ldc2; const float* gain; float* ss_out;   // producer: bf16((acc+resid)*gain[n]) and per-64-column row sums of squares
   const float* ss_in; int ss_n; float ss_eps;                   // consumer: acc rows scaled by 1/max(sqrt(sum ss_in[row][0..ss_n)) * K^-1/2, eps)

@@ -431,9 +431,13 @@ __global__ void iota_scale_kernel(int* out, int n, int step) {
 // w = p[S]/sum(p[S]) (router_normalize) or p[S]; p = clamp(softmax(l), 1e-9, 1-1e-9)   (modedit.py:345-349, 398-399, 418-419)
 template <int EMAX>
 __global__ void router_bwd_kernel(const float* __restrict__ dw, const int* __restrict__ idx, const float* __restrict__ probs, int B, int T, int E,
-                                  int k, int normalize, int idx_per_token, float* __restrict__ dlogits) {
+                                  int k, int normalize, int idx_per_token, float* __restrict__ dlogits, const float* __restrict__ shifted,
+                                  const float* __restrict__ lb_coef, const float* __restrict__ z_coef, int rows_per_layer) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  float lbc[EMAX];                                                       // load-balancing coefficient of this row's layer, per expert
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) lbc[e] = (lb_coef && e < E) ? lb_coef[(long)(b / rows_per_layer) * E + e] : 0.f;
   float dp[EMAX], p[EMAX];                                             // compile-time indexed only: stays in registers
 #pragma unroll
   for (int e = 0; e < EMAX; ++e) { dp[e] = 0.f; p[e] = e < E ? probs[(long)b * E + e] : 0.f; }
@@ -456,15 +460,17 @@ __global__ void router_bwd_kernel(const float* __restrict__ dw, const int* __res
     float s = 0.f, wd = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { pe[j] = j < k ? pick(p, es[j]) : 0.f; s += pe[j]; }
-    float add[8];
+    float add[8], dwj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dwj[j] = j < k ? dw[tok * k + j] + pick(lbc, es[j]) : 0.f;     // + d(gamma * LB) / d(router_probs[tok, e_j])
     if (normalize) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) if (j < k) wd += (pe[j] / s) * dw[tok * k + j];
+      for (int j = 0; j < 8; ++j) if (j < k) wd += (pe[j] / s) * dwj[j];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) add[j] = j < k ? (dw[tok * k + j] - wd) / s : 0.f;
+      for (int j = 0; j < 8; ++j) add[j] = j < k ? (dwj[j] - wd) / s : 0.f;
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) add[j] = j < k ? dw[tok * k + j] : 0.f;
+      for (int j = 0; j < 8; ++j) add[j] = dwj[j];
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -479,9 +485,69 @@ __global__ void router_bwd_kernel(const float* __restrict__ dw, const int* __res
       dot += dp[e] * p[e];
     }
   }
+  float dl[EMAX];
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) dl[e] = e < E ? p[e] * (dp[e] - dot) : 0.f;
+  if (shifted && z_coef) {
+    // router z-loss (modedit.py:930-969) on the max-shifted logits l: Z_row = log(sum_e exp(l_e) + 1e-6)^2;  the shift l = logits - max(logits)
+    // is differentiated like autograd does: the arg-max column (first one on a tie, torch.max) receives minus the row sum
+    float l[EMAX], ex[EMAX], S = 0.f;
+    int amax = 0;
+    float lmax = -3.4e38f;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+      l[e] = e < E ? shifted[(long)b * E + e] : -3.4e38f;
+      ex[e] = e < E ? __expf(l[e]) : 0.f;
+      S += ex[e];
+      if (e < E && l[e] > lmax) { lmax = l[e]; amax = e; }
+    }
+    const float zc = z_coef[0] * __logf(S + 1e-6f) / (S + 1e-6f);
+    float gsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) gsum += zc * ex[e];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) dl[e] += zc * ex[e] - (e == amax ? gsum : 0.f);
+  }
 #pragma unroll
   for (int e = 0; e < EMAX; ++e)
-    if (e < E) dlogits[(long)b * E + e] = p[e] * (dp[e] - dot);
+    if (e < E) dlogits[(long)b * E + e] = dl[e];
+}
+
+// ---- EDM preconditioning of the score-matching loss (score_wrappers.py:31-63)
+__global__ __launch_bounds__(256) void edm_noise_scale_kernel(const float* __restrict__ action, const float* __restrict__ noise, const float* __restrict__ sigma,
+                                                              float sd, int B, int n, float* __restrict__ xs) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * n) return;
+  const float s = sigma[i / n];
+  const float c_in = 1.0f / __fsqrt_rn(s * s + sd * sd);
+  xs[i] = (action[i] + noise[i] * s) * c_in;
+}
+// one workgroup, fixed summation order (deterministic): B * n is a few thousand elements
+__global__ __launch_bounds__(1024) void edm_loss_kernel(const float* __restrict__ F, const float* __restrict__ action, const float* __restrict__ noise,
+                                                        const float* __restrict__ sigma, float sd, int B, int n, float* __restrict__ loss, float* __restrict__ dF) {
+  __shared__ float red[16];
+  const long tot = (long)B * n;
+  const float inv = 1.0f / (float)tot;
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < tot; i += 1024) {
+    const float s = sigma[i / n];
+    const float s2 = s * s + sd * sd;
+    const float c_skip = sd * sd / s2, c_out = s * sd / __fsqrt_rn(s2);
+    const float noised = action[i] + noise[i] * s;
+    const float target = (action[i] - c_skip * noised) / c_out;
+    const float d = F[i] - target;
+    acc += d * d;
+    dF[i] = 2.0f * d * inv;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    loss[0] = t * inv;
+  }
 }
 
 // pos_emb backward (modedit.py:760-790: row 0 is added to the goal token, row 1 to BOTH image tokens and the first action token, row 1+a
@@ -670,9 +736,36 @@ extern "C" int mode_moe_router_bwd(const float* dw, const int32_t* idx, const fl
                                    int idx_per_token, float* dlogits, void* stream) {
   if (!dw || !idx || !probs || !dlogits || B < 0 || E <= 0 || E > 64 || k <= 0 || k > 8 || k > E) return MODE_ERR_BAD_ARG;
   if (B == 0) return MODE_OK;
-#define MODE_RB(EM) hipLaunchKernelGGL(router_bwd_kernel<EM>, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, dw, idx, probs, B, T, E, k, normalize, idx_per_token, dlogits)
+  return mode_moe_router_bwd_aux(dw, idx, probs, nullptr, nullptr, nullptr, B, B, T, E, k, normalize, idx_per_token, dlogits, stream);
+}
+
+extern "C" int mode_moe_router_bwd_aux(const float* dw, const int32_t* idx, const float* probs, const float* shifted, const float* lb_coef,
+                                       const float* z_coef, int B, int rows_per_layer, int T, int E, int k, int normalize, int idx_per_token,
+                                       float* dlogits, void* stream) {
+  if (!dw || !idx || !probs || !dlogits || B < 0 || E <= 0 || E > 64 || k <= 0 || k > 8 || k > E) return MODE_ERR_BAD_ARG;
+  if ((lb_coef || z_coef) && (rows_per_layer <= 0 || B % rows_per_layer)) return MODE_ERR_BAD_ARG;
+  if (z_coef && !shifted) return MODE_ERR_BAD_ARG;
+  if (rows_per_layer <= 0) rows_per_layer = B > 0 ? B : 1;
+  if (B == 0) return MODE_OK;
+#define MODE_RB(EM) hipLaunchKernelGGL(router_bwd_kernel<EM>, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, dw, idx, probs, B, T, E, k, normalize, idx_per_token, dlogits, shifted, lb_coef, z_coef, rows_per_layer)
   if (E <= 4) MODE_RB(4); else if (E <= 8) MODE_RB(8); else if (E <= 16) MODE_RB(16); else MODE_RB(64);
 #undef MODE_RB
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_edm_noise_scale(const float* action, const float* noise, const float* sigma, float sigma_data, int B, int n, float* x_scaled, void* stream) {
+  if (!action || !noise || !sigma || !x_scaled || B < 0 || n <= 0) return MODE_ERR_BAD_ARG;
+  if (B == 0) return MODE_OK;
+  hipLaunchKernelGGL(edm_noise_scale_kernel, dim3((unsigned)(((long)B * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, action, noise, sigma, sigma_data, B, n, x_scaled);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_edm_loss(const float* F, const float* action, const float* noise, const float* sigma, float sigma_data, int B, int n, float* loss,
+                             float* dF, void* stream) {
+  if (!F || !action || !noise || !sigma || !loss || !dF || B <= 0 || n <= 0) return MODE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(edm_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, F, action, noise, sigma, sigma_data, B, n, loss, dF);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }

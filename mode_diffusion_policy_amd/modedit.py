@@ -289,29 +289,67 @@ class MoDeDiT(nn.Module):
         self._account_usage(meta, ml, N)
         return den
 
-    def _ddim_chain(self, eng, img, goals, x, sigmas, sigma_data: float):
-        """Launch chain of a whole DDIM run; pure launches + tiny torch index math, no host sync -> capturable."""
-        B, T, D, Ly = x.shape[0], self.seq_len, self.embed_dim, self.num_layers
-        n = sigmas.numel() - 1
-        sig, nxt = sigmas[:-1].contiguous(), sigmas[1:]
-        s2 = sig * sig + sigma_data ** 2
-        c_in = (1.0 / s2.sqrt()).contiguous()
-        scal = torch.stack([sigma_data ** 2 / s2, sig * sigma_data / s2.sqrt(), nxt / sig, torch.zeros_like(sig)], 1).contiguous()
-        emb_all = eng.sigma_embed(sig)                                   # [n, D]: one conditioning row per step
-        img_e, goal_e = eng.embed_obs(img, goals)                        # step-invariant, hoisted (modedit.py:760,765)
-        idx, w, _, _ = eng.route(emb_all)                                # [L, n, k]: routing for ALL steps up front
+    def _schedule_state(self, eng, sig, B, sigma_data: float, out=None):
+        """Everything of a DDIM run that depends on the noise SCHEDULE only (not on the observations): per-step EDM scalings, the sigma
+        embeddings, and the routing of all steps and layers with its dispatch records.  The reference resolves the same thing once per noise level
+        and caches it (precompute_experts_for_inference / the cache read at modedit.py:542-546); here it is a set of device tensors the captured
+        launch chain reads.  Routing decisions cached by ``precompute_experts_for_inference`` for these exact sigma values (and these weights) are
+        CONSUMED here - no router launch at all; otherwise the fp32 router runs on the device.  With ``out`` the results are written in place
+        (the graph has the pointers baked in)."""
+        T, Ly = self.seq_len, self.num_layers
+        n = sig.numel() - 1
+        s, nxt = sig[:-1].contiguous(), sig[1:]
+        s2 = s * s + sigma_data ** 2
+        st = dict(c_in=(1.0 / s2.sqrt()).contiguous(),
+                  scal=torch.stack([sigma_data ** 2 / s2, s * sigma_data / s2.sqrt(), nxt / s, torch.zeros_like(s)], 1).contiguous(),
+                  emb_all=eng.sigma_embed(s))                            # [n, D]: one conditioning row per step
+        cached = None
+        if all(blk.fused_experts for blk in self.blocks) and getattr(self, "_fused_for", None) == eng._wkey:
+            keys = [float(v) for v in s.tolist()]                        # (host sync: only when the schedule state is (re)built)
+            if all(k_ in blk.fused_experts for blk in self.blocks for k_ in keys):
+                cached = keys
+        if cached is not None:
+            idx = torch.tensor([[blk.fused_experts[k_][0] for k_ in cached] for blk in self.blocks], dtype=torch.int32, device=eng.device)
+            w = torch.tensor([[blk.fused_experts[k_][1] for k_ in cached] for blk in self.blocks], dtype=torch.float32, device=eng.device)
+        else:
+            idx, w, _, _ = eng.route(st["emb_all"])                      # [L, n, k]: routing for ALL steps up front
         N = B * T
-        meta = eng.dispatch(idx, w, Ly * n, 1, N, N)                     # record (l, s) at l*n + s
-        ml = eng.meta_layout(N)
+        st.update(idx=idx.contiguous(), w=w.contiguous(), meta=eng.dispatch(idx.contiguous(), w.contiguous(), Ly * n, 1, N, N), from_cache=cached is not None)
+        if out is None:
+            return st
+        for k_ in ("c_in", "scal", "emb_all", "idx", "w", "meta"):
+            out[k_].copy_(st[k_])
+        out["from_cache"] = st["from_cache"]
+        return out
+
+    def _ddim_steps(self, eng, img, goals, x, sched, n: int):
+        """The observation-dependent launch chain of a DDIM run: embeddings of the observations + n denoiser forwards with the fused EDM / DDIM
+        update; pure launches, no host sync -> capturable.  Reads the schedule state by pointer."""
+        B, T = x.shape[0], self.seq_len
+        img_e, goal_e = eng.embed_obs(img, goals)                        # step-invariant, hoisted (modedit.py:760,765)
+        ml = eng.meta_layout(B * T)
+        emb_all, meta, c_in, scal = sched["emb_all"], sched["meta"], sched["c_in"], sched["scal"]
         for s in range(n):
             e = emb_all[s]
             eng.forward(B, e, 0, e, 0, meta.data_ptr() + 4 * s * ml.total_words, n * ml.total_words, goal_e, img_e, x,
                         c_in=c_in.data_ptr() + 4 * s, c_in_stride=0, scal_ptr=scal.data_ptr() + 16 * s, scal_stride=0, x_next=x)
-        return idx, meta, ml
+        return ml
+
+    def _account_ddim_usage(self, sched, ml, n, n_tokens):
+        """Expert-usage counters of a whole DDIM run (modedit.py:568-572, 594): one device-side add per chunk, outside the graph."""
+        Ly, E = self.num_layers, self.num_experts
+        counts = sched["meta"][:, ml.counts: ml.counts + E].view(Ly, n, E).sum(1)
+        if getattr(self, "_usage_dev", None) is None or self._usage_dev.device != counts.device:
+            self._usage_dev = torch.zeros(Ly, E, dtype=torch.int64, device=counts.device)
+        self._usage_dev += counts
+        for blk in self.blocks:
+            blk.total_tokens_processed += n_tokens * n
 
     @torch.no_grad()
     def sample_ddim_fused(self, states, action, goals, sigmas, sigma_data: float):
-        """sample_ddim (gc_sampling.py:922-951) o GCDenoiser o MoDeDiT as one hipGraph replay."""
+        """sample_ddim (gc_sampling.py:922-951) o GCDenoiser o MoDeDiT as one hipGraph replay.  The graph holds only what depends on the
+        observations (embeddings + the denoiser forwards); sigma embeddings, routing, dispatch and the EDM scalings of the schedule live in a
+        schedule state that is rebuilt only when the sigma VALUES, the weights or the batch size change."""
         import os
         eng = self.engine
         dev, B = eng.device, action.shape[0]
@@ -320,9 +358,10 @@ class MoDeDiT(nn.Module):
         img, goals = self._prep_obs(eng, states, goals)
         sig = sigmas.detach().to(device=dev, dtype=torch.float32).contiguous()
         x0 = action.detach().to(device=dev, dtype=torch.float32)
+        n = sig.numel() - 1
         if self.use_goal_in_routing:                                     # routing depends on the sample: per-step generic path
             x = x0.clone()
-            for i in range(sig.numel() - 1):
+            for i in range(n):
                 den = self.denoise({"state_images": img}, x, goals, sig[i].reshape(1), sigma_data)
                 r = sig[i + 1] / sig[i]
                 x = r * x + (1.0 - r) * den
@@ -330,31 +369,43 @@ class MoDeDiT(nn.Module):
         use_graph = os.environ.get("MODE_HIP_GRAPH", "1") != "0"
         if not use_graph:
             x = x0.clone().contiguous()
-            idx, meta, ml = self._ddim_chain(eng, img, goals, x, sig, sigma_data)
-            self._last_topk = idx
+            sched = self._schedule_state(eng, sig, B, sigma_data)
+            ml = self._ddim_steps(eng, img, goals, x, sched, n)
+            self._last_topk = sched["idx"]
+            self._account_ddim_usage(sched, ml, n, B * self.seq_len)
             return x
         key = (B, sig.numel(), eng.compute_dtype, eng._structs_for, str(dev), float(sigma_data))   # arena pointers are static: weight updates keep graphs valid
         ent = self._route_cache.get("graph")
+        # identity of the schedule: the caller's tensor (pointer + version: free), the weights, and the routing cache generation
+        sched_key = (sigmas.data_ptr(), sigmas._version, eng._wkey, getattr(self, "_fused_gen", 0))
         if ent is None or ent["key"] != key:
             st = dict(key=key, img=img.clone(), goals=goals.clone(), x=x0.clone().contiguous(), sig=sig.clone())
             # the graph owns its workspace: the engine's shared scratch buffer is re-allocated whenever a larger chain (a training step, a
             # bigger batch) asks for more, and a replay would then read freed memory
-            n_sig = sig.numel() - 1
-            st["ws"] = torch.empty(max(eng.workspace_bytes(B, 0), eng.workspace_bytes(0, n_sig)), dtype=torch.uint8, device=dev)
+            st["ws"] = torch.empty(max(eng.workspace_bytes(B, 0), eng.workspace_bytes(0, n)), dtype=torch.uint8, device=dev)
             with eng.pinned_workspace(st["ws"]):
+                st["sched"] = self._schedule_state(eng, st["sig"], B, sigma_data)
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):                            # warm-up: loads code objects
-                    self._ddim_chain(eng, st["img"], st["goals"], st["x"], st["sig"], sigma_data)
+                    self._ddim_steps(eng, st["img"], st["goals"], st["x"], st["sched"], n)
                 torch.cuda.current_stream(dev).wait_stream(side)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
-                    st["idx"], st["meta"], st["ml"] = self._ddim_chain(eng, st["img"], st["goals"], st["x"], st["sig"], sigma_data)
-            st["graph"] = g
+                    st["ml"] = self._ddim_steps(eng, st["img"], st["goals"], st["x"], st["sched"], n)
+            st["graph"], st["sched_key"] = g, sched_key
             self._route_cache["graph"] = ent = st
-        ent["img"].copy_(img); ent["goals"].copy_(goals); ent["x"].copy_(x0); ent["sig"].copy_(sig)
+        elif ent["sched_key"] != sched_key:
+            same_values = ent["sched_key"][2:] == sched_key[2:] and bool(torch.equal(sig, ent["sig"]))     # another tensor with the same schedule: one small sync
+            if not same_values:
+                ent["sig"].copy_(sig)
+                with eng.pinned_workspace(ent["ws"]):
+                    self._schedule_state(eng, ent["sig"], B, sigma_data, out=ent["sched"])
+            ent["sched_key"] = sched_key
+        ent["img"].copy_(img); ent["goals"].copy_(goals); ent["x"].copy_(x0)
         ent["graph"].replay()
-        self._last_topk = ent["idx"]
+        self._last_topk = ent["sched"]["idx"]
+        self._account_ddim_usage(ent["sched"], ent["ml"], n, B * self.seq_len)
         return ent["x"].clone()
 
     def _account_usage(self, meta, ml, n_tokens):
@@ -376,12 +427,20 @@ class MoDeDiT(nn.Module):
 
     # ------------------------------------------------------------------ aux losses (training side channel)
     def load_balancing_loss(self):
-        """modedit.py:898-928."""
+        """modedit.py:898-928.  After a training forward this is an output of the HIP autograd node: ``entropy_gamma * load_balancing_loss()``
+        added to the loss back-propagates into the routers (mode_agent.py:413-415)."""
+        aux = getattr(self, "_aux_losses", None)
+        if self.training and aux is not None:
+            return aux[0]
         terms = [b.probs["load_balancing_term"] for b in self.blocks if b.probs is not None]
         return sum(terms) / len(terms) if terms else 0.0
 
     def compute_router_z_loss(self, eps=1e-6):
-        """modedit.py:930-969 (on the max-shifted logits, as the reference does)."""
+        """modedit.py:930-969 (on the max-shifted logits, as the reference does); graph-attached after a training forward like
+        ``load_balancing_loss`` (eps is the reference's default 1e-6 there)."""
+        aux = getattr(self, "_aux_losses", None)
+        if self.training and aux is not None and eps == 1e-6:
+            return aux[1]
         z = [torch.log(torch.exp(lg).sum(-1) + eps).pow(2).mean() for lg in self.logits_per_layer]
         return sum(z) / len(z)
 
@@ -403,13 +462,18 @@ class MoDeDiT(nn.Module):
         idx, w, _, _ = eng.route(cond.contiguous())
         key = float(sig.item())
         idx_h, w_h = idx.cpu(), w.cpu()
+        if getattr(self, "_fused_for", None) != eng._wkey:               # entries made with other weights are stale: drop them
+            self.reset_all_caches()
+            self._fused_for = eng._wkey
         for i, blk in enumerate(self.blocks):
             blk.fused_experts[key] = (idx_h[i, 0].tolist(), w_h[i, 0].tolist())
             blk.routing_info[key] = {"indices": idx_h[i, 0].numpy(), "probs": w_h[i, 0].numpy()}
+        self._fused_gen = getattr(self, "_fused_gen", 0) + 1             # the sampler's schedule state picks the new entries up
 
     def reset_all_caches(self):
         for blk in self.blocks:
             blk.reset_expert_cache()
+        self._fused_gen = getattr(self, "_fused_gen", 0) + 1
 
     def freeze_router(self):
         for blk in self.blocks:

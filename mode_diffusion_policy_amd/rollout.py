@@ -91,10 +91,18 @@ class ChunkedRolloutPolicy:
         self.rollout_step_counter = 0
         self.pred_action_seq: Optional[torch.Tensor] = None
 
+    def _schedule(self, dev) -> torch.Tensor:
+        """The noise schedule of this policy, built once per device: handing the sampler the SAME tensor every call lets it recognise the
+        schedule (pointer + version) without comparing values."""
+        cached = getattr(self, "_sigmas", None)
+        if cached is None or cached.device != torch.device(dev):
+            cached = self._sigmas = get_noise_schedule(self.num_sampling_steps, self.noise_scheduler, self.sigma_min, self.sigma_max, dev)
+        return cached
+
     def precompute_expert_for_inference(self, goal=None) -> None:
         inner = self.model.inner_model
         dev = next(inner.parameters()).device
-        for sigma in get_noise_schedule(self.num_sampling_steps, self.noise_scheduler, self.sigma_min, self.sigma_max, dev)[:-1]:
+        for sigma in self._schedule(dev)[:-1]:
             inner.precompute_experts_for_inference(sigma, goal)
 
     @torch.no_grad()
@@ -106,7 +114,7 @@ class ChunkedRolloutPolicy:
         if self.need_precompute_experts_for_inference:
             self.precompute_expert_for_inference(latent_goal[:1] if self.model.inner_model.use_goal_in_routing else None)
             self.need_precompute_experts_for_inference = False
-        sigmas = get_noise_schedule(self.num_sampling_steps, self.noise_scheduler, self.sigma_min, self.sigma_max, dev)
+        sigmas = self._schedule(dev)
         x = torch.randn((len(latent_goal), self.act_window_size, self.action_dim), device=dev, generator=self.generator) * self.sigma_max
         return sample_loop(self.model, sigmas, x, perceptual_emb, latent_goal, self.sampler_type, extra_args)
 

@@ -422,6 +422,8 @@ def sample_dpm_fast(model, state, action, goal, sigma_min, sigma_max, n, scaler=
     solver = _EpsSolver(run)
     noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
     t_start, t_end = -torch.tensor(sigma_max).log(), -torch.tensor(sigma_min, device=action.device).log()
+    if not t_end > t_start and eta:                                     # gc_sampling.py:591-592
+        raise ValueError("eta must be 0 for reverse sampling")
     m = n // 3 + 1
     ts = torch.linspace(t_start, t_end.cpu(), m + 1, device=action.device)
     orders = [3] * (m - 2) + [2, 1] if n % 3 == 0 else [3] * (m - 1) + [n % 3]

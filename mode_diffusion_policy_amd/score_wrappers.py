@@ -40,7 +40,13 @@ class GCDenoiser(nn.Module):
         return c_skip, c_out, c_in
 
     def loss(self, state, action, goal, noise, sigma, **kwargs):
-        """Score-matching loss (score_wrappers.py:45-63) -> (loss, model_output)."""
+        """Score-matching loss (score_wrappers.py:45-63) -> (loss, model_output).  On a HIP MoDeDiT in training mode the scalings, the
+        target, the MSE and their backward are two HIP launches around the training chain (training.edm_loss); the expression below is
+        the generic path (eval-mode loss, extra kwargs)."""
+        m = self.inner_model
+        if isinstance(m, MoDeDiT) and m.training and not kwargs and torch.is_grad_enabled():
+            from .training import edm_loss
+            return edm_loss(self, state, action, goal, noise, sigma)
         c_skip, c_out, c_in = [append_dims(x, action.ndim) for x in self.get_scalings(sigma)]
         noised_input = action + noise * append_dims(sigma, action.ndim)
         model_output = self.inner_model(state, noised_input * c_in, goal, sigma, **kwargs)

@@ -6,8 +6,10 @@ expert ids drawn by ``torch.multinomial`` exactly where the reference draws them
 ``mode_dit_backward`` which writes the gradient of every parameter.  PyTorch only wires tensors together; no FLOP of the
 denoiser runs in eager PyTorch.
 
-Not differentiated this round: the auxiliary load-balancing / z losses (values are exposed for logging exactly like the
-reference — modedit.py:584-593, 898-969 — but carry no graph; their weights are 0.0 in conf/model/mode_agent.yaml:5-6).
+The auxiliary router losses (``MoDeDiT.load_balancing_loss`` / ``compute_router_z_loss``, modedit.py:898-969, per-block term :586-593) are
+outputs of the same autograd node: adding ``entropy_gamma * LB + router_z_delta * Z`` to the loss (mode_agent.py:413-419) trains the routers
+through ``mode_moe_router_bwd_aux``.  ``edm_loss`` is ``GCDenoiser.loss`` with its scalings, target and MSE (and their backward) as two HIP
+launches; ``diffusion_loss`` / ``training_step`` restate ``MoDEAgent.diffusion_loss`` / ``training_step`` (mode_agent.py:659-672, 386-440).
 """
 from __future__ import annotations
 
@@ -121,17 +123,36 @@ class _Run:
 
 
 class _DitTrainFn(torch.autograd.Function):
+    """Outputs: F (B, A_len, A), the load-balancing loss and the router z-loss of this forward (scalars).  One backward serves all three."""
+
     @staticmethod
     def forward(ctx, run, *params):
         ctx.run = run
         ctx.n = len(params)
-        return run.F
+        ctx.set_materialize_grads(False)                         # unused outputs hand None to backward, not zero tensors
+        return run.F, run.lb_loss, run.z_loss
 
     @staticmethod
-    def backward(ctx, dF):
+    def backward(ctx, dF, dlb, dz):
         run = ctx.run
-        grads = run.backward(dF.contiguous().float())
+        if dF is None:
+            dF = torch.zeros_like(run.F)
+        grads = run.backward(dF.contiguous().float(), dlb, dz)
         return (None, *grads)
+
+
+class _EdmLossFn(torch.autograd.Function):
+    """loss = mean((F - target)^2) computed by mode_edm_loss together with dF for a unit upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, F, loss, dF_unit):
+        ctx.save_for_backward(dF_unit)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dF_unit,) = ctx.saved_tensors
+        return dF_unit * dloss, None, None
 
 
 def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
@@ -211,7 +232,9 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         # batched over the layers (a dozen launches per step instead of ~120), then handed out as per-block views
         mask = torch.zeros(Ly, N, E, device=dev).scatter_(2, idx64, 1.0)
         rp = torch.zeros(Ly, N, E, device=dev).scatter_(2, idx64, wtok)
-        lb = E * (rp.mean(1) * (mask.sum(1) / N)).sum(-1)                                       # [L]
+        frac = mask.sum(1) / N                                                                  # [L, E] fraction of tokens per expert
+        lb = E * (rp.mean(1) * frac).sum(-1)                                                    # [L]
+        zl = torch.log(torch.exp(shifted).sum(-1) + 1e-6).pow(2).mean(-1)                       # [L] router z-loss per layer (modedit.py:930-969)
         logits_tok = shifted.unsqueeze(2).expand(Ly, B, T, E).reshape(Ly, N, E)
         model.logits_per_layer, model.probs_per_layer = [], []
         for l, blk in enumerate(model.blocks):
@@ -229,9 +252,18 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     params = list(model.parameters())
     names = [n for n, _ in model.named_parameters()]
 
-    def backward(dF: torch.Tensor):
+    def backward(dF: torch.Tensor, dlb=None, dz=None):
         """Writes every parameter gradient straight into the gradient arena and points ``p.grad`` at its slice.  The first backward after an
-        optimizer step (or ``zero_grad``) overwrites; further ones accumulate."""
+        optimizer step (or ``zero_grad``) overwrites; further ones accumulate.  ``dlb`` / ``dz``: upstream gradients of the two auxiliary
+        router losses (None = not part of the loss)."""
+        keep_aux = []
+        args.shifted = args.aux_lb_coef = args.aux_z_coef = None
+        if dlb is not None:                                                       # LB = mean_l E sum_e mean_n(rp[n,e]) f_{l,e}: linear in the combine weights
+            coef = (frac * (dlb.reshape(()).float() * (E / (Ly * N)))).contiguous()
+            keep_aux.append(coef); args.aux_lb_coef = coef.data_ptr()
+        if dz is not None:
+            zc = (dz.reshape(1).float() * (2.0 / (Ly * B))).contiguous()
+            keep_aux.append(zc); args.aux_z_coef = zc.data_ptr(); args.shifted = shifted.data_ptr()
         ts.ensure()
         mg = ts.grad_tables()
         ar = eng.arena
@@ -258,4 +290,67 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         return [None] * len(params)
 
     run.F, run.backward, run.keep = F, backward, keep_alive
-    return _DitTrainFn.apply(run, *params)
+    run.lb_loss, run.z_loss = lb.mean(), zl.mean()
+    Fo, lb_o, z_o = _DitTrainFn.apply(run, *params)
+    model._aux_losses = (lb_o, z_o)                                             # what load_balancing_loss() / compute_router_z_loss() return in training
+    return Fo
+
+
+def edm_loss(denoiser, state, action, goal, noise, sigma):
+    """``GCDenoiser.loss`` (score_wrappers.py:45-63) on the HIP chain: noised input and c_in scaling in one launch, target / MSE / dF in
+    another; returns (loss, model_output) like the reference."""
+    m = denoiser.inner_model
+    eng: DitEngine = m.engine
+    lib, dev = eng.lib, eng.device
+    for nm, t in (("action", action), ("noise", noise)):
+        if torch.is_grad_enabled() and torch.is_tensor(t) and t.requires_grad:
+            raise NotImplementedError(f"GCDenoiser.loss (HIP): {nm} requires grad, but the chain returns no input gradients")
+    f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    a, nz = f(action), f(noise)
+    B = a.shape[0]
+    n = a[0].numel()
+    sig = f(sigma).reshape(-1)
+    if sig.numel() == 1:
+        sig = sig.expand(B).contiguous()
+    xs = torch.empty_like(a)
+    sd = float(denoiser.sigma_data)
+    L.check(lib.mode_edm_noise_scale(a.data_ptr(), nz.data_ptr(), sig.data_ptr(), sd, B, n, xs.data_ptr(), _stream()), "edm_noise_scale")
+    F = m(state, xs, goal, sig)
+    loss = torch.empty(1, device=dev)
+    dF = torch.empty_like(a)
+    L.check(lib.mode_edm_loss(F.detach().contiguous().data_ptr(), a.data_ptr(), nz.data_ptr(), sig.data_ptr(), sd, B, n, loss.data_ptr(), dF.data_ptr(), _stream()),
+            "edm_loss")
+    return _EdmLossFn.apply(F, loss, dF), F
+
+
+def diffusion_loss(denoiser, perceptual_emb, latent_goal, actions, sample_density=None):
+    """``MoDEAgent.diffusion_loss`` (mode_agent.py:659-672): train mode, sigma ~ density (log-logistic by default), eps ~ N(0, 1)."""
+    from .utils import make_sample_density
+    denoiser.train()
+    density = sample_density or make_sample_density("loglogistic", sigma_data=float(denoiser.sigma_data))
+    sigmas = density(shape=(len(actions),), device=actions.device).to(actions.device)
+    noise = torch.randn_like(actions)
+    loss, _ = denoiser.loss(perceptual_emb, actions, latent_goal, noise, sigmas)
+    return loss
+
+
+def training_step(denoiser, batch, entropy_gamma: float = 0.0, router_z_delta: float = 0.0, sample_density=None):
+    """``MoDEAgent.training_step`` (mode_agent.py:386-440) for precomputed embeddings: ``batch`` maps a modality name to
+    ``{"perceptual_emb": {"state_images": ...}, "latent_goal": ..., "actions": ...}`` (what ``compute_input_embeddings`` hands over);
+    per modality ``act_loss (+ entropy_gamma * LB) (+ router_z_delta * Z)``, summed, divided by the number of modalities.
+    Returns (total_loss, action_loss, aux) with aux = the last modality's LB / Z values (what the reference logs)."""
+    inner = denoiser.inner_model
+    total, action_loss, aux = None, None, {}
+    for _, db in batch.items():
+        act = diffusion_loss(denoiser, db["perceptual_emb"], db["latent_goal"], db["actions"], sample_density)
+        t = act
+        if entropy_gamma > 0:
+            aux["load_balancing_loss"] = inner.load_balancing_loss()
+            t = t + aux["load_balancing_loss"] * entropy_gamma
+        if router_z_delta > 0:
+            aux["router_z_loss"] = inner.compute_router_z_loss()
+            t = t + router_z_delta * aux["router_z_loss"]
+        total = t if total is None else total + t
+        action_loss = act if action_loss is None else action_loss + act
+    n = len(batch)
+    return total / n, action_loss / n, aux

@@ -351,6 +351,22 @@ def router_z_loss(shifted_logits_per_layer: List[Tensor], T: int, eps: float = 1
     return sum(z) / len(z)
 
 
+def training_total_loss(sd, cfg: DiTConfig, sigma_data: float, state_images, action, goal, noise, sigma, entropy_gamma: float = 0.0,
+                        router_z_delta: float = 0.0, **kw):
+    """One modality of ``MoDEAgent.training_step`` (mode_agent.py:399-419): ``act_loss + entropy_gamma * load_balancing_loss() +
+    router_z_delta * compute_router_z_loss()`` with every term attached to the autograd graph.  Returns (total, act, lb, z)."""
+    c_skip, c_out, c_in = (t.reshape(-1, 1, 1) for t in edm_scalings(sigma.reshape(-1), sigma_data))
+    noised = action + noise * sigma.reshape(-1, 1, 1)
+    out, aux = dit_forward(sd, cfg, state_images, noised * c_in, goal, sigma, return_aux=True, **kw)
+    target = (action - c_skip * noised) / c_out
+    act = (out - target).pow(2).flatten(1).mean()
+    T, E, k = cfg.seq_len, cfg.num_experts, cfg.top_k
+    lb = sum(load_balancing_term(aux.probs[l], aux.topk_idx[l].reshape(-1, k), aux.combine_w[l].reshape(-1, k), T, E)
+             for l in range(cfg.n_layers)) / cfg.n_layers
+    z = router_z_loss(aux.shifted_logits, T)
+    return act + entropy_gamma * lb + router_z_delta * z, act, lb, z
+
+
 def uses_weight_decay(param_name: str) -> bool:
     """AdamW grouping rule (mode_agent.py:365-384): decay unless the NAME contains one of these."""
     return all(s not in param_name for s in ("bias", "LayerNorm", "embedding"))

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--screen", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--cfgs", default="0,17,17f16,17f32,17f48,17f14", help="variants to time: NN[fK] = gemm_cfg NN with pp_flags K; 0 = the 128x128 family (gemm_pp off)")
+    ap.add_argument("--cfgs", default="0,17,17f1,17f32,17f33,17f16", help="variants to time: NN[fK] = gemm_cfg NN with pp_flags K; 0 = the 128x128 family (gemm_pp off)")
     a = ap.parse_args()
     lib = L.load()
     dev = torch.device("cuda:0")

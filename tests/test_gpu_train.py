@@ -1,7 +1,9 @@
 """GPU parity of the score-matching training step (GCDenoiser.loss -> MoDeDiT train forward -> HIP backward) against the golden
 loss / output / gradients produced by the REAL reference's autograd (fixtures F5, deterministic config: all dropouts 0,
 use_argmax=True — dropout and the multinomial draw cannot be bit-matched).
-Tolerances: fp32 compute mode 1e-3 (observed ~1e-5); bf16 mode: loss/F 1e-2, gradient norms 3e-2, per-tensor rel-L2 6e-2."""
+Tolerances: fp32 compute mode 1e-3 (observed ~1e-5); bf16 mode: loss/F 1e-2; gradients: the reference's OWN fp32-vs-bf16-autocast gap measured on
+CPU with identical routing (oracle/measure_bf16_grad_gap.py -> tests/golden/bf16_grad_gap.json): norms <= 2.3e-2, per-tensor rel-L2 <= 3.8e-2;
+asserted here: norms 2.5e-2, per tensor 4e-2."""
 import numpy as np
 import pytest
 import torch
@@ -54,7 +56,7 @@ def test_loss_and_gradients_vs_reference(golden, cfgname, dtype):
     for n in none:
         if n != "gripper_embed.weight":
             assert grads[n] is None or float(grads[n].abs().max()) == 0.0, n       # un-routed experts: exact zeros (zero-filled buckets)
-    tol_n, tol_t = (1e-3, 1e-3) if dtype == "fp32" else (3e-2, 6e-2)
+    tol_n, tol_t = (1e-3, 1e-3) if dtype == "fp32" else (2.5e-2, 4e-2)
     bad = []
     for n, ref_norm in gn.items():
         if ref_norm <= 1e-6:
@@ -188,6 +190,7 @@ def test_arena_reducer_overlap_slices_and_events():
         scale = red.reduce()
         torch.cuda.synchronize()
         want = ar.grad.clone()
+        ar.grad_pending = False                                                             # as after an optimizer step: the next backward starts a fresh sum
         loss, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
         loss.backward()
         torch.cuda.synchronize()
@@ -282,3 +285,311 @@ def test_training_step_ragged_batches_vs_oracle_autograd(B):
         assert rel(p.grad, r) < 2e-3, (n, rel(p.grad, r))
         checked += 1
     assert checked > 40
+
+
+# ============================================================================================== round 2: the configurations the bench runs
+def _grad_report(m, sdg, tol_t, min_checked):
+    """Per-tensor rel-L2 of the arena gradients against the oracle's autograd; returns the worst error and asserts the un-routed zeros."""
+    worst, checked = (0.0, ""), 0
+    for n, p in m.named_parameters():
+        r = sdg[n].grad
+        if r is None or float(r.norm()) < 1e-7:
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-6, n
+            continue
+        e = rel(p.grad, r)
+        assert e < tol_t, (n, e)
+        worst = max(worst, (e, n)); checked += 1
+    assert checked >= min_checked
+    return worst
+
+
+# bf16 gradient tolerances are the REFERENCE'S OWN fp32-vs-bf16-autocast gradient gap (oracle/measure_bf16_grad_gap.py, tests/golden/
+# bf16_grad_gap.json: worst tensor 3.8e-2 (attention key bias), medians 0.7-1.1e-2, gradient norms <= 2.3e-2 with identical routing).
+BF16_GRAD_TOL = 4e-2
+
+
+@pytest.mark.parametrize("dtype,tol_l,tol_t", [("fp32", 1e-4, 2e-3), ("bf16", 1e-2, BF16_GRAD_TOL)])
+def test_c2block_training_vs_oracle_large_batch(dtype, tol_l, tol_t):
+    """One C2-sized block (D=1024, hd=128, 4 experts top-2) at B=128 - every GEMM tile shape of the benchmark's training step, including the
+    persistent 224x256 forward kernel - loss and ALL gradients against the oracle's autograd."""
+    cfg, sd, m = build_train("c2block", 300, dtype)
+    B = 128
+    inp = make_inputs(cfg, B, 77)
+    sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(3))
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_loss, _ = O.denoiser_loss(sdg, cfg, 0.5, inp["state_images"], inp["actions"], inp["goals"], inp["noise"], sig)
+    ref_loss.backward()
+    c = {k: v.cuda() for k, v in inp.items()}
+    den = M.GCDenoiser(m, 0.5).train()
+    loss, _ = den.loss({"state_images": c["state_images"]}, c["actions"], c["goals"], c["noise"], sig.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < tol_l * abs(float(ref_loss))
+    worst = _grad_report(m, sdg, tol_t, 30)
+    print(f"c2block B=128 {dtype}: worst gradient rel-L2 {worst[0]:.2e} ({worst[1]})")
+
+
+@pytest.mark.parametrize("dtype,tol_l,tol_t", [("fp32", 1e-4, 2e-3), ("bf16", 1e-2, BF16_GRAD_TOL)])
+def test_stochastic_training_path_vs_oracle_shared_randomness(dtype, tol_l, tol_t):
+    """The path `bench.py --mode train` times - multinomial routing per token row + attention / expert dropout - against the oracle's autograd
+    with SHARED randomness: the drawn expert ids are handed over, the hash dropout masks are a pure function of (step seed, stream, element)
+    and the oracle restates them bit for bit (oracle.mode_oracle.attn_keep_scale / mlp_keep_scale)."""
+    torch.manual_seed(11)
+    cfg, sd, m = build_train("c1e4", 210, dtype, attn_pdrop=0.3, mlp_pdrop=0.1, goal_drop=0.0, use_argmax=False)
+    B = 24
+    inp = make_inputs(cfg, B, 91)
+    sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(5))
+    c = {k: v.cuda() for k, v in inp.items()}
+    den = M.GCDenoiser(m, 0.5).train()
+    loss, _ = den.loss({"state_images": c["state_images"]}, c["actions"], c["goals"], c["noise"], sig.cuda())
+    loss.backward()
+    idx = m._last_topk.cpu().long()                                             # [L, B*T, k]: drawn per token row (modedit.py:390)
+    assert idx.shape == (cfg.n_layers, B * cfg.seq_len, cfg.top_k)
+    assert not torch.equal(idx[:, ::cfg.seq_len], idx[:, 1::cfg.seq_len])       # tokens of one sample do draw different experts
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_loss, _ = O.denoiser_loss(sdg, cfg, 0.5, inp["state_images"], inp["actions"], inp["goals"], inp["noise"], sig,
+                                  topk_idx=[idx[l].view(B, cfg.seq_len, cfg.top_k) for l in range(cfg.n_layers)],
+                                  dropout=dict(seed=m._last_seed, attn_p=0.3, mlp_p=0.1))
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < tol_l * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    worst = _grad_report(m, sdg, tol_t, 40)
+    print(f"stochastic c1e4 {dtype}: worst gradient rel-L2 {worst[0]:.2e} ({worst[1]})")
+    # the masks of different layers are independent streams (not index permutations of one another)
+    k0 = O.mlp_keep_scale(O.stream_seed(m._last_seed, 1), 0, 64, 1024, 0.1) > 0
+    k1 = O.mlp_keep_scale(O.stream_seed(m._last_seed, 3), 0, 64, 1024, 0.1) > 0
+    agree = float((k0 == k1).float().mean())
+    assert abs(agree - (0.9 * 0.9 + 0.1 * 0.1)) < 0.01, agree
+
+
+@pytest.fixture(scope="module")
+def c2_train_model():
+    torch.manual_seed(0)
+    cfg = get_config("c2")
+    m = M.MoDeDiT(obs_dim=cfg.obs_dim, goal_dim=cfg.goal_dim, device="cuda", goal_conditioned=True, action_dim=7, embed_dim=1024,
+                  embed_pdrob=0, attn_pdrop=0.3, mlp_pdrop=0.1, goal_drop=0.1, n_layers=12, n_heads=8, goal_seq_len=1, obs_seq_len=1,
+                  action_seq_len=10, num_experts=4, top_k=2, compute_dtype="bf16")
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if n_.endswith(".g"):
+                p.add_(0.1 * torch.randn_like(p))
+            if "router.router.mlp.3.weight" in n_:
+                p.mul_(20.0)
+        m.pos_emb.normal_(0, 0.1)
+    return cfg, m.to("cuda").train()
+
+
+def test_c2_full_size_training_step_properties(c2_train_model):
+    """BASELINE config 3 at full size (12 layers, D=1024, B=128, bf16): the training chain the bench times.  Finite; bit-deterministic under a
+    fixed seed (stochastic config: multinomial routing + hash dropouts); gradients of un-routed experts and of the dead parameter exactly zero."""
+    cfg, m = c2_train_model
+    B = 128
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, B, 13).items()}
+    den = M.GCDenoiser(m, 0.5).train()
+    sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(7)).cuda()
+    ar = None
+    runs = []
+    for rep in range(2):
+        torch.manual_seed(123)                                                  # goal mask, multinomial draw and dropout step seed
+        m.engine.arena.grad_pending = False
+        loss, F = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
+        loss.backward()
+        torch.cuda.synchronize()
+        ar = m.engine.arena
+        runs.append((float(loss), F.detach().clone(), ar.grad.clone()))
+    assert np.isfinite(runs[0][0]) and torch.isfinite(runs[0][1]).all() and torch.isfinite(runs[0][2]).all()
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    gn = float(runs[0][2][: ar.bounds["no_decay"]].norm())
+    assert 0.0 < gn < 1e6
+    # deterministic routing with ONE noise level for the whole batch: two of the four experts of every layer see no token
+    m.use_argmax = True
+    try:
+        m.engine.arena.grad_pending = False
+        s1 = torch.full((B,), 0.7, device="cuda")
+        loss, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], s1)
+        loss.backward()
+        torch.cuda.synchronize()
+        idx = m._last_topk.cpu().long()                                         # [L, B, k]
+        zeros = 0
+        for l, blk in enumerate(m.blocks):
+            used = set(idx[l].reshape(-1).tolist())
+            assert len(used) == 2
+            for e in range(4):
+                g1 = blk.experts[f"expert_{e}"].mlp[0].project.weight.grad
+                g2 = blk.experts[f"expert_{e}"].mlp[2].weight.grad
+                if e in used:
+                    assert float(g1.abs().max()) > 0 and float(g2.abs().max()) > 0
+                else:
+                    assert float(g1.abs().max()) == 0.0 and float(g2.abs().max()) == 0.0, (l, e)
+                    zeros += 1
+        assert zeros == 2 * cfg.n_layers and m.gripper_embed.weight.grad is None
+    finally:
+        m.use_argmax = False
+
+
+def test_gradient_accumulation_and_input_grad_guard():
+    """Two backwards before an optimizer step ADD (autograd semantics; the reference's training_step sums several losses,
+    mode_agent.py:386-440); an input that requires grad is refused instead of silently receiving no gradient."""
+    from mode_diffusion_policy_amd.optim import FusedAdamW
+    cfg, sd, m = build_train("c1e4", 210, "fp32")
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, 8, 3).items()}
+    den = M.GCDenoiser(m, 0.5).train()
+    sig = torch.full((8,), 0.9, device="cuda")
+    opt = FusedAdamW(m, lr=1e-3)
+    st = {"state_images": inp["state_images"]}
+    loss, _ = den.loss(st, inp["actions"], inp["goals"], inp["noise"], sig); loss.backward()
+    g1 = m.engine.arena.grad.clone()
+    loss, _ = den.loss(st, inp["actions"], inp["goals"], inp["noise"], sig); loss.backward()          # second backward: accumulates
+    assert rel(m.engine.arena.grad, 2.0 * g1) < 1e-6
+    opt.zero_grad()
+    loss, _ = den.loss(st, inp["actions"], inp["goals"], inp["noise"], sig); loss.backward()          # after zero_grad: a fresh sum
+    assert torch.equal(m.engine.arena.grad, g1)
+    opt.step()
+    loss, _ = den.loss(st, inp["actions"], inp["goals"], inp["noise"], sig); loss.backward()          # after step: fresh as well
+    g2 = m.engine.arena.grad.clone()
+    opt.zero_grad()
+    loss, _ = den.loss(st, inp["actions"], inp["goals"], inp["noise"], sig); loss.backward()
+    assert torch.equal(m.engine.arena.grad, g2) and not torch.equal(g2, g1)
+    with pytest.raises(NotImplementedError):
+        den.loss({"state_images": inp["state_images"].clone().requires_grad_(True)}, inp["actions"], inp["goals"], inp["noise"], sig)
+    from mode_diffusion_policy_amd.ddp import BucketedGradReducer
+    with pytest.raises(TypeError):
+        BucketedGradReducer(m)
+
+
+# ---------------------------------------------------------------------------------------------- world-2 data parallelism on ONE GPU
+def _dp_worker(rank, world, port, mode, comm, outdir):
+    """One data-parallel rank on cuda:0 (both ranks share the GPU; gloo carries device tensors): c1e4 MoDeDiT on its half of the batch through
+    the REAL path of `bench.py --mode train --gpus N`: ArenaGradReducer.for_model (per-block event-gated slices) + FusedAdamW.step(reducer, overlap)."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mode_diffusion_policy_amd.ddp import ArenaGradReducer
+        from mode_diffusion_policy_amd.optim import FusedAdamW
+        torch.cuda.set_device(0)
+        cfg, sd, m = build_train("c1e4", 210, "bf16")
+        B = 16
+        inp = {k: v.cuda() for k, v in make_inputs(cfg, B, 55).items()}
+        sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(9)).cuda()
+        sl = slice(rank * B // world, (rank + 1) * B // world)
+        den = M.GCDenoiser(m, 0.5).train()
+        opt = FusedAdamW(m, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+        red = ArenaGradReducer.for_model(m, mode=mode, comm_dtype=torch.bfloat16 if comm == "bf16" else torch.float32)
+        for step in range(2):
+            loss, _ = den.loss({"state_images": inp["state_images"][sl]}, inp["actions"][sl], inp["goals"][sl], inp["noise"][sl], sig[sl])
+            loss.backward()
+            opt.step(reducer=red, overlap=True)
+        torch.cuda.synchronize()
+        out = {n: p.detach().cpu() for n, p in m.named_parameters()}
+        # one more backward + the bare exchange: the reduced gradient itself (the optimizer's sign-like first steps amplify rounding noise)
+        m.engine.arena.grad_pending = False
+        loss, _ = den.loss({"state_images": inp["state_images"][sl]}, inp["actions"][sl], inp["goals"][sl], inp["noise"][sl], sig[sl])
+        loss.backward()
+        scale = red.reduce()
+        torch.cuda.synchronize()
+        out["__grad__"] = (m.engine.arena.grad[: m.engine.arena.bounds["no_decay"]] * scale).cpu()
+        torch.save(out, os.path.join(outdir, f"w{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,comm", [("allreduce", "fp32"), ("rs_ag", "fp32"), ("allreduce", "bf16")])
+def test_data_parallel_world2_equals_single_process_on_concatenated_batch(tmp_path, mode, comm):
+    """Reference semantics (Lightning DDP, mode/training_calvin.py:92-103): the mean of the per-rank gradients == the gradient of the mean loss
+    over the concatenated batch, so after AdamW steps every rank holds the weights of a single process that saw the whole batch."""
+    import socket
+    import torch.multiprocessing as mp
+    from mode_diffusion_policy_amd.optim import FusedAdamW
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, mode, comm, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    w = [torch.load(tmp_path / f"w{r}.pt") for r in range(2)]
+    # single process, whole batch
+    cfg, sd, m = build_train("c1e4", 210, "bf16")
+    B = 16
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, B, 55).items()}
+    sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(9)).cuda()
+    den = M.GCDenoiser(m, 0.5).train()
+    opt = FusedAdamW(m, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    for step in range(2):
+        loss, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
+        loss.backward()
+        opt.step()
+    # (a) the exchanged gradient == the whole-batch gradient (bf16 GEMMs of two half batches vs one whole batch: rounding-level differences)
+    m.engine.arena.grad_pending = False
+    loss, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
+    loss.backward()
+    torch.cuda.synchronize()
+    gref = m.engine.arena.grad[: m.engine.arena.bounds["no_decay"]].cpu()
+    assert torch.equal(w[0]["__grad__"], w[1]["__grad__"])
+    eg = rel(w[0].pop("__grad__"), gref); w[1].pop("__grad__")
+    assert eg < (2e-2 if comm == "bf16" else 1e-2), eg
+    # (b) the weights after two optimizer steps, relative to the UPDATE (w_new - w_init).  Adam's first steps are sign-like (m / sqrt(v) ~ g / |g|),
+    # so rounding-level gradient differences are amplified on the smallest gradients: observed up to 2.7e-2 (fp32 exchange) / 8.1e-2 (bf16 exchange)
+    tol = 2e-1 if comm == "bf16" else 8e-2
+    moved = 0
+    for n, p in m.named_parameters():
+        assert torch.equal(w[0][n], w[1][n]), n                                  # every rank ends with the same weights, bit for bit
+        upd = (p.detach().cpu() - sd[n]).double()
+        if float(upd.norm()) < 1e-12:
+            assert torch.equal(w[0][n], sd[n]), n                                # dead / un-routed: untouched on every rank (zero-filled gradient)
+            continue
+        e = float(((w[0][n] - sd[n]).double() - upd).norm() / upd.norm())
+        assert e < tol, (n, e)
+        moved += 1
+    assert moved > 50
+
+
+# ---------------------------------------------------------------------------------------------- auxiliary router losses + training_step
+@pytest.mark.parametrize("dtype,tol_l,tol_n,tol_t", [("fp32", 1e-4, 1e-3, 1e-3), ("bf16", 1e-2, 2.5e-2, BF16_GRAD_TOL)])
+def test_training_step_with_aux_losses_vs_reference(golden, dtype, tol_l, tol_n, tol_t):
+    """F12 (generated from the REAL reference, oracle/gen_golden_aux.py): training_step's `act_loss + entropy_gamma * load_balancing_loss() +
+    router_z_delta * compute_router_z_loss()` (mode_agent.py:399-419) with entropy_gamma = 0.01 (the value conf/model/mode_agent.yaml:5 recommends
+    for training from scratch) and router_z_delta = 0.001: loss terms and EVERY gradient, through mode_moe_router_bwd_aux."""
+    g = golden("F12_c1e4_aux_loss_grad")
+    cfg, sd, m = build_train(str(g["cfg"]), int(g["seed"]), dtype)
+    B = int(g["B"])
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, B, int(g["seed"]) + 1).items()}
+    den = M.GCDenoiser(m, 0.5).train()
+    sig = torch.from_numpy(g["sigma"]).cuda()
+    fixed = lambda shape, device: sig                                         # sigma supplied (the fixture pins it); eps = the fixture's noise
+    torch.manual_seed(0)
+    import mode_diffusion_policy_amd.training as TR
+    # diffusion_loss draws eps with randn_like: pin it through the lower-level call the step is made of
+    loss_act, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
+    lb, z = m.load_balancing_loss(), m.compute_router_z_loss()
+    total = loss_act + float(g["gamma"]) * lb + float(g["delta"]) * z
+    assert lb.requires_grad and z.requires_grad
+    assert abs(float(lb) - float(g["lb"])) < 1e-4 * abs(float(g["lb"])) and abs(float(z) - float(g["z"])) < 1e-4 * abs(float(g["z"]))
+    assert abs(float(total) - float(g["total"])) < tol_l * abs(float(g["total"]))
+    total.backward()
+    gn = dict(zip(g["gn_keys"].tolist(), g["gn_vals"].tolist()))
+    grads = {n: p.grad for n, p in m.named_parameters()}
+    for n, ref in gn.items():
+        if ref > 1e-6:
+            assert abs(float(grads[n].norm()) - ref) / ref < tol_n, (n, float(grads[n].norm()), ref)
+    for key in g.files:
+        if key.startswith("g:") and gn[key[2:]] > 1e-6:
+            assert rel(grads[key[2:]], g[key]) < tol_t, key
+        if key.startswith("gs:") and gn[key[3:]] > 1e-6:
+            got = grads[key[3:]].reshape(-1)[:2048].cpu()
+            assert float((got - torch.from_numpy(g[key])).norm()) < tol_t * gn[key[3:]], key
+    # without the aux terms the router gradient is measurably different (the fixture can tell a missing gradient path from the real one)
+    m.engine.arena.grad_pending = False
+    r_with = grads["blocks.0.router.router.mlp.3.weight"].clone()
+    la, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
+    la.backward()
+    assert rel(m.blocks[0].router.router.mlp[3].weight.grad, r_with) > 2e-2
+    # the package-level step: two "modalities", divided by their number (mode_agent.py:421-423); sigma / eps are drawn inside -> properties only
+    m.engine.arena.grad_pending = False
+    batch = {"lang": dict(perceptual_emb={"state_images": inp["state_images"]}, latent_goal=inp["goals"], actions=inp["actions"]),
+             "vis": dict(perceptual_emb={"state_images": inp["state_images"]}, latent_goal=inp["goals"], actions=inp["actions"])}
+    tot, act, aux = TR.training_step(den, batch, entropy_gamma=0.01, router_z_delta=0.001)
+    assert tot.requires_grad and float(tot) > float(act) > 0 and set(aux) == {"load_balancing_loss", "router_z_loss"}
+    tot.backward()                                                            # both modalities' backward passes accumulate into the arena
+    assert torch.isfinite(m.engine.arena.grad).all()

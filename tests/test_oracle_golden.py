@@ -157,3 +157,21 @@ def test_ddim_update_equals_reference_form():
     t, tn = -s.log(), -sn.log()
     ref = ((-tn).exp() / (-t).exp()) * x - (-(tn - t)).expm1() * d
     assert torch.allclose(O.ddim_update(x, d, float(s), float(sn)), ref, rtol=1e-12)
+
+
+def test_oracle_aux_loss_composition_vs_reference(golden):
+    """F12: act_loss + 0.01 * load_balancing_loss + 0.001 * router_z_loss composed on the real reference modules (mode_agent.py:399-419) and
+    differentiated by autograd: the oracle's restatement reproduces the losses and every gradient."""
+    g = golden("F12_c1e4_aux_loss_grad")
+    cfg = get_config(str(g["cfg"])); seed, B = int(g["seed"]), int(g["B"])
+    sd = {k: v.clone().requires_grad_(True) for k, v in make_state_dict(cfg, seed).items()}
+    inp = make_inputs(cfg, B, seed + 1)
+    tot, act, lb, z = O.training_total_loss(sd, cfg, 0.5, inp["state_images"], inp["actions"], inp["goals"], inp["noise"], torch.from_numpy(g["sigma"]),
+                                            float(g["gamma"]), float(g["delta"]))
+    tot.backward()
+    assert abs(float(tot) - float(g["total"])) < 1e-5 * abs(float(g["total"]))
+    assert abs(float(lb) - float(g["lb"])) < 1e-5 and abs(float(z) - float(g["z"])) < 1e-5
+    gn = dict(zip(g["gn_keys"].tolist(), g["gn_vals"].tolist()))
+    for n, ref in gn.items():
+        if ref > 1e-6:
+            assert abs(float(sd[n].grad.norm()) - ref) / ref < 1e-4, n
