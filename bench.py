@@ -65,6 +65,7 @@ def dominant_kernel_roofline(den, device, reps=240):
     cycling through the 12 layers' weights, as one hipGraph replay timed with HIP events on the stream it is launched on."""
     import ctypes as C
     from mode_diffusion_policy_amd import _lib as L
+    from mode_diffusion_policy_amd.engine import capture_graph
     m = den.inner_model
     eng = m.engine
     lib = L.load()
@@ -84,7 +85,8 @@ def dominant_kernel_roofline(den, device, reps=240):
         d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_SWIGLU, out_dtype=L.MODE_BF16, M=N * k, N=4 * D, K=D, A=u.data_ptr(), lda=D,
                            W=kp[f"l{l}.w1"].data_ptr(), ldw=D, w_expert_stride=8 * D * D, bias=kp[f"l{l}.b1"].data_ptr(),
                            bias_expert_stride=8 * D, resid=None, ldr=0, C=Hb.data_ptr(), ldc=4 * D, a_rows=mp + 4 * ml.perm,
-                           expert_offsets=mp + 4 * ml.offsets, num_experts=E, row_ss=ss.data_ptr(), row_ss_n=D // 64, row_eps=1e-6)
+                           expert_offsets=mp + 4 * ml.offsets, num_experts=E, row_ss=ss.data_ptr(), row_ss_n=D // 64, row_eps=1e-6,
+                           flags=L.GEMM_UNIFORM_GROUPS)                   # the sampler's hint: every sample routes alike (dit.hip sets it the same way)
         descs.append(d)
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(4):                                        # warm-up: clocks, code objects, L2/MALL state of a steady layer loop
@@ -94,7 +96,7 @@ def dominant_kernel_roofline(den, device, reps=240):
     # the `reps` launches are recorded into one hipGraph and replayed between two events on the replay stream: back-to-back launches like in
     # the sampler's chain, no host launch gaps inside the timed region
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
+    with capture_graph(g):
         cst = torch.cuda.current_stream().cuda_stream
         for i in range(reps):
             L.check(lib.mode_gemm(C.byref(descs[i % len(descs)]), cst))
@@ -130,6 +132,7 @@ def layer_kernel_breakdown(den, device, reps=120):
     launches cycling the 12 layers' weights (HIP events on the replay stream): {name: {us, frac, bound}}; frac against the roof that bounds it."""
     import ctypes as C
     from mode_diffusion_policy_amd import _lib as L
+    from mode_diffusion_policy_amd.engine import capture_graph
     m = den.inner_model
     eng = m.engine
     lib = L.load()
@@ -159,9 +162,9 @@ def layer_kernel_breakdown(den, device, reps=120):
                C2=h2.data_ptr(), ldc2=D, gain=kp["ln2_g"][l].data_ptr(), row_ss_out=ss.data_ptr()) for l in range(Ly)]
     up_d = [g(epilogue=L.EPI_SWIGLU, M=NK, N=4 * D, W=kp[f"l{l}.w1"].data_ptr(), w_expert_stride=8 * D * D, bias=kp[f"l{l}.b1"].data_ptr(),
               bias_expert_stride=8 * D, C=Hb.data_ptr(), ldc=4 * D, a_rows=mp + 4 * ml.perm, expert_offsets=mp + 4 * ml.offsets, num_experts=E,
-              row_ss=ss.data_ptr(), row_ss_n=D // 64, row_eps=1e-6) for l in range(Ly)]
+              row_ss=ss.data_ptr(), row_ss_n=D // 64, row_eps=1e-6, flags=L.GEMM_UNIFORM_GROUPS) for l in range(Ly)]
     dn_d = [g(M=NK, N=D, K=4 * D, A=Hb.data_ptr(), lda=4 * D, W=kp[f"l{l}.w2"].data_ptr(), ldw=4 * D, w_expert_stride=4 * D * D, C=Y.data_ptr(),
-              expert_offsets=mp + 4 * ml.offsets, num_experts=E, split_k=S, split_stride=NK * D) for l in range(Ly)]
+              expert_offsets=mp + 4 * ml.offsets, num_experts=E, split_k=S, split_stride=NK * D, flags=L.GEMM_UNIFORM_GROUPS) for l in range(Ly)]
 
     def gemm(ds):
         return lambda i, st: L.check(lib.mode_gemm(C.byref(ds[i % Ly]), st))
@@ -188,7 +191,7 @@ def layer_kernel_breakdown(den, device, reps=120):
             fn(i, st_of())
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+        with capture_graph(gr):
             cst = st_of()
             for i in range(reps):
                 fn(i, cst)
@@ -339,11 +342,22 @@ def train_bench(args, world, rank, device, dist):
     comm = torch.bfloat16 if os.environ.get("MODE_DP_COMM", "fp32") == "bf16" else torch.float32
     red = ArenaGradReducer.for_model(m, comm_dtype=comm) if world > 1 else None
 
+    # data-parallel step (world > 1): ZeRO-1 by default - per block slice reduce-scatter of the gradients, AdamW on this rank's shard, all-gather of
+    # the bf16 compute shadow (MODE_DP_ZERO1=fp32 gathers the fp32 masters instead, =0 falls back to the summed all-reduce + full optimizer pass)
+    z1 = os.environ.get("MODE_DP_ZERO1", "bf16" if world > 1 else "0")
+    z1 = None if z1 in ("0", "", "none") else z1
+    ev_bwd = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup + 2)]
+    ev_end = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup + 2)]
+    it = [0]
+
     def step():
         sig = rand_log_logistic((B,), loc=math.log(SIGMA_DATA), scale=0.5, min_value=SIGMA_MIN, max_value=SIGMA_MAX, device=device)
         loss, _ = den.loss({"state_images": img}, acts, goal, noise, sig)
         loss.backward()
-        opt.step(reducer=red, overlap=os.environ.get("MODE_OPT_OVERLAP", "1") == "1")   # per-block: exchange (RCCL) -> AdamW underneath the remaining backward
+        ev_bwd[it[0]].record()                                                           # the backward chain's last kernel
+        opt.step(reducer=red, overlap=os.environ.get("MODE_OPT_OVERLAP", "1") == "1", zero1=z1 if red is not None else None)   # per-block: exchange (RCCL) -> AdamW underneath the remaining backward
+        ev_end[it[0]].record()
+        it[0] += 1
         return loss
     for _ in range(max(args.warmup, 1)):
         loss = step()
@@ -370,8 +384,11 @@ def train_bench(args, world, rank, device, dist):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "configs[2]/[3]: score-matching training step of the full MoDE denoiser (12 layers, d=1024, 4 experts top-2), "
                                       "B=128 per GPU, log-logistic sigma, multinomial routing, dropouts on, fused AdamW, router unfrozen",
-                          "global_batch": B * world, "parallelism": f"dp{world}" + (" (bf16 gradient exchange)" if world > 1 and comm == torch.bfloat16 else "")},
-               "train_tflops_per_gpu": round(fl * args.steps / elapsed / 1e12, 1)}
+                          "global_batch": B * world, "parallelism": f"dp{world}" + (" (bf16 gradient exchange)" if world > 1 and comm == torch.bfloat16 else "") + (f" zero1/{z1}" if world > 1 and z1 else "")},
+               "train_tflops_per_gpu": round(fl * args.steps / elapsed / 1e12, 1),
+               # what is NOT hidden behind the backward: gradient exchange + optimizer (+ weight all-gather) still running after its last kernel
+               "exposed_exchange_and_optimizer_ms": round(sum(ev_bwd[i].elapsed_time(ev_end[i]) for i in range(it[0] - args.steps, it[0])) / args.steps, 3),
+               "dp_mode": ("zero1:" + z1) if (red is not None and z1) else ("allreduce" if red is not None else "single")}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

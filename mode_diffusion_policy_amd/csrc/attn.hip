@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
   qss += __shfl_xor(qss, 16, 64); qss += __shfl_xor(qss, 32, 64);
   kss += __shfl_xor(kss, 16, 64); kss += __shfl_xor(kss, 32, 64);
   const float qn = fmaxf(sqrtf(qss) * rsqrtf((float)HD), eps), kn = fmaxf(sqrtf(kss) * rsqrtf((float)HD), eps);
+  const float rqn = __frcp_rn(qn), rkn = __frcp_rn(kn);      // one reciprocal per row (64 per-element fp32 divisions per lane were ~2 us of this kernel)
 
   bf16x8 qfrag[NKS], kfrag[NKS];
 #pragma unroll
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
     uint32_t pq[4], pk[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      pq[i] = pack_bf16x2(qf[ks][2 * i] / qn * gq[2 * i], qf[ks][2 * i + 1] / qn * gq[2 * i + 1]);
-      pk[i] = pack_bf16x2(kf[ks][2 * i] / kn * gk[2 * i], kf[ks][2 * i + 1] / kn * gk[2 * i + 1]);
+      pq[i] = pack_bf16x2(qf[ks][2 * i] * rqn * gq[2 * i], qf[ks][2 * i + 1] * rqn * gq[2 * i + 1]);
+      pk[i] = pack_bf16x2(kf[ks][2 * i] * rkn * gk[2 * i], kf[ks][2 * i + 1] * rkn * gk[2 * i + 1]);
     }
     uint4 tq = make_uint4(pq[0], pq[1], pq[2], pq[3]), tk = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     qfrag[ks] = *reinterpret_cast<bf16x8*>(&tq);

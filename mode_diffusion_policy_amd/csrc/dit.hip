@@ -269,6 +269,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
   ModeMetaLayout ml;
   mode_moe_meta_layout(N, d.E, d.k, &ml);
   const int ysplit = down_proj_split(dt, 4 * D);
+  const bool uniform = a->cond_row_stride == 0;   // one conditioning row for the whole batch (the sampler): every sample routes to the same experts
   const int cond_rpc = T;   // one conditioning row per sample
   // cond addressing: row b at cond + b*cond_row_stride.  rmsnorm/combine kernels index cond by (row / rows_per_cond) * D, so a
   // shared row (stride 0) is expressed as rows_per_cond = N (every token maps to row 0).
@@ -314,12 +315,14 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     g.bias = lw.b1; g.w_expert_stride = 8L * D * D; g.bias_expert_stride = 8L * D;
     g.a_rows = meta + ml.perm; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
     if (fuse) { g.row_ss = rowss; g.row_ss_n = ssn; g.row_eps = d.eps; }
+    if (uniform) g.flags |= MODE_GEMM_UNIFORM_GROUPS;
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
     g = gemm_desc(dt, MODE_EPI_NONE, dt, NK, D, 4 * D, hbuf, 4 * D, lw.w2, 4 * D, ybuf, D);   // bf16 Y like the reference's autocast Linear
     g.w_expert_stride = 4L * D * D;
     g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
     g.split_k = ysplit; g.split_stride = (long)NK * D;
+    if (uniform) g.flags |= MODE_GEMM_UNIFORM_GROUPS;
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
     if (l + 1 < d.L) {

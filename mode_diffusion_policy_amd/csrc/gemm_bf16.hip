@@ -457,7 +457,8 @@ static int pick_cfg(const ModeGemmDesc* d) {
   // persistent ping-pong kernel (224 x 256 tiles, one workgroup per CU): whenever its tiles cover most of the chip - the expert up-projection from
   // B = 64 on (256 / 512 tiles at B = 64 / 128) and the K-sliced down-projection at B = 128 (16 x 4 tiles x 4 slices = 256).  Unsupported shapes
   // come back from its launcher and fall through to the 128x128 family below.
-  if (g_gemm_pp && (d->epilogue == MODE_EPI_SWIGLU || d->epilogue == MODE_EPI_NONE || d->epilogue == MODE_EPI_BIAS)) {
+  if (g_gemm_pp && (!d->expert_offsets || (d->flags & MODE_GEMM_UNIFORM_GROUPS)) &&
+      (d->epilogue == MODE_EPI_SWIGLU || d->epilogue == MODE_EPI_NONE || d->epilogue == MODE_EPI_BIAS)) {
     const int nout = d->epilogue == MODE_EPI_SWIGLU ? 128 : 256;
     const long tpp = ((rows + 223) / 224) * (d->N / nout) * (d->split_k > 1 ? d->split_k : 1);
     if (d->N % nout == 0 && tpp >= g_gemm_pp_min_tiles) return CFG_PP224;

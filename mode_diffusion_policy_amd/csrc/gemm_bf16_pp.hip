@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
   auto mma = [&](auto AH_, auto BH_) {
     constexpr int ah = decltype(AH_)::value, bh = decltype(BH_)::value, nf = ah ? FM1 : 4;
     if (ab_mma) return;
-    __builtin_amdgcn_s_setprio(1);
+    if (p.setprio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
 #pragma unroll
         for (int j = 0; j < 2; ++j)                              // swapped operands: D[weight row][token]
           acc[ah][bh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[bh][kh * 2 + j], A_[kh * 4 + i], acc[ah][bh][i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    if (p.setprio) __builtin_amdgcn_s_setprio(0);
   };
   auto stage = [&](auto OP_, auto T_, auto H_, const char* g, uint32_t o0, uint32_t o1) {
     constexpr int op = decltype(OP_)::value, t = decltype(T_)::value, h = decltype(H_)::value;
@@ -236,7 +236,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
   constexpr IC<1> _1{};
 #define PP_SB() __builtin_amdgcn_sched_barrier(0)
 #define PP_BAR() __builtin_amdgcn_s_barrier()
-  // one phase's compute part: barrier -> (fragments landed) -> 16 MFMAs -> barrier
+  // one phase's compute part: barrier -> (fragments landed) -> 16 MFMAs -> barrier.  (Measured and rejected: passing the second barrier after the
+  // first k32 half of the MFMAs so that its ~125-cycle release latency runs under the second half - 64.9 vs 60.4 us; the two wave rows then
+  // issue MFMAs into the same pipe at the same time and the split cluster schedules worse.)
 #define PP_COMPUTE(AH, BH)        \
   PP_BAR();                       \
   wait_lgkmcnt<0>();              \
@@ -279,33 +281,34 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
         for (int q = 0; q < 2; ++q) srow[h][q] = min(cur.row0 + h * 128 + (wave * 2 + q) * 8 + r8, last);   // rows past the segment re-read a valid row (never stored)
 #pragma unroll
       for (int q = 0; q < 2; ++q) nrow[q] = min(cur.row0 + (wave * 2 + q) * 16 + (lane >> 2), last);
-      if (p.a_rows) {                                              // condition hoisted: six independent loads
-        int tok[2][2], ntok[2];
+      // Issue order: the six index loads (hand-issued: the compiler would wait for them with vmcnt(0), i.e. behind the W DMA), then the four
+      // W half-tiles - cold in HBM, the longest latency of the start-up, and independent of the indices - then a COUNTED wait that lets the
+      // eight W DMA instructions stay in flight (loads retire in order), then the A half-tiles.
+      const bool gather = p.a_rows != nullptr;
+      int tk[6] = {0, 0, 0, 0, 0, 0};
+      if (gather) {
+        const int* ap[6] = {p.a_rows + srow[0][0], p.a_rows + srow[0][1], p.a_rows + srow[1][0], p.a_rows + srow[1][1],
+                            p.a_rows + (do_nrm ? nrow[0] : srow[0][0]), p.a_rows + (do_nrm ? nrow[1] : srow[0][0])};
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int q = 0; q < 2; ++q) tok[h][q] = p.a_rows[srow[h][q]];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) ntok[q] = do_nrm ? p.a_rows[nrow[q]] : 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int q = 0; q < 2; ++q) srow[h][q] = tok[h][q];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) nrow[q] = ntok[q];
+        for (int q = 0; q < 6; ++q) asm volatile("global_load_dword %0, %1, off" : "=v"(tk[q]) : "v"(ap[q]) : "memory");
+      }
+      stage(_1, _0, _0, Wc, b_off[0], b_off[1]);
+      stage(_1, _0, _1, Wc + w_half, b_off[0], b_off[1]);
+      stage(_1, _1, _0, Wc + 128, b_off[0], b_off[1]);
+      stage(_1, _1, _1, Wc + w_half + 128, b_off[0], b_off[1]);
+      if (gather) {
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(tk[0]), "+v"(tk[1]), "+v"(tk[2]), "+v"(tk[3]), "+v"(tk[4]), "+v"(tk[5])::"memory");
+        PP_SB();
+        srow[0][0] = tk[0]; srow[0][1] = tk[1]; srow[1][0] = tk[2]; srow[1][1] = tk[3]; nrow[0] = tk[4]; nrow[1] = tk[5];
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < 2; ++q) a_off[h][q] = (uint32_t)(((long)srow[h][q] * p.lda + lchunk * 8) * 2);
       if (L == wg * R) stamp(6);                                 // gathered-row indices landed
-      stage(_1, _0, _0, Wc, b_off[0], b_off[1]);
       stage(_0, _0, _0, Ak, a_off[0][0], a_off[0][1]);
-      stage(_1, _0, _1, Wc + w_half, b_off[0], b_off[1]);
       if (stage_a1) stage(_0, _0, _1, Ak, a_off[1][0], a_off[1][1]);
-      stage(_1, _1, _0, Wc + 128, b_off[0], b_off[1]);
       stage(_0, _1, _0, Ak + 128, a_off[0][0], a_off[0][1]);
-      stage(_1, _1, _1, Wc + w_half + 128, b_off[0], b_off[1]);
       if (stage_a1) stage(_0, _1, _1, Ak + 128, a_off[1][0], a_off[1][1]);
       if constexpr (SWI) {
         // fused ln_2 consumer: the tile rows' per-64-column partial sums of squares (64 B per token row) come in by DMA as well - 16 rows per

@@ -28,10 +28,11 @@ template <bool LP_BF16, int NCH>
 __device__ __forceinline__ void norm_store(const float* row, int D, float ssq, const float* g, const float* cond, float eps,
                                            float* y_f32, void* y_lp, int lane) {
   const float nrm = fmaxf(sqrtf(ssq) * rsqrtf((float)D), eps);
+  const float rnrm = __frcp_rn(nrm);                       // one reciprocal per row: a per-element fp32 division is a ~10-instruction VCC-serialised sequence
   for_chunks<NCH>(D, lane, [&](int d) {
     const float4 v = *reinterpret_cast<const float4*>(row + d);
     const float4 gg = *reinterpret_cast<const float4*>(g + d);
-    float4 o = make_float4(v.x / nrm * gg.x, v.y / nrm * gg.y, v.z / nrm * gg.z, v.w / nrm * gg.w);
+    float4 o = make_float4(v.x * rnrm * gg.x, v.y * rnrm * gg.y, v.z * rnrm * gg.z, v.w * rnrm * gg.w);
     if (cond) {
       const float4 c = *reinterpret_cast<const float4*>(cond + d);
       o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
@@ -87,7 +88,10 @@ __global__ __launch_bounds__(256) void rmsnorm_cond_kernel(const float* x, const
 }
 
 // ------------------------------------------------------------------------------------------------------- combine + norm
-template <bool LP_BF16, int NCH, int KK, bool FUSED>   // KK = top_k when known at compile time (1, 2), else 0; FUSED = ln_2 applied to u here
+// YS = split-K slab count of the down-projection when known at compile time (1, 2, 4), else 0.  With a run-time slab loop every slab's load
+// waited for the previous one's add (four dependent round trips per row at four slabs: 12 -> 16 us at B=128); unrolled, all the row's loads
+// are in flight together.
+template <bool LP_BF16, int NCH, int KK, bool FUSED, int YS>   // KK = top_k when known at compile time (1, 2), else 0; FUSED = ln_2 applied to u here
 __global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const void* __restrict__ Y, int y_bf16, int y_splits,
                                                            long y_split_stride, const int* __restrict__ pos,
                                                            const float* __restrict__ posw, int N, int D, int k,
@@ -103,6 +107,7 @@ __global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const
   const float* ur = u + (long)row * D;
   float u_nrm = 1.0f;
   if constexpr (FUSED) u_nrm = row_norm_from_partials(u_ss + (long)row * u_ss_n, u_ss_n, D, eps);
+  [[maybe_unused]] const float ru_nrm = __frcp_rn(u_nrm);
   const int kk = KK ? KK : k;
   long prow[KK ? KK : 8]; float pw[KK ? KK : 8];
 #pragma unroll
@@ -114,16 +119,26 @@ __global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const
     float4 uu = *reinterpret_cast<const float4*>(ur + d);
     if constexpr (FUSED) {                                // ln_2 applied here instead of in a kernel of its own
       const float4 gg = *reinterpret_cast<const float4*>(u_gain + d);
-      uu = make_float4(uu.x / u_nrm * gg.x, uu.y / u_nrm * gg.y, uu.z / u_nrm * gg.z, uu.w / u_nrm * gg.w);
+      uu = make_float4(uu.x * ru_nrm * gg.x, uu.y * ru_nrm * gg.y, uu.z * ru_nrm * gg.z, uu.w * ru_nrm * gg.w);
     }
     float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < (KK ? KK : 8); ++j) {           // ascending expert id: next += w * expert(x)   (modedit.py:566)
       if (j < kk) {
-        float4 y = load_y4(Y, y_bf16 != 0, prow[j] + d);
-        for (int z = 1; z < y_splits; ++z) {            // split-K slabs of the down-projection, added in slice order
-          const float4 t = load_y4(Y, y_bf16 != 0, (long)z * y_split_stride + prow[j] + d);
-          y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+        float4 y;
+        if constexpr (YS > 0) {                           // split-K slabs of the down-projection, added in slice order
+          float4 ys[YS];
+#pragma unroll
+          for (int z = 0; z < YS; ++z) ys[z] = load_y4(Y, y_bf16 != 0, (long)z * y_split_stride + prow[j] + d);
+          y = ys[0];
+#pragma unroll
+          for (int z = 1; z < YS; ++z) { y.x += ys[z].x; y.y += ys[z].y; y.z += ys[z].z; y.w += ys[z].w; }
+        } else {
+          y = load_y4(Y, y_bf16 != 0, prow[j] + d);
+          for (int z = 1; z < y_splits; ++z) {
+            const float4 t = load_y4(Y, y_bf16 != 0, (long)z * y_split_stride + prow[j] + d);
+            y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+          }
         }
         const float w = pw[j];
         nx.x = __fadd_rn(nx.x, __fmul_rn(w, y.x)); nx.y = __fadd_rn(nx.y, __fmul_rn(w, y.y));
@@ -148,11 +163,12 @@ __global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const
     }
     ssq = wave_sum(ssq);
     const float nrm = fmaxf(sqrtf(ssq) * rsqrtf((float)D), eps);
+    const float rnrm = __frcp_rn(nrm);                       // one reciprocal per row: a per-element fp32 division is a ~10-instruction VCC-serialised sequence
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int d = lane * 4 + c * 256;
       const float4 v = *reinterpret_cast<const float4*>(cache + d);
-      float4 o = make_float4(v.x / nrm * gq[c].x, v.y / nrm * gq[c].y, v.z / nrm * gq[c].z, v.w / nrm * gq[c].w);
+      float4 o = make_float4(v.x * rnrm * gq[c].x, v.y * rnrm * gq[c].y, v.z * rnrm * gq[c].z, v.w * rnrm * gq[c].w);
       if (cr) { o.x += cq[c].x; o.y += cq[c].y; o.z += cq[c].z; o.w += cq[c].w; }
       if constexpr (LP_BF16) {
         uint2 pk; pk.x = pack_bf16x2(o.x, o.y); pk.y = pack_bf16x2(o.z, o.w);
@@ -253,6 +269,7 @@ __global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
   const float* ur = h.u + row * D;
   const bool ybf = h.y_dtype == MODE_BF16;
   const float u_nrm = h.u_ss ? row_norm_from_partials(h.u_ss + row * h.u_ss_n, h.u_ss_n, D, h.eps) : 1.0f;
+  const float ru_nrm = __frcp_rn(u_nrm);
   // epilogue operands do not depend on the row math: fetch them first
   const bool act_lane = lane < h.A_dim;
   const long oidx = (long)ar * h.A_dim + lane;
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
     float4 uu = *reinterpret_cast<const float4*>(ur + d);
     if (h.u_ss) {
       const float4 gg = *reinterpret_cast<const float4*>(h.u_gain + d);
-      uu = make_float4(uu.x / u_nrm * gg.x, uu.y / u_nrm * gg.y, uu.z / u_nrm * gg.z, uu.w / u_nrm * gg.w);
+      uu = make_float4(uu.x * ru_nrm * gg.x, uu.y * ru_nrm * gg.y, uu.z * ru_nrm * gg.z, uu.w * ru_nrm * gg.w);
     }
     float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < h.k; ++j) {
@@ -299,10 +316,11 @@ __global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
     }
     ssq = wave_sum(ssq);
     const float nrm = fmaxf(sqrtf(ssq) * rsqrtf((float)D), h.eps);
+    const float rnrm = __frcp_rn(nrm);                       // one reciprocal per row: a per-element fp32 division is a ~10-instruction VCC-serialised sequence
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const float4 v = *reinterpret_cast<const float4*>(cache + lane * 4 + c * 256);
-      const float4 n = make_float4(v.x / nrm * gq[c].x, v.y / nrm * gq[c].y, v.z / nrm * gq[c].z, v.w / nrm * gq[c].w);
+      const float4 n = make_float4(v.x * rnrm * gq[c].x, v.y * rnrm * gq[c].y, v.z * rnrm * gq[c].z, v.w * rnrm * gq[c].w);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (j < h.A_dim) accv[j] += n.x * wq[c][j].x + n.y * wq[c][j].y + n.z * wq[c][j].z + n.w * wq[c][j].w;
@@ -310,10 +328,11 @@ __global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
   } else {
     ssq = wave_sum(ssq);
     const float nrm = fmaxf(sqrtf(ssq) * rsqrtf((float)D), h.eps);
+    const float rnrm = __frcp_rn(nrm);                       // one reciprocal per row: a per-element fp32 division is a ~10-instruction VCC-serialised sequence
     for (int d = lane * 4; d < D; d += 256) {
       const float4 v = *reinterpret_cast<const float4*>(cache + d);
       const float4 gg = *reinterpret_cast<const float4*>(h.g + d);
-      const float4 n = make_float4(v.x / nrm * gg.x, v.y / nrm * gg.y, v.z / nrm * gg.z, v.w / nrm * gg.w);
+      const float4 n = make_float4(v.x * rnrm * gg.x, v.y * rnrm * gg.y, v.z * rnrm * gg.z, v.w * rnrm * gg.w);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (j < h.A_dim) {
@@ -389,9 +408,11 @@ template <bool LP, int NCH>
 static void launch_combine_k(dim3 grid, size_t lds, hipStream_t st, const float* u, const void* Y, int ybf, int ys, long yss, const int* pos,
                              const float* posw, int N, int D, int k, const float* g, const float* cond, int rpc, float eps, float* x_next,
                              void* h, const float* u_ss, int u_ss_n, const float* u_gain) {
-#define MODE_COMBINE(KK, F) hipLaunchKernelGGL((combine_norm_kernel<LP, NCH, KK, F>), grid, dim3(256), lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h, u_ss, u_ss_n, u_gain)
-  if (u_ss) { if (k == 2) MODE_COMBINE(2, true); else if (k == 1) MODE_COMBINE(1, true); else MODE_COMBINE(0, true); }
-  else { if (k == 2) MODE_COMBINE(2, false); else if (k == 1) MODE_COMBINE(1, false); else MODE_COMBINE(0, false); }
+#define MODE_COMBINE(KK, F, S) hipLaunchKernelGGL((combine_norm_kernel<LP, NCH, KK, F, S>), grid, dim3(256), lds, st, u, Y, ybf, ys, yss, pos, posw, N, D, k, g, cond, rpc, eps, x_next, h, u_ss, u_ss_n, u_gain)
+  if (u_ss && k == 2 && (ys == 1 || ys == 2 || ys == 4)) {      // the chain's shapes: slab loop unrolled
+    if (ys == 4) MODE_COMBINE(2, true, 4); else if (ys == 2) MODE_COMBINE(2, true, 2); else MODE_COMBINE(2, true, 1);
+  } else if (u_ss) { if (k == 2) MODE_COMBINE(2, true, 0); else if (k == 1) MODE_COMBINE(1, true, 0); else MODE_COMBINE(0, true, 0); }
+  else { if (k == 2) MODE_COMBINE(2, false, 0); else if (k == 1) MODE_COMBINE(1, false, 0); else MODE_COMBINE(0, false, 0); }
 #undef MODE_COMBINE
 }
 

@@ -268,6 +268,63 @@ class ArenaGradReducer:
                 done[(lo, hi)] = e
         return done
 
+    def reduce_scatter_async(self, only=None):
+        """ZeRO-1 exchange: every slice (or only slice ``only``) is reduce-scattered IN PLACE (rank r ends up with the sum of its 1/world part of
+        the slice, at its own offset of the gradient arena - RCCL's in-place layout recvbuff == sendbuff + rank * count); queued on the
+        communication stream behind the slice's block event.  Returns [(lo, hi, shard_lo, shard_hi, event)] in slice order.  Half the bytes of an
+        all-reduce on the wire; the optimizer then updates only the shard and all-gathers the new weights (``FusedAdamW.step(zero1=...)``)."""
+        cur = torch.cuda.current_stream() if self._comm_stream is not None else None
+        rank = dist.get_rank(self.pg) if self.world > 1 else 0
+        out = []
+        from contextlib import nullcontext
+        for sl in (self.slices if only is None else [self.slices[only]]):
+            lo, hi, ev = sl if len(sl) == 3 else (sl[0], sl[1], None)
+            if (hi - lo) % self.world:
+                raise ValueError(f"slice [{lo}, {hi}) does not split evenly over {self.world} ranks")
+            per = (hi - lo) // self.world
+            slo, shi = lo + rank * per, lo + (rank + 1) * per
+            if self._comm_stream is not None:
+                if ev is not None:
+                    self._comm_stream.wait_event(ev)
+                else:
+                    self._comm_stream.wait_stream(cur)
+            with (torch.cuda.stream(self._comm_stream) if self._comm_stream is not None else nullcontext()):
+                if self.world > 1:
+                    g = self.grad[lo:hi]
+                    if self.comm_dtype != torch.float32:
+                        if self._stage is None or self._stage.numel() < g.numel():
+                            longest = max(h - l for l, h, *_ in self.slices)
+                            self._stage = torch.empty(longest, dtype=self.comm_dtype, device=g.device)
+                        st = self._stage[: g.numel()]
+                        st.copy_(g)
+                        dist.reduce_scatter_tensor(st[rank * per:(rank + 1) * per], st, op=dist.ReduceOp.SUM, group=self.pg)
+                        self.grad[slo:shi].copy_(st[rank * per:(rank + 1) * per])
+                    else:
+                        dist.reduce_scatter_tensor(self.grad[slo:shi], g, op=dist.ReduceOp.SUM, group=self.pg)
+                e = None
+                if self._comm_stream is not None:
+                    e = torch.cuda.Event()
+                    e.record(self._comm_stream)
+            out.append((lo, hi, slo, shi, e))
+        return out
+
+    def all_gather_async(self, flat: torch.Tensor, lo: int, hi: int, after=None):
+        """All-gather ``flat[lo:hi]`` in place (every rank contributes its 1/world part) on the communication stream, after ``after`` (an event
+        on another stream: the shard's optimizer update).  Returns the event recorded behind the collective."""
+        from contextlib import nullcontext
+        per = (hi - lo) // self.world
+        rank = dist.get_rank(self.pg) if self.world > 1 else 0
+        if self._comm_stream is not None and after is not None:
+            self._comm_stream.wait_event(after)
+        with (torch.cuda.stream(self._comm_stream) if self._comm_stream is not None else nullcontext()):
+            if self.world > 1:
+                dist.all_gather_into_tensor(flat[lo:hi], flat[lo + rank * per: lo + (rank + 1) * per], group=self.pg)
+            e = None
+            if self._comm_stream is not None:
+                e = torch.cuda.Event()
+                e.record(self._comm_stream)
+        return e
+
     def reduce(self) -> float:
         """Sum (or average) the gradient arena over ranks; returns the scale the optimizer still has to apply.  Call right after
         ``loss.backward()`` returned: the backward kernels are still executing, the collectives queue up behind their events."""

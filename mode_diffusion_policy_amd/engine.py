@@ -8,7 +8,9 @@ swap — SURVEY.md §7 "weight-layout staleness").
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import gc
 from typing import Optional, Tuple
 
 import torch
@@ -24,6 +26,23 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+@contextlib.contextmanager
+def capture_graph(graph: "torch.cuda.CUDAGraph"):
+    """hipGraph stream capture with the Python cyclic collector held off.  A collection that happens to fire inside the capture window can
+    run the destructor of an older, unreachable ``CUDAGraph`` (hipGraphExecDestroy + release of its private pool), which the runtime refuses
+    while a capture is open and the process aborts; so dead cycles are collected BEFORE the capture opens and the collector stays disabled
+    until it closes.  ``thread_local`` error mode: other threads (the RCCL watchdog) may touch the runtime during capture."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class DitEngine:

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .engine import DitEngine
+from .engine import DitEngine, capture_graph
 
 logger = logging.getLogger(__name__)
 
@@ -391,7 +391,7 @@ class MoDeDiT(nn.Module):
                     self._ddim_steps(eng, st["img"], st["goals"], st["x"], st["sched"], n)
                 torch.cuda.current_stream(dev).wait_stream(side)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
+                with capture_graph(g):
                     st["ml"] = self._ddim_steps(eng, st["img"], st["goals"], st["x"], st["sched"], n)
             st["graph"], st["sched_key"] = g, sched_key
             self._route_cache["graph"] = ent = st

@@ -85,7 +85,74 @@ class FusedAdamW:
         return blocks, rest
 
     @torch.no_grad()
-    def step(self, grad_scale: float = 1.0, overlap: bool = False, reducer=None, ema=None) -> None:
+    def _step_zero1(self, grad_scale: float, reducer, gather: str, lp, gd, gn) -> None:
+        """ZeRO-1 over the data-parallel ranks: per block slice {reduce-scatter of the gradients (behind the block's backward event) -> AdamW on
+        THIS rank's 1/world shard only -> all-gather of the updated weights}, everything chained per slice on side streams.  The HBM-bound
+        optimizer pass shrinks by the world size (20.5 GB -> 2.6 GB per rank at 8 GPUs: 3.4 -> ~0.45 ms) and the wire carries a reduce-scatter +
+        an all-gather (each half an all-reduce's bytes).  ``gather='fp32'``: the fp32 weights are gathered (every rank keeps exact masters,
+        the bf16 shadow is re-cast locally); ``gather='bf16'``: only the bf16 compute shadow is gathered (half the bytes again) - the fp32
+        masters of the OTHER ranks' shards are then refreshed from it (bf16-rounded) and ``gather_master()`` restores exact masters everywhere
+        before a checkpoint."""
+        eng, ar = self.eng, self.arena
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=eng.device, priority=int(os.environ.get("MODE_OPT_PRIO", "0")))
+        cur = torch.cuda.current_stream()
+        if self._ema_now[0] is not None:
+            raise NotImplementedError("ZeRO-1 step with a fused EMA: call ArenaEMA.update(step) after the step instead")
+        n_red = ar.bounds["no_decay"]
+        dec = ar.bounds["decay"]
+        parts, done = [], []
+        with torch.cuda.stream(self._side):
+            # collectives run in issue order: per slice reduce-scatter -> (shard update) -> all-gather, so that the all-gather of block l travels
+            # while the earlier blocks are still back-propagating instead of queueing behind every reduce-scatter
+            for si in range(len(reducer.slices)):
+                with torch.cuda.stream(cur):
+                    (lo, hi, slo, shi, ev), = reducer.reduce_scatter_async(only=si)
+                parts.append((lo, hi, slo, shi, ev))
+                if ev is not None:
+                    self._side.wait_event(ev)
+                # the shard may straddle the decay / no-decay boundary
+                if slo < min(shi, dec):
+                    self._launch(slo, min(shi, dec), gd, lp, grad_scale)
+                if max(slo, dec) < shi:
+                    self._launch(max(slo, dec), shi, gn, lp, grad_scale)
+                upd = torch.cuda.Event(); upd.record(self._side)
+                if gather == "bf16" and lp is not None:
+                    done.append((lo, hi, slo, shi, reducer.all_gather_async(lp, lo, hi, after=upd)))
+                else:
+                    done.append((lo, hi, slo, shi, reducer.all_gather_async(ar.flat, lo, hi, after=upd)))
+            for lo, hi, slo, shi, e in done:                           # refresh what was not gathered
+                if e is not None:
+                    self._side.wait_event(e)
+                if gather == "bf16" and lp is not None:
+                    if slo > lo:
+                        ar.flat[lo:slo].copy_(lp[lo:slo])
+                    if shi < hi:
+                        ar.flat[shi:hi].copy_(lp[shi:hi])
+                elif lp is not None:
+                    if slo > lo:
+                        lp[lo:slo].copy_(ar.flat[lo:slo])
+                    if shi < hi:
+                        lp[shi:hi].copy_(ar.flat[shi:hi])
+        cur.wait_stream(self._side)
+        covered = sum(hi - lo for lo, hi, *_ in parts)
+        if covered != n_red:
+            raise RuntimeError("ZeRO-1 step: the reducer's slices do not tile the optimised arena")
+        self._master_sharded = gather == "bf16" and lp is not None and reducer.world > 1
+
+    @torch.no_grad()
+    def gather_master(self, reducer) -> None:
+        """After ``zero1='bf16'`` steps: all-gather the exact fp32 masters of every shard (call before ``state_dict()`` / a checkpoint)."""
+        if not getattr(self, "_master_sharded", False):
+            return
+        ev = [reducer.all_gather_async(self.arena.flat, lo, hi, after=None) for lo, hi, *_ in [(s[0], s[1]) for s in reducer.slices]]
+        for e in ev:
+            if e is not None:
+                torch.cuda.current_stream().wait_event(e)
+        self._master_sharded = False
+
+    @torch.no_grad()
+    def step(self, grad_scale: float = 1.0, overlap: bool = False, reducer=None, ema=None, zero1=None) -> None:
         """One AdamW update of the whole arena.
 
         Default: (exchange gradients through ``reducer`` — its collectives overlap the backward —, then) two launches over the decay / no-decay
@@ -123,7 +190,11 @@ class FusedAdamW:
         events = train.events if (train is not None and train.events is not None) else None
         if reducer is not None and reducer.world > 1:
             grad_scale = grad_scale * (1.0 if reducer.average else 1.0 / reducer.world)
-        if not overlap or events is None:
+        if zero1 and reducer is not None and eng.device.type == "cuda":
+            if zero1 not in ("fp32", "bf16"):
+                raise ValueError("zero1 must be None, 'fp32' or 'bf16'")
+            self._step_zero1(grad_scale, reducer, zero1, lp, gd, gn)
+        elif not overlap or events is None:
             if reducer is not None:
                 reducer.reduce()
             self._launch(0, ar.bounds["decay"], gd, lp, grad_scale)

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--screen", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--cfgs", default="0,17,17f1,17f32,17f33,17f16", help="variants to time: NN[fK] = gemm_cfg NN with pp_flags K; 0 = the 128x128 family (gemm_pp off)")
+    ap.add_argument("--cfgs", default="0,17,17f128,17f16", help="variants to time: NN[fK] = gemm_cfg NN with pp_flags K; 0 = the 128x128 family (gemm_pp off)")
     a = ap.parse_args()
     lib = L.load()
     dev = torch.device("cuda:0")
@@ -60,7 +60,9 @@ def main():
         c, _, fl = str(v).partition("f")
         lib.mode_set_option(b"gemm_cfg", int(c))
         lib.mode_set_option(b"gemm_pp", 0 if int(c) == 0 else 1)
-        lib.mode_set_option(b"pp_flags", int(fl) if fl else 0)
+        fl = int(fl) if fl else 0
+        lib.mode_set_option(b"pp_flags", fl & 127)
+        lib.mode_set_option(b"gemm_setprio", 0 if fl & 128 else 1)              # f128 = no s_setprio around the MFMA clusters
 
     def run(cfg, d):
         setv(cfg)

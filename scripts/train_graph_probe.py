@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+from mode_diffusion_policy_amd.engine import capture_graph  # noqa: E402
 from mode_diffusion_policy_amd.utils import rand_log_logistic  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -46,7 +47,7 @@ torch.cuda.current_stream().wait_stream(side)
 torch.cuda.synchronize()
 try:
     gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+    with capture_graph(gr):
         fb()
     print(f"graph replay forward+backward: {timeit(gr.replay):.2f} ms", flush=True)
 except Exception as e:  # noqa: BLE001

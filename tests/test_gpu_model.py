@@ -228,6 +228,12 @@ def test_c2_full_size_properties(c2_model):
     # (3) batch-slice consistency: the first 8 samples alone give the same result as inside the batch of 128
     x8 = M.sample_ddim(den, {"state_images": inp["state_images"][:8]}, inp["x0"][:8], inp["goals"][:8], sig, disable=True)
     assert torch.equal(x8, x[:8])
+    # (3a) BASELINE configs[4]'s batch: 32 environments (other GEMM tile configurations than B=128 / B=8: 64x64 K-sliced down-projection, ring-2
+    #      128x128 up-projection) - finite, deterministic across replays, bit-identical to the same samples inside the batch of 128
+    st32 = {"state_images": inp["state_images"][:32]}
+    x32 = M.sample_ddim(den, st32, inp["x0"][:32], inp["goals"][:32], sig, disable=True)
+    assert torch.isfinite(x32).all() and torch.equal(x32, x[:32])
+    assert torch.equal(x32, M.sample_ddim(den, st32, inp["x0"][:32], inp["goals"][:32], sig, disable=True))
     # (3b) one and two environments take the weight-streaming GEMMs (another fp32 summation order): equal to bf16 rounding, not bit for bit
     for nb in (1, 2):
         xs = M.sample_ddim(den, {"state_images": inp["state_images"][:nb]}, inp["x0"][:nb], inp["goals"][:nb], sig, disable=True)
