@@ -124,6 +124,12 @@ typedef struct ModeGemmDesc {
  *                             fixed tiles-per-workgroup split loses to the 128x128 family when ragged segments add partial tiles (measured at
  *                             four ragged experts: 81 vs 74 us).  Never changes results (all forward kernels are bit-identical). */
 #define MODE_GEMM_UNIFORM_GROUPS 8
+/*   MODE_GEMM_SMALL_ROWS      bf16 forward layout: the caller vouches that no group (expert segment; the whole problem when ungrouped) has more
+ *                             than "gemm_skinny_rows" rows - the small-batch chain (B <= 2 environments).  The GEMM then always takes the
+ *                             weight-streaming kernel, and the fused ln_2 works on 16-column partials: MODE_EPI_RESIDUAL_NORM (N % 16 == 0)
+ *                             writes row_ss_out as [M, N/16], MODE_EPI_SWIGLU accepts any row_ss_n.  MODE_ERR_UNSUPPORTED when the streamer is
+ *                             switched off ("gemm_skinny_rows" = 0 / a forced "gemm_cfg") or does not take the shape. */
+#define MODE_GEMM_SMALL_ROWS 16
 int mode_gemm(const ModeGemmDesc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

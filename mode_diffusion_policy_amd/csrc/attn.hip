@@ -35,18 +35,15 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
   const bool tv = fr < T;
   const uint16_t* rowp = qkv + ((long)b * T + (tv ? fr : 0)) * ld + h * HD + fq * 8;
 
-  // ---- V^T fragments first: 4 keys x 1 dim per d-block, requested before anything else so the global latency hides under QK^T/softmax
+  // ---- V rows first (requested before anything else: the global latency hides under QK^T / softmax): FOUR 16-byte loads per lane, keys
+  // fq*4 + j, dims fr*8 .. fr*8+7.  Branch-free (clamped address + select): as predicated 2-byte loads this block compiled into 16 serial
+  // branch + s_waitcnt vmcnt(0) pairs, 7.4 us of dependent round trips per launch whatever the batch.
   const uint16_t* vbase = qkv + (long)b * T * ld + 2L * D + h * HD;
-  uint32_t vv[2 * NKS][2];
+  uint4 vr[4];
 #pragma unroll
-  for (int db = 0; db < 2 * NKS; ++db) {
-    uint32_t v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int key = fq * 4 + j;
-      v[j] = (key < T && db * 16 < HD) ? (uint32_t)vbase[(long)key * ld + db * 16 + fr] : 0u;
-    }
-    vv[db][0] = v[0] | (v[1] << 16); vv[db][1] = v[2] | (v[3] << 16);
+  for (int j = 0; j < 4; ++j) {
+    const int key = fq * 4 + j;
+    vr[j] = *reinterpret_cast<const uint4*>(vbase + (long)min(key, T - 1) * ld + min(fr * 8, HD - 8));   // masked where it is used
   }
 
   // ---- qk-norm gains: independent of everything else, fetched up front (their round trip used to follow the row-norm reduction)
@@ -58,16 +55,30 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
     gk4[ks][0] = *reinterpret_cast<const float4*>(kg + dg); gk4[ks][1] = *reinterpret_cast<const float4*>(kg + dg + 4);
   }
 
-  // ---- load q / k fragments: token row fr, dims ks*32 + fq*8 + [0,8)
+  // ---- load q / k fragments: token row fr, dims ks*32 + fq*8 + [0,8).  All loads of the kernel are requested here, ahead of any use; the
+  // scheduling barrier keeps the compiler from sinking them to their use sites (it did: ~20 waits on partial results in a row)
+  uint4 tq_[NKS], tk_[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int dq = (ks * 32 + fq * 8 < HD) ? ks * 32 : 0;     // clamped address + select below: no branch around the loads
+    tq_[ks] = *reinterpret_cast<const uint4*>(rowp + dq); tk_[ks] = *reinterpret_cast<const uint4*>(rowp + D + dq);
+  }
+  // (an empty asm that "modifies" every loaded register: the loads cannot move below it, so the kernel has ONE wait for one round trip)
+#define MODE_PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+#pragma unroll
+  for (int j = 0; j < 4; ++j) MODE_PIN4(vr[j]);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    MODE_PIN4(gq4[ks][0]); MODE_PIN4(gq4[ks][1]); MODE_PIN4(gk4[ks][0]); MODE_PIN4(gk4[ks][1]); MODE_PIN4(tq_[ks]); MODE_PIN4(tk_[ks]);
+  }
+#undef MODE_PIN4
   float qf[NKS][8], kf[NKS][8];
   float qss = 0.f, kss = 0.f;
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
-    uint4 rq = make_uint4(0, 0, 0, 0), rk = make_uint4(0, 0, 0, 0);
-    if (tv && ks * 32 + fq * 8 < HD) {
-      rq = *reinterpret_cast<const uint4*>(rowp + ks * 32);
-      rk = *reinterpret_cast<const uint4*>(rowp + D + ks * 32);
-    }
+    const bool okq = tv && ks * 32 + fq * 8 < HD;
+    const uint4 rq = make_uint4(okq ? tq_[ks].x : 0u, okq ? tq_[ks].y : 0u, okq ? tq_[ks].z : 0u, okq ? tq_[ks].w : 0u);
+    const uint4 rk = make_uint4(okq ? tk_[ks].x : 0u, okq ? tk_[ks].y : 0u, okq ? tk_[ks].z : 0u, okq ? tk_[ks].w : 0u);
     const uint32_t uq[4] = {rq.x, rq.y, rq.z, rq.w}, uk[4] = {rk.x, rk.y, rk.z, rk.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -125,18 +136,34 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const uint16_t* __restri
   uint4 tp = make_uint4(pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), 0u, 0u);
   const bf16x8 pfrag = *reinterpret_cast<bf16x8*>(&tp);          // B operand: slots 0..3 = keys fq*4+r, slots 4..7 = 0
 
-  // ---- O^T[d][query] = sum_key V[key][d] P[query][key]; A operand = V^T fragment: row d = db*16 + fr, slots j<4 = keys fq*4+j
-  uint16_t* yrow = y + ((long)b * T + fr) * D + h * HD + fq * 4;
+  // ---- O^T[row][query] = sum_key V[key][dim(row)] P[query][key].  MFMA i (0..7) takes as its 16 rows the dims fr*8 + i - element i of each
+  // lane's four V vectors is its A operand (k-slots j < 4 = keys fq*4+j, slots 4..7 zero) - so that a lane ends up with 8 CONSECUTIVE dims
+  // (fq*4+r)*8 .. +7 of its query per accumulator register r: four 16-byte stores.
+  uint32_t vd[4][4];
 #pragma unroll
-  for (int db = 0; db < 2 * NKS; ++db) {
-    uint4 tvv = make_uint4(vv[db][0], vv[db][1], 0u, 0u);
+  for (int j = 0; j < 4; ++j) {
+    const bool okv = fq * 4 + j < T && fr * 8 < HD;               // keys past T / dims past head_dim (clamped loads above) are zero operands
+    vd[j][0] = okv ? vr[j].x : 0u; vd[j][1] = okv ? vr[j].y : 0u; vd[j][2] = okv ? vr[j].z : 0u; vd[j][3] = okv ? vr[j].w : 0u;
+  }
+  float ov[4][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int dw = i >> 1, sh = (i & 1) * 16;
+    const uint32_t e0 = (vd[0][dw] >> sh) & 0xffffu, e1 = (vd[1][dw] >> sh) & 0xffffu, e2 = (vd[2][dw] >> sh) & 0xffffu, e3 = (vd[3][dw] >> sh) & 0xffffu;
+    uint4 tvv = make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), 0u, 0u);
     const bf16x8 vfrag = *reinterpret_cast<bf16x8*>(&tvv);
     f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag, o, 0, 0, 0);     // D[row = d_local][col = query]
-    if (tv && db * 16 < HD) {
-      uint2 pk; pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
-      *reinterpret_cast<uint2*>(yrow + db * 16) = pk;                           // y[b, query=fr, h*HD + db*16 + fq*4 + r]
-    }
+    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag, o, 0, 0, 0);     // D[row = fq*4 + r][col = query fr]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ov[r][i] = o[r];
+  }
+  uint16_t* yrow = y + ((long)b * T + fr) * D + h * HD;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int d0 = (fq * 4 + r) * 8;
+    if (tv && d0 < HD)
+      *reinterpret_cast<uint4*>(yrow + d0) = make_uint4(pack_bf16x2(ov[r][0], ov[r][1]), pack_bf16x2(ov[r][2], ov[r][3]),
+                                                        pack_bf16x2(ov[r][4], ov[r][5]), pack_bf16x2(ov[r][6], ov[r][7]));
   }
 }
 

@@ -20,6 +20,7 @@ extern int g_gemm_pp;
 extern int g_pp_flags;
 extern int g_gemm_pp_min_tiles;
 extern unsigned long long g_pp_trace;
+extern int g_combine_row_max;
 extern int g_tr_cfg;
 extern int g_gemm_group_m;
 extern int g_attn_bwd_stop;
@@ -44,7 +45,7 @@ static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
   w.y = take(N * D * esz);
   w.hbuf = take(NK * 4 * D * esz);
   w.ybuf = take(NK * D * 16);       // expert outputs (compute dtype): up to 8 bf16 split-K slabs of the down-projection (or one fp32 slab)
-  w.rowss = take(N * ((D + 63) / 64) * 4);   // fused ln_2: per-64-column sums of squares of the residual stream
+  w.rowss = take(N * ((D + 15) / 16) * 4);   // fused ln_2: per-64-column sums of squares of the residual stream (per 16 columns in the small-batch chain)
   w.meta = take((size_t)d.L * ml.total_words * 4);
   const size_t Rr = R > 0 ? R : 1;
   w.e1 = take(Rr * D * 4);
@@ -119,6 +120,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_skinny_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_skinny_rows = value; return MODE_OK; }
   if (!strcmp(key, "gemm_setprio")) { g_gemm_setprio = value != 0; return MODE_OK; }
   if (!strcmp(key, "fuse_ln2")) { g_fuse_ln2 = value != 0; return MODE_OK; }
+  if (!strcmp(key, "combine_row_max")) { if (value < 0) return MODE_ERR_BAD_ARG; g_combine_row_max = value; return MODE_OK; }
   if (!strcmp(key, "dn_split_k")) { if (value < 0 || value > 8) return MODE_ERR_BAD_ARG; g_dn_split_k = value; return MODE_OK; }
   return MODE_ERR_UNSUPPORTED;
 }
@@ -263,9 +265,12 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
   void* h = ws + L.h; void* qkv = ws + L.qkv; void* yat = ws + L.y; void* hbuf = ws + L.hbuf;
   void* ybuf = ws + L.ybuf;
   float* rowss = (float*)(ws + L.rowss);
-  // (a handful of token rows take the weight-streaming GEMM, which has no fused-ln_2 epilogue: ln_2 stays a kernel of its own there)
-  const bool fuse = g_fuse_ln2 && dt == MODE_BF16 && D % 64 == 0 && N > g_gemm_skinny_rows;
-  const int ssn = D / 64;
+  // Small-batch chain (B <= 2 environments: N <= "gemm_skinny_rows" token rows): every GEMM of the layer is a weight stream
+  // (MODE_GEMM_SMALL_ROWS: also the grouped ones, whose segments have at most N rows), the fused ln_2 works on 16-column partials.
+  const bool small = dt == MODE_BF16 && g_gemm_cfg == 0 && g_gemm_skinny_rows > 0 && N <= g_gemm_skinny_rows && D % 128 == 0;
+  const bool fuse = g_fuse_ln2 && dt == MODE_BF16 && D % 64 == 0;
+  const int ssn = small ? D / 16 : D / 64;
+  const int small_flag = small ? MODE_GEMM_SMALL_ROWS : 0;
   ModeMetaLayout ml;
   mode_moe_meta_layout(N, d.E, d.k, &ml);
   const int ysplit = down_proj_split(dt, 4 * D);
@@ -291,7 +296,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     const int32_t* meta = a->meta + (long)l * a->meta_layer_stride;
     // q,k,v as ONE GEMM [N,D] x [3D,D]^T + bias   (modedit.py:108-110, 141-143)
     ModeGemmDesc g = gemm_desc(dt, MODE_EPI_BIAS, dt, N, 3 * D, D, h, D, lw.wqkv, D, qkv, 3 * D);
-    g.bias = lw.bqkv;
+    g.bias = lw.bqkv; g.flags = small_flag;
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
     rc = mode_attn_block_fwd(qkv, lw.qn_g, lw.kn_g, yat, dt, B, T, d.H, D / d.H, d.eps, 0u, 0.0f, stream);
@@ -301,7 +306,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     // squares of x, the up-projection scales its accumulator rows by 1 / max(|x| D^-1/2, eps) — (x g / n) W^T == ((x g) W^T) / n — and the
     // combine / head kernel rebuilds the normalised fp32 residual from x, the sums and g.
     g = gemm_desc(dt, fuse ? MODE_EPI_RESIDUAL_NORM : MODE_EPI_RESIDUAL, MODE_F32, N, D, D, yat, D, lw.wo, D, x, D);
-    g.resid = x; g.ldr = D;
+    g.resid = x; g.ldr = D; g.flags = small_flag;
     if (fuse) { g.C2 = h; g.ldc2 = D; g.gain = lw.ln2_g; g.row_ss_out = rowss; }
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
@@ -315,6 +320,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     g.bias = lw.b1; g.w_expert_stride = 8L * D * D; g.bias_expert_stride = 8L * D;
     g.a_rows = meta + ml.perm; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
     if (fuse) { g.row_ss = rowss; g.row_ss_n = ssn; g.row_eps = d.eps; }
+    g.flags = small_flag;
     if (uniform) g.flags |= MODE_GEMM_UNIFORM_GROUPS;
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
@@ -322,6 +328,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     g.w_expert_stride = 4L * D * D;
     g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
     g.split_k = ysplit; g.split_stride = (long)NK * D;
+    g.flags = small_flag;
     if (uniform) g.flags |= MODE_GEMM_UNIFORM_GROUPS;
     rc = mode_gemm(&g, stream);
     if (rc) return rc;

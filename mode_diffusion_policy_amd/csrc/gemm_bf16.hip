@@ -485,7 +485,8 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
     return MODE_ERR_BAD_ARG;
   if ((d->epilogue == MODE_EPI_RESIDUAL || d->epilogue == MODE_EPI_RESIDUAL_NORM) && (!d->resid || d->out_dtype != MODE_F32 || d->ldr % 4))
     return MODE_ERR_BAD_ARG;
-  if (d->epilogue == MODE_EPI_RESIDUAL_NORM && (!d->C2 || !d->gain || !d->row_ss_out || d->N % 64 || d->ldc2 % 4 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
+  const bool small_rows = (d->flags & MODE_GEMM_SMALL_ROWS) != 0;
+  if (d->epilogue == MODE_EPI_RESIDUAL_NORM && (!d->C2 || !d->gain || !d->row_ss_out || d->N % (small_rows ? 16 : 64) || d->ldc2 % 4 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
   if (d->row_ss && (d->epilogue != MODE_EPI_SWIGLU || d->row_ss_n <= 0)) return MODE_ERR_BAD_ARG;
   if (d->M <= 0) return MODE_OK;
   GemmParams p;
@@ -511,9 +512,10 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.setprio = g_gemm_setprio;
   p.pp_flags = g_pp_flags;
   if (p.koffs && (d->num_k_groups <= 0 || p.split_k > 1 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
-  if (g_gemm_cfg == CFG_AUTO && d->M <= g_gemm_skinny_rows) {
+  if (small_rows && (g_gemm_cfg != CFG_AUTO || g_gemm_skinny_rows <= 0)) return MODE_ERR_UNSUPPORTED;   // the caller sized its row_ss buffers for the streamer
+  if (g_gemm_cfg == CFG_AUTO && (d->M <= g_gemm_skinny_rows || small_rows)) {
     const int rc = gemm_bf16_skinny_launch(d, p, s);
-    if (rc != MODE_ERR_UNSUPPORTED) return rc;
+    if (rc != MODE_ERR_UNSUPPORTED || small_rows) return rc;
   }
   int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d);
   if (cfg == CFG_PP256 || cfg == CFG_PP224) {

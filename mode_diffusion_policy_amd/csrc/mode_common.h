@@ -101,9 +101,21 @@ __device__ __forceinline__ float sum_row_partials(const float* __restrict__ sp, 
   return s;
 }
 
+// Wave-cooperative form for rows that carry MORE than 16 partials (the small-batch chain: the weight-streaming c_proj publishes one partial per
+// 16 columns, D/16 = 64 per row): lane j fetches partial j (+64, ...), butterfly sum — every lane of the wave returns the same value, and every
+// consumer of such rows (up-projection prologue, combine, head) uses this one function so that they all see the same norm.  n <= 16 keeps the
+// ascending-order sum above (the tiled chain's bit pattern).  All 64 lanes must call it together.
+__device__ __forceinline__ float sum_row_partials_wave(const float* __restrict__ sp, int n, int lane) {
+  if (n <= 16) return sum_row_partials(sp, n);
+  float s = 0.f;
+  for (int j = lane; j < n; j += 64) s += sp[j];
+  return wave_sum(s);
+}
+
 // Rows up to which the bf16 GEMM uses the weight-streaming kernel of gemm_bf16_skinny.hip ("gemm_skinny_rows" option; 0 = off)
 extern int g_gemm_skinny_rows;
 extern int g_gemm_setprio;
+extern int g_gemm_cfg;
 
 #define MODE_LAUNCH_CHECK()                                  \
   do {                                                       \

@@ -307,6 +307,80 @@ def test_fused_ln2_chain_matches_separate_kernels(N_tok, D, E, k, cfg):
     assert rel(xn_b, xn_a) < 1e-6 and rel(h_b.float(), h_a.float()) < 4e-3
 
 
+
+@pytest.mark.parametrize("N_tok,D,E,k,S", [(14, 1024, 4, 2, 4), (28, 1024, 4, 2, 2), (14, 256, 4, 2, 4), (28, 256, 2, 1, 1), (9, 128, 4, 2, 2)])
+def test_small_rows_fused_ln2_chain(N_tok, D, E, k, S):
+    """The small-batch chain (B <= 2 environments, MODE_GEMM_SMALL_ROWS): every GEMM is the weight streamer — also the grouped ones, whose
+    segments have at most N_tok rows although M = N_tok*k exceeds "gemm_skinny_rows" — and the fused ln_2 works on 16-column partials:
+    c_proj (RESIDUAL_NORM, [M, D/16] sums of squares) -> up-projection (row scale from D/16 partials) -> K-sliced down-projection ->
+    one-workgroup-per-row combine (u_ss with D/16 partials, S slabs).  Checked against fp64 torch fed the same bf16 operands."""
+    import ctypes as C
+    lib = L.load()
+    p, st = H.p, H.stream()
+    bf = torch.bfloat16
+    ya = rnd(N_tok, D, seed=1).to(bf).to(dev()); wo = rnd(D, D, seed=2, scale=D ** -0.5).to(bf).to(dev())
+    x0 = rnd(N_tok, D, seed=3).to(dev()); g2 = (1.0 + 0.2 * rnd(D, seed=4)).to(dev())
+    W1 = rnd(E, 8 * D, D, seed=5, scale=D ** -0.5).to(bf).to(dev()); b1 = rnd(E, 8 * D, seed=6, scale=0.1).to(dev())
+    W2 = rnd(E, D, 4 * D, seed=11, scale=(4 * D) ** -0.5).to(bf).to(dev())
+    logits = rnd(N_tok, E, seed=7).to(dev())
+    _, _, idx, w = H.route_topk(logits, k)
+    meta = H.dispatch_meta(idx, w, 1, N_tok, E)
+    NK, eps, n16 = N_tok * k, 1e-6, D // 16
+    FL = L.GEMM_SMALL_ROWS
+    # c_proj + residual + ln_2 producer: the residual stream is bit-identical to the plain RESIDUAL epilogue of the same kernel
+    x_ref = H.gemm(ya, wo, L.EPI_RESIDUAL, resid=x0, out_dtype=torch.float32)
+    x = torch.full((N_tok, D), float("nan"), device=dev()); xg = torch.zeros(N_tok, D, dtype=bf, device=dev())
+    ss = torch.full((N_tok, n16), float("nan"), device=dev())
+    d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_RESIDUAL_NORM, out_dtype=L.MODE_F32, M=N_tok, N=D, K=D, A=p(ya), lda=D, W=p(wo), ldw=D,
+                       resid=p(x0), ldr=D, C=p(x), ldc=D, C2=p(xg), ldc2=D, gain=p(g2), row_ss_out=p(ss), flags=FL)
+    L.check(lib.mode_gemm(C.byref(d), st), "c_proj small")
+    assert torch.equal(x, x_ref)
+    assert rel(ss, x_ref.double().pow(2).view(N_tok, n16, 16).sum(-1).float()) < 1e-6
+    assert rel(xg.float(), x_ref * g2) < 4e-3
+    # up-projection: M = NK rows may exceed gemm_skinny_rows, every expert segment has <= N_tok rows
+    hid = torch.full((NK, 4 * D), float("nan"), dtype=bf, device=dev())
+    d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_SWIGLU, out_dtype=L.MODE_BF16, M=NK, N=4 * D, K=D, A=p(xg), lda=D, W=p(W1), ldw=D,
+                       w_expert_stride=8 * D * D, bias=p(b1), bias_expert_stride=8 * D, C=p(hid), ldc=4 * D, a_rows=p(meta["perm"]),
+                       expert_offsets=p(meta["offsets"]), num_experts=E, row_ss=p(ss), row_ss_n=n16, row_eps=eps, flags=FL)
+    L.check(lib.mode_gemm(C.byref(d), st), "up-projection small")
+    nrm = (x_ref.double().pow(2).sum(1).sqrt() * D ** -0.5).clamp_min(eps).cpu()
+    perm = meta["perm"].cpu().long(); offs = meta["offsets"].cpu().long()
+    pre = torch.zeros(NK, 8 * D, dtype=torch.float64)
+    for e in range(E):
+        rows = perm[offs[e]:offs[e + 1]]
+        pre[offs[e]:offs[e + 1]] = (xg[rows].double().cpu() @ W1[e].double().cpu().t()) / nrm[rows, None] + b1[e].double().cpu()
+    want = pre[:, :4 * D] * torch.nn.functional.silu(pre[:, 4 * D:])
+    assert rel(hid.float(), want.float()) < 4e-3
+    # K-sliced down-projection through the streamer
+    Y = torch.full((S, NK, D), float("nan"), dtype=bf, device=dev())
+    d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=NK, N=D, K=4 * D, A=p(hid), lda=4 * D, W=p(W2), ldw=4 * D,
+                       w_expert_stride=4 * D * D, C=p(Y), ldc=D, expert_offsets=p(meta["offsets"]), num_experts=E, split_k=S, split_stride=NK * D, flags=FL)
+    L.check(lib.mode_gemm(C.byref(d), st), "down-projection small")
+    ywant = torch.zeros(NK, D, dtype=torch.float64)
+    for e in range(E):
+        ywant[offs[e]:offs[e + 1]] = hid[offs[e]:offs[e + 1]].double().cpu() @ W2[e].double().cpu().t()
+    assert rel(Y.float().sum(0), ywant.float()) < 6e-3
+    # combine (one workgroup per row): normalised residual rebuilt from x, the 16-column partials and the gain; slabs added in slice order
+    g1 = (1.0 + 0.1 * rnd(D, seed=9)).to(dev()); cond = rnd(N_tok, D, seed=10).to(dev())
+    xn_b = torch.empty_like(x); h_b = torch.empty(N_tok, D, dtype=bf, device=dev())
+    L.check(lib.mode_moe_combine_norm_fused_fwd(p(x), p(ss), n16, p(g2), p(Y), L.MODE_BF16, S, NK * D, p(meta["pos"]), p(meta["posw"]), N_tok, D, k,
+                                                p(g1), p(cond), 1, eps, p(xn_b), p(h_b), L.MODE_BF16, st), "combine small")
+    pos = meta["pos"].cpu().long().view(N_tok, k); posw = meta["posw"].cpu().view(N_tok, k).double()
+    ysum = Y.double().cpu().sum(0)
+    xn_want = x_ref.double().cpu() / nrm[:, None] * g2.double().cpu() + (posw[:, :, None] * ysum[pos]).sum(1)
+    n1 = (xn_want.pow(2).sum(1).sqrt() * D ** -0.5).clamp_min(eps)
+    h_want = xn_want / n1[:, None] * g1.double().cpu() + cond.double().cpu()
+    assert rel(xn_b, xn_want.float()) < 1e-5 and rel(h_b.float(), h_want.float()) < 4e-3
+    # without the streamer the flag is refused instead of silently changing the partials' granularity
+    lib.mode_set_option(b"gemm_skinny_rows", 0)
+    try:
+        d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_RESIDUAL_NORM, out_dtype=L.MODE_F32, M=N_tok, N=D, K=D, A=p(ya), lda=D, W=p(wo), ldw=D,
+                           resid=p(x0), ldr=D, C=p(x), ldc=D, C2=p(xg), ldc2=D, gain=p(g2), row_ss_out=p(ss), flags=FL)
+        assert lib.mode_gemm(C.byref(d), st) == -2          # MODE_ERR_UNSUPPORTED
+    finally:
+        lib.mode_set_option(b"gemm_skinny_rows", 32)
+
+
 # ------------------------------------------------------------------------------------------------- weight-streaming GEMM for a handful of rows
 def _both_paths(fn):
     """fn() with the weight-streaming kernel (default only for M <= 32; forced here up to 128 rows) and with the tiled kernel; returns (skinny, tiled)."""
