@@ -187,60 +187,70 @@ __global__ __launch_bounds__(256) void combine_norm_kernel(const float* u, const
 // Small-batch form (N <= "gemm_skinny_rows" token rows, i.e. B <= 2 environments): ONE WORKGROUP per row, a thread owns 4 columns per 1024,
 // so every load of the row (u, gains, conditioning, k x slabs expert rows) is requested at once and the kernel is two dependent round trips
 // (routing slots -> rows) plus one cross-wave reduction.  With one wave per row the 14 rows of B = 1 occupied four CUs for 12.7 us.
-template <bool LP_BF16, int KK, bool FUSED, int NC>   // NC = ceil(D / 1024) <= 4
-__global__ __launch_bounds__(256) void combine_norm_row_kernel(const float* u, const void* __restrict__ Y, int y_bf16, int y_splits,
+// Every load of the kernel is unconditional (clamped slab index / column + selects; Y's dtype and the slab count are template parameters): a
+// load under a run-time condition compiles into branch + load + s_waitcnt vmcnt(0), i.e. one dependent round trip per load (16 in a row here).
+template <bool LP_BF16, int KK, bool FUSED, int NC, bool YBF, int YS>   // NC = ceil(D / 1024) <= 4; YS = slab count bound (1, 2, 4, 8)
+__global__ __launch_bounds__(256) void combine_norm_row_kernel(const float* u, const void* __restrict__ Y, int y_splits,
                                                                long y_split_stride, const int* __restrict__ pos, const float* __restrict__ posw, int N,
-                                                               int D, int k, const float* __restrict__ g, const float* __restrict__ cond, int rpc, float eps,
+                                                               int D, const float* __restrict__ g, const float* __restrict__ cond, int rpc, float eps,
                                                                float* x_next, void* h, const float* __restrict__ u_ss, int u_ss_n,
                                                                const float* __restrict__ u_gain) {
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = blockIdx.x;
-  const int kk = KK ? KK : k;
-  long prow[KK ? KK : 8]; float pw[KK ? KK : 8];
+  long prow[KK]; float pw[KK];
 #pragma unroll
-  for (int j = 0; j < (KK ? KK : 8); ++j) {
-    if (j < kk) { prow[j] = (long)pos[(long)row * kk + j] * D; pw[j] = posw[(long)row * kk + j]; }
-  }
+  for (int j = 0; j < KK; ++j) { prow[j] = (long)pos[(long)row * KK + j] * D; pw[j] = posw[(long)row * KK + j]; }
   float u_nrm = 1.0f;
   if constexpr (FUSED) u_nrm = row_norm_from_partials(u_ss + (long)row * u_ss_n, u_ss_n, D, eps, lane);
   [[maybe_unused]] const float ru_nrm = __frcp_rn(u_nrm);
-  const float* cr = cond ? cond + (long)(row / rpc) * D : nullptr;
+  const float* cr = cond + (long)(row / rpc) * D;                    // (cond == nullptr: never dereferenced, see `hc` below)
+  const bool hc = cond != nullptr, hh = h != nullptr;
   float4 v[NC], gq[NC], cq[NC];
   float ssq = 0.f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int d = tid * 4 + c * 1024;
-    v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (d >= D) continue;
-    float4 uu = *reinterpret_cast<const float4*>(u + (long)row * D + d);
-    gq[c] = h ? *reinterpret_cast<const float4*>(g + d) : make_float4(0.f, 0.f, 0.f, 0.f);
-    cq[c] = cr ? *reinterpret_cast<const float4*>(cr + d) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (FUSED) {
-      const float4 gg = *reinterpret_cast<const float4*>(u_gain + d);
-      uu = make_float4(uu.x * ru_nrm * gg.x, uu.y * ru_nrm * gg.y, uu.z * ru_nrm * gg.z, uu.w * ru_nrm * gg.w);
-    }
+    const bool in = d < D;
+    const int dc = in ? d : 0;                                       // clamped column: the load always happens, the result is masked
+    float4 uu = *reinterpret_cast<const float4*>(u + (long)row * D + dc);
+    gq[c] = *reinterpret_cast<const float4*>((hh ? g : u) + dc);
+    cq[c] = *reinterpret_cast<const float4*>((hc ? cr : u) + dc);
+    float4 gg = make_float4(1.f, 1.f, 1.f, 1.f);
+    if constexpr (FUSED) gg = *reinterpret_cast<const float4*>(u_gain + dc);
+    float4 ys[KK][YS];
+#pragma unroll
+    for (int j = 0; j < KK; ++j)
+#pragma unroll
+      for (int z = 0; z < YS; ++z) {                                 // split-K slabs of the down-projection, all requested together
+        const long off = (long)(z < y_splits ? z : 0) * y_split_stride + prow[j] + dc;
+        if constexpr (YBF) {
+          const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(Y) + off);
+          ys[j][z] = make_float4(bf16_bits_to_f32(r.x & 0xffff), bf16_bits_to_f32(r.x >> 16), bf16_bits_to_f32(r.y & 0xffff), bf16_bits_to_f32(r.y >> 16));
+        } else {
+          ys[j][z] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Y) + off);
+        }
+      }
+    if constexpr (FUSED) uu = make_float4(uu.x * ru_nrm * gg.x, uu.y * ru_nrm * gg.y, uu.z * ru_nrm * gg.z, uu.w * ru_nrm * gg.w);
     float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < (KK ? KK : 8); ++j) {           // ascending expert id: next += w * expert(x)   (modedit.py:566)
-      if (j < kk) {
-        float4 ys[8];
+    for (int j = 0; j < KK; ++j) {                                   // ascending expert id: next += w * expert(x)   (modedit.py:566)
+      float4 y = ys[j][0];
 #pragma unroll
-        for (int z = 0; z < 8; ++z)                       // split-K slabs of the down-projection, all requested together, added in slice order
-          ys[z] = z < y_splits ? load_y4(Y, y_bf16 != 0, (long)z * y_split_stride + prow[j] + d) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 y = ys[0];
-#pragma unroll
-        for (int z = 1; z < 8; ++z) { if (z < y_splits) { y.x += ys[z].x; y.y += ys[z].y; y.z += ys[z].z; y.w += ys[z].w; } }
-        const float w = pw[j];
-        nx.x = __fadd_rn(nx.x, __fmul_rn(w, y.x)); nx.y = __fadd_rn(nx.y, __fmul_rn(w, y.y));
-        nx.z = __fadd_rn(nx.z, __fmul_rn(w, y.z)); nx.w = __fadd_rn(nx.w, __fmul_rn(w, y.w));
+      for (int z = 1; z < YS; ++z) {                                 // slabs added in slice order
+        const bool on = z < y_splits;
+        y.x += on ? ys[j][z].x : 0.f; y.y += on ? ys[j][z].y : 0.f; y.z += on ? ys[j][z].z : 0.f; y.w += on ? ys[j][z].w : 0.f;
       }
+      const float w = pw[j];
+      nx.x = __fadd_rn(nx.x, __fmul_rn(w, y.x)); nx.y = __fadd_rn(nx.y, __fmul_rn(w, y.y));
+      nx.z = __fadd_rn(nx.z, __fmul_rn(w, y.z)); nx.w = __fadd_rn(nx.w, __fmul_rn(w, y.w));
     }
     v[c] = make_float4(uu.x + nx.x, uu.y + nx.y, uu.z + nx.z, uu.w + nx.w);   // x + next_states (:595)
-    if (x_next) *reinterpret_cast<float4*>(x_next + (long)row * D + d) = v[c];
+    if (!in) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x_next && in) *reinterpret_cast<float4*>(x_next + (long)row * D + d) = v[c];
     ssq += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
   }
-  if (!h) return;
+  if (!hh) return;
   ssq = wave_sum(ssq);
   if (lane == 0) red[wave] = ssq;
   __syncthreads();
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(256) void combine_norm_row_kernel(const float* u, c
     const int d = tid * 4 + c * 1024;
     if (d >= D) continue;
     float4 o = make_float4(v[c].x * rnrm * gq[c].x, v[c].y * rnrm * gq[c].y, v[c].z * rnrm * gq[c].z, v[c].w * rnrm * gq[c].w);
-    if (cr) { o.x += cq[c].x; o.y += cq[c].y; o.z += cq[c].z; o.w += cq[c].w; }
+    if (hc) { o.x += cq[c].x; o.y += cq[c].y; o.z += cq[c].z; o.w += cq[c].w; }
     if constexpr (LP_BF16) {
       uint2 pk; pk.x = pack_bf16x2(o.x, o.y); pk.y = pack_bf16x2(o.z, o.w);
       *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(h) + (long)row * D + d) = pk;
@@ -537,13 +547,18 @@ extern "C" int mode_moe_combine_norm_fused_fwd(const float* u, const float* u_ss
   if (N <= g_combine_row_max && D <= 4096 && y_splits <= 8 && (k == 1 || k == 2)) {   // one workgroup per row
     const hipStream_t st = (hipStream_t)stream;
     const int nc = (D + 1023) / 1024;
-#define MODE_ROWK(LP, KK, F, NC) hipLaunchKernelGGL((combine_norm_row_kernel<LP, KK, F, NC>), dim3(N), dim3(256), 0, st, u, Y, ybf, y_splits, (long)y_split_stride, pos, posw, N, D, k, g, cond, rows_per_cond, eps, x_next, h, u_ss, u_ss_n, u_gain)
-#define MODE_ROWK_NC(LP, KK, F) do { if (nc == 1) MODE_ROWK(LP, KK, F, 1); else if (nc == 2) MODE_ROWK(LP, KK, F, 2); else MODE_ROWK(LP, KK, F, 4); } while (0)
+    const int ysb = y_splits <= 1 ? 1 : y_splits <= 2 ? 2 : y_splits <= 4 ? 4 : 8;
+#define MODE_ROWK(LP, KK, F, NC, YB, YS) hipLaunchKernelGGL((combine_norm_row_kernel<LP, KK, F, NC, YB, YS>), dim3(N), dim3(256), 0, st, u, Y, y_splits, (long)y_split_stride, pos, posw, N, D, g, cond, rows_per_cond, eps, x_next, h, u_ss, u_ss_n, u_gain)
+#define MODE_ROWK_YS(LP, KK, F, NC, YB) do { if (ysb == 1) MODE_ROWK(LP, KK, F, NC, YB, 1); else if (ysb == 2) MODE_ROWK(LP, KK, F, NC, YB, 2); else if (ysb == 4) MODE_ROWK(LP, KK, F, NC, YB, 4); else MODE_ROWK(LP, KK, F, NC, YB, 8); } while (0)
+#define MODE_ROWK_YB(LP, KK, F, NC) do { if (ybf) MODE_ROWK_YS(LP, KK, F, NC, true); else MODE_ROWK_YS(LP, KK, F, NC, false); } while (0)
+#define MODE_ROWK_NC(LP, KK, F) do { if (nc == 1) MODE_ROWK_YB(LP, KK, F, 1); else if (nc == 2) MODE_ROWK_YB(LP, KK, F, 2); else MODE_ROWK_YB(LP, KK, F, 4); } while (0)
 #define MODE_ROWK_F(LP, KK) do { if (u_ss) MODE_ROWK_NC(LP, KK, true); else MODE_ROWK_NC(LP, KK, false); } while (0)
     if (h_dtype == MODE_BF16) { if (k == 2) MODE_ROWK_F(true, 2); else MODE_ROWK_F(true, 1); }
     else { if (k == 2) MODE_ROWK_F(false, 2); else MODE_ROWK_F(false, 1); }
 #undef MODE_ROWK_F
 #undef MODE_ROWK_NC
+#undef MODE_ROWK_YB
+#undef MODE_ROWK_YS
 #undef MODE_ROWK
     MODE_LAUNCH_CHECK();
     return MODE_OK;
@@ -584,6 +599,109 @@ extern "C" int mode_embed_tokens_fwd(const ModeEmbedDesc* d, void* stream) {
   return MODE_OK;
 }
 
+namespace mode {
+// One workgroup per action row (the form of combine_norm_row_kernel): a thread owns 4 columns per 1024; every load of the row - residual, ln_2
+// partials and gain, k x slabs expert rows, final-norm gain, the A_dim head rows, bias, EDM scalings, noisy action - is unconditional (clamped
+// indices + selects, dtype / slab bound / top-k as template parameters) and requested before the first reduction.  The one-wave-per-row kernel
+// above had compiled into ~40 dependent branch + load + wait rounds: 18 us per denoise step whatever the batch.
+template <int KK, bool FUSED, bool YBF, int YS, int NC>
+__global__ __launch_bounds__(256) void head_ddim_row_kernel(const ModeHeadDesc h) {
+  __shared__ float red[4];
+  __shared__ float racc[4][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ar = blockIdx.x;                                       // action-row index in [0, B*A_len)
+  const int b = ar / h.A_len, ai = ar % h.A_len, D = h.D;
+  const long row = (long)b * h.T + (h.T - h.A_len) + ai;           // last A_len tokens (modedit.py:807)
+  long prow[KK]; float pw[KK];
+#pragma unroll
+  for (int j = 0; j < KK; ++j) { prow[j] = (long)h.pos[row * KK + j] * D; pw[j] = h.posw[row * KK + j]; }
+  float u_nrm = 1.0f;
+  if constexpr (FUSED) u_nrm = row_norm_from_partials(h.u_ss + row * h.u_ss_n, h.u_ss_n, D, h.eps, lane);
+  [[maybe_unused]] const float ru_nrm = __frcp_rn(u_nrm);
+  // epilogue operands (thread j < A_dim finishes output j): clamped, unconditional
+  const int jo = tid < h.A_dim ? tid : 0;
+  const long oidx = (long)ar * h.A_dim + jo;
+  const float bo = h.b_out[jo];
+  const bool has_sc = h.scal != nullptr;
+  const float* scp = has_sc ? h.scal + (long)b * h.scal_stride : h.b_out;   // (never used when !has_sc)
+  const float sc0 = scp[0], sc1 = has_sc ? scp[1] : 0.f, sc2 = has_sc ? scp[2] : 0.f;
+  const float xa = (has_sc ? h.x_a : h.b_out)[has_sc ? oidx : 0];
+  float4 v[NC], gq[NC], wq[NC][8];
+  float ssq = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int d = tid * 4 + c * 1024;
+    const bool in = d < D;
+    const int dc = in ? d : 0;
+    float4 uu = *reinterpret_cast<const float4*>(h.u + row * D + dc);
+    gq[c] = *reinterpret_cast<const float4*>(h.g + dc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wq[c][j] = *reinterpret_cast<const float4*>(h.w_out + (long)(j < h.A_dim ? j : 0) * D + dc);
+    float4 gg = make_float4(1.f, 1.f, 1.f, 1.f);
+    if constexpr (FUSED) gg = *reinterpret_cast<const float4*>(h.u_gain + dc);
+    float4 ys[KK][YS];
+#pragma unroll
+    for (int j = 0; j < KK; ++j)
+#pragma unroll
+      for (int z = 0; z < YS; ++z) {
+        const long off = (long)(z < h.y_splits ? z : 0) * h.y_split_stride + prow[j] + dc;
+        if constexpr (YBF) {
+          const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(h.Y) + off);
+          ys[j][z] = make_float4(bf16_bits_to_f32(r.x & 0xffff), bf16_bits_to_f32(r.x >> 16), bf16_bits_to_f32(r.y & 0xffff), bf16_bits_to_f32(r.y >> 16));
+        } else {
+          ys[j][z] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(h.Y) + off);
+        }
+      }
+    if constexpr (FUSED) uu = make_float4(uu.x * ru_nrm * gg.x, uu.y * ru_nrm * gg.y, uu.z * ru_nrm * gg.z, uu.w * ru_nrm * gg.w);
+    float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < KK; ++j) {
+      float4 y = ys[j][0];
+#pragma unroll
+      for (int z = 1; z < YS; ++z) {
+        const bool on = z < h.y_splits;
+        y.x += on ? ys[j][z].x : 0.f; y.y += on ? ys[j][z].y : 0.f; y.z += on ? ys[j][z].z : 0.f; y.w += on ? ys[j][z].w : 0.f;
+      }
+      const float w = pw[j];
+      nx.x = __fadd_rn(nx.x, __fmul_rn(w, y.x)); nx.y = __fadd_rn(nx.y, __fmul_rn(w, y.y));
+      nx.z = __fadd_rn(nx.z, __fmul_rn(w, y.z)); nx.w = __fadd_rn(nx.w, __fmul_rn(w, y.w));
+    }
+    v[c] = in ? make_float4(uu.x + nx.x, uu.y + nx.y, uu.z + nx.z, uu.w + nx.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ssq += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+  }
+  ssq = wave_sum(ssq);
+  if (lane == 0) red[wave] = ssq;
+  __syncthreads();
+  ssq = ((red[0] + red[1]) + red[2]) + red[3];
+  const float rnrm = __frcp_rn(fmaxf(sqrtf(ssq) * rsqrtf((float)D), h.eps));
+  float accv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) accv[j] = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float4 n = make_float4(v[c].x * rnrm * gq[c].x, v[c].y * rnrm * gq[c].y, v[c].z * rnrm * gq[c].z, v[c].w * rnrm * gq[c].w);   // v = 0 past D
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accv[j] += n.x * wq[c][j].x + n.y * wq[c][j].y + n.z * wq[c][j].z + n.w * wq[c][j].w;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) accv[j] = wave_sum(accv[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) racc[wave][j] = accv[j];
+  }
+  __syncthreads();
+  if (tid < h.A_dim) {
+    const float F = (((racc[0][tid] + racc[1][tid]) + racc[2][tid]) + racc[3][tid]) + bo;
+    if (h.F) h.F[oidx] = F;
+    if (has_sc) {
+      const float den = F * sc1 + xa * sc0;               // F*c_out + x*c_skip      (score_wrappers.py:79-80)
+      if (h.denoised) h.denoised[oidx] = den;
+      if (h.x_next) h.x_next[oidx] = sc2 * xa + (1.0f - sc2) * den;   // r*x + (1-r)*denoised (gc_sampling.py:948-950)
+    }
+  }
+}
+}  // namespace mode
+
 extern "C" int mode_head_ddim_fwd(const ModeHeadDesc* d, void* stream) {
   if (!d || !d->u || !d->Y || !d->pos || !d->posw || !d->g || !d->w_out || !d->b_out) return MODE_ERR_BAD_ARG;
   if (d->scal && !d->x_a) return MODE_ERR_BAD_ARG;
@@ -591,6 +709,24 @@ extern "C" int mode_head_ddim_fwd(const ModeHeadDesc* d, void* stream) {
   if ((d->D & 3) || d->A_dim > 8) return MODE_ERR_UNSUPPORTED;
   const int rows = d->B * d->A_len;
   if (rows == 0) return MODE_OK;
+  if (d->D <= 4096 && d->y_splits <= 8 && (d->k == 1 || d->k == 2) && d->A_dim >= 1) {   // one workgroup per row
+    const hipStream_t st = (hipStream_t)stream;
+    const int nc = (d->D + 1023) / 1024, ys = d->y_splits <= 1 ? 1 : d->y_splits <= 2 ? 2 : d->y_splits <= 4 ? 4 : 8;
+    const bool ybf = d->y_dtype == MODE_BF16, fu = d->u_ss != nullptr;
+#define MODE_HK(KK, F, YB, YS, NC) hipLaunchKernelGGL((head_ddim_row_kernel<KK, F, YB, YS, NC>), dim3(rows), dim3(256), 0, st, *d)
+#define MODE_HK_NC(KK, F, YB, YS) do { if (nc == 1) MODE_HK(KK, F, YB, YS, 1); else if (nc == 2) MODE_HK(KK, F, YB, YS, 2); else MODE_HK(KK, F, YB, YS, 4); } while (0)
+#define MODE_HK_YS(KK, F, YB) do { if (ys == 1) MODE_HK_NC(KK, F, YB, 1); else if (ys == 2) MODE_HK_NC(KK, F, YB, 2); else if (ys == 4) MODE_HK_NC(KK, F, YB, 4); else MODE_HK_NC(KK, F, YB, 8); } while (0)
+#define MODE_HK_YB(KK, F) do { if (ybf) MODE_HK_YS(KK, F, true); else MODE_HK_YS(KK, F, false); } while (0)
+#define MODE_HK_F(KK) do { if (fu) MODE_HK_YB(KK, true); else MODE_HK_YB(KK, false); } while (0)
+    if (d->k == 2) MODE_HK_F(2); else MODE_HK_F(1);
+#undef MODE_HK_F
+#undef MODE_HK_YB
+#undef MODE_HK_YS
+#undef MODE_HK_NC
+#undef MODE_HK
+    MODE_LAUNCH_CHECK();
+    return MODE_OK;
+  }
   const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   const size_t lds = (size_t)ROWS_PER_BLOCK * d->D * 4;
   if (d->D == 1024) hipLaunchKernelGGL(head_ddim_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, *d);
