@@ -52,17 +52,25 @@ int mode_hip_version(void);
  * structs against the library it actually loaded (tests/test_boundary.py does, for every struct of this header). */
 size_t mode_hip_sizeof(const char* struct_name);
 const char* mode_hip_status_string(int status);
-/* Tuning knobs (process-wide).  "gemm_cfg": bf16 GEMM tile geometry, 0 = auto (default), 1 = 128x128 ring-2, 2 = 128x128 ring-3,
- * 3 = 256x128 ring-3, 4 = 128x64 ring-3, 5 = 128x64 ring-4, 6 = 128x128 single-buffered (3 workgroups/CU), 7 = 128x64 single-buffered,
- * 8 = 128x64 ring-2, 9 = 256x256 ring-2 (8 waves), 10 = 256x128 ring-2, 11 = 256x256 ring-2 (16 waves), 12 = persistent 256x256 with
- * cross-tile operand prefetch, 13 = 128x128 single-buffered with <= 128 VGPRs (4 workgroups/CU), 14 = 64x64 ring-3, 15 = 64x64 ring-2 (no SwiGLU).  "gemm_tr_cfg": backward (transpose-read) GEMM geometry, 0 = auto, 1 = 128-wide ring-2, 2 = 64-wide ring-3,
- * 3 = 128-wide ring-3, 4 = 64-wide ring-2, 5 = 128-wide single-buffered.  "adamw_blocks": workgroup cap of one AdamW launch (0 = 256, one streaming workgroup per CU).
- * "gemm_skinny_rows": bf16 GEMMs with M <= this many rows use the weight-streaming kernel (default 32, 0 = off).
- * "gemm_setprio": 1 (default) = s_setprio 1 around the MFMA clusters of the tiled bf16 GEMM (waves of co-resident workgroups that are in their
- * MFMA phase win arbitration over waves issuing LDS / DMA work: +0.5 % on the up-projection, same-box A/B), 0 = off.
+/* Tuning knobs (process-wide; also settable through MODE_HIP_OPTS="key=value,..." when the Python binding loads the library).
+ * "gemm_cfg": bf16 forward GEMM tile geometry, 0 = auto (default), 1 = 128x128 ring-2, 4 = 128x64 ring-3, 6 = 128x128 single-buffered
+ *   (3 workgroups/CU), 8 = 128x64 ring-2, 13 = 128x128 single-buffered with <= 128 VGPRs (4 workgroups/CU), 14 = 64x64 ring-3 (no SwiGLU),
+ *   16 / 17 = persistent ping-pong 8-phase kernel with 256 / 224-row x 256-column tiles (gemm_bf16_pp.hip; epilogues NONE / BIAS / SWIGLU).
+ *   Every forward geometry produces bit-identical results (k-ordered fp32 MFMA chain, explicit-fma epilogues).
+ * "gemm_pp": 1 (default) = the heuristic may pick geometry 17; "gemm_pp_min_tiles": tile count from which it does (default 200).
+ * "gemm_group_m": m-tiles per XCD rasterisation group of the ring kernels (0 = default).
+ * "gemm_tr_cfg": backward (transpose-read) GEMM geometry, 0 = auto, 1 = 128-wide ring-2, 2 = 64-wide ring-3, 3 = 128-wide ring-3,
+ *   4 = 64-wide ring-2, 5 = 128-wide single-buffered.  "adamw_blocks": workgroup cap of one AdamW launch (0 = 256, one streaming workgroup per CU).
+ * "gemm_skinny_rows": bf16 GEMMs with M <= this many rows use the weight-streaming kernels, and mode_dit_forward runs a batch of at most this
+ *   many TOKEN rows as the small-batch chain (MODE_GEMM_SMALL_ROWS) (default 32 = two environments, 0 = off).
+ * "gemm_setprio": 1 (default) = s_setprio 1 around the MFMA clusters of the tiled bf16 GEMM, 0 = off.
  * "fuse_ln2": 1 (default) = ln_2 folded into the c_proj / up-projection / combine kernels on the bf16 path, 0 = its own kernel.
- * "dn_split_k": K-slices of the inference path's expert down-projection, 0 = default (2, for every batch size), 1 = off, <= 8.
- * "attn_bwd_stop": profiling aid, attention backward returns after phase n (0 = off).  Unknown keys return MODE_ERR_BAD_ARG. */
+ * "dn_split_k": K-slices of the inference path's expert down-projection, 0 = default (4, for every batch size), 1 = off, <= 8.
+ * "combine_row_max": token rows up to which the MoE combine runs one workgroup per row (default: always), 0 = one wave per row.
+ * Profiling aids: "pp_flags" (A/B and timing-ablation switches of the ping-pong kernel; 64 = small-batch GEMMs on the direct-fragment
+ *   streamer), "pp_trace_lo" / "pp_trace_hi" (low / high half of a device pointer to a timestamp buffer written by the ping-pong and
+ *   streaming GEMMs, 0 = off), "attn_bwd_stop" (attention backward returns after phase n, 0 = off).
+ * Unknown keys return MODE_ERR_BAD_ARG. */
 int mode_set_option(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------------------------
