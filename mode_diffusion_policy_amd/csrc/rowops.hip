@@ -580,12 +580,121 @@ extern "C" int mode_moe_combine_norm_fwd(const float* u, const void* Y, int y_dt
                                          eps, x_next, h, h_dtype, stream);
 }
 
+namespace mode {
+// One workgroup per token row (the form of the combine / head row kernels).  The token kind is uniform per workgroup: it selects a source row
+// and a positional row by POINTER (dummy = the positional table, masked by selects), so the row's loads are unconditional; only the action
+// rows' Linear(A_dim, D) sits behind a (scalar) branch.
+template <bool LP_BF16, int NC>
+__global__ __launch_bounds__(256) void embed_tokens_row_kernel(const ModeEmbedDesc e) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x, D = e.D, T = e.T;
+  const int b = row / T, t = row % T;
+  const int t0 = e.use_noise_token ? 1 : 0;            // first goal position
+  const int t_img = t0 + 1, t_act = t_img + e.n_img;   // goal_seq_len == 1 on this path
+  const int ai = t - t_act;
+  const bool is_act = ai >= 0, is_noise = t < t0, is_goal = !is_noise && t < t_img;
+  const float* src = is_noise ? e.emb_t + (long)b * e.emb_row_stride
+                   : is_goal  ? e.goal_e + (long)b * D
+                   : !is_act  ? e.img_e + ((long)b * e.n_img + (t - t_img)) * D : e.pos;
+  const float* pp = is_act ? e.pos + (long)(1 + ai) * D : is_goal ? e.pos : e.pos + D;   // both image tokens share pos row 1; the noise token has none
+  const bool has_src = !is_act, has_pos = !is_noise;
+  const float cin = (e.c_in ? e.c_in : e.pos)[e.c_in ? (long)b * e.c_in_stride : 0];
+  float a[8];
+  {
+    const long abase = ((long)b * e.A_len + (is_act ? ai : 0)) * e.A_dim;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = e.actions[abase + (j < e.A_dim ? j : 0)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = j < e.A_dim ? a[j] * (e.c_in ? cin : 1.0f) : 0.f;
+  }
+  const float* cr = e.cond ? e.cond + (long)b * e.cond_row_stride : e.pos;
+  float4 v[NC], gq[NC], cq[NC];
+  float ssq = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int d = tid * 4 + c * 1024;
+    const bool in = d < D;
+    const int dc = in ? d : 0;
+    const float4 sv = *reinterpret_cast<const float4*>(src + dc), pv = *reinterpret_cast<const float4*>(pp + dc);
+    gq[c] = *reinterpret_cast<const float4*>(e.g + dc);
+    cq[c] = *reinterpret_cast<const float4*>(cr + dc);
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (is_act) {
+      if (e.A_dim == 7) {
+        // rows d..d+3 of w_act [D, 7] are 28 contiguous floats starting at a 16-byte boundary (d % 4 == 0): 7 vector loads
+        float wv[28];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const float4 t4 = *reinterpret_cast<const float4*>(e.w_act + (long)dc * 7 + q * 4);
+          wv[4 * q] = t4.x; wv[4 * q + 1] = t4.y; wv[4 * q + 2] = t4.z; wv[4 * q + 3] = t4.w;
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          float s_ = 0.f;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) s_ = fmaf(a[j], wv[cc * 7 + j], s_);
+          o[cc] = s_;
+        }
+      } else {
+        float wr[4][8];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wr[cc][j] = e.w_act[(long)(dc + cc) * e.A_dim + (j < e.A_dim ? j : 0)];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          float s_ = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s_ = j < e.A_dim ? fmaf(a[j], wr[cc][j], s_) : s_;
+          o[cc] = s_;
+        }
+      }
+    }
+    const float4 s4 = has_src ? sv : make_float4(o[0], o[1], o[2], o[3]);
+    const float4 p4 = has_pos ? pv : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[c] = in ? make_float4(s4.x + p4.x, s4.y + p4.y, s4.z + p4.z, s4.w + p4.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) *reinterpret_cast<float4*>(e.x + (long)row * D + d) = v[c];
+    ssq += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+  }
+  ssq = wave_sum(ssq);
+  if (lane == 0) red[wave] = ssq;
+  __syncthreads();
+  ssq = ((red[0] + red[1]) + red[2]) + red[3];
+  const float rnrm = __frcp_rn(fmaxf(sqrtf(ssq) * rsqrtf((float)D), e.eps));
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int d = tid * 4 + c * 1024;
+    if (d >= D) continue;
+    float4 o = make_float4(v[c].x * rnrm * gq[c].x, v[c].y * rnrm * gq[c].y, v[c].z * rnrm * gq[c].z, v[c].w * rnrm * gq[c].w);
+    if (e.cond) { o.x += cq[c].x; o.y += cq[c].y; o.z += cq[c].z; o.w += cq[c].w; }
+    if constexpr (LP_BF16) {
+      uint2 pk; pk.x = pack_bf16x2(o.x, o.y); pk.y = pack_bf16x2(o.z, o.w);
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(e.h) + (long)row * D + d) = pk;
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(e.h) + (long)row * D + d) = o;
+    }
+  }
+}
+}  // namespace mode
+
 extern "C" int mode_embed_tokens_fwd(const ModeEmbedDesc* d, void* stream) {
   if (!d || !d->goal_e || !d->img_e || !d->actions || !d->w_act || !d->pos || !d->g || !d->x || !d->h) return MODE_ERR_BAD_ARG;
   if (d->use_noise_token && !d->emb_t) return MODE_ERR_BAD_ARG;
   if ((d->D & 3) || d->A_dim > 8 || d->T != (d->use_noise_token ? 1 : 0) + 1 + d->n_img + d->A_len) return MODE_ERR_UNSUPPORTED;
   const int rows = d->B * d->T;
   if (rows == 0) return MODE_OK;
+  if (d->D <= 4096 && d->A_dim >= 1) {                               // one workgroup per row
+    const hipStream_t st = (hipStream_t)stream;
+    const int nc = (d->D + 1023) / 1024;
+#define MODE_EK(LP, NC) hipLaunchKernelGGL((embed_tokens_row_kernel<LP, NC>), dim3(rows), dim3(256), 0, st, *d)
+#define MODE_EK_NC(LP) do { if (nc == 1) MODE_EK(LP, 1); else if (nc == 2) MODE_EK(LP, 2); else MODE_EK(LP, 4); } while (0)
+    if (d->h_dtype == MODE_BF16) MODE_EK_NC(true); else MODE_EK_NC(false);
+#undef MODE_EK_NC
+#undef MODE_EK
+    MODE_LAUNCH_CHECK();
+    return MODE_OK;
+  }
   const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   const size_t lds = (size_t)ROWS_PER_BLOCK * d->D * 4;
   if (d->D == 1024) {
