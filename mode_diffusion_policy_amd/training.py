@@ -235,13 +235,15 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         frac = mask.sum(1) / N                                                                  # [L, E] fraction of tokens per expert
         lb = E * (rp.mean(1) * frac).sum(-1)                                                    # [L]
         zl = torch.log(torch.exp(shifted).sum(-1) + 1e-6).pow(2).mean(-1)                       # [L] router z-loss per layer (modedit.py:930-969)
-        logits_tok = shifted.unsqueeze(2).expand(Ly, B, T, E).reshape(Ly, N, E)
         model.logits_per_layer, model.probs_per_layer = [], []
-        for l, blk in enumerate(model.blocks):
-            blk.logits = logits_tok[l]
-            blk.probs = {"probs": probs[l].unsqueeze(1).expand(B, T, E), "top_k_hot": mask[l].view(B, T, E), "load_balancing_term": lb[l]}
+        if getattr(model, "log_router_stats", True):          # per-block views the agent's logging reads (mode_agent.py:470-511); `model.log_router_stats = False` skips them
+            logits_tok = shifted.unsqueeze(2).expand(Ly, B, T, E).reshape(Ly, N, E)
+            for l, blk in enumerate(model.blocks):
+                blk.logits = logits_tok[l]
+                blk.probs = {"probs": probs[l].unsqueeze(1).expand(B, T, E), "top_k_hot": mask[l].view(B, T, E), "load_balancing_term": lb[l]}
+                model.logits_per_layer.append(blk.logits); model.probs_per_layer.append(blk.probs)
+        for blk in model.blocks:
             blk.total_tokens_processed += N
-            model.logits_per_layer.append(blk.logits); model.probs_per_layer.append(blk.probs)
         counts = meta[:, ml.counts: ml.counts + E]
         if getattr(model, "_train_usage_dev", None) is None or model._train_usage_dev.device != counts.device:
             model._train_usage_dev = torch.zeros(Ly, E, dtype=torch.int64, device=dev)

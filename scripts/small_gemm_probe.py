@@ -70,29 +70,34 @@ for name, (mk, mb) in cases.items():
     lib.mode_set_option(b"pp_flags", 0)
     print(f"B={B} {name:36s} " + "   ".join(out))
 
-# ---- does a weight slab that is already in the Infinity Cache (MALL) stream faster?  touch(i) = a torch reduction over the two active experts
-# of layer i's W1 right before gemm(i); 12 layers x 33.5 MB cycle through more than the 256 MB cache, so the untouched runs read HBM.
-ds = [cases["up swiglu+ln2 33.5MB"][0](i) for i in range(nl)]
+# ---- does a weight slab that is already in the Infinity Cache (MALL) stream faster?  touch(i) = a torch reduction over the ACTIVE weights of
+# layer i right before gemm(i); the 12 layers cycle through more than the 256 MB cache, so the untouched runs read HBM.
+STRIDE = int(os.environ.get("TOUCH_STRIDE", "0"))               # 0 = read every byte; n = one dword per n bytes (translation warm-up only)
 sink = torch.zeros(1, device=dev)
-def touch(i):
-    sink.add_(w1[i][1:3].view(torch.int32).sum())
-def run(kind, cst):
-    for i in range(reps):
-        if kind in ("touch", "both"):
-            touch(i % nl)
-        if kind in ("gemm", "both"):
-            L.check(lib.mode_gemm(C.byref(ds[i % nl]), cst))
-res = {}
-for kind in ("gemm", "touch", "both"):
-    run(kind, st0); torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with capture_graph(g):
-        run(kind, torch.cuda.current_stream().cuda_stream)
-    g.replay(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
-    res[kind] = e0.elapsed_time(e1) * 1e3 / reps
-print(f"MALL probe (up-projection): gemm alone {res['gemm']:.2f} us, touch alone {res['touch']:.2f} us, touch+gemm {res['both']:.2f} us -> gemm after touch {res['both'] - res['touch']:.2f} us")
+views = {"qkv": [w.view(torch.int32).view(-1) for w in wqkv], "c_proj": [w.view(torch.int32).view(-1) for w in wo],
+         "up": [w[1:3].view(torch.int32).view(-1) for w in w1], "down": [w[1:3].view(torch.int32).view(-1) for w in w2]}
+for cname, key in (("qkv [14x1024]x[3072x1024] 6.3MB", "qkv"), ("c_proj+resid+ln2 2.1MB", "c_proj"), ("up swiglu+ln2 33.5MB", "up"), ("down S=4 16.8MB", "down")):
+    ds = [cases[cname][0](i) for i in range(nl)]
+    flat = views[key]
+    def touch(i):
+        sink.add_((flat[i][:: STRIDE // 4] if STRIDE else flat[i]).sum())
+    def run(kind, cst):
+        for i in range(reps):
+            if kind in ("touch", "both"):
+                touch(i % nl)
+            if kind in ("gemm", "both"):
+                L.check(lib.mode_gemm(C.byref(ds[i % nl]), cst))
+    res = {}
+    for kind in ("gemm", "touch", "both"):
+        run(kind, st0); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with capture_graph(g):
+            run(kind, torch.cuda.current_stream().cuda_stream)
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        res[kind] = e0.elapsed_time(e1) * 1e3 / reps
+    print(f"MALL probe stride {STRIDE} {key:7s}: gemm alone {res['gemm']:.2f} us, touch alone {res['touch']:.2f} us, touch+gemm {res['both']:.2f} us -> gemm after touch {res['both'] - res['touch']:.2f} us")
 
 # ---- where a launch's time goes: 100-MHz timestamps per workgroup (start, segment known, operands consumed, done), relative to the first workgroup's start
 tr = torch.zeros(4096 * 4, dtype=torch.int64, device=dev)
