@@ -73,7 +73,7 @@ template <int V>
 using IC = std::integral_constant<int, V>;
 }  // namespace pp
 
-template <int EPI, bool OUT_BF16, int FM1>
+template <int EPI, bool OUT_BF16, int FM1, bool MERGED>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, unsigned long long* __restrict__ trace) {
   using namespace pp;
   constexpr int BM = 128 + 32 * FM1;                         // rows of an output tile: half 0 = 2 x 64, half 1 = 2 x 16*FM1
@@ -358,6 +358,74 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
     const char* Wn = cont ? w_tile_base(nxt) : Wc;             // no successor on this stream: the tail re-reads valid memory, never consumed
 
     // ------------------------------------------------------------------------------------------------ K loop: 8 phases = 2 K-steps
+    if constexpr (MERGED) {
+      // ---- FOUR phases per K-step pair: a phase = one A half x BOTH W halves (32 / 8*FM1 MFMAs per wave between two barriers instead of 16 /
+      // 4*FM1).  Per-workgroup cycle stamps put the 8-phase loop at ~2600 cycles per K-step against 1792 of MFMA issue: every barrier interval
+      // is one MFMA cluster (256 / 192 cycles) plus ~125 cycles of s_barrier release latency, and phase 1's twelve fragment reads per wave
+      // (384 cycles of LDS time per wave row) sit beside a 192-cycle cluster.  Both W halves are in registers anyway (Bf[2][4]), so merging
+      // costs no registers.  A half-tile is re-staged one whole phase after the phase whose read section read it last:
+      //   R(P0, t): reads W0 W1 A0 of K-step t;  stages A1[t+1]           R(P1, t): reads A1[t];  stages W0 W1 A0 of K-step t+2
+      // and every read section ends in ONE counted wait that leaves the newest K-step's worth of DMA (8 instructions; 6 on the waves that stage
+      // no A half 1) in flight: everything a later phase reads was issued before those.
+#define PP_COMPUTE2(AH)           \
+  PP_BAR();                       \
+  wait_lgkmcnt<0>();              \
+  PP_SB();                        \
+  mma(AH, _0);                    \
+  mma(AH, _1);                    \
+  PP_SB();                        \
+  PP_BAR();                       \
+  PP_SB();
+#define PP_WAIT_STEP() do { if (stage_a1) wait_vmcnt<8>(); else wait_vmcnt<6>(); } while (0)
+#pragma unroll 1
+      for (int kt = 0; kt < nk; kt += 2) {
+        const bool cross = kt + 2 >= nk;
+        const int k2 = cross ? kt + 2 - nk : kt + 2;           // K-step (kt+2) inside its own output tile
+        const char* A1 = Ak + (long)(kt + 1) * 128;
+        const char* A2 = Ak + (long)k2 * 128;
+        const char* W2 = (cross ? Wn : Wc) + (long)k2 * 128;
+        const bool waits = kt != 0 || !early_resident;          // first pair of a tile: K-steps 0 and 1 were resident before it began (and the
+                                                                // previous tile's stores may still be draining: vmcnt counts them)
+        // P0 of K-step kt [buffer 0]
+        rdB(_0, _0); rdB(_0, _1);
+        PP_SB();
+        rdA(_0, _0);
+        if (stage_a1 && kt != 0) stage(_0, _1, _1, A1, a_off[1][0], a_off[1][1]);   // (first pair of a tile: K-step 1 is complete already)
+        if (waits) PP_WAIT_STEP();
+        PP_COMPUTE2(_0)
+        // P1 of K-step kt
+        rdA(_0, _1);
+        stage(_1, _0, _0, W2, b_off[0], b_off[1]);
+        stage(_1, _0, _1, W2 + w_half, b_off[0], b_off[1]);
+        stage(_0, _0, _0, A2, a_off[0][0], a_off[0][1]);
+        if (waits) PP_WAIT_STEP();
+        if constexpr (HAS_BIAS) {
+          if (kt == 0) {                                         // this tile's bias slice -> the wave's own LDS slot (behind the wait: not counted by it)
+            const float* bsrc = p.bias + (long)cur.expert * p.bias_estride + (long)cur.n * NOUT;
+            const float* bl = SWI ? (lane < 32 ? bsrc + lane * 4 : bsrc + p.N + (lane - 32) * 4) : bsrc + lane * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bl,
+                                             (__attribute__((address_space(3))) void*)(smem + LDS_BIAS + wave * 1024), 16, 0, 0);
+          }
+        }
+        PP_COMPUTE2(_1)
+        // P0 of K-step kt+1 [buffer 1]
+        rdB(_1, _0); rdB(_1, _1);
+        PP_SB();
+        rdA(_1, _0);
+        if (stage_a1) stage(_0, _0, _1, A2, a_off[1][0], a_off[1][1]);
+        if (waits) PP_WAIT_STEP();
+        PP_COMPUTE2(_0)
+        // P1 of K-step kt+1; K-step kt+2 [buffer 0] retired by this wait
+        rdA(_1, _1);
+        stage(_1, _1, _0, W2 + 128, b_off[0], b_off[1]);
+        stage(_1, _1, _1, W2 + w_half + 128, b_off[0], b_off[1]);
+        stage(_0, _1, _0, A2 + 128, a_off[0][0], a_off[0][1]);
+        PP_WAIT_STEP();
+        PP_COMPUTE2(_1)
+      }
+#undef PP_WAIT_STEP
+#undef PP_COMPUTE2
+    } else {
 #pragma unroll 1
     for (int kt = 0; kt < nk; kt += 2) {
       const bool cross = kt + 2 >= nk;
@@ -411,6 +479,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
       stage(_1, _1, _1, W2 + w_half + 128, b_off[0], b_off[1]);
       wait_vmcnt<6>();
       PP_COMPUTE(_1, _1)
+    }
     }
     stamp(2 + 2 * min(L - wg * R, 1));
 
@@ -553,7 +622,7 @@ static int pp_num_cus() {
 
 unsigned long long g_pp_trace = 0;        // "pp_trace_lo" / "pp_trace_hi" options: device buffer of 256 x 8 x 8 cycle stamps (profiling aid), 0 = off
 
-template <int EPI, bool OUT_BF16, int FM1>
+template <int EPI, bool OUT_BF16, int FM1, bool MERGED>
 static int pp_launch(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   constexpr int BM = 128 + 32 * FM1, NOUT = (EPI == MODE_EPI_SWIGLU) ? 128 : 256;
   p.n_tiles = d->N / NOUT;
@@ -561,7 +630,7 @@ static int pp_launch(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   const long t_max = (long)p.m_tiles * p.n_tiles * p.split_k;
   const int ncu = pp_num_cus();
   const int grid = (int)(t_max < ncu ? t_max : ncu);           // one persistent workgroup per CU (140 KiB of LDS each)
-  auto kern = gemm_pp_kernel<EPI, OUT_BF16, FM1>;
+  auto kern = gemm_pp_kernel<EPI, OUT_BF16, FM1, MERGED>;
   static bool attr_set[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -594,8 +663,12 @@ int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, int rows224
   const bool ob = d->out_dtype == MODE_BF16;
 #define PP_CASE(E)                                                                                              \
   case E:                                                                                                       \
-    if (rows224) return ob ? pp_launch<E, true, 3>(p0, d, s) : pp_launch<E, false, 3>(p0, d, s);              \
-    return ob ? pp_launch<E, true, 4>(p0, d, s) : pp_launch<E, false, 4>(p0, d, s);
+    if (!(p0.pp_flags & 256)) {                                   /* 256 = the eight-phase loop (A/B) */                      \
+      if (rows224) return ob ? pp_launch<E, true, 3, true>(p0, d, s) : pp_launch<E, false, 3, true>(p0, d, s);  \
+      return ob ? pp_launch<E, true, 4, true>(p0, d, s) : pp_launch<E, false, 4, true>(p0, d, s);               \
+    }                                                                                                           \
+    if (rows224) return ob ? pp_launch<E, true, 3, false>(p0, d, s) : pp_launch<E, false, 3, false>(p0, d, s); \
+    return ob ? pp_launch<E, true, 4, false>(p0, d, s) : pp_launch<E, false, 4, false>(p0, d, s);
   switch (epi) {
     PP_CASE(MODE_EPI_NONE)
     PP_CASE(MODE_EPI_BIAS)

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--screen", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--cfgs", default="0,17,17f128,17f16", help="variants to time: NN[fK] = gemm_cfg NN with pp_flags K; 0 = the 128x128 family (gemm_pp off)")
+    ap.add_argument("--cfgs", default="0,17,17f256,16", help="variants to time: NN[fK] = gemm_cfg NN with pp_flags K; 0 = the 128x128 family (gemm_pp off)")
     a = ap.parse_args()
     lib = L.load()
     dev = torch.device("cuda:0")
@@ -61,7 +61,7 @@ def main():
         lib.mode_set_option(b"gemm_cfg", int(c))
         lib.mode_set_option(b"gemm_pp", 0 if int(c) == 0 else 1)
         fl = int(fl) if fl else 0
-        lib.mode_set_option(b"pp_flags", fl & 127)
+        lib.mode_set_option(b"pp_flags", fl & ~128)
         lib.mode_set_option(b"gemm_setprio", 0 if fl & 128 else 1)              # f128 = no s_setprio around the MFMA clusters
 
     def run(cfg, d):
@@ -74,7 +74,7 @@ def main():
     for name, pairs in routings.items():
         meta, ml = meta_for(pairs)
         ref1 = torch.zeros(NK, 4 * D, dtype=bf, device=dev); run(1, gemm1_desc(meta, ml, 0, ref1))
-        for cfg in ("16", "17"):
+        for cfg in ("16", "17", "16f256", "17f256"):
             bad = 0
             for it in range(a.screen):
                 out = torch.full((NK, 4 * D), float("nan"), dtype=bf, device=dev)
@@ -90,7 +90,7 @@ def main():
             ok &= bad == 0
         for S in (2, 4):
             ref2 = torch.zeros(S, NK, D, dtype=bf, device=dev); run(1, gemm2_desc(meta, ml, 0, ref2, S))
-            for cfg in ("16", "17"):
+            for cfg in ("16", "17", "16f256", "17f256"):
                 bad = 0
                 for it in range(a.screen):
                     out = torch.full((S, NK, D), float("nan"), dtype=bf, device=dev)
@@ -137,7 +137,7 @@ def main():
     out1 = torch.empty(NK, 4 * D, dtype=bf, device=dev)
     tr = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
     ptr = tr.data_ptr()
-    for v in [c for c in cfgs if c in ("17", "17f1", "16")]:
+    for v in [c for c in cfgs if c in ("17", "17f1", "16", "17f256")]:
         for wi in range(3):                                     # warm: code object, clocks
             run(v, gemm1_desc(meta, ml, wi, out1))
         tr.zero_()
