@@ -73,7 +73,7 @@ template <int V>
 using IC = std::integral_constant<int, V>;
 }  // namespace pp
 
-template <int EPI, bool OUT_BF16, int FM1, bool MERGED>
+template <int EPI, bool OUT_BF16, int FM1, int MERGED>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, unsigned long long* __restrict__ trace) {
   using namespace pp;
   constexpr int BM = 128 + 32 * FM1;                         // rows of an output tile: half 0 = 2 x 64, half 1 = 2 x 16*FM1
@@ -358,13 +358,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
     const char* Wn = cont ? w_tile_base(nxt) : Wc;             // no successor on this stream: the tail re-reads valid memory, never consumed
 
     // ------------------------------------------------------------------------------------------------ K loop: 8 phases = 2 K-steps
-    if constexpr (MERGED) {
+    if constexpr (MERGED != 0) {
       // ---- FOUR phases per K-step pair: a phase = one A half x BOTH W halves (32 / 8*FM1 MFMAs per wave between two barriers instead of 16 /
       // 4*FM1).  Per-workgroup cycle stamps put the 8-phase loop at ~2600 cycles per K-step against 1792 of MFMA issue: every barrier interval
       // is one MFMA cluster (256 / 192 cycles) plus ~125 cycles of s_barrier release latency, and phase 1's twelve fragment reads per wave
       // (384 cycles of LDS time per wave row) sit beside a 192-cycle cluster.  Both W halves are in registers anyway (Bf[2][4]), so merging
       // costs no registers.  A half-tile is re-staged one whole phase after the phase whose read section read it last:
       //   R(P0, t): reads W0 W1 A0 of K-step t;  stages A1[t+1]           R(P1, t): reads A1[t];  stages W0 W1 A0 of K-step t+2
+      // (Measured and rejected again at this phase length: passing the second barrier between the two W halves of a cluster so that its release
+      // latency runs under the second half - 62.0 vs 53.5 us.)
       // and every read section ends in ONE counted wait that leaves the newest K-step's worth of DMA (8 instructions; 6 on the waves that stage
       // no A half 1) in flight: everything a later phase reads was issued before those.
 #define PP_COMPUTE2(AH)           \
@@ -622,7 +624,7 @@ static int pp_num_cus() {
 
 unsigned long long g_pp_trace = 0;        // "pp_trace_lo" / "pp_trace_hi" options: device buffer of 256 x 8 x 8 cycle stamps (profiling aid), 0 = off
 
-template <int EPI, bool OUT_BF16, int FM1, bool MERGED>
+template <int EPI, bool OUT_BF16, int FM1, int MERGED>
 static int pp_launch(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   constexpr int BM = 128 + 32 * FM1, NOUT = (EPI == MODE_EPI_SWIGLU) ? 128 : 256;
   p.n_tiles = d->N / NOUT;
@@ -664,11 +666,11 @@ int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, int rows224
 #define PP_CASE(E)                                                                                              \
   case E:                                                                                                       \
     if (!(p0.pp_flags & 256)) {                                   /* 256 = the eight-phase loop (A/B) */                      \
-      if (rows224) return ob ? pp_launch<E, true, 3, true>(p0, d, s) : pp_launch<E, false, 3, true>(p0, d, s);  \
-      return ob ? pp_launch<E, true, 4, true>(p0, d, s) : pp_launch<E, false, 4, true>(p0, d, s);               \
+      if (rows224) return ob ? pp_launch<E, true, 3, 1>(p0, d, s) : pp_launch<E, false, 3, 1>(p0, d, s);        \
+      return ob ? pp_launch<E, true, 4, 1>(p0, d, s) : pp_launch<E, false, 4, 1>(p0, d, s);                     \
     }                                                                                                           \
-    if (rows224) return ob ? pp_launch<E, true, 3, false>(p0, d, s) : pp_launch<E, false, 3, false>(p0, d, s); \
-    return ob ? pp_launch<E, true, 4, false>(p0, d, s) : pp_launch<E, false, 4, false>(p0, d, s);
+    if (rows224) return ob ? pp_launch<E, true, 3, 0>(p0, d, s) : pp_launch<E, false, 3, 0>(p0, d, s);         \
+    return ob ? pp_launch<E, true, 4, 0>(p0, d, s) : pp_launch<E, false, 4, 0>(p0, d, s);
   switch (epi) {
     PP_CASE(MODE_EPI_NONE)
     PP_CASE(MODE_EPI_BIAS)
