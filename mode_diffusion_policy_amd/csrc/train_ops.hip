@@ -229,7 +229,10 @@ __global__ __launch_bounds__(256) void swiglu_bwd_bias_bf16x8_kernel(const uint1
 // One wave per row.  dy[row] = (dy_a ? dy_a[row] : 0) + (dy_b ? dy_b[row] : 0) + sum_j G[pos[row*k+j]]   (all fp32)
 // dx[row] (+)= (g*dy)/n - x * <g*dy, x> / (D n^3)   with n = max(||x||/sqrt(D), eps)  [clamped branch: dx = g*dy/eps]
 // dg partial: dgp[block][d] = sum over the block's 4 rows of dy_d * x_d / n  (reduced by colsum stage 2)
-template <int NCH>   // NCH > 0: D == 256*NCH, chunk loops fully unrolled so that a phase's loads are all in flight together (else generic D % 4 == 0)
+// KK >= 0: top-k and the slab count GS of G are compile-time and every load of a row is unconditional (absent dy_a / dy_b read a dummy row and
+// are masked): with run-time conditions around the loads the kernel compiled into 85 dependent load + s_waitcnt vmcnt(0) rounds (14.7 us per
+// launch, 25 launches per training step).  KK = -1: any k / g_splits.
+template <int NCH, int KK = -1, int GS = 1>   // NCH > 0: D == 256*NCH, chunk loops fully unrolled so that a phase's loads are all in flight together (else generic D % 4 == 0)
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* dy_a,
                                                           const float* dy_b, const float* __restrict__ G, const int* __restrict__ pos, int k,
                                                           int rows, int D, float eps, float* dx, int accumulate, float* __restrict__ dgp,
@@ -257,6 +260,25 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
     chunks([&](int d) {
       const float4 xv = *reinterpret_cast<const float4*>(x + (long)row * D + d);
       float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (KK >= 0) {
+        const bool ha = dy_a != nullptr, hb = dy_b != nullptr;
+        const float4 ta = *reinterpret_cast<const float4*>((ha ? dy_a : x) + (long)row * D + d);
+        const float4 tb = *reinterpret_cast<const float4*>((hb ? dy_b : x) + (long)row * D + d);
+        float4 tg[KK > 0 ? KK : 1][GS];
+#pragma unroll
+        for (int j = 0; j < KK; ++j)
+#pragma unroll
+          for (int z = 0; z < GS; ++z) tg[j][z] = *reinterpret_cast<const float4*>(G + (z < g_splits ? z : 0) * g_split_stride + prow[j] + d);
+        dv.x += ha ? ta.x : 0.f; dv.y += ha ? ta.y : 0.f; dv.z += ha ? ta.z : 0.f; dv.w += ha ? ta.w : 0.f;
+        dv.x += hb ? tb.x : 0.f; dv.y += hb ? tb.y : 0.f; dv.z += hb ? tb.z : 0.f; dv.w += hb ? tb.w : 0.f;
+#pragma unroll
+        for (int j = 0; j < KK; ++j)
+#pragma unroll
+          for (int z = 0; z < GS; ++z) {
+            const bool on = z < g_splits;
+            dv.x += on ? tg[j][z].x : 0.f; dv.y += on ? tg[j][z].y : 0.f; dv.z += on ? tg[j][z].z : 0.f; dv.w += on ? tg[j][z].w : 0.f;
+          }
+      } else {
       if (dy_a) { const float4 t = *reinterpret_cast<const float4*>(dy_a + (long)row * D + d); dv.x += t.x; dv.y += t.y; dv.z += t.z; dv.w += t.w; }
       if (dy_b) { const float4 t = *reinterpret_cast<const float4*>(dy_b + (long)row * D + d); dv.x += t.x; dv.y += t.y; dv.z += t.z; dv.w += t.w; }
 #pragma unroll
@@ -269,6 +291,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
             dv.x += t2.x; dv.y += t2.y; dv.z += t2.z; dv.w += t2.w;
           }
         }
+      }
       }
       const float4 gv = *reinterpret_cast<const float4*>(g + d);
       *reinterpret_cast<float4*>(sx + wave * D + d) = xv;
@@ -292,7 +315,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
       float4 o = make_float4(gv.x * dv.x * rn - xv.x * coef, gv.y * dv.y * rn - xv.y * coef, gv.z * dv.z * rn - xv.z * coef,
                              gv.w * dv.w * rn - xv.w * coef);
       float* dst = dx + (long)row * D + d;
-      if (accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+      if constexpr (KK >= 0) {
+        const float4 t = *reinterpret_cast<const float4*>(dst);      // (dx is always valid memory; masked when the call overwrites)
+        if (accumulate) { o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+      } else {
+        if (accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+      }
       *reinterpret_cast<float4*>(dst) = o;
       if (dx_lp) {
         if (lp_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dx_lp) + (long)row * D + d) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
@@ -676,7 +704,14 @@ int rmsnorm_bwd_launch(const float* x, const float* g, const float* dy_a, const 
   const size_t lds = (size_t)8 * D * 4;
   if (lds > 64 * 1024) return MODE_ERR_UNSUPPORTED;
   if (k > 8) return MODE_ERR_UNSUPPORTED;
-  if (D == 1024)
+#define MODE_RB(KK, GS) hipLaunchKernelGGL((rmsnorm_bwd_kernel<4, KK, GS>), dim3((rows + 3) / 4), dim3(256), lds, stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx, \
+                                        accumulate, dg_partial, dy_out, dx_lp, lp_dtype == MODE_BF16 ? 1 : 0, g_splits, g_split_stride)
+  if (D == 1024 && k <= 2 && g_splits <= 2) {                      // the chain's shapes: branch-free loads
+    if (k == 0) MODE_RB(0, 1);
+    else if (k == 1) { if (g_splits == 1) MODE_RB(1, 1); else MODE_RB(1, 2); }
+    else { if (g_splits == 1) MODE_RB(2, 1); else MODE_RB(2, 2); }
+  } else if (D == 1024)
+#undef MODE_RB
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, dim3((rows + 3) / 4), dim3(256), lds, stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx,
                        accumulate, dg_partial, dy_out, dx_lp, lp_dtype == MODE_BF16 ? 1 : 0, g_splits, g_split_stride);
   else
