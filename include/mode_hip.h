@@ -138,6 +138,11 @@ typedef struct ModeGemmDesc {
  *                             writes row_ss_out as [M, N/16], MODE_EPI_SWIGLU accepts any row_ss_n.  MODE_ERR_UNSUPPORTED when the streamer is
  *                             switched off ("gemm_skinny_rows" = 0 / a forced "gemm_cfg") or does not take the shape. */
 #define MODE_GEMM_SMALL_ROWS 16
+/*   MODE_GEMM_IDENTITY_ROWS   grouped + gathered, a PROMISE (unlike the hints above it changes what is read): inside every group the gather is
+ *                             the ascending identity, a_rows[expert_offsets[e] + i] == i - every token is routed to every active expert, in
+ *                             token order, which is what the dispatch permutation of a uniform-sigma sampler step looks like.  Kernels may then
+ *                             compute the row index instead of loading it (one dependent memory round trip less at the start of a workgroup). */
+#define MODE_GEMM_IDENTITY_ROWS 32
 int mode_gemm(const ModeGemmDesc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -321,7 +321,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     g.a_rows = meta + ml.perm; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
     if (fuse) { g.row_ss = rowss; g.row_ss_n = ssn; g.row_eps = d.eps; }
     g.flags = small_flag;
-    if (uniform) g.flags |= MODE_GEMM_UNIFORM_GROUPS;
+    if (uniform) g.flags |= MODE_GEMM_UNIFORM_GROUPS | MODE_GEMM_IDENTITY_ROWS;   // one routing row: every token goes to the same experts, segments in token order
     rc = mode_gemm(&g, stream);
     if (rc) return rc;
     g = gemm_desc(dt, MODE_EPI_NONE, dt, NK, D, 4 * D, hbuf, 4 * D, lw.w2, 4 * D, ybuf, D);   // bf16 Y like the reference's autocast Linear

@@ -511,6 +511,7 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.ss_in = d->row_ss; p.ss_n = d->row_ss_n; p.ss_eps = d->row_eps;
   p.setprio = g_gemm_setprio;
   p.pp_flags = g_pp_flags;
+  p.identity_rows = (d->flags & MODE_GEMM_IDENTITY_ROWS) && d->a_rows && d->expert_offsets ? 1 : 0;
   if (p.koffs && (d->num_k_groups <= 0 || p.split_k > 1 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
   if (small_rows && (g_gemm_cfg != CFG_AUTO || g_gemm_skinny_rows <= 0)) return MODE_ERR_UNSUPPORTED;   // the caller sized its row_ss buffers for the streamer
   if (g_gemm_cfg == CFG_AUTO && (d->M <= g_gemm_skinny_rows || small_rows)) {

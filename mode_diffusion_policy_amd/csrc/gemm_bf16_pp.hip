@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
   const int Lend = min(T, L + R);
   const int nk = p.K / BKK / S;                                // K-steps per slice (even, >= 2: checked by the launcher)
 
-  struct Tile { int m, n, slice, row0, row_end, expert; };
+  struct Tile { int m, n, slice, row0, row_end, expert, seg0; };
   auto map_tile = [&](int l, Tile& t) {
     const int per_band = GM * n_tiles * S;
     const int band = l / per_band, first_m = band * GM;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
     const int n_hi = q / run, r2 = q - n_hi * run;
     t.m = first_m + r2 / RN;
     t.n = n_hi * RN + r2 % RN;
-    t.expert = 0;
+    t.expert = 0; t.seg0 = 0;
     if (p.offsets) {
       int tt = t.m;
       bool found = false;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
       for (int e = 0; e < 8; ++e) {
         if (!found && e < p.E) {
           const int nt_e = (o[e + 1] - o[e] + BM - 1) / BM;
-          if (tt < nt_e) { t.row0 = o[e] + tt * BM; t.row_end = min(o[e + 1], t.row0 + BM); t.expert = e; found = true; }
+          if (tt < nt_e) { t.row0 = o[e] + tt * BM; t.row_end = min(o[e + 1], t.row0 + BM); t.expert = e; t.seg0 = o[e]; found = true; }
           else tt -= nt_e;
         }
       }
@@ -284,7 +284,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
       // Issue order: the six index loads (hand-issued: the compiler would wait for them with vmcnt(0), i.e. behind the W DMA), then the four
       // W half-tiles - cold in HBM, the longest latency of the start-up, and independent of the indices - then a COUNTED wait that lets the
       // eight W DMA instructions stay in flight (loads retire in order), then the A half-tiles.
-      const bool gather = p.a_rows != nullptr;
+      const bool gather = p.a_rows != nullptr && !p.identity_rows;
+      if (p.a_rows != nullptr && p.identity_rows) {               // promised: a_rows[o[e] + i] == i - no index round trip in front of the A tiles
+        const int seg0 = cur.seg0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) srow[h][q] -= seg0;
+        nrow[0] -= seg0; nrow[1] -= seg0;
+      }
       int tk[6] = {0, 0, 0, 0, 0, 0};
       if (gather) {
         const int* ap[6] = {p.a_rows + srow[0][0], p.a_rows + srow[0][1], p.a_rows + srow[1][0], p.a_rows + srow[1][1],

@@ -312,7 +312,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(const GemmParams 
     // ---- round trip 1: source rows of this wave's A half-rows, token ids of the rows whose norms it computes (uniform branches around the batches)
     int src[NIT];                                                    // half-row j*4 + wave -> row (j*4 + wave) >> 1
     [[maybe_unused]] int tok[ROWS / NW];
-    if (p.a_rows) {                                                  // (both batches inside one branch: one wait for all of them)
+    if (p.a_rows && p.identity_rows) {                               // promised a_rows[row0 + i] == i: no index round trip (MODE_GEMM_IDENTITY_ROWS)
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) src[j] = min(mb + ((j * 4 + wave) >> 1), row_end - 1) - row0;
+      if constexpr (EPI == MODE_EPI_SWIGLU) {
+#pragma unroll
+        for (int q = 0; q < ROWS / NW; ++q) tok[q] = min(mb + wave + q * NW, row_end - 1) - row0;
+      }
+    } else if (p.a_rows) {                                           // (both batches inside one branch: one wait for all of them)
 #pragma unroll
       for (int j = 0; j < NIT; ++j) src[j] = p.a_rows[min(mb + ((j * 4 + wave) >> 1), row_end - 1)];   // rows past the segment re-read a valid row (never stored)
       if constexpr (EPI == MODE_EPI_SWIGLU) {

@@ -49,7 +49,8 @@ def main():
         mp = meta.data_ptr()
         return L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_SWIGLU, out_dtype=L.MODE_BF16, M=NK, N=4 * D, K=D, A=x.data_ptr(), lda=D, W=w1[wi].data_ptr(), ldw=D,
                               w_expert_stride=8 * D * D, bias=b1.data_ptr(), bias_expert_stride=8 * D, C=out.data_ptr(), ldc=4 * D, a_rows=mp + 4 * ml.perm,
-                              expert_offsets=mp + 4 * ml.offsets, num_experts=E, row_ss=ssb.data_ptr(), row_ss_n=D // 64, row_eps=1e-6)
+                              expert_offsets=mp + 4 * ml.offsets, num_experts=E, row_ss=ssb.data_ptr(), row_ss_n=D // 64, row_eps=1e-6,
+                              flags=int(os.environ.get("PP_DESC_FLAGS", "0")))
 
     def gemm2_desc(meta, ml, wi, out, S):
         mp = meta.data_ptr()

@@ -381,6 +381,40 @@ def test_small_rows_fused_ln2_chain(N_tok, D, E, k, S):
         lib.mode_set_option(b"gemm_skinny_rows", 32)
 
 
+
+@pytest.mark.parametrize("B,D", [(128, 1024), (1, 1024), (2, 256)])
+def test_identity_rows_promise_matches_loaded_gather(B, D):
+    """MODE_GEMM_IDENTITY_ROWS: under a uniform-sigma step every sample routes to the same experts, so inside each expert segment the dispatch
+    permutation is the ascending identity (checked here on the real dispatch kernel) and the up-projection may compute its gather instead of
+    loading it: bit-identical output with and without the flag (persistent ping-pong kernel at B = 128, streaming kernel at B <= 2)."""
+    import ctypes as C
+    lib = L.load()
+    p, st = H.p, H.stream()
+    bf = torch.bfloat16
+    T, E, k = 14, 4, 2
+    N, NK = B * T, B * T * k
+    idx = torch.tensor([[3, 1]] * 1, dtype=torch.int32, device=dev()); w = torch.tensor([[0.7, 0.3]], device=dev())
+    ml = L.ModeMetaLayout(); lib.mode_moe_meta_layout(N, E, k, C.byref(ml))
+    meta = torch.empty(ml.total_words, dtype=torch.int32, device=dev())
+    L.check(lib.mode_dit_dispatch(p(idx), p(w), 1, k, 1, N, N, E, k, p(meta), st))       # one routing row shared by all N tokens
+    offs = meta[ml.offsets: ml.offsets + E + 1].cpu().long(); perm = meta[ml.perm: ml.perm + NK].cpu().long()
+    for e in range(E):
+        seg = perm[offs[e]: offs[e + 1]]
+        assert seg.numel() in (0, N) and torch.equal(seg, torch.arange(seg.numel()))
+    x = rnd(N, D, seed=1).to(bf).to(dev()); W1 = rnd(E, 8 * D, D, seed=2, scale=D ** -0.5).to(bf).to(dev()); b1 = rnd(E, 8 * D, seed=3, scale=0.1).to(dev())
+    ss = (torch.rand(N, D // 16, device=dev()) + 0.5) if N <= 32 else (torch.rand(N, D // 64, device=dev()) + 0.5)
+    outs = []
+    for extra in (0, L.GEMM_IDENTITY_ROWS):
+        out = torch.full((NK, 4 * D), float("nan"), dtype=bf, device=dev())
+        d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_SWIGLU, out_dtype=L.MODE_BF16, M=NK, N=4 * D, K=D, A=p(x), lda=D, W=p(W1), ldw=D,
+                           w_expert_stride=8 * D * D, bias=p(b1), bias_expert_stride=8 * D, C=p(out), ldc=4 * D, a_rows=p(meta) + 4 * ml.perm,
+                           expert_offsets=p(meta) + 4 * ml.offsets, num_experts=E, row_ss=p(ss), row_ss_n=ss.shape[1], row_eps=1e-6,
+                           flags=L.GEMM_UNIFORM_GROUPS | (L.GEMM_SMALL_ROWS if N <= 32 else 0) | extra)
+        L.check(lib.mode_gemm(C.byref(d), st), "up-projection")
+        outs.append(out)
+    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 # ------------------------------------------------------------------------------------------------- weight-streaming GEMM for a handful of rows
 def _both_paths(fn):
     """fn() with the weight-streaming kernel (default only for M <= 32; forced here up to 128 rows) and with the tiled kernel; returns (skinny, tiled)."""
