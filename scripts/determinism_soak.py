@@ -36,12 +36,13 @@ acts = torch.randn(B, 10, 7, generator=g).to(dev); noise = torch.randn(B, 10, 7,
 
 
 def grads():
+    m.engine.arena.grad_pending = False                      # as after optimizer.step() / zero_grad(): the next backward overwrites the arena (a second one would accumulate)
     torch.manual_seed(123)
     sg = rand_log_logistic((B,), loc=math.log(0.5), scale=0.5, min_value=1e-3, max_value=80.0, device=dev)
     loss, _ = den.loss({"state_images": img}, acts, goal, noise, sg)
     loss.backward()
     torch.cuda.synchronize()
-    return m.engine.arena.grad.clone(), float(loss)
+    return m.engine.arena.grad.clone(), float(loss.detach())
 
 
 ref_g, ref_l = grads()
