@@ -117,7 +117,7 @@ def dominant_kernel_roofline(den, device, reps=240):
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "r02_gemm_pmc.json")))
         ent = pj["kernels"].get("expert_up_projection")
-        if ent and ent.get("kernel_substr", "") in "gemm_pp_kernel<4, true, 3>":
+        if ent and ent.get("kernel_substr", "").startswith("gemm_pp_kernel<4, true, 3"):
             traffic, src = ent["hbm_bytes_per_launch"], "profiles/r02_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
     except Exception:
         pass

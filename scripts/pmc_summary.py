@@ -13,9 +13,9 @@ from collections import defaultdict
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_final"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_gemm_pmc.json"
-ROLES = [("gemm_pp_kernel<4, true, 3>", "expert_up_projection"), ("gemm_pp_kernel<0, true, 3>", "expert_down_projection"),
+ROLES = [("gemm_pp_kernel<4, true, 3,", "expert_up_projection"), ("gemm_pp_kernel<0, true, 3,", "expert_down_projection"),
          ("gemm_bf16_kernel<128, 64, 2, 2, 2, 1,", "qkv_projection"), ("gemm_bf16_kernel<64, 64, 2, 2, 3, 5,", "c_proj_residual_ln2"),
-         ("combine_norm_kernel", "combine_ln1"), ("attn_bf16_kernel", "attention")]
+         ("combine_norm_row_kernel", "combine_ln1"), ("attn_bf16_kernel", "attention")]
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for f in sorted(glob.glob(f"{root}/pmc*/p_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
