@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MODE_HIP_ABI_VERSION 3
+#define MODE_HIP_ABI_VERSION 4
 
 typedef enum ModeStatus {
   MODE_OK = 0,
@@ -456,12 +456,16 @@ typedef struct ModeForwardArgs {
   int32_t B; int32_t dtype;
   const float* emb_t; int64_t emb_row_stride;        /* sigma token rows; stride 0 => one row shared by the whole batch      */
   const float* cond;  int64_t cond_row_stride;       /* additive conditioning c (normally == emb_t)                          */
-  const int32_t* meta; int64_t meta_layer_stride;    /* L dispatch records (mode_dit_dispatch); stride in 4-byte words       */
+  const int32_t* meta; int64_t meta_layer_stride;    /* L dispatch records (mode_dit_dispatch); stride in 4-byte words; NULL: see below */
   const float* goal_e; const float* img_e;           /* hoisted embeddings fp32 [B,D], [B,n_img,D]                           */
   const float* actions;                              /* [B, A_len, A_dim] un-scaled noisy actions                            */
   const float* c_in; int64_t c_in_stride;            /* NULL => 1                                                            */
   const float* scal; int64_t scal_stride;            /* {c_skip,c_out,r,_} per sample (stride 4) / shared (0); NULL => F only */
   float* F; float* denoised; float* x_next;
+  /* ABI 4.  meta == NULL selects TOKEN routing (the reference's cond_router=False, modedit.py:296-301, 322-325, 550-553): every block routes
+   * each token on its own ln_2-normalised state through the block's router MLP (fp32), top-k and dispatch happen inside the chain, per layer.
+   * topk_idx_out (optional): int32 [L][B*T][k] - the experts every token took (for the caller's side channels / tests). */
+  int32_t* topk_idx_out;
 } ModeForwardArgs;
 int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w, const ModeForwardArgs* a,
                      void* workspace, size_t workspace_bytes, void* stream);

@@ -28,7 +28,7 @@ extern int g_adamw_blocks;
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t x, h, qkv, y, hbuf, ybuf, rowss, meta, e1, hid, logits, total;
+  size_t x, h, qkv, y, hbuf, ybuf, rowss, meta, e1, hid, logits, tr_hid, tr_logits, tr_idx, tr_w, tr_meta, total;
 };
 
 static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
@@ -51,6 +51,8 @@ static WsLayout ws_layout(const ModeDims& d, int B, int R, int dtype) {
   w.e1 = take(Rr * D * 4);
   w.hid = take(Rr * 2 * D * 4 * d.L);          // router hidden activations of all layers [R][L][2D]
   w.logits = take(Rr * d.E * 4 * d.L);
+  // token routing (cond_router=False): one layer's router activations / decisions / dispatch record at a time, N routing rows
+  w.tr_hid = take(N * 2 * D * 4); w.tr_logits = take(N * d.E * 4); w.tr_idx = take(NK * 4); w.tr_w = take(NK * 4); w.tr_meta = take((size_t)ml.total_words * 4);
   w.total = o;
   return w;
 }
@@ -253,7 +255,8 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
   int rc = check_dims(dims);
   if (rc) return rc;
   if (!w || !w->layers || !a || !workspace) return MODE_ERR_BAD_ARG;
-  if (!a->meta || !a->goal_e || !a->img_e || !a->actions || !a->cond) return MODE_ERR_BAD_ARG;
+  if (!a->goal_e || !a->img_e || !a->actions || !a->cond) return MODE_ERR_BAD_ARG;
+  const bool tok_route = a->meta == nullptr;                   // cond_router=False: routing on the token states, inside the chain
   if (a->B <= 0) return MODE_OK;
   const ModeDims& d = *dims;
   const int dt = a->dtype, B = a->B, T = d.T, D = d.D, N = B * T, NK = N * d.k;
@@ -267,14 +270,14 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
   float* rowss = (float*)(ws + L.rowss);
   // Small-batch chain (B <= 2 environments: N <= "gemm_skinny_rows" token rows): every GEMM of the layer is a weight stream
   // (MODE_GEMM_SMALL_ROWS: also the grouped ones, whose segments have at most N rows), the fused ln_2 works on 16-column partials.
-  const bool small = dt == MODE_BF16 && g_gemm_cfg == 0 && g_gemm_skinny_rows > 0 && N <= g_gemm_skinny_rows && D % 128 == 0;
-  const bool fuse = g_fuse_ln2 && dt == MODE_BF16 && D % 64 == 0;
+  const bool small = !tok_route && dt == MODE_BF16 && g_gemm_cfg == 0 && g_gemm_skinny_rows > 0 && N <= g_gemm_skinny_rows && D % 128 == 0;
+  const bool fuse = !tok_route && g_fuse_ln2 && dt == MODE_BF16 && D % 64 == 0;     // (token routing reads the normalised fp32 stream: ln_2 stays a kernel)
   const int ssn = small ? D / 16 : D / 64;
   const int small_flag = small ? MODE_GEMM_SMALL_ROWS : 0;
   ModeMetaLayout ml;
   mode_moe_meta_layout(N, d.E, d.k, &ml);
   const int ysplit = down_proj_split(dt, 4 * D);
-  const bool uniform = a->cond_row_stride == 0;   // one conditioning row for the whole batch (the sampler): every sample routes to the same experts
+  const bool uniform = !tok_route && a->cond_row_stride == 0;   // one conditioning row for the whole batch (the sampler): every sample routes to the same experts
   const int cond_rpc = T;   // one conditioning row per sample
   // cond addressing: row b at cond + b*cond_row_stride.  rmsnorm/combine kernels index cond by (row / rows_per_cond) * D, so a
   // shared row (stride 0) is expressed as rows_per_cond = N (every token maps to row 0).
@@ -293,7 +296,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
 
   for (int l = 0; l < d.L; ++l) {
     const ModeLayerWeights& lw = w->layers[l];
-    const int32_t* meta = a->meta + (long)l * a->meta_layer_stride;
+    const int32_t* meta = tok_route ? reinterpret_cast<const int32_t*>(ws + L.tr_meta) : a->meta + (long)l * a->meta_layer_stride;
     // q,k,v as ONE GEMM [N,D] x [3D,D]^T + bias   (modedit.py:108-110, 141-143)
     ModeGemmDesc g = gemm_desc(dt, MODE_EPI_BIAS, dt, N, 3 * D, D, h, D, lw.wqkv, D, qkv, 3 * D);
     g.bias = lw.bqkv; g.flags = small_flag;
@@ -314,6 +317,20 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
       // x = ln_2(x): overwrites the stream (modedit.py:539); low-precision copy feeds the experts
       rc = mode_rmsnorm_cond_fwd(x, lw.ln2_g, nullptr, N, D, 1, d.eps, x, h, dt, stream);
       if (rc) return rc;
+    }
+    if (tok_route) {
+      // router(x, None) on the ln_2-normalised token states (modedit.py:553, 322-325): Linear(D,2D) + GELU + Linear(2D,E) in fp32, softmax /
+      // clamp / top-k per token, dispatch record of this layer - the same kernels the conditioning-row router runs once per sampler schedule
+      float* r_hid = (float*)(ws + L.tr_hid); float* r_logits = (float*)(ws + L.tr_logits);
+      int32_t* r_idx = (int32_t*)(ws + L.tr_idx); float* r_w = (float*)(ws + L.tr_w); int32_t* m = (int32_t*)(ws + L.tr_meta);
+      ModeGemmDesc rg = gemm_desc(MODE_F32, MODE_EPI_BIAS_GELU, MODE_F32, N, 2 * D, D, x, D, lw.r_w0, D, r_hid, 2L * D);
+      rg.bias = lw.r_b0;
+      if ((rc = mode_gemm(&rg, stream))) return rc;
+      if ((rc = mode_router_logits(r_hid, 2L * D, lw.r_w3, 0, lw.r_b3, 0, 1, N, d.E, 2 * D, r_logits, stream))) return rc;
+      int32_t* idx_out = a->topk_idx_out ? a->topk_idx_out + (long)l * NK : r_idx;
+      if ((rc = mode_moe_route_topk_f32(r_logits, N, d.E, d.k, d.router_normalize, nullptr, nullptr, idx_out, r_w, stream))) return rc;
+      if ((rc = mode_moe_dispatch_meta(idx_out, r_w, N, 1, N, d.E, d.k, m + ml.counts, m + ml.offsets, m + ml.perm, m + ml.pos,
+                                       reinterpret_cast<float*>(m + ml.posw), nullptr, nullptr, stream))) return rc;
     }
     // experts: gather -> grouped GEMM (SwishGLU epilogue) -> grouped GEMM   (modedit.py:561-566, 83-90, 247-255)
     g = gemm_desc(dt, MODE_EPI_SWIGLU, dt, NK, 4 * D, D, h, D, lw.w1, D, hbuf, 4 * D);

@@ -136,7 +136,7 @@ class MoDeDiT(nn.Module):
         # flag combinations the reference itself cannot run or that leave the benchmarked path
         unsupported = dict(use_proprio=use_proprio, use_custom_attn_mask=use_custom_attn_mask, use_shared_expert=use_shared_expert,
                            not_goal_conditioned=not goal_conditioned, not_linear_output=not linear_output,
-                           not_cond_router=not cond_router, not_causal=not causal)
+                           not_causal=not causal)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"MoDeDiT (HIP): unsupported configuration flags: {bad}")
@@ -170,6 +170,10 @@ class MoDeDiT(nn.Module):
         self.use_shared_expert = use_shared_expert
         self.use_noise_token_as_input = use_noise_token_as_input
         self.use_goal_in_routing = use_goal_in_routing
+        # cond_router=False (modedit.py:296-301, 322-325, 550-553): every block routes each TOKEN on its own ln_2-normalised state instead of the
+        # conditioning row - same router parameters (Linear(D,2D), Linear(2D,E)), routing resolved inside the launch chain, per layer.  Inference
+        # (forward / denoise / every sampler); the training chain raises.
+        self.cond_router = bool(cond_router)
         self.init_style = init_style           # accepted and ignored, like the reference
         self.goal_conditioned, self.causal = goal_conditioned, causal
         self.n_img_tokens = n_img_tokens
@@ -234,11 +238,19 @@ class MoDeDiT(nn.Module):
         if self.use_goal_in_routing:                                       # modedit.py:801-802
             cond = (emb_t.expand(B, D) + goal_e).contiguous()
             R = B
-        idx, w, _, _ = eng.route(cond)
         N = B * T
+        F = torch.empty(B, self.action_seq_len, self.action_dim, dtype=torch.float32, device=dev)
+        if not self.cond_router:                                          # token routing inside the chain
+            idx = torch.empty(self.num_layers, N, self.top_k, dtype=torch.int32, device=dev)
+            eng.forward(B, emb_t, 0 if emb_t.shape[0] == 1 else D, cond, 0 if cond.shape[0] == 1 else D, None, 0, goal_e, img_e, acts, F=F, topk_out=idx)
+            self._last_topk = idx
+            self._account_token_usage(idx, N)
+            self.logits_per_layer = [None] * self.num_layers
+            self.probs_per_layer = [None] * self.num_layers
+            return F
+        idx, w, _, _ = eng.route(cond)
         meta = eng.dispatch(idx, w, self.num_layers, R, N if R == 1 else T, N)
         ml = eng.meta_layout(N)
-        F = torch.empty(B, self.action_seq_len, self.action_dim, dtype=torch.float32, device=dev)
         eng.forward(B, emb_t, 0 if emb_t.shape[0] == 1 else D, cond, 0 if cond.shape[0] == 1 else D,
                     meta.data_ptr(), ml.total_words, goal_e, img_e, acts, F=F)
         self._last_topk = idx
@@ -278,11 +290,18 @@ class MoDeDiT(nn.Module):
         if self.use_goal_in_routing:
             cond = (emb_t.expand(B, D) + goal_e).contiguous()
         Rr = cond.shape[0]
-        idx, w, _, _ = eng.route(cond)
         N = B * T
+        den = torch.empty_like(x)
+        if not self.cond_router:                                          # token routing inside the chain
+            idx = torch.empty(self.num_layers, N, self.top_k, dtype=torch.int32, device=dev)
+            eng.forward(B, emb_t, 0 if R == 1 else D, cond, 0 if Rr == 1 else D, None, 0, goal_e, img_e, x, c_in=c_in, c_in_stride=0 if R == 1 else 1,
+                        scal_ptr=scal.data_ptr(), scal_stride=0 if R == 1 else 4, denoised=den, topk_out=idx)
+            self._last_topk = idx
+            self._account_token_usage(idx, N)
+            return den
+        idx, w, _, _ = eng.route(cond)
         meta = eng.dispatch(idx, w, self.num_layers, Rr, N if Rr == 1 else T, N)
         ml = eng.meta_layout(N)
-        den = torch.empty_like(x)
         eng.forward(B, emb_t, 0 if R == 1 else D, cond, 0 if Rr == 1 else D, meta.data_ptr(), ml.total_words, goal_e, img_e, x,
                     c_in=c_in, c_in_stride=0 if R == 1 else 1, scal_ptr=scal.data_ptr(), scal_stride=0 if R == 1 else 4, denoised=den)
         self._last_topk = idx
@@ -359,7 +378,7 @@ class MoDeDiT(nn.Module):
         sig = sigmas.detach().to(device=dev, dtype=torch.float32).contiguous()
         x0 = action.detach().to(device=dev, dtype=torch.float32)
         n = sig.numel() - 1
-        if self.use_goal_in_routing:                                     # routing depends on the sample: per-step generic path
+        if self.use_goal_in_routing or not self.cond_router:             # routing depends on the sample / the tokens: per-step generic path
             x = x0.clone()
             for i in range(n):
                 den = self.denoise({"state_images": img}, x, goals, sig[i].reshape(1), sigma_data)
@@ -408,6 +427,16 @@ class MoDeDiT(nn.Module):
         self._account_ddim_usage(ent["sched"], ent["ml"], n, B * self.seq_len)
         return ent["x"].clone()
 
+    def _account_token_usage(self, idx, n_tokens):
+        """Expert-usage counters under token routing: idx int32 [L, N, k] -> per-layer histogram, kept on the device like ``_account_usage``."""
+        Ly, E = self.num_layers, self.num_experts
+        counts = torch.zeros(Ly, E, dtype=torch.int64, device=idx.device).scatter_add_(1, idx.reshape(Ly, -1).long(), torch.ones(Ly, idx[0].numel(), dtype=torch.int64, device=idx.device))
+        if getattr(self, "_usage_dev", None) is None or self._usage_dev.device != counts.device:
+            self._usage_dev = torch.zeros(Ly, E, dtype=torch.int64, device=counts.device)
+        self._usage_dev += counts
+        for blk in self.blocks:
+            blk.total_tokens_processed += n_tokens
+
     def _account_usage(self, meta, ml, n_tokens):
         """Expert-usage counters (modedit.py:568-572, 594) kept on-device; no host sync on the hot path."""
         counts = meta[:, ml.counts: ml.counts + self.num_experts]
@@ -449,7 +478,7 @@ class MoDeDiT(nn.Module):
         """Reference modedit.py:971-992 duplicates two experts' weights per (sigma, layer) (~12 GB at C2) and keys the cache on a
         Python float mean that only hits at B=1.  Here only the routing decision (e0,e1,p0,p1) is cached,
         keyed on the exact sigma bits; weights are never copied."""
-        if self.training:
+        if self.training or not self.cond_router:                        # token routing depends on the observations: nothing to cache per noise level
             return
         eng = self.engine
         sig = sigma.detach().to(device=eng.device, dtype=torch.float32).reshape(-1)[:1].contiguous()

@@ -156,6 +156,9 @@ class _EdmLossFn(torch.autograd.Function):
 
 
 def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
+    if not getattr(model, "cond_router", True):
+        raise NotImplementedError("MoDeDiT (HIP): cond_router=False is an inference path here; its training chain (router gradients into the token "
+                                  "states) is not built - no shipped config or checkpoint uses it")
     eng: DitEngine = model.engine
     if not hasattr(eng, "_train") or eng._train is None:
         eng._train = TrainState(eng)

@@ -264,12 +264,19 @@ def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, state_images: Tensor, act
             ak = attn_keep_scale(stream_seed(int(dropout["seed"]), 2 * l), B, cfg.n_heads, T, float(dropout["attn_p"]))
         x = x + causal_attention(sd, l, rmsnorm(x, sd[p + "ln_1.g"]) + c, cfg.n_heads, ak)   # :532
         u = rmsnorm(x, sd[p + "ln_2.g"])                                                # :539 (overwrites stream)
-        logits, probs = router_probs(sd, l, cond)                                       # distinct rows only
-        if topk_idx is None:
+        if not cfg.cond_router:
+            # token routing (modedit.py:296-301, 322-325, 553): router(x, None) on the ln_2-normalised token states, one decision per token
+            logits, probs = router_probs(sd, l, u.reshape(B * T, D))
+            idx, w = topk_route(probs, k, cfg.router_normalize)
+            if topk_idx is not None:
+                raise NotImplementedError("explicit expert ids with token routing")
+        elif topk_idx is None:
+            logits, probs = router_probs(sd, l, cond)                                   # distinct rows only
             idx_b, w_b = topk_route(probs, k, cfg.router_normalize)
             idx = idx_b[:, None, :].expand(B, T, k).reshape(B * T, k)
             w = w_b[:, None, :].expand(B, T, k).reshape(B * T, k)
         else:
+            logits, probs = router_probs(sd, l, cond)
             idx = topk_idx[l].reshape(B * T, k)
             pr = probs[:, None, :].expand(B, T, E).reshape(B * T, E).gather(1, idx)
             w = pr / pr.sum(-1, keepdim=True) if cfg.router_normalize else pr

@@ -175,3 +175,17 @@ def test_oracle_aux_loss_composition_vs_reference(golden):
     for n, ref in gn.items():
         if ref > 1e-6:
             assert abs(float(sd[n].grad.norm()) - ref) / ref < 1e-4, n
+
+
+def test_oracle_token_routing_vs_reference(golden):
+    """Oracle branch for cond_router=False (router on the ln_2-normalised token states) against fixture F14 (the reference with that flag)."""
+    import dataclasses
+    g = golden("F14_c1e4_token_routing")
+    cfg = dataclasses.replace(get_config(str(g["cfg"])), cond_router=False)
+    sd = make_state_dict(cfg, int(g["seed"])); inp = make_inputs(cfg, int(g["B"]), int(g["seed"]) + 1)
+    for tag in ("uniform", "persample"):
+        out, aux = O.dit_forward(sd, cfg, inp["state_images"], inp["actions"], inp["goals"], torch.from_numpy(g[f"{tag}_sigma"]), return_aux=True)
+        assert torch.equal(torch.stack(aux.topk_idx), torch.from_numpy(g[f"{tag}_idx"]).long())
+        assert float((out - torch.from_numpy(g[f"{tag}_out"])).norm() / torch.from_numpy(g[f"{tag}_out"]).norm()) < 2e-5
+    x = O.sample_ddim(sd, cfg, 0.5, inp["state_images"], inp["x0"], inp["goals"], torch.from_numpy(g["sigmas"]))
+    assert float((x - torch.from_numpy(g["x_final"])).norm() / torch.from_numpy(g["x_final"]).norm()) < 2e-5
