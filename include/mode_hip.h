@@ -63,6 +63,8 @@ const char* mode_hip_status_string(int status);
  *   4 = 64-wide ring-2, 5 = 128-wide single-buffered.  "adamw_blocks": workgroup cap of one AdamW launch (0 = 256, one streaming workgroup per CU).
  * "gemm_skinny_rows": bf16 GEMMs with M <= this many rows use the weight-streaming kernels, and mode_dit_forward runs a batch of at most this
  *   many TOKEN rows as the small-batch chain (MODE_GEMM_SMALL_ROWS) (default 32 = two environments, 0 = off).
+ * "gemm_mid_rows": ungrouped bf16 GEMMs with K = 1024 and at most this many rows (more than "gemm_skinny_rows") keep their weights in registers
+ *   and their A block in LDS - no K loop (default 128 = up to nine environments, 0 = off).
  * "gemm_setprio": 1 (default) = s_setprio 1 around the MFMA clusters of the tiled bf16 GEMM, 0 = off.
  * "fuse_ln2": 1 (default) = ln_2 folded into the c_proj / up-projection / combine kernels on the bf16 path, 0 = its own kernel.
  * "dn_split_k": K-slices of the inference path's expert down-projection, 0 = default (4, for every batch size), 1 = off, <= 8.

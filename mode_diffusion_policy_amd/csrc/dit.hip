@@ -21,6 +21,7 @@ extern int g_pp_flags;
 extern int g_gemm_pp_min_tiles;
 extern unsigned long long g_pp_trace;
 extern int g_combine_row_max;
+extern int g_gemm_mid_rows;
 extern int g_tr_cfg;
 extern int g_gemm_group_m;
 extern int g_attn_bwd_stop;
@@ -122,6 +123,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_skinny_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_skinny_rows = value; return MODE_OK; }
   if (!strcmp(key, "gemm_setprio")) { g_gemm_setprio = value != 0; return MODE_OK; }
   if (!strcmp(key, "fuse_ln2")) { g_fuse_ln2 = value != 0; return MODE_OK; }
+  if (!strcmp(key, "gemm_mid_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_mid_rows = value; return MODE_OK; }
   if (!strcmp(key, "combine_row_max")) { if (value < 0) return MODE_ERR_BAD_ARG; g_combine_row_max = value; return MODE_OK; }
   if (!strcmp(key, "dn_split_k")) { if (value < 0 || value > 8) return MODE_ERR_BAD_ARG; g_dn_split_k = value; return MODE_OK; }
   return MODE_ERR_UNSUPPORTED;

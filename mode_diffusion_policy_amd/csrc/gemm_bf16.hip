@@ -404,6 +404,8 @@ enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x64_NS3 = 4, CFG_128x128_NS1 = 
        CFG_PP256 = 16, CFG_PP224 = 17 };
 int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p, int rows224, hipStream_t s);   // gemm_bf16_pp.hip: persistent ping-pong 8-phase kernel
 int gemm_bf16_skinny_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_skinny.hip: weight streamer for a handful of rows
+int gemm_bf16_mid_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);      // gemm_bf16_skinny.hip: register-resident weights, no K loop (a few hundred rows)
+int g_gemm_mid_rows = 128;   // "gemm_mid_rows" option: ungrouped K = 1024 GEMMs with at most this many rows take gemm_bf16_mid_kernel (0 = off).  Measured chunk latency B = 4: 6.89 -> 6.60 ms, B = 8: 7.40 -> 7.14 ms; from ~200 rows on the M/32 re-reads of W through L2 cost more than the ring kernel (B = 16: 8.41 -> 8.50 ms, B = 32: 9.21 -> 9.48 ms)
 int g_gemm_cfg = CFG_AUTO;
 int g_gemm_setprio = 1;
 int g_gemm_skinny_rows = 32;   // measured (scripts/rollout_batch_probe.py): chunk latency B=1 9.4 -> 7.35 ms, B=2 8.7 -> 8.3 ms; from ~3 environments on the tiled kernel (64x64 tiles) is as fast or faster
@@ -517,6 +519,10 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
   if (g_gemm_cfg == CFG_AUTO && (d->M <= g_gemm_skinny_rows || small_rows)) {
     const int rc = gemm_bf16_skinny_launch(d, p, s);
     if (rc != MODE_ERR_UNSUPPORTED || small_rows) return rc;
+  }
+  if (g_gemm_cfg == CFG_AUTO && d->M <= g_gemm_mid_rows && !small_rows) {
+    const int rc = gemm_bf16_mid_launch(d, p, s);
+    if (rc != MODE_ERR_UNSUPPORTED) return rc;
   }
   int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d);
   if (cfg == CFG_PP256 || cfg == CFG_PP224) {

@@ -437,6 +437,101 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(const GemmParams 
   }
 }
 
+// ---- Medium M (33..128 rows: 3..9 environments), K = 1024, ungrouped: the QKV projection of small rollout batches.  The ring kernels
+// spend ~800 cycles per 64-column K-step there whatever the ring depth (s_barrier turnaround + exposed LDS read latency around 128 cycles of
+// MFMA: [448 x 1024] x [3072 x 1024] takes 11.6 us, a [112 x 1024] one 9.7 us).  This kernel has NO K loop over memory: a workgroup owns
+// 32 rows x 64 columns; each of its four waves keeps the whole K = 1024 of its 16 weight rows in registers (32 fragments, requested in one
+// burst) and the workgroup's A block sits in LDS as in gemm_bf16_stream_kernel (LDS-DMA, padded rows); then 32 x 2 MFMAs per wave straight
+// through - the same k-ordered fp32 chain as every other forward kernel, so the results are bit-identical to the ring kernels (the batch-slice
+// test compares B = 8 with the same samples inside B = 128).  W is re-read by the M/32 row blocks through L2 (default cache policy), which is
+// why the kernel stops paying from ~200 rows on ("gemm_mid_rows" option, default 128).
+template <int EPI, bool OUT_BF16>
+__global__ __launch_bounds__(256) void gemm_bf16_mid_kernel(const GemmParams p) {
+  constexpr int ROWS = 32, AROW = 2048 + 16, KS = 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* aimg = smem;                                                // [32][AROW]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = blockIdx.x * 64 + wave * 16;
+  const int mb = blockIdx.y * ROWS;
+  const int n = n0 + fq * 4;
+  // the A block first (LDS-DMA, nothing waits for it), then the wave's 32 weight fragments
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int hr = j * 4 + wave;                                     // half-row: row hr >> 1, 1-KiB half hr & 1
+    const int srow = min(mb + (hr >> 1), p.M - 1);                  // rows past M re-read a valid row (never stored)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.A + (long)srow * p.lda + (hr & 1) * 512 + lane * 8),
+                                     (__attribute__((address_space(3))) void*)(aimg + (hr >> 1) * AROW + (hr & 1) * 1024), 16, 0, 0);
+  }
+  // Weight fragments: loaded with four ADJACENT lanes on one row's 64 bytes of a k32 step (lane l: row l >> 2, 16-byte piece l & 3 - 16 requests
+  // of 64 B per instruction instead of 64 of 16 B: the per-CU L1 request rate, one per clock, was what bounded the direct fragment loads:
+  // 18.5 us at M = 448), then moved into MFMA layout (lane fr + 16*fq <- row fr, piece fq = loading lane 4*fr + fq) by ds_bpermute.
+  const uint16_t* wrow = p.W + (long)min(n0 + (lane >> 2), p.N - 1) * p.ldw + (lane & 3) * 8;
+  typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+  i32x4_t wraw[KS];
+#pragma unroll
+  for (int u = 0; u < KS; ++u) wraw[u] = *reinterpret_cast<const i32x4_t*>(wrow + 32 * u);
+  const int perm_addr = (4 * fr + fq) * 4;
+  [[maybe_unused]] float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (EPI == MODE_EPI_BIAS) e0 = *reinterpret_cast<const float4*>(p.bias + min(n, p.N - 4));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the DMA'd A block has landed (the compiler does not track it)
+  __syncthreads();
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const char* a0 = aimg + fr * AROW + fq * 16;
+  bf16x8 wf[KS];
+#pragma unroll
+  for (int u = 0; u < KS; ++u) {
+    i32x4_t t;
+    t[0] = __builtin_amdgcn_ds_bpermute(perm_addr, wraw[u][0]); t[1] = __builtin_amdgcn_ds_bpermute(perm_addr, wraw[u][1]);
+    t[2] = __builtin_amdgcn_ds_bpermute(perm_addr, wraw[u][2]); t[3] = __builtin_amdgcn_ds_bpermute(perm_addr, wraw[u][3]);
+    wf[u] = __builtin_bit_cast(bf16x8, t);
+  }
+#pragma unroll
+  for (int u = 0; u < KS; ++u) {
+    const bf16x8 af0 = *reinterpret_cast<const bf16x8*>(a0 + u * 64);
+    const bf16x8 af1 = *reinterpret_cast<const bf16x8*>(a0 + 16 * AROW + u * 64);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af1, acc[1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ml = mb + i * 16 + fr;
+    if (ml >= p.M || n >= p.N) continue;
+    f32x4 o = acc[i];
+    if constexpr (EPI == MODE_EPI_BIAS) { o[0] += e0.x; o[1] += e0.y; o[2] += e0.z; o[3] += e0.w; }
+    if constexpr (OUT_BF16) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.C) + ((long)ml * p.ldc + n) * 2) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+    else *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.C) + ((long)ml * p.ldc + n) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// Medium-M launcher: ungrouped, K == 1024, no split, NONE / BIAS epilogues, N % 64 == 0.  Returns MODE_ERR_UNSUPPORTED otherwise.
+int gemm_bf16_mid_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s) {
+  if (d->expert_offsets || d->a_rows || p.koffs || p.split_k != 1 || d->K != 1024 || d->N % 64 || p.ss_in) return MODE_ERR_UNSUPPORTED;
+  if (d->epilogue != MODE_EPI_NONE && d->epilogue != MODE_EPI_BIAS) return MODE_ERR_UNSUPPORTED;
+  constexpr size_t LDS = (size_t)32 * (2048 + 16);
+  const dim3 grid(d->N / 64, (d->M + 31) / 32);
+  const bool ob = d->out_dtype == MODE_BF16;
+#define MODE_MID(E, OB)                                                                                                                     \
+  do {                                                                                                                                      \
+    auto kern = gemm_bf16_mid_kernel<E, OB>;                                                                                                \
+    static bool attr_set[16] = {false};                                                                                                     \
+    int dev = 0;                                                                                                                            \
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return MODE_ERR_UNSUPPORTED;                                              \
+    if (!attr_set[dev]) {                                                                                                                   \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);      \
+      if (e != hipSuccess) return (int)e;                                                                                                   \
+      attr_set[dev] = true;                                                                                                                 \
+    }                                                                                                                                       \
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, p);                                                                                   \
+  } while (0)
+  if (d->epilogue == MODE_EPI_BIAS) { if (ob) MODE_MID(MODE_EPI_BIAS, true); else MODE_MID(MODE_EPI_BIAS, false); }
+  else { if (ob) MODE_MID(MODE_EPI_NONE, true); else MODE_MID(MODE_EPI_NONE, false); }
+#undef MODE_MID
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
 extern unsigned long long g_pp_trace;      // gemm_bf16_pp.hip
 
 template <int MT, int EPI, bool OUT_BF16>
