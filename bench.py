@@ -59,6 +59,66 @@ def synthetic_inputs(device, B):
     return img, goal, x0
 
 
+class PowerSampler:
+    """Socket power and shader clock of THIS process's GPU, sampled from the amdgpu hwmon files while a timed region runs.  The expert GEMMs
+    run the socket into its power cap (1377 W of 1400 W, 1.8-1.9 GHz instead of the 2.4 GHz the 2.5 PF/s peak is quoted at),
+    so the clock under load belongs next to every fraction-of-peak this file reports.  Best effort: every field is None when sysfs is not
+    readable (other driver, container without /sys)."""
+
+    def __init__(self, device_index=0, period_s=0.02):
+        import glob
+        self.dir, self.period, self.pw, self.ck, self._t, self._stop = None, period_s, [], [], None, False
+        try:
+            import ctypes
+            buf = ctypes.create_string_buffer(64)
+            if ctypes.CDLL("libamdhip64.so").hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+                raise OSError("hipDeviceGetPCIBusId")
+            bdf = buf.value.decode().lower()
+            hits = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if hits:
+                self.dir = hits[0]
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return int(f.read().strip())
+        except Exception:
+            return None
+
+    def _loop(self):
+        while not self._stop:
+            w = self._read("power1_input")
+            if w is None:
+                w = self._read("power1_average")
+            c = self._read("freq1_input")
+            if w is not None:
+                self.pw.append(w / 1e6)
+            if c is not None:
+                self.ck.append(c / 1e6)
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.dir:
+            import threading
+            self._t = threading.Thread(target=self._loop, daemon=True)
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._t:
+            self._t.join()
+
+    def summary(self):
+        cap = self._read("power1_cap") if self.dir else None
+        avg = lambda v: round(sum(v) / len(v), 1) if v else None
+        return {"socket_w_avg": avg(self.pw), "socket_w_max": round(max(self.pw), 1) if self.pw else None, "cap_w": cap / 1e6 if cap else None,
+                "sclk_mhz_avg": avg(self.ck), "sclk_mhz_min": round(min(self.ck), 1) if self.ck else None, "samples": len(self.pw),
+                "source": "amdgpu hwmon power1_input / freq1_input, 20-ms samples over the timed region" if self.dir else None}
+
+
 def dominant_kernel_roofline(den, device, reps=240):
     """Dominant kernel = grouped bf16 MFMA GEMM with SwishGLU epilogue (expert up-projection: 47 % of all FLOPs).  Launch it in
     isolation at the benchmark's exact shape (3584 gathered rows = 1792 tokens x top-2, K = 1024, 2 x 4096 weight rows per expert),
@@ -108,6 +168,10 @@ def dominant_kernel_roofline(den, device, reps=240):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
+    with PowerSampler(device.index or 0, period_s=0.005) as ps:   # the same graph replayed for ~0.3 s: power and clock of the kernel on its own
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize()
     flops = 2.0 * (N * k) * D * (8 * D)
     ach = flops / (us * 1e-6) / 1e12
     # HBM bytes per launch: NOT a literal - read from the machine-readable summary scripts/pmc_summary.py writes from the separate
@@ -124,7 +188,8 @@ def dominant_kernel_roofline(den, device, reps=240):
     return {"bound": "mfma", "kernel": "gemm_pp_kernel<SWIGLU, bf16, 224x256> (grouped expert up-projection + fused ln_2 scale + SwiGLU, M=3584 K=1024 N=2x4096)",
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
             # algorithmic bytes per launch (2 of 4 experts active under uniform sigma): A 3.7 MB + W1 33.6 MB + H 29.4 MB = 66.6 MB
-            "traffic": traffic, "traffic_source": src, "algorithmic_bytes": 66.6e6, "avg_launch_us": round(us, 2), "flops_per_launch": flops}
+            "traffic": traffic, "traffic_source": src, "algorithmic_bytes": 66.6e6, "avg_launch_us": round(us, 2), "flops_per_launch": flops,
+            "power": ps.summary()}
 
 
 def layer_kernel_breakdown(den, device, reps=120):
@@ -455,13 +520,14 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = chunk()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    with PowerSampler(device.index or 0) as psamp:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = chunk()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -502,6 +568,7 @@ def main():
         fl = flops_per_denoise_step(B_PER_GPU)
         res["e2e_tflops_per_gpu"] = round(fl * args.steps * N_SAMPLING_STEPS / elapsed / 1e12, 1)
         res["e2e_mfma_frac"] = round(res["e2e_tflops_per_gpu"] / MFMA_BF16_PEAK_TFLOPS, 4)
+        res["power"] = psamp.summary()                       # rank 0's socket over the timed region
         if args.dtype == "bf16":
             res["roofline"] = dominant_kernel_roofline(den, device)
             if n_gpus == 1 and not args.no_extras:
