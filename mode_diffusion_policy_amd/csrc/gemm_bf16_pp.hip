@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
   };
   // A half 1 of the 224-row tile has 96 rows = 12 pieces: waves 6 and 7 own pieces 12-15 and stage nothing (6 % fewer DMA bytes; the loop is
   // DMA-rate bound).  Their counted waits are unaffected: the A-half-1 stages (phases 1 / 5) are never among the newest six at a wait.
-  const bool stage_a1 = FM1 == 4 || (FM1 == 3 && wave < 6);   // (FM1 = 0: the 128-row tile has no A half 1 at all)
+  const bool stage_a1 = FM1 == 4 || wave < 6;
   auto stamp = [&](int slot) {                                  // profiling aid: per-wave cycle stamps ("pp_trace" option), 8 slots per wave
     if (trace && lane == 0) trace[((long)blockIdx.x * 8 + wave) * 8 + slot] = __builtin_readcyclecounter();
   };
@@ -655,9 +655,9 @@ static int pp_launch(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   return MODE_OK;
 }
 
-// Entered from gemm_bf16_launch with a validated descriptor and a filled parameter block; fm1 selects the tile height 128 + 32 * fm1 (4, 3 or 0).  Returns
+// Entered from gemm_bf16_launch with a validated descriptor and a filled parameter block; rows224 selects the 224-row tile.  Returns
 // MODE_ERR_UNSUPPORTED for shapes / epilogues this kernel does not take (the caller falls back to the 128x128 family).
-int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, int fm1, hipStream_t s) {
+int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, int rows224, hipStream_t s) {
   const int epi = d->epilogue;
   if (epi != MODE_EPI_NONE && epi != MODE_EPI_BIAS && epi != MODE_EPI_SWIGLU) return MODE_ERR_UNSUPPORTED;
   const int nout = epi == MODE_EPI_SWIGLU ? 128 : 256;
@@ -673,12 +673,11 @@ int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, int fm1, hi
   const bool ob = d->out_dtype == MODE_BF16;
 #define PP_CASE(E)                                                                                              \
   case E:                                                                                                       \
-    if (fm1 == 0) return ob ? pp_launch<E, true, 0, 1>(p0, d, s) : pp_launch<E, false, 0, 1>(p0, d, s);         \
     if (!(p0.pp_flags & 256)) {                                   /* 256 = the eight-phase loop (A/B) */                      \
-      if (fm1 == 3) return ob ? pp_launch<E, true, 3, 1>(p0, d, s) : pp_launch<E, false, 3, 1>(p0, d, s);       \
+      if (rows224) return ob ? pp_launch<E, true, 3, 1>(p0, d, s) : pp_launch<E, false, 3, 1>(p0, d, s);        \
       return ob ? pp_launch<E, true, 4, 1>(p0, d, s) : pp_launch<E, false, 4, 1>(p0, d, s);                     \
     }                                                                                                           \
-    if (fm1 == 3) return ob ? pp_launch<E, true, 3, 0>(p0, d, s) : pp_launch<E, false, 3, 0>(p0, d, s);        \
+    if (rows224) return ob ? pp_launch<E, true, 3, 0>(p0, d, s) : pp_launch<E, false, 3, 0>(p0, d, s);         \
     return ob ? pp_launch<E, true, 4, 0>(p0, d, s) : pp_launch<E, false, 4, 0>(p0, d, s);
   switch (epi) {
     PP_CASE(MODE_EPI_NONE)

@@ -75,7 +75,7 @@ def main():
     for name, pairs in routings.items():
         meta, ml = meta_for(pairs)
         ref1 = torch.zeros(NK, 4 * D, dtype=bf, device=dev); run(1, gemm1_desc(meta, ml, 0, ref1))
-        for cfg in ("16", "17", "18", "16f256", "17f256"):
+        for cfg in ("16", "17", "16f256", "17f256"):
             bad = 0
             for it in range(a.screen):
                 out = torch.full((NK, 4 * D), float("nan"), dtype=bf, device=dev)
@@ -91,7 +91,7 @@ def main():
             ok &= bad == 0
         for S in (2, 4):
             ref2 = torch.zeros(S, NK, D, dtype=bf, device=dev); run(1, gemm2_desc(meta, ml, 0, ref2, S))
-            for cfg in ("16", "17", "18", "16f256", "17f256"):
+            for cfg in ("16", "17", "16f256", "17f256"):
                 bad = 0
                 for it in range(a.screen):
                     out = torch.full((S, NK, D), float("nan"), dtype=bf, device=dev)
