@@ -42,7 +42,10 @@ __global__ __launch_bounds__(256, 1) void kloop(const __bf16* __restrict__ A, co
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int n_tiles = N / BN;
-  const int tm = blockIdx.x / n_tiles, tn = blockIdx.x % n_tiles;
+  // reps < 0: every workgroup works on tile (0, 0) - all operand traffic hits in L2 (separates the miss path from the L2 -> LDS path)
+  const bool same = reps < 0;
+  if (same) reps = -reps;
+  const int tm = same ? 0 : blockIdx.x / n_tiles, tn = same ? 0 : blockIdx.x % n_tiles;
   const int fr = lane & 15, fq = lane >> 4;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t a_rd = lds0 + (wr * 112 + fr) * 64 + ((fq ^ swz(fr >> 2)) * 16);
@@ -249,6 +252,21 @@ int main() {
   hipMemcpy(W, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
   hipLaunchKernelGGL(naive, dim3(N / 64, M / 4), dim3(256), 0, 0, A, W, Cref, M, N, K);
   hipDeviceSynchronize();
+  if (getenv("W4_SAMETILE")) {                                   // L2-resident operands: what does the L2 -> LDS DMA path deliver per CU?
+    auto kern = kloop<5, 2>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * SLOT);
+    const int grid = (M / BM) * (N / BN);
+    std::vector<long long> hc(grid);
+    for (int mode = 0; mode < 2; ++mode) {
+      for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 5 * SLOT, 0, A, W, C, M, N, K, mode ? -8 : 8, cyc);
+      hipDeviceSynchronize();
+      hipMemcpy(hc.data(), cyc, grid * 8, hipMemcpyDeviceToHost);
+      long long sum = 0; for (auto v : hc) sum += v;
+      printf("%s: %.0f cycles per K-step = %.1f B/clk/CU of LDS-DMA\n", mode ? "every workgroup on tile (0,0) [L2 hits]" : "256 distinct tiles", (double)sum / grid / 128,
+             (BM + BN) * 128.0 / ((double)sum / grid / 128));
+    }
+    return 0;
+  }
   if (getenv("W4_SUSTAIN")) {                                    // shader clock under sustained load: back-to-back launches for ~2 s
     auto kern = kloop<5, 2>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * SLOT);
