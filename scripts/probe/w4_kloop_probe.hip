@@ -257,13 +257,22 @@ int main() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * SLOT);
     const int grid = (M / BM) * (N / BN);
     std::vector<long long> hc(grid);
-    for (int mode = 0; mode < 2; ++mode) {
-      for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 5 * SLOT, 0, A, W, C, M, N, K, mode ? -8 : 8, cyc);
-      hipDeviceSynchronize();
+    std::vector<long long> hr(grid);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 2; ++mode) {                         // ~1.5 s of back-to-back launches per mode: the clock the socket sustains with / without L2 misses
+      float ms = 0;
+      for (int blk = 0; blk < 8; ++blk) {
+        hipEventRecord(e0);
+        for (int it = 0; it < 1000; ++it) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 5 * SLOT, 0, A, W, C, M, N, K, mode ? -8 : 8, cyc);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+      }
       hipMemcpy(hc.data(), cyc, grid * 8, hipMemcpyDeviceToHost);
-      long long sum = 0; for (auto v : hc) sum += v;
-      printf("%s: %.0f cycles per K-step = %.1f B/clk/CU of LDS-DMA\n", mode ? "every workgroup on tile (0,0) [L2 hits]" : "256 distinct tiles", (double)sum / grid / 128,
-             (BM + BN) * 128.0 / ((double)sum / grid / 128));
+      hipMemcpy(hr.data(), cyc + 2048, grid * 8, hipMemcpyDeviceToHost);
+      long long sum = 0, rsum = 0; for (auto v : hc) sum += v; for (auto v : hr) rsum += v;
+      printf("%s: %.0f cycles per K-step = %.1f B/clk/CU of LDS-DMA; sustained: shader clock %.2f GHz, %.0f TF/s\n",
+             mode ? "every workgroup on tile (0,0) [L2 hits]" : "256 distinct tiles", (double)sum / grid / 128, (BM + BN) * 128.0 / ((double)sum / grid / 128),
+             (double)sum / rsum / 10.0, 2.0 * M * N * K * 8 * 1000 / (ms * 1e-3) / 1e12);
     }
     return 0;
   }
