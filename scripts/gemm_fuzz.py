@@ -1,0 +1,134 @@
+"""Randomised robustness screen of mode_gemm under the AUTO dispatch (streamer / register-resident / ring / ping-pong regimes and their
+boundaries): random M, N, K, epilogue, output dtype, grouped (incl. empty experts) and gathered operands, split-K - each case against an fp32
+torch reference of the same bf16 operands, with canary rows around the output (out-of-bounds writes) and a NaN pre-fill (unwritten elements).
+Usage (GPU box): python scripts/gemm_fuzz.py [--cases 400] [--seed 0]"""
+import argparse
+import ctypes as C
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mode_diffusion_policy_amd import _lib as L  # noqa: E402
+
+
+def run(cases=400, seed=0, verbose=True):
+    """Returns (failed, unsupported)."""
+    a = argparse.Namespace(cases=cases, seed=seed)
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    rng = random.Random(a.seed)
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    p = lambda t: t.data_ptr() if t is not None else None
+    bf = torch.bfloat16
+    bad = unsupported = 0
+    Ms = [1, 2, 13, 14, 16, 17, 28, 31, 32, 33, 56, 100, 127, 128, 129, 200, 224, 225, 256, 300, 448, 449, 896, 1000, 1792, 2000, 3584, 3600]
+    for case in range(a.cases):
+        kind = rng.choice(["plain", "plain", "grouped", "grouped_gather", "splitk", "uniform"])
+        epi = rng.choice([L.EPI_NONE, L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_RESIDUAL, L.EPI_SWIGLU])
+        K = rng.choice([64, 128, 192, 256, 512, 1024, 2048, 4096])
+        N = rng.choice([4, 16, 20, 64, 96, 128, 192, 256, 384, 512, 1024, 2048, 3072, 4096])
+        M = rng.choice(Ms)
+        ob = rng.random() < 0.6
+        if epi == L.EPI_RESIDUAL:
+            ob = False
+        E = rng.choice([1, 2, 4, 8]) if kind.startswith("grouped") else (rng.choice([2, 4]) if kind == "uniform" else 0)
+        flags = 0
+        S = rng.choice([2, 4]) if kind == "splitk" else 1
+        if kind == "splitk":
+            epi = L.EPI_NONE; K = rng.choice([512, 1024, 2048, 4096])
+        if M * N * K > 3584 * 4096 * 4096 // 4:
+            K = 256
+        g = torch.Generator(device="cpu").manual_seed(case * 7919 + a.seed)
+        if kind == "uniform":                                      # the sampler's case: equal groups, rows of group e = tokens 0..M/E-1 (identity gather), hints set
+            M = max(E, M // E * E)
+            epi = rng.choice([L.EPI_SWIGLU, L.EPI_NONE, L.EPI_BIAS])
+        rows_src = M if kind != "grouped_gather" else rng.choice([max(1, M // 2), M])
+        if kind == "uniform":
+            rows_src = M // E
+        A = (torch.randn(rows_src, K, generator=g)).to(bf).to(dev)
+        nw = 2 * N if epi == L.EPI_SWIGLU else N
+        Wt = (torch.randn(max(E, 1), nw, K, generator=g) * K ** -0.5).to(bf).to(dev)
+        bias = torch.randn(max(E, 1), nw, generator=g).to(dev) if epi in (L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_SWIGLU) else None
+        resid = torch.randn(M, N, generator=g).to(dev) if epi == L.EPI_RESIDUAL else None
+        offsets = a_rows = None
+        counts = None
+        if E and kind != "uniform":
+            cuts = sorted(rng.randint(0, M) for _ in range(E - 1))
+            if rng.random() < 0.3 and E > 1:
+                cuts[0] = 0                                        # an empty first expert
+            bounds = [0] + cuts + [M]
+            counts = [bounds[i + 1] - bounds[i] for i in range(E)]
+            offsets = torch.tensor(bounds, dtype=torch.int32, device=dev)
+        if kind == "grouped_gather":
+            a_rows = torch.randint(0, rows_src, (M,), generator=g).to(torch.int32).to(dev)
+        if kind == "uniform":
+            counts = [M // E] * E
+            offsets = torch.arange(0, M + 1, M // E, dtype=torch.int32, device=dev)
+            a_rows = torch.arange(M // E, dtype=torch.int32, device=dev).repeat(E)
+            flags = L.GEMM_UNIFORM_GROUPS | (L.GEMM_IDENTITY_ROWS if rng.random() < 0.7 else 0)
+        PAD = 3
+        od = bf if ob else torch.float32
+        buf = torch.full((S, M + 2 * PAD, N), float("nan"), dtype=od, device=dev)
+        buf[:, :PAD] = 777.0; buf[:, M + PAD:] = 777.0
+        Cv = buf[:, PAD: PAD + M]
+        d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=epi, out_dtype=L.MODE_BF16 if ob else L.MODE_F32, M=M, N=N, K=K, A=p(A), lda=K, W=p(Wt), ldw=K,
+                           w_expert_stride=nw * K, bias=p(bias), bias_expert_stride=nw, resid=p(resid), ldr=N, C=Cv.data_ptr(), ldc=N,
+                           a_rows=p(a_rows), expert_offsets=p(offsets), num_experts=E, split_k=S, split_stride=(M + 2 * PAD) * N, flags=flags)
+        rc = lib.mode_gemm(C.byref(d), st())
+        torch.cuda.synchronize()
+        desc = f"case {case}: {kind} M={M} N={N} K={K} epi={epi} out={'bf16' if ob else 'f32'} E={E} counts={counts} S={S}"
+        if rc == -2:                                               # MODE_ERR_UNSUPPORTED: a documented refusal, not a failure
+            unsupported += 1
+            continue
+        if rc != 0:
+            print("ERROR rc", rc, desc); bad += 1
+            continue
+        # reference
+        Ag = A.float()[a_rows.long()] if a_rows is not None else A.float()[:M]
+        ref = torch.empty(S, M, N, device=dev)
+        Ks = K // S
+        for s_ in range(S):
+            Asl = Ag[:, s_ * Ks: (s_ + 1) * Ks]
+            if E:
+                h = torch.empty(M, nw, device=dev)
+                o = 0
+                for e in range(E):
+                    n = counts[e]
+                    h[o: o + n] = Asl[o: o + n] @ Wt[e].float()[:, s_ * Ks: (s_ + 1) * Ks].t() + (bias[e] if bias is not None else 0)
+                    o += n
+            else:
+                h = Asl @ Wt[0].float()[:, s_ * Ks: (s_ + 1) * Ks].t() + (bias[0] if bias is not None else 0)
+            if epi == L.EPI_BIAS_GELU:
+                h = torch.nn.functional.gelu(h)
+            elif epi == L.EPI_SWIGLU:
+                h = h[:, :N] * torch.nn.functional.silu(h[:, N:])
+            elif epi == L.EPI_RESIDUAL:
+                h = h + resid
+            ref[s_] = h
+        out = Cv.float()
+        ok_can = bool((buf[:, :PAD] == 777.0).all() and (buf[:, M + PAD:] == 777.0).all())
+        nan = int(out.isnan().sum())
+        err = float((out - ref).norm() / ref.norm().clamp_min(1e-20)) if nan == 0 else float("nan")
+        tol = 8e-3 if ob else 3e-3
+        if not ok_can or nan or not err < tol:
+            bad += 1
+            print(f"FAIL canary_ok={ok_can} nan={nan} rel={err:.3g}  {desc}")
+    if verbose:
+        print(f"{a.cases} cases: {bad} failed, {unsupported} reported unsupported")
+    return bad, unsupported
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=400)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    return 1 if run(a.cases, a.seed)[0] else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
