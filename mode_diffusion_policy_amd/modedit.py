@@ -209,7 +209,19 @@ class MoDeDiT(nn.Module):
             goals = goals * (1.0 - mask)
         if uncond:
             goals = torch.zeros_like(goals)
+        # the reference's goal_emb (nn.Linear(goal_dim, D), modedit.py:690) raises a shape error on anything else; the HIP GEMM would read
+        # goal_dim floats per row regardless - refuse here.  (goal_dim == 2 * obs_dim trips the slice above in the reference as well.)
+        if goals.shape[-1] != self.goal_dim or goals.shape[1] != self.goal_seq_len:
+            raise ValueError(f"goals must be (B, {self.goal_seq_len}, {self.goal_dim}) after preprocess_goals, got {tuple(goals.shape)}")
         return goals
+
+    def _check_batch(self, B, img, goals, actions) -> None:
+        """Shape contract of one call: the chain reads B x (n_img x obs_dim | goal_dim | A_len x A_dim) floats from raw pointers - a tensor of
+        any other shape must be refused here (the reference fails in its nn.Linear / torch.cat shape checks instead)."""
+        if img.shape[0] != B or goals.shape[0] != B:
+            raise ValueError(f"batch mismatch: actions have {B} samples, state_images {img.shape[0]}, goals {goals.shape[0]}")
+        if actions.dim() != 3 or actions.shape[1] != self.action_seq_len or actions.shape[2] != self.action_dim:
+            raise ValueError(f"actions must be (B, {self.action_seq_len}, {self.action_dim}), got {tuple(actions.shape)}")
 
     def forward(self, states, actions, goals, sigma, uncond: Optional[bool] = False):
         """states: {'state_images': (B, 2, obs_dim)}; actions (B, A_len, A_dim); goals (B,1,G)|(B,G); sigma (B,)|() -> (B, A_len, A_dim)."""
@@ -228,6 +240,7 @@ class MoDeDiT(nn.Module):
             raise ValueError(f"state_images must be (B, {self.n_img_tokens}, {self.obs_dim}), got {tuple(img.shape)}")
         goals = f(self.preprocess_goals(goals, 1, uncond=bool(uncond)))
         acts = f(actions)
+        self._check_batch(B, img, goals, acts)
         sig = f(sigma).reshape(-1)
         if sig.numel() not in (1, B):
             raise ValueError("sigma must be a scalar or have one entry per sample")
@@ -277,6 +290,7 @@ class MoDeDiT(nn.Module):
             return action.detach().to(device=dev, dtype=torch.float32).clone()
         img, goals = self._prep_obs(eng, states, goals)
         x = action.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self._check_batch(B, img, goals, x)
         sig = sigma.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
         if sig.numel() not in (1, B):
             raise ValueError("sigma must be a scalar or have one entry per sample")
@@ -377,6 +391,7 @@ class MoDeDiT(nn.Module):
         img, goals = self._prep_obs(eng, states, goals)
         sig = sigmas.detach().to(device=dev, dtype=torch.float32).contiguous()
         x0 = action.detach().to(device=dev, dtype=torch.float32)
+        self._check_batch(B, img, goals, x0)
         n = sig.numel() - 1
         if self.use_goal_in_routing or not self.cond_router:             # routing depends on the sample / the tokens: per-step generic path
             x = x0.clone()

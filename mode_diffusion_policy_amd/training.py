@@ -182,6 +182,7 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         raise ValueError(f"state_images must be (B, {model.n_img_tokens}, {model.obs_dim}), got {tuple(img.shape)}")
     gl = f(model.preprocess_goals(goals, 1, uncond=bool(uncond))).reshape(B, -1).contiguous()      # incl. the Bernoulli goal mask
     acts = f(actions)
+    model._check_batch(B, img, gl, acts)
     sig = f(sigma).reshape(-1)
     if sig.numel() == 1:
         sig = sig.expand(B).contiguous()

@@ -301,3 +301,26 @@ def test_binding_constants_match_header():
     for name in ("SKINNY_OK", "W_KN", "A_KM"):
         assert vals[f"MODE_GEMM_{name}"] == getattr(L, f"GEMM_{name}"), name
     assert vals["MODE_HIP_ABI_VERSION"] == L.ABI_VERSION
+
+
+def test_input_shape_contract_is_checked_before_any_launch():
+    """The chain reads raw pointers: a goal of the wrong width (incl. the reference's `goal_dim == 2 * obs_dim` slice, modedit.py:862-880, which makes
+    its own goal_emb raise), a batch mismatch or a mis-shaped action chunk must raise, not read out of bounds.  (CPU: the checks run before the
+    engine is touched.)"""
+    import torch
+    import mode_diffusion_policy_amd as M
+    m = M.MoDeDiT(obs_dim=32, goal_dim=64, device="cpu", goal_conditioned=True, action_dim=2, embed_dim=64, embed_pdrob=0, attn_pdrop=0.0,
+                  n_layers=1, n_heads=2, goal_seq_len=1, obs_seq_len=1, action_seq_len=4, state_dim=None, num_experts=2, top_k=1)
+    with pytest.raises(ValueError, match="goals must be"):
+        m.preprocess_goals(torch.zeros(3, 1, 64), 1)                 # 64 == 2 * obs_dim: sliced to 32 like the reference, then refused
+    m2 = M.MoDeDiT(obs_dim=32, goal_dim=16, device="cpu", goal_conditioned=True, action_dim=2, embed_dim=64, embed_pdrob=0, attn_pdrop=0.0,
+                   n_layers=1, n_heads=2, goal_seq_len=1, obs_seq_len=1, action_seq_len=4, state_dim=None, num_experts=2, top_k=1)
+    g = m2.preprocess_goals(torch.zeros(3, 16), 1)
+    assert g.shape == (3, 1, 16)
+    with pytest.raises(ValueError, match="goals must be"):
+        m2.preprocess_goals(torch.zeros(3, 1, 20), 1)
+    with pytest.raises(ValueError, match="batch mismatch"):
+        m2._check_batch(3, torch.zeros(2, 2, 32), g, torch.zeros(3, 4, 2))
+    with pytest.raises(ValueError, match="actions must be"):
+        m2._check_batch(3, torch.zeros(3, 2, 32), g, torch.zeros(3, 5, 2))
+    m2._check_batch(3, torch.zeros(3, 2, 32), g, torch.zeros(3, 4, 2))
