@@ -74,3 +74,41 @@ def test_random_geometry_vs_oracle(case, dtype):
     sched = M.get_sigmas_exponential(4, 1e-3, 80.0)
     x = M.sample_ddim(den, {"state_images": c["state_images"]}, c["x0"], c["goals"], sched.cuda(), disable=True)
     assert rel(x, O.sample_ddim(sd, cfg, 0.5, inp["state_images"], inp["x0"], inp["goals"], sched)) < tol, what
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MODE_FUZZ_TRAIN_CASES", "8"))))
+def test_random_geometry_training_vs_oracle_autograd(case):
+    """The same random geometries through the TRAINING chain (forward with stash, HIP backward, EDM loss kernels), fp32 mode: loss and every
+    parameter gradient against the oracle's autograd; un-routed experts' gradients exactly zero.  use_argmax=True (deterministic routing)."""
+    cfg, B, _ = draw(200 + case)
+    B = min(B, 64)
+    seed = 900 + case
+    sd = make_state_dict(cfg, seed)
+    m = M.MoDeDiT(obs_dim=cfg.obs_dim, goal_dim=cfg.goal_dim, device="cuda", goal_conditioned=True, action_dim=cfg.action_dim,
+                  embed_dim=cfg.embed_dim, embed_pdrob=0, attn_pdrop=0.0, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=1,
+                  obs_seq_len=1, action_seq_len=cfg.action_seq_len, state_dim=None, mlp_pdrop=0.0, goal_drop=0.0, num_experts=cfg.num_experts,
+                  top_k=cfg.top_k, use_argmax=True, compute_dtype="fp32", router_normalize=cfg.router_normalize,
+                  use_goal_in_routing=cfg.use_goal_in_routing, use_noise_token_as_input=cfg.use_noise_token_as_input)
+    m.load_state_dict(sd)
+    m = m.to("cuda").train()
+    inp = make_inputs(cfg, B, seed + 1)
+    sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(case))
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_loss, _ = O.denoiser_loss(sdg, cfg, 0.5, inp["state_images"], inp["actions"], inp["goals"], inp["noise"], sig)
+    ref_loss.backward()
+    c = {k: v.cuda() for k, v in inp.items()}
+    den = M.GCDenoiser(m, 0.5).train()
+    loss, _ = den.loss({"state_images": c["state_images"]}, c["actions"], c["goals"], c["noise"], sig.cuda())
+    loss.backward()
+    what = f"{dataclasses.asdict(cfg)} B={B}"
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss)), what
+    checked = 0
+    gmax = max(float(v.grad.norm()) for v in sdg.values() if v.grad is not None)
+    for n, p in m.named_parameters():
+        r = sdg[n].grad
+        if r is None or float(r.norm()) < 1e-6 * gmax:                # un-routed expert, dead parameter, or a saturated router (|grad| ~ 1e-10: below fp32 resolution of the chain)
+            assert p.grad is None or float(p.grad.norm()) < 1e-5 * gmax, (n, what)
+            continue
+        assert rel(p.grad, r) < 2e-3, (n, rel(p.grad, r), what)
+        checked += 1
+    assert checked >= 15, what
