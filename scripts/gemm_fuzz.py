@@ -49,9 +49,15 @@ def run(cases=400, seed=0, verbose=True):
         rows_src = M if kind != "grouped_gather" else rng.choice([max(1, M // 2), M])
         if kind == "uniform":
             rows_src = M // E
-        A = (torch.randn(rows_src, K, generator=g)).to(bf).to(dev)
+        # operands as sub-views of padded buffers: leading dimensions larger than K, base pointers at element offsets that keep the documented
+        # alignment (rows 16-byte aligned: lda / ldw multiples of 8 elements)
+        lda = K + 8 * rng.choice([0, 0, 1, 5]); ldw = K + 8 * rng.choice([0, 0, 2])
+        a_sk, w_sk = 8 * rng.choice([0, 0, 1, 3]), 8 * rng.choice([0, 0, 2])
+        Abuf = torch.randn(rows_src * lda + a_sk, generator=g).to(bf).to(dev)
+        A = Abuf[a_sk:].view(rows_src, lda)[:, :K]
         nw = 2 * N if epi == L.EPI_SWIGLU else N
-        Wt = (torch.randn(max(E, 1), nw, K, generator=g) * K ** -0.5).to(bf).to(dev)
+        Wbuf = (torch.randn(max(E, 1) * nw * ldw + w_sk, generator=g) * K ** -0.5).to(bf).to(dev)
+        Wt = Wbuf[w_sk:].view(max(E, 1), nw, ldw)[:, :, :K]
         bias = torch.randn(max(E, 1), nw, generator=g).to(dev) if epi in (L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_SWIGLU) else None
         resid = torch.randn(M, N, generator=g).to(dev) if epi == L.EPI_RESIDUAL else None
         offsets = a_rows = None
@@ -75,8 +81,8 @@ def run(cases=400, seed=0, verbose=True):
         buf = torch.full((S, M + 2 * PAD, N), float("nan"), dtype=od, device=dev)
         buf[:, :PAD] = 777.0; buf[:, M + PAD:] = 777.0
         Cv = buf[:, PAD: PAD + M]
-        d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=epi, out_dtype=L.MODE_BF16 if ob else L.MODE_F32, M=M, N=N, K=K, A=p(A), lda=K, W=p(Wt), ldw=K,
-                           w_expert_stride=nw * K, bias=p(bias), bias_expert_stride=nw, resid=p(resid), ldr=N, C=Cv.data_ptr(), ldc=N,
+        d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=epi, out_dtype=L.MODE_BF16 if ob else L.MODE_F32, M=M, N=N, K=K, A=p(A), lda=lda, W=p(Wt), ldw=ldw,
+                           w_expert_stride=nw * ldw, bias=p(bias), bias_expert_stride=nw, resid=p(resid), ldr=N, C=Cv.data_ptr(), ldc=N,
                            a_rows=p(a_rows), expert_offsets=p(offsets), num_experts=E, split_k=S, split_stride=(M + 2 * PAD) * N, flags=flags)
         rc = lib.mode_gemm(C.byref(d), st())
         torch.cuda.synchronize()
