@@ -50,12 +50,12 @@ class AdvancedLangEmbeddingBuffer:
             value = value.detach()
             if self._table is None:
                 self._table = torch.zeros((max(self.goal_instruction_buffer_size, 1),) + tuple(value.shape), dtype=value.dtype, device=value.device)
+            if len(self._slot) >= self.goal_instruction_buffer_size and self._slot:
+                _, row = self._slot.popitem(last=False)              # FIFO: the oldest insertion goes - also when `key` is already cached
+                self._free.append(row)                               # (lang_buffer.py:41-44 pops before it assigns; a duplicate inside one request at capacity evicts twice)
             if key in self._slot:                                    # re-insert of a live key: the value is replaced, its age is not
                 self._table[self._slot[key]].copy_(value)
                 return
-            if len(self._slot) >= self.goal_instruction_buffer_size and self._slot:
-                _, row = self._slot.popitem(last=False)              # FIFO: the oldest insertion goes
-                self._free.append(row)
             row = self._free.pop() if self._free else len(self._slot)
             self._table[row].copy_(value)
             self._slot[key] = row
