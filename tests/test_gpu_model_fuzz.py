@@ -4,9 +4,10 @@ indices bit-exact; outputs within the tolerances of test_gpu_model.py (fp32 1e-3
 chunk through the fused sampler per case.
 
 The stated bf16 tolerance (1e-2 rel-L2) was grounded on the reference's own fp32-vs-autocast gap at the C1 / C2 geometries (SURVEY.md section 8
-a-bis: widths 256 / 1024, hundreds of output values).  Narrow models (D < 256: fewer products per dot, less averaging) and outputs of a handful
-of numbers (B = 1, one action of 2 dims) fluctuate around it - the 150-case sweep's four outliers were 1.01e-2 ... 1.12e-2 - so those cases
-are held to 2e-2."""
+a-bis) and stays asserted there (test_gpu_model.py).  Across random geometries bf16 is noisier for narrow models, few-valued outputs and
+un-normalised top-1 routing: in the 400-case sweep five cases reached 1.01e-2 ... 1.12e-2 - and at exactly those five the REFERENCE's own
+fp32-vs-bf16-autocast gap is 0.6e-2 ... 1.7e-2 (oracle/measure_bf16_fwd_gap_geometries.py -> tests/golden/bf16_fwd_gap_geometries.json),
+i.e. the HIP path sits inside the reference's bf16 noise.  bf16 is therefore held to 2e-2 in this file."""
 import dataclasses
 import os
 import random
@@ -68,7 +69,7 @@ def test_random_geometry_vs_oracle(case, dtype):
         out = m({"state_images": c["state_images"]}, c["actions"], c["goals"], sig.cuda())
     what = f"{dataclasses.asdict(cfg)} B={B}"
     assert torch.equal(m._last_topk.cpu().long(), torch.stack(aux.topk_idx)[:, :, 0, :]), what
-    tol = TOL[dtype] if dtype == "fp32" or (cfg.embed_dim >= 256 and ref.numel() >= 64) else 2e-2
+    tol = TOL[dtype] if dtype == "fp32" else 2e-2
     assert rel(out, ref) < tol, what
     den = M.GCDenoiser(m, 0.5).eval()
     sched = M.get_sigmas_exponential(4, 1e-3, 80.0)
