@@ -119,6 +119,34 @@ class PowerSampler:
                 "source": "amdgpu hwmon power1_input / freq1_input, 20-ms samples over the timed region" if self.dir else None}
 
 
+def sustained_mfma_peak(device, seconds=1.2):
+    """What the socket sustains in bf16 MFMA at its power cap: register-resident v_mfma_f32_16x16x32_bf16 on every SIMD (mode_probe_mfma_burn,
+    csrc/probe.hip), back-to-back launches for `seconds`, rate of the last block.  The datasheet peak (2.5 PF/s at 2.4 GHz) is what every `frac`
+    of this file is quoted against; this number says how much of it the box delivers under load."""
+    import ctypes as C
+    from mode_diffusion_policy_amd import _lib as L
+    lib = L.load()
+    seed = torch.tensor([12345], dtype=torch.int32, device=device)
+    ncu = torch.cuda.get_device_properties(device).multi_processor_count
+    fl = C.c_double(0.0)
+    st = torch.cuda.current_stream().cuda_stream
+    iters = 4000                                              # ~0.55 ms per launch
+    L.check(lib.mode_probe_mfma_burn(seed.data_ptr(), None, ncu, iters, C.byref(fl), st))
+    torch.cuda.synchronize()
+    t_end = time.perf_counter() + seconds
+    rate = 0.0
+    with PowerSampler(device.index or 0, period_s=0.01) as ps:
+        while time.perf_counter() < t_end:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(100):
+                lib.mode_probe_mfma_burn(seed.data_ptr(), None, ncu, iters, None, st)
+            e1.record(); torch.cuda.synchronize()
+            rate = fl.value * 100 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    return {"tflops": round(rate, 1), "frac_of_datasheet_peak": round(rate / MFMA_BF16_PEAK_TFLOPS, 4), "power": ps.summary(),
+            "what": "register-resident v_mfma_f32_16x16x32_bf16 on all SIMDs, sustained (last 100-launch block of a 1.2-s burst)"}
+
+
 def dominant_kernel_roofline(den, device, reps=240):
     """Dominant kernel = grouped bf16 MFMA GEMM with SwishGLU epilogue (expert up-projection: 47 % of all FLOPs).  Launch it in
     isolation at the benchmark's exact shape (3584 gathered rows = 1792 tokens x top-2, K = 1024, 2 x 4096 weight rows per expert),
@@ -571,6 +599,10 @@ def main():
         res["power"] = psamp.summary()                       # rank 0's socket over the timed region
         if args.dtype == "bf16":
             res["roofline"] = dominant_kernel_roofline(den, device)
+            if n_gpus == 1 and not args.no_extras:
+                sp = sustained_mfma_peak(device)
+                res["roofline"]["sustained_mfma_peak"] = sp           # context for `frac`: `peak` stays the datasheet figure
+                res["roofline"]["frac_of_sustained_peak"] = round(res["roofline"]["achieved"] / sp["tflops"], 4) if sp["tflops"] else None
             if n_gpus == 1 and not args.no_extras:
                 res["layer_kernels"] = layer_kernel_breakdown(den, device)
                 res.update(extra_measurements(M, den, device))

@@ -75,6 +75,12 @@ const char* mode_hip_status_string(int status);
  * Unknown keys return MODE_ERR_BAD_ARG. */
 int mode_set_option(const char* key, int value);
 
+/* Measurement aid (not on the denoising path; nothing in the reference corresponds to it): one launch of `workgroups` x 8 waves issuing
+ * `iters` x 16 register-resident v_mfma_f32_16x16x32_bf16 each, operands derived from *seed (device).  bench.py times a burst of these to
+ * report the bf16 MFMA rate the socket SUSTAINS at its power cap beside the datasheet peak.  *flop_per_launch (host, optional) receives the
+ * FLOP count of the launch; out (device, optional) workgroups * 512 floats. */
+int mode_probe_mfma_burn(const uint32_t* seed, float* out, int workgroups, int iters, double* flop_per_launch, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * mode_gemm — C[M,N] = epilogue(A[M,K] @ W[N,K]^T), optionally grouped (MoE) and row-gathered.
  * Replaces every nn.Linear on the path (modedit.py:108-111 q/k/v/c_proj, :194-202 router, :86/:255 expert MLPs,

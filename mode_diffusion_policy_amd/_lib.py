@@ -121,6 +121,7 @@ PROTOTYPES = {
     "mode_hip_version": (C.c_int, []),
     "mode_hip_status_string": (C.c_char_p, [C.c_int]),
     "mode_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "mode_probe_mfma_burn": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, P(C.c_double), c_vp]),
     "mode_hip_sizeof": (c_sz, [C.c_char_p]),
     "mode_gemm": (C.c_int, [P(ModeGemmDesc), c_vp]),
     "mode_rmsnorm_cond_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_f32, c_vp, c_vp, C.c_int, c_vp]),

@@ -484,3 +484,17 @@ def test_skinny_grouped_gather_and_split_k(N_tok, E, k, D):
     for split in (1, 2):
         s, t = _both_paths(lambda: down(split))
         assert rel(s, want) < 6e-3 and rel(s, t) < 6e-3, split
+
+
+def test_probe_mfma_burn_runs_and_reports_flops():
+    """The measurement entry point bench.py uses for the sustained MFMA rate (csrc/probe.hip): launches, writes finite sums, reports its FLOPs."""
+    import ctypes as C
+    lib = L.load()
+    seed = torch.tensor([7], dtype=torch.int32, device=dev())
+    out = torch.full((4 * 512,), float("nan"), device=dev())
+    fl = C.c_double(0.0)
+    L.check(lib.mode_probe_mfma_burn(seed.data_ptr(), out.data_ptr(), 4, 130, C.byref(fl), H.stream()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and float(out.abs().max()) > 0
+    assert fl.value == 4 * 8 * 130 * 16 * 2.0 * 16 * 16 * 32
+    assert lib.mode_probe_mfma_burn(None, None, 4, 10, None, H.stream()) == -1          # MODE_ERR_BAD_ARG
