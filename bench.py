@@ -7,7 +7,8 @@ inputs, random-init weights (no datasets or checkpoints are reachable).
 A bench "step" = ONE 10-step DDIM chunk over one batch of B=128 action chunks (sample_ddim o GCDenoiser o MoDeDiT, i.e. 10
 denoiser forwards + 10 fused EDM/DDIM updates, replayed as one hipGraph).  value = n_gpus * steps * 10 / wall  [denoise-steps/s].
 Multi-GPU (inference): replicas only — each rank denoises its own B=128 batch, no data-path collective (DESIGN.md §multi-GPU);
-the data-parallel *training* exchange is benchmarked with --mode train once the backward kernels land.
+the data-parallel *training* step (configs[2]/[3]: fwd + bwd + gradient exchange + fused AdamW) runs in the SAME invocation on every
+rank and reports train_* / dp_mode / rccl_ranks next to the headline (also stand-alone: --mode train).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -352,9 +353,92 @@ def cpu_baseline():
             "c1_b8": legs["c1"], "c2_b128": c2}
 
 
+def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU):
+    """BASELINE configs[2]/[3]: the score-matching training step of `den` (fwd + bwd + fused AdamW) on B samples per rank, data parallel over
+    `world` ranks - ONE implementation shared by `--mode train`, by the default run's extra legs (N = 1) and by the N > 1 default run, so that a
+    SCALE record evidences the gradient exchange.  All ranks must call it together.  Every rank owns its own shard of the synthetic batch; the
+    gradient arena is exchanged in flat per-block slices behind the backward's block events (RCCL when `dist` is up), ZeRO-1 by default for
+    world > 1 (MODE_DP_ZERO1 = bf16 | fp32 | 0, MODE_DP_COMM = fp32 | bf16).  Timed like the contract says: barrier + synchronize on both sides,
+    MAX over ranks.  Returns the keys merged into the JSON line."""
+    import math
+    from mode_diffusion_policy_amd.ddp import ArenaGradReducer
+    from mode_diffusion_policy_amd.optim import FusedAdamW
+    from mode_diffusion_policy_amd.utils import rand_log_logistic
+    m = den.inner_model
+    was_training = den.training
+    den.train()
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)                 # every rank gets its own shard of the synthetic batch
+    A_len, A = m.action_seq_len, m.action_dim
+    img = torch.randn(B, m.n_img_tokens, m.obs_dim, generator=g).to(device); goal = torch.randn(B, 1, m.goal_dim, generator=g).to(device)
+    acts = torch.randn(B, A_len, A, generator=g).to(device); noise = torch.randn(B, A_len, A, generator=g).to(device)
+    opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)         # mode_agent.yaml:24-29, two groups as mode_agent.py:365-384
+    if os.environ.get("MODE_ADAMW_BLOCKS"):
+        m.engine.lib.mode_set_option(b"adamw_blocks", int(os.environ["MODE_ADAMW_BLOCKS"]))
+    # gradient exchange dtype: fp32 like the reference's DDP (default), or MODE_DP_COMM=bf16 = half the bytes on the xGMI links
+    comm = torch.bfloat16 if os.environ.get("MODE_DP_COMM", "fp32") == "bf16" else torch.float32
+    red = ArenaGradReducer.for_model(m, comm_dtype=comm) if dist is not None else None      # also with ONE rank under RCCL: same code path as N > 1
+    # data-parallel step (world > 1): ZeRO-1 by default - per block slice reduce-scatter of the gradients, AdamW on this rank's shard, all-gather of
+    # the bf16 compute shadow (MODE_DP_ZERO1=fp32 gathers the fp32 masters instead, =0 falls back to the summed all-reduce + full optimizer pass)
+    z1 = os.environ.get("MODE_DP_ZERO1", "bf16" if world > 1 else "0")
+    z1 = None if (z1 in ("0", "", "none") or red is None or world == 1) else z1
+    if z1 == "bf16" and m.engine.compute_dtype != "bf16":
+        z1 = "fp32"
+    n_ev = steps + max(warmup, 1) + 2
+    ev_bwd = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+    ev_end = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+    it = [0]
+    overlap = os.environ.get("MODE_OPT_OVERLAP", "1") == "1"
+
+    def step():
+        sig = rand_log_logistic((B,), loc=math.log(SIGMA_DATA), scale=0.5, min_value=SIGMA_MIN, max_value=SIGMA_MAX, device=device)
+        loss, _ = den.loss({"state_images": img}, acts, goal, noise, sig)
+        loss.backward()
+        ev_bwd[it[0]].record()                                                 # the backward chain's last kernel
+        opt.step(reducer=red, overlap=overlap, zero1=z1)                       # per block: exchange (RCCL) -> AdamW underneath the remaining backward
+        ev_end[it[0]].record()
+        it[0] += 1
+        return loss
+    for _ in range(max(warmup, 1)):
+        loss = step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss.detach()).all()
+    ranks = 1
+    if dist is not None:
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)                                                   # the number of ranks the collective library actually connected
+        ranks = int(round(float(one.item())))
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if z1:
+        opt.gather_state(red)                                                  # leave exact masters / moments on every rank
+    den.train(was_training)
+    ms = elapsed / steps * 1e3
+    d = m.engine.dims
+    fl = 3.0 * flops_per_denoise_step(B, L=d.L, D=d.D, H=d.H, T=d.T, E=d.E, k=d.k, O=d.O, G=d.G, A=d.A_dim, A_len=d.A_len)   # fwd + bwd ~ 3x forward (BASELINE.md section 4)
+    backend = dist.get_backend() if dist is not None else None
+    return {"train_ms_per_step": round(ms, 3), "train_samples_per_s": round(world * B / (ms * 1e-3), 1), "train_global_batch": B * world,
+            "train_mfma_frac": round(fl / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4), "train_tflops_per_gpu": round(fl / (ms * 1e-3) / 1e12, 1),
+            "dp_mode": ("zero1:" + z1) if z1 else ("allreduce" if (red is not None and world > 1) else "single"),
+            "dp_comm_dtype": "bf16" if comm == torch.bfloat16 else "fp32",
+            # what is NOT hidden behind the backward: gradient exchange + optimizer (+ weight all-gather) still running after its last kernel
+            "exposed_exchange_and_optimizer_ms": round(sum(ev_bwd[i].elapsed_time(ev_end[i]) for i in range(it[0] - steps, it[0])) / steps, 3),
+            "rccl_ranks": ranks if backend == "nccl" else None, "dp_backend": backend, "dp_ranks": ranks, "train_steps": steps}
+
+
 def extra_measurements(M, den, device):
-    """Driver-timed numbers of the other configurations, in the same process as the headline run (rank 0, N = 1 only):
-    configs[2] training step (fwd + bwd + fused AdamW, B=128), configs[4] rollout (B=32 environments) and the reference's real rollout case B=1."""
+    """Driver-timed numbers of the other inference configurations, in the same process as the headline run (rank 0, N = 1 only):
+    configs[4] rollout (B=32 environments) and the reference's real rollout case B=1.  (The training leg is `train_leg`, run by every N.)"""
     import math
     out = {}
     sig = M.get_sigmas_exponential(N_SAMPLING_STEPS, SIGMA_MIN, SIGMA_MAX).to(device)
@@ -381,107 +465,22 @@ def extra_measurements(M, den, device):
         out[f"{key}_mfma_frac"] = round(flops_per_denoise_step(batch) * N_SAMPLING_STEPS / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4)
         if key == "rollout":
             out["rollout_action_chunks_per_s"] = round(batch / (ms * 1e-3), 1)
-    # training step (the sampler graphs own their workspaces: the training chain may grow the shared one)
-    from mode_diffusion_policy_amd.optim import FusedAdamW
-    from mode_diffusion_policy_amd.utils import rand_log_logistic
-    den.train()
-    B = B_PER_GPU
-    g = torch.Generator(device="cpu").manual_seed(1234)
-    img = torch.randn(B, 2, C2["obs_dim"], generator=g).to(device); goal = torch.randn(B, 1, C2["goal_dim"], generator=g).to(device)
-    acts = torch.randn(B, 10, 7, generator=g).to(device); noise = torch.randn(B, 10, 7, generator=g).to(device)
-    opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
-
-    def step():
-        s_ = rand_log_logistic((B,), loc=math.log(SIGMA_DATA), scale=0.5, min_value=SIGMA_MIN, max_value=SIGMA_MAX, device=device)
-        loss, _ = den.loss({"state_images": img}, acts, goal, noise, s_)
-        loss.backward()
-        opt.step(overlap=True)
-        return loss
-    for _ in range(3):
-        loss = step()
-    torch.cuda.synchronize()
-    assert torch.isfinite(loss.detach()).all()
-    n = 10
-    t0 = time.perf_counter()
-    for _ in range(n):
-        step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / n * 1e3
-    out["train_ms_per_step"] = round(ms, 3)
-    out["train_samples_per_s"] = round(B / (ms * 1e-3), 1)
-    out["train_mfma_frac"] = round(3.0 * flops_per_denoise_step(B) / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4)
-    den.eval()
     return out
 
 
 def train_bench(args, world, rank, device, dist):
     """BASELINE configs 3/4: score-matching training step of the full model, B=128 per GPU (global 128*N), AdamW included,
-    gradient arena summed over ranks in flat slices (RCCL), 1/world folded into the fused AdamW pass."""
-    import math
-    from mode_diffusion_policy_amd.ddp import ArenaGradReducer
-    from mode_diffusion_policy_amd.optim import FusedAdamW
-    from mode_diffusion_policy_amd.utils import rand_log_logistic
+    gradient arena exchanged over ranks in flat slices (RCCL), 1/world folded into the fused AdamW pass."""
     M, den = build_model(device, args.dtype)
-    m = den.inner_model
-    den.train()
-    B = B_PER_GPU
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)                 # every rank gets its own shard of the synthetic batch
-    img = torch.randn(B, 2, C2["obs_dim"], generator=g).to(device); goal = torch.randn(B, 1, C2["goal_dim"], generator=g).to(device)
-    acts = torch.randn(B, 10, 7, generator=g).to(device); noise = torch.randn(B, 10, 7, generator=g).to(device)
-    opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)         # mode_agent.yaml:24-29, two groups as mode_agent.py:365-384
-    if os.environ.get("MODE_ADAMW_BLOCKS"):
-        m.engine.lib.mode_set_option(b"adamw_blocks", int(os.environ["MODE_ADAMW_BLOCKS"]))
-    # gradient exchange dtype: fp32 like the reference's DDP (default), or MODE_DP_COMM=bf16 = half the bytes on the xGMI links
-    comm = torch.bfloat16 if os.environ.get("MODE_DP_COMM", "fp32") == "bf16" else torch.float32
-    red = ArenaGradReducer.for_model(m, comm_dtype=comm) if world > 1 else None
-
-    # data-parallel step (world > 1): ZeRO-1 by default - per block slice reduce-scatter of the gradients, AdamW on this rank's shard, all-gather of
-    # the bf16 compute shadow (MODE_DP_ZERO1=fp32 gathers the fp32 masters instead, =0 falls back to the summed all-reduce + full optimizer pass)
-    z1 = os.environ.get("MODE_DP_ZERO1", "bf16" if world > 1 else "0")
-    z1 = None if z1 in ("0", "", "none") else z1
-    ev_bwd = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup + 2)]
-    ev_end = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup + 2)]
-    it = [0]
-
-    def step():
-        sig = rand_log_logistic((B,), loc=math.log(SIGMA_DATA), scale=0.5, min_value=SIGMA_MIN, max_value=SIGMA_MAX, device=device)
-        loss, _ = den.loss({"state_images": img}, acts, goal, noise, sig)
-        loss.backward()
-        ev_bwd[it[0]].record()                                                           # the backward chain's last kernel
-        opt.step(reducer=red, overlap=os.environ.get("MODE_OPT_OVERLAP", "1") == "1", zero1=z1 if red is not None else None)   # per-block: exchange (RCCL) -> AdamW underneath the remaining backward
-        ev_end[it[0]].record()
-        it[0] += 1
-        return loss
-    for _ in range(max(args.warmup, 1)):
-        loss = step()
-    torch.cuda.synchronize()
-    assert torch.isfinite(loss.detach()).all()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    t = train_leg(den, device, world, rank, dist, steps=args.steps, warmup=args.warmup)
     if rank == 0:
-        fl = 3.0 * flops_per_denoise_step(B)                                   # fwd + bwd ~ 3x forward (BASELINE.md §4)
-        res = {"metric": "train-samples/sec (score-matching step, B=128 per GPU, AdamW)", "value": round(world * B * args.steps / elapsed, 1),
-               "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        res = {"metric": "train-samples/sec (score-matching step, B=128 per GPU, AdamW)", "value": t["train_samples_per_s"],
+               "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t["train_ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "configs[2]/[3]: score-matching training step of the full MoDE denoiser (12 layers, d=1024, 4 experts top-2), "
                                       "B=128 per GPU, log-logistic sigma, multinomial routing, dropouts on, fused AdamW, router unfrozen",
-                          "global_batch": B * world, "parallelism": f"dp{world}" + (" (bf16 gradient exchange)" if world > 1 and comm == torch.bfloat16 else "") + (f" zero1/{z1}" if world > 1 and z1 else "")},
-               "train_tflops_per_gpu": round(fl * args.steps / elapsed / 1e12, 1),
-               # what is NOT hidden behind the backward: gradient exchange + optimizer (+ weight all-gather) still running after its last kernel
-               "exposed_exchange_and_optimizer_ms": round(sum(ev_bwd[i].elapsed_time(ev_end[i]) for i in range(it[0] - args.steps, it[0])) / args.steps, 3),
-               "dp_mode": ("zero1:" + z1) if (red is not None and z1) else ("allreduce" if red is not None else "single")}
+                          "global_batch": B_PER_GPU * world, "parallelism": f"dp{world} {t['dp_mode']} ({t['dp_comm_dtype']} gradient exchange)"}}
+        res.update(t)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
@@ -606,6 +605,12 @@ def main():
             if n_gpus == 1 and not args.no_extras:
                 res["layer_kernels"] = layer_kernel_breakdown(den, device)
                 res.update(extra_measurements(M, den, device))
+    # configs[2]/[3] in the same invocation: the data-parallel training step (ALL ranks: it holds the path's one collective).  The headline above
+    # is replicas of the sampler (no collective); this leg is what a multi-GPU record can show the gradient exchange with.  Last of the GPU legs:
+    # it updates the weights.
+    if args.dtype == "bf16" and not args.no_extras:
+        res.update(train_leg(den, device, world, rank, dist))
+    if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MODE_HIP_ABI_VERSION 4
+#define MODE_HIP_ABI_VERSION 5
 
 typedef enum ModeStatus {
   MODE_OK = 0,
@@ -52,10 +52,14 @@ int mode_hip_version(void);
  * structs against the library it actually loaded (tests/test_boundary.py does, for every struct of this header). */
 size_t mode_hip_sizeof(const char* struct_name);
 const char* mode_hip_status_string(int status);
-/* Tuning knobs (process-wide; also settable through MODE_HIP_OPTS="key=value,..." when the Python binding loads the library).
+/* Tuning knobs.  PROCESS-WIDE state read by the launchers at launch time: set them before issuing work (or through
+ * MODE_HIP_OPTS="key=value,..." when the Python binding loads the library), never concurrently with launches from another thread - this
+ * one entry point is NOT re-entrant; every other entry point is (no other global state, no allocation, no synchronisation).  Every knob only
+ * selects between implementations that produce the SAME result (geometries / fusion on-off / slice counts); the library ships no switch
+ * that changes results (the round-2 timing ablations and cycle-stamp buffers of the GEMM kernels were removed from the product).
  * "gemm_cfg": bf16 forward GEMM tile geometry, 0 = auto (default), 1 = 128x128 ring-2, 4 = 128x64 ring-3, 6 = 128x128 single-buffered
  *   (3 workgroups/CU), 8 = 128x64 ring-2, 13 = 128x128 single-buffered with <= 128 VGPRs (4 workgroups/CU), 14 = 64x64 ring-3 (no SwiGLU),
- *   16 / 17 = persistent ping-pong 8-phase kernel with 256 / 224-row x 256-column tiles (gemm_bf16_pp.hip; epilogues NONE / BIAS / SWIGLU).
+ *   16 / 17 = persistent ping-pong kernel with 256 / 224-row x 256-column tiles (gemm_bf16_pp.hip; epilogues NONE / BIAS / SWIGLU).
  *   Every forward geometry produces bit-identical results (k-ordered fp32 MFMA chain, explicit-fma epilogues).
  * "gemm_pp": 1 (default) = the heuristic may pick geometry 17; "gemm_pp_min_tiles": tile count from which it does (default 200).
  * "gemm_group_m": m-tiles per XCD rasterisation group of the ring kernels (0 = default).
@@ -65,13 +69,9 @@ const char* mode_hip_status_string(int status);
  *   many TOKEN rows as the small-batch chain (MODE_GEMM_SMALL_ROWS) (default 32 = two environments, 0 = off).
  * "gemm_mid_rows": ungrouped bf16 GEMMs with K = 1024 and at most this many rows (more than "gemm_skinny_rows") keep their weights in registers
  *   and their A block in LDS - no K loop (default 128 = up to nine environments, 0 = off).
- * "gemm_setprio": 1 (default) = s_setprio 1 around the MFMA clusters of the tiled bf16 GEMM, 0 = off.
  * "fuse_ln2": 1 (default) = ln_2 folded into the c_proj / up-projection / combine kernels on the bf16 path, 0 = its own kernel.
  * "dn_split_k": K-slices of the inference path's expert down-projection, 0 = default (4, for every batch size), 1 = off, <= 8.
  * "combine_row_max": token rows up to which the MoE combine runs one workgroup per row (default: always), 0 = one wave per row.
- * Profiling aids: "pp_flags" (A/B and timing-ablation switches of the ping-pong kernel; 64 = small-batch GEMMs on the direct-fragment
- *   streamer), "pp_trace_lo" / "pp_trace_hi" (low / high half of a device pointer to a timestamp buffer written by the ping-pong and
- *   streaming GEMMs, 0 = off), "attn_bwd_stop" (attention backward returns after phase n, 0 = off).
  * Unknown keys return MODE_ERR_BAD_ARG. */
 int mode_set_option(const char* key, int value);
 
@@ -474,6 +474,11 @@ typedef struct ModeForwardArgs {
    * each token on its own ln_2-normalised state through the block's router MLP (fp32), top-k and dispatch happen inside the chain, per layer.
    * topk_idx_out (optional): int32 [L][B*T][k] - the experts every token took (for the caller's side channels / tests). */
   int32_t* topk_idx_out;
+  /* ABI 5.  PROMISE by the caller: every dispatch record in `meta` was built from ONE routing row for the whole batch (mode_dit_dispatch with
+   * R = 1: the sampler's uniform sigma), i.e. every expert segment holds all N tokens in token order.  The chain then passes
+   * MODE_GEMM_UNIFORM_GROUPS | MODE_GEMM_IDENTITY_ROWS to the expert GEMMs (gather indices computed, not loaded).  0 = no promise (always
+   * correct).  It is NOT inferred from cond_row_stride: a shared conditioning row with per-sample routing is a legal call. */
+  int32_t uniform_routing;
 } ModeForwardArgs;
 int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w, const ModeForwardArgs* a,
                      void* workspace, size_t workspace_bytes, void* stream);
@@ -518,6 +523,12 @@ typedef struct ModeTrainArgs {
   const float* shifted;          /* [L, B, E] max-shifted router logits (mode_dit_route)     */
   const float* aux_lb_coef;      /* [L, E] device                                            */
   const float* aux_z_coef;       /* device scalar                                            */
+  /* ABI 5: gradients with respect to the INPUTS (backward only, each optional).  The reference trains its perceptual encoders through
+   * `state_images` (mode/models/mode_agent.py:404-411, 548-567: perceptual_emb comes straight from the FiLM-ResNets), so the backward chain
+   * must hand d state_images to whatever produced them:  d state_images = d img_e · W_tok,  d goals = d goal_e · W_goal  (d goal_e includes
+   * the conditioning/router path when goal_in_cond).  Two fp32 GEMMs on quantities the chain already holds. */
+  float* d_state_images;         /* out: [B*n_img, O] or NULL                                */
+  float* d_goals;                /* out: [B, G] or NULL (gradient w.r.t. the goals AFTER preprocess_goals / the Bernoulli mask) */
 } ModeTrainArgs;
 int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes,
                            void* stream);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MODE_HIP_LIB", os.path.join(_HERE, "libmode_hip.so"))
 
 MODE_BF16, MODE_F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_RESIDUAL_NORM = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 4
+ABI_VERSION = 5
 GEMM_SKINNY_OK, GEMM_W_KN, GEMM_A_KM, GEMM_UNIFORM_GROUPS, GEMM_SMALL_ROWS, GEMM_IDENTITY_ROWS = 1, 2, 4, 8, 16, 32
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -88,7 +88,8 @@ class ModeTrainArgs(C.Structure):
                 ("emb_t", c_vp), ("cond", c_vp), ("goal_in_cond", c_i32), ("state_images", c_vp), ("goals", c_vp), ("goal_e", c_vp),
                 ("img_e", c_vp), ("actions", c_vp), ("c_in", c_vp), ("c_in_stride", c_i64), ("actions_scaled", c_vp), ("act_rows", c_vp),
                 ("meta", c_vp), ("meta_layer_stride", c_i64), ("topk_idx", c_vp), ("topk_layer_stride", c_i64), ("idx_per_token", c_i32),
-                ("probs", c_vp), ("r_pre", c_vp), ("F", c_vp), ("layer_events", c_vp), ("shifted", c_vp), ("aux_lb_coef", c_vp), ("aux_z_coef", c_vp)]
+                ("probs", c_vp), ("r_pre", c_vp), ("F", c_vp), ("layer_events", c_vp), ("shifted", c_vp), ("aux_lb_coef", c_vp), ("aux_z_coef", c_vp),
+                ("d_state_images", c_vp), ("d_goals", c_vp)]
 
 
 class ModeLayerGrads(C.Structure):
@@ -112,7 +113,7 @@ class ModeForwardArgs(C.Structure):
     _fields_ = [("B", c_i32), ("dtype", c_i32), ("emb_t", c_vp), ("emb_row_stride", c_i64), ("cond", c_vp),
                 ("cond_row_stride", c_i64), ("meta", c_vp), ("meta_layer_stride", c_i64), ("goal_e", c_vp), ("img_e", c_vp),
                 ("actions", c_vp), ("c_in", c_vp), ("c_in_stride", c_i64), ("scal", c_vp), ("scal_stride", c_i64),
-                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp), ("topk_idx_out", c_vp)]
+                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp), ("topk_idx_out", c_vp), ("uniform_routing", c_i32)]
 
 
 P = C.POINTER

@@ -230,7 +230,7 @@ template <typename T2>
 __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__ qkv, const float* __restrict__ qg, const float* __restrict__ kg,
                                                        const T2* __restrict__ dY, T2* __restrict__ dqkv, float* __restrict__ dgq_part,
                                                        float* __restrict__ dgk_part, int B, int T, int H, int HD, float eps, uint32_t seed,
-                                                       uint32_t thresh, float inv_keep, int stop_after) {
+                                                       uint32_t thresh, float inv_keep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HP = HD + 1;                               // padded row (bank-conflict-free column walks)
   // v / dO (and dV, which replaces v) are kept in the INPUT dtype: for bf16 that is exact (the inputs are bf16, dV is rounded to bf16 on
@@ -287,7 +287,6 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
     }
   }
   __syncthreads();
-  if (stop_after == 1) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   for (int t = wave; t < T; t += 4) {                  // one wave per token: row norms
     float a = 0.f, c = 0.f;
     for (int d = lane; d < HD; d += 64) { a += sq[t * HP + d] * sq[t * HP + d]; c += sk[t * HP + d] * sk[t * HP + d]; }
@@ -298,14 +297,12 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
     }
   }
   __syncthreads();
-  if (stop_after == 2) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   for (int i = tid; i < T * HD; i += 256) {
     const int t = i / HD, d = i % HD;
     sqh[t * HP + d] = sq[t * HP + d] * srq[t] * qg[d];
     skh[t * HP + d] = sk[t * HP + d] * srk[t] * kg[d];
   }
   __syncthreads();
-  if (stop_after == 3) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   const float scale = rsqrtf((float)HD);
   // S = q_hat k_hat^T * scale (causal) and dPd = dO V^T: four lanes per (query, key) pair, each a quarter of the head dim with two
   // independent accumulator pairs (the one-thread-per-pair loop was a 128-deep chain of dependent LDS reads), xor-shuffle combine
@@ -342,7 +339,6 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
     }
   }
   __syncthreads();
-  if (stop_after == 4) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   {                                                     // softmax rows, dropout, dS = P * (dP - sum(dP*P)) * scale: 16 lanes per query row
     const int qi = wave * 4 + (lane >> 4), ki = lane & 15;
     const bool valid = qi < T && ki <= qi;
@@ -368,7 +364,6 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
     }
   }
   __syncthreads();
-  if (stop_after == 5) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   // dV[j][d] = sum_{i>=j} Pd[i][j] dO[i][d];  dq_hat[i][d] = sum_{j<=i} dS[i][j] k_hat[j][d];  dk_hat[j][d] = sum_{i>=j} dS[i][j] q_hat[i][d].
   // One thread per (role, head-dim column) — role 0: dq_hat, role 1: dV and dk_hat.  The T column values a thread needs are read from
   // LDS once into registers, the P / dS coefficients are wave-uniform broadcast reads, so the FMAs are independent of LDS latency.
@@ -403,7 +398,6 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
       for (int j = 0; j < TMAX; ++j) { o0[j] = dot16(spdT + j * 16, oc); o1[j] = dot16(sdsT + j * 16, qc); }
     }
     __syncthreads();
-  if (stop_after == 6) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
     if (act && role == 0) {
 #pragma unroll
       for (int t = 0; t < TMAX; ++t) if (t < T) sqh[t * HP + d] = o0[t];
@@ -416,14 +410,12 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
     }
   }
   __syncthreads();
-  if (stop_after == 7) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   for (int d = tid; d < HD; d += 256) {                 // gain-gradient partials of this (sample, head)
     float a = 0.f, c = 0.f;
     for (int t = 0; t < T; ++t) { a += sqh[t * HP + d] * sq[t * HP + d] * srq[t]; c += skh[t * HP + d] * sk[t * HP + d] * srk[t]; }
     dgq_part[(long)prob * HD + d] = a; dgk_part[(long)prob * HD + d] = c;
   }
   __syncthreads();
-  if (stop_after == 8) return;                        // profiling aid (mode_set_option "attn_bwd_stop")
   // qk-RMSNorm backward (x_hat = x * r * g): dx = g*dxh*r - x * <g*dxh, x> * r^3 / HD  (clamped rows: dx = g*dxh/eps); in place over d x_hat
   {                                                     // 16 lanes per token: all T tokens in one pass, 4-step xor-shuffle reductions
     const int t = tid >> 4, l16 = tid & 15;
@@ -466,7 +458,6 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
 
 }  // namespace mode
 
-namespace mode { int g_attn_bwd_stop = 0; }
 using namespace mode;
 
 static inline uint32_t attn_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)((double)p * 4294967296.0); }
@@ -511,10 +502,10 @@ extern "C" int mode_attn_block_bwd(const void* qkv, const float* q_gain, const f
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MODE_BF16)
     hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, dim3(B * H), dim3(256), lds, s, (const uint16_t*)qkv, q_gain, k_gain, (const uint16_t*)dy, (uint16_t*)dqkv,
-                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik, g_attn_bwd_stop);
+                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik);
   else
     hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B * H), dim3(256), lds, s, (const float*)qkv, q_gain, k_gain, (const float*)dy, (float*)dqkv,
-                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik, g_attn_bwd_stop);
+                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }

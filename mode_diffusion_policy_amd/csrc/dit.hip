@@ -17,14 +17,11 @@ int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N
 
 extern int g_gemm_cfg;
 extern int g_gemm_pp;
-extern int g_pp_flags;
 extern int g_gemm_pp_min_tiles;
-extern unsigned long long g_pp_trace;
 extern int g_combine_row_max;
 extern int g_gemm_mid_rows;
 extern int g_tr_cfg;
 extern int g_gemm_group_m;
-extern int g_attn_bwd_stop;
 extern int g_adamw_blocks;
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -112,16 +109,11 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!key) return MODE_ERR_BAD_ARG;
   if (!strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return MODE_OK; }
   if (!strcmp(key, "gemm_pp")) { g_gemm_pp = value != 0; return MODE_OK; }
-  if (!strcmp(key, "pp_flags")) { g_pp_flags = value; return MODE_OK; }
   if (!strcmp(key, "gemm_pp_min_tiles")) { g_gemm_pp_min_tiles = value; return MODE_OK; }
-  if (!strcmp(key, "pp_trace_lo")) { g_pp_trace = (g_pp_trace & 0xffffffff00000000ull) | (unsigned)value; return MODE_OK; }   // profiling aid:
-  if (!strcmp(key, "pp_trace_hi")) { g_pp_trace = (g_pp_trace & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); return MODE_OK; }   // device buffer of cycle stamps (gemm_bf16_pp.hip)
   if (!strcmp(key, "gemm_tr_cfg")) { g_tr_cfg = value; return MODE_OK; }
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return MODE_OK; }
-  if (!strcmp(key, "attn_bwd_stop")) { g_attn_bwd_stop = value; return MODE_OK; }
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }
   if (!strcmp(key, "gemm_skinny_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_skinny_rows = value; return MODE_OK; }
-  if (!strcmp(key, "gemm_setprio")) { g_gemm_setprio = value != 0; return MODE_OK; }
   if (!strcmp(key, "fuse_ln2")) { g_fuse_ln2 = value != 0; return MODE_OK; }
   if (!strcmp(key, "gemm_mid_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_mid_rows = value; return MODE_OK; }
   if (!strcmp(key, "combine_row_max")) { if (value < 0) return MODE_ERR_BAD_ARG; g_combine_row_max = value; return MODE_OK; }
@@ -279,7 +271,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
   ModeMetaLayout ml;
   mode_moe_meta_layout(N, d.E, d.k, &ml);
   const int ysplit = down_proj_split(dt, 4 * D);
-  const bool uniform = !tok_route && a->cond_row_stride == 0;   // one conditioning row for the whole batch (the sampler): every sample routes to the same experts
+  const bool uniform = !tok_route && a->uniform_routing != 0;   // the caller's promise (ModeForwardArgs::uniform_routing): one routing row for the whole batch (the sampler)
   const int cond_rpc = T;   // one conditioning row per sample
   // cond addressing: row b at cond + b*cond_row_stride.  rmsnorm/combine kernels index cond by (row / rows_per_cond) * D, so a
   // shared row (stride 0) is expressed as rows_per_cond = N (every token maps to row 0).

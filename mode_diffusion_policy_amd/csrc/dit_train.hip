@@ -447,6 +447,19 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, d.G, B, st1, B, st2, B, gr->w_goal, d.G);
       if ((rc = mode_gemm(&g, stream))) return rc;
     }
+    // input gradients (ABI 5): the upstream encoders train through these (mode_agent.py:404-411, 548-567)
+    if (a->d_state_images) {
+      if (d.O % 4) return MODE_ERR_UNSUPPORTED;
+      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, RI, d.O, D, dimg, D, w->w_tok, d.O, a->d_state_images, d.O);
+      g.flags = MODE_GEMM_W_KN;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    }
+    if (a->d_goals) {
+      if (d.G % 4) return MODE_ERR_UNSUPPORTED;
+      g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, B, d.G, D, dgoal, D, w->w_goal, d.G, a->d_goals, d.G);
+      g.flags = MODE_GEMM_W_KN;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    }
     // sigma path: emb_t = e1 W_sl^T, e1 = s * w_se + b_se
     g = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, D, D, B, demb, D, a->e1, D, gr->w_sl, D);
     g.flags = MODE_GEMM_A_KM | MODE_GEMM_W_KN;

@@ -185,13 +185,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
     if constexpr (EPI == MODE_EPI_SWIGLU) lds_read_seq<2048, BJ>(fb + BJ, b_base + slot_off + co + (BN / 2) * 128);
   };
   auto mma = [&](const bf16x8(&fa)[FM], const bf16x8(&fb)[FN]) {
-    if (p.setprio) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // swapped operands: D[n][m]
-    if (p.setprio) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- main loop
@@ -407,10 +407,8 @@ int gemm_bf16_skinny_launch(const ModeGemmDesc* d, const GemmParams& p, hipStrea
 int gemm_bf16_mid_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);      // gemm_bf16_skinny.hip: register-resident weights, no K loop (a few hundred rows)
 int g_gemm_mid_rows = 128;   // "gemm_mid_rows" option: ungrouped K = 1024 GEMMs with at most this many rows take gemm_bf16_mid_kernel (0 = off).  Measured chunk latency B = 4: 6.89 -> 6.60 ms, B = 8: 7.40 -> 7.14 ms; from ~200 rows on the M/32 re-reads of W through L2 cost more than the ring kernel (B = 16: 8.41 -> 8.50 ms, B = 32: 9.21 -> 9.48 ms)
 int g_gemm_cfg = CFG_AUTO;
-int g_gemm_setprio = 1;
 int g_gemm_skinny_rows = 32;   // measured (scripts/rollout_batch_probe.py): chunk latency B=1 9.4 -> 7.35 ms, B=2 8.7 -> 8.3 ms; from ~3 environments on the tiled kernel (64x64 tiles) is as fast or faster
 int g_gemm_pp_min_tiles = 200;   // "gemm_pp_min_tiles" option
-int g_pp_flags = 0;       // "pp_flags" option (GemmParams::pp_flags)
 int g_gemm_pp = 1;        // "gemm_pp" option: 1 = large problems go to the persistent ping-pong kernel (gemm_bf16_pp.hip), 0 = 128x128 family only
 int g_gemm_group_m = 0;   // "gemm_group_m" option: m-tiles per rasterisation group (0 = default 8; >= m_tiles = n-major partition over the XCDs)
 
@@ -454,12 +452,12 @@ static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipSt
 //   < 256 tiles of 128x64   : 64x64 tiles, 3-slot ring: twice the workgroups, two per CU (c_proj 15.1 -> 13.0 us at B=128, 12.4 -> 9.9 us at B=32)
 //   fewer                   : 128x64 tiles so that more CUs get a workgroup, 3-slot ring (two K-tiles in flight per workgroup: with
 //                             <= 1 workgroup per CU nothing else hides the fill latency)                 [c_proj, expert down-proj, small batches]
-static int pick_cfg(const ModeGemmDesc* d) {
+static int pick_cfg(const ModeGemmDesc* d, bool allow_pp) {
   const long rows = d->M;
   // persistent ping-pong kernel (224 x 256 tiles, one workgroup per CU): whenever its tiles cover most of the chip - the expert up-projection from
   // B = 64 on (256 / 512 tiles at B = 64 / 128) and the K-sliced down-projection at B = 128 (16 x 4 tiles x 4 slices = 256).  Unsupported shapes
   // come back from its launcher and fall through to the 128x128 family below.
-  if (g_gemm_pp && (!d->expert_offsets || (d->flags & MODE_GEMM_UNIFORM_GROUPS)) &&
+  if (allow_pp && (!d->expert_offsets || (d->flags & MODE_GEMM_UNIFORM_GROUPS)) &&
       (d->epilogue == MODE_EPI_SWIGLU || d->epilogue == MODE_EPI_NONE || d->epilogue == MODE_EPI_BIAS)) {
     const int nout = d->epilogue == MODE_EPI_SWIGLU ? 128 : 256;
     const long tpp = ((rows + 223) / 224) * (d->N / nout) * (d->split_k > 1 ? d->split_k : 1);
@@ -511,8 +509,6 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.koffs = d->k_group_offsets; p.c_gstride = d->c_group_stride;
   p.C2 = (uint16_t*)d->C2; p.ldc2 = d->ldc2; p.gain = d->gain; p.ss_out = d->row_ss_out;
   p.ss_in = d->row_ss; p.ss_n = d->row_ss_n; p.ss_eps = d->row_eps;
-  p.setprio = g_gemm_setprio;
-  p.pp_flags = g_pp_flags;
   p.identity_rows = (d->flags & MODE_GEMM_IDENTITY_ROWS) && d->a_rows && d->expert_offsets ? 1 : 0;
   if (p.koffs && (d->num_k_groups <= 0 || p.split_k > 1 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
   if (small_rows && (g_gemm_cfg != CFG_AUTO || g_gemm_skinny_rows <= 0)) return MODE_ERR_UNSUPPORTED;   // the caller sized its row_ss buffers for the streamer
@@ -524,12 +520,11 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
     const int rc = gemm_bf16_mid_launch(d, p, s);
     if (rc != MODE_ERR_UNSUPPORTED) return rc;
   }
-  int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d);
+  int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d, g_gemm_pp != 0);
   if (cfg == CFG_PP256 || cfg == CFG_PP224) {
     const int rc = gemm_bf16_pp_launch(d, p, cfg == CFG_PP224, s);
     if (rc != MODE_ERR_UNSUPPORTED) return rc;
-    const int keep = g_gemm_pp;                                    // shapes / epilogues the ping-pong kernel does not take
-    g_gemm_pp = 0; cfg = pick_cfg(d); g_gemm_pp = keep;
+    cfg = pick_cfg(d, false);                                      // shapes / epilogues the ping-pong kernel does not take
   }
   const bool ob = d->out_dtype == MODE_BF16;
 #define MODE_CASE(E) \

@@ -73,8 +73,8 @@ template <int V>
 using IC = std::integral_constant<int, V>;
 }  // namespace pp
 
-template <int EPI, bool OUT_BF16, int FM1, int MERGED>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, unsigned long long* __restrict__ trace) {
+template <int EPI, bool OUT_BF16, int FM1>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   using namespace pp;
   constexpr int BM = 128 + 32 * FM1;                         // rows of an output tile: half 0 = 2 x 64, half 1 = 2 x 16*FM1
   constexpr bool SWI = EPI == MODE_EPI_SWIGLU;
@@ -188,26 +188,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   bool fresh = true;
-  const bool ab_mma = p.pp_flags & 2, ab_rd = p.pp_flags & 4, ab_dma = p.pp_flags & 8, ab_st = p.pp_flags & 16;
-  const bool early_resident = !(p.pp_flags & 32);           // A/B switch: 32 = the epilogue's stores are issued without the vmcnt(0) in front (first-pair phase-4 wait kept)      // timing ablations (results are garbage)
-  auto rdA = [&](auto T_, auto H_) {
-    if (ab_rd) return;
+  // Everything the K loop calls is resolved at compile time (no run-time switches: the shipped loop is straight-line code between its barriers;
+  // the timing ablations and cycle stamps that measured it in round 2 are gone from the product library - the numbers stay in DESIGN.md).
+  auto rdA = [&](auto T_, auto H_) __attribute__((always_inline)) {
     constexpr int t = decltype(T_)::value, h = decltype(H_)::value;
     constexpr int base = (t * 2 + h) * HALF_BYTES, nf = h ? FM1 : 4;
     lds_read_seq<base, 2048, nf>(&A_[0], a_addr[h][0]);
     lds_read_seq<base, 2048, nf>(&A_[4], a_addr[h][1]);
   };
-  auto rdB = [&](auto T_, auto H_) {
-    if (ab_rd) return;
+  auto rdB = [&](auto T_, auto H_) __attribute__((always_inline)) {
     constexpr int t = decltype(T_)::value, h = decltype(H_)::value;
     constexpr int base = (t * 2 + h) * HALF_BYTES;
     lds_read_seq<base, 2048, 2>(&Bf[h][0], b_addr[0]);
     lds_read_seq<base, 2048, 2>(&Bf[h][2], b_addr[1]);
   };
-  auto mma = [&](auto AH_, auto BH_) {
+  auto mma = [&](auto AH_, auto BH_) __attribute__((always_inline)) {
     constexpr int ah = decltype(AH_)::value, bh = decltype(BH_)::value, nf = ah ? FM1 : 4;
-    if (ab_mma) return;
-    if (p.setprio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -215,40 +211,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
 #pragma unroll
         for (int j = 0; j < 2; ++j)                              // swapped operands: D[weight row][token]
           acc[ah][bh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[bh][kh * 2 + j], A_[kh * 4 + i], acc[ah][bh][i][j], 0, 0, 0);
-    if (p.setprio) __builtin_amdgcn_s_setprio(0);
   };
-  auto stage = [&](auto OP_, auto T_, auto H_, const char* g, uint32_t o0, uint32_t o1) {
+  auto stage = [&](auto OP_, auto T_, auto H_, const char* g, uint32_t o0, uint32_t o1) __attribute__((always_inline)) {
     constexpr int op = decltype(OP_)::value, t = decltype(T_)::value, h = decltype(H_)::value;
     constexpr int base = (op ? LDS_B : LDS_A) + (t * 2 + h) * HALF_BYTES;
-    if (ab_dma && !fresh) return;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + o0),
                                      (__attribute__((address_space(3))) void*)(smem + base + (wave * 2 + 0) * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + o1),
                                      (__attribute__((address_space(3))) void*)(smem + base + (wave * 2 + 1) * 1024), 16, 0, 0);
   };
   // A half 1 of the 224-row tile has 96 rows = 12 pieces: waves 6 and 7 own pieces 12-15 and stage nothing (6 % fewer DMA bytes; the loop is
-  // DMA-rate bound).  Their counted waits are unaffected: the A-half-1 stages (phases 1 / 5) are never among the newest six at a wait.
+  // DMA-rate bound).  Their counted waits differ (6 instead of 8 instructions per K-step): the K loop exists in two compile-time copies, one per
+  // wave role, selected ONCE per output tile - not by a branch in front of every stage / wait.
   const bool stage_a1 = FM1 == 4 || wave < 6;
-  auto stamp = [&](int slot) {                                  // profiling aid: per-wave cycle stamps ("pp_trace" option), 8 slots per wave
-    if (trace && lane == 0) trace[((long)blockIdx.x * 8 + wave) * 8 + slot] = __builtin_readcyclecounter();
-  };
   constexpr IC<0> _0{};
   constexpr IC<1> _1{};
 #define PP_SB() __builtin_amdgcn_sched_barrier(0)
 #define PP_BAR() __builtin_amdgcn_s_barrier()
-  // one phase's compute part: barrier -> (fragments landed) -> 16 MFMAs -> barrier.  (Measured and rejected: passing the second barrier after the
-  // first k32 half of the MFMAs so that its ~125-cycle release latency runs under the second half - 64.9 vs 60.4 us; the two wave rows then
-  // issue MFMAs into the same pipe at the same time and the split cluster schedules worse.)
-#define PP_COMPUTE(AH, BH)        \
-  PP_BAR();                       \
-  wait_lgkmcnt<0>();              \
-  PP_SB();                        \
-  mma(AH, BH);                    \
-  PP_SB();                        \
-  PP_BAR();                       \
-  PP_SB();
-
-  stamp(0);
   bool staggered = false;                                      // true while wave row 1 runs one barrier behind wave row 0
 
   Tile cur, nxt;
@@ -313,7 +292,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < 2; ++q) a_off[h][q] = (uint32_t)(((long)srow[h][q] * p.lda + lchunk * 8) * 2);
-      if (L == wg * R) stamp(6);                                 // gathered-row indices landed
       stage(_0, _0, _0, Ak, a_off[0][0], a_off[0][1]);
       if (stage_a1) stage(_0, _0, _1, Ak, a_off[1][0], a_off[1][1]);
       stage(_0, _1, _0, Ak + 128, a_off[0][0], a_off[0][1]);
@@ -349,13 +327,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
           reinterpret_cast<float*>(smem + LDS_NRM)[nrm_par * 256 + tid] = __frcp_rn(fmaxf(__fsqrt_rn(ssum) * rk, p.ss_eps));
         }
       }
-      if (L == wg * R) stamp(7);                                 // operands landed, inverse row norms written
       wait_lgkmcnt<0>();
       if (wr == 1) PP_BAR();                                     // stagger: wave row 1 runs one barrier behind wave row 0 from here on
       staggered = true;
       PP_SB();
       fresh = false;
-      stamp(1);
     }
     const bool has_next = L + 1 < Lend;
     bool cont = false;
@@ -365,133 +341,81 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
     }
     const char* Wn = cont ? w_tile_base(nxt) : Wc;             // no successor on this stream: the tail re-reads valid memory, never consumed
 
-    // ------------------------------------------------------------------------------------------------ K loop: 8 phases = 2 K-steps
-    if constexpr (MERGED != 0) {
-      // ---- FOUR phases per K-step pair: a phase = one A half x BOTH W halves (32 / 8*FM1 MFMAs per wave between two barriers instead of 16 /
-      // 4*FM1).  Per-workgroup cycle stamps put the 8-phase loop at ~2600 cycles per K-step against 1792 of MFMA issue: every barrier interval
-      // is one MFMA cluster (256 / 192 cycles) plus ~125 cycles of s_barrier release latency, and phase 1's twelve fragment reads per wave
-      // (384 cycles of LDS time per wave row) sit beside a 192-cycle cluster.  Both W halves are in registers anyway (Bf[2][4]), so merging
-      // costs no registers.  A half-tile is re-staged one whole phase after the phase whose read section read it last:
-      //   R(P0, t): reads W0 W1 A0 of K-step t;  stages A1[t+1]           R(P1, t): reads A1[t];  stages W0 W1 A0 of K-step t+2
-      // (Measured and rejected again at this phase length: passing the second barrier between the two W halves of a cluster so that its release
-      // latency runs under the second half - 62.0 vs 53.5 us.)
-      // and every read section ends in ONE counted wait that leaves the newest K-step's worth of DMA (8 instructions; 6 on the waves that stage
-      // no A half 1) in flight: everything a later phase reads was issued before those.
+    // ------------------------------------------------------------------------------------------------ K loop: 4 phases = 2 K-steps
+    // A phase = one A half x BOTH W halves (32 / 8*FM1 MFMAs per wave between two barriers).  A half-tile is re-staged one whole phase after the
+    // phase whose read section read it last:
+    //   R(P0, t): reads W0 W1 A0 of K-step t;  stages A1[t+1]           R(P1, t): reads A1[t];  stages W0 W1 A0 of K-step t+2
+    // and every read section ends in ONE counted wait that leaves the newest K-step's worth of DMA (8 instructions; 6 on the waves that stage
+    // no A half 1) in flight: everything a later phase reads was issued before those.  (Round-2 measurements behind this shape - the eight-phase
+    // loop, barrier hand-over inside a cluster, per-phase cycle stamps - are in DESIGN.md §4.)
+    // The FIRST pair of a tile is peeled (K-steps 0 and 1 were resident before it began and the previous tile's stores may still be draining -
+    // vmcnt counts them - so it takes no waits, skips the A1[1] stage and requests the bias slice), and the wave role is a template argument:
+    // between two barriers there is no branch.
 #define PP_COMPUTE2(AH)           \
   PP_BAR();                       \
   wait_lgkmcnt<0>();              \
   PP_SB();                        \
+  __builtin_amdgcn_s_setprio(1);  \
   mma(AH, _0);                    \
   mma(AH, _1);                    \
+  __builtin_amdgcn_s_setprio(0);  \
   PP_SB();                        \
   PP_BAR();                       \
   PP_SB();
-#define PP_WAIT_STEP() do { if (stage_a1) wait_vmcnt<8>(); else wait_vmcnt<6>(); } while (0)
-#pragma unroll 1
-      for (int kt = 0; kt < nk; kt += 2) {
-        const bool cross = kt + 2 >= nk;
-        const int k2 = cross ? kt + 2 - nk : kt + 2;           // K-step (kt+2) inside its own output tile
-        const char* A1 = Ak + (long)(kt + 1) * 128;
-        const char* A2 = Ak + (long)k2 * 128;
-        const char* W2 = (cross ? Wn : Wc) + (long)k2 * 128;
-        const bool waits = kt != 0 || !early_resident;          // first pair of a tile: K-steps 0 and 1 were resident before it began (and the
-                                                                // previous tile's stores may still be draining: vmcnt counts them)
-        // P0 of K-step kt [buffer 0]
-        rdB(_0, _0); rdB(_0, _1);
-        PP_SB();
-        rdA(_0, _0);
-        if (stage_a1 && kt != 0) stage(_0, _1, _1, A1, a_off[1][0], a_off[1][1]);   // (first pair of a tile: K-step 1 is complete already)
-        if (waits) PP_WAIT_STEP();
-        PP_COMPUTE2(_0)
-        // P1 of K-step kt
-        rdA(_0, _1);
-        stage(_1, _0, _0, W2, b_off[0], b_off[1]);
-        stage(_1, _0, _1, W2 + w_half, b_off[0], b_off[1]);
-        stage(_0, _0, _0, A2, a_off[0][0], a_off[0][1]);
-        if (waits) PP_WAIT_STEP();
-        if constexpr (HAS_BIAS) {
-          if (kt == 0) {                                         // this tile's bias slice -> the wave's own LDS slot (behind the wait: not counted by it)
-            const float* bsrc = p.bias + (long)cur.expert * p.bias_estride + (long)cur.n * NOUT;
-            const float* bl = SWI ? (lane < 32 ? bsrc + lane * 4 : bsrc + p.N + (lane - 32) * 4) : bsrc + lane * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bl,
-                                             (__attribute__((address_space(3))) void*)(smem + LDS_BIAS + wave * 1024), 16, 0, 0);
-          }
-        }
-        PP_COMPUTE2(_1)
-        // P0 of K-step kt+1 [buffer 1]
-        rdB(_1, _0); rdB(_1, _1);
-        PP_SB();
-        rdA(_1, _0);
-        if (stage_a1) stage(_0, _0, _1, A2, a_off[1][0], a_off[1][1]);
-        if (waits) PP_WAIT_STEP();
-        PP_COMPUTE2(_0)
-        // P1 of K-step kt+1; K-step kt+2 [buffer 0] retired by this wait
-        rdA(_1, _1);
-        stage(_1, _1, _0, W2 + 128, b_off[0], b_off[1]);
-        stage(_1, _1, _1, W2 + w_half + 128, b_off[0], b_off[1]);
-        stage(_0, _1, _0, A2 + 128, a_off[0][0], a_off[0][1]);
-        PP_WAIT_STEP();
-        PP_COMPUTE2(_1)
-      }
-#undef PP_WAIT_STEP
-#undef PP_COMPUTE2
-    } else {
-#pragma unroll 1
-    for (int kt = 0; kt < nk; kt += 2) {
+    auto kpair = [&](auto A1_, auto FIRST_, int kt) __attribute__((always_inline)) {
+      constexpr bool a1 = decltype(A1_)::value != 0, first = decltype(FIRST_)::value != 0;
+      constexpr int NW = a1 ? 8 : 6;
       const bool cross = kt + 2 >= nk;
       const int k2 = cross ? kt + 2 - nk : kt + 2;             // K-step (kt+2) inside its own output tile
       const char* A1 = Ak + (long)(kt + 1) * 128;
       const char* A2 = Ak + (long)k2 * 128;
       const char* W2 = (cross ? Wn : Wc) + (long)k2 * 128;
-      // phase 1: quadrant (A half 0, W half 0) of K-step kt [buffer 0]
-      rdB(_0, _0);
+      // P0 of K-step kt [buffer 0]
+      rdB(_0, _0); rdB(_0, _1);
       PP_SB();
       rdA(_0, _0);
-      if constexpr (HAS_BIAS) {
-        if (kt == 0) {                                           // this tile's bias slice -> the wave's own LDS slot (1 KiB = one DMA instruction)
-          const float* bsrc = p.bias + (long)cur.expert * p.bias_estride + (long)cur.n * NOUT;
-          const float* bl = SWI ? (lane < 32 ? bsrc + lane * 4 : bsrc + p.N + (lane - 32) * 4) : bsrc + lane * 4;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bl,
-                                           (__attribute__((address_space(3))) void*)(smem + LDS_BIAS + wave * 1024), 16, 0, 0);
-        }
-      }
-      if (stage_a1 && kt != 0) stage(_0, _1, _1, A1, a_off[1][0], a_off[1][1]);   // (first pair of a tile: K-step 1 is complete already)
-      wait_lgkmcnt<8>();                                       // the W fragment reads (issued first) are retired: W[0][0] may be refilled next phase
-      PP_COMPUTE(_0, _0)
-      // phase 2: (A0, W1)
-      rdB(_0, _1);
-      stage(_1, _0, _0, W2, b_off[0], b_off[1]);
-      PP_COMPUTE(_0, _1)
-      // phase 3: (A1, W0)
+      if constexpr (a1 && !first) stage(_0, _1, _1, A1, a_off[1][0], a_off[1][1]);
+      if constexpr (!first) wait_vmcnt<NW>();
+      PP_COMPUTE2(_0)
+      // P1 of K-step kt
       rdA(_0, _1);
-      stage(_0, _0, _0, A2, a_off[0][0], a_off[0][1]);
-      PP_COMPUTE(_1, _0)
-      // phase 4: (A1, W1); K-step kt+1 [buffer 1] retired for the next four phases
+      stage(_1, _0, _0, W2, b_off[0], b_off[1]);
       stage(_1, _0, _1, W2 + w_half, b_off[0], b_off[1]);
-      if (kt != 0 || !early_resident) wait_vmcnt<6>();          // (first pair of a tile: K-steps 0 and 1 were resident before it began)
-      PP_COMPUTE(_1, _1)
-      // phase 5: (A0, W0) of K-step kt+1
-      rdB(_1, _0);
+      stage(_0, _0, _0, A2, a_off[0][0], a_off[0][1]);
+      if constexpr (!first) wait_vmcnt<NW>();
+      if constexpr (HAS_BIAS && first) {                         // this tile's bias slice -> the wave's own LDS slot (behind the wait: not counted by it)
+        const float* bsrc = p.bias + (long)cur.expert * p.bias_estride + (long)cur.n * NOUT;
+        const float* bl = SWI ? (lane < 32 ? bsrc + lane * 4 : bsrc + p.N + (lane - 32) * 4) : bsrc + lane * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bl,
+                                         (__attribute__((address_space(3))) void*)(smem + LDS_BIAS + wave * 1024), 16, 0, 0);
+      }
+      PP_COMPUTE2(_1)
+      // P0 of K-step kt+1 [buffer 1]
+      rdB(_1, _0); rdB(_1, _1);
       PP_SB();
       rdA(_1, _0);
-      if (stage_a1) stage(_0, _0, _1, A2, a_off[1][0], a_off[1][1]);
-      wait_lgkmcnt<8>();
-      PP_COMPUTE(_0, _0)
-      // phase 6
-      rdB(_1, _1);
-      stage(_1, _1, _0, W2 + 128, b_off[0], b_off[1]);
-      PP_COMPUTE(_0, _1)
-      // phase 7
+      if constexpr (a1) stage(_0, _0, _1, A2, a_off[1][0], a_off[1][1]);
+      if constexpr (!first) wait_vmcnt<NW>();
+      PP_COMPUTE2(_0)
+      // P1 of K-step kt+1; K-step kt+2 [buffer 0] retired by this wait
       rdA(_1, _1);
-      stage(_0, _1, _0, A2 + 128, a_off[0][0], a_off[0][1]);
-      PP_COMPUTE(_1, _0)
-      // phase 8; K-step kt+2 [buffer 0] retired
+      stage(_1, _1, _0, W2 + 128, b_off[0], b_off[1]);
       stage(_1, _1, _1, W2 + w_half + 128, b_off[0], b_off[1]);
-      wait_vmcnt<6>();
-      PP_COMPUTE(_1, _1)
+      stage(_0, _1, _0, A2 + 128, a_off[0][0], a_off[0][1]);
+      wait_vmcnt<NW>();
+      PP_COMPUTE2(_1)
+    };
+    auto kloop = [&](auto A1_) __attribute__((always_inline)) {
+      kpair(A1_, _1, 0);
+#pragma unroll 1
+      for (int kt = 2; kt < nk; kt += 2) kpair(A1_, _0, kt);
+    };
+    if constexpr (FM1 == 4) {
+      kloop(_1);
+    } else {
+      if (stage_a1) kloop(_1); else kloop(_0);
     }
-    }
-    stamp(2 + 2 * min(L - wg * R, 1));
+#undef PP_COMPUTE2
 
     // ------------------------------------------------------------------------------------------------ epilogue: registers -> global
     // bias / SwiGLU in registers (a lane owns 8 consecutive output columns of a token row), stored straight from registers, 16 bytes per lane.
@@ -503,13 +427,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
     // run without any vmcnt wait; the first counted wait (phase 8) comes ~4.5k cycles after the stores were issued.
     {
       const int rows_valid = cur.row_end - cur.row0;
-      char* Ct = reinterpret_cast<char*>(p.C) + ((long)cur.slice * p.split_stride + (long)cur.row0 * p.ldc + (long)cur.n * NOUT + wc * 32 + fq * 8) * ESZ;
+      // store addressing = UNIFORM tile base (scalar registers) + one 32-bit per-lane offset shared by all rounds: the row / column a round adds is
+      // wave-uniform, so a lane's 14 stores need ONE address VGPR (64-bit per-round addresses had pushed the kernel into spills whose reloads -
+      // vmcnt counts stores too - serialised the stores)
+      char* Ct = reinterpret_cast<char*>(p.C) + ((long)cur.slice * p.split_stride + (long)cur.row0 * p.ldc + (long)cur.n * NOUT + wc * 32) * ESZ;
+      const uint32_t c_lane = (uint32_t)(fr * (int)p.ldc + fq * 8) * ESZ;
       if (cont && stage_a1) stage(_0, _1, _1, Ak + 128, a_off[1][0], a_off[1][1]);      // next tile, K-step 1, A half 1 (its slot was last read in phase 7)
       // The two wave rows run their epilogues CONCURRENTLY: wave row 0 passes one extra barrier here (it pairs with wave row 1's last phase
       // barrier, so row 1 is released into its epilogue one MFMA segment later instead of after row 0's whole epilogue) and wave row 1 passes one
       // after its epilogue (pairs with row 0's first barrier of the next tile), which restores the one-barrier stagger.
-      const bool epi_sync = !(p.pp_flags & 1);
-      if (epi_sync && wr == 0) PP_BAR();
+      if (wr == 0) PP_BAR();
       [[maybe_unused]] float4 bq[2][2];                        // bias of this lane's 8 columns: [W half][4-column group]
       [[maybe_unused]] float rs[2][4];
       if constexpr (HAS_BIAS) {
@@ -559,8 +486,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
           }
         }
       };
-      auto round_row = [&](int r) { const int fi = SWI ? r : r >> 1, a = fi < 4 ? 0 : 1, i = a ? fi - 4 : fi;
-                                    return a * 128 + (a ? wr * 16 * FM1 : wr * 64) + i * 16 + fr; };
+      auto round_urow = [&](int r) { const int fi = SWI ? r : r >> 1, a = fi < 4 ? 0 : 1, i = a ? fi - 4 : fi;       // wave-uniform part of the row
+                                     return a * 128 + (a ? wr * 16 * FM1 : wr * 64) + i * 16; };
       auto round_col = [&](int r) { return SWI ? 0 : (r & 1) * 128; };
       if constexpr (OUT_BF16) {
         u32x4 pk[R];
@@ -572,22 +499,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) asm volatile("" : "+v"(pk[r]));      // every output is computed before the wait below
-        if (early_resident) wait_vmcnt<0>();
+        wait_vmcnt<0>();
         PP_SB();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const int trow = round_row(r);
-          if (trow < rows_valid && !ab_st) *reinterpret_cast<u32x4*>(Ct + ((long)trow * p.ldc + round_col(r)) * 2) = pk[r];
+          const int urow = round_urow(r);
+          if (fr < rows_valid - urow) *reinterpret_cast<u32x4*>(Ct + ((long)urow * p.ldc + round_col(r)) * 2 + c_lane) = pk[r];
         }
       } else {
-        if (early_resident) wait_vmcnt<0>();
+        wait_vmcnt<0>();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           float ov[8];
           outputs(r, ov);
-          const int trow = round_row(r);
-          if (trow < rows_valid && !ab_st) {
-            float* c = reinterpret_cast<float*>(Ct) + (long)trow * p.ldc + round_col(r);
+          const int urow = round_urow(r);
+          if (fr < rows_valid - urow) {
+            float* c = reinterpret_cast<float*>(Ct + ((long)urow * p.ldc + round_col(r)) * 4 + c_lane);
             *reinterpret_cast<float4*>(c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
             *reinterpret_cast<float4*>(c + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
           }
@@ -601,9 +528,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (epi_sync && wr == 1) PP_BAR();
+      if (wr == 1) PP_BAR();
     }
-    stamp(3 + 2 * min(L - wg * R, 1));
     if (!has_next) break;
     ++L;
     cur = nxt;
@@ -612,7 +538,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p, uns
   }
   wait_vmcnt<0>();                                             // the tail of the operand stream must land before the LDS is released
   if (staggered && wr == 0) PP_BAR();                                       // balance the stagger barrier of wave row 1
-#undef PP_COMPUTE
 #undef PP_BAR
 #undef PP_SB
 }
@@ -630,9 +555,7 @@ static int pp_num_cus() {
   return ncu[dev];
 }
 
-unsigned long long g_pp_trace = 0;        // "pp_trace_lo" / "pp_trace_hi" options: device buffer of 256 x 8 x 8 cycle stamps (profiling aid), 0 = off
-
-template <int EPI, bool OUT_BF16, int FM1, int MERGED>
+template <int EPI, bool OUT_BF16, int FM1>
 static int pp_launch(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   constexpr int BM = 128 + 32 * FM1, NOUT = (EPI == MODE_EPI_SWIGLU) ? 128 : 256;
   p.n_tiles = d->N / NOUT;
@@ -640,7 +563,7 @@ static int pp_launch(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   const long t_max = (long)p.m_tiles * p.n_tiles * p.split_k;
   const int ncu = pp_num_cus();
   const int grid = (int)(t_max < ncu ? t_max : ncu);           // one persistent workgroup per CU (140 KiB of LDS each)
-  auto kern = gemm_pp_kernel<EPI, OUT_BF16, FM1, MERGED>;
+  auto kern = gemm_pp_kernel<EPI, OUT_BF16, FM1>;
   static bool attr_set[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -650,7 +573,7 @@ static int pp_launch(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pp::LDS_TOTAL, s, p, reinterpret_cast<unsigned long long*>(g_pp_trace));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pp::LDS_TOTAL, s, p);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
@@ -671,14 +594,10 @@ int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, int rows224
   if (wrows * d->ldw * 2 >= (1L << 32) || (long)d->M * d->lda * 2 >= (1L << 32)) return MODE_ERR_UNSUPPORTED;
   if (d->bias && ((reinterpret_cast<uintptr_t>(d->bias) & 15) || d->bias_expert_stride % 4)) return MODE_ERR_UNSUPPORTED;
   const bool ob = d->out_dtype == MODE_BF16;
-#define PP_CASE(E)                                                                                              \
-  case E:                                                                                                       \
-    if (!(p0.pp_flags & 256)) {                                   /* 256 = the eight-phase loop (A/B) */                      \
-      if (rows224) return ob ? pp_launch<E, true, 3, 1>(p0, d, s) : pp_launch<E, false, 3, 1>(p0, d, s);        \
-      return ob ? pp_launch<E, true, 4, 1>(p0, d, s) : pp_launch<E, false, 4, 1>(p0, d, s);                     \
-    }                                                                                                           \
-    if (rows224) return ob ? pp_launch<E, true, 3, 0>(p0, d, s) : pp_launch<E, false, 3, 0>(p0, d, s);         \
-    return ob ? pp_launch<E, true, 4, 0>(p0, d, s) : pp_launch<E, false, 4, 0>(p0, d, s);
+#define PP_CASE(E)                                                                                        \
+  case E:                                                                                                 \
+    if (rows224) return ob ? pp_launch<E, true, 3>(p0, d, s) : pp_launch<E, false, 3>(p0, d, s);         \
+    return ob ? pp_launch<E, true, 4>(p0, d, s) : pp_launch<E, false, 4>(p0, d, s);
   switch (epi) {
     PP_CASE(MODE_EPI_NONE)
     PP_CASE(MODE_EPI_BIAS)

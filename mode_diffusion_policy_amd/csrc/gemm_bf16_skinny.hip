@@ -85,7 +85,7 @@ __device__ __forceinline__ void row_norm_finish(const GemmParams& p, const int (
 }
 
 template <int MT, int EPI, bool OUT_BF16, int NW, int KST>
-__global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const GemmParams p, unsigned long long* trace) {
+__global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const GemmParams p) {
   constexpr int FNW = (EPI == MODE_EPI_SWIGLU) ? 2 : 1;            // W fragments per wave: value (+ gate)
   constexpr int U = (MT * FNW >= 4) ? 2 : 4;                         // k32 steps whose loads are in flight together (generic K)
   static_assert(MT <= NW && (MT * 16) % NW == 0, "one epilogue row fragment per wave");
@@ -99,13 +99,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const GemmPar
   const int n0 = blockIdx.x * 16;
   const int n = n0 + fq * 4;                                         // epilogue: a lane owns columns n .. n+3 of one row
 
-  // profiling aid ("pp_trace_lo/hi" options): 100-MHz timestamps per workgroup - start, segment known, operands consumed, done
-  const long wg = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
-  if (trace && threadIdx.x == 0) trace[wg * 4 + 0] = __builtin_amdgcn_s_memrealtime();
   int row0 = 0, row_end = p.M;
   if (p.offsets) { row0 = p.offsets[expert]; row_end = p.offsets[expert + 1]; }
   if (row_end <= row0) return;
-  if (trace && threadIdx.x == 0) trace[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime() + (row0 & 0);
   const uint16_t* W = p.W + (long)expert * p.w_estride;
   const float* bias = p.bias ? p.bias + (long)expert * p.bias_estride : nullptr;
 
@@ -220,7 +216,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const GemmPar
 #pragma unroll
       for (int j = 0; j < FNW; ++j) red[((wave * MT + i) * FNW + j) * 64 + lane] = acc[i][j];
     __syncthreads();
-    if (trace && threadIdx.x == 0) trace[wg * 4 + 2] = __builtin_amdgcn_s_memrealtime();
     if (wave < MT) {                                                 // wave i finishes row fragment i
       f32x4 v[FNW];
 #pragma unroll
@@ -262,10 +257,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const GemmPar
       }
     }
   }
-  if (trace) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) trace[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime();
-  }
 }
 
 // ---- The chain's shape: a K-slice of exactly 1024 columns per workgroup (QKV / c_proj / up-projection: K = 1024; down-projection: 4096 in four
@@ -276,7 +267,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const GemmPar
 // of padding per row (fragment reads conflict-free), read back as MFMA fragments.  Order of issue: index loads -> A DMA + W loads (nothing waits
 // between them) -> one wait -> fragments -> MFMAs.
 template <int MT, int EPI, bool OUT_BF16>
-__global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(const GemmParams p, unsigned long long* trace) {
+__global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(const GemmParams p) {
   constexpr int NW = 4, KS = 8, ROWS = MT * 16, AROW = 2048 + 16, NIT = ROWS / 2;   // NIT 16-byte chunks of A per thread
   constexpr int FNW = (EPI == MODE_EPI_SWIGLU) ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -290,12 +281,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(const GemmParams 
   const int n0 = blockIdx.x * 16;
   const int n = n0 + fq * 4;
 
-  const long wg = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
-  if (trace && tid == 0) trace[wg * 4 + 0] = __builtin_amdgcn_s_memrealtime();
   int row0 = 0, row_end = p.M;
   if (p.offsets) { row0 = p.offsets[expert]; row_end = p.offsets[expert + 1]; }
   if (row_end <= row0) return;
-  if (trace && tid == 0) trace[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime() + (row0 & 0);
   const uint16_t* W = p.W + (long)expert * p.w_estride;
   const float* bias = p.bias ? p.bias + (long)expert * p.bias_estride : nullptr;
   const int kslice = blockIdx.z * 1024;
@@ -390,7 +378,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(const GemmParams 
 #pragma unroll
       for (int j = 0; j < FNW; ++j) red[((wave * MT + i) * FNW + j) * 64 + lane] = acc[i][j];
     __syncthreads();
-    if (trace && tid == 0) trace[wg * 4 + 2] = __builtin_amdgcn_s_memrealtime();
     if (wave < MT) {                                                 // wave i finishes row fragment i
       f32x4 v[FNW];
 #pragma unroll
@@ -430,10 +417,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(const GemmParams 
         else *reinterpret_cast<float4*>(Cout + ((long)ml * p.ldc + n) * 4) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
-  }
-  if (trace) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) trace[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -532,8 +515,6 @@ int gemm_bf16_mid_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t
   return MODE_OK;
 }
 
-extern unsigned long long g_pp_trace;      // gemm_bf16_pp.hip
-
 template <int MT, int EPI, bool OUT_BF16>
 static int launch_skinny(const GemmParams& p, int groups, hipStream_t s) {
   // 8 K-slices per workgroup when K is long and the grid is small (down-projection: K = 4096 / split), else 4
@@ -541,9 +522,8 @@ static int launch_skinny(const GemmParams& p, int groups, hipStream_t s) {
   const dim3 grid((p.N + 15) / 16, groups, p.split_k);
   constexpr int FNW = (EPI == MODE_EPI_SWIGLU) ? 2 : 1;
   constexpr size_t RS = MT * 16 * 4;                                 // inverse row norms behind the reduction buffer
-  unsigned long long* tr = reinterpret_cast<unsigned long long*>(g_pp_trace);
   if constexpr (MT <= 2) {
-    if (kspl == 1024 && !(p.pp_flags & 64)) {                        // the chain's shapes: A block through LDS ("pp_flags" 64 = the direct-fragment kernel, A/B)
+    if (kspl == 1024) {                                              // the chain's shapes: A block through LDS
       constexpr size_t LDS = (size_t)MT * 16 * (2048 + 16) + RS;
       auto kern = gemm_bf16_stream_kernel<MT, EPI, OUT_BF16>;
       static bool attr_set[16] = {false};
@@ -556,17 +536,17 @@ static int launch_skinny(const GemmParams& p, int groups, hipStream_t s) {
           attr_set[dev] = true;
         }
       }
-      hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, p, tr);
+      hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, p);
       MODE_LAUNCH_CHECK();
       return MODE_OK;
     }
   }
   if (kspl % 256 == 0 && kspl >= 2048) {
-    hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, EPI, OUT_BF16, 8, 0>), grid, dim3(512), (size_t)8 * MT * FNW * 64 * 16 + RS, s, p, tr);
+    hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, EPI, OUT_BF16, 8, 0>), grid, dim3(512), (size_t)8 * MT * FNW * 64 * 16 + RS, s, p);
   } else if (kspl == 1024) {                                         // every load of the wave in flight at once
-    hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, EPI, OUT_BF16, 4, 8>), grid, dim3(256), (size_t)4 * MT * FNW * 64 * 16 + RS, s, p, tr);
+    hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, EPI, OUT_BF16, 4, 8>), grid, dim3(256), (size_t)4 * MT * FNW * 64 * 16 + RS, s, p);
   } else {
-    hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, EPI, OUT_BF16, 4, 0>), grid, dim3(256), (size_t)4 * MT * FNW * 64 * 16 + RS, s, p, tr);
+    hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, EPI, OUT_BF16, 4, 0>), grid, dim3(256), (size_t)4 * MT * FNW * 64 * 16 + RS, s, p);
   }
   MODE_LAUNCH_CHECK();
   return MODE_OK;

@@ -81,9 +81,7 @@ struct GemmParams {
   int split_k; long split_stride;     // split-K: blockIdx.y = K-slice, output slab = C + slice*split_stride elements
   const int* koffs; long c_gstride;   // K-groups: blockIdx.z = group, K range [koffs[z], koffs[z+1])
   int group_m;                        // m-tiles per rasterisation group (0 = kernel default)
-  int setprio;                        // raise the wave priority around the MFMA clusters ("gemm_setprio" option)
   int identity_rows;                  // MODE_GEMM_IDENTITY_ROWS: a_rows[offsets[e] + i] == i, the gather may be computed instead of loaded
-  int pp_flags;                       // gemm_bf16_pp.hip experiment switches ("pp_flags" option): A/B switches 1 = serial epilogues, 32 = stores ahead of the residency wait; timing ablations 2 / 4 / 8 / 16 = no MFMA / no fragment reads / no DMA in the K loop / no global stores
   // fused ln_2 (MODE_EPI_RESIDUAL_NORM producer / MODE_EPI_SWIGLU consumer): see include/mode_hip.h
   uint16_t* C2; long ldc2; const float* gain; float* ss_out;   // producer: bf16((acc+resid)*gain[n]) and per-64-column row sums of squares
   const float* ss_in; int ss_n; float ss_eps;                   // consumer: acc rows scaled by 1/max(sqrt(sum ss_in[row][0..ss_n)) * K^-1/2, eps)
@@ -115,7 +113,6 @@ __device__ __forceinline__ float sum_row_partials_wave(const float* __restrict__
 
 // Rows up to which the bf16 GEMM uses the weight-streaming kernel of gemm_bf16_skinny.hip ("gemm_skinny_rows" option; 0 = off)
 extern int g_gemm_skinny_rows;
-extern int g_gemm_setprio;
 extern int g_gemm_cfg;
 
 #define MODE_LAUNCH_CHECK()                                  \

@@ -212,6 +212,7 @@ class ArenaGradReducer:
         eng = model.engine
         ar = eng.arena
         ar.ensure_grad(model)
+        model.grad_mode = "arena"                                               # the exchange runs over the gradient arena the backward chain writes
         red = cls(ar.grad, ar.bounds["no_decay"], **kw)
         if overlap and ar.grad.device.type == "cuda":
             from .training import TrainState

@@ -23,6 +23,7 @@ except Exception:  # pragma: no cover
 from .score_wrappers import GCDenoiser
 from .modedit import MoDeDiT
 from .samplers import *  # noqa: F401,F403  the other samplers / schedules MoDEAgent.sample_loop and get_noise_schedule dispatch to
+from .samplers import tag_schedule
 
 
 def append_zero(action):
@@ -35,18 +36,18 @@ def get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0, device="cpu"):
     min_inv_rho = sigma_min ** (1 / rho)
     max_inv_rho = sigma_max ** (1 / rho)
     sigmas = (max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** rho
-    return append_zero(sigmas).to(device)
+    return tag_schedule(append_zero(sigmas).to(device), "karras", n, sigma_min, sigma_max, rho)
 
 
 def get_sigmas_exponential(n, sigma_min, sigma_max, device="cpu"):
     """exp(linspace(ln smax, ln smin, n)) ++ [0]   (gc_sampling.py:35-38) — the default ('exponential', mode_agent.yaml:14)."""
     sigmas = torch.linspace(math.log(sigma_max), math.log(sigma_min), n, device=device).exp()
-    return append_zero(sigmas)
+    return tag_schedule(append_zero(sigmas), "exponential", n, sigma_min, sigma_max)
 
 
 def get_sigmas_linear(n, sigma_min, sigma_max, device="cpu"):
     """gc_sampling.py:41-44."""
-    return append_zero(torch.linspace(sigma_max, sigma_min, n, device=device))
+    return tag_schedule(append_zero(torch.linspace(sigma_max, sigma_min, n, device=device)), "linear", n, sigma_min, sigma_max)
 
 
 @torch.no_grad()

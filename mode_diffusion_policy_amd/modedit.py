@@ -183,6 +183,10 @@ class MoDeDiT(nn.Module):
         self.compute_dtype = compute_dtype
         self._engine: Optional[DitEngine] = None
         self._route_cache = {}
+        # How the HIP backward hands over parameter gradients (training.py): "autograd" = through autograd like the reference module (accumulate
+        # hooks fire: torch DistributedDataParallel as Lightning wraps it, hook-driven clipping, any torch optimizer); "arena" = written straight
+        # into the flat gradient arena, p.grad aliases it, autograd sees None (FusedAdamW / ArenaGradReducer switch to it).
+        self.grad_mode = "autograd"
 
     # ------------------------------------------------------------------ engine access
     @property
@@ -265,7 +269,7 @@ class MoDeDiT(nn.Module):
         meta = eng.dispatch(idx, w, self.num_layers, R, N if R == 1 else T, N)
         ml = eng.meta_layout(N)
         eng.forward(B, emb_t, 0 if emb_t.shape[0] == 1 else D, cond, 0 if cond.shape[0] == 1 else D,
-                    meta.data_ptr(), ml.total_words, goal_e, img_e, acts, F=F)
+                    meta.data_ptr(), ml.total_words, goal_e, img_e, acts, F=F, uniform=R == 1)
         self._last_topk = idx
         self._account_usage(meta, ml, N)
         self.logits_per_layer = [None] * self.num_layers                   # only populated in training (modedit.py:584-593)
@@ -282,7 +286,7 @@ class MoDeDiT(nn.Module):
         return img, goals.reshape(img.shape[0], -1).contiguous()
 
     @torch.no_grad()
-    def denoise(self, states, action, goals, sigma, sigma_data: float):
+    def denoise(self, states, action, goals, sigma, sigma_data: float, _account: bool = True):
         """GCDenoiser.forward (score_wrappers.py:65-80) with c_in / c_out / c_skip fused into the HIP chain."""
         eng = self.engine
         dev, B, T, D = eng.device, action.shape[0], self.seq_len, self.embed_dim
@@ -317,10 +321,55 @@ class MoDeDiT(nn.Module):
         meta = eng.dispatch(idx, w, self.num_layers, Rr, N if Rr == 1 else T, N)
         ml = eng.meta_layout(N)
         eng.forward(B, emb_t, 0 if R == 1 else D, cond, 0 if Rr == 1 else D, meta.data_ptr(), ml.total_words, goal_e, img_e, x,
-                    c_in=c_in, c_in_stride=0 if R == 1 else 1, scal_ptr=scal.data_ptr(), scal_stride=0 if R == 1 else 4, denoised=den)
-        self._last_topk = idx
-        self._account_usage(meta, ml, N)
+                    c_in=c_in, c_in_stride=0 if R == 1 else 1, scal_ptr=scal.data_ptr(), scal_stride=0 if R == 1 else 4, denoised=den, uniform=Rr == 1)
+        self._last_topk, self._last_meta = idx, meta
+        if _account:
+            self._account_usage(meta, ml, N)
         return den
+
+    @torch.no_grad()
+    def denoise_graphed(self, states, action, goals, sigma, sigma_data: float):
+        """``denoise`` for a batch that shares ONE noise level (a 0-dim / 1-element sigma, device or host), replayed as a hipGraph: sigma embedding,
+        fp32 router + dispatch of all layers, EDM scalings, observation embeddings and the denoiser forward are captured once per batch size with
+        sigma as a DEVICE scalar, so the same graph serves every noise level of every sampler (euler, heun, dpm-solver++ ...: gc_sampling.py:165-994)
+        - no per-step host work beyond three small input copies.  Returns None when routing depends on the sample (goal / token routing)."""
+        if self.use_goal_in_routing or not self.cond_router:
+            return None
+        import os
+        eng = self.engine
+        dev, B = eng.device, action.shape[0]
+        if B == 0 or os.environ.get("MODE_HIP_GRAPH", "1") == "0":
+            return None
+        img, gl = self._prep_obs(eng, states, goals)
+        x = action.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self._check_batch(B, img, gl, x)
+        sig = torch.as_tensor(sigma, dtype=torch.float32).detach().reshape(-1)[:1]
+        key = (B, eng.compute_dtype, eng._structs_for, str(dev), float(sigma_data))
+        cache = self._route_cache.setdefault("denoise_graphs", {})
+        ent = cache.get(key)
+        if ent is None:
+            if len(cache) >= 8:                                          # a handful of batch sizes is the use case; do not hoard graphs
+                cache.pop(next(iter(cache)))
+            ent = dict(img=img.clone(), goals=gl.clone(), x=x.clone(), sig=torch.empty(1, device=dev))
+            ent["sig"].copy_(sig)
+            ent["ws"] = torch.empty(max(eng.workspace_bytes(B, 0), eng.workspace_bytes(0, 1)), dtype=torch.uint8, device=dev)
+            run = lambda: self.denoise({"state_images": ent["img"]}, ent["x"], ent["goals"], ent["sig"], sigma_data, _account=False)
+            with eng.pinned_workspace(ent["ws"]):
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):                            # warm-up outside the capture: loads code objects
+                    run()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with capture_graph(g):
+                    ent["out"] = run()
+                    ent["meta"] = self._last_meta
+            ent["graph"] = g
+            cache[key] = ent
+        ent["img"].copy_(img); ent["goals"].copy_(gl); ent["x"].copy_(x); ent["sig"].copy_(sig, non_blocking=True)
+        ent["graph"].replay()
+        self._account_usage(ent["meta"], eng.meta_layout(B * self.seq_len), B * self.seq_len)
+        return ent["out"].clone()
 
     def _schedule_state(self, eng, sig, B, sigma_data: float, out=None):
         """Everything of a DDIM run that depends on the noise SCHEDULE only (not on the observations): per-step EDM scalings, the sigma
@@ -365,7 +414,7 @@ class MoDeDiT(nn.Module):
         for s in range(n):
             e = emb_all[s]
             eng.forward(B, e, 0, e, 0, meta.data_ptr() + 4 * s * ml.total_words, n * ml.total_words, goal_e, img_e, x,
-                        c_in=c_in.data_ptr() + 4 * s, c_in_stride=0, scal_ptr=scal.data_ptr() + 16 * s, scal_stride=0, x_next=x)
+                        c_in=c_in.data_ptr() + 4 * s, c_in_stride=0, scal_ptr=scal.data_ptr() + 16 * s, scal_stride=0, x_next=x, uniform=True)
         return ml
 
     def _account_ddim_usage(self, sched, ml, n, n_tokens):
@@ -410,8 +459,12 @@ class MoDeDiT(nn.Module):
             return x
         key = (B, sig.numel(), eng.compute_dtype, eng._structs_for, str(dev), float(sigma_data))   # arena pointers are static: weight updates keep graphs valid
         ent = self._route_cache.get("graph")
-        # identity of the schedule: the caller's tensor (pointer + version: free), the weights, and the routing cache generation
-        sched_key = (sigmas.data_ptr(), sigmas._version, eng._wkey, getattr(self, "_fused_gen", 0))
+        # identity of the schedule: a host-side tag of its VALUES when the tensor came from a get_sigmas_* / get_noise_schedule generator (the
+        # agent builds a fresh tensor per chunk, mode_agent.py:752) - else the caller's tensor OBJECT (kept alive below, so neither its id nor its
+        # storage can be recycled while the key is live) -, the weights, and the routing cache generation.  No device read on either path.
+        tag = getattr(sigmas, "_mode_sched", None)
+        sid = ("tag", tag, sigmas._version) if tag is not None else ("obj", id(sigmas), sigmas._version)
+        sched_key = (sid, eng._wkey, getattr(self, "_fused_gen", 0))
         if ent is None or ent["key"] != key:
             st = dict(key=key, img=img.clone(), goals=goals.clone(), x=x0.clone().contiguous(), sig=sig.clone())
             # the graph owns its workspace: the engine's shared scratch buffer is re-allocated whenever a larger chain (a training step, a
@@ -428,9 +481,13 @@ class MoDeDiT(nn.Module):
                 with capture_graph(g):
                     st["ml"] = self._ddim_steps(eng, st["img"], st["goals"], st["x"], st["sched"], n)
             st["graph"], st["sched_key"] = g, sched_key
+            st["sig_ref"] = sigmas if tag is None else None
             self._route_cache["graph"] = ent = st
         elif ent["sched_key"] != sched_key:
-            same_values = ent["sched_key"][2:] == sched_key[2:] and bool(torch.equal(sig, ent["sig"]))     # another tensor with the same schedule: one small sync
+            # an UNTAGGED foreign tensor object that may carry the same values: one small device compare (host sync) - the rare path; tagged
+            # schedules and a reused tensor object never get here with an unchanged schedule
+            same_values = (tag is None and ent["sched_key"][1:] == sched_key[1:] and bool(torch.equal(sig, ent["sig"])))
+            ent["sig_ref"] = sigmas if tag is None else None
             if not same_values:
                 ent["sig"].copy_(sig)
                 with eng.pinned_workspace(ent["ws"]):

@@ -22,6 +22,7 @@ class FusedAdamW:
         self.model = model
         eng = model.engine                                   # adopts the parameters into the arena
         self.eng, self.arena = eng, eng.arena
+        model.grad_mode = "arena"                            # this optimizer reads the flat gradient arena: the backward chain writes there directly
         n = self.arena.bounds["no_decay"]                    # decay + no_decay regions (dead region excluded)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=eng.device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=eng.device)
@@ -29,6 +30,7 @@ class FusedAdamW:
         self._side = None
         self._ema_now = (None, 0.0)
         self._frozen = []
+        self._master_sharded = self._state_sharded = False
         self.param_groups = [dict(name="decay", lr=lr, betas=betas, eps=eps, weight_decay=weight_decay),
                              dict(name="no_decay", lr=lr, betas=betas, eps=eps, weight_decay=0.0)]
 
@@ -97,8 +99,6 @@ class FusedAdamW:
         if self._side is None:
             self._side = torch.cuda.Stream(device=eng.device, priority=int(os.environ.get("MODE_OPT_PRIO", "0")))
         cur = torch.cuda.current_stream()
-        if self._ema_now[0] is not None:
-            raise NotImplementedError("ZeRO-1 step with a fused EMA: call ArenaEMA.update(step) after the step instead")
         n_red = ar.bounds["no_decay"]
         dec = ar.bounds["decay"]
         parts, done = [], []
@@ -135,10 +135,44 @@ class FusedAdamW:
                     if shi < hi:
                         lp[shi:hi].copy_(ar.flat[shi:hi])
         cur.wait_stream(self._side)
-        covered = sum(hi - lo for lo, hi, *_ in parts)
-        if covered != n_red:
-            raise RuntimeError("ZeRO-1 step: the reducer's slices do not tile the optimised arena")
         self._master_sharded = gather == "bf16" and lp is not None and reducer.world > 1
+        self._state_sharded = reducer.world > 1                  # exp_avg / exp_avg_sq are current on this rank's shards only
+
+    def _validate_zero1(self, reducer, zero1, ema) -> None:
+        """Everything that can refuse a ZeRO-1 step, checked BEFORE any state changes or any collective is issued (a refusal half-way would leave
+        the ranks with different step counts / partially updated slices)."""
+        if zero1 not in ("fp32", "bf16"):
+            raise ValueError("zero1 must be None, 'fp32' or 'bf16'")
+        if ema is not None and ema.should_apply(self.step_count + 1):
+            raise NotImplementedError("ZeRO-1 step with a fused EMA (each rank only updates its shard): step without `ema=`, then call "
+                                      "opt.gather_state(reducer) and ArenaEMA.update(step) - the stand-alone pass must see exact masters")
+        ar = self.arena
+        n_red, dec, world = ar.bounds["no_decay"], ar.bounds["decay"], reducer.world
+        spans = sorted((sl[0], sl[1]) for sl in reducer.slices)
+        if not spans or spans[0][0] != 0 or spans[-1][1] != n_red or any(a[1] != b[0] for a, b in zip(spans[:-1], spans[1:])):
+            raise RuntimeError("ZeRO-1 step: the reducer's slices do not tile the optimised arena exactly once")
+        for lo, hi in spans:
+            if (hi - lo) % (4 * world) or lo % 4:
+                raise ValueError(f"ZeRO-1 step: slice [{lo}, {hi}) does not split into {world} shards of whole 16-byte groups (mode_adamw_step needs "
+                                 "n % 4 == 0 and 16-byte aligned pointers)")
+        if dec % 4:
+            raise ValueError("ZeRO-1 step: the decay / no-decay boundary of the arena is not 16-byte aligned")
+
+    @torch.no_grad()
+    def gather_state(self, reducer) -> None:
+        """After ZeRO-1 steps every rank holds current Adam moments (and, with ``zero1='bf16'``, exact fp32 masters) for its OWN shards only.
+        All-gathers ``exp_avg`` / ``exp_avg_sq`` per slice and the masters, so that ``state_dict()`` / a checkpoint written by any rank - or a
+        stand-alone ``ArenaEMA.update`` - sees the complete, exact state.  Collective: all ranks call it."""
+        self.gather_master(reducer)
+        if getattr(self, "_state_sharded", False):
+            evs = []
+            for sl in reducer.slices:
+                for buf in (self.exp_avg, self.exp_avg_sq):
+                    evs.append(reducer.all_gather_async(buf, sl[0], sl[1], after=None))
+            for e in evs:
+                if e is not None:
+                    torch.cuda.current_stream().wait_event(e)
+            self._state_sharded = False
 
     @torch.no_grad()
     def gather_master(self, reducer) -> None:
@@ -177,6 +211,9 @@ class FusedAdamW:
             raise RuntimeError("the parameter arena was rebuilt (model.to()/half()?): create a new FusedAdamW")
         if ar.grad is None:
             raise RuntimeError("no gradients: run a training forward + backward first")
+        use_zero1 = bool(zero1) and reducer is not None and eng.device.type == "cuda"
+        if use_zero1:
+            self._validate_zero1(reducer, zero1, ema)
         self.step_count += 1
         self._frozen = self._frozen_ranges()
         self._ema_now = (None, 0.0)
@@ -190,9 +227,7 @@ class FusedAdamW:
         events = train.events if (train is not None and train.events is not None) else None
         if reducer is not None and reducer.world > 1:
             grad_scale = grad_scale * (1.0 if reducer.average else 1.0 / reducer.world)
-        if zero1 and reducer is not None and eng.device.type == "cuda":
-            if zero1 not in ("fp32", "bf16"):
-                raise ValueError("zero1 must be None, 'fp32' or 'bf16'")
+        if use_zero1:
             self._step_zero1(grad_scale, reducer, zero1, lp, gd, gn)
         elif not overlap or events is None:
             if reducer is not None:
@@ -222,6 +257,9 @@ class FusedAdamW:
 
     # ---- checkpointing (same information as torch's optimizer state, flat)
     def state_dict(self) -> Dict:
+        if getattr(self, "_state_sharded", False) or getattr(self, "_master_sharded", False):
+            raise RuntimeError("FusedAdamW.state_dict(): after ZeRO-1 steps the moments (and with zero1='bf16' the fp32 masters) are current on "
+                               "each rank's own shards only - call opt.gather_state(reducer) on every rank first")
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
                 "param_groups": [dict(g) for g in self.param_groups]}
 
@@ -266,10 +304,14 @@ class ArenaEMA:
             self.flat = arena.flat.detach().clone()                       # starts as a copy of the weights (on_train_start)
 
     @torch.no_grad()
-    def update(self, step: int) -> None:
-        """Stand-alone EMA pass (when the optimizer is not FusedAdamW)."""
+    def update(self, step: int, optimizer=None) -> None:
+        """Stand-alone EMA pass (when the optimizer is not FusedAdamW, or after ZeRO-1 steps).  Pass the ``FusedAdamW`` as ``optimizer`` to have
+        sharded (bf16-rounded) masters refused instead of averaged."""
         if not self.should_apply(step):
             return
+        if optimizer is not None and (getattr(optimizer, "_master_sharded", False)):
+            raise RuntimeError("ArenaEMA.update(): the fp32 masters of the other ranks' shards are bf16-rounded after zero1='bf16' steps - call "
+                               "optimizer.gather_state(reducer) first")
         eng = self.model.engine
         self.ensure(eng.arena)
         n = eng.arena.bounds["total"]

@@ -26,17 +26,25 @@ def _with_zero(s: torch.Tensor) -> torch.Tensor:
     return torch.cat([s, s.new_zeros([1])])
 
 
+def tag_schedule(sigmas: torch.Tensor, *key) -> torch.Tensor:
+    """Attach the host-side identity of a schedule's VALUES (generator name + arguments) to the tensor object.  ``MoDEAgent.denoise_actions``
+    builds a fresh schedule tensor for every chunk (mode_agent.py:752, 842-861); the fused sampler recognises an unchanged schedule by this tag
+    instead of comparing device values (a host sync) or trusting a recyclable data pointer."""
+    sigmas._mode_sched = (key, str(sigmas.device), str(sigmas.dtype))
+    return sigmas
+
+
 def get_sigmas_vp(n, beta_d=19.9, beta_min=0.1, eps_s=1e-3, device="cpu"):
     """Continuous VP schedule sigma(t) = sqrt(exp(beta_d t^2 / 2 + beta_min t) - 1), t from 1 to eps_s (gc_sampling.py:84-88)."""
     t = torch.linspace(1, eps_s, n, device=device)
-    return _with_zero(torch.sqrt(torch.exp(beta_d * t ** 2 / 2 + beta_min * t) - 1))
+    return tag_schedule(_with_zero(torch.sqrt(torch.exp(beta_d * t ** 2 / 2 + beta_min * t) - 1)), "vp", n, beta_d, beta_min, eps_s)
 
 
 def get_sigmas_ve(n, sigma_min=0.02, sigma_max=100, device="cpu"):
     """Geometric variance schedule as the reference computes it (gc_sampling.py:61-68; note its index ramp runs to n+1, not n-1)."""
     t = torch.linspace(0, n + 1, n, device=device)
     var = (sigma_max ** 2) * ((sigma_min ** 2 / sigma_max ** 2) ** (t / (n - 1)))
-    return _with_zero(torch.sqrt(var))
+    return tag_schedule(_with_zero(torch.sqrt(var)), "ve", n, sigma_min, sigma_max)
 
 
 def cosine_beta_schedule(n, s=0.008, device="cpu"):
@@ -45,7 +53,7 @@ def cosine_beta_schedule(n, s=0.008, device="cpu"):
     acp = np.cos(((grid / (n + 1)) + s) / (1 + s) * np.pi * 0.5) ** 2
     acp = acp / acp[0]
     betas = np.clip(1 - acp[1:] / acp[:-1], 0, 0.999)
-    return _with_zero(torch.tensor(betas[::-1].copy(), device=device, dtype=torch.float32))
+    return tag_schedule(_with_zero(torch.tensor(betas[::-1].copy(), device=device, dtype=torch.float32)), "cosine_beta", n, s)
 
 
 def get_iddpm_sigmas(n, sigma_min=0.02, sigma_max=100, M=1000, j_0=0, C_1=0.001, C_2=0.008, device="cpu"):
@@ -60,7 +68,7 @@ def get_iddpm_sigmas(n, sigma_min=0.02, sigma_max=100, M=1000, j_0=0, C_1=0.001,
         u[j - 1] = ((u[j] ** 2 + 1) / (ab[j - 1] / ab[j]).clip(min=C_1) - 1).sqrt()
     kept = u[torch.logical_and(u >= sigma_min, u <= sigma_max)].numpy()
     pick = np.round((len(kept) - 1) / (n - 1) * np.arange(n, dtype=np.float64)).astype(np.int64)
-    return _with_zero(torch.tensor(kept[pick], dtype=torch.float64, device=device)).to(torch.float32)
+    return tag_schedule(_with_zero(torch.tensor(kept[pick], dtype=torch.float64, device=device)).to(torch.float32), "iddpm", n, sigma_min, sigma_max, M, j_0, C_1, C_2)
 
 
 # ------------------------------------------------------------------------------------------------------------------ primitives
@@ -109,6 +117,11 @@ class _Run:
         self.callback, self.scaler, self.x_key = callback, scaler, x_key
 
     def denoise(self, x, sigma):
+        fast = getattr(self.model, "denoise_uniform", None)              # GCDenoiser over the HIP MoDeDiT: one hipGraph replay per call
+        if fast is not None and not self.kw and torch.is_tensor(sigma) and sigma.numel() == 1:
+            out = fast(self.state, x, self.goal, sigma)
+            if out is not None:
+                return out
         return self.model(self.state, x, self.goal, sigma * self.ones, **self.kw)
 
     def report(self, x, i, sigma, sigma_hat, denoised):

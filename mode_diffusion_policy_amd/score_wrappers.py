@@ -61,5 +61,14 @@ class GCDenoiser(nn.Module):
         c_skip, c_out, c_in = [append_dims(x, action.ndim) for x in self.get_scalings(sigma)]
         return m(state, action * c_in, goal, sigma, **kwargs) * c_out + action * c_skip
 
+    def denoise_uniform(self, state, action, goal, sigma):
+        """D(x; sigma) for ONE noise level shared by the whole batch (what every k-diffusion style sampler asks for: ``sigma * ones``), as one
+        hipGraph replay of the HIP chain (``MoDeDiT.denoise_graphed``).  Returns None when the fast path does not apply (training mode, token /
+        goal routing, a foreign inner model) - the caller then takes ``forward``."""
+        m = self.inner_model
+        if isinstance(m, MoDeDiT) and not m.training and not torch.is_grad_enabled():
+            return m.denoise_graphed(state, action, goal, sigma, self.sigma_data)
+        return None
+
     def get_params(self):
         return self.inner_model.parameters()

@@ -95,26 +95,36 @@ class TrainState:
             self._ev_arr = (C.c_void_p * n)(*[ev.cuda_event for ev in self.events])
         return C.cast(self._ev_arr, C.c_void_p)
 
-    def grad_tables(self):
-        """ctypes tables pointing the backward chain at the gradient arena (built once per arena)."""
+    def grad_tables(self, flat=None):
+        """ctypes tables pointing the backward chain at a gradient buffer with the arena's layout: the gradient arena itself (built once,
+        cached) or ``flat`` - a per-backward buffer (autograd-visible gradients / accumulation).  Returns (tables, views-by-parameter-name)."""
         eng = self.eng
         ar = eng.arena
         m = eng.model
-        ar.ensure_grad(m)
-        if self.grads_for != id(ar.grad):
-            g = ar.g
-            lgr = (L.ModeLayerGrads * m.num_layers)()
-            for i in range(m.num_layers):
-                for fld, _ in L.ModeLayerGrads._fields_:
-                    t = g[fld][i] if fld in g else g[f"l{i}.{fld}"]          # routers / norm gains are stacked over layers
-                    setattr(lgr[i], fld, t.data_ptr())
-            mg = L.ModeModelGrads()
-            for fld in ("pos", "w_se", "b_se", "w_sl", "w_tok", "w_goal", "w_act", "ln_g", "w_out", "b_out"):
-                setattr(mg, fld, g[fld].data_ptr())
-            mg.layers = C.cast(lgr, C.POINTER(L.ModeLayerGrads))
-            self._lgr, self._mg = lgr, mg
-            self.grads_for = id(ar.grad)
-        return self._mg
+        if flat is None:
+            ar.ensure_grad(m)
+            if self.grads_for != id(ar.grad):
+                self._mg, self._lgr = self._tables(ar.g)
+                self.grads_for = id(ar.grad)
+            return self._mg, ar.g_by_name
+        from .arena import param_views
+        g = ar._views(flat)
+        mg, lgr = self._tables(g)
+        self._tmp_tables = (mg, lgr)                                            # keep the ctypes arrays alive across the launch
+        return mg, param_views(m, g)
+
+    def _tables(self, g):
+        m = self.eng.model
+        lgr = (L.ModeLayerGrads * m.num_layers)()
+        for i in range(m.num_layers):
+            for fld, _ in L.ModeLayerGrads._fields_:
+                t = g[fld][i] if fld in g else g[f"l{i}.{fld}"]              # routers / norm gains are stacked over layers
+                setattr(lgr[i], fld, t.data_ptr())
+        mg = L.ModeModelGrads()
+        for fld in ("pos", "w_se", "b_se", "w_sl", "w_tok", "w_goal", "w_act", "ln_g", "w_out", "b_out"):
+            setattr(mg, fld, g[fld].data_ptr())
+        mg.layers = C.cast(lgr, C.POINTER(L.ModeLayerGrads))
+        return mg, lgr
 
 
 class _Run:
@@ -123,12 +133,13 @@ class _Run:
 
 
 class _DitTrainFn(torch.autograd.Function):
-    """Outputs: F (B, A_len, A), the load-balancing loss and the router z-loss of this forward (scalars).  One backward serves all three."""
+    """Outputs: F (B, A_len, A), the load-balancing loss and the router z-loss of this forward (scalars).  One backward serves all three.
+    Inputs: the (fp32, on-device) state_images and preprocessed goals - so that an upstream encoder trains through the denoiser like it does
+    in the reference (mode_agent.py:404-411, 548-567) - and every parameter that can receive a gradient."""
 
     @staticmethod
-    def forward(ctx, run, *params):
+    def forward(ctx, run, img, goals, *params):
         ctx.run = run
-        ctx.n = len(params)
         ctx.set_materialize_grads(False)                         # unused outputs hand None to backward, not zero tensors
         return run.F, run.lb_loss, run.z_loss
 
@@ -137,8 +148,8 @@ class _DitTrainFn(torch.autograd.Function):
         run = ctx.run
         if dF is None:
             dF = torch.zeros_like(run.F)
-        grads = run.backward(dF.contiguous().float(), dlb, dz)
-        return (None, *grads)
+        d_img, d_goal, grads = run.backward(dF.contiguous().float(), dlb, dz, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return (None, d_img, d_goal, *grads)
 
 
 class _EdmLossFn(torch.autograd.Function):
@@ -169,18 +180,18 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     if B == 0:
         raise ValueError("training forward needs at least one sample")
     N, A_len, A = B * T, model.action_seq_len, model.action_dim
-    if torch.is_grad_enabled():
-        # The HIP backward produces parameter gradients only.  An upstream module that expects a gradient through one of the inputs (the
-        # reference trains its FiLM-ResNet encoders through state_images, mode_agent.py:548-567) would silently train on zeros: refuse.
-        for nm, t in (("states['state_images']", states["state_images"]), ("goals", goals), ("actions", actions)):
-            if torch.is_tensor(t) and t.requires_grad:
-                raise NotImplementedError(f"MoDeDiT (HIP) training forward: {nm} requires grad, but the backward chain returns no input gradients "
-                                          "(detach the input, or freeze the upstream encoder)")
+    if torch.is_grad_enabled() and torch.is_tensor(actions) and actions.requires_grad:
+        # d state_images and d goals are outputs of the backward chain (the reference trains its FiLM-ResNets through state_images,
+        # mode_agent.py:548-567); nothing upstream of the ACTIONS is trainable in the reference (they come from the dataset).
+        raise NotImplementedError("MoDeDiT (HIP) training forward: actions require grad, but the backward chain returns gradients for "
+                                  "state_images, goals and the parameters only (detach the actions)")
     f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
-    img = f(states["state_images"])
+    img_in = states["state_images"].to(device=dev, dtype=torch.float32)       # autograd-tracked casts: the node below returns d img_in / d goal_in
+    img = img_in.detach().contiguous()
     if img.dim() != 3 or img.shape[1] != model.n_img_tokens or img.shape[2] != model.obs_dim:
         raise ValueError(f"state_images must be (B, {model.n_img_tokens}, {model.obs_dim}), got {tuple(img.shape)}")
-    gl = f(model.preprocess_goals(goals, 1, uncond=bool(uncond))).reshape(B, -1).contiguous()      # incl. the Bernoulli goal mask
+    goal_in = model.preprocess_goals(goals.to(device=dev, dtype=torch.float32), 1, uncond=bool(uncond))      # incl. the Bernoulli goal mask
+    gl = goal_in.detach().reshape(B, -1).contiguous()
     acts = f(actions)
     model._check_batch(B, img, gl, acts)
     sig = f(sigma).reshape(-1)
@@ -255,13 +266,25 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     model._last_topk = idx
 
     keep_alive = (img, gl, acts, sig, e1, emb_t, img_e, goal_e, cond, idx, w, probs, shifted, r_pre, meta, act_rows, stash)
-    params = list(model.parameters())
-    names = [n for n, _ in model.named_parameters()]
+    # Function inputs = the parameters that can receive a gradient.  gripper_embed.weight is dead in the reference too (modedit.py:684): left out,
+    # so that DistributedDataParallel(find_unused_parameters=True) - how the reference trains, training_calvin.py:92-103 - sees it as unused.
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and n != "gripper_embed.weight"]
+    names, params = [n for n, _ in named], [p for _, p in named]
 
-    def backward(dF: torch.Tensor, dlb=None, dz=None):
-        """Writes every parameter gradient straight into the gradient arena and points ``p.grad`` at its slice.  The first backward after an
-        optimizer step (or ``zero_grad``) overwrites; further ones accumulate.  ``dlb`` / ``dz``: upstream gradients of the two auxiliary
-        router losses (None = not part of the loss)."""
+    def backward(dF: torch.Tensor, dlb=None, dz=None, want_img=False, want_goal=False):
+        """Runs the backward chain.  ``model.grad_mode``:
+
+        * ``"autograd"`` (default; what a foreign trainer - Lightning, torch DDP, hook-driven clipping - needs): every parameter gradient is
+          handed to autograd (views of one flat per-backward buffer with the arena's layout), so AccumulateGrad accumulates and its hooks fire
+          exactly as for the reference module.
+        * ``"arena"`` (set by ``FusedAdamW`` / ``ArenaGradReducer.for_model``): gradients are written straight into the gradient arena and
+          ``p.grad`` points at its slices; autograd sees None.  The first backward after an optimizer step overwrites, further ones accumulate.
+
+        ``dlb`` / ``dz``: upstream gradients of the two auxiliary router losses (None = not part of the loss).  Returns
+        (d state_images, d goals, [parameter gradients])."""
+        grad_mode = getattr(model, "grad_mode", "autograd")
+        if grad_mode not in ("autograd", "arena"):
+            raise ValueError(f"MoDeDiT.grad_mode must be 'autograd' or 'arena', got {grad_mode!r}")
         keep_aux = []
         args.shifted = args.aux_lb_coef = args.aux_z_coef = None
         if dlb is not None:                                                       # LB = mean_l E sum_e mean_n(rp[n,e]) f_{l,e}: linear in the combine weights
@@ -270,34 +293,45 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         if dz is not None:
             zc = (dz.reshape(1).float() * (2.0 / (Ly * B))).contiguous()
             keep_aux.append(zc); args.aux_z_coef = zc.data_ptr(); args.shifted = shifted.data_ptr()
+        d_img = torch.empty(B, model.n_img_tokens, model.obs_dim, device=dev) if want_img else None
+        d_goal = torch.empty(tuple(goal_in.shape), device=dev) if want_goal else None
+        args.d_state_images, args.d_goals = _ptr(d_img), _ptr(d_goal)
         ts.ensure()
-        mg = ts.grad_tables()
         ar = eng.arena
         wsb = lib.mode_dit_train_workspace_bytes(C.byref(d), B, eng.dt)
         if ts._ws is None or ts._ws.numel() < wsb:
             ts._ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        # A second backward before the optimizer consumed the first one (gradient accumulation; the reference's training_step sums the losses of
-        # several modalities, mode_agent.py:386-440) must ADD, like autograd does.  The chain overwrites the arena, so the earlier sum is parked
-        # in a side buffer around the launch (2.7 GB copy + add: the rare path; one backward per step pays nothing).
         nred = ar.bounds["no_decay"]
-        carry = None
-        if getattr(ar, "grad_pending", False) and any(p.grad is not None for p in params if p.requires_grad):
-            carry = ar.grad[:nred].clone()
+        all_params = list(model.parameters())
+        # The chain OVERWRITES its gradient buffer.  Straight into the arena when that is what the step wants (arena mode, first backward after
+        # the optimizer consumed the previous sum); otherwise into a buffer of its own: handed to autograd (autograd mode), or ADDED to the
+        # arena - a second backward before the optimizer step must accumulate like autograd does (the reference's training_step sums the losses
+        # of several modalities, mode_agent.py:386-440).
+        accumulate = grad_mode == "arena" and getattr(ar, "grad_pending", False) and any(p.grad is not None for p in all_params if p.requires_grad)
+        own = grad_mode != "arena" or accumulate
+        flat = torch.empty(ar.bounds["total"], device=dev) if own else None
+        mg, gv = ts.grad_tables(flat)
         L.check(lib.mode_dit_backward(C.byref(d), C.byref(eng._mw), C.byref(ts.wt), C.byref(args), stash.data_ptr(), dF.data_ptr(), C.byref(mg),
                                       ts._ws.data_ptr(), ts._ws.numel(), _stream()), "backward")
-        if carry is not None:
-            ar.grad[:nred].add_(carry)
+        if grad_mode != "arena":
+            return d_img, d_goal, [gv[n].view(p.shape) for n, p in zip(names, params)]
+        if accumulate:
+            ar.grad[:nred].add_(flat[:nred])
+            # the per-block events the chain recorded mid-way now precede this add: re-record them behind it, or an overlapped optimizer /
+            # reducer (FusedAdamW.step(overlap=True), ArenaGradReducer) gated on events[l] would read block l before its sum is complete
+            if ts.events is not None:
+                for ev in ts.events:
+                    ev.record()
+            gv = ar.g_by_name
         ar.grad_pending = True                                                  # cleared by FusedAdamW.step()/zero_grad() or p.grad = None
-        gv = ar.g_by_name
         for n, p in zip(names, params):
-            if p.requires_grad and n != "gripper_embed.weight":               # dead in the reference too (modedit.py:684): grad stays None
-                if p.grad is None or p.grad.data_ptr() != gv[n].data_ptr():
-                    p.grad = gv[n].view(p.shape)
-        return [None] * len(params)
+            if p.grad is None or p.grad.data_ptr() != gv[n].data_ptr():
+                p.grad = gv[n].view(p.shape)
+        return d_img, d_goal, [None] * len(params)
 
     run.F, run.backward, run.keep = F, backward, keep_alive
     run.lb_loss, run.z_loss = lb.mean(), zl.mean()
-    Fo, lb_o, z_o = _DitTrainFn.apply(run, *params)
+    Fo, lb_o, z_o = _DitTrainFn.apply(run, img_in, goal_in, *params)
     model._aux_losses = (lb_o, z_o)                                             # what load_balancing_loss() / compute_router_z_loss() return in training
     return Fo
 

@@ -35,11 +35,13 @@ def test_header_symbols_all_exported():
     assert lib.mode_hip_status_string(-2).decode().startswith("unsupported")
     assert lib.mode_set_option(b"gemm_cfg", 0) == 0 and lib.mode_set_option(b"nope", 1) == -2
     for key, default, bad in ((b"dn_split_k", 0, 9), (b"gemm_skinny_rows", 32, -1), (b"fuse_ln2", 1, None), (b"adamw_blocks", 0, None),
-                              (b"combine_row_max", 0x7fffffff, -1), (b"gemm_pp", 1, None), (b"gemm_pp_min_tiles", 200, None), (b"pp_flags", 0, None),
-                              (b"gemm_setprio", 1, None), (b"gemm_group_m", 0, None), (b"gemm_tr_cfg", 0, None), (b"gemm_mid_rows", 128, -1)):
+                              (b"combine_row_max", 0x7fffffff, -1), (b"gemm_pp", 1, None), (b"gemm_pp_min_tiles", 200, None),
+                              (b"gemm_group_m", 0, None), (b"gemm_tr_cfg", 0, None), (b"gemm_mid_rows", 128, -1)):
         assert lib.mode_set_option(key, default) == 0, key                                  # documented knobs exist (include/mode_hip.h)
         if bad is not None:
             assert lib.mode_set_option(key, bad) != 0, key
+    for key in (b"pp_flags", b"pp_trace_lo", b"pp_trace_hi", b"attn_bwd_stop", b"gemm_setprio"):
+        assert lib.mode_set_option(key, 0) == -2, key                                       # result-changing ablation switches / trace buffers do not ship
 
 
 def test_mode_hip_opts_env(monkeypatch):

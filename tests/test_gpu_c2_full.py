@@ -1,0 +1,123 @@
+"""GPU: the BENCHMARKED workload itself against the oracle - BASELINE configs[1] / configs[2] at full size (12 layers, d = 1024, 8 heads,
+4 experts top-2, obs 2048, goal 512, B = 128): one forward at a schedule noise level, the whole 10-step DDIM chunk, and one score-matching
+training step (stochastic path: multinomial routing + both dropouts, SHARED randomness) - twelve layers of error accumulation asserted as a
+number, not a property.  The oracle (fp32 CPU restatement, pinned to the reference by tests/golden) takes ~1-3 s per forward on the host.
+
+Tolerances: tests/tolerances.py (fp32 1e-3; bf16 outputs 2e-2 / loss 1e-2 / gradients 4e-2, conditional on identical routing - which is
+asserted bit-exact for every layer and every sampler step)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import mode_diffusion_policy_amd as M  # noqa: E402
+from oracle import mode_oracle as O  # noqa: E402
+from oracle.weights import get_config, make_inputs, make_state_dict  # noqa: E402
+from tolerances import GRAD, LOSS, OUT  # noqa: E402
+
+B, SEED = 128, 400
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double().cpu(); b = torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _model(cfg, sd, dtype, **over):
+    kw = dict(obs_dim=cfg.obs_dim, goal_dim=cfg.goal_dim, device="cuda", goal_conditioned=True, action_dim=7, embed_dim=cfg.embed_dim,
+              embed_pdrob=0, attn_pdrop=0.3, mlp_pdrop=0.1, goal_drop=0.0, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=1,
+              obs_seq_len=1, action_seq_len=10, num_experts=cfg.num_experts, top_k=cfg.top_k, compute_dtype=dtype)
+    kw.update(over)
+    m = M.MoDeDiT(**kw)
+    m.load_state_dict(sd)
+    return m.to("cuda")
+
+
+@pytest.fixture(scope="module")
+def c2():
+    cfg = get_config("c2")
+    sd = make_state_dict(cfg, SEED)
+    inp = make_inputs(cfg, B, SEED + 1)
+    sched = M.get_sigmas_exponential(10, 1e-3, 80.0)
+    # precondition of "bit-exact routing": the fixture's smallest top-k margin over the whole schedule (fp32 CPU vs fp32 MFMA differ by ~1e-7)
+    emb = O.sigma_embedding(sd, sched[:-1])
+    margin = 1.0
+    for l in range(cfg.n_layers):
+        _, p = O.router_probs(sd, l, emb)
+        top = p.sort(-1, descending=True).values
+        margin = min(margin, float((top[:, cfg.top_k - 1] - top[:, cfg.top_k]).min()))
+    assert margin > 1e-5, margin
+    with torch.no_grad():
+        ref_f, aux = O.dit_forward(sd, cfg, inp["state_images"], inp["actions"], inp["goals"], sched[3] * torch.ones(B), return_aux=True)
+        ref_x, ref_trace = O.sample_ddim(sd, cfg, 0.5, inp["state_images"], inp["x0"], inp["goals"], sched, trace=True)
+    return dict(cfg=cfg, sd=sd, inp=inp, sched=sched, ref_f=ref_f, aux=aux, ref_x=ref_x, ref_trace=ref_trace, margin=margin)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_c2_full_forward_and_ddim_vs_oracle(c2, dtype):
+    cfg, sd, inp, sched = c2["cfg"], c2["sd"], c2["inp"], c2["sched"]
+    m = _model(cfg, sd, dtype).eval()
+    c = {k: v.cuda() for k, v in inp.items()}
+    st = {"state_images": c["state_images"]}
+    with torch.no_grad():
+        f = m(st, c["actions"], c["goals"], (sched[3] * torch.ones(B)).cuda())
+    idx = m._last_topk.cpu().long()                                             # [L, R, k]
+    want = torch.stack(c2["aux"].topk_idx)[:, :, 0, :]                            # [L, B, k]: every sample routes alike at a shared sigma
+    assert torch.equal(idx.expand_as(want) if idx.shape[1] == 1 else idx, want)
+    e_f = rel(f, c2["ref_f"])
+    den = M.GCDenoiser(m, 0.5).eval()
+    steps = []
+    x = M.sample_ddim(den, st, c["x0"], c["goals"], sched.cuda(), disable=True, callback=lambda d: steps.append(d["action"].clone()))
+    xg = M.sample_ddim(den, st, c["x0"], c["goals"], sched.cuda(), disable=True)                # the benchmarked path: one hipGraph replay
+    e_x, e_g = rel(x, c2["ref_x"]), rel(xg, c2["ref_x"])
+    # routing of ALL sampler steps (resolved up front by the fused sampler): [L, n, k] against the oracle's router at every schedule level
+    emb = O.sigma_embedding(sd, sched[:-1])
+    for l in range(cfg.n_layers):
+        _, p = O.router_probs(sd, l, emb)
+        wi, _ = O.topk_route(p, cfg.top_k, cfg.router_normalize)
+        assert torch.equal(m._last_topk[l].cpu().long(), wi), l
+    print(f"C2 B=128 {dtype}: forward rel-L2 {e_f:.2e}, 10-step DDIM rel-L2 {e_x:.2e} (graph {e_g:.2e}); tol {OUT[dtype]:g}; top-k margin {c2['margin']:.1e}")
+    assert e_f < OUT[dtype] and e_x < OUT[dtype] and e_g < OUT[dtype]
+    assert rel(x, xg) < OUT[dtype]                                              # generic (callback) path vs the fused hipGraph path
+
+
+def test_c2_full_training_step_vs_oracle_shared_randomness(c2):
+    """configs[2]: the score-matching loss of the full model at B = 128 on the path the bench times (train mode, per-token multinomial routing,
+    attention + expert dropout), loss and a sample of gradients from every part of the network against the oracle's autograd, for both compute
+    modes on the SAME draw (the fp32 router makes the sampled expert ids identical in both)."""
+    cfg, sd, inp = c2["cfg"], c2["sd"], c2["inp"]
+    sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(3))
+    c = {k: v.cuda() for k, v in inp.items()}
+    names = ["tok_emb.weight", "goal_emb.weight", "action_emb.weight", "sigma_linear.weight", "pos_emb", "out.weight", "ln.g",
+             "blocks.0.attn.query.weight", "blocks.0.attn.key.bias", "blocks.0.attn.c_proj.weight", "blocks.0.ln_1.g", "blocks.5.ln_2.g",
+             "blocks.0.router.router.mlp.0.weight", "blocks.6.router.router.mlp.3.weight", "blocks.3.experts.expert_1.mlp.0.project.weight",
+             "blocks.11.experts.expert_2.mlp.2.weight", "blocks.11.experts.expert_0.mlp.0.project.bias", "blocks.7.attn.q_norm.g"]
+    runs = {}
+    for dtype in ("bf16", "fp32"):
+        m = _model(cfg, sd, dtype).train()
+        den = M.GCDenoiser(m, 0.5).train()
+        torch.manual_seed(77)                                                   # multinomial draw (device generator) + dropout step seed (host generator)
+        torch.cuda.manual_seed(77)
+        loss, F = den.loss({"state_images": c["state_images"]}, c["actions"], c["goals"], c["noise"], sig.cuda())
+        loss.backward()
+        runs[dtype] = dict(loss=float(loss), F=F.detach().cpu(), idx=m._last_topk.cpu().long(), seed=m._last_seed,
+                           grads={n: p.grad.detach().cpu() for n, p in m.named_parameters() if n in names})
+        del m, den
+        torch.cuda.empty_cache()
+    assert torch.equal(runs["bf16"]["idx"], runs["fp32"]["idx"]) and runs["bf16"]["seed"] == runs["fp32"]["seed"]
+    idx = runs["bf16"]["idx"]
+    sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    ref_loss, ref_F = O.denoiser_loss(sdg, cfg, 0.5, inp["state_images"], inp["actions"], inp["goals"], inp["noise"], sig,
+                                      topk_idx=[idx[l].view(B, cfg.seq_len, cfg.top_k) for l in range(cfg.n_layers)],
+                                      dropout=dict(seed=runs["bf16"]["seed"], attn_p=0.3, mlp_p=0.1))
+    ref_loss.backward()
+    for dtype in ("fp32", "bf16"):
+        r = runs[dtype]
+        e_l = abs(r["loss"] - float(ref_loss)) / abs(float(ref_loss))
+        e_F = rel(r["F"], ref_F.detach())
+        worst = max((rel(r["grads"][n], sdg[n].grad), n) for n in names)
+        print(f"C2 B=128 train {dtype}: loss rel err {e_l:.2e}, F rel-L2 {e_F:.2e}, worst sampled gradient {worst[0]:.2e} ({worst[1]})")
+        assert e_l < LOSS[dtype] and e_F < OUT[dtype]
+        for n in names:
+            assert rel(r["grads"][n], sdg[n].grad) < GRAD[dtype], (dtype, n, rel(r["grads"][n], sdg[n].grad))

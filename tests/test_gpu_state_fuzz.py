@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 import mode_diffusion_policy_amd as M  # noqa: E402
 from oracle import mode_oracle as O  # noqa: E402
 from oracle.weights import get_config, make_inputs, make_state_dict  # noqa: E402
+from tolerances import BF16_LOSS, BF16_OUT, FP32_LOSS, FP32_OUT  # noqa: E402
 
 
 def rel(a, b):
@@ -21,7 +22,7 @@ def rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_OUT), ("bf16", BF16_OUT)])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MODE_FUZZ_STATE_SEEDS", "2"))))
 def test_random_call_sequence_vs_oracle(seed, dtype, tol):
     cfg = get_config("c1e4")
@@ -85,7 +86,7 @@ def test_random_call_sequence_vs_oracle(seed, dtype, tol):
             sdg = {k: v.clone().requires_grad_(True) for k, v in cur.items()}
             ref_loss, _ = O.denoiser_loss(sdg, cfg, 0.5, inp["state_images"], inp["actions"], inp["goals"], inp["noise"], sig)
             ref_loss.backward()
-            assert abs(float(loss) - float(ref_loss)) < (1e-4 if dtype == "fp32" else 2e-2) * abs(float(ref_loss)), (step, log)
+            assert abs(float(loss) - float(ref_loss)) < (FP32_LOSS if dtype == "fp32" else BF16_LOSS) * abs(float(ref_loss)), (step, log)
             with torch.no_grad():
                 for name, p in m.named_parameters():
                     if p.grad is not None and sdg[name].grad is not None:

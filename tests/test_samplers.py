@@ -13,6 +13,7 @@ import mode_diffusion_policy_amd as M
 from mode_diffusion_policy_amd import gc_sampling, samplers
 from oracle import mode_oracle as O
 from oracle.weights import get_config, make_inputs, make_state_dict
+from tolerances import BF16_OUT, FP32_OUT
 
 RUNS = {
     "euler": lambda den, st, x0, g, s: samplers.sample_euler(den, st, x0, g, s, disable=True),
@@ -145,7 +146,7 @@ def test_remaining_samplers_vs_reference_on_oracle_denoiser(golden):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_OUT), ("bf16", BF16_OUT)])
 def test_samplers_on_hip_denoiser(golden, dtype, tol):
     g = golden("F10_samplers")
     cfg = get_config("c1e4"); sd = make_state_dict(cfg, int(g["seed"])); inp = {k: v.cuda() for k, v in make_inputs(cfg, 8, int(g["seed"]) + 1).items()}
