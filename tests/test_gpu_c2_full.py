@@ -3,8 +3,8 @@
 training step (stochastic path: multinomial routing + both dropouts, SHARED randomness) - twelve layers of error accumulation asserted as a
 number, not a property.  The oracle (fp32 CPU restatement, pinned to the reference by tests/golden) takes ~1-3 s per forward on the host.
 
-Tolerances: tests/tolerances.py (fp32 1e-3; bf16 outputs 2e-2 / loss 1e-2 / gradients 4e-2, conditional on identical routing - which is
-asserted bit-exact for every layer and every sampler step)."""
+Tolerances: tests/tolerances.py (fp32 1e-3; bf16 outputs 2e-2 / loss 1e-2 / full-depth gradients 8e-2, conditional on identical routing -
+which is asserted bit-exact for every layer and every sampler step)."""
 import numpy as np
 import pytest
 import torch
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 import mode_diffusion_policy_amd as M  # noqa: E402
 from oracle import mode_oracle as O  # noqa: E402
 from oracle.weights import get_config, make_inputs, make_state_dict  # noqa: E402
-from tolerances import GRAD, LOSS, OUT  # noqa: E402
+from tolerances import BF16_GRAD_FULL_DEPTH, BF16_TRAIN_OUT, FP32_GRAD, FP32_OUT, LOSS, OUT  # noqa: E402
 
 B, SEED = 128, 400
 
@@ -118,6 +118,6 @@ def test_c2_full_training_step_vs_oracle_shared_randomness(c2):
         e_F = rel(r["F"], ref_F.detach())
         worst = max((rel(r["grads"][n], sdg[n].grad), n) for n in names)
         print(f"C2 B=128 train {dtype}: loss rel err {e_l:.2e}, F rel-L2 {e_F:.2e}, worst sampled gradient {worst[0]:.2e} ({worst[1]})")
-        assert e_l < LOSS[dtype] and e_F < OUT[dtype]
+        assert e_l < LOSS[dtype] and e_F < (FP32_OUT if dtype == "fp32" else BF16_TRAIN_OUT)
         for n in names:
-            assert rel(r["grads"][n], sdg[n].grad) < GRAD[dtype], (dtype, n, rel(r["grads"][n], sdg[n].grad))
+            assert rel(r["grads"][n], sdg[n].grad) < (FP32_GRAD if dtype == "fp32" else BF16_GRAD_FULL_DEPTH), (dtype, n, rel(r["grads"][n], sdg[n].grad))
