@@ -59,7 +59,7 @@ const char* mode_hip_status_string(int status);
  * that changes results (the round-2 timing ablations and cycle-stamp buffers of the GEMM kernels were removed from the product).
  * "gemm_cfg": bf16 forward GEMM tile geometry, 0 = auto (default), 1 = 128x128 ring-2, 4 = 128x64 ring-3, 6 = 128x128 single-buffered
  *   (3 workgroups/CU), 8 = 128x64 ring-2, 13 = 128x128 single-buffered with <= 128 VGPRs (4 workgroups/CU), 14 = 64x64 ring-3 (no SwiGLU),
- *   16 / 17 = persistent ping-pong kernel with 256 / 224-row x 256-column tiles (gemm_bf16_pp.hip; epilogues NONE / BIAS / SWIGLU).
+ *   17 = persistent ping-pong kernel with 224-row x 256-column tiles (gemm_bf16_pp.hip; epilogues NONE / BIAS / SWIGLU).
  *   Every forward geometry produces bit-identical results (k-ordered fp32 MFMA chain, explicit-fma epilogues).
  * "gemm_pp": 1 (default) = the heuristic may pick geometry 17; "gemm_pp_min_tiles": tile count from which it does (default 200).
  * "gemm_group_m": m-tiles per XCD rasterisation group of the ring kernels (0 = default).

@@ -401,8 +401,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
 // (ids 2, 3, 5, 7, 9-12, 15 were measured-and-rejected geometries of round 1 - deeper rings, 256-wide one-barrier tiles, a persistent 256x256 kernel with
 // a serial epilogue - removed once the ping-pong kernel superseded them; the numbers stay in DESIGN.md)
 enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x64_NS3 = 4, CFG_128x128_NS1 = 6, CFG_128x64_NS2 = 8, CFG_128x128_NS1_4WG = 13, CFG_64x64_NS3 = 14,
-       CFG_PP256 = 16, CFG_PP224 = 17 };
-int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p, int rows224, hipStream_t s);   // gemm_bf16_pp.hip: persistent ping-pong 8-phase kernel
+       CFG_PP224 = 17 };
+int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_pp.hip: persistent ping-pong kernel, 224 x 256 tiles
 int gemm_bf16_skinny_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_skinny.hip: weight streamer for a handful of rows
 int gemm_bf16_mid_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);      // gemm_bf16_skinny.hip: register-resident weights, no K loop (a few hundred rows)
 int g_gemm_mid_rows = 128;   // "gemm_mid_rows" option: ungrouped K = 1024 GEMMs with at most this many rows take gemm_bf16_mid_kernel (0 = off).  Measured chunk latency B = 4: 6.89 -> 6.60 ms, B = 8: 7.40 -> 7.14 ms; from ~200 rows on the M/32 re-reads of W through L2 cost more than the ring kernel (B = 16: 8.41 -> 8.50 ms, B = 32: 9.21 -> 9.48 ms)
@@ -521,8 +521,8 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
     if (rc != MODE_ERR_UNSUPPORTED) return rc;
   }
   int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d, g_gemm_pp != 0);
-  if (cfg == CFG_PP256 || cfg == CFG_PP224) {
-    const int rc = gemm_bf16_pp_launch(d, p, cfg == CFG_PP224, s);
+  if (cfg == CFG_PP224) {
+    const int rc = gemm_bf16_pp_launch(d, p, s);
     if (rc != MODE_ERR_UNSUPPORTED) return rc;
     cfg = pick_cfg(d, false);                                      // shapes / epilogues the ping-pong kernel does not take
   }

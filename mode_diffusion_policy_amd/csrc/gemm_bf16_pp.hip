@@ -578,9 +578,11 @@ static int pp_launch(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   return MODE_OK;
 }
 
-// Entered from gemm_bf16_launch with a validated descriptor and a filled parameter block; rows224 selects the 224-row tile.  Returns
-// MODE_ERR_UNSUPPORTED for shapes / epilogues this kernel does not take (the caller falls back to the 128x128 family).
-int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, int rows224, hipStream_t s) {
+// Entered from gemm_bf16_launch with a validated descriptor and a filled parameter block.  Returns MODE_ERR_UNSUPPORTED for shapes /
+// epilogues this kernel does not take (the caller falls back to the 128x128 family).  Only the 224-row tile (FM1 = 3) is instantiated: the
+// 256-row variant needed more than 256 VGPRs once the K loop was peeled, and a spill inside the K loop breaks the COUNTED vmcnt waits (scratch
+// traffic counts in vmcnt) - tests/test_boundary.py::test_pp_kernel_isa_contract pins "no scratch access in an MFMA block" on the shipped ISA.
+int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, hipStream_t s) {
   const int epi = d->epilogue;
   if (epi != MODE_EPI_NONE && epi != MODE_EPI_BIAS && epi != MODE_EPI_SWIGLU) return MODE_ERR_UNSUPPORTED;
   const int nout = epi == MODE_EPI_SWIGLU ? 128 : 256;
@@ -594,10 +596,8 @@ int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, int rows224
   if (wrows * d->ldw * 2 >= (1L << 32) || (long)d->M * d->lda * 2 >= (1L << 32)) return MODE_ERR_UNSUPPORTED;
   if (d->bias && ((reinterpret_cast<uintptr_t>(d->bias) & 15) || d->bias_expert_stride % 4)) return MODE_ERR_UNSUPPORTED;
   const bool ob = d->out_dtype == MODE_BF16;
-#define PP_CASE(E)                                                                                        \
-  case E:                                                                                                 \
-    if (rows224) return ob ? pp_launch<E, true, 3>(p0, d, s) : pp_launch<E, false, 3>(p0, d, s);         \
-    return ob ? pp_launch<E, true, 4>(p0, d, s) : pp_launch<E, false, 4>(p0, d, s);
+#define PP_CASE(E) \
+  case E: return ob ? pp_launch<E, true, 3>(p0, d, s) : pp_launch<E, false, 3>(p0, d, s);
   switch (epi) {
     PP_CASE(MODE_EPI_NONE)
     PP_CASE(MODE_EPI_BIAS)

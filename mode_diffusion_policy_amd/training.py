@@ -309,7 +309,9 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         # of several modalities, mode_agent.py:386-440).
         accumulate = grad_mode == "arena" and getattr(ar, "grad_pending", False) and any(p.grad is not None for p in all_params if p.requires_grad)
         own = grad_mode != "arena" or accumulate
-        flat = torch.empty(ar.bounds["total"], device=dev) if own else None
+        # (accumulate: zero-filled - the chain does not write the 256-byte alignment gaps between tensors, and whatever sits there would be added
+        # into the arena's gaps; autograd mode only ever exposes per-tensor views)
+        flat = (torch.zeros if accumulate else torch.empty)(ar.bounds["total"], device=dev) if own else None
         mg, gv = ts.grad_tables(flat)
         L.check(lib.mode_dit_backward(C.byref(d), C.byref(eng._mw), C.byref(ts.wt), C.byref(args), stash.data_ptr(), dF.data_ptr(), C.byref(mg),
                                       ts._ws.data_ptr(), ts._ws.numel(), _stream()), "backward")

@@ -326,3 +326,40 @@ def test_input_shape_contract_is_checked_before_any_launch():
     with pytest.raises(ValueError, match="actions must be"):
         m2._check_batch(3, torch.zeros(3, 2, 32), g, torch.zeros(3, 5, 2))
     m2._check_batch(3, torch.zeros(3, 2, 32), g, torch.zeros(3, 4, 2))
+
+
+def test_pp_kernel_isa_contract(tmp_path):
+    """The persistent ping-pong GEMM (85 % of the benchmark's FLOPs) relies on two properties of its COMPILED K loop that no numerics test on
+    small shapes would catch reliably: (1) no scratch (spill) access inside a block that issues MFMAs - scratch traffic counts in vmcnt and would
+    make the loop's counted `s_waitcnt vmcnt(N)` release LDS tiles that are still being filled; (2) the loop is straight-line code between its
+    barriers: one basic block per K-step pair, whose only branch is the back edge (plus the loop-skip test of the peeled first pair).  Checked on
+    the gfx950 ISA hipcc produces from the shipped source (cross-compiles without a GPU)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "mode_diffusion_policy_amd", "csrc")
+    out = tmp_path / "pp.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"-I{csrc}", "-S",
+                    "--cuda-device-only", os.path.join(csrc, "gemm_bf16_pp.hip"), "-o", str(out)], check=True, capture_output=True)
+    asm = out.read_text()
+    kernels = [(m.group(1), m.start()) for m in re.finditer(r"^(_ZN4mode14gemm_pp_kernel\w+):", asm, flags=re.M)]
+    assert len(kernels) == 6                                         # {NONE, BIAS, SWIGLU} x {bf16, fp32 out}, 224-row tile only
+    for name, start in kernels:
+        body = asm[start: asm.index(".end_amdhsa_kernel", start)]
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) <= 256
+        blocks, cur = [], []
+        for line in body.split("\n"):
+            if re.match(r"^\.LBB\w+:", line):
+                blocks.append(cur); cur = []
+            else:
+                cur.append(line)
+        blocks.append(cur)
+        mf = [b for b in blocks if any("v_mfma" in x for x in b)]
+        assert len(mf) == 4, (name, len(mf))                         # 2 wave roles x {peeled first K-step pair, loop body}
+        for b in mf:
+            assert sum("v_mfma" in x for x in b) == 112              # 2 K-steps x (32 + 24) MFMAs per wave
+            assert sum("s_barrier" in x for x in b) == 8
+            assert not any("scratch_" in x for x in b), name          # (1)
+            assert sum("s_cbranch" in x for x in b) <= 2, name        # (2)
