@@ -553,6 +553,36 @@ int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w, const Mod
                       const void* stash, const float* dF, const ModeModelGrads* grads, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * FiLM-ResNet perceptual encoders (mode/models/perceptual_encoders/pretrained_resnets.py:5-60, resnets.py:27-200,
+ * mode_agent.py:548-567): the producer of `state_images`.  Convolutions stay library calls (MIOpen via the caller); these entry points are
+ * everything between two convolutions as ONE pass over the NCHW activation:
+ *   y = post_film( relu( pre_film( x * scale[c] + shift[c] ) + residual ) )
+ *   pre_film : v = pre_gamma[n,c] * v + pre_beta[n,c]          (BasicBlockWithModulation, resnets.py:64-71: after bn2, before the skip add)
+ *   post_film: v = (1 + post_gamma[n,c]) * v + post_beta[n,c]  (FiLMLayer after a whole stage, pretrained_resnets.py:19-23)
+ * scale / shift are the folded BatchNorm (eval: running statistics; training: the batch statistics of mode_bn_stats).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ModeBnFilmDesc {
+  int32_t N, C, HW; int32_t dtype;                 /* activation dtype of x / residual / y (and dy / dx): MODE_F32 or MODE_BF16 */
+  const void* x;                                   /* [N, C, HW] convolution output                                    */
+  const float* scale; const float* shift;          /* [C]                                                              */
+  const float* pre_gamma; const float* pre_beta;   /* [N, C] or both NULL                                              */
+  const void* residual;                            /* [N, C, HW] or NULL                                               */
+  int32_t relu;
+  const float* post_gamma; const float* post_beta; /* [N, C] or both NULL                                              */
+  void* y;                                         /* [N, C, HW] (unused by the backward)                              */
+} ModeBnFilmDesc;
+int mode_bn_film_act_fwd(const ModeBnFilmDesc* d, void* stream);
+size_t mode_bn_workspace_bytes(int N, int C);
+/* per-channel mean and BIASED variance over (N, HW) (training-mode nn.BatchNorm2d); fixed summation order, no atomics */
+int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, float* mean, float* var, void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of the fused chain.  mean / invstd [C]: the statistics scale / shift were folded from (scale = weight * invstd).  training != 0:
+ * gradient through the batch statistics; 0: dx = d * scale.  Outputs: dx, dresidual (iff d->residual), dweight / dbias [C] (BatchNorm affine),
+ * d_pre_* / d_post_* [N, C] (iff the corresponding FiLM is present). */
+int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, const float* mean, const float* invstd, int training, void* dx, void* dresidual,
+                         float* dweight, float* dbias, float* d_pre_gamma, float* d_pre_beta, float* d_post_gamma, float* d_post_beta,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

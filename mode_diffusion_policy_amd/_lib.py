@@ -116,6 +116,11 @@ class ModeForwardArgs(C.Structure):
                 ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp), ("topk_idx_out", c_vp), ("uniform_routing", c_i32)]
 
 
+class ModeBnFilmDesc(C.Structure):
+    _fields_ = [("N", c_i32), ("C", c_i32), ("HW", c_i32), ("dtype", c_i32), ("x", c_vp), ("scale", c_vp), ("shift", c_vp), ("pre_gamma", c_vp),
+                ("pre_beta", c_vp), ("residual", c_vp), ("relu", c_i32), ("post_gamma", c_vp), ("post_beta", c_vp), ("y", c_vp)]
+
+
 P = C.POINTER
 # name -> (restype, argtypes): every symbol include/mode_hip.h declares
 PROTOTYPES = {
@@ -181,6 +186,10 @@ PROTOTYPES = {
     "mode_dit_backward": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeModelWeightsT), P(ModeTrainArgs), c_vp, c_vp, P(ModeModelGrads),
                                     c_vp, c_sz, c_vp]),
     "mode_dit_forward": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeForwardArgs), c_vp, c_sz, c_vp]),
+    "mode_bn_film_act_fwd": (C.c_int, [P(ModeBnFilmDesc), c_vp]),
+    "mode_bn_workspace_bytes": (c_sz, [c_i32, c_i32]),
+    "mode_bn_stats": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mode_bn_film_act_bwd": (C.c_int, [P(ModeBnFilmDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
 }
 
 _lib: Optional[C.CDLL] = None

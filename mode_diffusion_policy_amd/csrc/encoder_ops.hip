@@ -1,0 +1,235 @@
+// FiLM-ResNet perceptual encoders: the producer of `state_images`.  The convolutions stay library calls (MIOpen through
+// PyTorch's conv2d - SURVEY: "convs via MIOpen first"); what is hand-written here is everything BETWEEN two convolutions, which the reference
+// runs as 3-6 separate elementwise / reduction launches per block:
+//
+//   y = post_film( relu( pre_film( batch_norm(x) ) + residual ) )
+//
+//   batch_norm : nn.BatchNorm2d after every conv                      (resnets.py:41-45, timm / torchvision BasicBlock / Bottleneck)
+//   pre_film   : v = gamma[n,c] * v + beta[n,c] after bn2              (BasicBlockWithModulation.forward, resnets.py:64-71)
+//   residual   : out += identity ; relu                                (resnets.py:76-77)
+//   post_film  : v = (1 + gamma[n,c]) * v + beta[n,c] after a stage    (FiLMLayer.forward, pretrained_resnets.py:19-23)
+//
+// Activations are NCHW (what conv2d produces): a (sample, channel) pair is one contiguous row of HW elements, FiLM and BN parameters are
+// constant along it.  Every kernel gives one WAVE a row (lanes stride over HW: coalesced 256-byte segments), so the per-row reductions of
+// the backward (FiLM gradients are sums over HW per (n, c)) are wave shuffles - no atomics, deterministic.  All of it is HBM-bound streaming:
+// forward reads x (+ residual) and writes y once; backward = one reduction pass (6 sums per row) + one pass that writes dx / d residual.
+#include "mode_common.h"
+
+using namespace mode;
+
+namespace mode {
+
+template <typename T>
+__device__ __forceinline__ float ld(const T* p, long i);
+template <>
+__device__ __forceinline__ float ld<float>(const float* p, long i) { return p[i]; }
+template <>
+__device__ __forceinline__ float ld<uint16_t>(const uint16_t* p, long i) { return bf16_bits_to_f32(p[i]); }
+template <typename T>
+__device__ __forceinline__ void st(T* p, long i, float v);
+template <>
+__device__ __forceinline__ void st<float>(float* p, long i, float v) { p[i] = v; }
+template <>
+__device__ __forceinline__ void st<uint16_t>(uint16_t* p, long i, float v) { p[i] = f32_to_bf16_bits(v); }
+
+struct RowParams {            // per (n, c) constants of the fused chain
+  float scale, shift, pg, pb, qg, qb;
+  bool pre, post;
+};
+__device__ __forceinline__ RowParams row_params(const ModeBnFilmDesc& d, int n, int c) {
+  RowParams r;
+  r.scale = d.scale[c]; r.shift = d.shift[c];
+  r.pre = d.pre_gamma != nullptr; r.post = d.post_gamma != nullptr;
+  const long nc = (long)n * d.C + c;
+  r.pg = r.pre ? d.pre_gamma[nc] : 1.f; r.pb = r.pre ? d.pre_beta[nc] : 0.f;
+  r.qg = r.post ? d.post_gamma[nc] : 0.f; r.qb = r.post ? d.post_beta[nc] : 0.f;
+  return r;
+}
+
+// ---- forward
+template <typename T>
+__global__ __launch_bounds__(256) void bn_film_act_fwd_kernel(const ModeBnFilmDesc d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + wave, rows = (long)d.N * d.C;
+  if (row >= rows) return;
+  const int n = (int)(row / d.C), c = (int)(row % d.C);
+  const RowParams r = row_params(d, n, c);
+  const T* x = reinterpret_cast<const T*>(d.x) + row * d.HW;
+  const T* res = d.residual ? reinterpret_cast<const T*>(d.residual) + row * d.HW : nullptr;
+  T* y = reinterpret_cast<T*>(d.y) + row * d.HW;
+  for (int i = lane; i < d.HW; i += 64) {
+    float v = __builtin_fmaf(ld(x, i), r.scale, r.shift);
+    if (r.pre) v = __builtin_fmaf(r.pg, v, r.pb);
+    if (res) v += ld(res, i);
+    if (d.relu) v = fmaxf(v, 0.f);
+    if (r.post) v = __builtin_fmaf(1.f + r.qg, v, r.qb);
+    st(y, i, v);
+  }
+}
+
+// ---- batch statistics (training-mode BatchNorm): per-row partial sums, then one thread per channel folds the N rows in double
+template <typename T>
+__global__ __launch_bounds__(256) void bn_row_sums_kernel(const T* __restrict__ x, long rows, int HW, float* __restrict__ psum, float* __restrict__ psq) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const T* p = x + row * HW;
+  float s = 0.f, q = 0.f;
+  for (int i = lane; i < HW; i += 64) { const float v = ld(p, i); s += v; q = __builtin_fmaf(v, v, q); }
+  s = wave_sum(s); q = wave_sum(q);
+  if (lane == 0) { psum[row] = s; psq[row] = q; }
+}
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int N, int C, long count,
+                                                          float* __restrict__ mean, float* __restrict__ var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int n = 0; n < N; ++n) { s += psum[(long)n * C + c]; q += psq[(long)n * C + c]; }
+  const double m = s / (double)count;
+  mean[c] = (float)m;
+  var[c] = (float)fmax(q / (double)count - m * m, 0.0);            // biased variance (what normalises the batch; nn.BatchNorm2d)
+}
+
+// ---- backward, pass 1: six sums per row
+//   sums[row] = { S dy*v4, S dy, S dv2*v1, S dv2, S dv1, S dv1*xhat }
+template <typename T>
+__global__ __launch_bounds__(256) void bn_film_act_bwd_sums_kernel(const ModeBnFilmDesc d, const T* __restrict__ dy, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, float* __restrict__ sums) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + wave, rows = (long)d.N * d.C;
+  if (row >= rows) return;
+  const int n = (int)(row / d.C), c = (int)(row % d.C);
+  const RowParams r = row_params(d, n, c);
+  const float mu = mean[c], is = invstd[c];
+  const T* x = reinterpret_cast<const T*>(d.x) + row * d.HW;
+  const T* res = d.residual ? reinterpret_cast<const T*>(d.residual) + row * d.HW : nullptr;
+  const T* g = dy + row * d.HW;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f;
+  for (int i = lane; i < d.HW; i += 64) {
+    const float xv = ld(x, i), gy = ld(g, i);
+    const float v1 = __builtin_fmaf(xv, r.scale, r.shift);
+    const float v2 = r.pre ? __builtin_fmaf(r.pg, v1, r.pb) : v1;
+    const float v3 = res ? v2 + ld(res, i) : v2;
+    const float v4 = d.relu ? fmaxf(v3, 0.f) : v3;
+    const float dv4 = r.post ? gy * (1.f + r.qg) : gy;
+    const float dv2 = (d.relu && v3 <= 0.f) ? 0.f : dv4;
+    const float dv1 = r.pre ? dv2 * r.pg : dv2;
+    a0 = __builtin_fmaf(gy, v4, a0); a1 += gy; a2 = __builtin_fmaf(dv2, v1, a2); a3 += dv2; a4 += dv1;
+    a5 = __builtin_fmaf(dv1, (xv - mu) * is, a5);
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3); a4 = wave_sum(a4); a5 = wave_sum(a5);
+  if (lane == 0) {
+    float* o = sums + row * 6;
+    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5;
+  }
+}
+// per-channel fold of the row sums (double), FiLM gradients are the row sums themselves
+__global__ __launch_bounds__(256) void bn_film_bwd_fold_kernel(const float* __restrict__ sums, int N, int C, float* __restrict__ dweight, float* __restrict__ dbias,
+                                                               float* __restrict__ dpg, float* __restrict__ dpb, float* __restrict__ dqg, float* __restrict__ dqb) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < (long)N * C) {
+    const float* s = sums + i * 6;
+    if (dqg) { dqg[i] = s[0]; dqb[i] = s[1]; }
+    if (dpg) { dpg[i] = s[2]; dpb[i] = s[3]; }
+  }
+  if (i < C) {
+    double b = 0.0, w = 0.0;
+    for (int n = 0; n < N; ++n) { b += sums[((long)n * C + i) * 6 + 4]; w += sums[((long)n * C + i) * 6 + 5]; }
+    dbias[i] = (float)b; dweight[i] = (float)w;
+  }
+}
+// pass 2: dx (training: through the batch statistics; eval: dv1 * scale) and d residual
+template <typename T>
+__global__ __launch_bounds__(256) void bn_film_act_bwd_dx_kernel(const ModeBnFilmDesc d, const T* __restrict__ dy, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ dweight,
+                                                                 const float* __restrict__ dbias, int training, T* __restrict__ dx, T* __restrict__ dres) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + wave, rows = (long)d.N * d.C;
+  if (row >= rows) return;
+  const int n = (int)(row / d.C), c = (int)(row % d.C);
+  const RowParams r = row_params(d, n, c);
+  const float mu = mean[c], is = invstd[c];
+  const float inv_m = 1.f / ((float)d.N * (float)d.HW);
+  const float mb = training ? dbias[c] * inv_m : 0.f, mw = training ? dweight[c] * inv_m : 0.f;
+  const T* x = reinterpret_cast<const T*>(d.x) + row * d.HW;
+  const T* res = d.residual ? reinterpret_cast<const T*>(d.residual) + row * d.HW : nullptr;
+  const T* g = dy + row * d.HW;
+  T* ox = dx + row * d.HW;
+  T* orr = dres ? dres + row * d.HW : nullptr;
+  for (int i = lane; i < d.HW; i += 64) {
+    const float xv = ld(x, i), gy = ld(g, i);
+    const float v1 = __builtin_fmaf(xv, r.scale, r.shift);
+    const float v2 = r.pre ? __builtin_fmaf(r.pg, v1, r.pb) : v1;
+    const float v3 = res ? v2 + ld(res, i) : v2;
+    const float dv4 = r.post ? gy * (1.f + r.qg) : gy;
+    const float dv2 = (d.relu && v3 <= 0.f) ? 0.f : dv4;
+    const float dv1 = r.pre ? dv2 * r.pg : dv2;
+    if (orr) st(orr, i, dv2);
+    st(ox, i, r.scale * (dv1 - mb - (xv - mu) * is * mw));      // scale = weight * invstd
+  }
+}
+
+static bool bn_desc_ok(const ModeBnFilmDesc* d) {
+  if (!d || !d->x || !d->scale || !d->shift || !d->y || d->N < 0 || d->C <= 0 || d->HW <= 0) return false;
+  if ((d->pre_gamma == nullptr) != (d->pre_beta == nullptr) || (d->post_gamma == nullptr) != (d->post_beta == nullptr)) return false;
+  return d->dtype == MODE_F32 || d->dtype == MODE_BF16;
+}
+
+}  // namespace mode
+
+extern "C" int mode_bn_film_act_fwd(const ModeBnFilmDesc* d, void* stream) {
+  if (!bn_desc_ok(d)) return MODE_ERR_BAD_ARG;
+  const long rows = (long)d->N * d->C;
+  if (rows == 0) return MODE_OK;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (d->dtype == MODE_F32) hipLaunchKernelGGL(bn_film_act_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(bn_film_act_fwd_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" size_t mode_bn_workspace_bytes(int N, int C) { return N < 0 || C <= 0 ? 0 : (size_t)N * C * 6 * 4 + 256; }
+
+extern "C" int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, float* mean, float* var, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !mean || !var || !workspace || N <= 0 || C <= 0 || HW <= 0) return MODE_ERR_BAD_ARG;
+  if (workspace_bytes < mode_bn_workspace_bytes(N, C)) return MODE_ERR_WORKSPACE;
+  const long rows = (long)N * C;
+  float* psum = (float*)workspace; float* psq = psum + rows;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == MODE_F32) hipLaunchKernelGGL(bn_row_sums_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, HW, psum, psq);
+  else if (dtype == MODE_BF16) hipLaunchKernelGGL(bn_row_sums_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, rows, HW, psum, psq);
+  else return MODE_ERR_BAD_ARG;
+  MODE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, psum, psq, N, C, (long)N * HW, mean, var);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, const float* mean, const float* invstd, int training, void* dx, void* dresidual,
+                                    float* dweight, float* dbias, float* d_pre_gamma, float* d_pre_beta, float* d_post_gamma, float* d_post_beta,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!bn_desc_ok(d) || !dy || !mean || !invstd || !dx || !dweight || !dbias || !workspace) return MODE_ERR_BAD_ARG;
+  if ((d->pre_gamma != nullptr) != (d_pre_gamma != nullptr && d_pre_beta != nullptr)) return MODE_ERR_BAD_ARG;
+  if ((d->post_gamma != nullptr) != (d_post_gamma != nullptr && d_post_beta != nullptr)) return MODE_ERR_BAD_ARG;
+  if ((d->residual != nullptr) != (dresidual != nullptr)) return MODE_ERR_BAD_ARG;
+  if (workspace_bytes < mode_bn_workspace_bytes(d->N, d->C)) return MODE_ERR_WORKSPACE;
+  const long rows = (long)d->N * d->C;
+  if (rows == 0) return MODE_OK;
+  float* sums = (float*)workspace;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == MODE_F32) hipLaunchKernelGGL(bn_film_act_bwd_sums_kernel<float>, grid, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, sums);
+  else hipLaunchKernelGGL(bn_film_act_bwd_sums_kernel<uint16_t>, grid, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, sums);
+  MODE_LAUNCH_CHECK();
+  const long nfold = rows > d->C ? rows : d->C;
+  hipLaunchKernelGGL(bn_film_bwd_fold_kernel, dim3((unsigned)((nfold + 255) / 256)), dim3(256), 0, s, sums, d->N, d->C, dweight, dbias, d_pre_gamma, d_pre_beta,
+                     d_post_gamma, d_post_beta);
+  MODE_LAUNCH_CHECK();
+  if (d->dtype == MODE_F32)
+    hipLaunchKernelGGL(bn_film_act_bwd_dx_kernel<float>, grid, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, dweight, dbias, training, (float*)dx, (float*)dresidual);
+  else
+    hipLaunchKernelGGL(bn_film_act_bwd_dx_kernel<uint16_t>, grid, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, dweight, dbias, training, (uint16_t*)dx,
+                       (uint16_t*)dresidual);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}

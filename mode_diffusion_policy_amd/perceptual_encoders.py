@@ -1,0 +1,285 @@
+"""FiLM-ResNet perceptual encoders on MI355X — the producers of ``perceptual_emb['state_images']``:
+
+* ``FiLMResNet18Policy / 34 / 50``  = mode/models/perceptual_encoders/pretrained_resnets.py:25-137 (a timm ResNet trunk, ``FiLMLayer`` after
+  every stage, global average pool -> (B, 512 | 2048) tokens; what ``MoDEAgent`` instantiates twice, mode_agent.py:82-91, 548-567);
+* ``ResNetEncoderWithFiLM``         = mode/models/perceptual_encoders/resnets.py:81-200 (torchvision ResNet-18 trunk, ``FilmModule`` ->
+  per-block gamma / beta applied after ``bn2``, ``fc`` head).
+
+Same constructor arguments, forward signatures and ``state_dict`` keys (``resnet.conv1.weight``, ``resnet.layer3.1.bn2.running_var``,
+``film2.gamma.weight`` ... — the agent's checkpoint loaders match by key, mode_agent.py:132-251), so published weights load unchanged; the
+trunks are built here from ``nn.Conv2d`` / ``nn.BatchNorm2d`` holders (neither ``timm`` nor ``torchvision`` is needed at run time —
+``pretrained=True`` therefore means "load a checkpoint": there is no network on the box).
+
+Compute: convolutions are MIOpen calls (``torch.nn.functional.conv2d`` — SURVEY: "convs via MIOpen first"); everything BETWEEN two
+convolutions — BatchNorm (eval or training statistics), the FiLM modulations, the residual add and the ReLU — is ONE hand-written HIP pass over
+the activation (``mode_bn_film_act_fwd``; the reference launches 3-6 elementwise kernels there), with a HIP backward
+(``mode_bn_film_act_bwd``: one reduction pass + one dx pass, deterministic) behind ``torch.autograd`` so the encoders train through the
+denoiser's input gradients (training.py).  No CPU path: the fused op raises off-device.
+
+Parity status: the FiLM wiring is pinned against the REFERENCE classes (oracle/gen_golden_encoders.py runs them on top of a stand-in trunk with
+the attribute names their constructors read, fixture F15); the trunk itself is the textbook ResNet restated — timm / torchvision are absent
+from the build image, so "trunk == timm's resnet50" rests on the key / shape contract only.  SyncBatchNorm (the reference trains with
+``sync_batchnorm=True``) is not built: under data parallelism batch statistics are per rank.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from .engine import _ptr, _stream
+
+
+# ------------------------------------------------------------------------------------------------------------------ fused op
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.MODE_F32
+    if t.dtype == torch.bfloat16:
+        return L.MODE_BF16
+    raise TypeError(f"encoder activations must be float32 or bfloat16, got {t.dtype}")
+
+
+def _desc(x, scale, shift, pre, res, relu, post, y) -> L.ModeBnFilmDesc:
+    N, Cc = x.shape[0], x.shape[1]
+    return L.ModeBnFilmDesc(N=N, C=Cc, HW=x[0, 0].numel(), dtype=_dt(x), x=_ptr(x), scale=_ptr(scale), shift=_ptr(shift),
+                            pre_gamma=_ptr(pre[0]) if pre else None, pre_beta=_ptr(pre[1]) if pre else None, residual=_ptr(res), relu=int(relu),
+                            post_gamma=_ptr(post[0]) if post else None, post_beta=_ptr(post[1]) if post else None, y=_ptr(y))
+
+
+class _BnFilmAct(torch.autograd.Function):
+    """y = post_film(relu(pre_film(batch_norm(x)) + residual)) as one HIP launch (two for training statistics); see csrc/encoder_ops.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b):
+        if x.device.type != "cuda":
+            raise L.ModeHipUnavailable("FiLM-ResNet encoders run through the HIP library only: inputs must live on a ROCm device")
+        lib = L.load()
+        x = x.contiguous()
+        N, Cc = x.shape[0], x.shape[1]
+        HW = x[0, 0].numel()
+        dev = x.device
+        f32 = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        w, b = f32(weight), f32(bias)
+        ws = torch.empty(lib.mode_bn_workspace_bytes(N, Cc), dtype=torch.uint8, device=dev)
+        if training:
+            mean = torch.empty(Cc, device=dev); var = torch.empty(Cc, device=dev)
+            L.check(lib.mode_bn_stats(x.data_ptr(), _dt(x), N, Cc, HW, mean.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn_stats")
+            if running_mean is not None:                                       # nn.BatchNorm2d bookkeeping: unbiased variance into the running estimate
+                with torch.no_grad():
+                    m = N * HW
+                    running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                    running_var.mul_(1 - momentum).add_((var * (m / max(m - 1, 1))).to(running_var.dtype), alpha=momentum)
+        else:
+            mean, var = f32(running_mean), f32(running_var)
+        invstd = torch.rsqrt(var + eps)
+        scale = w * invstd
+        shift = b - mean * scale
+        pre = (f32(pre_g).reshape(N, Cc), f32(pre_b).reshape(N, Cc)) if pre_g is not None else None
+        post = (f32(post_g).reshape(N, Cc), f32(post_b).reshape(N, Cc)) if post_g is not None else None
+        res = None if residual is None else residual.contiguous()
+        if res is not None and (res.shape != x.shape or res.dtype != x.dtype):
+            raise ValueError("residual must match the activation's shape and dtype")
+        y = torch.empty_like(x)
+        L.check(lib.mode_bn_film_act_fwd(C.byref(_desc(x, scale, shift, pre, res, relu, post, y)), _stream()), "bn_film_act_fwd")
+        ctx.save_for_backward(x, res, scale, shift, mean, invstd, *(pre or ()), *(post or ()))
+        ctx.cfg = (bool(training), bool(relu), pre is not None, post is not None, res is not None)
+        ctx.shapes = (None if pre_g is None else pre_g.shape, None if post_g is None else post_g.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        training, relu, has_pre, has_post, has_res = ctx.cfg
+        sv = list(ctx.saved_tensors)
+        x, res, scale, shift, mean, invstd = sv[:6]
+        rest = sv[6:]
+        pre = (rest[0], rest[1]) if has_pre else None
+        post = (rest[2 if has_pre else 0], rest[3 if has_pre else 1]) if has_post else None
+        N, Cc = x.shape[0], x.shape[1]
+        dev = x.device
+        dy = dy.contiguous().to(x.dtype)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dw = torch.empty(Cc, device=dev); db = torch.empty(Cc, device=dev)
+        dpg = torch.empty(N, Cc, device=dev) if has_pre else None; dpb = torch.empty(N, Cc, device=dev) if has_pre else None
+        dqg = torch.empty(N, Cc, device=dev) if has_post else None; dqb = torch.empty(N, Cc, device=dev) if has_post else None
+        ws = torch.empty(lib.mode_bn_workspace_bytes(N, Cc), dtype=torch.uint8, device=dev)
+        d = _desc(x, scale, shift, pre, res if has_res else None, relu, post, None)
+        d.y = x.data_ptr()                                                     # unused by the backward; the descriptor check wants a pointer
+        L.check(lib.mode_bn_film_act_bwd(C.byref(d), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), int(training), dx.data_ptr(), _ptr(dres),
+                                         dw.data_ptr(), db.data_ptr(), _ptr(dpg), _ptr(dpb), _ptr(dqg), _ptr(dqb), ws.data_ptr(), ws.numel(), _stream()),
+                "bn_film_act_bwd")
+        ps, qs = ctx.shapes
+        rs = lambda t, shp: None if t is None else t.reshape(shp)
+        # inputs: x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b
+        return dx, dw, db, None, None, None, None, None, None, dres, rs(dpg, ps), rs(dpb, ps), rs(dqg, qs), rs(dqb, qs)
+
+
+def bn_film_act(x, bn: nn.BatchNorm2d, relu: bool = True, residual=None, pre_film=None, post_film=None):
+    """``post_film(relu(pre_film(bn(x)) + residual))``; ``pre_film`` / ``post_film`` = (gamma, beta), each (N, C) (or broadcastable views of it)."""
+    pg, pb = pre_film if pre_film is not None else (None, None)
+    qg, qb = post_film if post_film is not None else (None, None)
+    return _BnFilmAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, 0.1 if bn.momentum is None else bn.momentum, bn.eps, relu,
+                            residual, pg, pb, qg, qb)
+
+
+# ------------------------------------------------------------------------------------------------------------------ trunk (parameter holders)
+class _Block(nn.Module):
+    """BasicBlock (expansion 1) / Bottleneck (expansion 4) holder with the timm / torchvision attribute names."""
+
+    def __init__(self, inplanes: int, planes: int, stride: int, bottleneck: bool):
+        super().__init__()
+        self.bottleneck, self.stride = bottleneck, stride
+        out = planes * (4 if bottleneck else 1)
+        if bottleneck:
+            self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False); self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False); self.bn2 = nn.BatchNorm2d(planes)
+            self.conv3 = nn.Conv2d(planes, out, 1, bias=False); self.bn3 = nn.BatchNorm2d(out)
+        else:
+            self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False); self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False); self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != out:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, out, 1, stride=stride, bias=False), nn.BatchNorm2d(out))
+        self.out_channels = out
+
+    def _conv(self, conv: nn.Conv2d, x):
+        return F.conv2d(x, conv.weight.to(x.dtype), None, conv.stride, conv.padding)
+
+    def forward(self, x, pre_film=None, post_film=None):
+        """``pre_film``: FiLM on the last BatchNorm's output before the skip add (resnets.py:64-71); ``post_film``: FiLM on the block output (the
+        stage-level FiLMLayer of pretrained_resnets.py fused into the stage's last block)."""
+        identity = x
+        if self.downsample is not None:
+            identity = bn_film_act(self._conv(self.downsample[0], x), self.downsample[1], relu=False)
+        out = bn_film_act(self._conv(self.conv1, x), self.bn1, relu=True)
+        if self.bottleneck:
+            out = bn_film_act(self._conv(self.conv2, out), self.bn2, relu=True)
+            return bn_film_act(self._conv(self.conv3, out), self.bn3, relu=True, residual=identity, pre_film=pre_film, post_film=post_film)
+        return bn_film_act(self._conv(self.conv2, out), self.bn2, relu=True, residual=identity, pre_film=pre_film, post_film=post_film)
+
+
+_ARCH = {"18": (False, (2, 2, 2, 2)), "34": (False, (3, 4, 6, 3)), "50": (True, (3, 4, 6, 3))}
+
+
+class _Trunk(nn.Module):
+    """conv1 / bn1 / maxpool / layer1..4 with the standard ResNet widths (He et al. 2016); attribute names as in timm (``act1``, ``global_pool``)
+    and torchvision (``relu``, ``avgpool``) so that either family's keys load."""
+
+    def __init__(self, arch: str):
+        super().__init__()
+        bottleneck, depths = _ARCH[arch]
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        for i, (planes, n) in enumerate(zip((64, 128, 256, 512), depths)):
+            blocks: List[_Block] = []
+            for j in range(n):
+                blocks.append(_Block(inplanes, planes, stride=(1 if i == 0 else 2) if j == 0 else 1, bottleneck=bottleneck))
+                inplanes = blocks[-1].out_channels
+            setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+        self.num_features = inplanes
+
+    def stem(self, x):
+        x = bn_film_act(F.conv2d(x, self.conv1.weight.to(x.dtype), None, 2, 3), self.bn1, relu=True)
+        return F.max_pool2d(x, 3, 2, 1)
+
+
+class FiLMLayer(nn.Module):
+    """gamma / beta = Linear(condition): x <- (1 + gamma) x + beta, zero-initialised (pretrained_resnets.py:5-23).  Holds parameters; the modulation
+    itself is fused into the preceding BatchNorm pass."""
+
+    def __init__(self, num_features: int, condition_dim: int):
+        super().__init__()
+        self.num_features, self.condition_dim = num_features, condition_dim
+        self.gamma = nn.Linear(condition_dim, num_features)
+        self.beta = nn.Linear(condition_dim, num_features)
+        for lin in (self.gamma, self.beta):
+            nn.init.zeros_(lin.weight); nn.init.zeros_(lin.bias)
+
+    def params(self, condition):
+        return self.gamma(condition), self.beta(condition)
+
+
+class _FiLMResNetPolicy(nn.Module):
+    arch = "50"
+
+    def __init__(self, condition_dim: int):
+        super().__init__()
+        self.resnet = _Trunk(self.arch)
+        widths = [getattr(self.resnet, f"layer{i}")[-1].out_channels for i in range(1, 5)]
+        self.film1, self.film2, self.film3, self.film4 = (FiLMLayer(w, condition_dim) for w in widths)
+
+    def forward(self, x, condition):
+        if condition.dim() == 3:
+            condition = condition.squeeze(1)
+        x = self.resnet.stem(x)
+        for i in range(1, 5):
+            film = getattr(self, f"film{i}").params(condition.to(torch.float32))
+            layer = getattr(self.resnet, f"layer{i}")
+            for j, blk in enumerate(layer):
+                x = blk(x, post_film=film if j == len(layer) - 1 else None)     # FiLM after the stage = epilogue of its last block
+        return x.mean(dim=(2, 3))                                             # global_pool + flatten(1)
+
+
+class FiLMResNet50Policy(_FiLMResNetPolicy):
+    arch = "50"
+
+
+class FiLMResNet34Policy(_FiLMResNetPolicy):
+    arch = "34"
+
+
+class FiLMResNet18Policy(_FiLMResNetPolicy):
+    arch = "18"
+
+
+class FilmModule(nn.Module):
+    """SiLU -> Linear(cond, 4 * hidden): ((gamma_0, beta_0), (gamma_1, beta_1)) for the two blocks of a ResNet-18 stage (resnets.py:27-44)."""
+
+    def __init__(self, input_size: int, hidden_size: int):
+        super().__init__()
+        self.modulation = nn.Sequential(nn.SiLU(), nn.Linear(input_size, 4 * hidden_size, bias=True))
+
+    def forward(self, c):
+        x = self.modulation(c).chunk(2, dim=-1)
+        return x[0].chunk(2, dim=-1), x[1].chunk(2, dim=-1)
+
+
+class ResNetEncoderWithFiLM(nn.Module):
+    """resnets.py:81-200: ResNet-18 trunk, per-block FiLM ``gamma * bn2(.) + beta`` before the skip add, average pool, ``fc`` to ``latent_dim``.
+    Accepts (B, C, H, W) or (B, T, C, H, W) like the reference."""
+
+    def __init__(self, cond_dim: int, latent_dim: int = 512, pretrained: bool = False, hidden_size: int = 512):
+        super().__init__()
+        if pretrained:
+            raise NotImplementedError("pretrained=True downloads ImageNet weights in the reference; load a checkpoint with load_state_dict instead")
+        self.latent_dim = latent_dim
+        t = _Trunk("18")
+        self.conv1, self.bn1 = t.conv1, t.bn1
+        self.film_module1, self.film_module2 = FilmModule(cond_dim, 64), FilmModule(cond_dim, 128)
+        self.film_module3, self.film_module4 = FilmModule(cond_dim, 256), FilmModule(cond_dim, 512)
+        self.layer1, self.layer2, self.layer3, self.layer4 = t.layer1, t.layer2, t.layer3, t.layer4
+        self.fc = nn.Linear(512, latent_dim)
+
+    def forward(self, x, conditioning_vector: Optional[torch.Tensor] = None):
+        B, t_steps, series = len(x), 1, False
+        if x.dim() == 5:
+            t_steps, series = x.shape[1], True
+            x = x.reshape(B * t_steps, *x.shape[2:])
+            if conditioning_vector is not None:
+                conditioning_vector = torch.cat([conditioning_vector for _ in range(t_steps)], dim=0)     # the reference's order (resnets.py:129)
+        x = bn_film_act(F.conv2d(x, self.conv1.weight.to(x.dtype), None, 2, 3), self.bn1, relu=True)
+        x = F.max_pool2d(x, 3, 2, 1)
+        for i in range(1, 5):
+            mods = getattr(self, f"film_module{i}")(conditioning_vector.to(torch.float32)) if conditioning_vector is not None else (None, None)
+            for j, blk in enumerate(getattr(self, f"layer{i}")):
+                x = blk(x, pre_film=mods[j])
+        x = self.fc(x.mean(dim=(2, 3)).to(self.fc.weight.dtype))
+        if series:
+            x = x.reshape(B, t_steps, self.latent_dim)
+        return x

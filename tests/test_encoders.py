@@ -1,0 +1,145 @@
+"""FiLM-ResNet perceptual encoders: drop-in contract on CPU, HIP parity on the GPU.
+
+Fixture F15 (oracle/gen_golden_encoders.py) = the REFERENCE's encoder classes (pretrained_resnets.py, resnets.py) on the stand-in trunk of
+oracle/resnet_oracle.py - timm / torchvision are not in the build image, so the trunk's identity with timm's is by architecture + key / shape
+contract only ("trunk parity unpinned"); the FiLM wiring, BatchNorm handling, forward and autograd are the reference's own code.
+Tolerances: fp32 activations, rel-L2 1e-3 on outputs (measured ~1e-6), 2e-3 on gradients (tests/tolerances.py FP32_*)."""
+import numpy as np
+import pytest
+import torch
+
+from mode_diffusion_policy_amd import perceptual_encoders as E
+from oracle import resnet_oracle as R
+from tolerances import FP32_GRAD, FP32_OUT
+
+CTORS = {"r50": lambda c: E.FiLMResNet50Policy(c), "r34": lambda c: E.FiLMResNet34Policy(c), "r18p": lambda c: E.FiLMResNet18Policy(c),
+         "r18f": lambda c: E.ResNetEncoderWithFiLM(c, latent_dim=96)}
+SEEDS = {"r50": 500, "r34": 501, "r18p": 502, "r18f": 503}
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double().cpu(); b = torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("tag", list(CTORS))
+def test_encoder_state_dict_contract(golden, tag):
+    """Same ``state_dict`` keys (and shapes) as the reference classes: checkpoints load by key (mode_agent.py:132-251)."""
+    g = golden("F15_encoders")
+    m = CTORS[tag](int(g["cond_dim"]))
+    assert list(m.state_dict().keys()) == list(g[f"{tag}_keys"])
+    if tag != "r18f":                                                         # FiLMLayer starts as the identity (pretrained_resnets.py:13-17)
+        assert all(float(p.abs().max()) == 0 for n, p in m.named_parameters() if n.startswith("film"))
+    with pytest.raises(Exception):                                           # no CPU path: the fused op needs the HIP library and a device tensor
+        m(torch.zeros(1, 3, 32, 32), torch.zeros(1, int(g["cond_dim"])))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(CTORS))
+def test_encoder_vs_reference_fixture(golden, tag):
+    g = golden("F15_encoders")
+    m = CTORS[tag](int(g["cond_dim"]))
+    m.load_state_dict(R.fill_encoder_state_dict(m.state_dict(), SEEDS[tag]))
+    m = m.cuda()
+    img = torch.from_numpy(g["img"]).cuda()
+    cond = torch.from_numpy(g["cond"]).cuda()
+    if tag == "r18f":
+        cond = cond.squeeze(1)
+    m.eval()
+    with torch.no_grad():
+        y = m(img, cond)
+    assert rel(y, g[f"{tag}_eval"]) < FP32_OUT, rel(y, g[f"{tag}_eval"])
+    m.train()
+    rm_key = [k for k in m.state_dict() if k.endswith("bn1.running_mean")][0]
+    xi = img.clone().requires_grad_(True); ci = cond.clone().requires_grad_(True)
+    yt = m(xi, ci)
+    assert rel(yt, g[f"{tag}_train"]) < FP32_OUT
+    (yt * torch.from_numpy(g[f"{tag}_w"]).cuda()).sum().backward()
+    assert rel(m.state_dict()[rm_key], g[f"{tag}_rm"]) < 1e-5                  # running statistics updated like nn.BatchNorm2d
+    assert rel(xi.grad, g[f"{tag}_dimg"]) < FP32_GRAD and rel(ci.grad, g[f"{tag}_dcond"]) < FP32_GRAD
+    params = dict(m.named_parameters())
+    gn = dict(zip(g[f"{tag}_gn_keys"].tolist(), g[f"{tag}_gn_vals"].tolist()))
+    worst = 0.0
+    for k, ref in gn.items():
+        assert params[k].grad is not None, k
+        if ref > 1e-7:
+            worst = max(worst, abs(float(params[k].grad.norm()) - ref) / ref)
+    assert worst < FP32_GRAD, worst
+    for key in g.files:
+        if key.startswith(f"{tag}_g:"):
+            assert rel(params[key.split(":", 1)[1]].grad, g[key]) < FP32_GRAD, key
+    print(f"{tag}: eval {rel(y, g[f'{tag}_eval']):.1e}, train {rel(yt, g[f'{tag}_train']):.1e}, d img {rel(xi.grad, g[f'{tag}_dimg']):.1e}, worst grad norm {worst:.1e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("N,C,H,pre,post,res", [(3, 8, 5, True, False, True), (4, 64, 7, False, True, True), (2, 5, 9, False, False, False), (6, 130, 3, True, True, True)])
+def test_bn_film_act_vs_torch_autograd(N, C, H, pre, post, res, training, dtype, tol):
+    """The fused HIP pass and its backward against the same chain written with torch ops (fp32 autograd on the same values)."""
+    torch.manual_seed(N * 100 + C)
+    dev = "cuda"
+    x = torch.randn(N, C, H, H, device=dev).to(dtype)
+    bn = torch.nn.BatchNorm2d(C).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2); bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    bn.train(training)
+    ref_bn = torch.nn.BatchNorm2d(C).to(dev); ref_bn.load_state_dict(bn.state_dict()); ref_bn.train(training)
+    mk = lambda: torch.randn(N, C, device=dev).mul(0.5)
+    pg, pb, qg, qb = mk(), mk(), mk(), mk()
+    r = torch.randn(N, C, H, H, device=dev).to(dtype)
+    leaves = [t.clone().requires_grad_(True) for t in (x, pg, pb, qg, qb, r)]
+    x1, pg1, pb1, qg1, qb1, r1 = leaves
+    y = E.bn_film_act(x1, bn, relu=True, residual=r1 if res else None, pre_film=(pg1, pb1) if pre else None, post_film=(qg1, qb1) if post else None)
+    refl = [t.clone().float().requires_grad_(True) for t in (x, pg, pb, qg, qb, r)]
+    x2, pg2, pb2, qg2, qb2, r2 = refl
+    v = ref_bn(x2)
+    if pre:
+        v = pg2[:, :, None, None] * v + pb2[:, :, None, None]
+    if res:
+        v = v + r2
+    v = torch.relu(v)
+    if post:
+        v = (1 + qg2[:, :, None, None]) * v + qb2[:, :, None, None]
+    assert rel(y.float(), v) < tol
+    w = torch.randn_like(v)
+    (y.float() * w).sum().backward(); (v * w).sum().backward()
+    assert rel(x1.grad.float(), x2.grad) < max(tol, 2e-5) * (4 if dtype == torch.bfloat16 else 1)
+    assert rel(bn.weight.grad, ref_bn.weight.grad) < max(tol, 2e-5) and rel(bn.bias.grad, ref_bn.bias.grad) < max(tol, 2e-5)
+    if res:
+        assert rel(r1.grad.float(), r2.grad) < tol
+    if pre:
+        assert rel(pg1.grad, pg2.grad) < max(tol, 2e-5) and rel(pb1.grad, pb2.grad) < max(tol, 2e-5)
+    if post:
+        assert rel(qg1.grad, qg2.grad) < max(tol, 2e-5) and rel(qb1.grad, qb2.grad) < max(tol, 2e-5)
+    if training:
+        assert rel(bn.running_mean, ref_bn.running_mean) < 1e-5 and rel(bn.running_var, ref_bn.running_var) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.gpu
+def test_encoders_train_through_the_hip_denoiser():
+    """MoDEAgent.embed_visual_obs + diffusion_loss (mode_agent.py:548-567, 659-672) on this package's classes: two FiLM-ResNets produce the
+    `state_images` tokens, the HIP denoiser's backward hands d state_images back (training.py), and the encoders' own HIP backward carries it to
+    their first convolution and to the FiLM layers - one `loss.backward()`, every gradient finite and non-zero."""
+    import mode_diffusion_policy_amd as M
+    from oracle.weights import get_config, make_inputs, make_state_dict
+    cfg = get_config("c1e4")                                                  # obs_dim 512 = the ResNet-18 / 34 token width
+    den = M.MoDeDiT(obs_dim=cfg.obs_dim, goal_dim=cfg.goal_dim, device="cuda", goal_conditioned=True, action_dim=7, embed_dim=cfg.embed_dim, embed_pdrob=0,
+                    attn_pdrop=0.0, mlp_pdrop=0.0, goal_drop=0.0, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=1, obs_seq_len=1,
+                    action_seq_len=10, num_experts=cfg.num_experts, top_k=cfg.top_k, use_argmax=True, compute_dtype="bf16")
+    den.load_state_dict(make_state_dict(cfg, 210))
+    model = M.GCDenoiser(den.cuda().train(), 0.5).train()
+    B = 4
+    static, gripper = M.FiLMResNet18Policy(cfg.goal_dim).cuda().train(), M.FiLMResNet18Policy(cfg.goal_dim).cuda().train()
+    for enc, seed in ((static, 1), (gripper, 2)):
+        enc.load_state_dict({k: v.cuda() for k, v in R.fill_encoder_state_dict(enc.state_dict(), seed).items()})
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, B, 5).items()}
+    rgb_s, rgb_g = torch.randn(B, 3, 64, 64, device="cuda"), torch.randn(B, 3, 48, 48, device="cuda")
+    tokens = torch.stack([static(rgb_s, inp["goals"]), gripper(rgb_g, inp["goals"])], dim=1)            # (B, 2, 512)
+    loss, _ = model.loss({"state_images": tokens}, inp["actions"], inp["goals"], inp["noise"], torch.full((B,), 0.8, device="cuda"))
+    loss.backward()
+    for enc in (static, gripper):
+        for n, p in enc.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        assert float(enc.resnet.conv1.weight.grad.abs().max()) > 0 and float(enc.film4.gamma.weight.grad.abs().max()) > 0
+    assert float(den.tok_emb.weight.grad.abs().max()) > 0
