@@ -45,6 +45,15 @@ def main():
         with torch.no_grad():
             y = m(img, c)
         out[f"{tag}_eval"] = y.numpy()
+        # eval-mode gradients (BatchNorm on running statistics: well conditioned at any depth)
+        xe = img.clone().requires_grad_(True); ce = c.clone().requires_grad_(True)
+        ye = m(xe, ce)
+        we = torch.from_numpy(np.random.RandomState(seed + 2).standard_normal(tuple(ye.shape)).astype(np.float32))
+        (ye * we).sum().backward()
+        out[f"{tag}_we"] = we.numpy(); out[f"{tag}_e_dimg"] = xe.grad.numpy(); out[f"{tag}_e_dcond"] = ce.grad.numpy()
+        en = [k for k, p in m.named_parameters() if p.grad is not None]
+        out[f"{tag}_e_gn_keys"] = np.array(en); out[f"{tag}_e_gn_vals"] = np.array([float(dict(m.named_parameters())[k].grad.norm()) for k in en], dtype=np.float64)
+        m.zero_grad(set_to_none=True)
         m.train()
         xi = img.clone().requires_grad_(True); ci = c.clone().requires_grad_(True)
         yt = m(xi, ci)

