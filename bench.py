@@ -207,13 +207,15 @@ def dominant_kernel_roofline(den, device, reps=240):
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command (FETCH_SIZE doubled: gfx950 correction, MI355X_MICROARCH.md "HBM");
     # null when the summary is absent or was taken on another kernel.
     traffic, src = None, None
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_gemm_pmc.json")))
-        ent = pj["kernels"].get("expert_up_projection")
-        if ent and ent.get("kernel_substr", "").startswith("gemm_pp_kernel<4, true, 3"):
-            traffic, src = ent["hbm_bytes_per_launch"], "profiles/r02_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
-    except Exception:
-        pass
+    for fn in ("r03_gemm_pmc.json", "r02_gemm_pmc.json"):                 # the newest committed collection that sampled THIS kernel
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            ent = pj["kernels"].get("expert_up_projection")
+            if ent and ent.get("kernel_substr", "").startswith("gemm_pp_kernel<4, true, 3"):
+                traffic, src = ent["hbm_bytes_per_launch"], f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                break
+        except Exception:
+            pass
     return {"bound": "mfma", "kernel": "gemm_pp_kernel<SWIGLU, bf16, 224x256> (grouped expert up-projection + fused ln_2 scale + SwiGLU, M=3584 K=1024 N=2x4096)",
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
             # algorithmic bytes per launch (2 of 4 experts active under uniform sigma): A 3.7 MB + W1 33.6 MB + H 29.4 MB = 66.6 MB
@@ -475,6 +477,21 @@ def extra_measurements(M, den, device):
         out[f"{key}_mfma_frac"] = round(flops_per_denoise_step(batch) * N_SAMPLING_STEPS / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4)
         if key == "rollout":
             out["rollout_action_chunks_per_s"] = round(batch / (ms * 1e-3), 1)
+    # the non-DDIM samplers of MoDEAgent.sample_loop (mode_agent.py:798-839): host recurrences around ONE hipGraph replay per denoiser call
+    # (sigma is a device scalar of the captured chain: MoDeDiT.denoise_graphed) - B = 128, 10 model evaluations per chunk
+    from mode_diffusion_policy_amd import samplers as S
+    img, goal, x0 = synthetic_inputs(device, B_PER_GPU)
+    for name, fn in (("euler", S.sample_euler), ("dpmpp_2m", S.sample_dpmpp_2m)):
+        for _ in range(2):
+            xs = fn(den, {"state_images": img}, x0, goal, sig, disable=True)
+        torch.cuda.synchronize()
+        assert torch.isfinite(xs).all()
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn(den, {"state_images": img}, x0, goal, sig, disable=True)
+        torch.cuda.synchronize()
+        out[f"sampler_{name}_denoise_steps_per_s"] = round(n * N_SAMPLING_STEPS / (time.perf_counter() - t0), 1)
     return out
 
 
