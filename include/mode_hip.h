@@ -578,10 +578,13 @@ size_t mode_bn_workspace_bytes(int N, int C);
 int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, float* mean, float* var, void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the fused chain.  mean / invstd [C]: the statistics scale / shift were folded from (scale = weight * invstd).  training != 0:
  * gradient through the batch statistics; 0: dx = d * scale.  Outputs: dx, dresidual (iff d->residual), dweight / dbias [C] (BatchNorm affine),
- * d_pre_* / d_post_* [N, C] (iff the corresponding FiLM is present). */
-int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, const float* mean, const float* invstd, int training, void* dx, void* dresidual,
-                         float* dweight, float* dbias, float* d_pre_gamma, float* d_pre_beta, float* d_post_gamma, float* d_post_beta,
-                         void* workspace, size_t workspace_bytes, void* stream);
+ * d_pre_* / d_post_* [N, C] (iff the corresponding FiLM is present).
+ * phase 0 = everything; for nn.SyncBatchNorm (mode/training_calvin.py:102 sync_batchnorm=True) the caller runs phase 1 (reductions only: dweight /
+ * dbias are THIS rank's sums), sums dweight / dbias over the ranks, and runs phase 2 (dx / dresidual only) with those sums and inv_count =
+ * 1 / (global N * HW); inv_count <= 0 means 1 / (N * HW). */
+int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, const float* mean, const float* invstd, int training, int phase, float inv_count,
+                         void* dx, void* dresidual, float* dweight, float* dbias, float* d_pre_gamma, float* d_pre_beta, float* d_post_gamma,
+                         float* d_post_beta, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

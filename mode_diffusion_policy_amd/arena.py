@@ -111,10 +111,11 @@ class ParamArena:
     def _views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
         return {key: flat[off: off + int(torch.Size(shp).numel())].view(shp) for key, shp, off in self.layout}
 
-    def owns(self, model) -> bool:
-        """True while every parameter still aliases its arena slice (``.to()`` / ``.half()`` / re-assignment breaks that)."""
+    def owns(self, model, named=None) -> bool:
+        """True while every parameter still aliases its arena slice (``.to()`` / ``.half()`` / re-assignment breaks that).  ``named``: a cached
+        [(name, parameter)] list (``DitEngine.named_params``) instead of a walk over the module tree."""
         ptrs = self._ptrs
-        for nm, p in model.named_parameters():
+        for nm, p in (named if named is not None else model.named_parameters()):
             if p.data_ptr() != ptrs.get(nm) or p.dtype != torch.float32:
                 return False
         return True

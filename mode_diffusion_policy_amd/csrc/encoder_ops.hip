@@ -142,14 +142,13 @@ __global__ __launch_bounds__(256) void bn_film_bwd_fold_kernel(const float* __re
 template <typename T>
 __global__ __launch_bounds__(256) void bn_film_act_bwd_dx_kernel(const ModeBnFilmDesc d, const T* __restrict__ dy, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ dweight,
-                                                                 const float* __restrict__ dbias, int training, T* __restrict__ dx, T* __restrict__ dres) {
+                                                                 const float* __restrict__ dbias, int training, float inv_m, T* __restrict__ dx, T* __restrict__ dres) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + wave, rows = (long)d.N * d.C;
   if (row >= rows) return;
   const int n = (int)(row / d.C), c = (int)(row % d.C);
   const RowParams r = row_params(d, n, c);
   const float mu = mean[c], is = invstd[c];
-  const float inv_m = 1.f / ((float)d.N * (float)d.HW);
   const float mb = training ? dbias[c] * inv_m : 0.f, mw = training ? dweight[c] * inv_m : 0.f;
   const T* x = reinterpret_cast<const T*>(d.x) + row * d.HW;
   const T* res = d.residual ? reinterpret_cast<const T*>(d.residual) + row * d.HW : nullptr;
@@ -205,9 +204,9 @@ extern "C" int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, flo
   return MODE_OK;
 }
 
-extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, const float* mean, const float* invstd, int training, void* dx, void* dresidual,
-                                    float* dweight, float* dbias, float* d_pre_gamma, float* d_pre_beta, float* d_post_gamma, float* d_post_beta,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, const float* mean, const float* invstd, int training, int phase, float inv_count,
+                                    void* dx, void* dresidual, float* dweight, float* dbias, float* d_pre_gamma, float* d_pre_beta, float* d_post_gamma,
+                                    float* d_post_beta, void* workspace, size_t workspace_bytes, void* stream) {
   if (!bn_desc_ok(d) || !dy || !mean || !invstd || !dx || !dweight || !dbias || !workspace) return MODE_ERR_BAD_ARG;
   if ((d->pre_gamma != nullptr) != (d_pre_gamma != nullptr && d_pre_beta != nullptr)) return MODE_ERR_BAD_ARG;
   if ((d->post_gamma != nullptr) != (d_post_gamma != nullptr && d_post_beta != nullptr)) return MODE_ERR_BAD_ARG;
@@ -215,21 +214,28 @@ extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, con
   if (workspace_bytes < mode_bn_workspace_bytes(d->N, d->C)) return MODE_ERR_WORKSPACE;
   const long rows = (long)d->N * d->C;
   if (rows == 0) return MODE_OK;
+  if (phase < 0 || phase > 2) return MODE_ERR_BAD_ARG;
   float* sums = (float*)workspace;
   const dim3 grid((unsigned)((rows + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
-  if (d->dtype == MODE_F32) hipLaunchKernelGGL(bn_film_act_bwd_sums_kernel<float>, grid, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, sums);
-  else hipLaunchKernelGGL(bn_film_act_bwd_sums_kernel<uint16_t>, grid, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, sums);
-  MODE_LAUNCH_CHECK();
-  const long nfold = rows > d->C ? rows : d->C;
-  hipLaunchKernelGGL(bn_film_bwd_fold_kernel, dim3((unsigned)((nfold + 255) / 256)), dim3(256), 0, s, sums, d->N, d->C, dweight, dbias, d_pre_gamma, d_pre_beta,
-                     d_post_gamma, d_post_beta);
-  MODE_LAUNCH_CHECK();
-  if (d->dtype == MODE_F32)
-    hipLaunchKernelGGL(bn_film_act_bwd_dx_kernel<float>, grid, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, dweight, dbias, training, (float*)dx, (float*)dresidual);
-  else
-    hipLaunchKernelGGL(bn_film_act_bwd_dx_kernel<uint16_t>, grid, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, dweight, dbias, training, (uint16_t*)dx,
-                       (uint16_t*)dresidual);
-  MODE_LAUNCH_CHECK();
+  if (phase != 2) {                                            // reductions: FiLM gradients per (n, c), BatchNorm affine gradients per channel
+    if (d->dtype == MODE_F32) hipLaunchKernelGGL(bn_film_act_bwd_sums_kernel<float>, grid, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, sums);
+    else hipLaunchKernelGGL(bn_film_act_bwd_sums_kernel<uint16_t>, grid, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, sums);
+    MODE_LAUNCH_CHECK();
+    const long nfold = rows > d->C ? rows : d->C;
+    hipLaunchKernelGGL(bn_film_bwd_fold_kernel, dim3((unsigned)((nfold + 255) / 256)), dim3(256), 0, s, sums, d->N, d->C, dweight, dbias, d_pre_gamma, d_pre_beta,
+                       d_post_gamma, d_post_beta);
+    MODE_LAUNCH_CHECK();
+  }
+  if (phase != 1) {                                            // dx / d residual from the (possibly cross-rank summed) channel sums
+    const float inv_m = inv_count > 0.f ? inv_count : 1.f / ((float)d->N * (float)d->HW);
+    if (d->dtype == MODE_F32)
+      hipLaunchKernelGGL(bn_film_act_bwd_dx_kernel<float>, grid, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, dweight, dbias, training, inv_m, (float*)dx,
+                         (float*)dresidual);
+    else
+      hipLaunchKernelGGL(bn_film_act_bwd_dx_kernel<uint16_t>, grid, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, dweight, dbias, training, inv_m,
+                         (uint16_t*)dx, (uint16_t*)dresidual);
+    MODE_LAUNCH_CHECK();
+  }
   return MODE_OK;
 }

@@ -66,9 +66,32 @@ class DitEngine:
                                eps=1e-6)
 
     # ------------------------------------------------------------------ weights
+    def param_index(self):
+        """[(owner module, attribute name, parameter, dotted name)] of the model, cached.  ``Module.named_parameters()`` walks the module tree
+        through nested generators - three walks per training step cost ~10 ms of host time under a profiler (the eager training chain is the
+        one host-sensitive leg: a slow host then makes the step host-bound).  The cache is validated by identity against the owners'
+        ``_parameters`` dicts (a re-assigned Parameter object rebuilds it); re-allocated storage is caught by ``ParamArena.owns``."""
+        idx = getattr(self, "_pidx", None)
+        if idx is not None and all(mod._parameters.get(n) is p for mod, n, p, _ in idx):
+            return idx
+        idx = []
+        nmod = 0
+        for mname, mod in self.model.named_modules():
+            nmod += 1
+            for n, p in mod._parameters.items():
+                if p is not None:
+                    idx.append((mod, n, p, f"{mname}.{n}" if mname else n))
+        order = {nm: i for i, (nm, _) in enumerate(self.model.named_parameters())}      # registration order = what named_parameters() yields
+        idx.sort(key=lambda t: order[t[3]])
+        self._pidx, self._pidx_modules = idx, nmod
+        return idx
+
+    def named_params(self):
+        return [(nm, p) for _, _, p, nm in self.param_index()]
+
     def _key(self):
         ar = self.arena
-        return (id(ar), ar.version, tuple(p._version for p in self.model.parameters()))
+        return (id(ar), ar.version, tuple(p._version for _, _, p, _ in self.param_index()))
 
     def ensure_weights(self) -> None:
         """Adopt the module's parameters into the flat arena (once) and keep the compute shadow current.
@@ -78,7 +101,7 @@ class DitEngine:
         ``.to()`` / ``.half()`` re-allocate parameters -> they no longer alias the arena and it is rebuilt."""
         m = self.model
         ar = self.arena
-        if ar is None or not ar.owns(m):
+        if ar is None or not ar.owns(m, self.named_params()):
             dev = m.pos_emb.device
             if dev.type != "cuda":
                 raise L.ModeHipUnavailable("MoDeDiT parameters must live on a ROCm device: the denoising path has no CPU implementation")

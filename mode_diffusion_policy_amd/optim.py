@@ -44,7 +44,7 @@ class FusedAdamW:
         torch's AdamW skips tensors without a gradient, so these slices are left untouched."""
         ar = self.arena
         base = ar.flat.data_ptr()
-        spans = sorted(((p.data_ptr() - base) // 4, (p.data_ptr() - base) // 4 + p.numel()) for p in self.model.parameters() if not p.requires_grad)
+        spans = sorted(((p.data_ptr() - base) // 4, (p.data_ptr() - base) // 4 + p.numel()) for _, p in self.eng.named_params() if not p.requires_grad)
         merged = []
         for lo, hi in spans:
             if merged and lo <= merged[-1][1]:

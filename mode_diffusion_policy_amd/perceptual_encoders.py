@@ -18,8 +18,9 @@ denoiser's input gradients (training.py).  No CPU path: the fused op raises off-
 
 Parity status: the FiLM wiring is pinned against the REFERENCE classes (oracle/gen_golden_encoders.py runs them on top of a stand-in trunk with
 the attribute names their constructors read, fixture F15); the trunk itself is the textbook ResNet restated — timm / torchvision are absent
-from the build image, so "trunk == timm's resnet50" rests on the key / shape contract only.  SyncBatchNorm (the reference trains with
-``sync_batchnorm=True``) is not built: under data parallelism batch statistics are per rank.
+from the build image, so "trunk == timm's resnet50" rests on the key / shape contract only.  ``nn.SyncBatchNorm`` holders (what Lightning's
+``sync_batchnorm=True`` converts the BatchNorm2d modules into, mode/training_calvin.py:102) are honoured: statistics and the backward's channel
+sums are all-reduced over the module's process group (two small collectives per BatchNorm and direction).
 """
 from __future__ import annotations
 
@@ -54,7 +55,7 @@ class _BnFilmAct(torch.autograd.Function):
     """y = post_film(relu(pre_film(batch_norm(x)) + residual)) as one HIP launch (two for training statistics); see csrc/encoder_ops.hip."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b, sync_group=None):
         if x.device.type != "cuda":
             raise L.ModeHipUnavailable("FiLM-ResNet encoders run through the HIP library only: inputs must live on a ROCm device")
         lib = L.load()
@@ -68,11 +69,21 @@ class _BnFilmAct(torch.autograd.Function):
         if training:
             mean = torch.empty(Cc, device=dev); var = torch.empty(Cc, device=dev)
             L.check(lib.mode_bn_stats(x.data_ptr(), _dt(x), N, Cc, HW, mean.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn_stats")
+            m = N * HW
+            if sync_group is not None:
+                # nn.SyncBatchNorm (Lightning's sync_batchnorm=True, mode/training_calvin.py:102): the statistics of the GLOBAL batch - one small
+                # all-reduce of [sum, sum of squares, count] per BatchNorm (RCCL; 2C + 1 floats)
+                import torch.distributed as dist
+                pack = torch.cat([mean * m, (var + mean * mean) * m, torch.full((1,), float(m), device=dev)])
+                dist.all_reduce(pack, group=sync_group if sync_group is not True else None)
+                m = pack[-1]                                                   # global element count per channel: stays on the device (no host sync)
+                mean = pack[:Cc] / m
+                var = (pack[Cc:2 * Cc] / m - mean * mean).clamp_min_(0.0)
             if running_mean is not None:                                       # nn.BatchNorm2d bookkeeping: unbiased variance into the running estimate
                 with torch.no_grad():
-                    m = N * HW
                     running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
-                    running_var.mul_(1 - momentum).add_((var * (m / max(m - 1, 1))).to(running_var.dtype), alpha=momentum)
+                    unbias = (m / (m - 1).clamp_min(1.0)) if torch.is_tensor(m) else (m / max(m - 1, 1))
+                    running_var.mul_(1 - momentum).add_((var * unbias).to(running_var.dtype), alpha=momentum)
         else:
             mean, var = f32(running_mean), f32(running_var)
         invstd = torch.rsqrt(var + eps)
@@ -87,6 +98,7 @@ class _BnFilmAct(torch.autograd.Function):
         L.check(lib.mode_bn_film_act_fwd(C.byref(_desc(x, scale, shift, pre, res, relu, post, y)), _stream()), "bn_film_act_fwd")
         ctx.save_for_backward(x, res, scale, shift, mean, invstd, *(pre or ()), *(post or ()))
         ctx.cfg = (bool(training), bool(relu), pre is not None, post is not None, res is not None)
+        ctx.sync = (sync_group, m) if (training and sync_group is not None) else None
         ctx.shapes = (None if pre_g is None else pre_g.shape, None if post_g is None else post_g.shape)
         return y
 
@@ -110,21 +122,37 @@ class _BnFilmAct(torch.autograd.Function):
         ws = torch.empty(lib.mode_bn_workspace_bytes(N, Cc), dtype=torch.uint8, device=dev)
         d = _desc(x, scale, shift, pre, res if has_res else None, relu, post, None)
         d.y = x.data_ptr()                                                     # unused by the backward; the descriptor check wants a pointer
-        L.check(lib.mode_bn_film_act_bwd(C.byref(d), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), int(training), dx.data_ptr(), _ptr(dres),
-                                         dw.data_ptr(), db.data_ptr(), _ptr(dpg), _ptr(dpb), _ptr(dqg), _ptr(dqb), ws.data_ptr(), ws.numel(), _stream()),
-                "bn_film_act_bwd")
+        def call(phase, inv_count, dw_, db_):
+            L.check(lib.mode_bn_film_act_bwd(C.byref(d), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), int(training), phase, float(inv_count), dx.data_ptr(),
+                                             _ptr(dres), dw_.data_ptr(), db_.data_ptr(), _ptr(dpg), _ptr(dpb), _ptr(dqg), _ptr(dqb), ws.data_ptr(), ws.numel(),
+                                             _stream()), "bn_film_act_bwd")
+        if ctx.sync is None:
+            call(0, 0.0, dw, db)
+        else:                                                                  # SyncBatchNorm: channel sums over ALL ranks feed dx; dweight / dbias stay this rank's
+            import torch.distributed as dist
+            group, m_global = ctx.sync                                      # m_global: device scalar
+            call(1, 0.0, dw, db)
+            tot = torch.stack([dw, db])
+            dist.all_reduce(tot, group=group if group is not True else None)
+            tot = tot / m_global                                            # the global MEANS, so that phase 2 runs with inv_count = 1
+            call(2, 1.0, tot[0].contiguous(), tot[1].contiguous())
         ps, qs = ctx.shapes
         rs = lambda t, shp: None if t is None else t.reshape(shp)
         # inputs: x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b
-        return dx, dw, db, None, None, None, None, None, None, dres, rs(dpg, ps), rs(dpb, ps), rs(dqg, qs), rs(dqb, qs)
+        return dx, dw, db, None, None, None, None, None, None, dres, rs(dpg, ps), rs(dpb, ps), rs(dqg, qs), rs(dqb, qs), None
 
 
 def bn_film_act(x, bn: nn.BatchNorm2d, relu: bool = True, residual=None, pre_film=None, post_film=None):
     """``post_film(relu(pre_film(bn(x)) + residual))``; ``pre_film`` / ``post_film`` = (gamma, beta), each (N, C) (or broadcastable views of it)."""
     pg, pb = pre_film if pre_film is not None else (None, None)
     qg, qb = post_film if post_film is not None else (None, None)
+    sync = None
+    if isinstance(bn, nn.SyncBatchNorm) and bn.training:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.process_group) > 1:
+            sync = bn.process_group if bn.process_group is not None else True
     return _BnFilmAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, 0.1 if bn.momentum is None else bn.momentum, bn.eps, relu,
-                            residual, pg, pb, qg, qb)
+                            residual, pg, pb, qg, qb, sync)
 
 
 # ------------------------------------------------------------------------------------------------------------------ trunk (parameter holders)

@@ -268,7 +268,7 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     keep_alive = (img, gl, acts, sig, e1, emb_t, img_e, goal_e, cond, idx, w, probs, shifted, r_pre, meta, act_rows, stash)
     # Function inputs = the parameters that can receive a gradient.  gripper_embed.weight is dead in the reference too (modedit.py:684): left out,
     # so that DistributedDataParallel(find_unused_parameters=True) - how the reference trains, training_calvin.py:92-103 - sees it as unused.
-    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and n != "gripper_embed.weight"]
+    named = [(n, p) for n, p in eng.named_params() if p.requires_grad and n != "gripper_embed.weight"]
     names, params = [n for n, _ in named], [p for _, p in named]
 
     def backward(dF: torch.Tensor, dlb=None, dz=None, want_img=False, want_goal=False):
@@ -302,7 +302,7 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         if ts._ws is None or ts._ws.numel() < wsb:
             ts._ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         nred = ar.bounds["no_decay"]
-        all_params = list(model.parameters())
+        all_params = [p for _, p in eng.named_params()]
         # The chain OVERWRITES its gradient buffer.  Straight into the arena when that is what the step wants (arena mode, first backward after
         # the optimizer consumed the previous sum); otherwise into a buffer of its own: handed to autograd (autograd mode), or ADDED to the
         # arena - a second backward before the optimizer step must accumulate like autograd does (the reference's training_step sums the losses

@@ -157,3 +157,60 @@ def test_encoders_train_through_the_hip_denoiser():
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
         assert float(enc.resnet.conv1.weight.grad.abs().max()) > 0 and float(enc.film4.gamma.weight.grad.abs().max()) > 0
     assert float(den.tok_emb.weight.grad.abs().max()) > 0
+
+
+def _syncbn_worker(rank, world, port, outdir):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        N, C, H = 6, 12, 5
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(N, C, H, H, generator=g).cuda(); r = torch.randn(N, C, H, H, generator=g).cuda(); w = torch.randn(N, C, H, H, generator=g).cuda()
+        pg = torch.randn(N, C, generator=g).cuda(); pb = torch.randn(N, C, generator=g).cuda()
+        bn = torch.nn.SyncBatchNorm(C).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.2, 0.2, C))
+        sl = slice(rank * N // world, (rank + 1) * N // world)
+        xs = x[sl].clone().requires_grad_(True); rs = r[sl].clone().requires_grad_(True)
+        y = E.bn_film_act(xs, bn, relu=True, residual=rs, pre_film=(pg[sl], pb[sl]))
+        (y * w[sl]).sum().backward()
+        torch.cuda.synchronize()
+        torch.save(dict(y=y.detach().cpu(), dx=xs.grad.cpu(), dr=rs.grad.cpu(), dw=bn.weight.grad.cpu(), db=bn.bias.grad.cpu(), rm=bn.running_mean.cpu(),
+                        rv=bn.running_var.cpu()), os.path.join(outdir, f"s{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sync_batchnorm_world2_equals_one_process_on_the_whole_batch(tmp_path):
+    """nn.SyncBatchNorm holders (Lightning's sync_batchnorm=True, mode/training_calvin.py:102): with the batch split over two ranks the fused op
+    normalises with the statistics of the WHOLE batch and back-propagates through them - outputs / dx / d residual equal the single-process
+    BatchNorm2d run on the concatenated batch, the per-rank affine gradients sum to it, running statistics agree on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=200)
+        assert p.exitcode == 0
+    o = [torch.load(tmp_path / f"s{r}.pt") for r in range(2)]
+    N, C, H = 6, 12, 5
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, C, H, H, generator=g).cuda(); r = torch.randn(N, C, H, H, generator=g).cuda(); w = torch.randn(N, C, H, H, generator=g).cuda()
+    pg = torch.randn(N, C, generator=g).cuda(); pb = torch.randn(N, C, generator=g).cuda()
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.2, 0.2, C))
+    xs = x.clone().requires_grad_(True); rs = r.clone().requires_grad_(True)
+    y = E.bn_film_act(xs, bn, relu=True, residual=rs, pre_film=(pg, pb))
+    (y * w).sum().backward()
+    cat = lambda k: torch.cat([o[0][k], o[1][k]])
+    assert rel(cat("y"), y) < 1e-5 and rel(cat("dx"), xs.grad) < 1e-4 and rel(cat("dr"), rs.grad) < 1e-5
+    assert rel(o[0]["dw"] + o[1]["dw"], bn.weight.grad) < 1e-4 and rel(o[0]["db"] + o[1]["db"], bn.bias.grad) < 1e-4
+    assert torch.equal(o[0]["rm"], o[1]["rm"]) and rel(o[0]["rm"], bn.running_mean) < 1e-5 and rel(o[0]["rv"], bn.running_var) < 1e-5
