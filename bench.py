@@ -385,7 +385,7 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU):
     z1 = None if (z1 in ("0", "", "none") or red is None or world == 1) else z1
     if z1 == "bf16" and m.engine.compute_dtype != "bf16":
         z1 = "fp32"
-    n_ev = 2 * steps + max(warmup, 1) + 2
+    n_ev = 8 * steps + max(warmup, 1) + 2
     ev_bwd = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
     ev_end = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
     it = [0]
@@ -409,10 +409,11 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU):
         one = torch.ones(1, device=device)
         dist.all_reduce(one)                                                   # the number of ranks the collective library actually connected
         ranks = int(round(float(one.item())))
-    # TWO timed blocks of `steps` steps, the faster one reported (both listed): the eager training chain is the one leg of this file whose first
-    # seconds in a process can run 2x slow right after another GPU process exited on the box (seen: 29 vs 13 ms)
+    # Timed blocks of `steps` steps until the two fastest agree within 5 % (at most 8; all listed), the fastest reported: the eager training chain
+    # is the one leg of this file that runs 2-3x slow for the first seconds of a process started right after another GPU process exited on the box
+    # (seen: 27 / 46 ms blocks, then 13 ms; the graph-captured sampler never shows it)
     blocks = []
-    for _ in range(2):
+    for _ in range(8):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -428,9 +429,12 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         blocks.append(el)
-    best = min(range(2), key=lambda i: blocks[i])
+        srt = sorted(blocks)
+        if len(blocks) >= 2 and srt[1] <= 1.05 * srt[0]:                       # two blocks agree on the steady state (every rank sees the same MAX-reduced times)
+            break
+    best = min(range(len(blocks)), key=lambda i: blocks[i])
     elapsed = blocks[best]
-    ev_lo = it[0] - (2 - best) * steps                                         # events of the reported block
+    ev_lo = it[0] - (len(blocks) - best) * steps                               # events of the reported block
     if z1:
         opt.gather_state(red)                                                  # leave exact masters / moments on every rank
     den.train(was_training)
