@@ -491,7 +491,7 @@ int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w, const Mode
 typedef struct ModeStashLayout {
   uint64_t x0, h1, qkv, yattn, x1, ub, P, Hd, Y;     /* byte offsets inside one layer record */
   uint64_t layer_stride;
-  uint64_t xL, yL, u_tmp, global_bytes;              /* global part (precedes the layer records) */
+  uint64_t xL, yL, u_tmp, tr_hid, tr_logits, global_bytes;   /* global part (precedes the layer records); tr_*: token-router scratch */
   uint64_t total_bytes;
 } ModeStashLayout;
 int mode_dit_train_stash_layout(const ModeDims* dims, int B, int dtype, ModeStashLayout* out);
@@ -512,7 +512,7 @@ typedef struct ModeTrainArgs {
   const int32_t* act_rows;                                /* [B*A_len] token row of every action token                    */
   const int32_t* meta; int64_t meta_layer_stride;         /* L per-token dispatch records                                 */
   const int32_t* topk_idx; int64_t topk_layer_stride; int32_t idx_per_token;   /* [L][B*T or B][k] expert ids            */
-  const float* probs;            /* [L, B, E] clamped softmax of the router                  */
+  const float* probs;            /* [L, B, E] clamped softmax of the router ([L, N, E] under token routing: written by phase 0) */
   const float* r_pre;            /* [B, L, 2D] router pre-GELU activations (mode_dit_route)  */
   float* F;                      /* out: [B, A_len, A]                                       */
   void* const* layer_events;     /* optional hipEvent_t[L] (backward only): event l is recorded on the stream as soon as ALL weight
@@ -529,9 +529,22 @@ typedef struct ModeTrainArgs {
    * the conditioning/router path when goal_in_cond).  Two fp32 GEMMs on quantities the chain already holds. */
   float* d_state_images;         /* out: [B*n_img, O] or NULL                                */
   float* d_goals;                /* out: [B, G] or NULL (gradient w.r.t. the goals AFTER preprocess_goals / the Bernoulli mask) */
+  /* ABI 5: TOKEN routing in training (the reference's cond_router=False, modedit.py:296-301, 322-325, 550-553: every block routes each token on
+   * its own ln_2-normalised state).  The forward is driven layer by layer (mode_dit_forward_train_layer): phase 0 of layer l runs attention +
+   * ln_2 + the block's fp32 router and writes, for THAT layer, probs[l] / tr_shifted[l] ([L, N, E], N = B*T routing rows), the pre-GELU
+   * activations tr_pre[l] ([L, N, 2D], kept for the backward) and the top-k choice into tr_topk_idx / tr_topk_w ([N, k], one layer's worth);
+   * the caller then fixes the experts of the layer (top-k, or torch.multinomial on probs[l] like modedit.py:390), fills topk_idx[l]
+   * (idx_per_token = 1) and meta[l], and runs phase 1 (experts + combine).  The backward (one call) back-propagates every block's router in
+   * place: d u gets the router's term, r_pre / the batched conditioning-row router backward are not used. */
+  int32_t token_routing;
+  float* tr_pre; float* tr_shifted; int32_t* tr_topk_idx; float* tr_topk_w;
 } ModeTrainArgs;
 int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes,
                            void* stream);
+/* One layer of the training forward in two phases (see ModeTrainArgs.token_routing): phase 0 = [token embedding if layer == 0,] QKV, attention,
+ * c_proj + residual, ln_2 [, token router]; phase 1 = experts, combine [, output head if layer == L - 1].  Phases must be called in order. */
+int mode_dit_forward_train_layer(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes,
+                                 int layer, int phase, void* stream);
 
 typedef struct ModeLayerGrads {           /* fp32 gradients, same shapes as ModeLayerWeights (packed qkv / stacked experts) */
   float* ln1_g; float* ln2_g; float* qn_g; float* kn_g; float* wqkv; float* bqkv; float* wo;

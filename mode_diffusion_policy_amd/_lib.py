@@ -73,7 +73,7 @@ c_u64, c_u32 = C.c_uint64, C.c_uint32
 
 
 class ModeStashLayout(C.Structure):
-    _fields_ = [(n, c_u64) for n in ("x0", "h1", "qkv", "yattn", "x1", "ub", "P", "Hd", "Y", "layer_stride", "xL", "yL", "u_tmp", "global_bytes",
+    _fields_ = [(n, c_u64) for n in ("x0", "h1", "qkv", "yattn", "x1", "ub", "P", "Hd", "Y", "layer_stride", "xL", "yL", "u_tmp", "tr_hid", "tr_logits", "global_bytes",
                                      "total_bytes")]
 
 
@@ -89,7 +89,8 @@ class ModeTrainArgs(C.Structure):
                 ("img_e", c_vp), ("actions", c_vp), ("c_in", c_vp), ("c_in_stride", c_i64), ("actions_scaled", c_vp), ("act_rows", c_vp),
                 ("meta", c_vp), ("meta_layer_stride", c_i64), ("topk_idx", c_vp), ("topk_layer_stride", c_i64), ("idx_per_token", c_i32),
                 ("probs", c_vp), ("r_pre", c_vp), ("F", c_vp), ("layer_events", c_vp), ("shifted", c_vp), ("aux_lb_coef", c_vp), ("aux_z_coef", c_vp),
-                ("d_state_images", c_vp), ("d_goals", c_vp)]
+                ("d_state_images", c_vp), ("d_goals", c_vp), ("token_routing", c_i32), ("tr_pre", c_vp), ("tr_shifted", c_vp), ("tr_topk_idx", c_vp),
+                ("tr_topk_w", c_vp)]
 
 
 class ModeLayerGrads(C.Structure):
@@ -169,6 +170,7 @@ PROTOTYPES = {
     "mode_dit_train_stash_layout": (C.c_int, [P(ModeDims), C.c_int, C.c_int, P(ModeStashLayout)]),
     "mode_dit_train_workspace_bytes": (c_sz, [P(ModeDims), C.c_int, C.c_int]),
     "mode_dit_forward_train": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeTrainArgs), c_vp, c_sz, c_vp]),
+    "mode_dit_forward_train_layer": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeTrainArgs), c_vp, c_sz, c_i32, c_i32, c_vp]),
     "mode_moe_grouped_mlp_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "mode_moe_grouped_mlp_fwd": (C.c_int, [P(ModeGroupedMlpDesc), c_vp]),
     "mode_moe_grouped_mlp_bwd": (C.c_int, [P(ModeGroupedMlpDesc), c_vp, c_sz, c_vp]),

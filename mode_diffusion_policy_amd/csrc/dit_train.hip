@@ -36,7 +36,7 @@ ModeGemmDesc gdesc(int dtype, int epi, int out_dtype, int M, int N, int K, const
 
 struct TrainWs {   // backward workspace offsets
   size_t dxa, dxb, dyl, dys, dhd, dp, dus, dwt, t_big, t_mid, t_d, t_d2, dx1lp, dyattn, dqkv, dh1, dgp, apq, apk, csw, dcond, dlog, dhid, dpre,
-      st1, st2, tmp_rd, demb, de1, dimg, dgoal, total;
+      st1, st2, tmp_rd, demb, de1, dimg, dgoal, tr_dlog, tr_dpre, tr_u, tr_du, total;
 };
 
 TrainWs train_ws(const ModeDims& d, int B, int dtype) {
@@ -69,6 +69,8 @@ TrainWs train_ws(const ModeDims& d, int B, int dtype) {
   w.st1 = t(smallT); w.st2 = t(smallT);
   w.tmp_rd = t(R * D * 4);
   w.demb = t((size_t)B * D * 4); w.de1 = t((size_t)B * D * 4); w.dimg = t((size_t)B * d.n_img * D * 4); w.dgoal = t((size_t)B * D * 4);
+  // token routing (cond_router=False): one layer's router backward - dlogits [N,E], dpre [N,2D], recomputed ln_2 output [N,D], d u from the router [N,D]
+  w.tr_dlog = t(N * (size_t)d.E * 4); w.tr_dpre = t(N * 2 * D * 4); w.tr_u = t(N * D * 4); w.tr_du = t(N * D * 4);
   w.total = t.o;
   return w;
 }
@@ -95,6 +97,7 @@ extern "C" int mode_dit_train_stash_layout(const ModeDims* dims, int B, int dtyp
   out->layer_stride = t.o;
   Take g;
   out->xL = g(N * D * 4); out->yL = g(N * D * 4); out->u_tmp = g(N * D * 4);
+  out->tr_hid = g(N * 2 * D * 4); out->tr_logits = g(N * (size_t)dims->E * 4);      /* token routing (cond_router=False): one layer's router scratch */
   out->global_bytes = g.o;
   out->total_bytes = out->global_bytes + out->layer_stride * dims->L;
   return MODE_OK;
@@ -106,15 +109,20 @@ extern "C" size_t mode_dit_train_workspace_bytes(const ModeDims* dims, int B, in
 }
 
 // ------------------------------------------------------------------------------------------------------------------ forward
-extern "C" int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes,
-                                      void* stream) {
+// Layers [l0, l1) of the training forward; phases bit 0 = everything up to and including ln_2 (+ the token router of cond_router=False), bit 1 =
+// experts + combine (+ the output head behind the last layer).  Conditioning-row routing runs all layers with both phases in one call; token
+// routing is driven layer by layer from the host, which draws the expert ids between the two phases (modedit.py:390: torch.multinomial per token).
+static int forward_train_impl(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes, int l0, int l1,
+                              int phases, void* stream) {
   int rc = check_train_dims(dims);
   if (rc) return rc;
   if (!w || !w->layers || !a || !stash || !a->meta || !a->goal_e || !a->img_e || !a->actions || !a->emb_t || !a->cond || !a->act_rows || !a->F)
     return MODE_ERR_BAD_ARG;
   const ModeDims& d = *dims;
+  if (l0 < 0 || l1 > d.L || l0 >= l1) return MODE_ERR_BAD_ARG;
   const int dt = a->dtype, B = a->B, T = d.T, D = d.D, N = B * T, NK = N * d.k;
   if (dt == MODE_BF16 && (D % 64 || (D / d.H) % 16 || (D / d.H) > 128)) return MODE_ERR_UNSUPPORTED;
+  if (a->token_routing && (!a->tr_pre || !a->probs || !a->tr_shifted || !a->tr_topk_idx || !a->tr_topk_w)) return MODE_ERR_BAD_ARG;
   ModeStashLayout sl;
   rc = mode_dit_train_stash_layout(dims, B, dt, &sl);
   if (rc) return rc;
@@ -125,49 +133,84 @@ extern "C" int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeigh
   ModeMetaLayout ml;
   mode_moe_meta_layout(N, d.E, d.k, &ml);
 
-  ModeEmbedDesc e;
-  memset(&e, 0, sizeof(e));
-  e.B = B; e.T = T; e.D = D; e.A_len = d.A_len; e.A_dim = d.A_dim; e.n_img = d.n_img; e.use_noise_token = d.use_noise_token;
-  e.emb_t = a->emb_t; e.emb_row_stride = D; e.goal_e = a->goal_e; e.img_e = a->img_e; e.actions = a->actions;
-  e.c_in = a->c_in; e.c_in_stride = a->c_in_stride; e.w_act = w->w_act; e.pos = w->pos; e.g = w->layers[0].ln1_g;
-  e.cond = a->cond; e.cond_row_stride = D; e.eps = d.eps; e.x = (float*)(L_(0) + sl.x0); e.h = L_(0) + sl.h1; e.h_dtype = dt;
-  rc = mode_embed_tokens_fwd(&e, stream);
-  if (rc) return rc;
+  if (l0 == 0 && (phases & 1)) {
+    ModeEmbedDesc e;
+    memset(&e, 0, sizeof(e));
+    e.B = B; e.T = T; e.D = D; e.A_len = d.A_len; e.A_dim = d.A_dim; e.n_img = d.n_img; e.use_noise_token = d.use_noise_token;
+    e.emb_t = a->emb_t; e.emb_row_stride = D; e.goal_e = a->goal_e; e.img_e = a->img_e; e.actions = a->actions;
+    e.c_in = a->c_in; e.c_in_stride = a->c_in_stride; e.w_act = w->w_act; e.pos = w->pos; e.g = w->layers[0].ln1_g;
+    e.cond = a->cond; e.cond_row_stride = D; e.eps = d.eps; e.x = (float*)(L_(0) + sl.x0); e.h = L_(0) + sl.h1; e.h_dtype = dt;
+    rc = mode_embed_tokens_fwd(&e, stream);
+    if (rc) return rc;
+  }
 
-  for (int l = 0; l < d.L; ++l) {
+  for (int l = l0; l < l1; ++l) {
     const ModeLayerWeights& lw = w->layers[l];
     char* S = L_(l);
     const int32_t* meta = a->meta + (long)l * a->meta_layer_stride;
     float* x0 = (float*)(S + sl.x0); float* x1 = (float*)(S + sl.x1);
-    ModeGemmDesc g = gdesc(dt, MODE_EPI_BIAS, dt, N, 3 * D, D, S + sl.h1, D, lw.wqkv, D, S + sl.qkv, 3 * D);
-    g.bias = lw.bqkv;
-    if ((rc = mode_gemm(&g, stream))) return rc;
-    if ((rc = mode_attn_block_fwd(S + sl.qkv, lw.qn_g, lw.kn_g, S + sl.yattn, dt, B, T, d.H, D / d.H, d.eps, mode_stream_seed(a->seed, 2 * l), a->attn_pdrop, stream)))
-      return rc;
-    g = gdesc(dt, MODE_EPI_RESIDUAL, MODE_F32, N, D, D, S + sl.yattn, D, lw.wo, D, x1, D);
-    g.resid = x0; g.ldr = D;
-    if ((rc = mode_gemm(&g, stream))) return rc;
-    if ((rc = mode_rmsnorm_cond_fwd(x1, lw.ln2_g, nullptr, N, D, 1, d.eps, u_tmp, S + sl.ub, dt, stream))) return rc;
-    g = gdesc(dt, MODE_EPI_BIAS, dt, NK, 8 * D, D, S + sl.ub, D, lw.w1, D, S + sl.P, 8 * D);          // pre-activation [value | gate] kept for backward
-    g.bias = lw.b1; g.w_expert_stride = 8L * D * D; g.bias_expert_stride = 8L * D;
-    g.a_rows = meta + ml.perm; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
-    if ((rc = mode_gemm(&g, stream))) return rc;
-    if ((rc = mode_swiglu_fwd(S + sl.P, S + sl.Hd, NK, 4 * D, dt, mode_stream_seed(a->seed, 2 * l + 1), a->mlp_pdrop, stream))) return rc;
-    g = gdesc(dt, MODE_EPI_NONE, dt, NK, D, 4 * D, S + sl.Hd, 4 * D, lw.w2, 4 * D, S + sl.Y, D);
-    g.w_expert_stride = 4L * D * D; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
-    if ((rc = mode_gemm(&g, stream))) return rc;
-    const bool last = l + 1 == d.L;
-    float* xn = last ? (float*)(sg + sl.xL) : (float*)(L_(l + 1) + sl.x0);
-    rc = mode_moe_combine_norm_fwd(u_tmp, S + sl.Y, dt, 1, 0, meta + ml.pos, reinterpret_cast<const float*>(meta + ml.posw), N, D, d.k,
-                                   last ? nullptr : w->layers[l + 1].ln1_g, last ? nullptr : a->cond, T, d.eps, xn,
-                                   last ? nullptr : (void*)(L_(l + 1) + sl.h1), dt, stream);
-    if (rc) return rc;
+    ModeGemmDesc g;
+    if (phases & 1) {
+      g = gdesc(dt, MODE_EPI_BIAS, dt, N, 3 * D, D, S + sl.h1, D, lw.wqkv, D, S + sl.qkv, 3 * D);
+      g.bias = lw.bqkv;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      if ((rc = mode_attn_block_fwd(S + sl.qkv, lw.qn_g, lw.kn_g, S + sl.yattn, dt, B, T, d.H, D / d.H, d.eps, mode_stream_seed(a->seed, 2 * l), a->attn_pdrop, stream)))
+        return rc;
+      g = gdesc(dt, MODE_EPI_RESIDUAL, MODE_F32, N, D, D, S + sl.yattn, D, lw.wo, D, x1, D);
+      g.resid = x0; g.ldr = D;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      if ((rc = mode_rmsnorm_cond_fwd(x1, lw.ln2_g, nullptr, N, D, 1, d.eps, u_tmp, S + sl.ub, dt, stream))) return rc;
+      if (a->token_routing) {
+        // router(x, None) on the ln_2-normalised TOKEN states (modedit.py:296-301, 322-325, 553): fp32 like every router of this library; the
+        // pre-GELU activations stay for the backward; probabilities / shifted logits / top-k of THIS layer go out to the host
+        float* pre = a->tr_pre + (size_t)l * N * 2 * D;
+        float* hid = (float*)(sg + sl.tr_hid); float* logits = (float*)(sg + sl.tr_logits);
+        ModeGemmDesc rg = gdesc(MODE_F32, MODE_EPI_BIAS, MODE_F32, N, 2 * D, D, u_tmp, D, lw.r_w0, D, pre, 2L * D);
+        rg.bias = lw.r_b0;
+        if ((rc = mode_gemm(&rg, stream))) return rc;
+        if ((rc = mode_gelu_fwd(pre, hid, (int64_t)N * 2 * D, stream))) return rc;
+        if ((rc = mode_router_logits(hid, 2L * D, lw.r_w3, 0, lw.r_b3, 0, 1, N, d.E, 2 * D, logits, stream))) return rc;
+        if ((rc = mode_moe_route_topk_f32(logits, N, d.E, d.k, d.router_normalize, a->tr_shifted + (size_t)l * N * d.E,
+                                          const_cast<float*>(a->probs) + (size_t)l * N * d.E, a->tr_topk_idx, a->tr_topk_w, stream))) return rc;
+      }
+    }
+    if (phases & 2) {
+      g = gdesc(dt, MODE_EPI_BIAS, dt, NK, 8 * D, D, S + sl.ub, D, lw.w1, D, S + sl.P, 8 * D);          // pre-activation [value | gate] kept for backward
+      g.bias = lw.b1; g.w_expert_stride = 8L * D * D; g.bias_expert_stride = 8L * D;
+      g.a_rows = meta + ml.perm; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      if ((rc = mode_swiglu_fwd(S + sl.P, S + sl.Hd, NK, 4 * D, dt, mode_stream_seed(a->seed, 2 * l + 1), a->mlp_pdrop, stream))) return rc;
+      g = gdesc(dt, MODE_EPI_NONE, dt, NK, D, 4 * D, S + sl.Hd, 4 * D, lw.w2, 4 * D, S + sl.Y, D);
+      g.w_expert_stride = 4L * D * D; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+      const bool last = l + 1 == d.L;
+      float* xn = last ? (float*)(sg + sl.xL) : (float*)(L_(l + 1) + sl.x0);
+      rc = mode_moe_combine_norm_fwd(u_tmp, S + sl.Y, dt, 1, 0, meta + ml.pos, reinterpret_cast<const float*>(meta + ml.posw), N, D, d.k,
+                                     last ? nullptr : w->layers[l + 1].ln1_g, last ? nullptr : a->cond, T, d.eps, xn,
+                                     last ? nullptr : (void*)(L_(l + 1) + sl.h1), dt, stream);
+      if (rc) return rc;
+    }
   }
-  float* yL = (float*)(sg + sl.yL);
-  if ((rc = mode_rmsnorm_cond_fwd((const float*)(sg + sl.xL), w->ln_g, nullptr, N, D, 1, d.eps, yL, nullptr, MODE_F32, stream))) return rc;
-  ModeGemmDesc g = gdesc(MODE_F32, MODE_EPI_BIAS, MODE_F32, B * d.A_len, d.A_dim, D, yL, D, w->w_out, D, a->F, d.A_dim);
-  g.bias = w->b_out; g.a_rows = a->act_rows;
-  return mode_gemm(&g, stream);
+  if (l1 == d.L && (phases & 2)) {
+    float* yL = (float*)(sg + sl.yL);
+    if ((rc = mode_rmsnorm_cond_fwd((const float*)(sg + sl.xL), w->ln_g, nullptr, N, D, 1, d.eps, yL, nullptr, MODE_F32, stream))) return rc;
+    ModeGemmDesc g = gdesc(MODE_F32, MODE_EPI_BIAS, MODE_F32, B * d.A_len, d.A_dim, D, yL, D, w->w_out, D, a->F, d.A_dim);
+    g.bias = w->b_out; g.a_rows = a->act_rows;
+    return mode_gemm(&g, stream);
+  }
+  return MODE_OK;
+}
+
+extern "C" int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes,
+                                      void* stream) {
+  if (a && a->token_routing) return MODE_ERR_BAD_ARG;           // token routing is driven layer by layer: mode_dit_forward_train_layer
+  return forward_train_impl(dims, w, a, stash, stash_bytes, 0, dims ? dims->L : 0, 3, stream);
+}
+
+extern "C" int mode_dit_forward_train_layer(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes,
+                                            int layer, int phase, void* stream) {
+  if (phase != 0 && phase != 1) return MODE_ERR_BAD_ARG;
+  return forward_train_impl(dims, w, a, stash, stash_bytes, layer, layer + 1, phase == 0 ? 1 : 2, stream);
 }
 
 // ----------------------------------------------------------------------------------------------------------------- backward
@@ -177,7 +220,9 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
   int rc = check_train_dims(dims);
   if (rc) return rc;
   if (!w || !w->layers || !wt || !wt->layers || !a || !stash || !dF || !gr || !gr->layers || !workspace) return MODE_ERR_BAD_ARG;
-  if (!a->meta || !a->act_rows || !a->probs || !a->r_pre || !a->topk_idx || !a->sigma || !a->state_images || !a->goals || !a->e1) return MODE_ERR_BAD_ARG;
+  if (!a->meta || !a->act_rows || !a->probs || !a->topk_idx || !a->sigma || !a->state_images || !a->goals || !a->e1) return MODE_ERR_BAD_ARG;
+  const bool tokr = a->token_routing != 0;
+  if (tokr ? (!a->tr_pre || !a->idx_per_token) : !a->r_pre) return MODE_ERR_BAD_ARG;
   const ModeDims& d = *dims;
   const int dt = a->dtype, B = a->B, T = d.T, D = d.D, N = B * T, NK = N * d.k, E = d.E, R = B * d.A_len, A = d.A_dim, hd = D / d.H;
   for (int l = 1; l < d.L; ++l) {                      // the batched router backward needs layer-contiguous router weights / gradients
@@ -251,6 +296,29 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     const int32_t* pos = meta + ml.pos; const float* posw = reinterpret_cast<const float*>(meta + ml.posw);
     // (1) combine backward: dY (sorted rows) and router-weight gradients
     if ((rc = mode_moe_combine_bwd(DXa, S + sl.Y, dt, pos, posw, N, D, d.k, dYs, dwt + (size_t)l * NK, stream))) return rc;
+    // (1b) token routing: this block's router, back-propagated in place - its input is the block's own ln_2 output, so d u gets a second term
+    const float* du_router = nullptr;
+    if (tokr) {
+      float* dlogl = (float*)(ws + W.tr_dlog); float* dprel = (float*)(ws + W.tr_dpre); float* u_re = (float*)(ws + W.tr_u); float* dur = (float*)(ws + W.tr_du);
+      const float* probs_l = a->probs + (size_t)l * N * E;
+      const float* shifted_l = a->shifted ? a->shifted + (size_t)l * N * E : nullptr;
+      const float* pre_l = a->tr_pre + (size_t)l * N * 2 * D;
+      if ((rc = mode_moe_router_bwd_aux(dwt + (size_t)l * NK, a->topk_idx + (long)l * a->topk_layer_stride, probs_l, shifted_l,
+                                        a->aux_lb_coef ? a->aux_lb_coef + (long)l * E : nullptr, shifted_l ? a->aux_z_coef : nullptr, N, N, 1, E, d.k,
+                                        d.router_normalize, 1, dlogl, stream))) return rc;
+      if ((rc = colsum(dlogl, E, N, E, MODE_F32, nullptr, 0, 1, lg.r_b3, 0))) return rc;
+      if ((rc = mode_router_mlp_bwd(dlogl, pre_l, lw.r_w3, 1, N, E, 2 * D, dprel, lg.r_w3, stream))) return rc;
+      if ((rc = colsum(dprel, 2L * D, N, 2 * D, MODE_F32, nullptr, 0, 1, lg.r_b0, 0))) return rc;
+      // the router read the fp32 ln_2 output (not its bf16 copy): recompute it from the stashed pre-norm stream
+      if ((rc = mode_rmsnorm_cond_fwd((const float*)(S + sl.x1), lw.ln2_g, nullptr, N, D, 1, d.eps, u_re, nullptr, MODE_F32, stream))) return rc;
+      ModeGemmDesc rg = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, 2 * D, D, N, dprel, 2L * D, u_re, D, lg.r_w0, D);      // dW0 = dpre^T u
+      rg.flags = MODE_GEMM_A_KM | MODE_GEMM_W_KN;
+      if ((rc = mode_gemm(&rg, stream))) return rc;
+      rg = gdesc(MODE_F32, MODE_EPI_NONE, MODE_F32, N, D, 2 * D, dprel, 2L * D, lw.r_w0, D, dur, D);                     // d u (router) = dpre W0
+      rg.flags = MODE_GEMM_W_KN;
+      if ((rc = mode_gemm(&rg, stream))) return rc;
+      du_router = dur;
+    }
     // (2) expert down-projection: dH = dY W2 ; dW2_e = dY_e^T H_e
     ModeGemmDesc g;
     if (tr) {                                        // bf16: operands as they lie in memory, fragments by LDS transpose reads
@@ -305,7 +373,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     float* dgp2 = dgp + (size_t)(1 + d.L + l) * nblk4 * D;                  // gain partials are reduced for all layers after the loop
     float* dgp1 = dgp + (size_t)(1 + l) * nblk4 * D;
     float* apq_l = apq + (size_t)l * B * D; float* apk_l = apk + (size_t)l * B * D;
-    if ((rc = rmsnorm_bwd_launch((const float*)(S + sl.x1), lw.ln2_g, DXa, nullptr, dUs, tr ? du_split : 1, (long)NK * D, pos, d.k, N, D, d.eps, DXb, 0, dgp2,
+    if ((rc = rmsnorm_bwd_launch((const float*)(S + sl.x1), lw.ln2_g, DXa, du_router, dUs, tr ? du_split : 1, (long)NK * D, pos, d.k, N, D, d.eps, DXb, 0, dgp2,
                                  nullptr, dx1lp, dt, (hipStream_t)stream)))
       return rc;
     // (6) c_proj: d yattn = dx1 Wo ; dWo = dx1^T yattn
@@ -375,7 +443,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
   }
 
   // ---- router MLPs of all layers in one batch (fp32).  r_pre / dpre are [B][L][2D]; weights and gradients [L][...] contiguous.
-  {
+  if (!tokr) {
     const int Ly = d.L, H2 = 2 * D;
     const ModeLayerWeights& w0 = w->layers[0];
     const ModeLayerGrads& g0 = gr->layers[0];

@@ -171,8 +171,8 @@ class MoDeDiT(nn.Module):
         self.use_noise_token_as_input = use_noise_token_as_input
         self.use_goal_in_routing = use_goal_in_routing
         # cond_router=False (modedit.py:296-301, 322-325, 550-553): every block routes each TOKEN on its own ln_2-normalised state instead of the
-        # conditioning row - same router parameters (Linear(D,2D), Linear(2D,E)), routing resolved inside the launch chain, per layer.  Inference
-        # (forward / denoise / every sampler); the training chain raises.
+        # conditioning row - same router parameters (Linear(D,2D), Linear(2D,E)), routing resolved inside the launch chain, per layer: inference
+        # (forward / denoise / every sampler) and training (layer-by-layer forward with the host's multinomial draw in between, training.py).
         self.cond_router = bool(cond_router)
         self.init_style = init_style           # accepted and ignored, like the reference
         self.goal_conditioned, self.causal = goal_conditioned, causal

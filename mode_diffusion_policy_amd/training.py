@@ -167,9 +167,7 @@ class _EdmLossFn(torch.autograd.Function):
 
 
 def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
-    if not getattr(model, "cond_router", True):
-        raise NotImplementedError("MoDeDiT (HIP): cond_router=False is an inference path here; its training chain (router gradients into the token "
-                                  "states) is not built - no shipped config or checkpoint uses it")
+    tokr = not getattr(model, "cond_router", True)             # token routing: every block routes each token on its own ln_2 state (modedit.py:296-301)
     eng: DitEngine = model.engine
     if not hasattr(eng, "_train") or eng._train is None:
         eng._train = TrainState(eng)
@@ -210,8 +208,19 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     L.check(lib.mode_gemm(C.byref(g), _stream()), "sigma_linear")
     img_e, goal_e = eng.embed_obs(img, gl)
     cond = (emb_t + goal_e).contiguous() if model.use_goal_in_routing else emb_t
-    idx_top, w_top, probs, shifted, r_pre = eng.route(cond, want_probs=True, want_pre=True)          # [L,B,*]
-    if model.use_argmax:
+    r_pre = None
+    if tokr:
+        # routing depends on the layer's own token states: resolved layer by layer inside the forward below (N routing rows per layer)
+        probs = torch.empty(Ly, N, E, device=dev); shifted = torch.empty(Ly, N, E, device=dev)
+        tr_pre = torch.empty(Ly, N, 2 * D, device=dev)
+        idx = torch.empty(Ly, N, k, dtype=torch.int32, device=dev); w = torch.empty(Ly, N, k, device=dev)
+        tr_idx = torch.empty(N, k, dtype=torch.int32, device=dev); tr_w = torch.empty(N, k, device=dev)
+        per_tok, tpr, Rr = 1, 1, N
+    else:
+        idx_top, w_top, probs, shifted, r_pre = eng.route(cond, want_probs=True, want_pre=True)      # [L,B,*]
+    if tokr:
+        pass
+    elif model.use_argmax:
         idx, w, per_tok, tpr, Rr = idx_top, w_top, 0, T, B                                           # top-k also in training (modedit.py:389)
     else:
         # expert ids are SAMPLED per token row without replacement (modedit.py:390); the draw stays on the host side of the ABI
@@ -222,8 +231,8 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         L.check(lib.mode_moe_weights_from_idx(probs.data_ptr(), idx.data_ptr(), Ly * N, T, E, k, int(model.router_normalize),
                                               w.data_ptr(), _stream()), "weights_from_idx")
         per_tok, tpr, Rr = 1, 1, N
-    meta = eng.dispatch(idx, w, Ly, Rr, tpr, N)
     ml = eng.meta_layout(N)
+    meta = torch.empty(Ly, ml.total_words, dtype=torch.int32, device=dev) if tokr else eng.dispatch(idx, w, Ly, Rr, tpr, N)
     act_rows = (torch.arange(B, device=dev).repeat_interleave(A_len) * T + (T - A_len) + torch.arange(A_len, device=dev).repeat(B)).to(torch.int32)
     sl = L.ModeStashLayout()
     L.check(lib.mode_dit_train_stash_layout(C.byref(d), B, eng.dt, C.byref(sl)), "stash_layout")
@@ -237,8 +246,22 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
                            goal_e=goal_e.data_ptr(), img_e=img_e.data_ptr(), actions=acts.data_ptr(), c_in=None, c_in_stride=0,
                            actions_scaled=acts.data_ptr(), act_rows=act_rows.data_ptr(), meta=meta.data_ptr(), meta_layer_stride=ml.total_words,
                            topk_idx=idx.data_ptr(), topk_layer_stride=idx.stride(0), idx_per_token=per_tok, probs=probs.data_ptr(),
-                           r_pre=r_pre.data_ptr(), F=F.data_ptr(), layer_events=ts.layer_events())
-    L.check(lib.mode_dit_forward_train(C.byref(d), C.byref(eng._mw), C.byref(args), stash.data_ptr(), stash.numel(), _stream()), "forward_train")
+                           r_pre=_ptr(r_pre), F=F.data_ptr(), layer_events=ts.layer_events())
+    if not tokr:
+        L.check(lib.mode_dit_forward_train(C.byref(d), C.byref(eng._mw), C.byref(args), stash.data_ptr(), stash.numel(), _stream()), "forward_train")
+    else:
+        args.token_routing, args.tr_pre, args.tr_shifted = 1, tr_pre.data_ptr(), shifted.data_ptr()
+        args.tr_topk_idx, args.tr_topk_w = tr_idx.data_ptr(), tr_w.data_ptr()
+        for l in range(Ly):
+            L.check(lib.mode_dit_forward_train_layer(C.byref(d), C.byref(eng._mw), C.byref(args), stash.data_ptr(), stash.numel(), l, 0, _stream()), "forward_train_layer/0")
+            if model.use_argmax:                                                                    # top-k also in training (modedit.py:389)
+                idx[l].copy_(tr_idx); w[l].copy_(tr_w)
+            else:                                                                                   # sampled per token without replacement (modedit.py:390)
+                idx[l].copy_(torch.multinomial(probs[l], k, replacement=False))
+                L.check(lib.mode_moe_weights_from_idx(probs[l].data_ptr(), idx[l].data_ptr(), N, 1, E, k, int(model.router_normalize), w[l].data_ptr(),
+                                                      _stream()), "weights_from_idx")
+            L.check(lib.mode_dit_dispatch(idx[l].data_ptr(), w[l].data_ptr(), 1, N * k, N, 1, N, E, k, meta[l].data_ptr(), _stream()), "dispatch")
+            L.check(lib.mode_dit_forward_train_layer(C.byref(d), C.byref(eng._mw), C.byref(args), stash.data_ptr(), stash.numel(), l, 1, _stream()), "forward_train_layer/1")
 
     # ---- reference side channels (training only, modedit.py:584-593, 816-820); values for logging, no graph
     with torch.no_grad():
@@ -252,10 +275,11 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         zl = torch.log(torch.exp(shifted).sum(-1) + 1e-6).pow(2).mean(-1)                       # [L] router z-loss per layer (modedit.py:930-969)
         model.logits_per_layer, model.probs_per_layer = [], []
         if getattr(model, "log_router_stats", True):          # per-block views the agent's logging reads (mode_agent.py:470-511); `model.log_router_stats = False` skips them
-            logits_tok = shifted.unsqueeze(2).expand(Ly, B, T, E).reshape(Ly, N, E)
+            logits_tok = shifted if tokr else shifted.unsqueeze(2).expand(Ly, B, T, E).reshape(Ly, N, E)
             for l, blk in enumerate(model.blocks):
                 blk.logits = logits_tok[l]
-                blk.probs = {"probs": probs[l].unsqueeze(1).expand(B, T, E), "top_k_hot": mask[l].view(B, T, E), "load_balancing_term": lb[l]}
+                blk.probs = {"probs": probs[l].view(B, T, E) if tokr else probs[l].unsqueeze(1).expand(B, T, E), "top_k_hot": mask[l].view(B, T, E),
+                             "load_balancing_term": lb[l]}
                 model.logits_per_layer.append(blk.logits); model.probs_per_layer.append(blk.probs)
         for blk in model.blocks:
             blk.total_tokens_processed += N
@@ -265,7 +289,7 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         model._train_usage_dev += counts
     model._last_topk = idx
 
-    keep_alive = (img, gl, acts, sig, e1, emb_t, img_e, goal_e, cond, idx, w, probs, shifted, r_pre, meta, act_rows, stash)
+    keep_alive = (img, gl, acts, sig, e1, emb_t, img_e, goal_e, cond, idx, w, probs, shifted, r_pre, meta, act_rows, stash) + ((tr_pre, tr_idx, tr_w) if tokr else ())
     # Function inputs = the parameters that can receive a gradient.  gripper_embed.weight is dead in the reference too (modedit.py:684): left out,
     # so that DistributedDataParallel(find_unused_parameters=True) - how the reference trains, training_calvin.py:92-103 - sees it as unused.
     named = [(n, p) for n, p in eng.named_params() if p.requires_grad and n != "gripper_embed.weight"]
@@ -291,7 +315,7 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
             coef = (frac * (dlb.reshape(()).float() * (E / (Ly * N)))).contiguous()
             keep_aux.append(coef); args.aux_lb_coef = coef.data_ptr()
         if dz is not None:
-            zc = (dz.reshape(1).float() * (2.0 / (Ly * B))).contiguous()
+            zc = (dz.reshape(1).float() * (2.0 / (Ly * (N if tokr else B)))).contiguous()          # mean over the routing rows of a layer, mean over layers
             keep_aux.append(zc); args.aux_z_coef = zc.data_ptr(); args.shifted = shifted.data_ptr()
         d_img = torch.empty(B, model.n_img_tokens, model.obs_dim, device=dev) if want_img else None
         d_goal = torch.empty(tuple(goal_in.shape), device=dev) if want_goal else None

@@ -267,9 +267,12 @@ def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, state_images: Tensor, act
         if not cfg.cond_router:
             # token routing (modedit.py:296-301, 322-325, 553): router(x, None) on the ln_2-normalised token states, one decision per token
             logits, probs = router_probs(sd, l, u.reshape(B * T, D))
-            idx, w = topk_route(probs, k, cfg.router_normalize)
-            if topk_idx is not None:
-                raise NotImplementedError("explicit expert ids with token routing")
+            if topk_idx is None:
+                idx, w = topk_route(probs, k, cfg.router_normalize)
+            else:                                                            # training: ids drawn per token by the caller (modedit.py:390)
+                idx = topk_idx[l].reshape(B * T, k)
+                pr = probs.gather(1, idx)
+                w = pr / pr.sum(-1, keepdim=True) if cfg.router_normalize else pr
         elif topk_idx is None:
             logits, probs = router_probs(sd, l, cond)                                   # distinct rows only
             idx_b, w_b = topk_route(probs, k, cfg.router_normalize)
