@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--screen", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--cfgs", default="0,17,17f256,16", help="variants to time: NN[fK] = gemm_cfg NN with pp_flags K; 0 = the 128x128 family (gemm_pp off)")
+    ap.add_argument("--cfgs", default="0,17", help="gemm_cfg values to time: 17 = persistent ping-pong kernel, 0 = the 128x128 family (gemm_pp off), 1 / 13 ... = one ring geometry")
     a = ap.parse_args()
     lib = L.load()
     dev = torch.device("cuda:0")
@@ -57,13 +57,9 @@ def main():
         return L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=NK, N=D, K=4 * D, A=hin.data_ptr(), lda=4 * D, W=w2[wi].data_ptr(), ldw=4 * D,
                               w_expert_stride=4 * D * D, C=out.data_ptr(), ldc=D, expert_offsets=mp + 4 * ml.offsets, num_experts=E, split_k=S, split_stride=NK * D)
 
-    def setv(v):
-        c, _, fl = str(v).partition("f")
-        lib.mode_set_option(b"gemm_cfg", int(c))
-        lib.mode_set_option(b"gemm_pp", 0 if int(c) == 0 else 1)
-        fl = int(fl) if fl else 0
-        lib.mode_set_option(b"pp_flags", fl & ~128)
-        lib.mode_set_option(b"gemm_setprio", 0 if fl & 128 else 1)              # f128 = no s_setprio around the MFMA clusters
+    def setv(v):                                                # (round 2's "NNfK" ablation variants no longer exist: the product ships no pp_flags)
+        lib.mode_set_option(b"gemm_cfg", int(v))
+        lib.mode_set_option(b"gemm_pp", 0 if int(v) == 0 else 1)
 
     def run(cfg, d):
         setv(cfg)
@@ -75,7 +71,7 @@ def main():
     for name, pairs in routings.items():
         meta, ml = meta_for(pairs)
         ref1 = torch.zeros(NK, 4 * D, dtype=bf, device=dev); run(1, gemm1_desc(meta, ml, 0, ref1))
-        for cfg in ("16", "17", "16f256", "17f256"):
+        for cfg in ("17",):
             bad = 0
             for it in range(a.screen):
                 out = torch.full((NK, 4 * D), float("nan"), dtype=bf, device=dev)
@@ -91,7 +87,7 @@ def main():
             ok &= bad == 0
         for S in (2, 4):
             ref2 = torch.zeros(S, NK, D, dtype=bf, device=dev); run(1, gemm2_desc(meta, ml, 0, ref2, S))
-            for cfg in ("16", "17", "16f256", "17f256"):
+            for cfg in ("17",):
                 bad = 0
                 for it in range(a.screen):
                     out = torch.full((S, NK, D), float("nan"), dtype=bf, device=dev)
@@ -133,29 +129,6 @@ def main():
             line = "  ".join(f"{c}: med {sorted(v)[len(v) // 2]:6.1f} min {min(v):6.1f} us ({fl / min(v) / 1e6:6.0f} TF/s)" for c, v in res.items())
             print(f"{name:20s} {cname:44s} {line}")
 
-    # ---- cycle-stamp trace of one launch per variant (gemm1, uniform routing): where a workgroup's time goes
-    meta, ml = meta_for(routings["uniform(2 experts)"])
-    out1 = torch.empty(NK, 4 * D, dtype=bf, device=dev)
-    tr = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
-    ptr = tr.data_ptr()
-    for v in [c for c in cfgs if c in ("17", "17f1", "16", "17f256")]:
-        for wi in range(3):                                     # warm: code object, clocks
-            run(v, gemm1_desc(meta, ml, wi, out1))
-        tr.zero_()
-        lib.mode_set_option(b"pp_trace_lo", C.c_int32(ptr & 0xffffffff).value); lib.mode_set_option(b"pp_trace_hi", C.c_int32((ptr >> 32) & 0xffffffff).value)
-        run(v, gemm1_desc(meta, ml, 3, out1))
-        torch.cuda.synchronize()
-        lib.mode_set_option(b"pp_trace_lo", 0); lib.mode_set_option(b"pp_trace_hi", 0)
-        t = tr.view(256, 8, 8).cpu().double()
-        live = t[:, 0, 0] > 0
-        t = t[live]
-        t = t - t[:, :, 0].min(1).values[:, None, None]          # per workgroup, relative to its first wave's start (cycle counters differ per XCD)
-        names = ["start", "primed", "k-loop 0", "epilogue 0", "k-loop 1", "epilogue 1", "k-loop 2", "epilogue 2"]
-        print(f"trace cfg {v}: {int(live.sum())} workgroups; cycles since the workgroup's first wave started: median / max over workgroups, wave-row 0 | wave-row 1")
-        names[6], names[7] = "  row indices", "  row norms"
-        for sl in (0, 6, 7, 1, 2, 3, 4, 5):
-            a0 = t[:, :4, sl].max(1).values; a1 = t[:, 4:, sl].max(1).values
-            print(f"   {names[sl]:12s} {a0.median():9.0f} / {a0.max():9.0f}   |  {a1.median():9.0f} / {a1.max():9.0f}")
     return 0 if ok else 1
 
 
