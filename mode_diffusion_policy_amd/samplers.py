@@ -99,12 +99,19 @@ def _exp_step(x, denoised, s_from, s_to):
 
 def _churn(x, sigmas, i, s_churn, s_tmin, s_tmax, s_noise):
     """Algorithm 2's stochastic 'churn': raise the noise level to sigma_hat = sigma_i (1 + gamma) by adding fresh noise."""
-    gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.0
+    # (s_churn = 0 - the agent's default - makes gamma 0 whatever sigma is: no tensor-vs-float comparison, i.e. no host sync per step)
+    gamma = 0.0 if s_churn <= 0 else (min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.0)
     eps = torch.randn_like(x) * s_noise
     sigma_hat = sigmas[i] * (gamma + 1)
     if gamma > 0:
         x = x + eps * (sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5
     return x, sigma_hat
+
+
+def _zero_levels(sigmas):
+    """[sigma_i == 0 for every level] on the HOST, read once per sampler call: the step loops branch on "is the next level zero" (Euler fallback on the
+    final step) - asking the device tensor inside the loop is one host sync per step, which keeps the host from running ahead of the GPU."""
+    return (sigmas == 0).tolist()
 
 
 class _Run:
@@ -167,13 +174,14 @@ def sample_heun(model, state, action, goal, sigmas, scaler=None, extra_args=None
                 s_tmax=float("inf"), s_noise=1.0):
     """Heun (2nd-order) steps of Algorithm 2: Euler predictor, trapezoidal corrector, plain Euler into sigma = 0 (gc_sampling.py:257-312)."""
     run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
+    zeros = _zero_levels(sigmas)
     for i in range(len(sigmas) - 1):
         action, sigma_hat = _churn(action, sigmas, i, s_churn, s_tmin, s_tmax, s_noise)
         denoised = run.denoise(action, sigma_hat)
         d = to_d(action, sigma_hat, denoised)
         run.report(action, i, sigmas[i], sigma_hat, denoised)
         dt = sigmas[i + 1] - sigma_hat
-        if sigmas[i + 1] == 0:
+        if zeros[i + 1]:
             action = action + d * dt
         else:
             probe = action + d * dt
@@ -188,12 +196,13 @@ def sample_dpm_2(model, state, action, goal, sigmas, scaler=None, extra_args=Non
                  s_tmax=float("inf"), s_noise=1.0):
     """Midpoint method in log-sigma (DPM-Solver-2 flavoured), Euler into sigma = 0 (gc_sampling.py:315-373)."""
     run = _Run(model, state, goal, action, extra_args, callback, scaler, "action")
+    zeros = _zero_levels(sigmas)
     for i in range(len(sigmas) - 1):
         action, sigma_hat = _churn(action, sigmas, i, s_churn, s_tmin, s_tmax, s_noise)
         denoised = run.denoise(action, sigma_hat)
         d = to_d(action, sigma_hat, denoised)
         run.report(action, i, sigmas[i], sigma_hat, denoised)
-        if sigmas[i + 1] == 0:
+        if zeros[i + 1]:
             action = action + d * (sigmas[i + 1] - sigma_hat)
         else:
             sigma_mid = sigma_hat.log().lerp(sigmas[i + 1].log(), 0.5).exp()
@@ -261,11 +270,12 @@ def sample_lms(model, state, action, goal, sigmas, scaler=None, extra_args=None,
 def sample_dpmpp_2m(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None):
     """DPM-Solver++(2M): exponential-integrator steps with a two-point extrapolation of the denoised prediction (gc_sampling.py:700-734)."""
     run = _Run(model, state, goal, action, extra_args, callback, None, "action")
+    zeros = _zero_levels(sigmas)
     previous = None
     for i in range(len(sigmas) - 1):
         denoised = run.denoise(action, sigmas[i])
         run.report(action, i, sigmas[i], sigmas[i], denoised)
-        if previous is None or sigmas[i + 1] == 0:
+        if previous is None or zeros[i + 1]:
             action = _exp_step(action, denoised, sigmas[i], sigmas[i + 1])
         else:
             h = sigmas[i].log() - sigmas[i + 1].log()
@@ -306,10 +316,11 @@ def sample_dpmpp_2s_ancestral(model, state, action, goal, sigmas, scaler=None, e
 def sample_dpmpp_2s(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, eta=1.0):
     """Deterministic DPM-Solver++(2S) (gc_sampling.py:956-994)."""
     run = _Run(model, state, goal, action, extra_args, callback, scaler, "action")
+    zeros = _zero_levels(sigmas)
     for i in range(len(sigmas) - 1):
         denoised = run.denoise(action, sigmas[i])
         run.report(action, i, sigmas[i], sigmas[i], denoised)
-        if sigmas[i + 1] == 0:
+        if zeros[i + 1]:
             action = action + to_d(action, sigmas[i], denoised) * (sigmas[i + 1] - sigmas[i])
         else:
             action = _dpmpp_2s_core(run, action, denoised, sigmas[i], sigmas[i + 1])
@@ -363,13 +374,14 @@ def sample_dpmpp_sde(model, state, action, goal, sigmas, extra_args=None, callba
     moves (to the intermediate level t + r h, then to t_next with the two predictions blended by 1/(2r)), each split into a deterministic
     move to sigma_down and fresh noise of scale sigma_up (``get_ancestral_step``); plain Euler on the final sigma = 0 step."""
     run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
+    zeros = _zero_levels(sigmas)
     if noise_sampler is None:
         noise_sampler = BrownianTreeNoiseSampler(action, sigmas[sigmas > 0].min(), sigmas.max())
     x = action
     for i in range(len(sigmas) - 1):
         denoised = run.denoise(x, sigmas[i])
         run.report(x, i, sigmas[i], sigmas[i], denoised)
-        if sigmas[i + 1] == 0:
+        if zeros[i + 1]:
             x = x + to_d(x, sigmas[i], denoised) * (sigmas[i + 1] - sigmas[i])
             continue
         t, t_next = sigmas[i].log().neg(), sigmas[i + 1].log().neg()
