@@ -481,6 +481,37 @@ def extra_measurements(M, den, device):
         out[f"{key}_mfma_frac"] = round(flops_per_denoise_step(batch) * N_SAMPLING_STEPS / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4)
         if key == "rollout":
             out["rollout_action_chunks_per_s"] = round(batch / (ms * 1e-3), 1)
+    # the fused BatchNorm + FiLM + residual + ReLU pass of the FiLM-ResNet encoders at a ResNet-50 stage-1 shape
+    # (B = 128 frames, 256 channels, 56 x 56, bf16): algorithmic bytes = x + residual read, y written (forward); + dy read, dx / d residual written
+    # and x / residual / dy read a second time by the reduction pass (backward)
+    from mode_diffusion_policy_amd import perceptual_encoders as PE
+    xe = torch.randn(128, 256, 56, 56, device=device).to(torch.bfloat16); re_ = torch.randn_like(xe)
+    bn = torch.nn.BatchNorm2d(256).to(device).eval()
+    gq, bq = torch.randn(128, 256, device=device) * 0.1, torch.randn(128, 256, device=device) * 0.1
+    x1 = xe.clone().requires_grad_(True); r1 = re_.clone().requires_grad_(True)
+    for _ in range(3):
+        ye = PE.bn_film_act(x1, bn, relu=True, residual=r1, post_film=(gq, bq))
+        ye.backward(xe)
+    torch.cuda.synchronize()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    nrep = 20
+    e0.record()
+    for _ in range(nrep):
+        with torch.no_grad():
+            PE.bn_film_act(xe, bn, relu=True, residual=re_, post_film=(gq, bq))
+    e1.record()
+    for _ in range(nrep):
+        ye = PE.bn_film_act(x1, bn, relu=True, residual=r1, post_film=(gq, bq))
+        ye.backward(xe)
+    e2.record(); torch.cuda.synchronize()
+    nbytes = xe.numel() * 2
+    fwd_us = e0.elapsed_time(e1) * 1e3 / nrep
+    fb_us = e1.elapsed_time(e2) * 1e3 / nrep
+    out["encoder_bn_film_fwd_us"] = round(fwd_us, 1)
+    out["encoder_bn_film_fwd_hbm_frac"] = round(3 * nbytes / (fwd_us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
+    out["encoder_bn_film_fwd_bwd_us"] = round(fb_us, 1)
+    out["encoder_bn_film_fwd_bwd_hbm_frac"] = round((3 + 8) * nbytes / (fb_us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
+    del xe, re_, x1, r1, ye
     # the non-DDIM samplers of MoDEAgent.sample_loop (mode_agent.py:798-839): host recurrences around ONE hipGraph replay per denoiser call
     # (sigma is a device scalar of the captured chain: MoDeDiT.denoise_graphed) - B = 128, 10 model evaluations per chunk
     from mode_diffusion_policy_amd import samplers as S

@@ -311,3 +311,15 @@ class ResNetEncoderWithFiLM(nn.Module):
         if series:
             x = x.reshape(B, t_steps, self.latent_dim)
         return x
+
+
+def embed_visual_obs(static_resnet, gripper_resnet, rgb_static, rgb_gripper, latent_goal=None):
+    """``MoDEAgent.embed_visual_obs`` (mode_agent.py:548-567): (B, T, C, H, W) camera streams -> ``{'state_images': (B, 2 T, obs_dim)}``, the
+    ``perceptual_emb`` the denoiser consumes (one token per camera and frame; T = 1 in every shipped config)."""
+    B, T = rgb_static.shape[0], rgb_static.shape[1]
+    s = rgb_static.reshape(B * T, *rgb_static.shape[2:]); g = rgb_gripper.reshape(B * T, *rgb_gripper.shape[2:])
+    if latent_goal is not None:
+        st, gt = static_resnet(s, latent_goal), gripper_resnet(g, latent_goal)
+    else:
+        st, gt = static_resnet(s), gripper_resnet(g)
+    return {"state_images": torch.cat([st.reshape(B, T, -1), gt.reshape(B, T, -1)], dim=1)}

@@ -149,8 +149,9 @@ def test_encoders_train_through_the_hip_denoiser():
         enc.load_state_dict({k: v.cuda() for k, v in R.fill_encoder_state_dict(enc.state_dict(), seed).items()})
     inp = {k: v.cuda() for k, v in make_inputs(cfg, B, 5).items()}
     rgb_s, rgb_g = torch.randn(B, 3, 64, 64, device="cuda"), torch.randn(B, 3, 48, 48, device="cuda")
-    tokens = torch.stack([static(rgb_s, inp["goals"]), gripper(rgb_g, inp["goals"])], dim=1)            # (B, 2, 512)
-    loss, _ = model.loss({"state_images": tokens}, inp["actions"], inp["goals"], inp["noise"], torch.full((B,), 0.8, device="cuda"))
+    emb = M.embed_visual_obs(static, gripper, rgb_s.unsqueeze(1), rgb_g.unsqueeze(1), inp["goals"])     # {'state_images': (B, 2, 512)}
+    assert emb["state_images"].shape == (B, 2, cfg.obs_dim)
+    loss, _ = model.loss(emb, inp["actions"], inp["goals"], inp["noise"], torch.full((B,), 0.8, device="cuda"))
     loss.backward()
     for enc in (static, gripper):
         for n, p in enc.named_parameters():
