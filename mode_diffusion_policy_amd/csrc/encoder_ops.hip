@@ -32,6 +32,33 @@ __device__ __forceinline__ void st<float>(float* p, long i, float v) { p[i] = v;
 template <>
 __device__ __forceinline__ void st<uint16_t>(uint16_t* p, long i, float v) { p[i] = f32_to_bf16_bits(v); }
 
+// VEC consecutive elements of a row per lane and iteration (16-byte accesses: 8 bf16 / 4 fp32; 8-byte for rows whose length is only a multiple of 4;
+// scalar otherwise - 7 x 7 maps).  One wave covers VEC * 64 elements per iteration.
+template <typename T, int VEC>
+__device__ __forceinline__ void ldv(const T* __restrict__ p, long i, float (&v)[VEC]) {
+  if constexpr (VEC == 1) { v[0] = ld(p, i); }
+  else if constexpr (sizeof(T) == 4) {
+    static_assert(VEC == 4, "fp32 rows: 4 elements per access");
+    const float4 t = *reinterpret_cast<const float4*>(p + i);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (VEC == 8) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p + i);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+  } else {
+    const uint2 t = *reinterpret_cast<const uint2*>(p + i);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void stv(T* __restrict__ p, long i, const float (&v)[VEC]) {
+  if constexpr (VEC == 1) { st(p, i, v[0]); }
+  else if constexpr (sizeof(T) == 4) { *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]); }
+  else if constexpr (VEC == 8) { *reinterpret_cast<uint4*>(p + i) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])); }
+  else { *reinterpret_cast<uint2*>(p + i) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
+}
+
 struct RowParams {            // per (n, c) constants of the fused chain
   float scale, shift, pg, pb, qg, qb;
   bool pre, post;
@@ -47,7 +74,7 @@ __device__ __forceinline__ RowParams row_params(const ModeBnFilmDesc& d, int n, 
 }
 
 // ---- forward
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_film_act_fwd_kernel(const ModeBnFilmDesc d) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + wave, rows = (long)d.N * d.C;
@@ -57,25 +84,37 @@ __global__ __launch_bounds__(256) void bn_film_act_fwd_kernel(const ModeBnFilmDe
   const T* x = reinterpret_cast<const T*>(d.x) + row * d.HW;
   const T* res = d.residual ? reinterpret_cast<const T*>(d.residual) + row * d.HW : nullptr;
   T* y = reinterpret_cast<T*>(d.y) + row * d.HW;
-  for (int i = lane; i < d.HW; i += 64) {
-    float v = __builtin_fmaf(ld(x, i), r.scale, r.shift);
-    if (r.pre) v = __builtin_fmaf(r.pg, v, r.pb);
-    if (res) v += ld(res, i);
-    if (d.relu) v = fmaxf(v, 0.f);
-    if (r.post) v = __builtin_fmaf(1.f + r.qg, v, r.qb);
-    st(y, i, v);
+  for (int i = lane * VEC; i < d.HW; i += 64 * VEC) {
+    float v[VEC], rv[VEC];
+    ldv<T, VEC>(x, i, v);
+    if (res) ldv<T, VEC>(res, i, rv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t = __builtin_fmaf(v[j], r.scale, r.shift);
+      if (r.pre) t = __builtin_fmaf(r.pg, t, r.pb);
+      if (res) t += rv[j];
+      if (d.relu) t = fmaxf(t, 0.f);
+      if (r.post) t = __builtin_fmaf(1.f + r.qg, t, r.qb);
+      v[j] = t;
+    }
+    stv<T, VEC>(y, i, v);
   }
 }
 
 // ---- batch statistics (training-mode BatchNorm): per-row partial sums, then one thread per channel folds the N rows in double
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_row_sums_kernel(const T* __restrict__ x, long rows, int HW, float* __restrict__ psum, float* __restrict__ psq) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
   const T* p = x + row * HW;
   float s = 0.f, q = 0.f;
-  for (int i = lane; i < HW; i += 64) { const float v = ld(p, i); s += v; q = __builtin_fmaf(v, v, q); }
+  for (int i = lane * VEC; i < HW; i += 64 * VEC) {
+    float v[VEC];
+    ldv<T, VEC>(p, i, v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s += v[j]; q = __builtin_fmaf(v[j], v[j], q); }
+  }
   s = wave_sum(s); q = wave_sum(q);
   if (lane == 0) { psum[row] = s; psq[row] = q; }
 }
@@ -92,7 +131,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 
 // ---- backward, pass 1: six sums per row
 //   sums[row] = { S dy*v4, S dy, S dv2*v1, S dv2, S dv1, S dv1*xhat }
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_film_act_bwd_sums_kernel(const ModeBnFilmDesc d, const T* __restrict__ dy, const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, float* __restrict__ sums) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -105,17 +144,23 @@ __global__ __launch_bounds__(256) void bn_film_act_bwd_sums_kernel(const ModeBnF
   const T* res = d.residual ? reinterpret_cast<const T*>(d.residual) + row * d.HW : nullptr;
   const T* g = dy + row * d.HW;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f;
-  for (int i = lane; i < d.HW; i += 64) {
-    const float xv = ld(x, i), gy = ld(g, i);
-    const float v1 = __builtin_fmaf(xv, r.scale, r.shift);
-    const float v2 = r.pre ? __builtin_fmaf(r.pg, v1, r.pb) : v1;
-    const float v3 = res ? v2 + ld(res, i) : v2;
-    const float v4 = d.relu ? fmaxf(v3, 0.f) : v3;
-    const float dv4 = r.post ? gy * (1.f + r.qg) : gy;
-    const float dv2 = (d.relu && v3 <= 0.f) ? 0.f : dv4;
-    const float dv1 = r.pre ? dv2 * r.pg : dv2;
-    a0 = __builtin_fmaf(gy, v4, a0); a1 += gy; a2 = __builtin_fmaf(dv2, v1, a2); a3 += dv2; a4 += dv1;
-    a5 = __builtin_fmaf(dv1, (xv - mu) * is, a5);
+  for (int i = lane * VEC; i < d.HW; i += 64 * VEC) {
+    float xv[VEC], gv[VEC], rv[VEC];
+    ldv<T, VEC>(x, i, xv); ldv<T, VEC>(g, i, gv);
+    if (res) ldv<T, VEC>(res, i, rv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float gy = gv[j];
+      const float v1 = __builtin_fmaf(xv[j], r.scale, r.shift);
+      const float v2 = r.pre ? __builtin_fmaf(r.pg, v1, r.pb) : v1;
+      const float v3 = res ? v2 + rv[j] : v2;
+      const float v4 = d.relu ? fmaxf(v3, 0.f) : v3;
+      const float dv4 = r.post ? gy * (1.f + r.qg) : gy;
+      const float dv2 = (d.relu && v3 <= 0.f) ? 0.f : dv4;
+      const float dv1 = r.pre ? dv2 * r.pg : dv2;
+      a0 = __builtin_fmaf(gy, v4, a0); a1 += gy; a2 = __builtin_fmaf(dv2, v1, a2); a3 += dv2; a4 += dv1;
+      a5 = __builtin_fmaf(dv1, (xv[j] - mu) * is, a5);
+    }
   }
   a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3); a4 = wave_sum(a4); a5 = wave_sum(a5);
   if (lane == 0) {
@@ -139,7 +184,7 @@ __global__ __launch_bounds__(256) void bn_film_bwd_fold_kernel(const float* __re
   }
 }
 // pass 2: dx (training: through the batch statistics; eval: dv1 * scale) and d residual
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_film_act_bwd_dx_kernel(const ModeBnFilmDesc d, const T* __restrict__ dy, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ dweight,
                                                                  const float* __restrict__ dbias, int training, float inv_m, T* __restrict__ dx, T* __restrict__ dres) {
@@ -155,18 +200,41 @@ __global__ __launch_bounds__(256) void bn_film_act_bwd_dx_kernel(const ModeBnFil
   const T* g = dy + row * d.HW;
   T* ox = dx + row * d.HW;
   T* orr = dres ? dres + row * d.HW : nullptr;
-  for (int i = lane; i < d.HW; i += 64) {
-    const float xv = ld(x, i), gy = ld(g, i);
-    const float v1 = __builtin_fmaf(xv, r.scale, r.shift);
-    const float v2 = r.pre ? __builtin_fmaf(r.pg, v1, r.pb) : v1;
-    const float v3 = res ? v2 + ld(res, i) : v2;
-    const float dv4 = r.post ? gy * (1.f + r.qg) : gy;
-    const float dv2 = (d.relu && v3 <= 0.f) ? 0.f : dv4;
-    const float dv1 = r.pre ? dv2 * r.pg : dv2;
-    if (orr) st(orr, i, dv2);
-    st(ox, i, r.scale * (dv1 - mb - (xv - mu) * is * mw));      // scale = weight * invstd
+  for (int i = lane * VEC; i < d.HW; i += 64 * VEC) {
+    float xv[VEC], gv[VEC], rv[VEC], o1[VEC], o2[VEC];
+    ldv<T, VEC>(x, i, xv); ldv<T, VEC>(g, i, gv);
+    if (res) ldv<T, VEC>(res, i, rv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float v1 = __builtin_fmaf(xv[j], r.scale, r.shift);
+      const float v2 = r.pre ? __builtin_fmaf(r.pg, v1, r.pb) : v1;
+      const float v3 = res ? v2 + rv[j] : v2;
+      const float dv4 = r.post ? gv[j] * (1.f + r.qg) : gv[j];
+      const float dv2 = (d.relu && v3 <= 0.f) ? 0.f : dv4;
+      const float dv1 = r.pre ? dv2 * r.pg : dv2;
+      o2[j] = dv2;
+      o1[j] = r.scale * (dv1 - mb - (xv[j] - mu) * is * mw);       // scale = weight * invstd
+    }
+    if (orr) stv<T, VEC>(orr, i, o2);
+    stv<T, VEC>(ox, i, o1);
   }
 }
+
+// widest access the rows allow: every row starts at row * HW elements, so HW must be a multiple of the vector length (and the base 16-byte aligned)
+static int bn_vec(int dtype, int HW, const void* a, const void* b, const void* c, const void* e, const void* f) {
+  const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)e | (uintptr_t)f;
+  if (al & 15) return 1;
+  if (dtype == MODE_BF16 && HW % 8 == 0) return 8;
+  if (HW % 4 == 0) return 4;
+  return 1;
+}
+#define BN_DISPATCH(KERNEL, dt, vec, ...)                                                              \
+  do {                                                                                                  \
+    if ((dt) == MODE_F32) { if ((vec) >= 4) { KERNEL(float, 4, __VA_ARGS__); } else { KERNEL(float, 1, __VA_ARGS__); } }          \
+    else if ((vec) == 8) { KERNEL(uint16_t, 8, __VA_ARGS__); }                                         \
+    else if ((vec) == 4) { KERNEL(uint16_t, 4, __VA_ARGS__); }                                         \
+    else { KERNEL(uint16_t, 1, __VA_ARGS__); }                                                         \
+  } while (0)
 
 static bool bn_desc_ok(const ModeBnFilmDesc* d) {
   if (!d || !d->x || !d->scale || !d->shift || !d->y || d->N < 0 || d->C <= 0 || d->HW <= 0) return false;
@@ -181,8 +249,10 @@ extern "C" int mode_bn_film_act_fwd(const ModeBnFilmDesc* d, void* stream) {
   const long rows = (long)d->N * d->C;
   if (rows == 0) return MODE_OK;
   const dim3 grid((unsigned)((rows + 3) / 4));
-  if (d->dtype == MODE_F32) hipLaunchKernelGGL(bn_film_act_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *d);
-  else hipLaunchKernelGGL(bn_film_act_fwd_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+  const int vec = bn_vec(d->dtype, d->HW, d->x, d->residual, d->y, nullptr, nullptr);
+#define K_FWD(T, V, s_) hipLaunchKernelGGL((bn_film_act_fwd_kernel<T, V>), grid, dim3(256), 0, s_, *d)
+  BN_DISPATCH(K_FWD, d->dtype, vec, (hipStream_t)stream);
+#undef K_FWD
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
@@ -195,9 +265,11 @@ extern "C" int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, flo
   const long rows = (long)N * C;
   float* psum = (float*)workspace; float* psq = psum + rows;
   const dim3 grid((unsigned)((rows + 3) / 4));
-  if (dtype == MODE_F32) hipLaunchKernelGGL(bn_row_sums_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, HW, psum, psq);
-  else if (dtype == MODE_BF16) hipLaunchKernelGGL(bn_row_sums_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, rows, HW, psum, psq);
-  else return MODE_ERR_BAD_ARG;
+  if (dtype != MODE_F32 && dtype != MODE_BF16) return MODE_ERR_BAD_ARG;
+  const int vec = bn_vec(dtype, HW, x, nullptr, nullptr, nullptr, nullptr);
+#define K_SUM(T, V, s_) hipLaunchKernelGGL((bn_row_sums_kernel<T, V>), grid, dim3(256), 0, s_, (const T*)x, rows, HW, psum, psq)
+  BN_DISPATCH(K_SUM, dtype, vec, (hipStream_t)stream);
+#undef K_SUM
   MODE_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, psum, psq, N, C, (long)N * HW, mean, var);
   MODE_LAUNCH_CHECK();
@@ -218,9 +290,11 @@ extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, con
   float* sums = (float*)workspace;
   const dim3 grid((unsigned)((rows + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
+  const int vec = bn_vec(d->dtype, d->HW, d->x, d->residual, dy, dx, dresidual);
   if (phase != 2) {                                            // reductions: FiLM gradients per (n, c), BatchNorm affine gradients per channel
-    if (d->dtype == MODE_F32) hipLaunchKernelGGL(bn_film_act_bwd_sums_kernel<float>, grid, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, sums);
-    else hipLaunchKernelGGL(bn_film_act_bwd_sums_kernel<uint16_t>, grid, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, sums);
+#define K_BS(T, V, s_) hipLaunchKernelGGL((bn_film_act_bwd_sums_kernel<T, V>), grid, dim3(256), 0, s_, *d, (const T*)dy, mean, invstd, sums)
+    BN_DISPATCH(K_BS, d->dtype, vec, s);
+#undef K_BS
     MODE_LAUNCH_CHECK();
     const long nfold = rows > d->C ? rows : d->C;
     hipLaunchKernelGGL(bn_film_bwd_fold_kernel, dim3((unsigned)((nfold + 255) / 256)), dim3(256), 0, s, sums, d->N, d->C, dweight, dbias, d_pre_gamma, d_pre_beta,
@@ -229,12 +303,9 @@ extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, con
   }
   if (phase != 1) {                                            // dx / d residual from the (possibly cross-rank summed) channel sums
     const float inv_m = inv_count > 0.f ? inv_count : 1.f / ((float)d->N * (float)d->HW);
-    if (d->dtype == MODE_F32)
-      hipLaunchKernelGGL(bn_film_act_bwd_dx_kernel<float>, grid, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, dweight, dbias, training, inv_m, (float*)dx,
-                         (float*)dresidual);
-    else
-      hipLaunchKernelGGL(bn_film_act_bwd_dx_kernel<uint16_t>, grid, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, dweight, dbias, training, inv_m,
-                         (uint16_t*)dx, (uint16_t*)dresidual);
+#define K_DX(T, V, s_) hipLaunchKernelGGL((bn_film_act_bwd_dx_kernel<T, V>), grid, dim3(256), 0, s_, *d, (const T*)dy, mean, invstd, dweight, dbias, training, inv_m, (T*)dx, (T*)dresidual)
+    BN_DISPATCH(K_DX, d->dtype, vec, s);
+#undef K_DX
     MODE_LAUNCH_CHECK();
   }
   return MODE_OK;

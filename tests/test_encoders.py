@@ -88,7 +88,8 @@ def test_encoder_vs_reference_fixture(golden, tag):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("training", [False, True])
-@pytest.mark.parametrize("N,C,H,pre,post,res", [(3, 8, 5, True, False, True), (4, 64, 7, False, True, True), (2, 5, 9, False, False, False), (6, 130, 3, True, True, True)])
+@pytest.mark.parametrize("N,C,H,pre,post,res", [(3, 8, 5, True, False, True), (4, 64, 7, False, True, True), (2, 5, 9, False, False, False), (6, 130, 3, True, True, True),
+                                                (4, 24, 8, True, True, True), (2, 16, 28, False, True, True), (3, 12, 14, True, False, True), (2, 7, 6, False, False, True)])   # row lengths 64 / 784 (16-byte accesses), 196 / 36 (8-byte in bf16), the others scalar
 def test_bn_film_act_vs_torch_autograd(N, C, H, pre, post, res, training, dtype, tol):
     """The fused HIP pass and its backward against the same chain written with torch ops (fp32 autograd on the same values)."""
     torch.manual_seed(N * 100 + C)
