@@ -4,15 +4,16 @@
 // Why a second tiled kernel: the 128x128 one-barrier-per-K-step loop of gemm_bf16.hip tops out at ~840 TF/s (33 % of the bf16 MFMA peak): a
 // workgroup's fill / LDS-read / MFMA phases serialise and a 128x128x64 step moves 32 KiB through the vector-memory path per 512 MFMA cycles.
 // This kernel changes the structure, not the tuning:
-//   * (128 + 32*FM1) x 256 output tile (FM1 = 4: 256 rows, FM1 = 3: 224 rows - 3584 sorted rows = 16 x 224 gives 512 tiles = exactly two per CU),
+//   * (128 + 32*FM1) x 256 output tile; shipped: FM1 = 3 = 224 rows (3584 sorted rows = 16 x 224 gives 512 tiles = exactly two per CU),
 //     BK = 64, 8 wave64 as 2 (M) x 4 (N): half the L2->LDS bytes per flop of the 128x128 tile.
-//   * The operand tile of a K-step lives in LDS as four 16-KiB HALF-tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255), two K-steps
-//     resident (128 KiB).  A wave's output is the 2 x 2 grid of quadrants {A half} x {W half}; one K-step = four PHASES of 16 MFMAs
-//     (v_mfma_f32_16x16x32_bf16), each phase: {ds_read the operand fragments the phase needs | issue ONE half-tile of global_load_lds for a
-//     K-step 1.5 steps ahead} -> s_barrier -> MFMAs -> s_barrier.  A half-tile is re-filled two phases after its last fragment read.
-//   * Counted waits only: `s_waitcnt vmcnt(6)` once per K-step (three half-tiles stay in flight across every barrier), never vmcnt(0);
-//     a staged half-tile is read one phase after the wait that retires it (the wait sits before a barrier every reader passes).
-//   * The two wave rows run STAGGERED by one barrier: while waves 0-3 issue their 16 MFMAs, waves 4-7 (their SIMD partners) issue fragment
+//   * The operand tile of a K-step lives in LDS as four 16-KiB HALF-tiles (A rows 0-127 / 128-223, W rows 0-127 / 128-255), two K-steps
+//     resident (128 KiB).  A wave's output is the 2 x 2 grid of quadrants {A half} x {W half}; one K-step = two PHASES: a phase = one A half x
+//     BOTH W halves (32 / 24 MFMAs, v_mfma_f32_16x16x32_bf16): {ds_read the fragments the phase needs | issue the global_load_lds of half-tiles
+//     one to two K-steps ahead} -> s_barrier -> MFMAs -> s_barrier.  A half-tile is re-filled one whole phase after its last fragment read.
+//   * Counted waits only: every read section ends in ONE `s_waitcnt vmcnt(8 | 6)` that leaves the newest K-step's worth of DMA in flight, never
+//     vmcnt(0); the loop body is straight-line code (first K-step pair peeled, wave role a template argument: see the comments at the loop) -
+//     tests/test_boundary.py::test_pp_kernel_isa_contract pins "no scratch access, no branch but the back edge" on the compiled ISA.
+//   * The two wave rows run STAGGERED by one barrier: while waves 0-3 issue their MFMA cluster, waves 4-7 (their SIMD partners) issue fragment
 //     reads and DMA, and vice versa - the matrix pipe of every SIMD always has one wave feeding it (s_setprio around the MFMA cluster).
 //   * PERSISTENT: one workgroup per CU walks its output tiles (consecutive n-tiles of one m-tile, so the gathered A rows and their per-lane
 //     DMA sources never change) and the operand stream never stops: while the last K-steps of a tile run, the first two K-steps of the NEXT
