@@ -670,12 +670,41 @@ def main():
     # configs[2]/[3] in the same invocation: the data-parallel training step (ALL ranks: it holds the path's one collective).  The headline above
     # is replicas of the sampler (no collective); this leg is what a multi-GPU record can show the gradient exchange with.  Last of the GPU legs:
     # it updates the weights.
+    train_failed = False
     if args.dtype == "bf16" and not args.no_extras:
-        res.update(train_leg(den, device, world, rank, dist))
+        # The training leg is the only part of this file with a data-path collective.  It has run on RCCL with ONE rank and on gloo with two
+        # (tests/test_gpu_train_dropin.py); no multi-GPU box was available to the build.  So at N > 1 it runs under a watchdog: if it raises or does
+        # not come back, the headline line (replicas, measured above) is still printed - without the train_* keys, with the reason.
+        wd = None
+        if world > 1:
+            import threading
+            limit = float(os.environ.get("MODE_TRAIN_LEG_TIMEOUT", "240"))
+
+            def _bail():
+                if rank == 0:
+                    res["train_leg_error"] = f"no result after {limit:.0f} s (collective did not complete): headline reported without the training leg"
+                    print(json.dumps(res), flush=True)
+                os._exit(0)
+            wd = threading.Timer(limit, _bail)
+            wd.daemon = True
+            wd.start()
+        try:
+            res.update(train_leg(den, device, world, rank, dist))
+        except Exception as e:                                              # noqa: BLE001
+            if world == 1:
+                raise
+            train_failed = True
+            res["train_leg_error"] = repr(e)[:400]
+        finally:
+            if wd is not None:
+                wd.cancel()
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
+    if train_failed:                                                        # the other ranks may be stuck in a collective: no final barrier
+        sys.stdout.flush()
+        os._exit(0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
