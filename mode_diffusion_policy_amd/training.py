@@ -139,15 +139,18 @@ class _DitTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, run, img, goals, *params):
+        # The outputs must NOT stay reachable from ctx: output -> grad_fn -> ctx -> run -> output is a cycle through the C++ autograd node that
+        # Python's collector cannot even see - it would pin the activation stash (1.5 GiB at C2 / B = 128) of every step for the life of the process.
+        outs, run.outs = run.outs, None
         ctx.run = run
         ctx.set_materialize_grads(False)                         # unused outputs hand None to backward, not zero tensors
-        return run.F, run.lb_loss, run.z_loss
+        return outs
 
     @staticmethod
     def backward(ctx, dF, dlb, dz):
         run = ctx.run
         if dF is None:
-            dF = torch.zeros_like(run.F)
+            dF = torch.zeros(run.F_shape, device=run.device)
         d_img, d_goal, grads = run.backward(dF.contiguous().float(), dlb, dz, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return (None, d_img, d_goal, *grads)
 
@@ -355,8 +358,9 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
                 p.grad = gv[n].view(p.shape)
         return d_img, d_goal, [None] * len(params)
 
-    run.F, run.backward, run.keep = F, backward, keep_alive
-    run.lb_loss, run.z_loss = lb.mean(), zl.mean()
+    run.backward, run.keep = backward, keep_alive
+    run.F_shape, run.device = tuple(F.shape), dev
+    run.outs = (F, lb.mean(), zl.mean())                                        # taken out of `run` by the node (see _DitTrainFn.forward)
     Fo, lb_o, z_o = _DitTrainFn.apply(run, img_in, goal_in, *params)
     model._aux_losses = (lb_o, z_o)                                             # what load_balancing_loss() / compute_router_z_loss() return in training
     return Fo
