@@ -409,9 +409,9 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU):
         one = torch.ones(1, device=device)
         dist.all_reduce(one)                                                   # the number of ranks the collective library actually connected
         ranks = int(round(float(one.item())))
-    # Timed blocks of `steps` steps until the two fastest agree within 5 % (at most 8; all listed), the fastest reported: the eager training chain
-    # is the one leg of this file that runs 2-3x slow for the first seconds of a process started right after another GPU process exited on the box
-    # (seen: 27 / 46 ms blocks, then 13 ms; the graph-captured sampler never shows it)
+    # Timed blocks of `steps` steps until the two fastest agree within 5 % (at most 8; all listed), the fastest reported.  (Rounds 1-2 saw 2-4x slower
+    # blocks in some processes and blamed the box; round 3 found the cause - the training node leaked every step's activation stash, DESIGN.md section 4
+    # "Round 3" - and with the leak fixed 800 consecutive steps stay within 0.5 %.  The block list stays in the line as the evidence.)
     blocks = []
     for _ in range(8):
         if dist is not None:
