@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MODE_HIP_ABI_VERSION 5
+#define MODE_HIP_ABI_VERSION 6
 
 typedef enum ModeStatus {
   MODE_OK = 0,
@@ -459,6 +459,20 @@ int mode_dit_route(const ModeDims* dims, const ModeModelWeights* w, const float*
  * w[n, j] = probs[n / tokens_per_row, idx[n, j]] (/ their sum when normalize). */
 int mode_moe_weights_from_idx(const float* probs, const int32_t* idx, int N, int tokens_per_row, int E, int k, int normalize, float* w,
                               void* stream);
+
+/* Training draw of the expert ids: k per token row WITHOUT replacement, distributed like torch.multinomial(probs, k, replacement=False)
+ * (modedit.py:390) - the exponential race torch itself uses for that case: keys probs[n / tokens_per_row, e] / expo[n, e], the k largest in order.
+ * expo [N, E]: i.i.d. Exp(1) variates drawn by the caller (the randomness stays on the caller's generator).  Also writes the combine weights
+ * of mode_moe_weights_from_idx.  idx int32 [N, k], w fp32 [N, k].  E <= 64. */
+int mode_moe_sample_experts(const float* probs, const float* expo, int N, int tokens_per_row, int E, int k, int normalize, int32_t* idx, float* w,
+                            void* stream);
+/* Router side channels of a training forward for all L layers in one launch (modedit.py:584-593 load-balancing term, 816-820 expert usage,
+ * 930-969 router z-loss).  idx / w [L, R, k]: every routing row stands for tokens_per_row token rows; shifted [L, Rs, E] (logits - rowmax).
+ * Outputs: frac [L, E] share of token rows per expert; lb [L] = E * sum_e mean_n(scattered combine weights) * frac; zl [L] = mean_r
+ * (log(sum_e exp(shifted) + 1e-6))^2; lb_mean / zl_mean: their means over the layers; mask [L, R * tokens_per_row, E] one-hot-of-k rows or NULL;
+ * usage int64 [L, E] or NULL: token rows per expert are ADDED.  Deterministic (fixed summation order, no atomics).  E <= 16. */
+int mode_moe_aux_stats(const int32_t* idx, const float* w, int L, int R, int tokens_per_row, int E, int k, const float* shifted, int Rs,
+                       float* frac, float* lb, float* zl, float* lb_mean, float* zl_mean, float* mask, int64_t* usage, void* stream);
 
 typedef struct ModeForwardArgs {
   int32_t B; int32_t dtype;

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MODE_HIP_LIB", os.path.join(_HERE, "libmode_hip.so"))
 
 MODE_BF16, MODE_F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_RESIDUAL_NORM = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 5
+ABI_VERSION = 6
 GEMM_SKINNY_OK, GEMM_W_KN, GEMM_A_KM, GEMM_UNIFORM_GROUPS, GEMM_SMALL_ROWS, GEMM_IDENTITY_ROWS = 1, 2, 4, 8, 16, 32
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -167,6 +167,8 @@ PROTOTYPES = {
     "mode_dit_embed_obs": (C.c_int, [P(ModeDims), P(ModeModelWeights), c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
     "mode_dit_route": (C.c_int, [P(ModeDims), P(ModeModelWeights), c_vp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mode_moe_weights_from_idx": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
+    "mode_moe_sample_experts": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
+    "mode_moe_aux_stats": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mode_dit_train_stash_layout": (C.c_int, [P(ModeDims), C.c_int, C.c_int, P(ModeStashLayout)]),
     "mode_dit_train_workspace_bytes": (c_sz, [P(ModeDims), C.c_int, C.c_int]),
     "mode_dit_forward_train": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeTrainArgs), c_vp, c_sz, c_vp]),

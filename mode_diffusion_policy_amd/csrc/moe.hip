@@ -60,6 +60,108 @@ __global__ void weights_from_idx_kernel(const float* __restrict__ probs, const i
   for (int j = 0; j < k; ++j) { const float v = p[idx[(long)n * k + j]]; w[(long)n * k + j] = normalize ? v / s : v; }
 }
 
+// ---- training draw: k expert ids per token row WITHOUT replacement, distributed like torch.multinomial(probs, k, replacement=False)
+// (modedit.py:390).  torch's own algorithm for that case is the exponential race: keys p_e / q_e with q ~ Exp(1) i.i.d., the k largest keys in
+// order - the caller supplies q (torch.empty(N, E).exponential_(): the draw stays on torch's generator), this kernel does the race, the
+// top-k and the combine weights of weights_from_idx_kernel in one pass (torch spends ~20 launches on validation + topk + sort there).
+__global__ void sample_experts_kernel(const float* __restrict__ probs, const float* __restrict__ expo, int N, int tpr, int E, int k, int normalize,
+                                      int* __restrict__ idx, float* __restrict__ w) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* p = probs + (long)(n / tpr) * E;
+  const float* q = expo + (long)n * E;
+  unsigned long long taken = 0ull;
+  float s = 0.f;
+  for (int j = 0; j < k; ++j) {
+    float best = -1.f; int bi = 0;
+    for (int e = 0; e < E; ++e) {
+      if ((taken >> e) & 1ull) continue;
+      const float key = p[e] / q[e];                                   // q == 0 -> +inf: wins, as it should; ties -> lower expert id
+      if (key > best) { best = key; bi = e; }
+    }
+    taken |= 1ull << bi;
+    idx[(long)n * k + j] = bi;
+    s += p[bi];
+  }
+  for (int j = 0; j < k; ++j) { const float v = p[idx[(long)n * k + j]]; w[(long)n * k + j] = normalize ? v / s : v; }
+}
+
+// ---- training side channels of the routers (modedit.py:584-593, 816-820, 930-969), all layers in ONE single-workgroup launch:
+//   frac[l,e]  = share of token rows routed to expert e            lb[l] = E * sum_e mean_n(rp[l,n,e]) * frac[l,e]   (rp = combine weights scattered)
+//   zl[l]      = mean_r (log(sum_e exp(shifted[l,r,e]) + 1e-6))^2  lb_mean / zl_mean = means over the layers
+//   mask[l,n,e] (optional) = 1 where token n uses expert e         usage[l,e] (optional, int64) += token rows per expert
+// Fixed summation order (per-thread strided partials -> xor butterfly -> waves in order): deterministic, no atomics.  E <= 16.
+__global__ __launch_bounds__(1024) void moe_aux_stats_kernel(const int* __restrict__ idx, const float* __restrict__ w, int L, int R, int tpr, int E, int k,
+                                                             const float* __restrict__ shifted, int Rs, float* __restrict__ frac, float* __restrict__ lb,
+                                                             float* __restrict__ zl, float* __restrict__ lb_mean, float* __restrict__ zl_mean,
+                                                             float* __restrict__ mask, long long* __restrict__ usage) {
+  __shared__ float s_part[16][33];
+  __shared__ float s_tot[33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long N = (long)R * tpr;
+  float lb_acc = 0.f, zl_acc = 0.f;
+  for (int l = 0; l < L; ++l) {
+    float cnt[16], ws[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { cnt[e] = 0.f; ws[e] = 0.f; }
+    float z = 0.f;
+    for (int r = tid; r < R; r += 1024) {
+      const int* ir = idx + ((long)l * R + r) * k;
+      const float* wr = w + ((long)l * R + r) * k;
+      unsigned m = 0u;
+      for (int j = 0; j < k; ++j) {
+        const int e = ir[j];
+        const float wv = wr[j];
+        m |= 1u << e;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (c == e) { cnt[c] += 1.f; ws[c] += wv; }
+      }
+      if (mask) {
+        for (int t = 0; t < tpr; ++t) {
+          float* mr = mask + ((long)l * N + (long)r * tpr + t) * E;
+          for (int e = 0; e < E; ++e) mr[e] = ((m >> e) & 1u) ? 1.f : 0.f;
+        }
+      }
+    }
+    for (int r = tid; r < Rs; r += 1024) {
+      const float* sr = shifted + ((long)l * Rs + r) * E;
+      float se = 0.f;
+      for (int e = 0; e < E; ++e) se += expf(sr[e]);
+      const float lg = logf(se + 1e-6f);
+      z += lg * lg;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { cnt[e] = wave_sum(cnt[e]); ws[e] = wave_sum(ws[e]); }
+    z = wave_sum(z);
+    __syncthreads();                                                   // s_part / s_tot of the previous layer are no longer read
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s_part[wave][e] = cnt[e]; s_part[wave][16 + e] = ws[e]; }
+      s_part[wave][32] = z;
+    }
+    __syncthreads();
+    if (tid < 33) {
+      float t = 0.f;
+      for (int wv = 0; wv < 16; ++wv) t += s_part[wv][tid];
+      s_tot[tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float acc = 0.f;
+      for (int e = 0; e < E; ++e) {
+        const float f = s_tot[e] / (float)R;                           // every routing row stands for tpr token rows: the ratio is the same
+        frac[(long)l * E + e] = f;
+        acc += (s_tot[16 + e] / (float)R) * f;
+        if (usage) usage[(long)l * E + e] += (long long)(s_tot[e] + 0.5f) * tpr;
+      }
+      const float lbl = (float)E * acc, zll = s_tot[32] / (float)Rs;
+      lb[l] = lbl; zl[l] = zll;
+      lb_acc += lbl; zl_acc += zll;
+    }
+  }
+  if (tid == 0) { *lb_mean = lb_acc / (float)L; *zl_mean = zl_acc / (float)L; }
+}
+
 // ---- dispatch metadata: one workgroup per problem (layer); blockDim = 1024
 struct MetaBatch {
   const int* idx; const float* w; long idx_bstride;          // [R,k] per problem
@@ -196,6 +298,27 @@ extern "C" int mode_moe_dispatch_meta(const int32_t* idx, const float* w, int R,
   if (!idx || !w || !counts || !offsets || !perm || !pos || !posw || (!poffsets != !prow)) return MODE_ERR_BAD_ARG;
   MetaBatch mb{idx, w, 0, counts, offsets, perm, pos, posw, poffsets, prow, 0};
   return dispatch_meta_batched(mb, 1, R, tokens_per_row, N, E, k, (hipStream_t)stream);
+}
+
+extern "C" int mode_moe_sample_experts(const float* probs, const float* expo, int N, int tokens_per_row, int E, int k, int normalize, int32_t* idx,
+                                       float* w, void* stream) {
+  if (!probs || !expo || !idx || !w || N < 0 || tokens_per_row <= 0 || E <= 0 || k <= 0 || k > E) return MODE_ERR_BAD_ARG;
+  if (E > 64) return MODE_ERR_UNSUPPORTED;
+  if (N == 0) return MODE_OK;
+  hipLaunchKernelGGL(sample_experts_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, probs, expo, N, tokens_per_row, E, k, normalize, idx, w);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_moe_aux_stats(const int32_t* idx, const float* w, int L, int R, int tokens_per_row, int E, int k, const float* shifted, int Rs,
+                                  float* frac, float* lb, float* zl, float* lb_mean, float* zl_mean, float* mask, int64_t* usage, void* stream) {
+  if (!idx || !w || !shifted || !frac || !lb || !zl || !lb_mean || !zl_mean || L <= 0 || R <= 0 || Rs <= 0 || tokens_per_row <= 0 || E <= 0 || k <= 0 || k > E)
+    return MODE_ERR_BAD_ARG;
+  if (E > 16) return MODE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(moe_aux_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, idx, w, L, R, tokens_per_row, E, k, shifted, Rs, frac, lb, zl, lb_mean,
+                     zl_mean, mask, (long long*)usage);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
 }
 
 extern "C" int mode_moe_weights_from_idx(const float* probs, const int32_t* idx, int N, int tokens_per_row, int E, int k, int normalize, float* w,

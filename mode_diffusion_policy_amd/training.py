@@ -35,6 +35,7 @@ class TrainState:
         self._ws = None
         self.events = None                 # one event per block: "all weight gradients of block l are written" (data-parallel overlap)
         self._ev_arr = None
+        self._act_rows: Dict[tuple, torch.Tensor] = {}
 
     def _build(self) -> None:
         eng = self.eng
@@ -94,6 +95,18 @@ class TrainState:
                 ev.record()                                                     # forces creation of the underlying hipEvent
             self._ev_arr = (C.c_void_p * n)(*[ev.cuda_event for ev in self.events])
         return C.cast(self._ev_arr, C.c_void_p)
+
+    def act_rows(self, B: int, T: int, A_len: int) -> torch.Tensor:
+        """Token rows of the action positions (the last A_len of every sample's T), int32 [B * A_len]; built once per batch size."""
+        key = (B, T, A_len)
+        hit = self._act_rows.get(key)
+        if hit is None:
+            dev = self.eng.device
+            hit = (torch.arange(B, device=dev).repeat_interleave(A_len) * T + (T - A_len) + torch.arange(A_len, device=dev).repeat(B)).to(torch.int32)
+            if len(self._act_rows) >= 8:
+                self._act_rows.clear()
+            self._act_rows[key] = hit
+        return hit
 
     def grad_tables(self, flat=None):
         """ctypes tables pointing the backward chain at a gradient buffer with the arena's layout: the gradient arena itself (built once,
@@ -218,6 +231,7 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         tr_pre = torch.empty(Ly, N, 2 * D, device=dev)
         idx = torch.empty(Ly, N, k, dtype=torch.int32, device=dev); w = torch.empty(Ly, N, k, device=dev)
         tr_idx = torch.empty(N, k, dtype=torch.int32, device=dev); tr_w = torch.empty(N, k, device=dev)
+        tr_expo = None if model.use_argmax else torch.empty(Ly, N, E, device=dev).exponential_()     # the per-layer draws' Exp(1) variates, one launch
         per_tok, tpr, Rr = 1, 1, N
     else:
         idx_top, w_top, probs, shifted, r_pre = eng.route(cond, want_probs=True, want_pre=True)      # [L,B,*]
@@ -227,16 +241,18 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         idx, w, per_tok, tpr, Rr = idx_top, w_top, 0, T, B                                           # top-k also in training (modedit.py:389)
     else:
         # expert ids are SAMPLED per token row without replacement (modedit.py:390); the draw stays on the host side of the ABI
-        pt = probs.unsqueeze(2).expand(Ly, B, T, E).reshape(Ly * N, E)
-        idx = torch.multinomial(pt, k, replacement=False).to(torch.int32).view(Ly, N, k).contiguous()
+        # torch.multinomial(p, k, replacement=False) IS an exponential race (keys p / q, q ~ Exp(1), the k largest): the variates come from
+        # torch's generator, race + top-k + combine weights are one launch for all layers (token row n of layer l reads probs row
+        # (l*N + n) / T = l*B + b) - torch.multinomial itself costs ~20 launches per step (input validation, topk, sort, copies)
+        expo = torch.empty(Ly * N, E, device=dev).exponential_()
+        idx = torch.empty(Ly, N, k, dtype=torch.int32, device=dev)
         w = torch.empty(Ly, N, k, device=dev)
-        # all layers in one launch: token row n of layer l reads probs row (l*N + n) / T = l*B + b
-        L.check(lib.mode_moe_weights_from_idx(probs.data_ptr(), idx.data_ptr(), Ly * N, T, E, k, int(model.router_normalize),
-                                              w.data_ptr(), _stream()), "weights_from_idx")
+        L.check(lib.mode_moe_sample_experts(probs.data_ptr(), expo.data_ptr(), Ly * N, T, E, k, int(model.router_normalize), idx.data_ptr(),
+                                            w.data_ptr(), _stream()), "sample_experts")
         per_tok, tpr, Rr = 1, 1, N
     ml = eng.meta_layout(N)
     meta = torch.empty(Ly, ml.total_words, dtype=torch.int32, device=dev) if tokr else eng.dispatch(idx, w, Ly, Rr, tpr, N)
-    act_rows = (torch.arange(B, device=dev).repeat_interleave(A_len) * T + (T - A_len) + torch.arange(A_len, device=dev).repeat(B)).to(torch.int32)
+    act_rows = ts.act_rows(B, T, A_len)
     sl = L.ModeStashLayout()
     L.check(lib.mode_dit_train_stash_layout(C.byref(d), B, eng.dt, C.byref(sl)), "stash_layout")
     stash = torch.empty(sl.total_bytes, dtype=torch.uint8, device=dev)
@@ -260,24 +276,40 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
             if model.use_argmax:                                                                    # top-k also in training (modedit.py:389)
                 idx[l].copy_(tr_idx); w[l].copy_(tr_w)
             else:                                                                                   # sampled per token without replacement (modedit.py:390)
-                idx[l].copy_(torch.multinomial(probs[l], k, replacement=False))
-                L.check(lib.mode_moe_weights_from_idx(probs[l].data_ptr(), idx[l].data_ptr(), N, 1, E, k, int(model.router_normalize), w[l].data_ptr(),
-                                                      _stream()), "weights_from_idx")
+                L.check(lib.mode_moe_sample_experts(probs[l].data_ptr(), tr_expo[l].data_ptr(), N, 1, E, k, int(model.router_normalize), idx[l].data_ptr(),
+                                                    w[l].data_ptr(), _stream()), "sample_experts")
             L.check(lib.mode_dit_dispatch(idx[l].data_ptr(), w[l].data_ptr(), 1, N * k, N, 1, N, E, k, meta[l].data_ptr(), _stream()), "dispatch")
             L.check(lib.mode_dit_forward_train_layer(C.byref(d), C.byref(eng._mw), C.byref(args), stash.data_ptr(), stash.numel(), l, 1, _stream()), "forward_train_layer/1")
 
-    # ---- reference side channels (training only, modedit.py:584-593, 816-820); values for logging, no graph
+    # ---- reference side channels (training only, modedit.py:584-593, 816-820, 930-969): load-balancing term, z-loss, expert usage, the per-block
+    # views the agent's logging reads - one launch for all layers (E <= 16; wider MoEs take the torch expressions below)
     with torch.no_grad():
-        idx64 = (idx if per_tok else idx.unsqueeze(2).expand(Ly, B, T, k).reshape(Ly, N, k)).long()
-        wtok = w if per_tok else w.unsqueeze(2).expand(Ly, B, T, k).reshape(Ly, N, k)
-        # batched over the layers (a dozen launches per step instead of ~120), then handed out as per-block views
-        mask = torch.zeros(Ly, N, E, device=dev).scatter_(2, idx64, 1.0)
-        rp = torch.zeros(Ly, N, E, device=dev).scatter_(2, idx64, wtok)
-        frac = mask.sum(1) / N                                                                  # [L, E] fraction of tokens per expert
-        lb = E * (rp.mean(1) * frac).sum(-1)                                                    # [L]
-        zl = torch.log(torch.exp(shifted).sum(-1) + 1e-6).pow(2).mean(-1)                       # [L] router z-loss per layer (modedit.py:930-969)
+        counts_l = meta[:, ml.counts: ml.counts + E]
+        if getattr(model, "_train_usage_dev", None) is None or model._train_usage_dev.device != counts_l.device:
+            model._train_usage_dev = torch.zeros(Ly, E, dtype=torch.int64, device=dev)
+        want_views = bool(getattr(model, "log_router_stats", True))     # `model.log_router_stats = False` skips the per-block views (mode_agent.py:470-511)
+        Rs = N if tokr else B
+        if E <= 16:
+            idx, w = idx.contiguous(), w.contiguous()
+            st = torch.empty(Ly * E + 2 * Ly + 2, device=dev)
+            frac, lb, zl = st[:Ly * E].view(Ly, E), st[Ly * E: Ly * E + Ly], st[Ly * E + Ly: Ly * E + 2 * Ly]
+            lb_mean, zl_mean = st[Ly * E + 2 * Ly], st[Ly * E + 2 * Ly + 1]
+            mask = torch.empty(Ly, N, E, device=dev) if want_views else None
+            L.check(lib.mode_moe_aux_stats(idx.data_ptr(), w.data_ptr(), Ly, Rr, tpr, E, k, shifted.data_ptr(), Rs, frac.data_ptr(), lb.data_ptr(),
+                                           zl.data_ptr(), lb_mean.data_ptr(), zl_mean.data_ptr(), _ptr(mask), model._train_usage_dev.data_ptr(), _stream()),
+                    "aux_stats")
+        else:
+            idx64 = (idx if per_tok else idx.unsqueeze(2).expand(Ly, B, T, k).reshape(Ly, N, k)).long()
+            wtok = w if per_tok else w.unsqueeze(2).expand(Ly, B, T, k).reshape(Ly, N, k)
+            mask = torch.zeros(Ly, N, E, device=dev).scatter_(2, idx64, 1.0)
+            rp = torch.zeros(Ly, N, E, device=dev).scatter_(2, idx64, wtok)
+            frac = mask.sum(1) / N                                                                  # [L, E] fraction of tokens per expert
+            lb = E * (rp.mean(1) * frac).sum(-1)                                                    # [L]
+            zl = torch.log(torch.exp(shifted).sum(-1) + 1e-6).pow(2).mean(-1)                       # [L] router z-loss per layer
+            lb_mean, zl_mean = lb.mean(), zl.mean()
+            model._train_usage_dev += counts_l
         model.logits_per_layer, model.probs_per_layer = [], []
-        if getattr(model, "log_router_stats", True):          # per-block views the agent's logging reads (mode_agent.py:470-511); `model.log_router_stats = False` skips them
+        if want_views:
             logits_tok = shifted if tokr else shifted.unsqueeze(2).expand(Ly, B, T, E).reshape(Ly, N, E)
             for l, blk in enumerate(model.blocks):
                 blk.logits = logits_tok[l]
@@ -286,10 +318,6 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
                 model.logits_per_layer.append(blk.logits); model.probs_per_layer.append(blk.probs)
         for blk in model.blocks:
             blk.total_tokens_processed += N
-        counts = meta[:, ml.counts: ml.counts + E]
-        if getattr(model, "_train_usage_dev", None) is None or model._train_usage_dev.device != counts.device:
-            model._train_usage_dev = torch.zeros(Ly, E, dtype=torch.int64, device=dev)
-        model._train_usage_dev += counts
     model._last_topk = idx
 
     keep_alive = (img, gl, acts, sig, e1, emb_t, img_e, goal_e, cond, idx, w, probs, shifted, r_pre, meta, act_rows, stash) + ((tr_pre, tr_idx, tr_w) if tokr else ())
@@ -360,7 +388,7 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
 
     run.backward, run.keep = backward, keep_alive
     run.F_shape, run.device = tuple(F.shape), dev
-    run.outs = (F, lb.mean(), zl.mean())                                        # taken out of `run` by the node (see _DitTrainFn.forward)
+    run.outs = (F, lb_mean, zl_mean)                                        # taken out of `run` by the node (see _DitTrainFn.forward)
     Fo, lb_o, z_o = _DitTrainFn.apply(run, img_in, goal_in, *params)
     model._aux_losses = (lb_o, z_o)                                             # what load_balancing_loss() / compute_router_z_loss() return in training
     return Fo

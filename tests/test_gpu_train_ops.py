@@ -391,3 +391,71 @@ def test_swiglu_bwd_bias_fused_matches_separate_kernels(rows, Hdim, E, p_drop):
         assert rel(Hd.float()[keep], (ref_h / (1 - p_drop))[keep]) < 6e-3
     else:
         assert rel(Hd.float(), ref_h) < 6e-3
+
+
+@pytest.mark.parametrize("N,T,E,k,norm", [(1792, 14, 4, 2, 1), (300, 1, 8, 3, 0), (64, 4, 16, 16, 1), (1000, 1, 5, 1, 1)])
+def test_sample_experts_is_the_exponential_race_of_torch_multinomial(N, T, E, k, norm):
+    """mode_moe_sample_experts against the same race written in torch ((p / q).topk(k) - torch.multinomial's own algorithm without replacement):
+    identical ids in identical order, combine weights of mode_moe_weights_from_idx; plus a distribution check of the first pick against p."""
+    lib = L.load()
+    torch.manual_seed(N + E)
+    R = N // T
+    probs = torch.softmax(torch.randn(R, E, device="cuda") * 1.5, -1).clamp(1e-9, 1 - 1e-9)
+    expo = torch.empty(N, E, device="cuda").exponential_()
+    idx = torch.empty(N, k, dtype=torch.int32, device="cuda"); w = torch.empty(N, k, device="cuda")
+    L.check(lib.mode_moe_sample_experts(probs.data_ptr(), expo.data_ptr(), N, T, E, k, norm, idx.data_ptr(), w.data_ptr(), None), "sample")
+    ptok = probs.repeat_interleave(T, 0)
+    ref_idx = (ptok / expo).topk(k, dim=-1).indices
+    assert torch.equal(idx.long(), ref_idx)
+    assert all(len(set(r)) == k for r in idx[:50].tolist())                                    # without replacement
+    pw = ptok.gather(1, ref_idx)
+    ref_w = pw / pw.sum(-1, keepdim=True) if norm else pw
+    assert torch.equal(w, ref_w) or float((w - ref_w).abs().max()) < 1e-7
+    w2 = torch.empty_like(w)
+    L.check(lib.mode_moe_weights_from_idx(probs.data_ptr(), idx.data_ptr(), N, T, E, k, norm, w2.data_ptr(), None), "w_from_idx")
+    assert torch.equal(w, w2)
+    # distribution: many draws of the FIRST pick from one row follow p (the race is exact, not an approximation)
+    M = 200_000
+    p1 = probs[:1].contiguous()
+    ex = torch.empty(M, E, device="cuda").exponential_()
+    i1 = torch.empty(M, 1, dtype=torch.int32, device="cuda"); w1 = torch.empty(M, 1, device="cuda")
+    L.check(lib.mode_moe_sample_experts(p1.data_ptr(), ex.data_ptr(), M, M, E, 1, 0, i1.data_ptr(), w1.data_ptr(), None), "sample")
+    freq = torch.bincount(i1.view(-1).long(), minlength=E).float() / M
+    sd = (p1[0] * (1 - p1[0]) / M).sqrt()
+    assert bool(((freq - p1[0]).abs() < 5 * sd + 1e-4).all()), (freq, p1)
+
+
+@pytest.mark.parametrize("Ly,R,T,E,k,tok", [(12, 128, 14, 4, 2, False), (3, 1792, 1, 4, 2, True), (2, 40, 5, 16, 3, False), (1, 2500, 1, 7, 2, True)])
+def test_moe_aux_stats_vs_torch_expressions(Ly, R, T, E, k, tok):
+    """One launch for the router side channels of a training forward (load-balancing term, z-loss, usage, one-hot-of-k mask) against the torch
+    expressions it replaced (= the reference's, modedit.py:584-593, 816-820, 930-969)."""
+    lib = L.load()
+    torch.manual_seed(Ly * 100 + R)
+    N = R * T
+    Rs = N if tok else R
+    idx = torch.stack([torch.stack([torch.randperm(E, device="cuda")[:k] for _ in range(R)]) for _ in range(Ly)]).to(torch.int32)
+    w = torch.rand(Ly, R, k, device="cuda")
+    shifted = torch.randn(Ly, Rs, E, device="cuda")
+    shifted = shifted - shifted.max(-1, keepdim=True).values
+    st = torch.empty(Ly * E + 2 * Ly + 2, device="cuda")
+    frac, lb, zl = st[:Ly * E].view(Ly, E), st[Ly * E: Ly * E + Ly], st[Ly * E + Ly: Ly * E + 2 * Ly]
+    mask = torch.full((Ly, N, E), 7.0, device="cuda")
+    usage = torch.full((Ly, E), 5, dtype=torch.int64, device="cuda")
+    L.check(lib.mode_moe_aux_stats(idx.data_ptr(), w.data_ptr(), Ly, R, T, E, k, shifted.data_ptr(), Rs, frac.data_ptr(), lb.data_ptr(), zl.data_ptr(),
+                                   st[Ly * E + 2 * Ly:].data_ptr(), st[Ly * E + 2 * Ly + 1:].data_ptr(), mask.data_ptr(), usage.data_ptr(), None), "aux")
+    idx64 = idx.unsqueeze(2).expand(Ly, R, T, k).reshape(Ly, N, k).long()
+    wtok = w.unsqueeze(2).expand(Ly, R, T, k).reshape(Ly, N, k)
+    mref = torch.zeros(Ly, N, E, device="cuda").scatter_(2, idx64, 1.0)
+    rp = torch.zeros(Ly, N, E, device="cuda").scatter_(2, idx64, wtok)
+    fref = mref.sum(1) / N
+    lbref = E * (rp.mean(1) * fref).sum(-1)
+    zref = torch.log(torch.exp(shifted).sum(-1) + 1e-6).pow(2).mean(-1)
+    assert torch.equal(mask, mref)
+    assert torch.equal(usage, 5 + mref.sum(1).long())
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(frac, fref) < 1e-6 and rel(lb, lbref) < 1e-5 and rel(zl, zref) < 1e-5
+    assert abs(float(st[Ly * E + 2 * Ly]) - float(lbref.mean())) < 1e-5 * float(lbref.mean()) and abs(float(st[-1]) - float(zref.mean())) < 1e-5 * float(zref.mean())
+    # without the optional outputs
+    L.check(lib.mode_moe_aux_stats(idx.data_ptr(), w.data_ptr(), Ly, R, T, E, k, shifted.data_ptr(), Rs, frac.data_ptr(), lb.data_ptr(), zl.data_ptr(),
+                                   st[Ly * E + 2 * Ly:].data_ptr(), st[Ly * E + 2 * Ly + 1:].data_ptr(), None, None, None), "aux")
+    assert rel(lb, lbref) < 1e-5
