@@ -242,7 +242,8 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
     else:
         # expert ids are SAMPLED per token row without replacement (modedit.py:390); the draw stays on the host side of the ABI
         # torch.multinomial(p, k, replacement=False) IS an exponential race (keys p / q, q ~ Exp(1), the k largest): the variates come from
-        # torch's generator, race + top-k + combine weights are one launch for all layers (token row n of layer l reads probs row
+        # torch's generator exactly as multinomial draws them, so the ids equal torch.multinomial's for the same generator state
+        # (tests/test_gpu_train_ops.py); race + top-k + combine weights are one launch for all layers (token row n of layer l reads probs row
         # (l*N + n) / T = l*B + b) - torch.multinomial itself costs ~20 launches per step (input validation, topk, sort, copies)
         expo = torch.empty(Ly * N, E, device=dev).exponential_()
         idx = torch.empty(Ly, N, k, dtype=torch.int32, device=dev)

@@ -414,6 +414,14 @@ def test_sample_experts_is_the_exponential_race_of_torch_multinomial(N, T, E, k,
     w2 = torch.empty_like(w)
     L.check(lib.mode_moe_weights_from_idx(probs.data_ptr(), idx.data_ptr(), N, T, E, k, norm, w2.data_ptr(), None), "w_from_idx")
     assert torch.equal(w, w2)
+    # same generator state -> the SAME ids as torch.multinomial itself (its no-replacement path draws q = empty_like(p).exponential_() and takes
+    # topk(p / q); aten/src/ATen/native/Distributions.cpp): the replacement changes launches, not the random stream
+    torch.manual_seed(77)
+    ref_m = torch.multinomial(ptok, k, replacement=False)
+    torch.manual_seed(77)
+    expo2 = torch.empty(N, E, device="cuda").exponential_()
+    L.check(lib.mode_moe_sample_experts(probs.data_ptr(), expo2.data_ptr(), N, T, E, k, norm, idx.data_ptr(), w.data_ptr(), None), "sample")
+    assert torch.equal(idx.long(), ref_m)
     # distribution: many draws of the FIRST pick from one row follow p (the race is exact, not an approximation)
     M = 200_000
     p1 = probs[:1].contiguous()
