@@ -549,6 +549,74 @@ def train_bench(args, world, rank, device, dist):
         dist.destroy_process_group()
 
 
+def agent_bench(args, world, rank, device, dist):
+    """SURVEY section 8(f) rank 1 end to end: the reference AGENT's training step - two FiLM-ResNet-50 encoders (static + gripper camera, 224 x 224,
+    conditioned on the latent goal, mode_agent.py:548-567, conf/model/mode_agent.yaml resnet_type '50', calvin_transforms.yaml) feeding the denoiser's
+    score-matching loss, everything under torch.autocast(bfloat16) like the reference's trainer (conf/config_calvin.yaml:37), backward THROUGH the
+    denoiser into both encoders, AdamW on all of it (fused arena AdamW for the denoiser, torch AdamW for the encoders).  Convolutions: MIOpen;
+    BatchNorm / FiLM / ReLU / residual between them: the fused HIP pass (csrc/encoder_ops.hip).  One rank; single-GPU number."""
+    import math
+    from mode_diffusion_policy_amd.optim import FusedAdamW
+    from mode_diffusion_policy_amd.perceptual_encoders import FiLMResNet50Policy, embed_visual_obs
+    from mode_diffusion_policy_amd.utils import rand_log_logistic
+    M, den = build_model(device, args.dtype)
+    m = den.inner_model
+    den.train()
+    B = args.agent_batch
+    torch.manual_seed(0)
+    enc_s, enc_g = FiLMResNet50Policy(512).to(device).train(), FiLMResNet50Policy(512).to(device).train()
+    for enc in (enc_s, enc_g):                                                 # the reference zero-initialises FiLM: give the modulation something to do
+        for n_, p_ in enc.named_parameters():
+            if n_.startswith("film"):
+                torch.nn.init.normal_(p_, std=0.02)
+    g = torch.Generator().manual_seed(1)
+    rgb_s = torch.randn(B, 1, 3, 224, 224, generator=g).to(device); rgb_g = torch.randn(B, 1, 3, 224, 224, generator=g).to(device)
+    goal = torch.randn(B, 1, 512, generator=g).to(device)
+    acts = torch.randn(B, 10, 7, generator=g).to(device); noise = torch.randn(B, 10, 7, generator=g).to(device)
+    opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    opt_e = torch.optim.AdamW(list(enc_s.parameters()) + list(enc_g.parameters()), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    enc_ms = [0.0, 0.0]
+
+    def step(timed=False):
+        sig = rand_log_logistic((B,), loc=math.log(0.5), scale=0.5, min_value=1e-3, max_value=80.0, device=device)
+        if timed:
+            ev[0].record()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            emb = embed_visual_obs(enc_s, enc_g, rgb_s, rgb_g, goal.squeeze(1))
+            if timed:
+                ev[1].record()
+            loss, _ = den.loss(emb, acts, goal, noise, sig)
+        loss.backward()
+        opt.step(overlap=True)
+        opt_e.step()
+        opt_e.zero_grad(set_to_none=True)
+        return loss
+    for _ in range(max(args.warmup, 2)):                                        # includes MIOpen's per-shape algorithm search
+        loss = step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss.detach()).all()
+    blocks = []
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(); blocks.append((time.perf_counter() - t0) / args.steps * 1e3)
+    step(timed=True); torch.cuda.synchronize()
+    enc_fwd_ms = ev[0].elapsed_time(ev[1])
+    ms = min(blocks)
+    n_enc = sum(p_.numel() for e in (enc_s, enc_g) for p_ in e.parameters())
+    res = {"metric": "agent-train-samples/sec (2x FiLM-ResNet-50 @224 + MoDE denoiser, B per GPU, AdamW)", "value": round(B / (ms * 1e-3), 1), "unit": "samples/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16 (torch.autocast for the encoders, bf16 MFMA chain for the denoiser)", "data": "synthetic",
+           "config": {"workload": "SURVEY 8(f)-1: MoDEAgent training step - embed_visual_obs (2 x FiLMResNet50Policy, 224 x 224 RGB, latent-goal FiLM) -> "
+                                  "GCDenoiser.loss (12 layers, d=1024, 4 experts top-2) -> backward through both -> AdamW", "global_batch": B,
+                      "parallelism": "single GPU"},
+           "agent_ms_per_step_blocks": [round(b, 3) for b in blocks], "encoders_forward_ms": round(enc_fwd_ms, 3), "encoder_params": n_enc,
+           "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -557,7 +625,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel breakdown and the train / rollout / B=1 legs of the default run")
-    ap.add_argument("--mode", default="sample", choices=["sample", "train", "rollout"],
+    ap.add_argument("--agent-batch", type=int, default=64, help="--mode agent: samples per step (the reference's config_calvin.yaml batch_size is 64 per GPU)")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train", "rollout", "agent"],
                     help="sample (default, BASELINE metric): 10-step DDIM chunks at B=128; train: configs[2]/[3] score-matching steps "
                          "(fwd+bwd+AdamW, DP all-reduce); rollout: configs[4], B=32 environments, router pre-cached per noise level")
     args = ap.parse_args()
@@ -588,6 +657,8 @@ def main():
 
     if args.mode == "train":
         return train_bench(args, world, rank, device, dist)
+    if args.mode == "agent":
+        return agent_bench(args, world, rank, device, dist)
     M, den = build_model(device, args.dtype)
     rollout = args.mode == "rollout"
     batch = 32 if rollout else B_PER_GPU

@@ -603,6 +603,14 @@ int mode_bn_film_act_fwd(const ModeBnFilmDesc* d, void* stream);
 size_t mode_bn_workspace_bytes(int N, int C);
 /* per-channel mean and BIASED variance over (N, HW) (training-mode nn.BatchNorm2d); fixed summation order, no atomics */
 int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, float* mean, float* var, void* workspace, size_t workspace_bytes, void* stream);
+/* Everything a BatchNorm2d contributes before the fused pass, in two launches: x != NULL (training) - batch mean / biased variance over (N, HW) as
+ * mode_bn_stats, x == NULL (eval) - the statistics are running_mean / running_var; then invstd = 1 / sqrt(var + eps), scale = weight * invstd, shift =
+ * bias - mean * scale (weight / bias NULL = 1 / 0), and nn.BatchNorm2d's bookkeeping IN PLACE when training and the pointers are given: running_mean /
+ * running_var (unbiased variance; momentum >= 0: exponential average, < 0: cumulative average 1 / num_batches_tracked as with momentum=None),
+ * num_batches_tracked += 1.  All outputs [C] fp32. */
+int mode_bn_prepare(const void* x, int dtype, int N, int C, int HW, const float* weight, const float* bias, float eps, float momentum,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* var, float* invstd, float* scale,
+                    float* shift, void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the fused chain.  mean / invstd [C]: the statistics scale / shift were folded from (scale = weight * invstd).  training != 0:
  * gradient through the batch statistics; 0: dx = d * scale.  Outputs: dx, dresidual (iff d->residual), dweight / dbias [C] (BatchNorm affine),
  * d_pre_* / d_post_* [N, C] (iff the corresponding FiLM is present).

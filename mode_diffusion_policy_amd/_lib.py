@@ -193,6 +193,8 @@ PROTOTYPES = {
     "mode_bn_film_act_fwd": (C.c_int, [P(ModeBnFilmDesc), c_vp]),
     "mode_bn_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "mode_bn_stats": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mode_bn_prepare": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, C.c_float, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
+                                  c_vp]),
     "mode_bn_film_act_bwd": (C.c_int, [P(ModeBnFilmDesc), c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
 }
 

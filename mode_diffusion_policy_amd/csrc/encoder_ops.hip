@@ -14,6 +14,7 @@
 // the backward (FiLM gradients are sums over HW per (n, c)) are wave shuffles - no atomics, deterministic.  All of it is HBM-bound streaming:
 // forward reads x (+ residual) and writes y once; backward = one reduction pass (6 sums per row) + one pass that writes dx / d residual.
 #include "mode_common.h"
+#include <algorithm>
 
 using namespace mode;
 
@@ -118,16 +119,70 @@ __global__ __launch_bounds__(256) void bn_row_sums_kernel(const T* __restrict__ 
   s = wave_sum(s); q = wave_sum(q);
   if (lane == 0) { psum[row] = s; psq[row] = q; }
 }
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int N, int C, long count,
-                                                          float* __restrict__ mean, float* __restrict__ var) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+// Per-channel fold of per-row partials: a 1024-thread workgroup owns 64 channels, its 16 waves split the N rows (coalesced 256-byte reads of 64
+// neighbouring channels), partials meet in LDS as doubles and are added in wave order: deterministic.  (One thread per channel walking all N rows,
+// the first version, took 17 us per BatchNorm - a serial chain of N strided loads - and there are 106 BatchNorms per ResNet-50 pair.)
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int N, int C, double count,
+                                                           float* __restrict__ mean, float* __restrict__ var) {
+  __shared__ double lds[2 * 16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int n = wave; n < N; n += 16) { a += (double)psum[(long)n * C + c]; b += (double)psq[(long)n * C + c]; }
+  lds[wave * 64 + lane] = a; lds[(16 + wave) * 64 + lane] = b;
+  __syncthreads();
+  if (wave != 0 || c >= C) return;
   double s = 0.0, q = 0.0;
-  for (int n = 0; n < N; ++n) { s += psum[(long)n * C + c]; q += psq[(long)n * C + c]; }
-  const double m = s / (double)count;
+  for (int w = 0; w < 16; ++w) { s += lds[w * 64 + lane]; q += lds[(16 + w) * 64 + lane]; }
+  const double m = s / count;
   mean[c] = (float)m;
-  var[c] = (float)fmax(q / (double)count - m * m, 0.0);            // biased variance (what normalises the batch; nn.BatchNorm2d)
+  var[c] = (float)fmax(q / count - m * m, 0.0);                          // biased variance (what normalises the batch; nn.BatchNorm2d)
 }
+
+// Everything a BatchNorm needs before the fused pass, in one launch after the row sums: batch mean / biased variance (training) or the running
+// statistics (eval), invstd, the folded scale = weight * invstd and shift = bias - mean * scale, and nn.BatchNorm2d's bookkeeping - running_mean /
+// running_var (unbiased variance, momentum or cumulative average) and num_batches_tracked - updated in place.
+__global__ __launch_bounds__(1024) void bn_prepare_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int N, int C, double count, int training,
+                                                          const float* __restrict__ weight, const float* __restrict__ bias, float eps, float momentum,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
+                                                          float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+  __shared__ double lds[2 * 16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const bool valid = c < C;
+  double m, v;
+  if (training) {
+    double acc[2] = {0.0, 0.0};
+    if (valid)
+      for (int n = wave; n < N; n += 16) { acc[0] += (double)psum[(long)n * C + c]; acc[1] += (double)psq[(long)n * C + c]; }
+    lds[wave * 64 + lane] = acc[0]; lds[(16 + wave) * 64 + lane] = acc[1];
+    __syncthreads();
+    double s = 0.0, q = 0.0;
+    for (int w = 0; w < 16; ++w) { s += lds[w * 64 + lane]; q += lds[(16 + w) * 64 + lane]; }
+    m = s / count;
+    v = fmax(q / count - m * m, 0.0);                                      // biased variance (what normalises the batch; nn.BatchNorm2d)
+  } else {
+    m = valid ? (double)running_mean[c] : 0.0; v = valid ? (double)running_var[c] : 1.0;
+  }
+  if (wave != 0 || !valid) return;
+  const float mf = (float)m, vf = (float)v;
+  const float is = 1.0f / sqrtf(vf + eps);
+  const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
+  const float sc = w * is;
+  mean[c] = mf; var[c] = vf; invstd[c] = is; scale[c] = sc; shift[c] = b - mf * sc;
+  if (training && running_mean) {
+    // exponential moving average with `momentum`, or the cumulative average when momentum < 0 (nn.BatchNorm2d(momentum=None)): factor = 1 / batches seen
+    const float f = momentum >= 0.f ? momentum : 1.0f / (float)((nbt ? *nbt : 0) + 1);
+    const float unbias = (float)(count / fmax(count - 1.0, 1.0));
+    running_mean[c] = running_mean[c] * (1.f - f) + mf * f;
+    running_var[c] = running_var[c] * (1.f - f) + vf * unbias * f;
+  }
+  // num_batches_tracked += 1: here when nobody reads it (momentum given); the cumulative-average case counts in a launch of its own, after all reads
+  if (training && nbt && momentum >= 0.f && blockIdx.x == 0 && lane == 0) *nbt += 1;
+}
+__global__ void bn_count_step_kernel(long long* nbt) { *nbt += 1; }          // num_batches_tracked += 1, after every channel block read it
 
 // ---- backward, pass 1: six sums per row
 //   sums[row] = { S dy*v4, S dy, S dv2*v1, S dv2, S dv1, S dv1*xhat }
@@ -168,19 +223,29 @@ __global__ __launch_bounds__(256) void bn_film_act_bwd_sums_kernel(const ModeBnF
     o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5;
   }
 }
-// per-channel fold of the row sums (double), FiLM gradients are the row sums themselves
-__global__ __launch_bounds__(256) void bn_film_bwd_fold_kernel(const float* __restrict__ sums, int N, int C, float* __restrict__ dweight, float* __restrict__ dbias,
-                                                               float* __restrict__ dpg, float* __restrict__ dpb, float* __restrict__ dqg, float* __restrict__ dqb) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < (long)N * C) {
-    const float* s = sums + i * 6;
-    if (dqg) { dqg[i] = s[0]; dqb[i] = s[1]; }
-    if (dpg) { dpg[i] = s[2]; dpb[i] = s[3]; }
-  }
-  if (i < C) {
-    double b = 0.0, w = 0.0;
-    for (int n = 0; n < N; ++n) { b += sums[((long)n * C + i) * 6 + 4]; w += sums[((long)n * C + i) * 6 + 5]; }
-    dbias[i] = (float)b; dweight[i] = (float)w;
+// per-channel fold of the row sums (double; 64 channels per 1024-thread workgroup, the 16 waves split the rows), FiLM gradients are the row sums themselves
+__global__ __launch_bounds__(1024) void bn_film_bwd_fold_kernel(const float* __restrict__ sums, int N, int C, float* __restrict__ dweight, float* __restrict__ dbias,
+                                                                float* __restrict__ dpg, float* __restrict__ dpb, float* __restrict__ dqg, float* __restrict__ dqb) {
+  __shared__ double lds[2 * 16 * 64];
+  const long total = (long)N * C;
+  if (dqg || dpg)
+    for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < total; i += (long)gridDim.x * 1024) {
+      const float* s = sums + i * 6;
+      if (dqg) { dqg[i] = s[0]; dqb[i] = s[1]; }
+      if (dpg) { dpg[i] = s[2]; dpb[i] = s[3]; }
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  if (blockIdx.x * 64 >= C) return;                                        // (whole workgroup: no barrier is skipped by part of it)
+  double b = 0.0, w = 0.0;
+  if (c < C)
+    for (int n = wave; n < N; n += 16) { const float* s = sums + ((long)n * C + c) * 6; b += (double)s[4]; w += (double)s[5]; }
+  lds[wave * 64 + lane] = b; lds[(16 + wave) * 64 + lane] = w;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    double tb = 0.0, tw = 0.0;
+    for (int k = 0; k < 16; ++k) { tb += lds[k * 64 + lane]; tw += lds[(16 + k) * 64 + lane]; }
+    dbias[c] = (float)tb; dweight[c] = (float)tw;
   }
 }
 // pass 2: dx (training: through the batch statistics; eval: dv1 * scale) and d residual
@@ -271,8 +336,39 @@ extern "C" int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, flo
   BN_DISPATCH(K_SUM, dtype, vec, (hipStream_t)stream);
 #undef K_SUM
   MODE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, psum, psq, N, C, (long)N * HW, mean, var);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, psum, psq, N, C, (double)N * (double)HW, mean, var);
   MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_bn_prepare(const void* x, int dtype, int N, int C, int HW, const float* weight, const float* bias, float eps, float momentum,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* var, float* invstd, float* scale,
+                               float* shift, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!mean || !var || !invstd || !scale || !shift || N <= 0 || C <= 0 || HW <= 0) return MODE_ERR_BAD_ARG;
+  const int training = x != nullptr;
+  if (!training && (!running_mean || !running_var)) return MODE_ERR_BAD_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return MODE_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* psum = nullptr; float* psq = nullptr;
+  if (training) {
+    if (!workspace || workspace_bytes < mode_bn_workspace_bytes(N, C)) return MODE_ERR_WORKSPACE;
+    if (dtype != MODE_F32 && dtype != MODE_BF16) return MODE_ERR_BAD_ARG;
+    const long rows = (long)N * C;
+    psum = (float*)workspace; psq = psum + rows;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const int vec = bn_vec(dtype, HW, x, nullptr, nullptr, nullptr, nullptr);
+#define K_SUM(T, V, s_) hipLaunchKernelGGL((bn_row_sums_kernel<T, V>), grid, dim3(256), 0, s_, (const T*)x, rows, HW, psum, psq)
+    BN_DISPATCH(K_SUM, dtype, vec, s);
+#undef K_SUM
+    MODE_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(bn_prepare_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, psum, psq, N, C, (double)N * (double)HW, training, weight, bias, eps, momentum,
+                     running_mean, running_var, (long long*)num_batches_tracked, mean, var, invstd, scale, shift);
+  MODE_LAUNCH_CHECK();
+  if (training && num_batches_tracked && momentum < 0.f) {
+    hipLaunchKernelGGL(bn_count_step_kernel, dim3(1), dim3(1), 0, s, (long long*)num_batches_tracked);
+    MODE_LAUNCH_CHECK();
+  }
   return MODE_OK;
 }
 
@@ -296,9 +392,9 @@ extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, con
     BN_DISPATCH(K_BS, d->dtype, vec, s);
 #undef K_BS
     MODE_LAUNCH_CHECK();
-    const long nfold = rows > d->C ? rows : d->C;
-    hipLaunchKernelGGL(bn_film_bwd_fold_kernel, dim3((unsigned)((nfold + 255) / 256)), dim3(256), 0, s, sums, d->N, d->C, dweight, dbias, d_pre_gamma, d_pre_beta,
-                       d_post_gamma, d_post_beta);
+    const long cblocks = (d->C + 63) / 64, eblocks = (d_pre_gamma || d_post_gamma) ? std::min<long>((rows + 1023) / 1024, 256) : 0;
+    hipLaunchKernelGGL(bn_film_bwd_fold_kernel, dim3((unsigned)std::max(cblocks, eblocks)), dim3(1024), 0, s, sums, d->N, d->C, dweight, dbias, d_pre_gamma,
+                       d_pre_beta, d_post_gamma, d_post_beta);
     MODE_LAUNCH_CHECK();
   }
   if (phase != 1) {                                            // dx / d residual from the (possibly cross-rank summed) channel sums

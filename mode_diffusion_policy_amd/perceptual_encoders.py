@@ -55,7 +55,8 @@ class _BnFilmAct(torch.autograd.Function):
     """y = post_film(relu(pre_film(batch_norm(x)) + residual)) as one HIP launch (two for training statistics); see csrc/encoder_ops.hip."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b, sync_group=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b, sync_group=None,
+                num_batches_tracked=None):
         if x.device.type != "cuda":
             raise L.ModeHipUnavailable("FiLM-ResNet encoders run through the HIP library only: inputs must live on a ROCm device")
         lib = L.load()
@@ -65,30 +66,50 @@ class _BnFilmAct(torch.autograd.Function):
         dev = x.device
         f32 = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
         w, b = f32(weight), f32(bias)
-        ws = torch.empty(lib.mode_bn_workspace_bytes(N, Cc), dtype=torch.uint8, device=dev)
-        if training:
-            mean = torch.empty(Cc, device=dev); var = torch.empty(Cc, device=dev)
-            L.check(lib.mode_bn_stats(x.data_ptr(), _dt(x), N, Cc, HW, mean.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn_stats")
-            m = N * HW
-            if sync_group is not None:
-                # nn.SyncBatchNorm (Lightning's sync_batchnorm=True, mode/training_calvin.py:102): the statistics of the GLOBAL batch - one small
-                # all-reduce of [sum, sum of squares, count] per BatchNorm (RCCL; 2C + 1 floats)
-                import torch.distributed as dist
-                pack = torch.cat([mean * m, (var + mean * mean) * m, torch.full((1,), float(m), device=dev)])
-                dist.all_reduce(pack, group=sync_group if sync_group is not True else None)
-                m = pack[-1]                                                   # global element count per channel: stays on the device (no host sync)
-                mean = pack[:Cc] / m
-                var = (pack[Cc:2 * Cc] / m - mean * mean).clamp_min_(0.0)
-            if running_mean is not None:                                       # nn.BatchNorm2d bookkeeping: unbiased variance into the running estimate
-                with torch.no_grad():
-                    running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
-                    unbias = (m / (m - 1).clamp_min(1.0)) if torch.is_tensor(m) else (m / max(m - 1, 1))
-                    running_var.mul_(1 - momentum).add_((var * unbias).to(running_var.dtype), alpha=momentum)
+        m = N * HW
+        fp32_buf = lambda t: t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == dev)
+        if sync_group is None and fp32_buf(running_mean) and fp32_buf(running_var) and (training or running_mean is not None):
+            # one call: (row sums +) per-channel statistics, invstd, folded scale / shift, and nn.BatchNorm2d's bookkeeping in place (running
+            # statistics with the unbiased variance, num_batches_tracked) - a dozen torch launches per BatchNorm otherwise, 106 BatchNorms per
+            # pair of ResNet-50s
+            st = torch.empty(5, Cc, device=dev)
+            mean, var, invstd, scale, shift = st[0], st[1], st[2], st[3], st[4]
+            ws = torch.empty(lib.mode_bn_workspace_bytes(N, Cc), dtype=torch.uint8, device=dev) if training else None
+            nbt = num_batches_tracked if (training and num_batches_tracked is not None and num_batches_tracked.dtype == torch.int64
+                                          and num_batches_tracked.device == dev) else None
+            with torch.no_grad():
+                L.check(lib.mode_bn_prepare(x.data_ptr() if training else None, _dt(x), N, Cc, HW, _ptr(w), _ptr(b), float(eps),
+                                            -1.0 if momentum is None else float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(nbt), mean.data_ptr(),
+                                            var.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _ptr(ws), 0 if ws is None else ws.numel(),
+                                            _stream()), "bn_prepare")
         else:
-            mean, var = f32(running_mean), f32(running_var)
-        invstd = torch.rsqrt(var + eps)
-        scale = w * invstd
-        shift = b - mean * scale
+            ws = torch.empty(lib.mode_bn_workspace_bytes(N, Cc), dtype=torch.uint8, device=dev)
+            if training:
+                mean = torch.empty(Cc, device=dev); var = torch.empty(Cc, device=dev)
+                L.check(lib.mode_bn_stats(x.data_ptr(), _dt(x), N, Cc, HW, mean.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn_stats")
+                if sync_group is not None:
+                    # nn.SyncBatchNorm (Lightning's sync_batchnorm=True, mode/training_calvin.py:102): the statistics of the GLOBAL batch - one small
+                    # all-reduce of [sum, sum of squares, count] per BatchNorm (RCCL; 2C + 1 floats)
+                    import torch.distributed as dist
+                    pack = torch.cat([mean * m, (var + mean * mean) * m, torch.full((1,), float(m), device=dev)])
+                    dist.all_reduce(pack, group=sync_group if sync_group is not True else None)
+                    m = pack[-1]                                               # global element count per channel: stays on the device (no host sync)
+                    mean = pack[:Cc] / m
+                    var = (pack[Cc:2 * Cc] / m - mean * mean).clamp_min_(0.0)
+                if running_mean is not None:                                   # nn.BatchNorm2d bookkeeping: unbiased variance into the running estimate
+                    with torch.no_grad():
+                        if num_batches_tracked is not None:
+                            num_batches_tracked.add_(1)
+                        f = (1.0 / num_batches_tracked.to(torch.float32)) if momentum is None else momentum
+                        unbias = (m / (m - 1).clamp_min(1.0)) if torch.is_tensor(m) else (m / max(m - 1, 1))
+                        running_mean.mul_(1 - f).add_((mean * f).to(running_mean.dtype))
+                        running_var.mul_(1 - f).add_((var * unbias * f).to(running_var.dtype))
+            else:
+                mean, var = f32(running_mean), f32(running_var)
+            invstd = torch.rsqrt(var + eps)
+            w1 = w if w is not None else torch.ones(Cc, device=dev)
+            scale = w1 * invstd
+            shift = (b if b is not None else 0.0) - mean * scale
         pre = (f32(pre_g).reshape(N, Cc), f32(pre_b).reshape(N, Cc)) if pre_g is not None else None
         post = (f32(post_g).reshape(N, Cc), f32(post_b).reshape(N, Cc)) if post_g is not None else None
         res = None if residual is None else residual.contiguous()
@@ -139,7 +160,7 @@ class _BnFilmAct(torch.autograd.Function):
         ps, qs = ctx.shapes
         rs = lambda t, shp: None if t is None else t.reshape(shp)
         # inputs: x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b
-        return dx, dw, db, None, None, None, None, None, None, dres, rs(dpg, ps), rs(dpb, ps), rs(dqg, qs), rs(dqb, qs), None
+        return dx, dw, db, None, None, None, None, None, None, dres, rs(dpg, ps), rs(dpb, ps), rs(dqg, qs), rs(dqb, qs), None, None
 
 
 def bn_film_act(x, bn: nn.BatchNorm2d, relu: bool = True, residual=None, pre_film=None, post_film=None):
@@ -151,8 +172,9 @@ def bn_film_act(x, bn: nn.BatchNorm2d, relu: bool = True, residual=None, pre_fil
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.process_group) > 1:
             sync = bn.process_group if bn.process_group is not None else True
-    return _BnFilmAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, 0.1 if bn.momentum is None else bn.momentum, bn.eps, relu,
-                            residual, pg, pb, qg, qb, sync)
+    training = bn.training or bn.running_mean is None                       # no running statistics -> batch statistics also in eval (nn.BatchNorm2d)
+    return _BnFilmAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, relu, residual, pg, pb, qg, qb, sync,
+                            bn.num_batches_tracked if bn.training else None)
 
 
 # ------------------------------------------------------------------------------------------------------------------ trunk (parameter holders)

@@ -268,3 +268,37 @@ def test_encoder_and_denoiser_under_autocast_like_lightning_bf16():
     yard = rel(tg["autocast"], tg["fp32"])
     assert rel(out["autocast"][1], out["fp32"][1]) < 1.25 * yard + 0.02, (rel(out["autocast"][1], out["fp32"][1]), yard)
     assert rel(out["autocast"][2], out["fp32"][2]) < 0.1                      # the denoiser's own arithmetic is autocast-independent: only its inputs moved
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("momentum", [0.1, None, 0.3])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_prepare_bookkeeping_matches_nn_batchnorm(momentum, dtype):
+    """mode_bn_prepare (statistics + folded scale / shift + running_mean / running_var / num_batches_tracked in place) against nn.BatchNorm2d itself over
+    three training steps and an eval step - exponential and cumulative (momentum=None) averaging, C not a multiple of the 64-channel block."""
+    torch.manual_seed(3)
+    C_, N_ = 70, 19
+    ref = torch.nn.BatchNorm2d(C_, momentum=momentum).cuda()
+    mine = torch.nn.BatchNorm2d(C_, momentum=momentum).cuda()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5); ref.bias.normal_()
+        mine.load_state_dict(ref.state_dict())
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for step in range(3):
+        x = (torch.randn(N_, C_, 9, 11, device="cuda") * (1 + step) + 0.3 * step).to(dtype)
+        y_ref = torch.relu(ref(x.float()))
+        y = E.bn_film_act(x, mine, relu=True)
+        assert y.dtype == dtype and rel(y, y_ref) < tol
+        assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
+        stat_tol = 1e-5 if dtype == torch.float32 else 1e-5             # the statistics are computed from the same (already rounded) activations
+        assert rel(mine.running_mean, ref.running_mean) < stat_tol and rel(mine.running_var, ref.running_var) < stat_tol
+    ref.eval(); mine.eval()
+    x = torch.randn(N_, C_, 9, 11, device="cuda").to(dtype)
+    assert rel(E.bn_film_act(x, mine, relu=False), ref(x.float())) < tol
+    assert int(mine.num_batches_tracked) == 3                                # eval leaves the bookkeeping alone
+    # gradients through the fused statistics path still match autograd of the reference expression
+    ref.train(); mine.train()
+    xr = torch.randn(N_, C_, 9, 11, device="cuda", requires_grad=True); xm = xr.detach().clone().requires_grad_(True)
+    gy = torch.randn(N_, C_, 9, 11, device="cuda")
+    (torch.relu(ref(xr)) * gy).sum().backward(); (E.bn_film_act(xm, mine, relu=True) * gy).sum().backward()
+    assert rel(xm.grad, xr.grad) < 1e-4 and rel(mine.weight.grad, ref.weight.grad) < 1e-4 and rel(mine.bias.grad, ref.bias.grad) < 1e-4
