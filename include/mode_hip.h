@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MODE_HIP_ABI_VERSION 6
+#define MODE_HIP_ABI_VERSION 7
 
 typedef enum ModeStatus {
   MODE_OK = 0,
@@ -583,7 +583,7 @@ int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w, const Mod
 /* ------------------------------------------------------------------------------------------------------------------
  * FiLM-ResNet perceptual encoders (mode/models/perceptual_encoders/pretrained_resnets.py:5-60, resnets.py:27-200,
  * mode_agent.py:548-567): the producer of `state_images`.  Convolutions stay library calls (MIOpen via the caller); these entry points are
- * everything between two convolutions as ONE pass over the NCHW activation:
+ * everything between two convolutions as ONE pass over the activation (NCHW, or channels_last - ModeBnFilmDesc.channels_last):
  *   y = post_film( relu( pre_film( x * scale[c] + shift[c] ) + residual ) )
  *   pre_film : v = pre_gamma[n,c] * v + pre_beta[n,c]          (BasicBlockWithModulation, resnets.py:64-71: after bn2, before the skip add)
  *   post_film: v = (1 + post_gamma[n,c]) * v + post_beta[n,c]  (FiLMLayer after a whole stage, pretrained_resnets.py:19-23)
@@ -598,17 +598,20 @@ typedef struct ModeBnFilmDesc {
   int32_t relu;
   const float* post_gamma; const float* post_beta; /* [N, C] or both NULL                                              */
   void* y;                                         /* [N, C, HW] (unused by the backward)                              */
+  int32_t channels_last;                           /* 0: x / residual / y (dy, dx) are [N][C][HW] (NCHW); 1: [N][HW][C] (torch.channels_last: what MIOpen's
+                                                      implicit-GEMM convolutions read and write without layout transposes); needs C % 8 == 0 (bf16) / 4 (fp32) */
 } ModeBnFilmDesc;
 int mode_bn_film_act_fwd(const ModeBnFilmDesc* d, void* stream);
-size_t mode_bn_workspace_bytes(int N, int C);
+size_t mode_bn_workspace_bytes(int N, int C, int HW, int dtype, int channels_last);
 /* per-channel mean and BIASED variance over (N, HW) (training-mode nn.BatchNorm2d); fixed summation order, no atomics */
-int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, float* mean, float* var, void* workspace, size_t workspace_bytes, void* stream);
+int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, int channels_last, float* mean, float* var, void* workspace, size_t workspace_bytes,
+                  void* stream);
 /* Everything a BatchNorm2d contributes before the fused pass, in two launches: x != NULL (training) - batch mean / biased variance over (N, HW) as
  * mode_bn_stats, x == NULL (eval) - the statistics are running_mean / running_var; then invstd = 1 / sqrt(var + eps), scale = weight * invstd, shift =
  * bias - mean * scale (weight / bias NULL = 1 / 0), and nn.BatchNorm2d's bookkeeping IN PLACE when training and the pointers are given: running_mean /
  * running_var (unbiased variance; momentum >= 0: exponential average, < 0: cumulative average 1 / num_batches_tracked as with momentum=None),
  * num_batches_tracked += 1.  All outputs [C] fp32. */
-int mode_bn_prepare(const void* x, int dtype, int N, int C, int HW, const float* weight, const float* bias, float eps, float momentum,
+int mode_bn_prepare(const void* x, int dtype, int N, int C, int HW, int channels_last, const float* weight, const float* bias, float eps, float momentum,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* var, float* invstd, float* scale,
                     float* shift, void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the fused chain.  mean / invstd [C]: the statistics scale / shift were folded from (scale = weight * invstd).  training != 0:

@@ -224,15 +224,23 @@ __global__ __launch_bounds__(256) void bn_film_act_bwd_sums_kernel(const ModeBnF
   }
 }
 // per-channel fold of the row sums (double; 64 channels per 1024-thread workgroup, the 16 waves split the rows), FiLM gradients are the row sums themselves
-__global__ __launch_bounds__(1024) void bn_film_bwd_fold_kernel(const float* __restrict__ sums, int N, int C, float* __restrict__ dweight, float* __restrict__ dbias,
-                                                                float* __restrict__ dpg, float* __restrict__ dpb, float* __restrict__ dqg, float* __restrict__ dqb) {
+__global__ __launch_bounds__(1024) void bn_film_bwd_fold_kernel(const float* __restrict__ sums, int NS, int S, int C, float* __restrict__ dweight,
+                                                                float* __restrict__ dbias, float* __restrict__ dpg, float* __restrict__ dpb, float* __restrict__ dqg,
+                                                                float* __restrict__ dqb) {
+  // sums: [NS = samples * S pixel splits][C][6]; FiLM gradients per (sample, channel) = the S splits added in order, BatchNorm affine gradients = all NS rows
   __shared__ double lds[2 * 16 * 64];
-  const long total = (long)N * C;
+  const int N = NS;
+  const long total = (long)(NS / S) * C;
   if (dqg || dpg)
     for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < total; i += (long)gridDim.x * 1024) {
-      const float* s = sums + i * 6;
-      if (dqg) { dqg[i] = s[0]; dqb[i] = s[1]; }
-      if (dpg) { dpg[i] = s[2]; dpb[i] = s[3]; }
+      const long smp = i / C, c_ = i % C;
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+      for (int k = 0; k < S; ++k) {
+        const float* s = sums + ((smp * S + k) * C + c_) * 6;
+        t0 += s[0]; t1 += s[1]; t2 += s[2]; t3 += s[3];
+      }
+      if (dqg) { dqg[i] = t0; dqb[i] = t1; }
+      if (dpg) { dpg[i] = t2; dpb[i] = t3; }
     }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -285,6 +293,204 @@ __global__ __launch_bounds__(256) void bn_film_act_bwd_dx_kernel(const ModeBnFil
   }
 }
 
+// =====================================================================================================================
+// channels_last (NHWC) activations: x[n][p][c] - what MIOpen's fast implicit-GEMM convolutions read and write natively (from NCHW tensors it wraps
+// them in layout transposes: 10 % of the agent's training step).  BN / FiLM parameters now vary along the FASTEST axis: a thread owns W = 16 bytes of
+// consecutive channels (8 bf16 / 4 fp32) of one pixel, a 256-thread workgroup = 8 such channel vectors (CT = 8 W channels: one 128-byte segment per
+// pixel) x 32 pixel lanes, and walks the pixels [p0, p1) of ONE sample n (FiLM parameters are per sample).  grid = (channel tiles, N, S pixel
+// splits).  The reductions (statistics, the six backward sums) fold the 32 pixel lanes by xor shuffles (lanes 8 apart hold the same channels) and
+// LDS across the four waves, and write the SAME per-(row, channel) layout the NCHW kernels write with rows = N * S - the per-channel folds
+// (bn_prepare_kernel, bn_film_bwd_fold_kernel) are shared.  C % W == 0 required.
+template <typename T>
+struct Nhwc { static constexpr int W = 16 / sizeof(T); static constexpr int CT = 8 * W; };
+
+template <int W>
+__device__ __forceinline__ void ldc(const float* __restrict__ p, long i, float (&v)[W]) {
+#pragma unroll
+  for (int j = 0; j < W; j += 4) { const float4 t = *reinterpret_cast<const float4*>(p + i + j); v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w; }
+}
+// fold K * W per-thread sums over the 32 pixel lanes of the workgroup; the result lands in threads 0..7 (pixel lane 0 of wave 0), returns true there
+template <int KW>
+__device__ __forceinline__ bool nhwc_fold(float (&a)[KW], float* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, oct = threadIdx.x & 7;
+#pragma unroll
+  for (int j = 0; j < KW; ++j) { a[j] += __shfl_xor(a[j], 8, 64); a[j] += __shfl_xor(a[j], 16, 64); a[j] += __shfl_xor(a[j], 32, 64); }
+  if (lane < 8) {
+#pragma unroll
+    for (int j = 0; j < KW; ++j) lds[(wave * 8 + oct) * KW + j] = a[j];
+  }
+  __syncthreads();
+  if (threadIdx.x >= 8) return false;
+#pragma unroll
+  for (int j = 0; j < KW; ++j) a[j] = lds[(0 * 8 + oct) * KW + j] + lds[(1 * 8 + oct) * KW + j] + lds[(2 * 8 + oct) * KW + j] + lds[(3 * 8 + oct) * KW + j];
+  return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_nhwc_stats_kernel(const T* __restrict__ x, int C, int HW, int S, float* __restrict__ psum, float* __restrict__ psq) {
+  constexpr int W = Nhwc<T>::W, CT = Nhwc<T>::CT;
+  __shared__ float lds[4 * 8 * 2 * W];
+  const int oct = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * CT + oct * W, n = blockIdx.y, sp = blockIdx.z;
+  const int p0 = (int)((long)HW * sp / S), p1 = (int)((long)HW * (sp + 1) / S);
+  float a[2 * W];
+#pragma unroll
+  for (int j = 0; j < 2 * W; ++j) a[j] = 0.f;
+  if (c0 < C)
+    for (int p = p0 + pl; p < p1; p += 32) {
+      float v[W];
+      ldv<T, W>(x, ((long)n * HW + p) * C + c0, v);
+#pragma unroll
+      for (int j = 0; j < W; ++j) { a[j] += v[j]; a[W + j] = __builtin_fmaf(v[j], v[j], a[W + j]); }
+    }
+  if (nhwc_fold<2 * W>(a, lds) && c0 < C) {
+    const long o = ((long)n * S + sp) * C + c0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) { psum[o + j] = a[j]; psq[o + j] = a[W + j]; }
+  }
+}
+
+template <int W>
+struct ChanParams { float sc[W], sh[W], pg[W], pb[W], qg[W], qb[W]; bool pre, post; };
+template <int W>
+__device__ __forceinline__ void chan_params(const ModeBnFilmDesc& d, int n, int c0, ChanParams<W>& r) {
+  ldc<W>(d.scale, c0, r.sc); ldc<W>(d.shift, c0, r.sh);
+  r.pre = d.pre_gamma != nullptr; r.post = d.post_gamma != nullptr;
+  const long nc = (long)n * d.C + c0;
+  if (r.pre) { ldc<W>(d.pre_gamma, nc, r.pg); ldc<W>(d.pre_beta, nc, r.pb); }
+  if (r.post) { ldc<W>(d.post_gamma, nc, r.qg); ldc<W>(d.post_beta, nc, r.qb); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_film_act_fwd_nhwc_kernel(const ModeBnFilmDesc d, int S) {
+  constexpr int W = Nhwc<T>::W, CT = Nhwc<T>::CT;
+  const int oct = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * CT + oct * W, n = blockIdx.y;
+  if (c0 >= d.C) return;
+  const int p0 = (int)((long)d.HW * blockIdx.z / S), p1 = (int)((long)d.HW * (blockIdx.z + 1) / S);
+  ChanParams<W> r;
+  chan_params<W>(d, n, c0, r);
+  const T* x = reinterpret_cast<const T*>(d.x);
+  const T* res = reinterpret_cast<const T*>(d.residual);
+  T* y = reinterpret_cast<T*>(d.y);
+  for (int p = p0 + pl; p < p1; p += 32) {
+    const long o = ((long)n * d.HW + p) * d.C + c0;
+    float v[W], rv[W];
+    ldv<T, W>(x, o, v);
+    if (res) ldv<T, W>(res, o, rv);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      float t = __builtin_fmaf(v[j], r.sc[j], r.sh[j]);
+      if (r.pre) t = __builtin_fmaf(r.pg[j], t, r.pb[j]);
+      if (res) t += rv[j];
+      if (d.relu) t = fmaxf(t, 0.f);
+      if (r.post) t = __builtin_fmaf(1.f + r.qg[j], t, r.qb[j]);
+      v[j] = t;
+    }
+    stv<T, W>(y, o, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_film_act_bwd_sums_nhwc_kernel(const ModeBnFilmDesc d, const T* __restrict__ dy, const float* __restrict__ mean,
+                                                                        const float* __restrict__ invstd, int S, float* __restrict__ sums) {
+  constexpr int W = Nhwc<T>::W, CT = Nhwc<T>::CT;
+  __shared__ float lds[4 * 8 * 6 * W];
+  const int oct = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * CT + oct * W, n = blockIdx.y, sp = blockIdx.z;
+  const int p0 = (int)((long)d.HW * sp / S), p1 = (int)((long)d.HW * (sp + 1) / S);
+  float a[6 * W];
+#pragma unroll
+  for (int j = 0; j < 6 * W; ++j) a[j] = 0.f;
+  if (c0 < d.C) {
+    ChanParams<W> r;
+    chan_params<W>(d, n, c0, r);
+    float mu[W], is[W];
+    ldc<W>(mean, c0, mu); ldc<W>(invstd, c0, is);
+    const T* x = reinterpret_cast<const T*>(d.x);
+    const T* res = reinterpret_cast<const T*>(d.residual);
+    for (int p = p0 + pl; p < p1; p += 32) {
+      const long o = ((long)n * d.HW + p) * d.C + c0;
+      float xv[W], gv[W], rv[W];
+      ldv<T, W>(x, o, xv); ldv<T, W>(dy, o, gv);
+      if (res) ldv<T, W>(res, o, rv);
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const float gy = gv[j];
+        const float v1 = __builtin_fmaf(xv[j], r.sc[j], r.sh[j]);
+        const float v2 = r.pre ? __builtin_fmaf(r.pg[j], v1, r.pb[j]) : v1;
+        const float v3 = res ? v2 + rv[j] : v2;
+        const float v4 = d.relu ? fmaxf(v3, 0.f) : v3;
+        const float dv4 = r.post ? gy * (1.f + r.qg[j]) : gy;
+        const float dv2 = (d.relu && v3 <= 0.f) ? 0.f : dv4;
+        const float dv1 = r.pre ? dv2 * r.pg[j] : dv2;
+        a[0 * W + j] = __builtin_fmaf(gy, v4, a[0 * W + j]); a[1 * W + j] += gy; a[2 * W + j] = __builtin_fmaf(dv2, v1, a[2 * W + j]); a[3 * W + j] += dv2;
+        a[4 * W + j] += dv1; a[5 * W + j] = __builtin_fmaf(dv1, (xv[j] - mu[j]) * is[j], a[5 * W + j]);
+      }
+    }
+  }
+  if (nhwc_fold<6 * W>(a, lds) && c0 < d.C) {
+    float* o = sums + (((long)n * S + sp) * d.C + c0) * 6;
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) o[j * 6 + k] = a[k * W + j];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_film_act_bwd_dx_nhwc_kernel(const ModeBnFilmDesc d, const T* __restrict__ dy, const float* __restrict__ mean,
+                                                                      const float* __restrict__ invstd, const float* __restrict__ dweight,
+                                                                      const float* __restrict__ dbias, int training, float inv_m, int S, T* __restrict__ dx,
+                                                                      T* __restrict__ dres) {
+  constexpr int W = Nhwc<T>::W, CT = Nhwc<T>::CT;
+  const int oct = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * CT + oct * W, n = blockIdx.y;
+  if (c0 >= d.C) return;
+  const int p0 = (int)((long)d.HW * blockIdx.z / S), p1 = (int)((long)d.HW * (blockIdx.z + 1) / S);
+  ChanParams<W> r;
+  chan_params<W>(d, n, c0, r);
+  float mu[W], is[W], mb[W], mw[W];
+  ldc<W>(mean, c0, mu); ldc<W>(invstd, c0, is);
+  if (training) { ldc<W>(dbias, c0, mb); ldc<W>(dweight, c0, mw); }
+#pragma unroll
+  for (int j = 0; j < W; ++j) { mb[j] = training ? mb[j] * inv_m : 0.f; mw[j] = training ? mw[j] * inv_m : 0.f; }
+  const T* x = reinterpret_cast<const T*>(d.x);
+  const T* res = reinterpret_cast<const T*>(d.residual);
+  for (int p = p0 + pl; p < p1; p += 32) {
+    const long o = ((long)n * d.HW + p) * d.C + c0;
+    float xv[W], gv[W], rv[W], o1[W], o2[W];
+    ldv<T, W>(x, o, xv); ldv<T, W>(dy, o, gv);
+    if (res) ldv<T, W>(res, o, rv);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const float v1 = __builtin_fmaf(xv[j], r.sc[j], r.sh[j]);
+      const float v2 = r.pre ? __builtin_fmaf(r.pg[j], v1, r.pb[j]) : v1;
+      const float v3 = res ? v2 + rv[j] : v2;
+      const float dv4 = r.post ? gv[j] * (1.f + r.qg[j]) : gv[j];
+      const float dv2 = (d.relu && v3 <= 0.f) ? 0.f : dv4;
+      const float dv1 = r.pre ? dv2 * r.pg[j] : dv2;
+      o2[j] = dv2;
+      o1[j] = r.sc[j] * (dv1 - mb[j] - (xv[j] - mu[j]) * is[j] * mw[j]);       // scale = weight * invstd
+    }
+    if (dres) stv<T, W>(dres, o, o2);
+    stv<T, W>(dx, o, o1);
+  }
+}
+
+// pixel splits of a sample: enough workgroups to fill the part (early layers have few channel tiles), chunks of >= 64 pixels
+static int nhwc_splits(int N, int C, int HW, int CT) {
+  const long wg = (long)N * ((C + CT - 1) / CT);
+  long S = std::max<long>(1, 1024 / std::max<long>(wg, 1));
+  S = std::min<long>(S, std::max(1, HW / 64));
+  return (int)std::min<long>(S, 32);
+}
+static int nhwc_ct(int dtype) { return dtype == MODE_BF16 ? 64 : 32; }
+static bool nhwc_ok(int dtype, int C, const void* a, const void* b, const void* c, const void* e, const void* f) {
+  const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)e | (uintptr_t)f;
+  return !(al & 15) && C % (dtype == MODE_BF16 ? 8 : 4) == 0;
+}
+
 // widest access the rows allow: every row starts at row * HW elements, so HW must be a multiple of the vector length (and the base 16-byte aligned)
 static int bn_vec(int dtype, int HW, const void* a, const void* b, const void* c, const void* e, const void* f) {
   const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)e | (uintptr_t)f;
@@ -313,6 +519,15 @@ extern "C" int mode_bn_film_act_fwd(const ModeBnFilmDesc* d, void* stream) {
   if (!bn_desc_ok(d)) return MODE_ERR_BAD_ARG;
   const long rows = (long)d->N * d->C;
   if (rows == 0) return MODE_OK;
+  if (d->channels_last) {
+    if (!nhwc_ok(d->dtype, d->C, d->x, d->residual, d->y, d->scale, d->shift)) return MODE_ERR_UNSUPPORTED;
+    const int CT = nhwc_ct(d->dtype), S = nhwc_splits(d->N, d->C, d->HW, CT);
+    const dim3 g((d->C + CT - 1) / CT, d->N, S);
+    if (d->dtype == MODE_BF16) hipLaunchKernelGGL(bn_film_act_fwd_nhwc_kernel<uint16_t>, g, dim3(256), 0, (hipStream_t)stream, *d, S);
+    else hipLaunchKernelGGL(bn_film_act_fwd_nhwc_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, *d, S);
+    MODE_LAUNCH_CHECK();
+    return MODE_OK;
+  }
   const dim3 grid((unsigned)((rows + 3) / 4));
   const int vec = bn_vec(d->dtype, d->HW, d->x, d->residual, d->y, nullptr, nullptr);
 #define K_FWD(T, V, s_) hipLaunchKernelGGL((bn_film_act_fwd_kernel<T, V>), grid, dim3(256), 0, s_, *d)
@@ -322,26 +537,49 @@ extern "C" int mode_bn_film_act_fwd(const ModeBnFilmDesc* d, void* stream) {
   return MODE_OK;
 }
 
-extern "C" size_t mode_bn_workspace_bytes(int N, int C) { return N < 0 || C <= 0 ? 0 : (size_t)N * C * 6 * 4 + 256; }
+// rows of per-(row, channel) partials: N for NCHW (one wave per (n, c) row), N * pixel splits for channels_last
+static long bn_rows(int N, int C, int HW, int dtype, int channels_last) { return channels_last ? (long)N * nhwc_splits(N, C, HW, nhwc_ct(dtype)) : (long)N; }
+extern "C" size_t mode_bn_workspace_bytes(int N, int C, int HW, int dtype, int channels_last) {
+  return N < 0 || C <= 0 || HW <= 0 ? 0 : (size_t)bn_rows(N, C, HW, dtype, channels_last) * C * 6 * 4 + 256;
+}
 
-extern "C" int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, float* mean, float* var, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!x || !mean || !var || !workspace || N <= 0 || C <= 0 || HW <= 0) return MODE_ERR_BAD_ARG;
-  if (workspace_bytes < mode_bn_workspace_bytes(N, C)) return MODE_ERR_WORKSPACE;
-  const long rows = (long)N * C;
-  float* psum = (float*)workspace; float* psq = psum + rows;
-  const dim3 grid((unsigned)((rows + 3) / 4));
+// row sums (NCHW) / per-split channel sums (channels_last) into psum / psq [NS][C]
+static int bn_partial_sums(const void* x, int dtype, int N, int C, int HW, int channels_last, float* psum_base, hipStream_t s, float** psum, float** psq, long* NS_out) {
   if (dtype != MODE_F32 && dtype != MODE_BF16) return MODE_ERR_BAD_ARG;
-  const int vec = bn_vec(dtype, HW, x, nullptr, nullptr, nullptr, nullptr);
-#define K_SUM(T, V, s_) hipLaunchKernelGGL((bn_row_sums_kernel<T, V>), grid, dim3(256), 0, s_, (const T*)x, rows, HW, psum, psq)
-  BN_DISPATCH(K_SUM, dtype, vec, (hipStream_t)stream);
+  const long NS = bn_rows(N, C, HW, dtype, channels_last);
+  *NS_out = NS;
+  *psum = psum_base; *psq = psum_base + NS * C;
+  if (channels_last) {
+    if (!nhwc_ok(dtype, C, x, nullptr, nullptr, nullptr, nullptr)) return MODE_ERR_UNSUPPORTED;
+    const int CT = nhwc_ct(dtype), S = (int)(NS / N);
+    const dim3 g((C + CT - 1) / CT, N, S);
+    if (dtype == MODE_BF16) hipLaunchKernelGGL(bn_nhwc_stats_kernel<uint16_t>, g, dim3(256), 0, s, (const uint16_t*)x, C, HW, S, *psum, *psq);
+    else hipLaunchKernelGGL(bn_nhwc_stats_kernel<float>, g, dim3(256), 0, s, (const float*)x, C, HW, S, *psum, *psq);
+  } else {
+    const long rows = (long)N * C;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const int vec = bn_vec(dtype, HW, x, nullptr, nullptr, nullptr, nullptr);
+#define K_SUM(T, V, s_) hipLaunchKernelGGL((bn_row_sums_kernel<T, V>), grid, dim3(256), 0, s_, (const T*)x, rows, HW, *psum, *psq)
+    BN_DISPATCH(K_SUM, dtype, vec, s);
 #undef K_SUM
-  MODE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, psum, psq, N, C, (double)N * (double)HW, mean, var);
+  }
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
 
-extern "C" int mode_bn_prepare(const void* x, int dtype, int N, int C, int HW, const float* weight, const float* bias, float eps, float momentum,
+extern "C" int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, int channels_last, float* mean, float* var, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  if (!x || !mean || !var || !workspace || N <= 0 || C <= 0 || HW <= 0) return MODE_ERR_BAD_ARG;
+  if (workspace_bytes < mode_bn_workspace_bytes(N, C, HW, dtype, channels_last)) return MODE_ERR_WORKSPACE;
+  float *psum, *psq;
+  long NS = N;
+  if (int rc = bn_partial_sums(x, dtype, N, C, HW, channels_last, (float*)workspace, (hipStream_t)stream, &psum, &psq, &NS)) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, psum, psq, (int)NS, C, (double)N * (double)HW, mean, var);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+extern "C" int mode_bn_prepare(const void* x, int dtype, int N, int C, int HW, int channels_last, const float* weight, const float* bias, float eps, float momentum,
                                float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* var, float* invstd, float* scale,
                                float* shift, void* workspace, size_t workspace_bytes, void* stream) {
   if (!mean || !var || !invstd || !scale || !shift || N <= 0 || C <= 0 || HW <= 0) return MODE_ERR_BAD_ARG;
@@ -350,19 +588,12 @@ extern "C" int mode_bn_prepare(const void* x, int dtype, int N, int C, int HW, c
   if ((running_mean == nullptr) != (running_var == nullptr)) return MODE_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   float* psum = nullptr; float* psq = nullptr;
+  long NS = N;
   if (training) {
-    if (!workspace || workspace_bytes < mode_bn_workspace_bytes(N, C)) return MODE_ERR_WORKSPACE;
-    if (dtype != MODE_F32 && dtype != MODE_BF16) return MODE_ERR_BAD_ARG;
-    const long rows = (long)N * C;
-    psum = (float*)workspace; psq = psum + rows;
-    const dim3 grid((unsigned)((rows + 3) / 4));
-    const int vec = bn_vec(dtype, HW, x, nullptr, nullptr, nullptr, nullptr);
-#define K_SUM(T, V, s_) hipLaunchKernelGGL((bn_row_sums_kernel<T, V>), grid, dim3(256), 0, s_, (const T*)x, rows, HW, psum, psq)
-    BN_DISPATCH(K_SUM, dtype, vec, s);
-#undef K_SUM
-    MODE_LAUNCH_CHECK();
+    if (!workspace || workspace_bytes < mode_bn_workspace_bytes(N, C, HW, dtype, channels_last)) return MODE_ERR_WORKSPACE;
+    if (int rc = bn_partial_sums(x, dtype, N, C, HW, channels_last, (float*)workspace, s, &psum, &psq, &NS)) return rc;
   }
-  hipLaunchKernelGGL(bn_prepare_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, psum, psq, N, C, (double)N * (double)HW, training, weight, bias, eps, momentum,
+  hipLaunchKernelGGL(bn_prepare_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, psum, psq, (int)NS, C, (double)N * (double)HW, training, weight, bias, eps, momentum,
                      running_mean, running_var, (long long*)num_batches_tracked, mean, var, invstd, scale, shift);
   MODE_LAUNCH_CHECK();
   if (training && num_batches_tracked && momentum < 0.f) {
@@ -379,7 +610,7 @@ extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, con
   if ((d->pre_gamma != nullptr) != (d_pre_gamma != nullptr && d_pre_beta != nullptr)) return MODE_ERR_BAD_ARG;
   if ((d->post_gamma != nullptr) != (d_post_gamma != nullptr && d_post_beta != nullptr)) return MODE_ERR_BAD_ARG;
   if ((d->residual != nullptr) != (dresidual != nullptr)) return MODE_ERR_BAD_ARG;
-  if (workspace_bytes < mode_bn_workspace_bytes(d->N, d->C)) return MODE_ERR_WORKSPACE;
+  if (workspace_bytes < mode_bn_workspace_bytes(d->N, d->C, d->HW, d->dtype, d->channels_last)) return MODE_ERR_WORKSPACE;
   const long rows = (long)d->N * d->C;
   if (rows == 0) return MODE_OK;
   if (phase < 0 || phase > 2) return MODE_ERR_BAD_ARG;
@@ -387,21 +618,39 @@ extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, con
   const dim3 grid((unsigned)((rows + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
   const int vec = bn_vec(d->dtype, d->HW, d->x, d->residual, dy, dx, dresidual);
+  const int cl = d->channels_last;
+  if (cl && !nhwc_ok(d->dtype, d->C, d->x, d->residual, dy, dx, dresidual)) return MODE_ERR_UNSUPPORTED;
+  const int CT = nhwc_ct(d->dtype), S = cl ? nhwc_splits(d->N, d->C, d->HW, CT) : 1;
+  const dim3 g((d->C + CT - 1) / CT, d->N, S);
   if (phase != 2) {                                            // reductions: FiLM gradients per (n, c), BatchNorm affine gradients per channel
+    if (cl) {
+      if (d->dtype == MODE_BF16) hipLaunchKernelGGL(bn_film_act_bwd_sums_nhwc_kernel<uint16_t>, g, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, S, sums);
+      else hipLaunchKernelGGL(bn_film_act_bwd_sums_nhwc_kernel<float>, g, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, S, sums);
+    } else {
 #define K_BS(T, V, s_) hipLaunchKernelGGL((bn_film_act_bwd_sums_kernel<T, V>), grid, dim3(256), 0, s_, *d, (const T*)dy, mean, invstd, sums)
-    BN_DISPATCH(K_BS, d->dtype, vec, s);
+      BN_DISPATCH(K_BS, d->dtype, vec, s);
 #undef K_BS
+    }
     MODE_LAUNCH_CHECK();
     const long cblocks = (d->C + 63) / 64, eblocks = (d_pre_gamma || d_post_gamma) ? std::min<long>((rows + 1023) / 1024, 256) : 0;
-    hipLaunchKernelGGL(bn_film_bwd_fold_kernel, dim3((unsigned)std::max(cblocks, eblocks)), dim3(1024), 0, s, sums, d->N, d->C, dweight, dbias, d_pre_gamma,
+    hipLaunchKernelGGL(bn_film_bwd_fold_kernel, dim3((unsigned)std::max(cblocks, eblocks)), dim3(1024), 0, s, sums, d->N * S, S, d->C, dweight, dbias, d_pre_gamma,
                        d_pre_beta, d_post_gamma, d_post_beta);
     MODE_LAUNCH_CHECK();
   }
   if (phase != 1) {                                            // dx / d residual from the (possibly cross-rank summed) channel sums
     const float inv_m = inv_count > 0.f ? inv_count : 1.f / ((float)d->N * (float)d->HW);
+    if (cl) {
+      if (d->dtype == MODE_BF16)
+        hipLaunchKernelGGL(bn_film_act_bwd_dx_nhwc_kernel<uint16_t>, g, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, dweight, dbias, training, inv_m, S,
+                           (uint16_t*)dx, (uint16_t*)dresidual);
+      else
+        hipLaunchKernelGGL(bn_film_act_bwd_dx_nhwc_kernel<float>, g, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, dweight, dbias, training, inv_m, S, (float*)dx,
+                           (float*)dresidual);
+    } else {
 #define K_DX(T, V, s_) hipLaunchKernelGGL((bn_film_act_bwd_dx_kernel<T, V>), grid, dim3(256), 0, s_, *d, (const T*)dy, mean, invstd, dweight, dbias, training, inv_m, (T*)dx, (T*)dresidual)
-    BN_DISPATCH(K_DX, d->dtype, vec, s);
+      BN_DISPATCH(K_DX, d->dtype, vec, s);
 #undef K_DX
+    }
     MODE_LAUNCH_CHECK();
   }
   return MODE_OK;

@@ -44,11 +44,16 @@ def _dt(t: torch.Tensor) -> int:
     raise TypeError(f"encoder activations must be float32 or bfloat16, got {t.dtype}")
 
 
-def _desc(x, scale, shift, pre, res, relu, post, y) -> L.ModeBnFilmDesc:
+def _is_cl(x: torch.Tensor) -> bool:
+    """torch.channels_last storage of a 4-D activation (and not also plain-contiguous, as 1 x 1 maps / single channels are)."""
+    return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+
+
+def _desc(x, scale, shift, pre, res, relu, post, y, cl=False) -> L.ModeBnFilmDesc:
     N, Cc = x.shape[0], x.shape[1]
     return L.ModeBnFilmDesc(N=N, C=Cc, HW=x[0, 0].numel(), dtype=_dt(x), x=_ptr(x), scale=_ptr(scale), shift=_ptr(shift),
                             pre_gamma=_ptr(pre[0]) if pre else None, pre_beta=_ptr(pre[1]) if pre else None, residual=_ptr(res), relu=int(relu),
-                            post_gamma=_ptr(post[0]) if post else None, post_beta=_ptr(post[1]) if post else None, y=_ptr(y))
+                            post_gamma=_ptr(post[0]) if post else None, post_beta=_ptr(post[1]) if post else None, y=_ptr(y), channels_last=int(cl))
 
 
 class _BnFilmAct(torch.autograd.Function):
@@ -60,10 +65,14 @@ class _BnFilmAct(torch.autograd.Function):
         if x.device.type != "cuda":
             raise L.ModeHipUnavailable("FiLM-ResNet encoders run through the HIP library only: inputs must live on a ROCm device")
         lib = L.load()
-        x = x.contiguous()
+        # channels_last activations stay channels_last (the NHWC kernels of encoder_ops.hip; needs whole 16-byte channel vectors); everything else NCHW
+        cl = _is_cl(x) and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0
+        fmt = torch.channels_last if cl else torch.contiguous_format
+        x = x.contiguous(memory_format=fmt)
         N, Cc = x.shape[0], x.shape[1]
         HW = x[0, 0].numel()
         dev = x.device
+        wsb = lib.mode_bn_workspace_bytes(N, Cc, HW, _dt(x), int(cl))
         f32 = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
         w, b = f32(weight), f32(bias)
         m = N * HW
@@ -74,19 +83,19 @@ class _BnFilmAct(torch.autograd.Function):
             # pair of ResNet-50s
             st = torch.empty(5, Cc, device=dev)
             mean, var, invstd, scale, shift = st[0], st[1], st[2], st[3], st[4]
-            ws = torch.empty(lib.mode_bn_workspace_bytes(N, Cc), dtype=torch.uint8, device=dev) if training else None
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if training else None
             nbt = num_batches_tracked if (training and num_batches_tracked is not None and num_batches_tracked.dtype == torch.int64
                                           and num_batches_tracked.device == dev) else None
             with torch.no_grad():
-                L.check(lib.mode_bn_prepare(x.data_ptr() if training else None, _dt(x), N, Cc, HW, _ptr(w), _ptr(b), float(eps),
+                L.check(lib.mode_bn_prepare(x.data_ptr() if training else None, _dt(x), N, Cc, HW, int(cl), _ptr(w), _ptr(b), float(eps),
                                             -1.0 if momentum is None else float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(nbt), mean.data_ptr(),
                                             var.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _ptr(ws), 0 if ws is None else ws.numel(),
                                             _stream()), "bn_prepare")
         else:
-            ws = torch.empty(lib.mode_bn_workspace_bytes(N, Cc), dtype=torch.uint8, device=dev)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             if training:
                 mean = torch.empty(Cc, device=dev); var = torch.empty(Cc, device=dev)
-                L.check(lib.mode_bn_stats(x.data_ptr(), _dt(x), N, Cc, HW, mean.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn_stats")
+                L.check(lib.mode_bn_stats(x.data_ptr(), _dt(x), N, Cc, HW, int(cl), mean.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn_stats")
                 if sync_group is not None:
                     # nn.SyncBatchNorm (Lightning's sync_batchnorm=True, mode/training_calvin.py:102): the statistics of the GLOBAL batch - one small
                     # all-reduce of [sum, sum of squares, count] per BatchNorm (RCCL; 2C + 1 floats)
@@ -112,13 +121,13 @@ class _BnFilmAct(torch.autograd.Function):
             shift = (b if b is not None else 0.0) - mean * scale
         pre = (f32(pre_g).reshape(N, Cc), f32(pre_b).reshape(N, Cc)) if pre_g is not None else None
         post = (f32(post_g).reshape(N, Cc), f32(post_b).reshape(N, Cc)) if post_g is not None else None
-        res = None if residual is None else residual.contiguous()
+        res = None if residual is None else residual.contiguous(memory_format=fmt)
         if res is not None and (res.shape != x.shape or res.dtype != x.dtype):
             raise ValueError("residual must match the activation's shape and dtype")
-        y = torch.empty_like(x)
-        L.check(lib.mode_bn_film_act_fwd(C.byref(_desc(x, scale, shift, pre, res, relu, post, y)), _stream()), "bn_film_act_fwd")
+        y = torch.empty_like(x, memory_format=fmt)
+        L.check(lib.mode_bn_film_act_fwd(C.byref(_desc(x, scale, shift, pre, res, relu, post, y, cl)), _stream()), "bn_film_act_fwd")
         ctx.save_for_backward(x, res, scale, shift, mean, invstd, *(pre or ()), *(post or ()))
-        ctx.cfg = (bool(training), bool(relu), pre is not None, post is not None, res is not None)
+        ctx.cfg = (bool(training), bool(relu), pre is not None, post is not None, res is not None, cl)
         ctx.sync = (sync_group, m) if (training and sync_group is not None) else None
         ctx.shapes = (None if pre_g is None else pre_g.shape, None if post_g is None else post_g.shape)
         return y
@@ -126,7 +135,8 @@ class _BnFilmAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = L.load()
-        training, relu, has_pre, has_post, has_res = ctx.cfg
+        training, relu, has_pre, has_post, has_res, cl = ctx.cfg
+        fmt = torch.channels_last if cl else torch.contiguous_format
         sv = list(ctx.saved_tensors)
         x, res, scale, shift, mean, invstd = sv[:6]
         rest = sv[6:]
@@ -134,14 +144,14 @@ class _BnFilmAct(torch.autograd.Function):
         post = (rest[2 if has_pre else 0], rest[3 if has_pre else 1]) if has_post else None
         N, Cc = x.shape[0], x.shape[1]
         dev = x.device
-        dy = dy.contiguous().to(x.dtype)
-        dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if has_res else None
+        dy = dy.to(x.dtype).contiguous(memory_format=fmt)
+        dx = torch.empty_like(x, memory_format=fmt)
+        dres = torch.empty_like(x, memory_format=fmt) if has_res else None
         dw = torch.empty(Cc, device=dev); db = torch.empty(Cc, device=dev)
         dpg = torch.empty(N, Cc, device=dev) if has_pre else None; dpb = torch.empty(N, Cc, device=dev) if has_pre else None
         dqg = torch.empty(N, Cc, device=dev) if has_post else None; dqb = torch.empty(N, Cc, device=dev) if has_post else None
-        ws = torch.empty(lib.mode_bn_workspace_bytes(N, Cc), dtype=torch.uint8, device=dev)
-        d = _desc(x, scale, shift, pre, res if has_res else None, relu, post, None)
+        ws = torch.empty(lib.mode_bn_workspace_bytes(N, Cc, x[0, 0].numel(), _dt(x), int(cl)), dtype=torch.uint8, device=dev)
+        d = _desc(x, scale, shift, pre, res if has_res else None, relu, post, None, cl)
         d.y = x.data_ptr()                                                     # unused by the backward; the descriptor check wants a pointer
         def call(phase, inv_count, dw_, db_):
             L.check(lib.mode_bn_film_act_bwd(C.byref(d), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), int(training), phase, float(inv_count), dx.data_ptr(),
@@ -161,6 +171,26 @@ class _BnFilmAct(torch.autograd.Function):
         rs = lambda t, shp: None if t is None else t.reshape(shp)
         # inputs: x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b
         return dx, dw, db, None, None, None, None, None, None, dres, rs(dpg, ps), rs(dpb, ps), rs(dqg, qs), rs(dqb, qs), None, None
+
+
+# Activation layout inside the encoders.  True: torch.channels_last - MIOpen's implicit-GEMM convolutions run on NHWC data and wrap NCHW tensors in
+# layout transposes (10 % of the agent's training step, scripts/step_kernel_profile.sh); the fused pass has kernels for both layouts.  The encoders'
+# inputs and outputs are ordinary tensors either way (the layout is a stride pattern, not a shape).
+CHANNELS_LAST = True
+
+
+def _to_layout(x: torch.Tensor) -> torch.Tensor:
+    return x.contiguous(memory_format=torch.channels_last) if (CHANNELS_LAST and x.dim() == 4) else x
+
+
+def _conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """conv2d through MIOpen with the module's weight in the activations' dtype and layout.  The PARAMETER's storage is converted to channels_last
+    once (values, shape and state_dict unchanged), so no per-call weight transposes are left."""
+    w = conv.weight
+    if CHANNELS_LAST and w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
+        with torch.no_grad():
+            w.data = w.data.contiguous(memory_format=torch.channels_last)
+    return F.conv2d(x, w.to(x.dtype), None, conv.stride, conv.padding)
 
 
 def bn_film_act(x, bn: nn.BatchNorm2d, relu: bool = True, residual=None, pre_film=None, post_film=None):
@@ -198,7 +228,7 @@ class _Block(nn.Module):
         self.out_channels = out
 
     def _conv(self, conv: nn.Conv2d, x):
-        return F.conv2d(x, conv.weight.to(x.dtype), None, conv.stride, conv.padding)
+        return _conv2d(conv, x)
 
     def forward(self, x, pre_film=None, post_film=None):
         """``pre_film``: FiLM on the last BatchNorm's output before the skip add (resnets.py:64-71); ``post_film``: FiLM on the block output (the
@@ -235,7 +265,7 @@ class _Trunk(nn.Module):
         self.num_features = inplanes
 
     def stem(self, x):
-        x = bn_film_act(F.conv2d(x, self.conv1.weight.to(x.dtype), None, 2, 3), self.bn1, relu=True)
+        x = bn_film_act(_conv2d(self.conv1, _to_layout(x)), self.bn1, relu=True)
         return F.max_pool2d(x, 3, 2, 1)
 
 
@@ -323,7 +353,7 @@ class ResNetEncoderWithFiLM(nn.Module):
             x = x.reshape(B * t_steps, *x.shape[2:])
             if conditioning_vector is not None:
                 conditioning_vector = torch.cat([conditioning_vector for _ in range(t_steps)], dim=0)     # the reference's order (resnets.py:129)
-        x = bn_film_act(F.conv2d(x, self.conv1.weight.to(x.dtype), None, 2, 3), self.bn1, relu=True)
+        x = bn_film_act(_conv2d(self.conv1, _to_layout(x)), self.bn1, relu=True)
         x = F.max_pool2d(x, 3, 2, 1)
         for i in range(1, 5):
             mods = getattr(self, f"film_module{i}")(conditioning_vector.to(torch.float32)) if conditioning_vector is not None else (None, None)

@@ -302,3 +302,32 @@ def test_bn_prepare_bookkeeping_matches_nn_batchnorm(momentum, dtype):
     gy = torch.randn(N_, C_, 9, 11, device="cuda")
     (torch.relu(ref(xr)) * gy).sum().backward(); (E.bn_film_act(xm, mine, relu=True) * gy).sum().backward()
     assert rel(xm.grad, xr.grad) < 1e-4 and rel(mine.weight.grad, ref.weight.grad) < 1e-4 and rel(mine.bias.grad, ref.bias.grad) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C_,H,W_,dtype", [(6, 64, 56, 56, torch.bfloat16), (5, 2048, 7, 7, torch.bfloat16), (3, 72, 9, 5, torch.bfloat16), (4, 36, 12, 12, torch.float32),
+                                              (2, 256, 28, 28, torch.float32)])
+@pytest.mark.parametrize("training", [True, False])
+def test_fused_pass_channels_last_equals_nchw(N, C_, H, W_, dtype, training):
+    """The NHWC kernels (channel vectors per thread, pixel splits, shared per-channel folds) against the NCHW kernels on the same values: forward, running
+    statistics, every gradient - with residual, pre- and post-FiLM, channel counts that are not a multiple of the 64-channel tile."""
+    torch.manual_seed(N * C_ + H)
+    mk = lambda *s: torch.randn(*s, device="cuda")
+    x = (mk(N, C_, H, W_) * 1.5 + 0.2).to(dtype); res = mk(N, C_, H, W_).to(dtype); gy = mk(N, C_, H, W_).to(dtype)
+    film = [mk(N, C_) * 0.3 for _ in range(4)]
+    outs = {}
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        bn = torch.nn.BatchNorm2d(C_).cuda().train(training)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C_)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C_))
+            bn.running_mean.copy_(torch.linspace(-0.1, 0.1, C_)); bn.running_var.copy_(torch.linspace(0.8, 1.3, C_))
+        xi = x.clone().contiguous(memory_format=fmt).requires_grad_(True); ri = res.clone().contiguous(memory_format=fmt).requires_grad_(True)
+        fl = [f.clone().requires_grad_(True) for f in film]
+        y = E.bn_film_act(xi, bn, relu=True, residual=ri, pre_film=(fl[0], fl[1]), post_film=(fl[2], fl[3]))
+        assert y.is_contiguous(memory_format=fmt)
+        y.backward(gy.contiguous(memory_format=fmt))
+        outs[fmt] = [y.detach(), xi.grad, ri.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()] + [f.grad for f in fl]
+    tol = 2e-5 if dtype == torch.float32 else 1e-2          # bf16: both round the same fp32 values except where the summation order of a reduction differs
+    for a, b in zip(outs[torch.channels_last], outs[torch.contiguous_format]):
+        assert a.shape == b.shape and rel(a, b) < tol, rel(a, b)
+    assert rel(outs[torch.channels_last][0], outs[torch.contiguous_format][0]) < (1e-6 if not training else tol)    # eval forward: same arithmetic per element
