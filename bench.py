@@ -596,11 +596,12 @@ def agent_bench(args, world, rank, device, dist):
         loss = step()
     torch.cuda.synchronize()
     assert torch.isfinite(loss.detach()).all()
-    blocks = []
+    blocks, host = [], []
     for _ in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        host.append((time.perf_counter() - t0) / args.steps * 1e3)               # the loop returned: everything is enqueued
         torch.cuda.synchronize(); blocks.append((time.perf_counter() - t0) / args.steps * 1e3)
     step(timed=True); torch.cuda.synchronize()
     enc_fwd_ms = ev[0].elapsed_time(ev[1])
@@ -612,7 +613,7 @@ def agent_bench(args, world, rank, device, dist):
            "config": {"workload": "SURVEY 8(f)-1: MoDEAgent training step - embed_visual_obs (2 x FiLMResNet50Policy, 224 x 224 RGB, latent-goal FiLM) -> "
                                   "GCDenoiser.loss (12 layers, d=1024, 4 experts top-2) -> backward through both -> AdamW", "global_batch": B,
                       "parallelism": "single GPU"},
-           "agent_ms_per_step_blocks": [round(b, 3) for b in blocks], "encoders_forward_ms": round(enc_fwd_ms, 3), "encoder_params": n_enc,
+           "agent_ms_per_step_blocks": [round(b, 3) for b in blocks], "host_enqueue_ms_per_step": round(min(host), 3), "encoders_forward_ms": round(enc_fwd_ms, 3), "encoder_params": n_enc,
            "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
     print(json.dumps(res), flush=True)
 

@@ -122,22 +122,32 @@ __global__ __launch_bounds__(256) void bn_row_sums_kernel(const T* __restrict__ 
 // Per-channel fold of per-row partials: a 1024-thread workgroup owns 64 channels, its 16 waves split the N rows (coalesced 256-byte reads of 64
 // neighbouring channels), partials meet in LDS as doubles and are added in wave order: deterministic.  (One thread per channel walking all N rows,
 // the first version, took 17 us per BatchNorm - a serial chain of N strided loads - and there are 106 BatchNorms per ResNet-50 pair.)
+// per-channel folds of [rows][C] partials: a 1024-thread workgroup owns FC = 16 channels, its 64 row lanes split the rows (a wave reads 4 rows x 64 bytes),
+// partials meet in LDS as doubles and are added in row-lane order: deterministic; C / 16 workgroups keep even a 64-channel layer on four CUs' worth of
+// memory pipes (64 channels per workgroup - the previous shape - left a 256-channel fold on 4 workgroups: 9 us per launch, 212 launches per step)
+constexpr int FC = 16, FR = 64;
+__device__ __forceinline__ bool fold_pair(double& a, double& b, double* lds) {
+  const int cl = threadIdx.x & (FC - 1), rl = threadIdx.x / FC;
+  lds[(rl * FC + cl) * 2] = a; lds[(rl * FC + cl) * 2 + 1] = b;
+  __syncthreads();
+  if (rl != 0) return false;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < FR; ++k) { s += lds[(k * FC + cl) * 2]; q += lds[(k * FC + cl) * 2 + 1]; }
+  a = s; b = q;
+  return true;
+}
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int N, int C, double count,
                                                            float* __restrict__ mean, float* __restrict__ var) {
-  __shared__ double lds[2 * 16 * 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  __shared__ double lds[2 * FC * FR];
+  const int cl = threadIdx.x & (FC - 1), rl = threadIdx.x / FC;
+  const int c = blockIdx.x * FC + cl;
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (int n = wave; n < N; n += 16) { a += (double)psum[(long)n * C + c]; b += (double)psq[(long)n * C + c]; }
-  lds[wave * 64 + lane] = a; lds[(16 + wave) * 64 + lane] = b;
-  __syncthreads();
-  if (wave != 0 || c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int w = 0; w < 16; ++w) { s += lds[w * 64 + lane]; q += lds[(16 + w) * 64 + lane]; }
-  const double m = s / count;
+    for (int n = rl; n < N; n += FR) { a += (double)psum[(long)n * C + c]; b += (double)psq[(long)n * C + c]; }
+  if (!fold_pair(a, b, lds) || c >= C) return;
+  const double m = a / count;
   mean[c] = (float)m;
-  var[c] = (float)fmax(q / count - m * m, 0.0);                          // biased variance (what normalises the batch; nn.BatchNorm2d)
+  var[c] = (float)fmax(b / count - m * m, 0.0);                          // biased variance (what normalises the batch; nn.BatchNorm2d)
 }
 
 // Everything a BatchNorm needs before the fused pass, in one launch after the row sums: batch mean / biased variance (training) or the running
@@ -148,25 +158,23 @@ __global__ __launch_bounds__(1024) void bn_prepare_kernel(const float* __restric
                                                           float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
                                                           float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd, float* __restrict__ scale,
                                                           float* __restrict__ shift) {
-  __shared__ double lds[2 * 16 * 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  __shared__ double lds[2 * FC * FR];
+  const int cl = threadIdx.x & (FC - 1), rl = threadIdx.x / FC;
+  const int c = blockIdx.x * FC + cl;
   const bool valid = c < C;
   double m, v;
   if (training) {
-    double acc[2] = {0.0, 0.0};
-    if (valid)
-      for (int n = wave; n < N; n += 16) { acc[0] += (double)psum[(long)n * C + c]; acc[1] += (double)psq[(long)n * C + c]; }
-    lds[wave * 64 + lane] = acc[0]; lds[(16 + wave) * 64 + lane] = acc[1];
-    __syncthreads();
     double s = 0.0, q = 0.0;
-    for (int w = 0; w < 16; ++w) { s += lds[w * 64 + lane]; q += lds[(16 + w) * 64 + lane]; }
+    if (valid)
+      for (int n = rl; n < N; n += FR) { s += (double)psum[(long)n * C + c]; q += (double)psq[(long)n * C + c]; }
+    if (!fold_pair(s, q, lds)) return;
     m = s / count;
     v = fmax(q / count - m * m, 0.0);                                      // biased variance (what normalises the batch; nn.BatchNorm2d)
   } else {
+    if (rl != 0) return;
     m = valid ? (double)running_mean[c] : 0.0; v = valid ? (double)running_var[c] : 1.0;
   }
-  if (wave != 0 || !valid) return;
+  if (!valid) return;
   const float mf = (float)m, vf = (float)v;
   const float is = 1.0f / sqrtf(vf + eps);
   const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(1024) void bn_prepare_kernel(const float* __restric
     running_var[c] = running_var[c] * (1.f - f) + vf * unbias * f;
   }
   // num_batches_tracked += 1: here when nobody reads it (momentum given); the cumulative-average case counts in a launch of its own, after all reads
-  if (training && nbt && momentum >= 0.f && blockIdx.x == 0 && lane == 0) *nbt += 1;
+  if (training && nbt && momentum >= 0.f && blockIdx.x == 0 && cl == 0) *nbt += 1;
 }
 __global__ void bn_count_step_kernel(long long* nbt) { *nbt += 1; }          // num_batches_tracked += 1, after every channel block read it
 
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(1024) void bn_film_bwd_fold_kernel(const float* __r
                                                                 float* __restrict__ dbias, float* __restrict__ dpg, float* __restrict__ dpb, float* __restrict__ dqg,
                                                                 float* __restrict__ dqb) {
   // sums: [NS = samples * S pixel splits][C][6]; FiLM gradients per (sample, channel) = the S splits added in order, BatchNorm affine gradients = all NS rows
-  __shared__ double lds[2 * 16 * 64];
+  __shared__ double lds[2 * FC * FR];
   const int N = NS;
   const long total = (long)(NS / S) * C;
   if (dqg || dpg)
@@ -242,19 +250,13 @@ __global__ __launch_bounds__(1024) void bn_film_bwd_fold_kernel(const float* __r
       if (dqg) { dqg[i] = t0; dqb[i] = t1; }
       if (dpg) { dpg[i] = t2; dpb[i] = t3; }
     }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  if (blockIdx.x * 64 >= C) return;                                        // (whole workgroup: no barrier is skipped by part of it)
+  const int cl = threadIdx.x & (FC - 1), rl = threadIdx.x / FC;
+  const int c = blockIdx.x * FC + cl;
+  if (blockIdx.x * FC >= C) return;                                        // (whole workgroup: no barrier is skipped by part of it)
   double b = 0.0, w = 0.0;
   if (c < C)
-    for (int n = wave; n < N; n += 16) { const float* s = sums + ((long)n * C + c) * 6; b += (double)s[4]; w += (double)s[5]; }
-  lds[wave * 64 + lane] = b; lds[(16 + wave) * 64 + lane] = w;
-  __syncthreads();
-  if (wave == 0 && c < C) {
-    double tb = 0.0, tw = 0.0;
-    for (int k = 0; k < 16; ++k) { tb += lds[k * 64 + lane]; tw += lds[(16 + k) * 64 + lane]; }
-    dbias[c] = (float)tb; dweight[c] = (float)tw;
-  }
+    for (int n = rl; n < N; n += FR) { const float* s = sums + ((long)n * C + c) * 6; b += (double)s[4]; w += (double)s[5]; }
+  if (fold_pair(b, w, lds) && c < C) { dbias[c] = (float)b; dweight[c] = (float)w; }
 }
 // pass 2: dx (training: through the batch statistics; eval: dv1 * scale) and d residual
 template <typename T, int VEC>
@@ -336,13 +338,23 @@ __global__ __launch_bounds__(256) void bn_nhwc_stats_kernel(const T* __restrict_
   float a[2 * W];
 #pragma unroll
   for (int j = 0; j < 2 * W; ++j) a[j] = 0.f;
-  if (c0 < C)
-    for (int p = p0 + pl; p < p1; p += 32) {
+  if (c0 < C) {
+    int p = p0 + pl;
+    for (; p + 32 < p1; p += 64) {                                       // two pixels in flight per thread (the loop is one memory round trip per pass)
+      float v[W], u[W];
+      ldv<T, W>(x, ((long)n * HW + p) * C + c0, v); ldv<T, W>(x, ((long)n * HW + p + 32) * C + c0, u);
+#pragma unroll
+      for (int j = 0; j < W; ++j) { a[j] += v[j]; a[W + j] = __builtin_fmaf(v[j], v[j], a[W + j]); }
+#pragma unroll
+      for (int j = 0; j < W; ++j) { a[j] += u[j]; a[W + j] = __builtin_fmaf(u[j], u[j], a[W + j]); }
+    }
+    for (; p < p1; p += 32) {
       float v[W];
       ldv<T, W>(x, ((long)n * HW + p) * C + c0, v);
 #pragma unroll
       for (int j = 0; j < W; ++j) { a[j] += v[j]; a[W + j] = __builtin_fmaf(v[j], v[j], a[W + j]); }
     }
+  }
   if (nhwc_fold<2 * W>(a, lds) && c0 < C) {
     const long o = ((long)n * S + sp) * C + c0;
 #pragma unroll
@@ -409,11 +421,22 @@ __global__ __launch_bounds__(256) void bn_film_act_bwd_sums_nhwc_kernel(const Mo
     ldc<W>(mean, c0, mu); ldc<W>(invstd, c0, is);
     const T* x = reinterpret_cast<const T*>(d.x);
     const T* res = reinterpret_cast<const T*>(d.residual);
-    for (int p = p0 + pl; p < p1; p += 32) {
+    float xn[W], gn[W], rn[W];
+    int p = p0 + pl;
+    if (p < p1) {
       const long o = ((long)n * d.HW + p) * d.C + c0;
+      ldv<T, W>(x, o, xn); ldv<T, W>(dy, o, gn);
+      if (res) ldv<T, W>(res, o, rn);
+    }
+    for (; p < p1; p += 32) {
       float xv[W], gv[W], rv[W];
-      ldv<T, W>(x, o, xv); ldv<T, W>(dy, o, gv);
-      if (res) ldv<T, W>(res, o, rv);
+#pragma unroll
+      for (int j = 0; j < W; ++j) { xv[j] = xn[j]; gv[j] = gn[j]; rv[j] = rn[j]; }
+      if (p + 32 < p1) {                                                 // the next pixel's operands are requested before this pixel's arithmetic
+        const long o = ((long)n * d.HW + p + 32) * d.C + c0;
+        ldv<T, W>(x, o, xn); ldv<T, W>(dy, o, gn);
+        if (res) ldv<T, W>(res, o, rn);
+      }
 #pragma unroll
       for (int j = 0; j < W; ++j) {
         const float gy = gv[j];
@@ -481,8 +504,8 @@ __global__ __launch_bounds__(256) void bn_film_act_bwd_dx_nhwc_kernel(const Mode
 // pixel splits of a sample: enough workgroups to fill the part (early layers have few channel tiles), chunks of >= 64 pixels
 static int nhwc_splits(int N, int C, int HW, int CT) {
   const long wg = (long)N * ((C + CT - 1) / CT);
-  long S = std::max<long>(1, 1024 / std::max<long>(wg, 1));
-  S = std::min<long>(S, std::max(1, HW / 64));
+  long S = std::max<long>(1, 768 / std::max<long>(wg, 1));
+  S = std::min<long>(S, std::max(1, HW / 128));
   return (int)std::min<long>(S, 32);
 }
 static int nhwc_ct(int dtype) { return dtype == MODE_BF16 ? 64 : 32; }
@@ -574,7 +597,7 @@ extern "C" int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, int
   float *psum, *psq;
   long NS = N;
   if (int rc = bn_partial_sums(x, dtype, N, C, HW, channels_last, (float*)workspace, (hipStream_t)stream, &psum, &psq, &NS)) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, psum, psq, (int)NS, C, (double)N * (double)HW, mean, var);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, psum, psq, (int)NS, C, (double)N * (double)HW, mean, var);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
@@ -593,7 +616,7 @@ extern "C" int mode_bn_prepare(const void* x, int dtype, int N, int C, int HW, i
     if (!workspace || workspace_bytes < mode_bn_workspace_bytes(N, C, HW, dtype, channels_last)) return MODE_ERR_WORKSPACE;
     if (int rc = bn_partial_sums(x, dtype, N, C, HW, channels_last, (float*)workspace, s, &psum, &psq, &NS)) return rc;
   }
-  hipLaunchKernelGGL(bn_prepare_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, psum, psq, (int)NS, C, (double)N * (double)HW, training, weight, bias, eps, momentum,
+  hipLaunchKernelGGL(bn_prepare_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, psum, psq, (int)NS, C, (double)N * (double)HW, training, weight, bias, eps, momentum,
                      running_mean, running_var, (long long*)num_batches_tracked, mean, var, invstd, scale, shift);
   MODE_LAUNCH_CHECK();
   if (training && num_batches_tracked && momentum < 0.f) {
@@ -632,7 +655,7 @@ extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, con
 #undef K_BS
     }
     MODE_LAUNCH_CHECK();
-    const long cblocks = (d->C + 63) / 64, eblocks = (d_pre_gamma || d_post_gamma) ? std::min<long>((rows + 1023) / 1024, 256) : 0;
+    const long cblocks = (d->C + 15) / 16, eblocks = (d_pre_gamma || d_post_gamma) ? std::min<long>((rows + 1023) / 1024, 256) : 0;
     hipLaunchKernelGGL(bn_film_bwd_fold_kernel, dim3((unsigned)std::max(cblocks, eblocks)), dim3(1024), 0, s, sums, d->N * S, S, d->C, dweight, dbias, d_pre_gamma,
                        d_pre_beta, d_post_gamma, d_post_beta);
     MODE_LAUNCH_CHECK();
