@@ -7,6 +7,7 @@ if [ -z "$PMC_ONLY" ]; then
 cd $R && python bench.py > $O/bench_sample.json 2> $O/bench_sample.err
 python bench.py --mode train > $O/bench_train.json 2>> $O/bench_sample.err
 python bench.py --mode rollout > $O/bench_rollout.json 2>> $O/bench_sample.err
+python bench.py --mode agent --steps 5 --warmup 2 > $O/bench_agent.json 2>> $O/bench_sample.err
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sample -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o p -- python $R/bench.py --mode train --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
