@@ -183,6 +183,17 @@ def _to_layout(x: torch.Tensor) -> torch.Tensor:
     return x.contiguous(memory_format=torch.channels_last) if (CHANNELS_LAST and x.dim() == 4) else x
 
 
+def _store_channels_last(module: nn.Module) -> None:
+    """Convolution weights of ``module`` into channels_last STORAGE (same values, shapes and state_dict).  Done at construction, i.e. before anything
+    (torch DDP's bucket views, an optimizer's state) has looked at the parameters' strides."""
+    if not CHANNELS_LAST:
+        return
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, nn.Conv2d) and not m.weight.is_contiguous(memory_format=torch.channels_last):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+
+
 def _conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     """conv2d through MIOpen with the module's weight in the activations' dtype and layout.  The PARAMETER's storage is converted to channels_last
     once (values, shape and state_dict unchanged), so no per-call weight transposes are left."""
@@ -263,6 +274,7 @@ class _Trunk(nn.Module):
                 inplanes = blocks[-1].out_channels
             setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
         self.num_features = inplanes
+        _store_channels_last(self)
 
     def stem(self, x):
         x = bn_film_act(_conv2d(self.conv1, _to_layout(x)), self.bn1, relu=True)
