@@ -192,10 +192,13 @@ class DitEngine:
                                               _stream()), "sigma_embed")
         return emb
 
-    def embed_obs(self, state_images: torch.Tensor, goals: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def embed_obs(self, state_images: torch.Tensor, goals: torch.Tensor, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
         B = state_images.shape[0]
-        img_e = torch.empty(B * self.dims.n_img, self.dims.D, dtype=torch.float32, device=self.device)
-        goal_e = torch.empty(B, self.dims.D, dtype=torch.float32, device=self.device)
+        if out is not None:
+            img_e, goal_e = out
+        else:
+            img_e = torch.empty(B * self.dims.n_img, self.dims.D, dtype=torch.float32, device=self.device)
+            goal_e = torch.empty(B, self.dims.D, dtype=torch.float32, device=self.device)
         L.check(self.lib.mode_dit_embed_obs(C.byref(self.dims), C.byref(self._mw), state_images.data_ptr(), goals.data_ptr(), B,
                                             img_e.data_ptr(), goal_e.data_ptr(), _stream()), "embed_obs")
         return img_e, goal_e

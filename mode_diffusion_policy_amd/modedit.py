@@ -286,15 +286,17 @@ class MoDeDiT(nn.Module):
         return img, goals.reshape(img.shape[0], -1).contiguous()
 
     @torch.no_grad()
-    def denoise(self, states, action, goals, sigma, sigma_data: float, _account: bool = True):
-        """GCDenoiser.forward (score_wrappers.py:65-80) with c_in / c_out / c_skip fused into the HIP chain."""
+    def denoise(self, states, action, goals, sigma, sigma_data: float, _account: bool = True, _obs_emb=None):
+        """GCDenoiser.forward (score_wrappers.py:65-80) with c_in / c_out / c_skip fused into the HIP chain.  ``_obs_emb``: (img_e, goal_e) already
+        computed for these observations (denoise_graphed keeps them across the calls of one sampler run)."""
         eng = self.engine
         dev, B, T, D = eng.device, action.shape[0], self.seq_len, self.embed_dim
         if B == 0:
             return action.detach().to(device=dev, dtype=torch.float32).clone()
-        img, goals = self._prep_obs(eng, states, goals)
         x = action.detach().to(device=dev, dtype=torch.float32).contiguous()
-        self._check_batch(B, img, goals, x)
+        if _obs_emb is None:
+            img, goals = self._prep_obs(eng, states, goals)
+            self._check_batch(B, img, goals, x)
         sig = sigma.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
         if sig.numel() not in (1, B):
             raise ValueError("sigma must be a scalar or have one entry per sample")
@@ -303,7 +305,7 @@ class MoDeDiT(nn.Module):
         c_in = (1.0 / s2.sqrt()).contiguous()
         scal = torch.stack([sigma_data ** 2 / s2, sig * sigma_data / s2.sqrt(), torch.zeros_like(sig), torch.zeros_like(sig)], 1).contiguous()
         emb_t = eng.sigma_embed(sig)
-        img_e, goal_e = eng.embed_obs(img, goals)
+        img_e, goal_e = _obs_emb if _obs_emb is not None else eng.embed_obs(img, goals)
         cond = emb_t
         if self.use_goal_in_routing:
             cond = (emb_t.expand(B, D) + goal_e).contiguous()
@@ -340,24 +342,35 @@ class MoDeDiT(nn.Module):
         dev, B = eng.device, action.shape[0]
         if B == 0 or os.environ.get("MODE_HIP_GRAPH", "1") == "0":
             return None
-        img, gl = self._prep_obs(eng, states, goals)
         x = action.detach().to(device=dev, dtype=torch.float32).contiguous()
-        self._check_batch(B, img, gl, x)
         sig = torch.as_tensor(sigma, dtype=torch.float32).detach().reshape(-1)[:1]
         key = (B, eng.compute_dtype, eng._structs_for, str(dev), float(sigma_data))
         cache = self._route_cache.setdefault("denoise_graphs", {})
         ent = cache.get(key)
+        # The observations are the same tensors for every denoiser call of a sampler run (gc_sampling.py's loops pass `state` / `goal` through
+        # unchanged): their embeddings - two fp32 GEMMs, 6 % of a call at B = 128 - are computed once per (tensor objects, in-place version, weights)
+        # and kept beside the graph.  The cache holds references to the tensors it was computed from, so an address cannot be recycled under it.
+        src = (states["state_images"], goals)
+        okey = (src[0]._version, src[1]._version, eng._wkey)
+        fresh = ent is None or ent.get("obs_ref") is None or ent["obs_ref"][0] is not src[0] or ent["obs_ref"][1] is not src[1] or ent["obs_key"] != okey
+        if fresh:
+            img, gl = self._prep_obs(eng, states, goals)
+            self._check_batch(B, img, gl, x)
+        elif x.shape != ent["x"].shape:
+            raise ValueError(f"action must be {tuple(ent['x'].shape)}, got {tuple(x.shape)}")
         if ent is None:
             if len(cache) >= 8:                                          # a handful of batch sizes is the use case; do not hoard graphs
                 cache.pop(next(iter(cache)))
-            ent = dict(img=img.clone(), goals=gl.clone(), x=x.clone(), sig=torch.empty(1, device=dev))
+            ent = dict(img=img.clone(), goals=gl.clone(), x=x.clone(), sig=torch.empty(1, device=dev),
+                       img_e=torch.empty(B * self.n_img_tokens, self.embed_dim, device=dev), goal_e=torch.empty(B, self.embed_dim, device=dev))
             ent["sig"].copy_(sig)
             ent["ws"] = torch.empty(max(eng.workspace_bytes(B, 0), eng.workspace_bytes(0, 1)), dtype=torch.uint8, device=dev)
-            run = lambda: self.denoise({"state_images": ent["img"]}, ent["x"], ent["goals"], ent["sig"], sigma_data, _account=False)
+            run = lambda: self.denoise(None, ent["x"], None, ent["sig"], sigma_data, _account=False, _obs_emb=(ent["img_e"], ent["goal_e"]))
             with eng.pinned_workspace(ent["ws"]):
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):                            # warm-up outside the capture: loads code objects
+                    eng.embed_obs(ent["img"], ent["goals"], out=(ent["img_e"], ent["goal_e"]))
                     run()
                 torch.cuda.current_stream(dev).wait_stream(side)
                 g = torch.cuda.CUDAGraph()
@@ -366,7 +379,13 @@ class MoDeDiT(nn.Module):
                     ent["meta"] = self._last_meta
             ent["graph"] = g
             cache[key] = ent
-        ent["img"].copy_(img); ent["goals"].copy_(gl); ent["x"].copy_(x); ent["sig"].copy_(sig, non_blocking=True)
+        if fresh:
+            ent["img"].copy_(img); ent["goals"].copy_(gl)
+            eng.embed_obs(ent["img"], ent["goals"], out=(ent["img_e"], ent["goal_e"]))
+            # (a Bernoulli goal mask - training mode with goal_drop > 0 - must be redrawn per call: no reuse then)
+            keep = not (self.training and getattr(self, "goal_drop", 0.0) > 0)
+            ent["obs_ref"], ent["obs_key"] = (src if keep else None), okey
+        ent["x"].copy_(x); ent["sig"].copy_(sig, non_blocking=True)
         ent["graph"].replay()
         self._account_usage(ent["meta"], eng.meta_layout(B * self.seq_len), B * self.seq_len)
         return ent["out"].clone()

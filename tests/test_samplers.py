@@ -167,3 +167,38 @@ def test_samplers_on_hip_denoiser(golden, dtype, tol):
         if key.startswith("dpm_fast_n4"):
             continue                                  # 2 coarse steps from sigma = 80: |x| ~ 75-94, an ill-conditioned solve, CPU-checked only
         assert rel(x, g2[key]) < tol, (key, rel(x, g2[key]))
+
+
+@pytest.mark.gpu
+def test_graphed_denoise_observation_cache_is_never_stale():
+    """``denoise_graphed`` keeps the observation embeddings of one sampler run beside its graph.  Whatever changes between two calls - the tensors'
+    contents in place, new tensor objects (also ones the allocator puts at a recycled address), the weights - the next call must see it: every call is
+    compared with the eager chain on the same inputs."""
+    from test_gpu_model import build
+    cfg, sd, m = build("c1e4", 210, "fp32")
+    den = M.GCDenoiser(m, 0.5).eval()
+    B = 5
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, B, 3).items()}
+    state = {"state_images": inp["state_images"].clone()}
+    goal = inp["goals"].clone()
+    x = inp["actions"].clone()
+    sig = torch.tensor(1.7, device="cuda")
+
+    def check(tag):
+        with torch.no_grad():
+            fast = den.denoise_uniform(state, x, goal, sig)
+            ref = den(state, x, goal, sig * torch.ones(B, device="cuda"))
+        assert fast is not None
+        r = float((fast - ref).norm() / ref.norm())
+        assert r < 1e-5, (tag, r)
+    check("first"); check("same tensors: cached")
+    state["state_images"].mul_(1.5); check("state changed in place")
+    goal.add_(0.3); check("goal changed in place")
+    for i in range(4):                                                        # fresh objects every call (what a rollout loop does); old ones die -> addresses recycle
+        state = {"state_images": torch.randn_like(inp["state_images"]) * (1 + i)}
+        goal = torch.randn_like(inp["goals"])
+        check(f"new tensors {i}")
+    with torch.no_grad():
+        m.tok_emb.weight.mul_(1.1); m.goal_emb.weight.add_(0.01)
+    check("weights changed in place")
+    sig = torch.tensor(0.2, device="cuda"); check("another sigma, same observations")
