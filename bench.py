@@ -698,6 +698,33 @@ def main():
     denoise_steps = n_gpus * args.steps * N_SAMPLING_STEPS
     value = denoise_steps / elapsed
     if rollout:
+        agent_extra = {}
+        if rank == 0 and not args.no_extras:
+            # the rollout as the AGENT runs it (mode_agent.py:584-637): raw 224 x 224 frames of two cameras -> two FiLM-ResNet-50s (eval, autocast bf16) ->
+            # 10-step DDIM chunk; replanning call latency with the encoders captured in a hipGraph (GraphedVisualEncoder) and eager
+            from mode_diffusion_policy_amd import rollout as RO
+            from mode_diffusion_policy_amd.perceptual_encoders import FiLMResNet50Policy, embed_visual_obs
+            enc_s, enc_g = FiLMResNet50Policy(512).to(device).eval(), FiLMResNet50Policy(512).to(device).eval()
+            for key, nb in (("agent_b1", 1), ("agent_b32", 32)):
+                gen = torch.Generator().manual_seed(3)
+                frames = {"rgb_obs": {"rgb_static": torch.randn(nb, 1, 3, 224, 224, generator=gen).to(device),
+                                      "rgb_gripper": torch.randn(nb, 1, 3, 224, 224, generator=gen).to(device)}}
+                lg = torch.randn(nb, 512, generator=gen).to(device)
+                pol = RO.ChunkedRolloutPolicy(den, multistep=1, static_resnet=enc_s, gripper_resnet=enc_g)
+                plain = RO.ChunkedRolloutPolicy(den, multistep=1)
+
+                def eager_call():
+                    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                        tok = embed_visual_obs(enc_s, enc_g, frames["rgb_obs"]["rgb_static"], frames["rgb_obs"]["rgb_gripper"], lg)
+                    return plain.step({"state_images": tok["state_images"].float()}, lg)
+                for name, fn in (("graphed", lambda: pol.step(frames, lg)), ("eager", eager_call)):
+                    for _ in range(3):
+                        fn()
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    for _ in range(20):
+                        fn()
+                    torch.cuda.synchronize()
+                    agent_extra[f"{key}_replan_ms_{name}_encoders"] = round((time.perf_counter() - t1) / 20 * 1e3, 3)
         if rank == 0:
             print(json.dumps({
                 "metric": "action-chunks/sec (B=32 envs, 10-step DDIM per chunk)", "value": round(n_gpus * args.steps * batch / elapsed, 1),
@@ -708,7 +735,7 @@ def main():
                                        "sampler, routing pre-cached per noise level, full MoDE denoiser", "global_batch": batch * n_gpus,
                            "parallelism": f"replicas x{n_gpus} (no data-path collective)"},
                 "latency_ms_per_chunk_call": round(elapsed / args.steps * 1e3, 3),
-                "e2e_tflops_per_gpu": round(flops_per_denoise_step(batch) * args.steps * N_SAMPLING_STEPS / elapsed / 1e12, 1)}), flush=True)
+                "e2e_tflops_per_gpu": round(flops_per_denoise_step(batch) * args.steps * N_SAMPLING_STEPS / elapsed / 1e12, 1), **agent_extra}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()

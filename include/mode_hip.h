@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MODE_HIP_ABI_VERSION 7
+#define MODE_HIP_ABI_VERSION 8
 
 typedef enum ModeStatus {
   MODE_OK = 0,
@@ -598,6 +598,9 @@ typedef struct ModeBnFilmDesc {
   int32_t relu;
   const float* post_gamma; const float* post_beta; /* [N, C] or both NULL                                              */
   void* y;                                         /* [N, C, HW] (unused by the backward)                              */
+  /* ABI 8.  Forward only, when scale == shift == NULL: the eval-mode BatchNorm is folded inside the pass - scale = bn_weight / sqrt(bn_var + bn_eps),
+   * shift = bn_bias - bn_mean * scale ([C] fp32 each; bn_weight / bn_bias may be NULL = 1 / 0): one launch per BatchNorm in the rollout. */
+  const float* bn_weight; const float* bn_bias; const float* bn_mean; const float* bn_var; float bn_eps;
   int32_t channels_last;                           /* 0: x / residual / y (dy, dx) are [N][C][HW] (NCHW); 1: [N][HW][C] (torch.channels_last: what MIOpen's
                                                       implicit-GEMM convolutions read and write without layout transposes); needs C % 8 == 0 (bf16) / 4 (fp32) */
 } ModeBnFilmDesc;

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MODE_HIP_LIB", os.path.join(_HERE, "libmode_hip.so"))
 
 MODE_BF16, MODE_F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_RESIDUAL_NORM = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 7
+ABI_VERSION = 8
 GEMM_SKINNY_OK, GEMM_W_KN, GEMM_A_KM, GEMM_UNIFORM_GROUPS, GEMM_SMALL_ROWS, GEMM_IDENTITY_ROWS = 1, 2, 4, 8, 16, 32
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -119,7 +119,8 @@ class ModeForwardArgs(C.Structure):
 
 class ModeBnFilmDesc(C.Structure):
     _fields_ = [("N", c_i32), ("C", c_i32), ("HW", c_i32), ("dtype", c_i32), ("x", c_vp), ("scale", c_vp), ("shift", c_vp), ("pre_gamma", c_vp),
-                ("pre_beta", c_vp), ("residual", c_vp), ("relu", c_i32), ("post_gamma", c_vp), ("post_beta", c_vp), ("y", c_vp), ("channels_last", c_i32)]
+                ("pre_beta", c_vp), ("residual", c_vp), ("relu", c_i32), ("post_gamma", c_vp), ("post_beta", c_vp), ("y", c_vp),
+                ("bn_weight", c_vp), ("bn_bias", c_vp), ("bn_mean", c_vp), ("bn_var", c_vp), ("bn_eps", c_f32), ("channels_last", c_i32)]
 
 
 P = C.POINTER

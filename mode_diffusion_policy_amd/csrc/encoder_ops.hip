@@ -66,7 +66,12 @@ struct RowParams {            // per (n, c) constants of the fused chain
 };
 __device__ __forceinline__ RowParams row_params(const ModeBnFilmDesc& d, int n, int c) {
   RowParams r;
-  r.scale = d.scale[c]; r.shift = d.shift[c];
+  if (d.scale) { r.scale = d.scale[c]; r.shift = d.shift[c]; }
+  else {                                                        // eval-mode BatchNorm folded here: no separate launch for scale / shift
+    const float is = 1.0f / sqrtf(d.bn_var[c] + d.bn_eps);
+    r.scale = (d.bn_weight ? d.bn_weight[c] : 1.f) * is;
+    r.shift = (d.bn_bias ? d.bn_bias[c] : 0.f) - d.bn_mean[c] * r.scale;
+  }
   r.pre = d.pre_gamma != nullptr; r.post = d.post_gamma != nullptr;
   const long nc = (long)n * d.C + c;
   r.pg = r.pre ? d.pre_gamma[nc] : 1.f; r.pb = r.pre ? d.pre_beta[nc] : 0.f;
@@ -366,7 +371,19 @@ template <int W>
 struct ChanParams { float sc[W], sh[W], pg[W], pb[W], qg[W], qb[W]; bool pre, post; };
 template <int W>
 __device__ __forceinline__ void chan_params(const ModeBnFilmDesc& d, int n, int c0, ChanParams<W>& r) {
-  ldc<W>(d.scale, c0, r.sc); ldc<W>(d.shift, c0, r.sh);
+  if (d.scale) { ldc<W>(d.scale, c0, r.sc); ldc<W>(d.shift, c0, r.sh); }
+  else {                                                        // eval-mode BatchNorm folded here (same expressions as bn_prepare_kernel)
+    float mu[W], va[W];
+    ldc<W>(d.bn_mean, c0, mu); ldc<W>(d.bn_var, c0, va);
+#pragma unroll
+    for (int j = 0; j < W; ++j) { r.sc[j] = 1.0f / sqrtf(va[j] + d.bn_eps); r.sh[j] = 0.f; }
+    if (d.bn_weight) { float w[W]; ldc<W>(d.bn_weight, c0, w);
+#pragma unroll
+      for (int j = 0; j < W; ++j) r.sc[j] *= w[j]; }
+    if (d.bn_bias) ldc<W>(d.bn_bias, c0, r.sh);
+#pragma unroll
+    for (int j = 0; j < W; ++j) r.sh[j] -= mu[j] * r.sc[j];
+  }
   r.pre = d.pre_gamma != nullptr; r.post = d.post_gamma != nullptr;
   const long nc = (long)n * d.C + c0;
   if (r.pre) { ldc<W>(d.pre_gamma, nc, r.pg); ldc<W>(d.pre_beta, nc, r.pb); }
@@ -531,7 +548,9 @@ static int bn_vec(int dtype, int HW, const void* a, const void* b, const void* c
   } while (0)
 
 static bool bn_desc_ok(const ModeBnFilmDesc* d) {
-  if (!d || !d->x || !d->scale || !d->shift || !d->y || d->N < 0 || d->C <= 0 || d->HW <= 0) return false;
+  if (!d || !d->x || !d->y || d->N < 0 || d->C <= 0 || d->HW <= 0) return false;
+  if ((d->scale == nullptr) != (d->shift == nullptr)) return false;
+  if (!d->scale && (!d->bn_mean || !d->bn_var)) return false;                      // either folded scale / shift, or the raw eval-mode BatchNorm
   if ((d->pre_gamma == nullptr) != (d->pre_beta == nullptr) || (d->post_gamma == nullptr) != (d->post_beta == nullptr)) return false;
   return d->dtype == MODE_F32 || d->dtype == MODE_BF16;
 }
@@ -543,7 +562,7 @@ extern "C" int mode_bn_film_act_fwd(const ModeBnFilmDesc* d, void* stream) {
   const long rows = (long)d->N * d->C;
   if (rows == 0) return MODE_OK;
   if (d->channels_last) {
-    if (!nhwc_ok(d->dtype, d->C, d->x, d->residual, d->y, d->scale, d->shift)) return MODE_ERR_UNSUPPORTED;
+    if (!nhwc_ok(d->dtype, d->C, d->x, d->residual, d->y, d->scale ? d->scale : d->bn_mean, d->scale ? d->shift : d->bn_var)) return MODE_ERR_UNSUPPORTED;
     const int CT = nhwc_ct(d->dtype), S = nhwc_splits(d->N, d->C, d->HW, CT);
     const dim3 g((d->C + CT - 1) / CT, d->N, S);
     if (d->dtype == MODE_BF16) hipLaunchKernelGGL(bn_film_act_fwd_nhwc_kernel<uint16_t>, g, dim3(256), 0, (hipStream_t)stream, *d, S);
@@ -629,7 +648,7 @@ extern "C" int mode_bn_prepare(const void* x, int dtype, int N, int C, int HW, i
 extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, const float* mean, const float* invstd, int training, int phase, float inv_count,
                                     void* dx, void* dresidual, float* dweight, float* dbias, float* d_pre_gamma, float* d_pre_beta, float* d_post_gamma,
                                     float* d_post_beta, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!bn_desc_ok(d) || !dy || !mean || !invstd || !dx || !dweight || !dbias || !workspace) return MODE_ERR_BAD_ARG;
+  if (!bn_desc_ok(d) || !d->scale || !dy || !mean || !invstd || !dx || !dweight || !dbias || !workspace) return MODE_ERR_BAD_ARG;
   if ((d->pre_gamma != nullptr) != (d_pre_gamma != nullptr && d_pre_beta != nullptr)) return MODE_ERR_BAD_ARG;
   if ((d->post_gamma != nullptr) != (d_post_gamma != nullptr && d_post_beta != nullptr)) return MODE_ERR_BAD_ARG;
   if ((d->residual != nullptr) != (dresidual != nullptr)) return MODE_ERR_BAD_ARG;

@@ -49,11 +49,15 @@ def _is_cl(x: torch.Tensor) -> bool:
     return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
 
 
-def _desc(x, scale, shift, pre, res, relu, post, y, cl=False) -> L.ModeBnFilmDesc:
+def _desc(x, scale, shift, pre, res, relu, post, y, cl=False, raw_bn=None) -> L.ModeBnFilmDesc:
+    """``raw_bn`` = (weight, bias, running_mean, running_var, eps) instead of scale / shift: the eval-mode BatchNorm is folded inside the pass."""
     N, Cc = x.shape[0], x.shape[1]
-    return L.ModeBnFilmDesc(N=N, C=Cc, HW=x[0, 0].numel(), dtype=_dt(x), x=_ptr(x), scale=_ptr(scale), shift=_ptr(shift),
-                            pre_gamma=_ptr(pre[0]) if pre else None, pre_beta=_ptr(pre[1]) if pre else None, residual=_ptr(res), relu=int(relu),
-                            post_gamma=_ptr(post[0]) if post else None, post_beta=_ptr(post[1]) if post else None, y=_ptr(y), channels_last=int(cl))
+    d = L.ModeBnFilmDesc(N=N, C=Cc, HW=x[0, 0].numel(), dtype=_dt(x), x=_ptr(x), scale=_ptr(scale), shift=_ptr(shift),
+                         pre_gamma=_ptr(pre[0]) if pre else None, pre_beta=_ptr(pre[1]) if pre else None, residual=_ptr(res), relu=int(relu),
+                         post_gamma=_ptr(post[0]) if post else None, post_beta=_ptr(post[1]) if post else None, y=_ptr(y), channels_last=int(cl))
+    if raw_bn is not None:
+        d.bn_weight, d.bn_bias, d.bn_mean, d.bn_var, d.bn_eps = _ptr(raw_bn[0]), _ptr(raw_bn[1]), _ptr(raw_bn[2]), _ptr(raw_bn[3]), float(raw_bn[4])
+    return d
 
 
 class _BnFilmAct(torch.autograd.Function):
@@ -77,6 +81,18 @@ class _BnFilmAct(torch.autograd.Function):
         w, b = f32(weight), f32(bias)
         m = N * HW
         fp32_buf = lambda t: t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == dev)
+        if (not training and not any(ctx.needs_input_grad) and running_mean is not None and fp32_buf(running_mean) and fp32_buf(running_var)
+                and Cc % 4 == 0):
+            # inference (the rollout): the eval-mode BatchNorm is folded INSIDE the pass from the module's own buffers - one launch per BatchNorm
+            pre = (f32(pre_g).reshape(N, Cc), f32(pre_b).reshape(N, Cc)) if pre_g is not None else None
+            post = (f32(post_g).reshape(N, Cc), f32(post_b).reshape(N, Cc)) if post_g is not None else None
+            res = None if residual is None else residual.contiguous(memory_format=fmt)
+            if res is not None and (res.shape != x.shape or res.dtype != x.dtype):
+                raise ValueError("residual must match the activation's shape and dtype")
+            y = torch.empty_like(x, memory_format=fmt)
+            L.check(lib.mode_bn_film_act_fwd(C.byref(_desc(x, None, None, pre, res, relu, post, y, cl, raw_bn=(w, b, running_mean, running_var, eps))),
+                                             _stream()), "bn_film_act_fwd")
+            return y
         if sync_group is None and fp32_buf(running_mean) and fp32_buf(running_var) and (training or running_mean is not None):
             # one call: (row sums +) per-channel statistics, invstd, folded scale / shift, and nn.BatchNorm2d's bookkeeping in place (running
             # statistics with the unbiased variance, num_batches_tracked) - a dozen torch launches per BatchNorm otherwise, 106 BatchNorms per
@@ -194,6 +210,15 @@ def _store_channels_last(module: nn.Module) -> None:
                 m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
 
 
+# {id(conv): weight already in the compute dtype}: set by GraphedVisualEncoder around its warm-up and capture, so that the per-call weight casts of
+# autocast (one launch per convolution) are not part of the replayed graph; it refreshes the copies in place when a weight's version moves.
+_W_OVERRIDE: Optional[dict] = None
+
+
+def _compute_dtype(x: torch.Tensor) -> torch.dtype:
+    return torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+
+
 def _conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     """conv2d through MIOpen with the module's weight in the activations' dtype and layout.  The PARAMETER's storage is converted to channels_last
     once (values, shape and state_dict unchanged), so no per-call weight transposes are left."""
@@ -201,6 +226,10 @@ def _conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     if CHANNELS_LAST and w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
         with torch.no_grad():
             w.data = w.data.contiguous(memory_format=torch.channels_last)
+    if _W_OVERRIDE is not None:
+        hit = _W_OVERRIDE.get(id(conv))
+        if hit is not None and hit.dtype == _compute_dtype(x):
+            return F.conv2d(x.to(hit.dtype), hit, None, conv.stride, conv.padding)
     return F.conv2d(x, w.to(x.dtype), None, conv.stride, conv.padding)
 
 
@@ -387,3 +416,98 @@ def embed_visual_obs(static_resnet, gripper_resnet, rgb_static, rgb_gripper, lat
     else:
         st, gt = static_resnet(s), gripper_resnet(g)
     return {"state_images": torch.cat([st.reshape(B, T, -1), gt.reshape(B, T, -1)], dim=1)}
+
+
+class GraphedVisualEncoder:
+    """``embed_visual_obs`` for the rollout as ONE hipGraph replay per call.
+
+    In the rollout the two encoders run in eval mode on a handful of frames (the reference agent: one environment, B = 1, mode_agent.py:584-637):
+    ~640 launches of microseconds each - 10.2 ms of host time at B = 1 for two FiLM-ResNet-50s, more than twice the 10-step denoising chunk they
+    feed.  The launch sequence does not depend on the data, so it is captured once per (batch, image shapes, dtype) and replayed: 2.8 ms at B = 1
+    (scripts/encoder_eval_latency.py).  The graph reads parameters and BatchNorm buffers where they live: in-place updates (``load_state_dict``,
+    an EMA swap) are seen by the next replay; re-allocated parameters (``.to()``, ``.half()``) or a switch to training mode re-capture.
+
+    ``autocast_dtype``: run under ``torch.autocast`` like the reference's trainer / evaluation precision (None = the tensors' own dtype)."""
+
+    def __init__(self, static_resnet: nn.Module, gripper_resnet: nn.Module, autocast_dtype: Optional[torch.dtype] = torch.bfloat16, max_graphs: int = 4):
+        self.static_resnet, self.gripper_resnet = static_resnet, gripper_resnet
+        self.autocast_dtype, self.max_graphs = autocast_dtype, max_graphs
+        self._graphs = {}
+        self._fork = None
+
+    def _eager(self, rgb_static, rgb_gripper, latent_goal):
+        """embed_visual_obs with the two cameras on two streams (fork / join): at rollout batch sizes every kernel is a few microseconds of a
+        dependent chain, and the two encoders do not depend on each other - captured, they become two parallel branches of the graph."""
+        import contextlib
+        ac = (lambda: torch.autocast("cuda", dtype=self.autocast_dtype)) if self.autocast_dtype is not None else contextlib.nullcontext
+        B, T = rgb_static.shape[0], rgb_static.shape[1]
+        s = rgb_static.reshape(B * T, *rgb_static.shape[2:]); g = rgb_gripper.reshape(B * T, *rgb_gripper.shape[2:])
+        cur = torch.cuda.current_stream(rgb_static.device)
+        if self._fork is None or self._fork.device != rgb_static.device:
+            self._fork = torch.cuda.Stream(device=rgb_static.device)
+        self._fork.wait_stream(cur)
+        with torch.cuda.stream(self._fork), ac():
+            gt = self.gripper_resnet(g, latent_goal) if latent_goal is not None else self.gripper_resnet(g)
+        with ac():
+            st = self.static_resnet(s, latent_goal) if latent_goal is not None else self.static_resnet(s)
+        cur.wait_stream(self._fork)
+        return torch.cat([st.reshape(B, T, -1), gt.reshape(B, T, -1)], dim=1)
+
+    def _weights(self, dtype: torch.dtype) -> dict:
+        """Convolution weights of both encoders in the compute dtype, refreshed IN PLACE when a Parameter's version (or storage) changed - the graph
+        reads these copies, so an in-place weight update is seen by the next replay."""
+        cache = self.__dict__.setdefault("_wcache", {})
+        out = {}
+        for enc in (self.static_resnet, self.gripper_resnet):
+            for m in enc.modules():
+                if isinstance(m, nn.Conv2d):
+                    w = m.weight
+                    ent = cache.get(id(m))
+                    if ent is None or ent[2].dtype != dtype or ent[2].device != w.device:
+                        ent = cache[id(m)] = [None, None, torch.empty_like(w, dtype=dtype)]
+                    if ent[0] != w._version or ent[1] != w.data_ptr():
+                        ent[2].copy_(w)
+                        ent[0], ent[1] = w._version, w.data_ptr()
+                    out[id(m)] = ent[2]
+        return out
+
+    def _param_key(self):
+        return tuple(p.data_ptr() for m in (self.static_resnet, self.gripper_resnet) for p in list(m.parameters())[:2] + list(m.parameters())[-2:])
+
+    @torch.no_grad()
+    def __call__(self, rgb_static: torch.Tensor, rgb_gripper: torch.Tensor, latent_goal: Optional[torch.Tensor] = None):
+        import os
+        from .engine import capture_graph
+        if self.static_resnet.training or self.gripper_resnet.training or rgb_static.device.type != "cuda" or os.environ.get("MODE_HIP_GRAPH", "1") == "0":
+            return {"state_images": self._eager(rgb_static, rgb_gripper, latent_goal)}       # batch statistics / no device: nothing to replay
+        wdt = self.autocast_dtype if self.autocast_dtype is not None else rgb_static.dtype
+        key = (tuple(rgb_static.shape), rgb_static.dtype, tuple(rgb_gripper.shape), rgb_gripper.dtype,
+               None if latent_goal is None else (tuple(latent_goal.shape), latent_goal.dtype), str(rgb_static.device), self._param_key())
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = dict(s=rgb_static.clone(), g=rgb_gripper.clone(), c=None if latent_goal is None else latent_goal.clone())
+            dev = rgb_static.device
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            global _W_OVERRIDE
+            saved, _W_OVERRIDE = _W_OVERRIDE, self._weights(wdt)
+            try:
+                with torch.cuda.stream(side):                                    # outside the capture: MIOpen's algorithm search, code-object loads
+                    for _ in range(2):
+                        self._eager(ent["s"], ent["g"], ent["c"])
+                torch.cuda.current_stream(dev).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with capture_graph(graph):
+                    ent["out"] = self._eager(ent["s"], ent["g"], ent["c"])
+            finally:
+                _W_OVERRIDE = saved
+            ent["graph"] = graph
+            self._graphs[key] = ent
+        self._weights(wdt)                                                       # weights whose version moved since the last call: re-cast in place
+        ent["s"].copy_(rgb_static); ent["g"].copy_(rgb_gripper)
+        if latent_goal is not None:
+            ent["c"].copy_(latent_goal)
+        ent["graph"].replay()
+        return {"state_images": ent["out"].clone()}

@@ -71,13 +71,24 @@ class ChunkedRolloutPolicy:
     ``step(perceptual_emb, latent_goal)``: ``perceptual_emb = {'state_images': (B, 2, obs_dim)}`` (the encoders' output), ``latent_goal``
     (B, G) or (B, 1, G); returns the actions of this control step, (B, action_dim).  With the default DDIM sampler a replanning call is one
     hipGraph replay; the routing decisions of every noise level are resolved once (``precompute_experts_for_inference``) like the agent does
-    on its first inference call."""
+    on its first inference call.
+
+    With ``static_resnet`` / ``gripper_resnet`` (the agent's perceptual encoders, mode_agent.py:132-160) ``step`` also takes the environment's
+    observation as the agent does - ``{'rgb_obs': {'rgb_static': (B, T, 3, H, W), 'rgb_gripper': ...}}`` - and embeds it on replanning steps
+    (``MoDEAgent.forward``, mode_agent.py:598-603) through ``GraphedVisualEncoder``: one more hipGraph replay instead of ~640 eager launches."""
 
     def __init__(self, denoiser, num_sampling_steps: int = 10, sigma_min: float = 0.001, sigma_max: float = 80.0,
                  noise_scheduler: str = "exponential", sampler_type: str = "ddim", act_window_size: int = 10, multistep: int = 10,
-                 action_dim: int = 7, generator: Optional[torch.Generator] = None):
+                 action_dim: int = 7, generator: Optional[torch.Generator] = None, static_resnet=None, gripper_resnet=None,
+                 encoder_autocast: Optional[torch.dtype] = torch.bfloat16):
         if multistep > act_window_size:
             raise ValueError("multistep cannot exceed the planned window")
+        if (static_resnet is None) != (gripper_resnet is None):
+            raise ValueError("give both perceptual encoders or neither")
+        self.encoders = None
+        if static_resnet is not None:
+            from .perceptual_encoders import GraphedVisualEncoder
+            self.encoders = GraphedVisualEncoder(static_resnet.eval(), gripper_resnet.eval(), encoder_autocast)
         self.model = denoiser
         self.num_sampling_steps, self.sigma_min, self.sigma_max = num_sampling_steps, sigma_min, sigma_max
         self.noise_scheduler, self.sampler_type = noise_scheduler, sampler_type
@@ -119,9 +130,21 @@ class ChunkedRolloutPolicy:
         return sample_loop(self.model, sigmas, x, perceptual_emb, latent_goal, self.sampler_type, extra_args)
 
     @torch.no_grad()
-    def step(self, perceptual_emb: Dict[str, torch.Tensor], latent_goal: torch.Tensor) -> torch.Tensor:
+    def embed(self, obs: Dict, latent_goal: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Raw camera observation -> ``perceptual_emb`` (``MoDEAgent.embed_visual_obs``, mode_agent.py:548-567); embedded observations pass through."""
+        if "state_images" in obs:
+            return obs
+        if self.encoders is None:
+            raise ValueError("raw observations ('rgb_obs') need the policy's perceptual encoders: pass static_resnet / gripper_resnet")
+        rgb = obs["rgb_obs"]
+        goal = latent_goal.reshape(latent_goal.shape[0], -1)
+        emb = self.encoders(rgb["rgb_static"], rgb["rgb_gripper"], goal)
+        return {"state_images": emb["state_images"].to(torch.float32)}
+
+    @torch.no_grad()
+    def step(self, perceptual_emb: Dict, latent_goal: torch.Tensor) -> torch.Tensor:
         if self.rollout_step_counter % self.multistep == 0:
-            self.pred_action_seq = self.denoise_actions(perceptual_emb, latent_goal)
+            self.pred_action_seq = self.denoise_actions(self.embed(perceptual_emb, latent_goal), latent_goal)
         current = self.pred_action_seq[:, self.rollout_step_counter]
         self.rollout_step_counter += 1
         if self.rollout_step_counter == self.multistep:

@@ -105,3 +105,51 @@ def test_chunked_rollout_policy_batch_of_envs():
     pol2 = rollout.ChunkedRolloutPolicy(den, sampler_type="dpmpp_2m", noise_scheduler="karras", multistep=10)
     a = pol2.step(obs, inp["goals"])
     assert a.shape == (B, 7) and torch.isfinite(a).all()
+
+
+@pytest.mark.gpu
+def test_policy_with_graphed_perceptual_encoders():
+    """The rollout as the agent runs it (mode_agent.py:584-637): raw camera frames -> two FiLM-ResNets -> 10-step DDIM chunk.  The encoders go
+    through GraphedVisualEncoder (one hipGraph replay): same tokens as the eager ``embed_visual_obs`` (the same launches),
+    the plan matches the plan from the eager tokens, in-place weight changes are seen, training mode falls back to the eager path."""
+    from oracle import resnet_oracle as R
+    cfg = get_config("c1e4")
+    m = _model(cfg, "cuda", "bf16")
+    m.load_state_dict(make_state_dict(cfg, 210))
+    den = M.GCDenoiser(m.cuda().eval(), 0.5).eval()
+    encs = []
+    for seed in (1, 2):
+        e = M.FiLMResNet18Policy(cfg.goal_dim).cuda().eval()
+        e.load_state_dict({k: v.cuda() for k, v in R.fill_encoder_state_dict(e.state_dict(), seed).items()})
+        encs.append(e)
+    B = 3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    frames = lambda: {"rgb_obs": {"rgb_static": torch.randn(B, 1, 3, 64, 64, device="cuda", generator=g), "rgb_gripper": torch.randn(B, 1, 3, 64, 64, device="cuda", generator=g)}}
+    goal = torch.randn(B, cfg.goal_dim, device="cuda", generator=g)
+    if encs[0].resnet.num_features != cfg.obs_dim:
+        pytest.skip("fixture geometry: encoder width != obs_dim")
+    pol = rollout.ChunkedRolloutPolicy(den, multistep=2, static_resnet=encs[0], gripper_resnet=encs[1], encoder_autocast=None,
+                                       generator=torch.Generator(device="cuda").manual_seed(9))
+    ref = rollout.ChunkedRolloutPolicy(den, multistep=2, generator=torch.Generator(device="cuda").manual_seed(9))
+    for it in range(3):
+        obs = frames()
+        with torch.no_grad():
+            tok = M.embed_visual_obs(encs[0], encs[1], obs["rgb_obs"]["rgb_static"], obs["rgb_obs"]["rgb_gripper"], goal)
+        got = pol.embed(obs, goal)["state_images"]
+        assert torch.equal(got, tok["state_images"].float()) or float((got - tok["state_images"]).abs().max()) < 1e-5 * float(tok["state_images"].abs().max())
+        a = [pol.step(obs, goal).clone() for _ in range(2)]
+        b = [ref.step(tok, goal).clone() for _ in range(2)]
+        # (MIOpen's split-K convolutions add with atomics: two runs of the SAME encoder launches differ in the last fp32 bits, ~3e-7 of the token scale,
+        # which the bf16 denoiser turns into a few 1e-3 of the plan - so the plans are compared at the bf16 output tolerance, the tokens at 1e-5)
+        for x, y in zip(a, b):
+            assert float((x - y).norm() / y.norm()) < 2e-2, it
+        if it == 1:                                                          # in-place weight change: the graph reads the parameters where they live
+            with torch.no_grad():
+                encs[0].resnet.conv1.weight.mul_(1.05); encs[1].film4.gamma.weight.add_(0.01)
+    assert len(pol.encoders._graphs) == 1
+    encs[0].train()
+    out = pol.encoders(obs["rgb_obs"]["rgb_static"], obs["rgb_obs"]["rgb_gripper"], goal)["state_images"]     # batch statistics: eager path
+    assert out.shape == (B, 2, encs[0].resnet.num_features) and torch.isfinite(out).all()
+    encs[0].eval()
+    with pytest.raises(ValueError):
+        ref.step(frames(), goal)
