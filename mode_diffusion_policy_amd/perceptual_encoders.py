@@ -457,18 +457,19 @@ class GraphedVisualEncoder:
         """Convolution weights of both encoders in the compute dtype, refreshed IN PLACE when a Parameter's version (or storage) changed - the graph
         reads these copies, so an in-place weight update is seen by the next replay."""
         cache = self.__dict__.setdefault("_wcache", {})
+        convs = self.__dict__.get("_convs")
+        if convs is None:                                                        # the module tree is fixed: walk it once
+            convs = self._convs = [m for enc in (self.static_resnet, self.gripper_resnet) for m in enc.modules() if isinstance(m, nn.Conv2d)]
         out = {}
-        for enc in (self.static_resnet, self.gripper_resnet):
-            for m in enc.modules():
-                if isinstance(m, nn.Conv2d):
-                    w = m.weight
-                    ent = cache.get(id(m))
-                    if ent is None or ent[2].dtype != dtype or ent[2].device != w.device:
-                        ent = cache[id(m)] = [None, None, torch.empty_like(w, dtype=dtype)]
-                    if ent[0] != w._version or ent[1] != w.data_ptr():
-                        ent[2].copy_(w)
-                        ent[0], ent[1] = w._version, w.data_ptr()
-                    out[id(m)] = ent[2]
+        for m in convs:
+            w = m.weight
+            ent = cache.get(id(m))
+            if ent is None or ent[2].dtype != dtype or ent[2].device != w.device:
+                ent = cache[id(m)] = [None, None, torch.empty_like(w, dtype=dtype)]
+            if ent[0] != w._version or ent[1] != w.data_ptr():
+                ent[2].copy_(w)
+                ent[0], ent[1] = w._version, w.data_ptr()
+            out[id(m)] = ent[2]
         return out
 
     def _param_key(self):
