@@ -559,6 +559,7 @@ def agent_bench(args, world, rank, device, dist):
     from mode_diffusion_policy_amd.optim import FusedAdamW
     from mode_diffusion_policy_amd.perceptual_encoders import FiLMResNet50Policy, embed_visual_obs
     from mode_diffusion_policy_amd.utils import rand_log_logistic
+    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
     M, den = build_model(device, args.dtype)
     m = den.inner_model
     den.train()
@@ -614,7 +615,7 @@ def agent_bench(args, world, rank, device, dist):
                                   "GCDenoiser.loss (12 layers, d=1024, 4 experts top-2) -> backward through both -> AdamW", "global_batch": B,
                       "parallelism": "single GPU"},
            "agent_ms_per_step_blocks": [round(b, 3) for b in blocks], "host_enqueue_ms_per_step": round(min(host), 3), "encoders_forward_ms": round(enc_fwd_ms, 3), "encoder_params": n_enc,
-           "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+           "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "miopen_benchmark": bool(args.miopen_benchmark)}
     print(json.dumps(res), flush=True)
 
 
@@ -626,6 +627,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel breakdown and the train / rollout / B=1 legs of the default run")
+    ap.add_argument("--miopen-benchmark", action="store_true", help="--mode agent: torch.backends.cudnn.benchmark = True (MIOpen's exhaustive per-shape search; the "
+                    "reference's trainer runs with benchmark=False, mode/training_calvin.py:96)")
     ap.add_argument("--agent-batch", type=int, default=64, help="--mode agent: samples per step (the reference's config_calvin.yaml batch_size is 64 per GPU)")
     ap.add_argument("--mode", default="sample", choices=["sample", "train", "rollout", "agent"],
                     help="sample (default, BASELINE metric): 10-step DDIM chunks at B=128; train: configs[2]/[3] score-matching steps "
