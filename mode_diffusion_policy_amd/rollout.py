@@ -63,6 +63,12 @@ def sample_loop(model, sigmas, x_t, state, goal, sampler_type: str = "ddim", ext
     return table[sampler_type]()
 
 
+# Samplers whose step loop depends on the schedule only (no data-dependent control flow, no host-side noise source): whole call capturable in a hipGraph.
+# Not here: "ddim" (its own fused graph), "lms" / "dpmpp_2_with_lms" (host-side quadrature of the schedule), "dpmpp_2m_sde" (torchsde Brownian tree on
+# the host), "dpm_adaptive" / "dpm_fast" (step sizes from error norms / host floats).
+_GRAPHABLE_SAMPLERS = ("euler", "euler_ancestral", "heun", "dpm", "ancestral", "dpmpp_2m", "dpmpp_2s", "dpmpp_2s_ancestral")
+
+
 class ChunkedRolloutPolicy:
     """Action-chunking policy for a batch of environments: plan ``act_window_size`` actions with the sampler, emit one per control step,
     replan every ``multistep`` steps (``MoDEAgent.forward`` / ``step`` / ``denoise_actions`` / ``precompute_expert_for_inference``,
@@ -127,7 +133,68 @@ class ChunkedRolloutPolicy:
             self.need_precompute_experts_for_inference = False
         sigmas = self._schedule(dev)
         x = torch.randn((len(latent_goal), self.act_window_size, self.action_dim), device=dev, generator=self.generator) * self.sigma_max
+        if self.sampler_type in _GRAPHABLE_SAMPLERS and not extra_args:
+            out = self._sample_graphed(sigmas, x, perceptual_emb, latent_goal)
+            if out is not None:
+                return out
         return sample_loop(self.model, sigmas, x, perceptual_emb, latent_goal, self.sampler_type, extra_args)
+
+    def _sample_graphed(self, sigmas, x, perceptual_emb, latent_goal):
+        """The whole sampler call (every denoiser call, every update of the recurrence, the samplers' own noise draws) as ONE hipGraph replay - what the
+        fused DDIM path does for ``ddim``, for the samplers whose control flow does not depend on the data (euler, heun, dpm-solver(++) ...: the step
+        loop only branches on which levels of the SCHEDULE are zero).  Captured once per (sampler, batch, weights storage); the ancestral samplers' noise
+        comes from torch's default generator, which hipGraph capture advances per replay.  None = not applicable (goal / token routing, training mode,
+        MODE_HIP_GRAPH=0): the caller takes the step-by-step path."""
+        import os
+        from . import samplers as S
+        from .engine import capture_graph
+        from .modedit import MoDeDiT
+        den = self.model
+        inner = getattr(den, "inner_model", None)
+        if (not isinstance(inner, MoDeDiT) or inner.training or inner.use_goal_in_routing or not inner.cond_router or len(x) == 0
+                or os.environ.get("MODE_HIP_GRAPH", "1") == "0"):
+            return None
+        eng = inner.engine
+        dev, B = eng.device, x.shape[0]
+        img, gl = inner._prep_obs(eng, perceptual_emb, latent_goal)
+        inner._check_batch(B, img, gl, x)
+        cache = self.__dict__.setdefault("_chunk_graphs", {})
+        key = (self.sampler_type, B, eng.compute_dtype, eng._structs_for, str(dev), id(sigmas), sigmas._version, float(den.sigma_data))
+        ent = cache.get(key)
+        if ent is None:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            ent = dict(x=x.clone(), img=img.clone(), goals=gl.clone(), sig=sigmas,
+                       img_e=torch.empty(B * inner.n_img_tokens, inner.embed_dim, device=dev), goal_e=torch.empty(B, inner.embed_dim, device=dev))
+            ent["ws"] = torch.empty(max(eng.workspace_bytes(B, 0), eng.workspace_bytes(0, 1)), dtype=torch.uint8, device=dev)
+            state = {"state_images": ent["img"].view(B, inner.n_img_tokens, -1)}
+            goal3 = ent["goals"].view(B, 1, -1)
+
+            def chunk():
+                eng.embed_obs(ent["img"], ent["goals"], out=(ent["img_e"], ent["goal_e"]))
+                S._CHUNK_CAPTURE = dict(inner=inner, sigma_data=float(den.sigma_data), obs_emb=(ent["img_e"], ent["goal_e"]), metas=[])
+                try:
+                    out = sample_loop(den, sigmas, ent["x"], state, goal3, self.sampler_type, None)
+                    return out, S._CHUNK_CAPTURE["metas"]
+                finally:
+                    S._CHUNK_CAPTURE = None
+            with eng.pinned_workspace(ent["ws"]):
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):                                # warm-up outside the capture (code objects, the schedule's host-side reads)
+                    chunk()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with capture_graph(graph):
+                    ent["out"], ent["metas"] = chunk()
+            ent["graph"] = graph
+            cache[key] = ent
+        ent["x"].copy_(x); ent["img"].copy_(img); ent["goals"].copy_(gl)
+        ent["graph"].replay()
+        ml = eng.meta_layout(B * inner.seq_len)
+        for meta in ent["metas"]:                                             # expert-usage counters, as the step-by-step path keeps them
+            inner._account_usage(meta, ml, B * inner.seq_len)
+        return ent["out"].clone()
 
     @torch.no_grad()
     def embed(self, obs: Dict, latent_goal: torch.Tensor) -> Dict[str, torch.Tensor]:

@@ -86,9 +86,28 @@ def get_ancestral_step(sigma_from, sigma_to, eta=1.0):
     """(sigma_down, sigma_up) of an ancestral step (gc_sampling.py:102-109)."""
     if not eta:
         return sigma_to, 0.0
-    sigma_up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    cand = eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5
+    # (python's min() on device tensors is a host comparison = one sync per step; torch.minimum is the same number without it)
+    sigma_up = torch.minimum(sigma_to, cand) if torch.is_tensor(sigma_to) and torch.is_tensor(cand) else min(sigma_to, cand)
     sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
     return sigma_down, sigma_up
+
+
+def _ancestral_plan(sigmas, eta):
+    """(sigma_down [n], sigma_up [n], [sigma_down_i == 0 on the HOST]) of all ancestral steps of a schedule: the step loops branch on "is sigma_down
+    zero", which depends on the schedule alone - read once per schedule tensor (kept on the object like ``_zero_levels``) instead of once per step."""
+    hit = getattr(sigmas, "_mode_anc", None)
+    if hit is not None and hit[0] == (sigmas._version, float(eta)):
+        return hit[1]
+    down, up = get_ancestral_step(sigmas[:-1], sigmas[1:], eta=eta)
+    if not torch.is_tensor(up):
+        up = torch.zeros_like(down)
+    plan = (down, up, (down == 0).tolist())
+    try:
+        sigmas._mode_anc = ((sigmas._version, float(eta)), plan)
+    except Exception:                                                        # noqa: BLE001
+        pass
+    return plan
 
 
 def _exp_step(x, denoised, s_from, s_to):
@@ -109,9 +128,25 @@ def _churn(x, sigmas, i, s_churn, s_tmin, s_tmax, s_noise):
 
 
 def _zero_levels(sigmas):
-    """[sigma_i == 0 for every level] on the HOST, read once per sampler call: the step loops branch on "is the next level zero" (Euler fallback on the
-    final step) - asking the device tensor inside the loop is one host sync per step, which keeps the host from running ahead of the GPU."""
-    return (sigmas == 0).tolist()
+    """[sigma_i == 0 for every level] on the HOST: the step loops branch on "is the next level zero" (Euler fallback on the final step) - asking the
+    device tensor inside the loop is one host sync per step, which keeps the host from running ahead of the GPU.  Read once per schedule TENSOR (kept
+    on the object with its in-place version): a policy that hands the sampler the same schedule every chunk pays no host sync at all, and the whole
+    sampler call becomes capturable in a hipGraph (rollout.ChunkedRolloutPolicy)."""
+    hit = getattr(sigmas, "_mode_zero", None)
+    if hit is not None and hit[0] == sigmas._version:
+        return hit[1]
+    z = (sigmas == 0).tolist()
+    try:
+        sigmas._mode_zero = (sigmas._version, z)
+    except Exception:                                                        # noqa: BLE001  (tensor subclasses without a __dict__)
+        pass
+    return z
+
+
+# Set by rollout.ChunkedRolloutPolicy while it captures a whole sampler call in ONE hipGraph: {"inner": MoDeDiT, "sigma_data": float, "obs_emb":
+# (img_e, goal_e), "metas": []}.  A hipGraph cannot be replayed inside a capture, so _Run.denoise then issues the eager launch chain of
+# MoDeDiT.denoise (device-scalar sigma, observation embeddings computed once at the top of the captured chunk) instead of denoise_graphed's replay.
+_CHUNK_CAPTURE = None
 
 
 class _Run:
@@ -124,6 +159,12 @@ class _Run:
         self.callback, self.scaler, self.x_key = callback, scaler, x_key
 
     def denoise(self, x, sigma):
+        cc = _CHUNK_CAPTURE
+        if cc is not None and not self.kw and torch.is_tensor(sigma) and sigma.numel() == 1:
+            inner = cc["inner"]
+            out = inner.denoise(None, x, None, sigma.reshape(1), cc["sigma_data"], _account=False, _obs_emb=cc["obs_emb"])
+            cc["metas"].append(inner._last_meta)
+            return out
         fast = getattr(self.model, "denoise_uniform", None)              # GCDenoiser over the HIP MoDeDiT: one hipGraph replay per call
         if fast is not None and not self.kw and torch.is_tensor(sigma) and sigma.numel() == 1:
             out = fast(self.state, x, self.goal, sigma)
@@ -158,12 +199,13 @@ def sample_euler(model, state, action, goal, sigmas, scaler=None, extra_args=Non
 def sample_euler_ancestral(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, eta=1.0):
     """Euler step to sigma_down, then fresh noise of scale sigma_up (gc_sampling.py:214-254)."""
     run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
+    downs, ups, down_zero = _ancestral_plan(sigmas, eta)
     for i in range(len(sigmas) - 1):
         denoised = run.denoise(action, sigmas[i])
-        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        sigma_down, sigma_up = downs[i], ups[i]
         run.report(action, i, sigmas[i], sigmas[i], denoised)
         action = action + to_d(action, sigmas[i], denoised) * (sigma_down - sigmas[i])
-        if sigma_down > 0:
+        if not down_zero[i]:
             action = action + torch.randn_like(action) * sigma_up
         action = run.clip(action)
     return action
@@ -217,12 +259,13 @@ def sample_dpm_2(model, state, action, goal, sigmas, scaler=None, extra_args=Non
 def sample_dpm_2_ancestral(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, eta=1.0):
     """Midpoint step to sigma_down plus ancestral noise (gc_sampling.py:376-410)."""
     run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
+    downs, ups, down_zero = _ancestral_plan(sigmas, eta)
     for i in range(len(sigmas) - 1):
         denoised = run.denoise(action, sigmas[i])
-        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        sigma_down, sigma_up = downs[i], ups[i]
         run.report(action, i, sigmas[i], sigmas[i], denoised)
         d = to_d(action, sigmas[i], denoised)
-        if sigma_down == 0:
+        if down_zero[i]:
             action = action + d * (sigma_down - sigmas[i])
         else:
             sigma_mid = sigmas[i].log().lerp(sigma_down.log(), 0.5).exp()
@@ -300,11 +343,12 @@ def sample_dpmpp_2s_ancestral(model, state, action, goal, sigmas, scaler=None, e
     """DPM-Solver++(2S) steps to sigma_down plus ancestral noise (gc_sampling.py:874-920)."""
     run = _Run(model, state, goal, action, extra_args, callback, scaler, "action")
     noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+    downs, ups, down_zero = _ancestral_plan(sigmas, eta)
     for i in range(len(sigmas) - 1):
         denoised = run.denoise(action, sigmas[i])
-        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        sigma_down, sigma_up = downs[i], ups[i]
         run.report(action, i, sigmas[i], sigmas[i], denoised)
-        if sigma_down == 0:
+        if down_zero[i]:
             action = action + to_d(action, sigmas[i], denoised) * (sigma_down - sigmas[i])
         else:
             action = _dpmpp_2s_core(run, action, denoised, sigmas[i], sigma_down)

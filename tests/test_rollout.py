@@ -153,3 +153,40 @@ def test_policy_with_graphed_perceptual_encoders():
     encs[0].eval()
     with pytest.raises(ValueError):
         ref.step(frames(), goal)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_whole_sampler_call_as_one_graph(dtype, monkeypatch):
+    """Non-DDIM samplers through the policy: the whole call is one hipGraph replay.  Deterministic samplers must reproduce the step-by-step path
+    (MODE_HIP_GRAPH=0: the reference-shaped host loop over the same kernels); the ancestral ones draw their noise inside the graph - finite, fresh per
+    replay, and the usage counters advance like on the step-by-step path."""
+    cfg = get_config("c1e4")
+    m = _model(cfg, "cuda", dtype)
+    m.load_state_dict(make_state_dict(cfg, 210))
+    den = M.GCDenoiser(m.cuda().eval(), 0.5).eval()
+    B = 5
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, B, 3).items()}
+    obs = {"state_images": inp["state_images"]}
+    tol = 1e-5 if dtype == "fp32" else 2e-2
+    for name in rollout._GRAPHABLE_SAMPLERS:
+        mk = lambda: rollout.ChunkedRolloutPolicy(den, sampler_type=name, noise_scheduler="karras", multistep=10, generator=torch.Generator(device="cuda").manual_seed(11))
+        pol, ref = mk(), mk()
+        plans = []
+        for it in range(3):
+            o = {"state_images": inp["state_images"] * (1 + 0.1 * it)}
+            tokens0 = [int(b.total_tokens_processed) for b in m.blocks]
+            p = pol.denoise_actions(o, inp["goals"])
+            calls = (int(m.blocks[0].total_tokens_processed) - tokens0[0]) // (B * m.seq_len)
+            monkeypatch.setenv("MODE_HIP_GRAPH", "0")
+            tokens1 = int(m.blocks[0].total_tokens_processed)
+            r = ref.denoise_actions(o, inp["goals"])
+            calls_ref = (int(m.blocks[0].total_tokens_processed) - tokens1) // (B * m.seq_len)
+            monkeypatch.delenv("MODE_HIP_GRAPH")
+            assert p.shape == r.shape == (B, 10, 7) and torch.isfinite(p).all()
+            assert calls == calls_ref and calls >= 10, (name, calls, calls_ref)           # same number of denoiser calls accounted
+            if "ancestral" not in name:
+                assert float((p - r).norm() / r.norm()) < tol, (name, it, float((p - r).norm() / r.norm()))
+            plans.append(p)
+        assert len(pol._chunk_graphs) == 1                                            # one capture, three replays
+        assert not torch.equal(plans[0], plans[1])
