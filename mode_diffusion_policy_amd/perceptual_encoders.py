@@ -212,6 +212,7 @@ def _store_channels_last(module: nn.Module) -> None:
 
 # {id(conv): weight already in the compute dtype}: set by GraphedVisualEncoder around its warm-up and capture, so that the per-call weight casts of
 # autocast (one launch per convolution) are not part of the replayed graph; it refreshes the copies in place when a weight's version moves.
+# Process-wide, set and restored around one call (not re-entrant: stream capture is not either).
 _W_OVERRIDE: Optional[dict] = None
 
 

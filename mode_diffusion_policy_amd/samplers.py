@@ -146,6 +146,7 @@ def _zero_levels(sigmas):
 # Set by rollout.ChunkedRolloutPolicy while it captures a whole sampler call in ONE hipGraph: {"inner": MoDeDiT, "sigma_data": float, "obs_emb":
 # (img_e, goal_e), "metas": []}.  A hipGraph cannot be replayed inside a capture, so _Run.denoise then issues the eager launch chain of
 # MoDeDiT.denoise (device-scalar sigma, observation embeddings computed once at the top of the captured chunk) instead of denoise_graphed's replay.
+# Process-wide and not re-entrant, like hipGraph stream capture itself (one capture per thread at a time; the policy sets and clears it around its own call).
 _CHUNK_CAPTURE = None
 
 
