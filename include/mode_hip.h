@@ -60,8 +60,10 @@ const char* mode_hip_status_string(int status);
  * "gemm_cfg": bf16 forward GEMM tile geometry, 0 = auto (default), 1 = 128x128 ring-2, 4 = 128x64 ring-3, 6 = 128x128 single-buffered
  *   (3 workgroups/CU), 8 = 128x64 ring-2, 13 = 128x128 single-buffered with <= 128 VGPRs (4 workgroups/CU), 14 = 64x64 ring-3 (no SwiGLU),
  *   17 = persistent ping-pong kernel with 224-row x 256-column tiles (gemm_bf16_pp.hip; epilogues NONE / BIAS / SWIGLU).
+ *   18 = the same kernel with 256-row tiles (epilogues NONE / BIAS; the heuristic takes it for RAGGED expert segments whose expected tiles fill whole
+ *   rounds of the part: the training forward's up-projection).  A forced geometry that does not take a shape falls back to the heuristic's choice.
  *   Every forward geometry produces bit-identical results (k-ordered fp32 MFMA chain, explicit-fma epilogues).
- * "gemm_pp": 1 (default) = the heuristic may pick geometry 17; "gemm_pp_min_tiles": tile count from which it does (default 200).
+ * "gemm_pp": 1 (default) = the heuristic may pick geometries 17 / 18; "gemm_pp_min_tiles": tile count from which it does (default 200).
  * "gemm_group_m": m-tiles per XCD rasterisation group of the ring kernels (0 = default).
  * "gemm_tr_cfg": backward (transpose-read) GEMM geometry, 0 = auto, 1 = 128-wide ring-2, 2 = 64-wide ring-3, 3 = 128-wide ring-3,
  *   4 = 64-wide ring-2, 5 = 128-wide single-buffered.  "adamw_blocks": workgroup cap of one AdamW launch (0 = 256, one streaming workgroup per CU).

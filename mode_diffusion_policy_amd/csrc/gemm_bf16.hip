@@ -401,8 +401,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
 // (ids 2, 3, 5, 7, 9-12, 15 were measured-and-rejected geometries of round 1 - deeper rings, 256-wide one-barrier tiles, a persistent 256x256 kernel with
 // a serial epilogue - removed once the ping-pong kernel superseded them; the numbers stay in DESIGN.md)
 enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x64_NS3 = 4, CFG_128x128_NS1 = 6, CFG_128x64_NS2 = 8, CFG_128x128_NS1_4WG = 13, CFG_64x64_NS3 = 14,
-       CFG_PP224 = 17 };
-int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_pp.hip: persistent ping-pong kernel, 224 x 256 tiles
+       CFG_PP224 = 17, CFG_PP256 = 18 };
+int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p, int rows256, hipStream_t s);   // gemm_bf16_pp.hip: persistent ping-pong kernel, 224 / 256 x 256 tiles
 int gemm_bf16_skinny_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_skinny.hip: weight streamer for a handful of rows
 int gemm_bf16_mid_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);      // gemm_bf16_skinny.hip: register-resident weights, no K loop (a few hundred rows)
 int g_gemm_mid_rows = 128;   // "gemm_mid_rows" option: ungrouped K = 1024 GEMMs with at most this many rows take gemm_bf16_mid_kernel (0 = off).  Measured chunk latency B = 4: 6.89 -> 6.60 ms, B = 8: 7.40 -> 7.14 ms; from ~200 rows on the M/32 re-reads of W through L2 cost more than the ring kernel (B = 16: 8.41 -> 8.50 ms, B = 32: 9.21 -> 9.48 ms)
@@ -463,6 +463,17 @@ static int pick_cfg(const ModeGemmDesc* d, bool allow_pp) {
     const long tpp = ((rows + 223) / 224) * (d->N / nout) * (d->split_k > 1 ? d->split_k : 1);
     if (d->N % nout == 0 && tpp >= g_gemm_pp_min_tiles) return CFG_PP224;
   }
+  // RAGGED expert segments (device-side offsets, no uniformity promise: the training forward's per-token multinomial routing): 224-row tiles leave half
+  // of the experts with a nearly empty fifth tile (measured equal to the ring kernels, scripts/ragged_pp_probe.py), 256-row tiles cover the same rows in
+  // four - the up-projection of the training forward is 512 tiles = exactly two rounds: 88.9 -> 73.1 us.  Taken when the expected tile count (segment
+  // lengths within 6 % of their mean) fills whole rounds of the part; anything else stays on the ring kernels.
+  if (allow_pp && d->expert_offsets && !(d->flags & MODE_GEMM_UNIFORM_GROUPS) && d->num_experts > 0 && d->split_k <= 1 &&
+      (d->epilogue == MODE_EPI_NONE || d->epilogue == MODE_EPI_BIAS) && d->N % 256 == 0) {
+    const long per = (long)((double)rows / d->num_experts * 1.06) + 1;
+    const long t4 = (long)d->num_experts * ((per + 255) / 256) * (d->N / 256);
+    const long rounds = (t4 + 255) / 256;
+    if (t4 >= 256 && t4 * 10 >= rounds * 256 * 9) return CFG_PP256;
+  }
   const int nout128 = (d->epilogue == MODE_EPI_SWIGLU) ? 64 : 128;
   const long t128 = ((rows + 127) / 128) * ((d->N + nout128 - 1) / nout128);
   const long t64 = ((rows + 127) / 128) * ((d->N + 63) / 64);
@@ -521,8 +532,8 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
     if (rc != MODE_ERR_UNSUPPORTED) return rc;
   }
   int cfg = g_gemm_cfg != CFG_AUTO ? g_gemm_cfg : pick_cfg(d, g_gemm_pp != 0);
-  if (cfg == CFG_PP224) {
-    const int rc = gemm_bf16_pp_launch(d, p, s);
+  if (cfg == CFG_PP224 || cfg == CFG_PP256) {
+    const int rc = gemm_bf16_pp_launch(d, p, cfg == CFG_PP256, s);
     if (rc != MODE_ERR_UNSUPPORTED) return rc;
     cfg = pick_cfg(d, false);                                      // shapes / epilogues the ping-pong kernel does not take
   }

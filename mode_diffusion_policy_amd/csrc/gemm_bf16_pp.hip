@@ -580,11 +580,13 @@ static int pp_launch(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
 }
 
 // Entered from gemm_bf16_launch with a validated descriptor and a filled parameter block.  Returns MODE_ERR_UNSUPPORTED for shapes /
-// epilogues this kernel does not take (the caller falls back to the 128x128 family).  Only the 224-row tile (FM1 = 3) is instantiated: the
-// 256-row variant needed more than 256 VGPRs once the K loop was peeled, and a spill inside the K loop breaks the COUNTED vmcnt waits (scratch
-// traffic counts in vmcnt) - tests/test_boundary.py::test_pp_kernel_isa_contract pins "no scratch access in an MFMA block" on the shipped ISA.
-int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, hipStream_t s) {
+// epilogues this kernel does not take (the caller falls back to the 128x128 family).  Tiles: 224 rows (FM1 = 3, all epilogues) and 256 rows (FM1 = 4,
+// NONE / BIAS: ragged expert segments).  A spill inside the K loop would break the COUNTED vmcnt waits (scratch traffic counts in vmcnt; seen once on an
+// earlier 256-row SwiGLU variant) - tests/test_boundary.py::test_pp_kernel_isa_contract pins "no scratch access in an MFMA block" on the shipped ISA of
+// every instantiation.
+int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, int rows256, hipStream_t s) {
   const int epi = d->epilogue;
+  if (rows256 && epi == MODE_EPI_SWIGLU) return MODE_ERR_UNSUPPORTED;          // the 256-row tile exists for the NONE / BIAS epilogues (see below)
   if (epi != MODE_EPI_NONE && epi != MODE_EPI_BIAS && epi != MODE_EPI_SWIGLU) return MODE_ERR_UNSUPPORTED;
   const int nout = epi == MODE_EPI_SWIGLU ? 128 : 256;
   const int S = p0.split_k;
@@ -597,6 +599,13 @@ int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p0, hipStream_t
   if (wrows * d->ldw * 2 >= (1L << 32) || (long)d->M * d->lda * 2 >= (1L << 32)) return MODE_ERR_UNSUPPORTED;
   if (d->bias && ((reinterpret_cast<uintptr_t>(d->bias) & 15) || d->bias_expert_stride % 4)) return MODE_ERR_UNSUPPORTED;
   const bool ob = d->out_dtype == MODE_BF16;
+  if (rows256) {
+    // 256-row tile (FM1 = 4): for RAGGED expert segments.  With the reference's per-token multinomial routing an expert owns 896 +- 30 of the 3584 sorted
+    // rows: five 224-row tiles for half of the experts (608-640 tiles = three rounds of a 256-CU part), but four 256-row tiles for all of them (512 tiles
+    // = two rounds).  Same loop, same numerics; the ISA contract test covers these instantiations too (no scratch access in an MFMA block).
+    if (epi == MODE_EPI_NONE) return ob ? pp_launch<MODE_EPI_NONE, true, 4>(p0, d, s) : pp_launch<MODE_EPI_NONE, false, 4>(p0, d, s);
+    return ob ? pp_launch<MODE_EPI_BIAS, true, 4>(p0, d, s) : pp_launch<MODE_EPI_BIAS, false, 4>(p0, d, s);
+  }
 #define PP_CASE(E) \
   case E: return ob ? pp_launch<E, true, 3>(p0, d, s) : pp_launch<E, false, 3>(p0, d, s);
   switch (epi) {

@@ -21,7 +21,7 @@ def desc(l):
     return L.ModeGemmDesc(dtype=0, epilogue=L.EPI_BIAS, out_dtype=0, M=NK, N=8 * D, K=D, A=u.data_ptr(), lda=D, W=W1[l].data_ptr(), ldw=D, w_expert_stride=8 * D * D,
                           bias=b1.data_ptr(), bias_expert_stride=8 * D, C=P.data_ptr(), ldc=8 * D, a_rows=perm.data_ptr(), expert_offsets=offsets.data_ptr(), num_experts=E)
 outs = {}
-for cfg in (0, 17, 13, 1):
+for cfg in (0, 17, 18, 13, 1):
     lib.mode_set_option(b"gemm_cfg", cfg)
     st = torch.cuda.current_stream().cuda_stream
     rc = lib.mode_gemm(C.byref(desc(0)), st); torch.cuda.synchronize()

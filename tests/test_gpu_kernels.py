@@ -30,7 +30,7 @@ def rnd(*shape, seed=0, scale=1.0):
 
 # ----------------------------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1792, 3072, 1024), (100, 192, 64), (257, 1024, 256), (14, 64, 128), (1, 128, 64)])
-@pytest.mark.parametrize("cfg", [0, 1, 4, 6, 8, 13, 14, 17])
+@pytest.mark.parametrize("cfg", [0, 1, 4, 6, 8, 13, 14, 17, 18])
 def test_gemm_bf16_plain_bias(M, N, K, cfg):
     # asymmetric operands: a transposed/permuted C-write cannot pass
     A = rnd(M, K, seed=1).to(torch.bfloat16); W = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
@@ -55,7 +55,7 @@ def test_gemm_bf16_identity_asymmetric():
     assert torch.equal(out.cpu(), W.float().t().contiguous())
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 4, 6, 8, 13, 17])
+@pytest.mark.parametrize("cfg", [0, 1, 4, 6, 8, 13, 17, 18])
 @pytest.mark.parametrize("M,D", [(300, 256), (3584, 1024)])
 def test_gemm_bf16_swiglu_residual(M, D, cfg):
     L.load().mode_set_option(b"gemm_cfg", cfg)
@@ -76,7 +76,7 @@ def _swiglu_residual(M, D):
     assert rel(out2, A.float() @ Wo.float().t() + r) < 2e-3
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 4, 6, 8, 13, 17])
+@pytest.mark.parametrize("cfg", [0, 1, 4, 6, 8, 13, 17, 18])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("N_tok,E,k,D", [(70, 4, 2, 64), (1792, 4, 2, 256), (112, 2, 1, 256), (5, 4, 2, 64), (900, 4, 2, 128)])
 def test_grouped_gather_gemm(dtype, N_tok, E, k, D, cfg):
@@ -135,7 +135,7 @@ def _grouped_gather_gemm(dtype, N_tok, E, k, D):
     assert rel(hh.float(), href) < (5e-3 if dtype == torch.bfloat16 else 1e-6)
 
 
-@pytest.mark.parametrize("cfg", [0, 4, 17])
+@pytest.mark.parametrize("cfg", [0, 4, 17, 18])
 @pytest.mark.parametrize("S", [2, 4])
 def test_gemm_bf16_split_k(cfg, S):
     """split-K: slice z writes its partial sums to slab z; the slabs add up to the un-split product."""
@@ -246,7 +246,7 @@ def test_dispatch_meta_bit_exact(R, tpr, E, k):
 
 
 # ------------------------------------------------------------------------------------------------- fused ln_2 (c_proj -> experts -> combine)
-@pytest.mark.parametrize("cfg", [0, 1, 4, 6, 13, 17])
+@pytest.mark.parametrize("cfg", [0, 1, 4, 6, 13, 17, 18])
 @pytest.mark.parametrize("N_tok,D,E,k", [(70, 128, 4, 2), (1792, 256, 4, 2), (1792, 1024, 4, 2), (37, 64, 2, 1)])
 def test_fused_ln2_chain_matches_separate_kernels(N_tok, D, E, k, cfg):
     """MODE_EPI_RESIDUAL_NORM producer + MODE_EPI_SWIGLU(row_ss) consumer + combine(u_ss) against the three-kernel formulation
