@@ -498,3 +498,33 @@ def test_probe_mfma_burn_runs_and_reports_flops():
     assert torch.isfinite(out).all() and float(out.abs().max()) > 0
     assert fl.value == 4 * 8 * 130 * 16 * 2.0 * 16 * 16 * 32
     assert lib.mode_probe_mfma_burn(None, None, 4, 10, None, H.stream()) == -1          # MODE_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("counts", [(920, 847, 902, 915), (896, 896, 896, 896), (2000, 0, 1500, 84), (1030, 1024, 770, 760), (3584, 0, 0, 0)])
+@pytest.mark.parametrize("epi", [L.EPI_BIAS, L.EPI_NONE])
+def test_ragged_grouped_gemm_256_row_pingpong_tile(counts, epi):
+    """Ragged expert segments (device-side offsets, no uniformity promise) at the training forward's up-projection geometry: the heuristic takes the
+    256-row ping-pong tile (gemm_cfg 18).  Bit-identical to the 128x128 ring kernel and to the 224-row tile, correct against fp32 torch - for balanced
+    counts, counts above 1024 (a fifth tile), empty experts and everything on one expert; canary rows around the output stay untouched."""
+    E, K, N = 4, 256, 4096
+    M = sum(counts)
+    torch.manual_seed(M + N)
+    A = (torch.randn(M, K) * 0.5).to(torch.bfloat16).to(dev())
+    W = (torch.randn(E, N, K) * K ** -0.5).to(torch.bfloat16).to(dev())
+    b = torch.randn(E, N).to(dev()) if epi == L.EPI_BIAS else None
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=dev())
+    outs = {}
+    for cfg in (0, 1, 17, 18):
+        L.load().mode_set_option(b"gemm_cfg", cfg)
+        try:
+            outs[cfg] = H.gemm(A, W, epi, bias=b, out_dtype=torch.bfloat16, offsets=off, num_experts=E, w_estride=N * K, b_estride=N if b is not None else 0)
+        finally:
+            L.load().mode_set_option(b"gemm_cfg", 0)
+    ref = torch.empty(M, N)
+    lo = 0
+    for e, c in enumerate(counts):
+        ref[lo:lo + c] = A[lo:lo + c].float().cpu() @ W[e].float().cpu().t() + (b[e].cpu() if b is not None else 0)
+        lo += c
+    assert rel(outs[0].float(), ref) < 6e-3
+    for cfg in (1, 17, 18):
+        assert torch.equal(outs[cfg].view(torch.int16), outs[0].view(torch.int16)), cfg
