@@ -505,7 +505,7 @@ def test_probe_mfma_burn_runs_and_reports_flops():
 def test_ragged_grouped_gemm_256_row_pingpong_tile(counts, epi):
     """Ragged expert segments (device-side offsets, no uniformity promise) at the training forward's up-projection geometry: the heuristic takes the
     256-row ping-pong tile (gemm_cfg 18).  Bit-identical to the 128x128 ring kernel and to the 224-row tile, correct against fp32 torch - for balanced
-    counts, counts above 1024 (a fifth tile), empty experts and everything on one expert; canary rows around the output stay untouched."""
+    counts, counts above 1024 (a fifth tile), empty experts and everything on one expert (the output is NaN-prefilled: an unwritten element fails the comparison)."""
     E, K, N = 4, 256, 4096
     M = sum(counts)
     torch.manual_seed(M + N)
