@@ -172,12 +172,13 @@ class ChunkedRolloutPolicy:
 
             def chunk():
                 eng.embed_obs(ent["img"], ent["goals"], out=(ent["img_e"], ent["goal_e"]))
-                S._CHUNK_CAPTURE = dict(inner=inner, sigma_data=float(den.sigma_data), obs_emb=(ent["img_e"], ent["goal_e"]), metas=[])
+                cc = dict(inner=inner, sigma_data=float(den.sigma_data), obs_emb=(ent["img_e"], ent["goal_e"]), metas=[])
+                S._set_chunk_capture(cc)
                 try:
                     out = sample_loop(den, sigmas, ent["x"], state, goal3, self.sampler_type, None)
-                    return out, S._CHUNK_CAPTURE["metas"]
+                    return out, cc["metas"]
                 finally:
-                    S._CHUNK_CAPTURE = None
+                    S._set_chunk_capture(None)
             with eng.pinned_workspace(ent["ws"]):
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
@@ -251,3 +252,110 @@ def load_denoiser_checkpoint(model, source, prefix: str = "model.inner_model.", 
         picked[name] = t
     res = model.load_state_dict(picked, strict=strict)
     return list(res.missing_keys), list(res.unexpected_keys), skipped
+
+
+# Key prefixes of older published checkpoints -> the agent's current attribute names (mode_agent.py:216-226).  Tried in this order, first match wins,
+# and only for keys the agent does not have under their own name.
+_AGENT_KEY_REMAP = (
+    ("img_encoder_image_wrist.", "gripper_resnet."),
+    ("img_encoder_image_secondary.", "static_resnet."),
+    ("img_encoder_image_primary.", "static_resnet."),
+    ("net.", "gripper_resnet.resnet."),
+)
+
+
+def _fit_checkpoint_tensor(key: str, t: torch.Tensor, shape) -> Optional[torch.Tensor]:
+    """The reference loader's shape rule (mode_agent.py:163-200): equal shapes pass; a 0-d entry becomes zeros; 1-d -> 1-d of another length is tiled
+    (BatchNorm vectors); 1-d or 2-d -> 4-d with the same element count is viewed as the convolution weight; ``running_*`` buffers of another rank
+    with the same element count are viewed; anything else is incompatible (None)."""
+    shape = tuple(shape)
+    if tuple(t.shape) == shape:
+        return t
+    want = 1
+    for d in shape:
+        want *= d
+    if t.dim() == 0:
+        return torch.zeros(shape, device=t.device)
+    if t.dim() == 1 and len(shape) == 1:
+        return t.repeat(shape[0] // t.shape[0]) if t.shape[0] != shape[0] else t
+    if t.dim() == 1 and len(shape) == 4:
+        return t.view(shape)                                                   # raises on an element-count mismatch, like the reference
+    if t.dim() == 2 and len(shape) == 4 and t.numel() == want:
+        return t.view(shape)
+    if "running_" in key and t.dim() != len(shape) and t.numel() == want:
+        return t.view(shape)
+    return None
+
+
+def _agent_parts(target) -> Dict[str, torch.nn.Module]:
+    """{'model': GCDenoiser, 'static_resnet': ..., 'gripper_resnet': ...} from a mapping, a ChunkedRolloutPolicy, or any object with those attributes
+    (the attribute names ARE the key prefixes of the agent's state_dict, mode_agent.py:79, 90-91)."""
+    if isinstance(target, dict):
+        parts = dict(target)
+    else:
+        parts = {"model": getattr(target, "model", None)}
+        enc = getattr(target, "encoders", None)
+        for name in ("static_resnet", "gripper_resnet"):
+            parts[name] = getattr(target, name, None) if getattr(target, name, None) is not None else getattr(enc, name, None)
+    parts = {k: v for k, v in parts.items() if v is not None}
+    if not parts:
+        raise ValueError("nothing to load into: expected 'model' and / or 'static_resnet' / 'gripper_resnet'")
+    return parts
+
+
+def load_agent_checkpoint(target, source, strict: bool = False, verbose: bool = False) -> Dict[str, object]:
+    """Load ONE agent checkpoint - the published HF ``.safetensors``, a Lightning ``.ckpt`` / ``torch.save``d ``state_dict`` or a mapping - into the
+    denoiser AND both perceptual encoders, as ``MoDEAgent.load_pretrained_parameters`` does (mode_agent.py:135-251): CLIP tensors are skipped
+    (``'visual'`` / ``'clip'`` in the key), keys the agent does not know are retried under the prefix table of older releases
+    (``img_encoder_image_wrist.`` -> ``gripper_resnet.``, ``img_encoder_image_primary.`` / ``secondary.`` -> ``static_resnet.``, ``net.`` ->
+    ``gripper_resnet.resnet.``), tensors are fitted by the reference's reshape rule, incompatible ones are skipped and reported, and the result is
+    loaded with ``load_state_dict(strict=strict)``.
+
+    ``target``: ``{'model': GCDenoiser, 'static_resnet': m, 'gripper_resnet': m}`` (any subset), a ``ChunkedRolloutPolicy`` built with encoders, or an
+    object with those attributes.  Returns ``{'direct', 'reshaped', 'skipped', 'missing', 'unexpected'}`` (counts for the first two, key lists for the
+    rest; keys carry the agent-level prefix).  Parameters are written in place (arena views, the graphs' static pointers stay valid)."""
+    if isinstance(source, (str, bytes)):
+        path = source if isinstance(source, str) else source.decode()
+        if path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(path)
+        else:
+            sd = torch.load(path, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+    else:
+        sd = dict(source)
+    parts = _agent_parts(target)
+    current = {f"{name}.{k}": v for name, mod in parts.items() for k, v in mod.state_dict().items()}
+    picked: Dict[str, Dict[str, torch.Tensor]] = {name: {} for name in parts}
+    direct, reshaped, skipped = 0, 0, []
+    for key, t in sd.items():
+        if "visual" in key or "clip" in key.lower():
+            continue
+        tkey = key
+        if key not in current:
+            for old, new in _AGENT_KEY_REMAP:
+                if key.startswith(old):
+                    tkey = key.replace(old, new)
+                    break
+        if tkey not in current:
+            continue                                                           # the reference drops unknown keys before load_state_dict too
+        fitted = _fit_checkpoint_tensor(tkey, t, current[tkey].shape)
+        if fitted is None:
+            skipped.append(tkey)
+            if verbose:
+                print(f"Skipping incompatible tensor {tkey}: checkpoint {tuple(t.shape)} vs {tuple(current[tkey].shape)}")
+            continue
+        if tuple(fitted.shape) != tuple(t.shape):
+            reshaped += 1
+        else:
+            direct += 1
+        name, sub = tkey.split(".", 1)
+        picked[name][sub] = fitted
+    missing, unexpected = [], []
+    for name, mod in parts.items():
+        res = mod.load_state_dict(picked[name], strict=strict)
+        missing += [f"{name}.{k}" for k in res.missing_keys]
+        unexpected += [f"{name}.{k}" for k in res.unexpected_keys]
+    if verbose:
+        print(f"Direct copies: {direct}  reshaped: {reshaped}  skipped: {len(skipped)}  missing: {len(missing)}")
+    return {"direct": direct, "reshaped": reshaped, "skipped": skipped, "missing": missing, "unexpected": unexpected}

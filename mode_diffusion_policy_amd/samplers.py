@@ -16,6 +16,8 @@ and keep the reference's observable behaviour: argument names and defaults, the 
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 import torch
 from scipy import integrate
@@ -146,8 +148,17 @@ def _zero_levels(sigmas):
 # Set by rollout.ChunkedRolloutPolicy while it captures a whole sampler call in ONE hipGraph: {"inner": MoDeDiT, "sigma_data": float, "obs_emb":
 # (img_e, goal_e), "metas": []}.  A hipGraph cannot be replayed inside a capture, so _Run.denoise then issues the eager launch chain of
 # MoDeDiT.denoise (device-scalar sigma, observation embeddings computed once at the top of the captured chunk) instead of denoise_graphed's replay.
-# Process-wide and not re-entrant, like hipGraph stream capture itself (one capture per thread at a time; the policy sets and clears it around its own call).
-_CHUNK_CAPTURE = None
+# Per THREAD (hipGraph stream capture is a per-thread state too: one capture per thread at a time; the policy sets and clears it around its own call),
+# so two policies capturing on two threads do not see each other's hook.
+_CAPTURE_TLS = threading.local()
+
+
+def _set_chunk_capture(cc):
+    _CAPTURE_TLS.cc = cc
+
+
+def _chunk_capture():
+    return getattr(_CAPTURE_TLS, "cc", None)
 
 
 class _Run:
@@ -160,7 +171,7 @@ class _Run:
         self.callback, self.scaler, self.x_key = callback, scaler, x_key
 
     def denoise(self, x, sigma):
-        cc = _CHUNK_CAPTURE
+        cc = _chunk_capture()
         if cc is not None and not self.kw and torch.is_tensor(sigma) and sigma.numel() == 1:
             inner = cc["inner"]
             out = inner.denoise(None, x, None, sigma.reshape(1), cc["sigma_data"], _account=False, _obs_emb=cc["obs_emb"])

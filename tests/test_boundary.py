@@ -44,6 +44,16 @@ def test_header_symbols_all_exported():
         assert lib.mode_set_option(key, 0) == -2, key                                       # result-changing ablation switches / trace buffers do not ship
 
 
+def test_integration_doc_abi_matches_header():
+    """The ctypes stub printed in INTEGRATION.md asserts the ABI version the header defines (a maintainer pasting it must not hit the assert)."""
+    hdr = open(os.path.join(ROOT, "include", "mode_hip.h")).read()
+    abi = int(re.search(r"#define\s+MODE_HIP_ABI_VERSION\s+(\d+)", hdr).group(1))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stated = [int(v) for v in re.findall(r"mode_hip_version\(\)\s*==\s*(\d+)", doc)]
+    assert stated and all(v == abi for v in stated), (stated, abi)
+    assert abi == L.ABI_VERSION
+
+
 def test_mode_hip_opts_env(monkeypatch):
     """MODE_HIP_OPTS="key=value,..." is applied when the library is loaded; unknown keys fail loudly."""
     lib = L.load()

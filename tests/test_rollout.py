@@ -69,6 +69,68 @@ def test_checkpoint_loader_by_key(tmp_path):
     assert "out.bias" in missing and "pos_emb" in missing and skipped == ["pos_emb"] and not unexpected
 
 
+def test_agent_checkpoint_loader_reference_key_names(tmp_path):
+    """One agent checkpoint written under the key names of the reference's releases (mode_agent.py:209-251): the denoiser under
+    ``model.inner_model.``, the static camera under the old ``img_encoder_image_primary.`` prefix, the gripper camera partly under
+    ``img_encoder_image_wrist.`` and partly under ``net.`` (-> ``gripper_resnet.resnet.``), CLIP tensors to be ignored, a flattened convolution
+    weight, a tiled BatchNorm vector, a 0-d entry, an incompatible tensor.  Every tensor must land where the reference's loader puts it."""
+    from safetensors.torch import save_file
+    from mode_diffusion_policy_amd import perceptual_encoders as E
+    from oracle import resnet_oracle as R
+    cfg = get_config("tiny")
+    sd = make_state_dict(cfg, 7)
+    den = M.GCDenoiser(_model(cfg, "cpu"), 0.5)
+    stat, grip = E.FiLMResNet18Policy(32), E.FiLMResNet18Policy(32)
+    s_sd = R.fill_encoder_state_dict(stat.state_dict(), 11)
+    g_sd = R.fill_encoder_state_dict(grip.state_dict(), 12)
+    ck = {"model.inner_model." + k: v.clone() for k, v in sd.items()}
+    ck.update({"img_encoder_image_primary." + k: v.clone() for k, v in s_sd.items()})
+    for k, v in g_sd.items():
+        if k.startswith("resnet.layer1."):
+            ck["net." + k[len("resnet."):]] = v.clone()
+        else:
+            ck["img_encoder_image_wrist." + k] = v.clone()
+    ck["clip_model.visual.proj"] = torch.zeros(4, 4)
+    ck["model.visual_stub"] = torch.zeros(2)
+    ck["img_encoder_image_primary.resnet.conv1.weight"] = s_sd["resnet.conv1.weight"].reshape(-1).clone()          # conv weight stored 1-d
+    ck["img_encoder_image_wrist.resnet.layer2.0.conv1.weight"] = g_sd["resnet.layer2.0.conv1.weight"].reshape(128, -1).clone()   # ... stored 2-d
+    half = g_sd["resnet.bn1.weight"][:32].clone()
+    ck["img_encoder_image_wrist.resnet.bn1.weight"] = half                                                            # shorter vector: tiled
+    ck["img_encoder_image_wrist.resnet.bn1.num_batches_tracked"] = torch.tensor(5)
+    ck["img_encoder_image_primary.resnet.bn1.bias"] = torch.tensor(0.0)                                                # 0-d: zeros of the target shape
+    ck["img_encoder_image_primary.resnet.layer1.0.conv1.weight"] = torch.zeros(3, 5, 7)                                # incompatible: skipped
+    path = os.path.join(tmp_path, "model_cleaned.safetensors")
+    save_file({k: v.contiguous() for k, v in ck.items()}, path)
+    before = stat.state_dict()["resnet.layer1.0.conv1.weight"].clone()
+    res = rollout.load_agent_checkpoint({"model": den, "static_resnet": stat, "gripper_resnet": grip}, path)
+    assert res["skipped"] == ["static_resnet.resnet.layer1.0.conv1.weight"] and res["missing"] == res["skipped"] and not res["unexpected"]
+    assert res["reshaped"] == 4
+    for k, v in den.inner_model.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    for k, v in stat.state_dict().items():
+        want = s_sd[k]
+        if k == "resnet.bn1.bias":
+            want = torch.zeros_like(want)
+        if k == "resnet.layer1.0.conv1.weight":
+            want = before
+        assert torch.equal(v, want), k
+    for k, v in grip.state_dict().items():
+        want = g_sd[k]
+        if k == "resnet.bn1.weight":
+            want = half.repeat(2)
+        if k == "resnet.bn1.num_batches_tracked":
+            want = torch.tensor(5)
+        assert torch.equal(v, want), k
+    # strict=True surfaces what is absent (the reference passes `strict` through to load_state_dict)
+    with pytest.raises(RuntimeError, match="Missing key"):
+        rollout.load_agent_checkpoint({"model": den, "static_resnet": stat}, {"model.inner_model.pos_emb": sd["pos_emb"]}, strict=True)
+    # an object with the agent's attribute names works as well as the mapping
+    class _Agent:
+        pass
+    a = _Agent(); a.model, a.static_resnet, a.gripper_resnet = den, stat, grip
+    assert rollout.load_agent_checkpoint(a, path)["direct"] == res["direct"]
+
+
 @pytest.mark.gpu
 def test_chunked_rollout_policy_batch_of_envs():
     cfg = get_config("c1e4")
