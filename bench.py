@@ -55,11 +55,17 @@ def flops_executed_per_chunk(B, steps=N_SAMPLING_STEPS, L=12, D=1024, H=8, T=14,
     return steps * per_step + per_chunk
 
 
+def _dry_run_layers():
+    """MODE_BENCH_DRYRUN_LAYERS=n: a PLUMBING run of this file with an n-layer model (the world-2 test on one GPU, where the collective is gloo through
+    host memory).  The JSON line then carries "dry_run": true and is not a measurement of BASELINE's configuration."""
+    return int(os.environ.get("MODE_BENCH_DRYRUN_LAYERS", "0"))
+
+
 def build_model(device, dtype="bf16"):
     import mode_diffusion_policy_amd as M
     torch.manual_seed(0)
     m = M.MoDeDiT(obs_dim=C2["obs_dim"], goal_dim=C2["goal_dim"], device=str(device), goal_conditioned=True, action_dim=7,
-                  embed_dim=C2["embed_dim"], embed_pdrob=0, attn_pdrop=0.3, n_layers=C2["n_layers"], n_heads=C2["n_heads"],
+                  embed_dim=C2["embed_dim"], embed_pdrob=0, attn_pdrop=0.3, n_layers=_dry_run_layers() or C2["n_layers"], n_heads=C2["n_heads"],
                   goal_seq_len=1, obs_seq_len=1, action_seq_len=10, mlp_pdrop=0.1, goal_drop=0.1, num_experts=C2["num_experts"],
                   top_k=C2["top_k"], compute_dtype=dtype)
     return M, M.GCDenoiser(m.to(device).eval(), SIGMA_DATA).eval()
@@ -368,13 +374,15 @@ def cpu_baseline():
             "c1_b8": legs["c1"], "c2_b128": c2}
 
 
-def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU):
+def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU, zero1=None):
     """BASELINE configs[2]/[3]: the score-matching training step of `den` (fwd + bwd + fused AdamW) on B samples per rank, data parallel over
     `world` ranks - ONE implementation shared by `--mode train`, by the default run's extra legs (N = 1) and by the N > 1 default run, so that a
     SCALE record evidences the gradient exchange.  All ranks must call it together.  Every rank owns its own shard of the synthetic batch; the
-    gradient arena is exchanged in flat per-block slices behind the backward's block events (RCCL when `dist` is up), ZeRO-1 by default for
-    world > 1 (MODE_DP_ZERO1 = bf16 | fp32 | 0, MODE_DP_COMM = fp32 | bf16).  Timed like the contract says: barrier + synchronize on both sides,
-    MAX over ranks.  Returns the keys merged into the JSON line."""
+    gradient arena is exchanged in flat per-block slices behind the backward's block events (RCCL when `dist` is up).  Default exchange: the plain
+    overlapped all-reduce - what the reference's DDP does (mode/training_calvin.py:92-103); `zero1` ("bf16" | "fp32"; or MODE_DP_ZERO1 when the argument
+    is None) selects the sharded-optimizer variant instead; MODE_DP_COMM = fp32 | bf16 the wire dtype.  The number of ranks the collective library
+    actually connected is checked BEFORE anything is timed.  Timed like the contract says: barrier + synchronize on both sides, MAX over ranks.
+    Returns the keys merged into the JSON line."""
     import math
     from mode_diffusion_policy_amd.ddp import ArenaGradReducer
     from mode_diffusion_policy_amd.optim import FusedAdamW
@@ -392,9 +400,16 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU):
     # gradient exchange dtype: fp32 like the reference's DDP (default), or MODE_DP_COMM=bf16 = half the bytes on the xGMI links
     comm = torch.bfloat16 if os.environ.get("MODE_DP_COMM", "fp32") == "bf16" else torch.float32
     red = ArenaGradReducer.for_model(m, comm_dtype=comm) if dist is not None else None      # also with ONE rank under RCCL: same code path as N > 1
-    # data-parallel step (world > 1): ZeRO-1 by default - per block slice reduce-scatter of the gradients, AdamW on this rank's shard, all-gather of
-    # the bf16 compute shadow (MODE_DP_ZERO1=fp32 gathers the fp32 masters instead, =0 falls back to the summed all-reduce + full optimizer pass)
-    z1 = os.environ.get("MODE_DP_ZERO1", "bf16" if world > 1 else "0")
+    # data-parallel step (world > 1): summed all-reduce + full optimizer pass by default (the mode closest to the reference's DDP); ZeRO-1 on request -
+    # per block slice reduce-scatter of the gradients, AdamW on this rank's shard, all-gather of the bf16 compute shadow ("fp32": of the fp32 masters)
+    z1 = zero1 if zero1 is not None else os.environ.get("MODE_DP_ZERO1", "0")
+    ranks = 1
+    if dist is not None:                                                       # before any timed or exchanged step: did every rank join the communicator?
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)
+        ranks = int(round(float(one.item())))
+        if ranks != world:
+            raise RuntimeError(f"collective library connected {ranks} ranks, WORLD_SIZE is {world}")
     z1 = None if (z1 in ("0", "", "none") or red is None or world == 1) else z1
     if z1 == "bf16" and m.engine.compute_dtype != "bf16":
         z1 = "fp32"
@@ -417,11 +432,6 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU):
         loss = step()
     torch.cuda.synchronize()
     assert torch.isfinite(loss.detach()).all()
-    ranks = 1
-    if dist is not None:
-        one = torch.ones(1, device=device)
-        dist.all_reduce(one)                                                   # the number of ranks the collective library actually connected
-        ranks = int(round(float(one.item())))
     # Timed blocks of `steps` steps until the two fastest agree within 5 % (at most 8; all listed), the fastest reported.  (Rounds 1-2 saw 2-4x slower
     # blocks in some processes and blamed the box; round 3 found the cause - the training node leaked every step's activation stash, DESIGN.md section 4
     # "Round 3" - and with the leak fixed 800 consecutive steps stay within 0.5 %.  The block list stays in the line as the evidence.)
@@ -669,7 +679,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = torch.device("cuda", local)
+    # MODE_BENCH_SHARE_GPU=1 + MODE_BENCH_BACKEND=gloo: every rank on cuda:0 with a host-side collective - the world-2 dry run of this whole file on a
+    # ONE-GPU box (tests/test_gpu_train_dropin.py; two RCCL ranks cannot share a device).  Never set by the driver.
+    share = os.environ.get("MODE_BENCH_SHARE_GPU", "0") == "1"
+    backend = os.environ.get("MODE_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", 0 if share else local)
     torch.cuda.set_device(device)
     dist = None
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:       # launched by torch.distributed.run (also with one rank)
@@ -680,7 +694,10 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=device)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(backend)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -773,6 +790,7 @@ def main():
             dist.destroy_process_group()
         return
     res = {
+        **({"dry_run": True, "dry_run_layers": _dry_run_layers()} if _dry_run_layers() else {}),
         "metric": "denoise-steps/sec (B=128, 10-step chunk)", "value": round(value, 2), "unit": "denoise-steps/s", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -802,35 +820,51 @@ def main():
                 res.update(extra_measurements(M, den, device))
     # configs[2]/[3] in the same invocation: the data-parallel training step (ALL ranks: it holds the path's one collective).  The headline above
     # is replicas of the sampler (no collective); this leg is what a multi-GPU record can show the gradient exchange with.  Last of the GPU legs:
-    # it updates the weights.
+    # it updates the weights.  Order at N > 1: (1) the plain overlapped all-reduce - what the reference's DDP does (mode/training_calvin.py:92-103) -
+    # under the train_* keys; (2) only after that has come back, the ZeRO-1 variant under zero1_* keys.  Each leg runs under its own watchdog: the
+    # multi-rank RCCL path has only ever run with ONE rank on RCCL and with two on gloo (tests/test_gpu_train_dropin.py), so if a leg raises or does
+    # not come back, everything measured before it is still printed - with the reason.  Progress goes to stderr as each leg completes.
     train_failed = False
+    if rank == 0:
+        print(f"[bench] headline done: {res['value']} {res['unit']} on {n_gpus} GPU(s)", file=sys.stderr, flush=True)
     if args.dtype == "bf16" and not args.no_extras:
-        # The training leg is the only part of this file with a data-path collective.  It has run on RCCL with ONE rank and on gloo with two
-        # (tests/test_gpu_train_dropin.py); no multi-GPU box was available to the build.  So at N > 1 it runs under a watchdog: if it raises or does
-        # not come back, the headline line (replicas, measured above) is still printed - without the train_* keys, with the reason.
-        wd = None
-        if world > 1:
-            import threading
-            limit = float(os.environ.get("MODE_TRAIN_LEG_TIMEOUT", "240"))
+        forced = os.environ.get("MODE_DP_ZERO1")                                # an explicit choice runs as the one and only leg (A/B runs)
+        legs = [("train", forced if forced is not None else "0")]
+        if world > 1 and forced is None and os.environ.get("MODE_BENCH_ZERO1_LEG", "1") == "1":
+            legs.append(("zero1", "bf16"))
+        limit = float(os.environ.get("MODE_TRAIN_LEG_TIMEOUT", "240"))
+        for leg, z1 in legs:
+            wd = None
+            if world > 1:
+                import threading
 
-            def _bail():
+                def _bail(leg=leg):
+                    if rank == 0:
+                        res[f"{leg}_leg_error"] = f"no result after {limit:.0f} s (collective did not complete): reported without this leg"
+                        print(json.dumps(res), flush=True)
+                    os._exit(0)
+                wd = threading.Timer(limit, _bail)
+                wd.daemon = True
+                wd.start()
+            try:
+                out = train_leg(den, device, world, rank, dist, zero1=z1, steps=int(os.environ.get("MODE_BENCH_TRAIN_STEPS", "10")))
+                if leg == "train":
+                    res.update(out)
+                else:                                                           # second set of keys, after the headline and the all-reduce leg
+                    res.update({("zero1_" + k[len("train_"):] if k.startswith("train_") else "zero1_" + k): v for k, v in out.items()})
                 if rank == 0:
-                    res["train_leg_error"] = f"no result after {limit:.0f} s (collective did not complete): headline reported without the training leg"
-                    print(json.dumps(res), flush=True)
-                os._exit(0)
-            wd = threading.Timer(limit, _bail)
-            wd.daemon = True
-            wd.start()
-        try:
-            res.update(train_leg(den, device, world, rank, dist))
-        except Exception as e:                                              # noqa: BLE001
-            if world == 1:
-                raise
-            train_failed = True
-            res["train_leg_error"] = repr(e)[:400]
-        finally:
-            if wd is not None:
-                wd.cancel()
+                    print(f"[bench] {leg} leg done: {out['train_ms_per_step']} ms/step, {out['train_samples_per_s']} samples/s, mode {out['dp_mode']}, "
+                          f"{out['dp_ranks']} rank(s) on {out['dp_backend']}", file=sys.stderr, flush=True)
+            except Exception as e:                                              # noqa: BLE001
+                if world == 1:
+                    raise
+                train_failed = True
+                res[f"{leg}_leg_error"] = repr(e)[:400]
+            finally:
+                if wd is not None:
+                    wd.cancel()
+            if train_failed:
+                break
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()

@@ -403,6 +403,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
 enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x64_NS3 = 4, CFG_128x128_NS1 = 6, CFG_128x64_NS2 = 8, CFG_128x128_NS1_4WG = 13, CFG_64x64_NS3 = 14,
        CFG_PP224 = 17, CFG_PP256 = 18 };
 int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p, int rows256, hipStream_t s);   // gemm_bf16_pp.hip: persistent ping-pong kernel, 224 / 256 x 256 tiles
+int pp_num_cus();                                                                                   // gemm_bf16_pp.hip: compute units of the current device (= its grid)
 int gemm_bf16_skinny_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_skinny.hip: weight streamer for a handful of rows
 int gemm_bf16_mid_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);      // gemm_bf16_skinny.hip: register-resident weights, no K loop (a few hundred rows)
 int g_gemm_mid_rows = 128;   // "gemm_mid_rows" option: ungrouped K = 1024 GEMMs with at most this many rows take gemm_bf16_mid_kernel (0 = off).  Measured chunk latency B = 4: 6.89 -> 6.60 ms, B = 8: 7.40 -> 7.14 ms; from ~200 rows on the M/32 re-reads of W through L2 cost more than the ring kernel (B = 16: 8.41 -> 8.50 ms, B = 32: 9.21 -> 9.48 ms)
@@ -471,8 +472,9 @@ static int pick_cfg(const ModeGemmDesc* d, bool allow_pp) {
       (d->epilogue == MODE_EPI_NONE || d->epilogue == MODE_EPI_BIAS) && d->N % 256 == 0) {
     const long per = (long)((double)rows / d->num_experts * 1.06) + 1;
     const long t4 = (long)d->num_experts * ((per + 255) / 256) * (d->N / 256);
-    const long rounds = (t4 + 255) / 256;
-    if (t4 >= 256 && t4 * 10 >= rounds * 256 * 9) return CFG_PP256;
+    const long ncu = pp_num_cus();                              // one persistent workgroup per CU: a "round" is one tile on every CU of THIS part
+    const long rounds = (t4 + ncu - 1) / ncu;
+    if (t4 >= ncu && t4 * 10 >= rounds * ncu * 9) return CFG_PP256;
   }
   const int nout128 = (d->epilogue == MODE_EPI_SWIGLU) ? 64 : 128;
   const long t128 = ((rows + 127) / 128) * ((d->N + nout128 - 1) / nout128);

@@ -544,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------ host side
-static int pp_num_cus() {
+int pp_num_cus() {   // also used by the tile heuristic (gemm_bf16.hip: pick_cfg)
   static int ncu[16] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;

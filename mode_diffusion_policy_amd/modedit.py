@@ -481,8 +481,13 @@ class MoDeDiT(nn.Module):
         # identity of the schedule: a host-side tag of its VALUES when the tensor came from a get_sigmas_* / get_noise_schedule generator (the
         # agent builds a fresh tensor per chunk, mode_agent.py:752) - else the caller's tensor OBJECT (kept alive below, so neither its id nor its
         # storage can be recycled while the key is live) -, the weights, and the routing cache generation.  No device read on either path.
+        # A tag only vouches for the values the generator wrote: once the tensor has been edited in place (its version moved past the one recorded in
+        # the tag) two tagged tensors with different edits would share (tag, version) - such a tensor is identified as an object, with the device
+        # compare below as the fallback, like any untagged tensor.
         tag = getattr(sigmas, "_mode_sched", None)
-        sid = ("tag", tag, sigmas._version) if tag is not None else ("obj", id(sigmas), sigmas._version)
+        if tag is not None and sigmas._version != tag[3]:
+            tag = None
+        sid = ("tag", tag) if tag is not None else ("obj", id(sigmas), sigmas._version)
         sched_key = (sid, eng._wkey, getattr(self, "_fused_gen", 0))
         if ent is None or ent["key"] != key:
             st = dict(key=key, img=img.clone(), goals=goals.clone(), x=x0.clone().contiguous(), sig=sig.clone())

@@ -65,7 +65,10 @@ class _BnFilmAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b, sync_group=None,
-                num_batches_tracked=None):
+                num_batches_tracked=None, grad_enabled=True):
+        # ``grad_enabled``: torch.is_grad_enabled() at the CALL site (inside Function.forward it is always False, and ctx.needs_input_grad reflects the
+        # inputs' requires_grad even under torch.no_grad()): under no_grad nothing will be back-propagated, whatever the parameters say
+        wants_grad = grad_enabled and any(ctx.needs_input_grad)
         if x.device.type != "cuda":
             raise L.ModeHipUnavailable("FiLM-ResNet encoders run through the HIP library only: inputs must live on a ROCm device")
         lib = L.load()
@@ -81,7 +84,7 @@ class _BnFilmAct(torch.autograd.Function):
         w, b = f32(weight), f32(bias)
         m = N * HW
         fp32_buf = lambda t: t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == dev)
-        if (not training and not any(ctx.needs_input_grad) and running_mean is not None and fp32_buf(running_mean) and fp32_buf(running_var)
+        if (not training and not wants_grad and running_mean is not None and fp32_buf(running_mean) and fp32_buf(running_var)
                 and Cc % 4 == 0):
             # inference (the rollout): the eval-mode BatchNorm is folded INSIDE the pass from the module's own buffers - one launch per BatchNorm
             pre = (f32(pre_g).reshape(N, Cc), f32(pre_b).reshape(N, Cc)) if pre_g is not None else None
@@ -186,7 +189,7 @@ class _BnFilmAct(torch.autograd.Function):
         ps, qs = ctx.shapes
         rs = lambda t, shp: None if t is None else t.reshape(shp)
         # inputs: x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b
-        return dx, dw, db, None, None, None, None, None, None, dres, rs(dpg, ps), rs(dpb, ps), rs(dqg, qs), rs(dqb, qs), None, None
+        return dx, dw, db, None, None, None, None, None, None, dres, rs(dpg, ps), rs(dpb, ps), rs(dqg, qs), rs(dqb, qs), None, None, None
 
 
 # Activation layout inside the encoders.  True: torch.channels_last - MIOpen's implicit-GEMM convolutions run on NHWC data and wrap NCHW tensors in
@@ -245,7 +248,7 @@ def bn_film_act(x, bn: nn.BatchNorm2d, relu: bool = True, residual=None, pre_fil
             sync = bn.process_group if bn.process_group is not None else True
     training = bn.training or bn.running_mean is None                       # no running statistics -> batch statistics also in eval (nn.BatchNorm2d)
     return _BnFilmAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, relu, residual, pg, pb, qg, qb, sync,
-                            bn.num_batches_tracked if bn.training else None)
+                            bn.num_batches_tracked if bn.training else None, torch.is_grad_enabled())
 
 
 # ------------------------------------------------------------------------------------------------------------------ trunk (parameter holders)
@@ -464,9 +467,12 @@ class GraphedVisualEncoder:
         out = {}
         for m in convs:
             w = m.weight
-            ent = cache.get(id(m))
-            if ent is None or ent[2].dtype != dtype or ent[2].device != w.device:
-                ent = cache[id(m)] = [None, None, torch.empty_like(w, dtype=dtype)]
+            # one copy per (convolution, dtype, device): a graph captured for another input dtype keeps reading ITS copies - nothing a captured graph
+            # points at is ever re-allocated while the parameter itself stays where it is (a moved parameter changes _param_key -> new graphs)
+            ck = (id(m), dtype, str(w.device))
+            ent = cache.get(ck)
+            if ent is None:
+                ent = cache[ck] = [None, None, torch.empty_like(w, dtype=dtype)]
             if ent[0] != w._version or ent[1] != w.data_ptr():
                 ent[2].copy_(w)
                 ent[0], ent[1] = w._version, w.data_ptr()
@@ -474,7 +480,9 @@ class GraphedVisualEncoder:
         return out
 
     def _param_key(self):
-        return tuple(p.data_ptr() for m in (self.static_resnet, self.gripper_resnet) for p in list(m.parameters())[:2] + list(m.parameters())[-2:])
+        """Fingerprint of where EVERY tensor the captured graphs read lives (convolution / BatchNorm / FiLM parameters and the BatchNorm buffers of both
+        encoders): a re-allocated interior tensor (``p.data = ...``, ``.to()``, ``.half()``) must re-capture, not replay against freed memory."""
+        return hash(tuple(t.data_ptr() for m in (self.static_resnet, self.gripper_resnet) for t in list(m.parameters()) + list(m.buffers())))
 
     @torch.no_grad()
     def __call__(self, rgb_static: torch.Tensor, rgb_gripper: torch.Tensor, latent_goal: Optional[torch.Tensor] = None):

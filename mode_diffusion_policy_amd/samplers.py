@@ -32,7 +32,7 @@ def tag_schedule(sigmas: torch.Tensor, *key) -> torch.Tensor:
     """Attach the host-side identity of a schedule's VALUES (generator name + arguments) to the tensor object.  ``MoDEAgent.denoise_actions``
     builds a fresh schedule tensor for every chunk (mode_agent.py:752, 842-861); the fused sampler recognises an unchanged schedule by this tag
     instead of comparing device values (a host sync) or trusting a recyclable data pointer."""
-    sigmas._mode_sched = (key, str(sigmas.device), str(sigmas.dtype))
+    sigmas._mode_sched = (key, str(sigmas.device), str(sigmas.dtype), sigmas._version)     # the tag describes the values AT THIS VERSION only
     return sigmas
 
 

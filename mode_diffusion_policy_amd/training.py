@@ -13,6 +13,7 @@ launches; ``diffusion_loss`` / ``training_step`` restate ``MoDEAgent.diffusion_l
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from typing import Dict
 
@@ -122,9 +123,15 @@ class TrainState:
             return self._mg, ar.g_by_name
         from .arena import param_views
         g = ar._views(flat)
-        mg, lgr = self._tables(g)
-        self._tmp_tables = (mg, lgr)                                            # keep the ctypes arrays alive across the launch
-        return mg, param_views(m, g)
+        # the ctypes tables hold absolute addresses: cached per base pointer (the caching allocator hands a freed 2.7-GB block straight back, so a
+        # training loop in autograd mode builds them once); the parameter views must be views of THIS tensor object and are rebuilt
+        cache = self.__dict__.setdefault("_flat_tables", {})
+        hit = cache.get(flat.data_ptr())
+        if hit is None:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            hit = cache[flat.data_ptr()] = self._tables(g)
+        return hit[0], param_views(m, g)
 
     def _tables(self, g):
         m = self.eng.model
@@ -367,10 +374,21 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         own = grad_mode != "arena" or accumulate
         # (accumulate: zero-filled - the chain does not write the 256-byte alignment gaps between tensors, and whatever sits there would be added
         # into the arena's gaps; autograd mode only ever exposes per-tensor views)
+        # Memory: in autograd mode every backward allocates one buffer of the arena's size (2.7 GB at C2) and the p.grad views AccumulateGrad keeps
+        # pin it until the gradients are dropped; a two-modality training_step holds two plus the accumulated one.  The buffer is NOT zero-filled
+        # (0.5 ms per backward at C2): the chain writes every element of every tensor it returns - MODE_DEBUG_GRAD_COVERAGE=1 checks exactly that
+        # (NaN pre-fill, every returned view must come back finite; tests/test_gpu_train_dropin.py runs it over the shipped layouts).
+        debug_cov = own and not accumulate and os.environ.get("MODE_DEBUG_GRAD_COVERAGE", "0") == "1"
         flat = (torch.zeros if accumulate else torch.empty)(ar.bounds["total"], device=dev) if own else None
+        if debug_cov:
+            flat.fill_(float("nan"))
         mg, gv = ts.grad_tables(flat)
         L.check(lib.mode_dit_backward(C.byref(d), C.byref(eng._mw), C.byref(ts.wt), C.byref(args), stash.data_ptr(), dF.data_ptr(), C.byref(mg),
                                       ts._ws.data_ptr(), ts._ws.numel(), _stream()), "backward")
+        if debug_cov:
+            holes = [n for n in names if not bool(torch.isfinite(gv[n]).all())]
+            if holes:
+                raise RuntimeError(f"backward chain left gradient elements unwritten (or non-finite) in: {holes[:8]}")
         if grad_mode != "arena":
             return d_img, d_goal, [gv[n].view(p.shape) for n, p in zip(names, params)]
         if accumulate:

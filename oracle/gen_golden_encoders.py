@@ -71,6 +71,50 @@ def main():
         print(tag, "out", tuple(y.shape), "params", sum(p.numel() for p in m.parameters()), "tensors with grad", len(names), flush=True)
     np.savez_compressed(os.path.join(OUT, "F15_encoders.npz"), B=B, cond_dim=cond_dim, **out)
     print("wrote F15_encoders.npz", os.path.getsize(os.path.join(OUT, "F15_encoders.npz")) // 1024, "KiB")
+    deep_trunks_training_fixture(P, cond_dim)
+
+
+DEEP_B, DEEP_HW, DEEP_SEED, DEEP_KEEP = 16, 128, 9, (0, 5, 10, 15)
+
+
+def deep_inputs(cond_dim):
+    """Inputs of F15b, regenerated from the seed by the test as well (3 MB of images that need not be stored)."""
+    rs = np.random.RandomState(DEEP_SEED)
+    img = torch.from_numpy(rs.standard_normal((DEEP_B, 3, DEEP_HW, DEEP_HW)).astype(np.float32))
+    cond = torch.from_numpy(rs.standard_normal((DEEP_B, 1, cond_dim)).astype(np.float32))
+    return img, cond
+
+
+def deep_trunks_training_fixture(P, cond_dim):
+    """F15b: TRAINING-mode forward + backward of the 34- / 50-layer encoders (the reference's classes) in FLOAT64 on 16 frames of 128 x 128.
+    Why fp64: the gradient through 36 / 53 training-mode BatchNorms amplifies fp32 rounding so much that the reference's OWN fp32 run is 0.6-1.8e-2
+    (ResNet-34) / 1.6-2.6e-2 (ResNet-50) away from this one (oracle/measure_fp32_encoder_grad_gap.py -> tests/golden/fp32_encoder_grad_gap.json) - an
+    fp32 fixture would carry that much noise itself.  d img is stored for four of the sixteen frames + its norm over all; values are stored as fp32."""
+    img, cond = deep_inputs(cond_dim)
+    out = {}
+    f32 = lambda t: t.detach().to(torch.float32).numpy()
+    for tag, ctor, seed in (("r50", lambda: P.FiLMResNet50Policy(cond_dim), 500), ("r34", lambda: P.FiLMResNet34Policy(cond_dim), 501)):
+        m = ctor()
+        m.load_state_dict(R.fill_encoder_state_dict(m.state_dict(), seed))
+        m = m.double().train()
+        xi = img.double().requires_grad_(True); ci = cond.double().requires_grad_(True)
+        yt = m(xi, ci)
+        w = torch.from_numpy(np.random.RandomState(seed + 1).standard_normal(tuple(yt.shape)).astype(np.float32))
+        (yt * w.double()).sum().backward()
+        out[f"{tag}_train"] = f32(yt); out[f"{tag}_w"] = w.numpy()
+        out[f"{tag}_dimg_keep"] = f32(xi.grad[list(DEEP_KEEP)]); out[f"{tag}_dimg_norm"] = np.float64(xi.grad.norm())
+        out[f"{tag}_dcond"] = f32(ci.grad)
+        params = dict(m.named_parameters())
+        names = [k for k, p in params.items() if p.grad is not None]
+        pick = [names[0], names[len(names) // 3], names[2 * len(names) // 3]] + [k for k in names if "film" in k][:4] + [k for k in names if k.endswith("bn1.weight")][:2]
+        for k in dict.fromkeys(pick):
+            if params[k].numel() <= 300_000:
+                out[f"{tag}_g:{k}"] = f32(params[k].grad)
+        out[f"{tag}_gn_keys"] = np.array(names); out[f"{tag}_gn_vals"] = np.array([float(params[k].grad.norm()) for k in names], dtype=np.float64)
+        out[f"{tag}_rm"] = f32(m.state_dict()[[k for k in m.state_dict() if k.endswith("bn1.running_mean")][0]])
+        print("F15b", tag, "train out", tuple(yt.shape), flush=True)
+    np.savez_compressed(os.path.join(OUT, "F15b_encoders_train.npz"), B=DEEP_B, HW=DEEP_HW, seed=DEEP_SEED, keep=np.array(DEEP_KEEP), cond_dim=cond_dim, **out)
+    print("wrote F15b_encoders_train.npz", os.path.getsize(os.path.join(OUT, "F15b_encoders_train.npz")) // 1024, "KiB")
 
 
 if __name__ == "__main__":

@@ -136,6 +136,29 @@ def test_ddim_vs_golden(golden, cfgname, dtype, graph, monkeypatch):
     assert rel(x3, x) < (1e-5 if dtype == "fp32" else BF16_OUT)
 
 
+def test_tagged_schedules_edited_in_place_are_not_confused():
+    """Two schedules from the same generator call carry the same value tag; edited in place DIFFERENTLY (both at version 1) they must not share a
+    schedule state: the tag only vouches for the values the generator wrote (round-3 advisor finding)."""
+    cfg, sd, m = build("c1e4", 210, "fp32")
+    inp = cuda_inputs(make_inputs(cfg, 4, 9))
+    den = M.GCDenoiser(m, 0.5).eval()
+    st = {"state_images": inp["state_images"]}
+    cpu = {k: v.cpu() for k, v in inp.items()}
+    base = M.get_sigmas_exponential(6, 1e-3, 80.0, "cuda")
+    x_base = M.sample_ddim(den, st, inp["x0"], inp["goals"], base, disable=True)
+    s1 = M.get_sigmas_exponential(6, 1e-3, 80.0, "cuda"); s1[2] = 7.5
+    s2 = M.get_sigmas_exponential(6, 1e-3, 80.0, "cuda"); s2[4] = 0.02
+    assert s1._version == s2._version
+    x1 = M.sample_ddim(den, st, inp["x0"], inp["goals"], s1, disable=True)
+    x2 = M.sample_ddim(den, st, inp["x0"], inp["goals"], s2, disable=True)
+    for x, s in ((x_base, base), (x1, s1), (x2, s2)):
+        ref = O.sample_ddim(sd, cfg, 0.5, cpu["state_images"], cpu["x0"], cpu["goals"], s.cpu())
+        assert rel(x, ref) < FP32_OUT
+    assert not torch.equal(x1, x2) and not torch.equal(x1, x_base)
+    # an untouched twin of the generator call still takes the tag path and replays the unchanged schedule
+    assert torch.equal(M.sample_ddim(den, st, inp["x0"], inp["goals"], M.get_sigmas_exponential(6, 1e-3, 80.0, "cuda"), disable=True), x_base)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_gcdenoiser_forward_vs_oracle(dtype):
     cfg, sd, m = build("c1e4", 210, dtype)

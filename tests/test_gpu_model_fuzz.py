@@ -7,7 +7,7 @@ The stated bf16 tolerance (1e-2 rel-L2) was grounded on the reference's own fp32
 a-bis) and stays asserted there (test_gpu_model.py).  Across random geometries bf16 is noisier for narrow models, few-valued outputs and
 un-normalised top-1 routing: in the 400-case sweep five cases reached 1.01e-2 ... 1.12e-2 - and at exactly those five the REFERENCE's own
 fp32-vs-bf16-autocast gap is 0.6e-2 ... 1.7e-2 (oracle/measure_bf16_fwd_gap_geometries.py -> tests/golden/bf16_fwd_gap_geometries.json),
-i.e. the HIP path sits inside the reference's bf16 noise.  That is why the ONE bf16 output tolerance of the suite (tests/tolerances.py) is 2e-2."""
+i.e. the HIP path sits inside the reference's bf16 noise.  That is why THIS file (and only this file) asserts tolerances.BF16_OUT_FUZZ = 2e-2."""
 import dataclasses
 import os
 import random
@@ -22,7 +22,7 @@ import mode_diffusion_policy_amd as M  # noqa: E402
 from oracle import mode_oracle as O  # noqa: E402
 from oracle.weights import make_inputs, make_state_dict  # noqa: E402
 
-from tolerances import OUT as TOL  # noqa: E402  (one number per quantity: tests/tolerances.py)
+from tolerances import OUT_FUZZ as TOL  # noqa: E402  (random geometries: the 2e-2 bf16 envelope; fixture geometries keep 1e-2, tests/tolerances.py)
 
 
 def rel(a, b):

@@ -134,6 +134,27 @@ def test_autograd_mode_fires_hooks_and_accumulates_like_autograd(dtype):
         a.backward()
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("variant", ["default", "stochastic", "token_routing", "goal_routing", "no_noise_token", "c2block"])
+def test_autograd_mode_backward_writes_every_gradient_element(variant, dtype, monkeypatch):
+    """``grad_mode='autograd'`` hands out views of an UNINITIALISED per-backward buffer (round-3 advisor finding): the chain must write every element of
+    every tensor it returns.  MODE_DEBUG_GRAD_COVERAGE=1 pre-fills the buffer with NaN and raises on anything left behind - run over the layouts the
+    library ships (conditioning / token / goal routing, with and without the noise token, multinomial routing + dropouts, the wide block)."""
+    monkeypatch.setenv("MODE_DEBUG_GRAD_COVERAGE", "1")
+    over = {"default": {}, "stochastic": dict(use_argmax=False, attn_pdrop=0.3, mlp_pdrop=0.1), "token_routing": dict(cond_router=False),
+            "goal_routing": dict(use_goal_in_routing=True), "no_noise_token": dict(use_noise_token_as_input=False), "c2block": {}}[variant]
+    cfg, sd, m = build_train("c2block" if variant == "c2block" else "c1e4", 210, dtype, **over)
+    B = 24
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, B, 3).items()}
+    sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(9)).cuda()
+    den = M.GCDenoiser(m, 0.5).train()
+    loss, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
+    (loss + 0.01 * m.load_balancing_loss() + 0.001 * m.compute_router_z_loss()).backward()
+    for n, p in m.named_parameters():
+        if n != "gripper_embed.weight":
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_accumulated_backwards_then_overlapped_step_with_reducer(overlap):
     """Two backwards before the optimizer step (arena mode), then ``FusedAdamW.step(overlap=..., reducer=...)``: the per-block events the optimizer /
@@ -269,9 +290,12 @@ def _bench_leg_worker(rank, world, port, outdir):
         torch.cuda.set_device(0)
         cfg, sd, m = build_train("c1e4", 210, "bf16", attn_pdrop=0.3, mlp_pdrop=0.1, goal_drop=0.1, use_argmax=False)
         den = M.GCDenoiser(m, 0.5)
-        out = bench.train_leg(den, torch.device("cuda", 0), world, rank, dist, steps=3, warmup=1, B=8)
+        out = bench.train_leg(den, torch.device("cuda", 0), world, rank, dist, steps=3, warmup=1, B=8)                    # default: overlapped all-reduce
         torch.cuda.synchronize()
         out["_w_sum"] = float(m.engine.arena.flat.double().sum())
+        z = bench.train_leg(den, torch.device("cuda", 0), world, rank, dist, steps=3, warmup=1, B=8, zero1="bf16")     # then the sharded optimizer
+        torch.cuda.synchronize()
+        out["_zero1"] = dict(z, _w_sum=float(m.engine.arena.flat.double().sum()))
         json.dump(out, open(os.path.join(outdir, f"b{rank}.json"), "w"))
     finally:
         dist.destroy_process_group()
@@ -279,8 +303,8 @@ def _bench_leg_worker(rank, world, port, outdir):
 
 def test_bench_train_leg_world2_dry_run_and_rccl_world1(tmp_path):
     """`bench.py --gpus N` runs `train_leg` on every rank so that a multi-GPU record shows the gradient exchange (BASELINE configs[3]).  Exactly that
-    function: (a) world 2 on ONE GPU over gloo (two RCCL ranks cannot share a device) - ZeRO-1 default, all keys present, both ranks end with the
-    same weights; (b) world 1 under RCCL, the way the driver launches N = 1 through torch.distributed.run."""
+    function: (a) world 2 on ONE GPU over gloo (two RCCL ranks cannot share a device) - the all-reduce default, then ZeRO-1 on the same model, all keys
+    present, both ranks end with the same weights after each; (b) world 1 under RCCL, the way the driver launches N = 1 through torch.distributed.run."""
     import json
     import sys
     import torch.distributed as dist
@@ -295,9 +319,11 @@ def test_bench_train_leg_world2_dry_run_and_rccl_world1(tmp_path):
         assert p.exitcode == 0
     r = [json.load(open(tmp_path / f"b{i}.json")) for i in range(2)]
     keys = {"train_ms_per_step", "train_samples_per_s", "dp_mode", "exposed_exchange_and_optimizer_ms", "rccl_ranks", "dp_ranks", "dp_backend"}
-    assert keys <= set(r[0]) and r[0]["dp_ranks"] == 2 and r[0]["dp_mode"] == "zero1:bf16" and r[0]["dp_backend"] == "gloo" and r[0]["rccl_ranks"] is None
+    assert keys <= set(r[0]) and r[0]["dp_ranks"] == 2 and r[0]["dp_mode"] == "allreduce" and r[0]["dp_backend"] == "gloo" and r[0]["rccl_ranks"] is None
     assert r[0]["train_global_batch"] == 16 and r[0]["train_ms_per_step"] == r[1]["train_ms_per_step"]      # MAX over ranks, whole-job rate
     assert r[0]["_w_sum"] == r[1]["_w_sum"]                                                                 # ranks end with identical weights
+    z = [x["_zero1"] for x in r]
+    assert keys <= set(z[0]) and z[0]["dp_mode"] == "zero1:bf16" and z[0]["dp_ranks"] == 2 and z[0]["_w_sum"] == z[1]["_w_sum"] != r[0]["_w_sum"]
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("nccl", rank=0, world_size=1)
@@ -309,6 +335,34 @@ def test_bench_train_leg_world2_dry_run_and_rccl_world1(tmp_path):
         assert out["rccl_ranks"] == 1 and out["dp_backend"] == "nccl" and out["dp_mode"] == "single" and out["train_ms_per_step"] > 0
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_main_world2_end_to_end_through_torch_distributed_run(tmp_path):
+    """The WHOLE of bench.py the way the driver launches N = 2 - ``python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`` - on this
+    one-GPU box: both ranks on cuda:0, the collective on gloo (MODE_BENCH_SHARE_GPU / MODE_BENCH_BACKEND), a 1-layer model (MODE_BENCH_DRYRUN_LAYERS:
+    the gloo exchange goes through host memory).  Checks the control flow a SCALE run takes and nothing else: rendezvous, replica headline with
+    MAX-over-ranks timing, all-reduce training leg first (rank count verified before timing), ZeRO-1 leg second under its own keys, ONE JSON line on
+    stdout from rank 0, clean exit of both ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MODE_BENCH_SHARE_GPU="1", MODE_BENCH_BACKEND="gloo", MODE_BENCH_DRYRUN_LAYERS="1", MODE_BENCH_TRAIN_STEPS="2",
+               MODE_TRAIN_LEG_TIMEOUT="200", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MODE_DP_ZERO1", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["dry_run"] is True and r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["global_batch"] == 256 and r["value"] > 0
+    assert r["dp_mode"] == "allreduce" and r["dp_ranks"] == 2 and r["dp_backend"] == "gloo" and r["train_global_batch"] == 256 and r["train_ms_per_step"] > 0
+    assert r["zero1_dp_mode"] == "zero1:bf16" and r["zero1_dp_ranks"] == 2 and r["zero1_ms_per_step"] > 0
+    assert "train_leg_error" not in r and "zero1_leg_error" not in r
+    assert "[bench] headline done" in p.stderr and "[bench] train leg done" in p.stderr and "[bench] zero1 leg done" in p.stderr
 
 
 # ---------------------------------------------------------------------------------------------- cond_router=False: token routing in TRAINING

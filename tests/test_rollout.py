@@ -213,6 +213,22 @@ def test_policy_with_graphed_perceptual_encoders():
     out = pol.encoders(obs["rgb_obs"]["rgb_static"], obs["rgb_obs"]["rgb_gripper"], goal)["state_images"]     # batch statistics: eager path
     assert out.shape == (B, 2, encs[0].resnet.num_features) and torch.isfinite(out).all()
     encs[0].eval()
+    # (round-3 advisor finding) an INTERIOR tensor re-allocated behind the graph's back - a BatchNorm weight in the middle of the trunk replaced through
+    # ``.data`` - must re-capture instead of replaying against the freed storage; a second input dtype gets its own weight copies and graph, and the
+    # first dtype's graph still replays correctly afterwards
+    obs = frames()
+    with torch.no_grad():
+        bn = encs[1].resnet.layer2[0].bn1
+        bn.weight.data = bn.weight.data.clone() * 1.5
+        tok = M.embed_visual_obs(encs[0], encs[1], obs["rgb_obs"]["rgb_static"], obs["rgb_obs"]["rgb_gripper"], goal)["state_images"]
+    got = pol.encoders(obs["rgb_obs"]["rgb_static"], obs["rgb_obs"]["rgb_gripper"], goal)["state_images"]
+    assert float((got - tok).abs().max()) < 1e-5 * float(tok.abs().max()) and len(pol.encoders._graphs) == 2
+    half = pol.encoders(obs["rgb_obs"]["rgb_static"].bfloat16(), obs["rgb_obs"]["rgb_gripper"].bfloat16(), goal)["state_images"]
+    assert float((half.float() - tok).norm() / tok.norm()) < 5e-2 and len(pol.encoders._graphs) == 3
+    again = pol.encoders(obs["rgb_obs"]["rgb_static"], obs["rgb_obs"]["rgb_gripper"], goal)["state_images"]
+    assert float((again - tok).abs().max()) < 1e-5 * float(tok.abs().max()) and len(pol.encoders._graphs) == 3
+    # folded-BatchNorm inference path (one launch per BatchNorm) is taken under no_grad even though the BatchNorm weights require grad
+    assert all(p.requires_grad for p in encs[0].parameters())
     with pytest.raises(ValueError):
         ref.step(frames(), goal)
 

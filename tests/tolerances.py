@@ -7,9 +7,11 @@ bf16 arithmetic (conditioning-row routing: the shipped configuration).
 * fp32 compute mode: the north star's 1e-3 (measured 5e-7 ... 2e-5).
 * bf16 compute mode (the benchmarked one): ONE number per quantity, each the envelope of the REFERENCE's own fp32-vs-``torch.autocast(bfloat16)``
   gap measured on CPU with identical routing (the generating scripts and their outputs are committed):
-    - outputs (predicted noise F, denoised, sampler results): 2e-2.  Reference gap: 4-6e-3 at the C1 / C2 geometries (SURVEY.md section 8 a-bis),
-      0.6-1.7e-2 on small random geometries (oracle/measure_bf16_fwd_gap_geometries.py -> tests/golden/bf16_fwd_gap_geometries.json).  Measured
-      here: 3-5e-3 at C1 / C2 (printed by the tests), <= 1.12e-2 over 400 random geometries.
+    - outputs (predicted noise F, denoised, sampler results) at the FIXTURE geometries - C1, C2, the C2 block, c1e4, and the full-size benchmarked
+      model: 1e-2, the number SURVEY.md section 8 a-bis states (reference gap there: 4-6e-3; measured here: 3-9e-3, printed by the tests).
+    - the same outputs on RANDOM geometries (test_gpu_model_fuzz.py only): 2e-2.  Narrow models, few-valued outputs and un-normalised top-1 routing
+      are noisier in bf16 for ANY implementation: the reference's own gap there is 0.6-1.7e-2 (oracle/measure_bf16_fwd_gap_geometries.py ->
+      tests/golden/bf16_fwd_gap_geometries.json); measured here <= 1.12e-2 over 400 random geometries.
     - loss: 1e-2 (reference gap <= 7e-4).
     - model output of the TRAINING forward (per-token multinomial routing, attention dropout 0.3 / expert dropout 0.1 with their 1/(1-p)
       rescaling): 4e-2, the envelope of the gradients that are computed from it (measured 2.0e-2 at full C2 size, B = 128; eval-mode forward
@@ -17,7 +19,7 @@ bf16 arithmetic (conditioning-row routing: the shipped configuration).
     - gradients of the one- / two-block fixtures (oracle/measure_bf16_grad_gap.py -> tests/golden/bf16_grad_gap.json): per tensor 4e-2 (reference:
       worst 3.8e-2, attention key bias; medians 0.7-1.1e-2), gradient norms 2.5e-2 (reference <= 2.3e-2).
     - gradients of the FULL 12-block model (oracle/measure_bf16_grad_gap_c2_full.py -> tests/golden/bf16_grad_gap_c2_full.json: the reference
-      with an fp32 router, fp32 vs autocast, identical routing): per tensor 8e-2.  The rounding accumulates through twelve blocks down and back
+      with an fp32 router, fp32 vs autocast, identical routing): per tensor 6e-2.  The rounding accumulates through twelve blocks down and back
       up - the reference's own gap there: median 2.6-2.8e-2, p90 5.1-6.3e-2, worst tensor of a block 5.5e-2 ... 4.3e-1, and the cancellation-
       dominated tensors (router MLPs: differences of <dy, Y> dot products; attention key bias: ~0 by shift invariance of the softmax) 0.1 ... 3.3.
       Measured here at full size: worst sampled tensor 4.5e-2 (a router weight), everything else < 4e-2.
@@ -28,16 +30,18 @@ FP32_OUT = 1e-3
 FP32_LOSS = 1e-4
 FP32_GRAD = 2e-3
 
-BF16_OUT = 2e-2
+BF16_OUT = 1e-2            # fixture geometries + the full-size benchmarked model
+BF16_OUT_FUZZ = 2e-2       # random geometries (tests/test_gpu_model_fuzz.py) and the dpm_fast sampler (tests/test_samplers.py: 2.5x the error amplification of the others, fp32 too)
 BF16_LOSS = 1e-2
 BF16_GRAD = 4e-2
 BF16_GRAD_NORM = 2.5e-2
-BF16_GRAD_FULL_DEPTH = 8e-2
+BF16_GRAD_FULL_DEPTH = 6e-2
 BF16_TRAIN_OUT = 4e-2
 
 BF16_TOKROUTE_AGREE = 0.97
 BF16_TOKROUTE_OUT = 5e-2
 
 OUT = {"fp32": FP32_OUT, "bf16": BF16_OUT}
+OUT_FUZZ = {"fp32": FP32_OUT, "bf16": BF16_OUT_FUZZ}
 LOSS = {"fp32": FP32_LOSS, "bf16": BF16_LOSS}
 GRAD = {"fp32": FP32_GRAD, "bf16": BF16_GRAD}
