@@ -293,9 +293,18 @@ def layer_kernel_breakdown(den, device, reps=120):
         L.check(lib.mode_moe_combine_norm_fused_fwd(xo.data_ptr(), ss.data_ptr(), D // 64, kp["ln2_g"][l].data_ptr(), Y.data_ptr(), L.MODE_BF16, S, NK * D,
                                                     mp + 4 * ml.pos, mp + 4 * ml.posw, N, D, k, kp["ln1_g"][(l + 1) % Ly].data_ptr(), cond.data_ptr(), N, 1e-6,
                                                     x.data_ptr(), h.data_ptr(), L.MODE_BF16, st))
+    def qkv_attn(i, st):
+        l = i % Ly
+        qa = L.ModeQkvAttnDesc(dtype=L.MODE_BF16, B=B, T=T, H=H, D=D, h=h.data_ptr(), ldh=D, wqkv=kp[f"l{l}.wqkv"].data_ptr(), ldw=D, bqkv=kp[f"l{l}.bqkv"].data_ptr(),
+                               q_gain=kp["qn_g"][l].data_ptr(), k_gain=kp["kn_g"][l].data_ptr(), eps=1e-6, y=yat.data_ptr(), ldy=D)
+        L.check(lib.mode_qkv_attn_fwd(C.byref(qa), st))
     MB = 1e6
-    items = [("qkv_gemm", gemm(qkv_d), "mfma", 2.0 * N * D * 3 * D),
-             ("attention", attn, "hbm", (N * 3 * D + N * D) * 2.0),
+    attn_flops = 4.0 * B * H * T * T * (D // H)
+    # the chain runs QKV projection + attention as ONE launch at this batch (round 4, qkv_attn.hip); the two kernels it replaces are timed for reference
+    # ("unfused:" entries, not part of sum_us)
+    items = [("qkv_gemm+attention", qkv_attn, "mfma", 2.0 * N * D * 3 * D + attn_flops),
+             ("unfused:qkv_gemm", gemm(qkv_d), "mfma", 2.0 * N * D * 3 * D),
+             ("unfused:attention", attn, "hbm", (N * 3 * D + N * D) * 2.0),
              ("c_proj_gemm+resid+ln2", gemm(cpr_d), "mfma", 2.0 * N * D * D),
              ("expert_up_gemm+swiglu", gemm(up_d), "mfma", 2.0 * NK * D * 8 * D),
              ("expert_down_gemm_4slices", gemm(dn_d), "mfma", 2.0 * NK * 4 * D * D),
@@ -311,12 +320,14 @@ def layer_kernel_breakdown(den, device, reps=120):
             for i in range(reps):
                 fn(i, cst)
         gr.replay(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / reps
+        us = 1e9
+        for _ in range(3):                                                    # best of three replays (clock ramps / other kernels' tails between the legs)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
+            us = min(us, e0.elapsed_time(e1) * 1e3 / reps)
         peak = MFMA_BF16_PEAK_TFLOPS * 1e12 if bound == "mfma" else HBM_PEAK_GBS * 1e9
         out[name] = {"us": round(us, 2), "bound": bound, "frac": round(work / (us * 1e-6) / peak, 4)}
-    out["sum_us"] = round(sum(v["us"] for v in out.values()), 1)
+    out["sum_us"] = round(sum(v["us"] for n_, v in out.items() if not n_.startswith("unfused:")), 1)
     return out
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MODE_HIP_ABI_VERSION 8
+#define MODE_HIP_ABI_VERSION 9
 
 typedef enum ModeStatus {
   MODE_OK = 0,
@@ -74,6 +74,9 @@ const char* mode_hip_status_string(int status);
  * "fuse_ln2": 1 (default) = ln_2 folded into the c_proj / up-projection / combine kernels on the bf16 path, 0 = its own kernel.
  * "dn_split_k": K-slices of the inference path's expert down-projection, 0 = default (4, for every batch size), 1 = off, <= 8.
  * "combine_row_max": token rows up to which the MoE combine runs one workgroup per row (default: always), 0 = one wave per row.
+ * "fuse_qkv_attn": 1 (default) = mode_dit_forward runs the QKV projection and the attention of a block as ONE launch (mode_qkv_attn_fwd) where that
+ *   kernel applies, 0 = mode_gemm + mode_attn_block_fwd.  "fuse_qkv_attn_min_b": smallest batch it is taken for (default 56); "qkv_attn_w3": 1 (default) = its weight tiles ride a three-slot LDS ring
+ *   (160 KiB per workgroup), 0 = two slots; "qkv_attn_waves": 8 (default) or 4 waves per workgroup.  Same results either way.
  * Unknown keys return MODE_ERR_BAD_ARG. */
 int mode_set_option(const char* key, int value);
 
@@ -172,6 +175,26 @@ int mode_rmsnorm_cond_fwd(const float* x, const float* g, const float* cond, int
  * ------------------------------------------------------------------------------------------------------------------ */
 int mode_attn_block_fwd(const void* qkv, const float* q_gain, const float* k_gain, void* y, int dtype,
                         int B, int T, int H, int head_dim, float eps, uint32_t seed, float p_drop, void* stream);
+/* ------------------------------------------------------------------------------------------------------------------
+ * mode_qkv_attn_fwd (ABI 9) — Attention.forward up to c_proj as ONE launch (modedit.py:108-110, 125-127, 141-165): q, k, v = Linear(h) with the
+ * packed [3D, D] weight / [3D] bias ([q | k | v] rows), qk-RMSNorm, causal softmax(QK^T / sqrt(hd)) V, heads merged into y [B*T, D].  A workgroup owns
+ * (a group of whole samples, one head): the 3 * head_dim weight rows of that head are everything its attention needs, so q | k | v never go to HBM.
+ * Results are BIT-IDENTICAL to mode_gemm(MODE_EPI_BIAS, out bf16) followed by mode_attn_block_fwd (same accumulation order, same rounding points, one
+ * shared attention body).  bf16 only, inference only (no dropout, nothing stashed); head_dim == 128, T <= 16, D % 64 == 0, 16-byte aligned operands -
+ * anything else returns MODE_ERR_UNSUPPORTED and the caller runs the two kernels.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ModeQkvAttnDesc {
+  int32_t dtype;                 /* MODE_BF16 */
+  int32_t B, T, H, D;            /* samples, tokens per sample, heads, model width (head_dim = D / H) */
+  const void* h; int64_t ldh;    /* [B*T, D] bf16: ln_1(x) + c */
+  const void* wqkv; int64_t ldw; /* [3D, D] bf16 */
+  const float* bqkv;             /* [3D] */
+  const float* q_gain; const float* k_gain;   /* [head_dim] */
+  float eps;
+  void* y; int64_t ldy;          /* [B*T, D] bf16 */
+} ModeQkvAttnDesc;
+int mode_qkv_attn_fwd(const ModeQkvAttnDesc* desc, void* stream);
+
 /* backward of the above (training): dy [B*T, D] -> dqkv [B*T, 3D]; dgq_partial / dgk_partial [B*H, head_dim] are per-(sample, head)
  * partial gradients of the qk-norm gains (reduce with mode_colsum).  Attention dropout (SDPA dropout_p, modedit.py:149) is a
  * counter-based hash mask keyed by (seed, sample, head, query, key), regenerated here. */

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MODE_HIP_LIB", os.path.join(_HERE, "libmode_hip.so"))
 
 MODE_BF16, MODE_F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_RESIDUAL_NORM = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 8
+ABI_VERSION = 9
 GEMM_SKINNY_OK, GEMM_W_KN, GEMM_A_KM, GEMM_UNIFORM_GROUPS, GEMM_SMALL_ROWS, GEMM_IDENTITY_ROWS = 1, 2, 4, 8, 16, 32
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -117,6 +117,11 @@ class ModeForwardArgs(C.Structure):
                 ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp), ("topk_idx_out", c_vp), ("uniform_routing", c_i32)]
 
 
+class ModeQkvAttnDesc(C.Structure):
+    _fields_ = [("dtype", c_i32), ("B", c_i32), ("T", c_i32), ("H", c_i32), ("D", c_i32), ("h", c_vp), ("ldh", c_i64), ("wqkv", c_vp), ("ldw", c_i64),
+                ("bqkv", c_vp), ("q_gain", c_vp), ("k_gain", c_vp), ("eps", c_f32), ("y", c_vp), ("ldy", c_i64)]
+
+
 class ModeBnFilmDesc(C.Structure):
     _fields_ = [("N", c_i32), ("C", c_i32), ("HW", c_i32), ("dtype", c_i32), ("x", c_vp), ("scale", c_vp), ("shift", c_vp), ("pre_gamma", c_vp),
                 ("pre_beta", c_vp), ("residual", c_vp), ("relu", c_i32), ("post_gamma", c_vp), ("post_beta", c_vp), ("y", c_vp),
@@ -134,6 +139,7 @@ PROTOTYPES = {
     "mode_gemm": (C.c_int, [P(ModeGemmDesc), c_vp]),
     "mode_rmsnorm_cond_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_f32, c_vp, c_vp, C.c_int, c_vp]),
     "mode_attn_block_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32, C.c_uint32, c_f32, c_vp]),
+    "mode_qkv_attn_fwd": (C.c_int, [C.POINTER(ModeQkvAttnDesc), c_vp]),
     "mode_attn_block_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32, C.c_uint32,
                                       c_f32, c_vp]),
     "mode_sigma_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, c_vp]),

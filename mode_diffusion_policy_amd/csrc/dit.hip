@@ -18,6 +18,7 @@ int dispatch_meta_batched(const MetaBatch& mb, int nbatch, int R, int tpr, int N
 extern int g_gemm_cfg;
 extern int g_gemm_pp;
 extern int g_gemm_pp_min_tiles;
+extern int g_fuse_qkv_attn, g_fuse_qkv_attn_min_b, g_qkv_attn_w3, g_qkv_attn_waves;   // qkv_attn.hip
 extern int g_combine_row_max;
 extern int g_gemm_mid_rows;
 extern int g_tr_cfg;
@@ -90,7 +91,7 @@ extern "C" size_t mode_hip_sizeof(const char* n) {
 #define MODE_SZ(T) if (!strcmp(n, #T)) return sizeof(T);
   MODE_SZ(ModeGemmDesc) MODE_SZ(ModeEmbedDesc) MODE_SZ(ModeHeadDesc) MODE_SZ(ModeGroupedMlpDesc) MODE_SZ(ModeDims) MODE_SZ(ModeLayerWeights)
   MODE_SZ(ModeModelWeights) MODE_SZ(ModeMetaLayout) MODE_SZ(ModeForwardArgs) MODE_SZ(ModeStashLayout) MODE_SZ(ModeTrainArgs) MODE_SZ(ModeLayerGrads)
-  MODE_SZ(ModeModelGrads) MODE_SZ(ModeLayerWeightsT) MODE_SZ(ModeModelWeightsT) MODE_SZ(ModeBnFilmDesc)
+  MODE_SZ(ModeModelGrads) MODE_SZ(ModeLayerWeightsT) MODE_SZ(ModeModelWeightsT) MODE_SZ(ModeBnFilmDesc) MODE_SZ(ModeQkvAttnDesc)
 #undef MODE_SZ
   return 0;
 }
@@ -117,6 +118,10 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "fuse_ln2")) { g_fuse_ln2 = value != 0; return MODE_OK; }
   if (!strcmp(key, "gemm_mid_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_mid_rows = value; return MODE_OK; }
   if (!strcmp(key, "combine_row_max")) { if (value < 0) return MODE_ERR_BAD_ARG; g_combine_row_max = value; return MODE_OK; }
+  if (!strcmp(key, "fuse_qkv_attn")) { g_fuse_qkv_attn = value != 0; return MODE_OK; }
+  if (!strcmp(key, "qkv_attn_waves")) { if (value != 4 && value != 8) return MODE_ERR_BAD_ARG; g_qkv_attn_waves = value; return MODE_OK; }
+  if (!strcmp(key, "qkv_attn_w3")) { g_qkv_attn_w3 = value != 0; return MODE_OK; }
+  if (!strcmp(key, "fuse_qkv_attn_min_b")) { if (value < 0) return MODE_ERR_BAD_ARG; g_fuse_qkv_attn_min_b = value; return MODE_OK; }
   if (!strcmp(key, "dn_split_k")) { if (value < 0 || value > 8) return MODE_ERR_BAD_ARG; g_dn_split_k = value; return MODE_OK; }
   return MODE_ERR_UNSUPPORTED;
 }
@@ -268,6 +273,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
   const bool fuse = !tok_route && g_fuse_ln2 && dt == MODE_BF16 && D % 64 == 0;     // (token routing reads the normalised fp32 stream: ln_2 stays a kernel)
   const int ssn = small ? D / 16 : D / 64;
   const int small_flag = small ? MODE_GEMM_SMALL_ROWS : 0;
+  const bool qa_fused = g_fuse_qkv_attn && !small && dt == MODE_BF16 && g_gemm_cfg == 0 && B >= g_fuse_qkv_attn_min_b;
   ModeMetaLayout ml;
   mode_moe_meta_layout(N, d.E, d.k, &ml);
   const int ysplit = down_proj_split(dt, 4 * D);
@@ -292,12 +298,26 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
     const ModeLayerWeights& lw = w->layers[l];
     const int32_t* meta = tok_route ? reinterpret_cast<const int32_t*>(ws + L.tr_meta) : a->meta + (long)l * a->meta_layer_stride;
     // q,k,v as ONE GEMM [N,D] x [3D,D]^T + bias   (modedit.py:108-110, 141-143)
-    ModeGemmDesc g = gemm_desc(dt, MODE_EPI_BIAS, dt, N, 3 * D, D, h, D, lw.wqkv, D, qkv, 3 * D);
-    g.bias = lw.bqkv; g.flags = small_flag;
-    rc = mode_gemm(&g, stream);
-    if (rc) return rc;
-    rc = mode_attn_block_fwd(qkv, lw.qn_g, lw.kn_g, yat, dt, B, T, d.H, D / d.H, d.eps, 0u, 0.0f, stream);
-    if (rc) return rc;
+    // ... and the attention behind it (modedit.py:125-127, 145-165).  Large batches: ONE launch per block (qkv_attn.hip, bit-identical to the two
+    // kernels); shapes it does not take come back MODE_ERR_UNSUPPORTED.
+    ModeGemmDesc g;
+    rc = MODE_ERR_UNSUPPORTED;
+    if (qa_fused) {
+      ModeQkvAttnDesc qa;
+      memset(&qa, 0, sizeof(qa));
+      qa.dtype = dt; qa.B = B; qa.T = T; qa.H = d.H; qa.D = D; qa.h = h; qa.ldh = D; qa.wqkv = lw.wqkv; qa.ldw = D; qa.bqkv = lw.bqkv;
+      qa.q_gain = lw.qn_g; qa.k_gain = lw.kn_g; qa.eps = d.eps; qa.y = yat; qa.ldy = D;
+      rc = mode_qkv_attn_fwd(&qa, stream);
+      if (rc && rc != MODE_ERR_UNSUPPORTED) return rc;
+    }
+    if (rc == MODE_ERR_UNSUPPORTED) {
+      g = gemm_desc(dt, MODE_EPI_BIAS, dt, N, 3 * D, D, h, D, lw.wqkv, D, qkv, 3 * D);
+      g.bias = lw.bqkv; g.flags = small_flag;
+      rc = mode_gemm(&g, stream);
+      if (rc) return rc;
+      rc = mode_attn_block_fwd(qkv, lw.qn_g, lw.kn_g, yat, dt, B, T, d.H, D / d.H, d.eps, 0u, 0.0f, stream);
+      if (rc) return rc;
+    }
     // c_proj (no bias) + residual, in place on the fp32 stream   (modedit.py:111, 166, 532)
     // ln_2 (modedit.py:539) has no kernel of its own on the bf16 path: the c_proj epilogue also writes bf16(x * g) and per-64-column sums of
     // squares of x, the up-projection scales its accumulator rows by 1 / max(|x| D^-1/2, eps) — (x g / n) W^T == ((x g) W^T) / n — and the

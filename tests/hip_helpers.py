@@ -77,6 +77,16 @@ def attn(qkv, qg, kg, B, T, H, hd, eps=1e-6, seed=0, p_drop=0.0):
     return y
 
 
+def qkv_attn(h, wqkv, bqkv, qg, kg, B, T, H, eps=1e-6):
+    """mode_qkv_attn_fwd: returns (status, y) - the caller decides what an UNSUPPORTED (-2) shape means."""
+    lib = L.load()
+    D = h.shape[1]
+    y = torch.full((B * T, D), float("nan"), dtype=h.dtype, device=h.device)
+    d = L.ModeQkvAttnDesc(dtype=dt_of(h), B=B, T=T, H=H, D=D, h=p(h), ldh=h.stride(0), wqkv=p(wqkv), ldw=wqkv.stride(0), bqkv=p(bqkv), q_gain=p(qg),
+                          k_gain=p(kg), eps=eps, y=p(y), ldy=y.stride(0))
+    return lib.mode_qkv_attn_fwd(C.byref(d), stream()), y
+
+
 def combine_norm(u, Y, pos, posw, k, g, cond, rows_per_cond, eps=1e-6, h_dtype=torch.bfloat16):
     lib = L.load()
     N, D = u.shape

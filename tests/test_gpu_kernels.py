@@ -205,6 +205,45 @@ def test_attention(dtype, B, T, Hh, hd):
     assert rel(y0, v0) < (8e-3 if dtype == torch.bfloat16 else 1e-6)
 
 
+@pytest.mark.parametrize("B,T,Hh", [(128, 14, 8), (1, 14, 8), (5, 14, 2), (37, 16, 4), (9, 5, 1), (64, 11, 8), (130, 14, 8)])
+def test_fused_qkv_attention_is_bit_identical_to_gemm_plus_attention(B, T, Hh):
+    """mode_qkv_attn_fwd (one launch: QKV projection + qk-RMSNorm + causal attention, q | k | v never in HBM) against the two kernels it replaces:
+    every output bit equal (same k-ordered MFMA chain, same rounding points, one shared attention body) - whole and partial sample groups, ragged
+    last group, 1-16 tokens per sample, and against the fp32 torch reference at the attention tolerance."""
+    hd = 128
+    D = Hh * hd
+    h = rnd(B * T, D, seed=61).to(torch.bfloat16).to(dev())
+    w = rnd(3 * D, D, seed=62, scale=D ** -0.5).to(torch.bfloat16).to(dev())
+    b = (0.1 * rnd(3 * D, seed=63)).to(dev())
+    qg = (1 + 0.1 * rnd(hd, seed=64)).to(dev()); kg = (1 + 0.1 * rnd(hd, seed=65)).to(dev())
+    rc, y = H.qkv_attn(h, w, b, qg, kg, B, T, Hh)
+    assert rc == 0
+    lib = L.load()
+    try:                                                                        # the other three geometries of the kernel: same bits
+        for waves, w3 in ((8, 0), (4, 1), (4, 0)):
+            assert lib.mode_set_option(b"qkv_attn_waves", waves) == 0 and lib.mode_set_option(b"qkv_attn_w3", w3) == 0
+            rc2, y_two = H.qkv_attn(h, w, b, qg, kg, B, T, Hh)
+            assert rc2 == 0 and torch.equal(y, y_two), (waves, w3)
+    finally:
+        lib.mode_set_option(b"qkv_attn_waves", 8); lib.mode_set_option(b"qkv_attn_w3", 1)
+    qkv = H.gemm(h, w, epilogue=L.EPI_BIAS, bias=b)
+    y2 = H.attn(qkv, qg, kg, B, T, Hh, hd)
+    assert not torch.isnan(y.float()).any()
+    assert torch.equal(y, y2)
+    q, k, v = (t.float().cpu().view(B, T, Hh, hd).transpose(1, 2) for t in qkv.split(D, dim=-1))
+    q = O.rmsnorm(q, qg.cpu()); k = O.rmsnorm(k, kg.cpu())
+    att = (q @ k.transpose(-2, -1)) / math.sqrt(hd)
+    att = att.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril(), float("-inf")).softmax(-1)
+    assert rel(y.float(), (att @ v).transpose(1, 2).reshape(B * T, D)) < 1.2e-2
+
+
+def test_fused_qkv_attention_refuses_what_it_does_not_take():
+    h = rnd(28, 256, seed=66).to(torch.bfloat16).to(dev()); w = rnd(768, 256, seed=67).to(torch.bfloat16).to(dev())
+    b = rnd(768, seed=68).to(dev()); g = torch.ones(64, device=dev())
+    assert H.qkv_attn(h, w, b, g, g, 2, 14, 4)[0] == -2                          # head_dim 64: the two kernels
+    assert H.qkv_attn(h.float(), w.float(), b, g, g, 2, 14, 4)[0] == -2          # fp32 parity mode
+
+
 # ---------------------------------------------------------------------------------------------------------------- routing
 @pytest.mark.parametrize("R,E,k", [(1, 4, 2), (128, 4, 2), (8, 2, 1), (77, 8, 3), (5, 3, 2)])
 def test_route_topk_bit_exact(R, E, k):
