@@ -15,6 +15,8 @@ namespace mode {
 int rmsnorm_bwd_launch(const float* x, const float* g, const float* dy_a, const float* dy_b, const float* G, int g_splits, long g_split_stride,
                        const int32_t* pos, int k, int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* dx_lp,
                        int lp_dtype, hipStream_t stream);   // train_ops.hip
+bool gemm_bf16_pptr_accepts(const ModeGemmDesc* d);                                      // gemm_bf16_pptr.hip: would mode_gemm take the ping-pong kernel?
+int gather_rows_bf16(const void* in, long ld_in, const int* rows, int n, int cols, void* out, long ld_out, hipStream_t s);   // gemm_bf16_pptr.hip
 }
 
 namespace {
@@ -47,7 +49,7 @@ TrainWs train_ws(const ModeDims& d, int B, int dtype) {
   TrainWs w{};
   Take t;
   w.dxa = t(N * D * 4); w.dxb = t(N * D * 4); w.dyl = t(N * D * 4);
-  w.dys = t(NK * D * esz); w.dhd = t(NK * 4 * D * esz); w.dp = t(NK * 8 * D * esz); w.dus = t(NK * D * 4 * 2);   /* dU: two K-slice slabs of the up-projection data gradient */ w.dwt = t(NK * 4 * (size_t)d.L);      // router-weight gradients of ALL layers [L][N*k]
+  w.dys = t(NK * D * esz); w.dhd = t(NK * 4 * D * esz); w.dp = t(NK * 8 * D * esz); w.dus = t(NK * D * 4 * 4);   /* dU: up to four K-slice slabs of the up-projection data gradient */ w.dwt = t(NK * 4 * (size_t)d.L);      // router-weight gradients of ALL layers [L][N*k]
   w.t_big = t(8 * D * NKp * esz);            // dP^T  [8D, NKp]   (also dqkv^T [3D, Np])
   w.t_mid = t(4 * D * NKp * esz);            // Hd^T  [4D, NKp]
   w.t_d = t(D * NKp * esz);                  // dY^T / u^T / dx1^T / h1^T  [D, NKp]
@@ -233,7 +235,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       return MODE_ERR_UNSUPPORTED;
   }
   const bool tr = dt == MODE_BF16 && D % 8 == 0;      // bf16: backward GEMMs read row-major operands directly (gemm_bf16_tr.hip); no transposed copies
-  const int du_split = (tr && (8 * D) % 128 == 0) ? 2 : 1;   // K-slices of the up-projection data gradient
+  int du_split = (tr && (8 * D) % 128 == 0) ? 2 : 1;   // K-slices of the up-projection data gradient
   const bool bf = dt == MODE_BF16;
   const long NKp = ((long)NK + 63) / 64 * 64 + 64L * E, Np = ((long)N + 63) / 64 * 64;
   const int Ktok = bf ? (int)Np : N;                       // token-dim contraction length (bf16 kernel needs a multiple of 64: zero padded)
@@ -350,13 +352,21 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     if (tr) {
       // K = 8D with only NK*D/128^2 = 224 output tiles: two K-slices (fp32 slabs, added by the ln_2 backward's gather-sum) double the workgroups
       // and allow 128-wide tiles, as for the inference down-projection (112 -> ~80 us)
+      // large batches: the persistent ping-pong kernel (gemm_bf16_pptr.hip) takes 256 x 256 tiles - FOUR K-slices give it one tile per CU
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 8 * D, dP, 8 * D, lw.w1, D, dUs, D);
       g.w_expert_stride = 8L * D * D; g.expert_offsets = offsets; g.num_experts = E; g.flags = MODE_GEMM_W_KN;
-      g.split_k = du_split; g.split_stride = (long)NK * D;
+      g.split_k = 4; g.split_stride = (long)NK * D;
+      du_split = ((8 * D) % 512 == 0 && mode::gemm_bf16_pptr_accepts(&g)) ? 4 : du_split;
+      g.split_k = du_split;
       if ((rc = mode_gemm(&g, stream))) return rc;
-      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 8 * D, D, NK, dP, 8 * D, S + sl.ub, D, lg.w1, D);          // u rows gathered through perm
-      g.k_group_offsets = offsets; g.num_k_groups = E; g.c_group_stride = 8L * D * D; g.w_rows = meta + ml.perm;
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 8 * D, D, NK, dP, 8 * D, Td2, D, lg.w1, D);
+      g.k_group_offsets = offsets; g.num_k_groups = E; g.c_group_stride = 8L * D * D;
       g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
+      if (mode::gemm_bf16_pptr_accepts(&g)) {                   // it reads its K rows where they lie: sorted-order copy of the u rows first (7 MB)
+        if ((rc = mode::gather_rows_bf16(S + sl.ub, D, meta + ml.perm, NK, D, Td2, D, hs))) return rc;
+      } else {
+        g.W = S + sl.ub; g.w_rows = meta + ml.perm;             // ring kernel: u rows gathered through perm inside the GEMM
+      }
       if ((rc = mode_gemm(&g, stream))) return rc;
     } else {
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 8 * D, dP, 8 * D, lt->w1T, 8 * D, dUs, D);

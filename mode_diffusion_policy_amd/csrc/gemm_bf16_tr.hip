@@ -336,7 +336,9 @@ static int tr_launch(TrParams p, const ModeGemmDesc* d, hipStream_t s) {
   return MODE_OK;
 }
 
-int g_tr_cfg = 0;   // "gemm_tr_cfg" option: 0 auto, 1 = 128-wide NS2, 2 = 64-wide NS3, 3 = 128-wide NS3, 4 = 64-wide NS2, 5 = 128-wide NS1
+int g_tr_cfg = 0;   // "gemm_tr_cfg" option: 0 auto, 1 = 128-wide NS2, 2 = 64-wide NS3, 3 = 128-wide NS3, 4 = 64-wide NS2, 5 = 128-wide NS1,
+                    // 6 = the persistent ping-pong kernel (gemm_bf16_pptr.hip) for every shape it takes, 7 = auto without it
+int gemm_bf16_pptr_launch(const ModeGemmDesc* d, bool force, hipStream_t s);   // gemm_bf16_pptr.hip: 256 x 256 ping-pong tiles, large problems
 
 int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
   const bool a_km = (d->flags & MODE_GEMM_A_KM) != 0;
@@ -352,6 +354,10 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
     if (d->K % 64 != 0 || d->K <= 0 || d->k_group_offsets || d->w_rows) return MODE_ERR_UNSUPPORTED;
   }
   if (d->M <= 0) return MODE_OK;
+  if (g_tr_cfg == 0 || g_tr_cfg == 6) {                        // large problems: the ping-pong structure (MODE_ERR_UNSUPPORTED = not its shape)
+    const int rc = gemm_bf16_pptr_launch(d, g_tr_cfg == 6, s);
+    if (rc != MODE_ERR_UNSUPPORTED) return rc;
+  }
   TrParams p;
   p.A = (const uint16_t*)d->A; p.lda = d->lda; p.W = (const uint16_t*)d->W; p.ldw = d->ldw; p.w_estride = d->w_expert_stride;
   p.C = d->C; p.ldc = d->ldc; p.offsets = d->expert_offsets; p.E = d->num_experts;
@@ -363,7 +369,7 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
   // tiles (twice the workgroups) with a 3-slot ring so one workgroup keeps two tiles in flight
   const long groups = (a_km && d->k_group_offsets) ? d->num_k_groups : 1;
   const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * groups;
-  int cfg = g_tr_cfg;
+  int cfg = g_tr_cfg >= 6 ? 0 : g_tr_cfg;
   // measured (profiles/): weight gradients (short K per tile, >= 3 workgroups per CU) are 4 % faster single-buffered; data gradients are not
   if (cfg == 0) cfg = (a_km && t128 >= 768) ? 5 : ((t128 * split >= 448 || d->w_rows) ? 1 : 2);      // K-slices count as workgroups
   if (d->w_rows && (cfg == 2 || cfg == 3)) cfg = 1;

@@ -706,10 +706,10 @@ int rmsnorm_bwd_launch(const float* x, const float* g, const float* dy_a, const 
   if (k > 8) return MODE_ERR_UNSUPPORTED;
 #define MODE_RB(KK, GS) hipLaunchKernelGGL((rmsnorm_bwd_kernel<4, KK, GS>), dim3((rows + 3) / 4), dim3(256), lds, stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx, \
                                         accumulate, dg_partial, dy_out, dx_lp, lp_dtype == MODE_BF16 ? 1 : 0, g_splits, g_split_stride)
-  if (D == 1024 && k <= 2 && g_splits <= 2) {                      // the chain's shapes: branch-free loads
+  if (D == 1024 && k <= 2 && g_splits <= 4) {                      // the chain's shapes: branch-free loads
     if (k == 0) MODE_RB(0, 1);
-    else if (k == 1) { if (g_splits == 1) MODE_RB(1, 1); else MODE_RB(1, 2); }
-    else { if (g_splits == 1) MODE_RB(2, 1); else MODE_RB(2, 2); }
+    else if (k == 1) { if (g_splits == 1) MODE_RB(1, 1); else if (g_splits == 2) MODE_RB(1, 2); else MODE_RB(1, 4); }
+    else { if (g_splits == 1) MODE_RB(2, 1); else if (g_splits == 2) MODE_RB(2, 2); else MODE_RB(2, 4); }
   } else if (D == 1024)
 #undef MODE_RB
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, dim3((rows + 3) / 4), dim3(256), lds, stream, x, g, dy_a, dy_b, G, pos, k, rows, D, eps, dx,

@@ -150,3 +150,142 @@ def test_f32_wgrad_layout(R, M, N, groups):
             assert float(Cc[z].abs().max()) == 0.0
         else:
             assert rel(Cc[z], ref) < 2e-6
+
+
+# ---- the persistent ping-pong form of the same products (gemm_bf16_pptr.hip): forced with "gemm_tr_cfg" 6, compared with fp32 torch AND with the ring kernels
+@pytest.fixture
+def force_pptr():
+    lib = L.load()
+    lib.mode_set_option(b"gemm_tr_cfg", 6)
+    yield lib
+    lib.mode_set_option(b"gemm_tr_cfg", 0)
+
+
+def _run(d, what):
+    L.check(L.load().mode_gemm(C.byref(d), stream()), what)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("counts,K,N,split", [([896, 896, 896, 896], 1024, 512, 1), ([871, 925, 903, 885], 256, 256, 1), ([0, 1000, 3, 517], 512, 768, 1),
+                                              ([129, 0, 0, 0], 128, 256, 1), ([300, 1100, 20, 257], 2048, 256, 4), ([896, 896, 896, 896], 1024, 256, 2)])
+def test_pptr_dgrad_grouped(force_pptr, counts, K, N, split, out_dtype):
+    """Ragged expert segments (incl. empty ones, more than four 256-row tiles, a 3-row segment), K-slices; rows past a segment must never be stored
+    (NaN canaries stay) and every slice is exactly its K range."""
+    if split > 1 and out_dtype == torch.bfloat16:
+        pytest.skip("K-slices write fp32 slabs")
+    E = len(counts); M = sum(counts)
+    g = torch.Generator().manual_seed(sum(counts) + K + N)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = torch.randn(E, K, N, generator=g).to(torch.bfloat16).cuda()
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).cuda()
+    Cc = torch.full((split, M + 7, N), float("nan"), dtype=out_dtype, device="cuda")
+    d = _desc(out_dtype=L.MODE_BF16 if out_dtype == torch.bfloat16 else L.MODE_F32, M=M, N=N, K=K, A=p(A), lda=K, W=p(W), ldw=N, w_expert_stride=K * N,
+              C=p(Cc), ldc=N, expert_offsets=p(off), num_experts=E, flags=L.GEMM_W_KN, split_k=split, split_stride=(M + 7) * N)
+    _run(d, "pptr dgrad")
+    assert torch.isnan(Cc[:, M:].float()).all()                       # canary rows behind the last segment
+    tot = Cc[:, :M].float().sum(0)
+    assert torch.isfinite(tot).all()
+    tol = 1e-5 if out_dtype == torch.float32 else 4e-3
+    o = 0
+    for e, c in enumerate(counts):
+        if c:
+            assert rel(tot[o:o + c], A[o:o + c].float() @ W[e].float()) < tol, e
+            if split > 1:
+                ks = K // split
+                assert rel(Cc[1, o:o + c], A[o:o + c, ks:2 * ks].float() @ W[e, ks:2 * ks].float()) < 1e-5
+        o += c
+    # same k-ordered fp32 MFMA chain as the ring kernels: bit-identical
+    force_pptr.mode_set_option(b"gemm_tr_cfg", 7)
+    C2 = torch.full_like(Cc, float("nan"))
+    d.C = p(C2)
+    _run(d, "ring dgrad")
+    assert torch.equal(C2[:, :M].view(torch.int16 if out_dtype == torch.bfloat16 else torch.int32), Cc[:, :M].view(torch.int16 if out_dtype == torch.bfloat16 else torch.int32))
+
+
+@pytest.mark.parametrize("M,K,N", [(256, 128, 256), (1792, 3072, 1024), (300, 256, 512), (3584, 1024, 4096)])
+def test_pptr_dgrad_plain(force_pptr, M, K, N):
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = torch.randn(K, N, generator=g).to(torch.bfloat16).cuda()
+    Cc = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    d = _desc(out_dtype=L.MODE_BF16, M=M, N=N, K=K, A=p(A), lda=K, W=p(W), ldw=N, C=p(Cc), ldc=N, flags=L.GEMM_W_KN)
+    _run(d, "pptr dgrad plain")
+    assert rel(Cc.float(), A.float() @ W.float()) < 4e-3
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("counts,M,N", [([896, 896, 896, 896], 256, 512), ([871, 925, 903, 885], 512, 256), ([0, 1001, 3, 517], 256, 256), ([5, 0, 70, 0], 256, 256),
+                                        ([64, 128, 129, 1], 256, 256)])
+def test_pptr_wgrad_expert_segments(force_pptr, counts, M, N, out_dtype):
+    """Per-expert weight gradients over arbitrary (unpadded, empty, shorter than one K-step pair) row ranges: rows past a range contribute exactly
+    nothing even when the neighbouring rows are poisoned."""
+    E = len(counts); R = sum(counts)
+    g = torch.Generator().manual_seed(R + M)
+    A = torch.randn(R, M, generator=g).to(torch.bfloat16).cuda()
+    X = torch.randn(R, N, generator=g).to(torch.bfloat16).cuda()
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).cuda()
+    Cc = torch.full((E, M, N), float("nan"), dtype=out_dtype, device="cuda")
+    d = _desc(out_dtype=L.MODE_BF16 if out_dtype == torch.bfloat16 else L.MODE_F32, M=M, N=N, K=R, A=p(A), lda=M, W=p(X), ldw=N, C=p(Cc), ldc=N,
+              k_group_offsets=p(off), num_k_groups=E, c_group_stride=M * N, flags=L.GEMM_W_KN | L.GEMM_A_KM)
+    _run(d, "pptr wgrad")
+    tol = 1e-5 if out_dtype == torch.float32 else 4e-3
+    o = 0
+    for e, c in enumerate(counts):
+        if c == 0:
+            assert float(Cc[e].float().abs().max()) == 0.0
+        else:
+            assert rel(Cc[e].float(), A[o:o + c].float().t() @ X[o:o + c].float()) < tol, e
+        o += c
+    if out_dtype == torch.float32:
+        force_pptr.mode_set_option(b"gemm_tr_cfg", 7)
+        C2 = torch.full_like(Cc, float("nan"))
+        d.C = p(C2)
+        _run(d, "ring wgrad")
+        assert torch.equal(C2.view(torch.int32), Cc.view(torch.int32))
+
+
+@pytest.mark.parametrize("R,M,N", [(1792, 1024, 1024), (100, 256, 256), (1793, 512, 768)])
+def test_pptr_wgrad_plain(force_pptr, R, M, N):
+    g = torch.Generator().manual_seed(R + M)
+    A = torch.randn(R, M, generator=g).to(torch.bfloat16).cuda()
+    X = torch.randn(R, N, generator=g).to(torch.bfloat16).cuda()
+    Cc = torch.full((M, N), float("nan"), device="cuda")
+    d = _desc(out_dtype=L.MODE_F32, M=M, N=N, K=R, A=p(A), lda=M, W=p(X), ldw=N, C=p(Cc), ldc=N, flags=L.GEMM_W_KN | L.GEMM_A_KM)
+    _run(d, "pptr wgrad plain")
+    assert rel(Cc, A.float().t() @ X.float()) < 1e-5
+
+
+def test_pptr_training_shapes_full_size(force_pptr):
+    """The four expert GEMMs of one C2 / B = 128 backward layer at their real sizes (ragged multinomial segments), against fp32 torch."""
+    D, E = 1024, 4
+    counts = [871, 925, 903, 885]; NK = sum(counts)
+    g = torch.Generator().manual_seed(3)
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).cuda()
+    rn = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    dY, W2, H = rn(NK, D), rn(E, D, 4 * D), rn(NK, 4 * D)
+    dH = torch.full((NK, 4 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    d = _desc(out_dtype=L.MODE_BF16, M=NK, N=4 * D, K=D, A=p(dY), lda=D, W=p(W2), ldw=4 * D, w_expert_stride=4 * D * D, C=p(dH), ldc=4 * D,
+              expert_offsets=p(off), num_experts=E, flags=L.GEMM_W_KN)
+    _run(d, "dH")
+    dW2 = torch.full((E, D, 4 * D), float("nan"), device="cuda")
+    d = _desc(out_dtype=L.MODE_F32, M=D, N=4 * D, K=NK, A=p(dY), lda=D, W=p(H), ldw=4 * D, C=p(dW2), ldc=4 * D, k_group_offsets=p(off), num_k_groups=E,
+              c_group_stride=4 * D * D, flags=L.GEMM_W_KN | L.GEMM_A_KM)
+    _run(d, "dW2")
+    dP, W1, U = rn(NK, 8 * D), rn(E, 8 * D, D), rn(NK, D)
+    dU = torch.full((4, NK, D), float("nan"), device="cuda")
+    d = _desc(out_dtype=L.MODE_F32, M=NK, N=D, K=8 * D, A=p(dP), lda=8 * D, W=p(W1), ldw=D, w_expert_stride=8 * D * D, C=p(dU), ldc=D,
+              expert_offsets=p(off), num_experts=E, flags=L.GEMM_W_KN, split_k=4, split_stride=NK * D)
+    _run(d, "dU")
+    dW1 = torch.full((E, 8 * D, D), float("nan"), device="cuda")
+    d = _desc(out_dtype=L.MODE_F32, M=8 * D, N=D, K=NK, A=p(dP), lda=8 * D, W=p(U), ldw=D, C=p(dW1), ldc=D, k_group_offsets=p(off), num_k_groups=E,
+              c_group_stride=8 * D * D, flags=L.GEMM_W_KN | L.GEMM_A_KM)
+    _run(d, "dW1")
+    o = 0
+    for e, c in enumerate(counts):
+        s = slice(o, o + c)
+        assert rel(dH[s].float(), dY[s].float() @ W2[e].float()) < 4e-3
+        assert rel(dW2[e], dY[s].float().t() @ H[s].float()) < 1e-5
+        assert rel(dU[:, s].sum(0), dP[s].float() @ W1[e].float()) < 1e-5
+        assert rel(dW1[e], dP[s].float().t() @ U[s].float()) < 1e-5
+        o += c
