@@ -66,7 +66,11 @@ const char* mode_hip_status_string(int status);
  * "gemm_pp": 1 (default) = the heuristic may pick geometries 17 / 18; "gemm_pp_min_tiles": tile count from which it does (default 200).
  * "gemm_group_m": m-tiles per XCD rasterisation group of the ring kernels (0 = default).
  * "gemm_tr_cfg": backward (transpose-read) GEMM geometry, 0 = auto, 1 = 128-wide ring-2, 2 = 64-wide ring-3, 3 = 128-wide ring-3,
- *   4 = 64-wide ring-2, 5 = 128-wide single-buffered.  "adamw_blocks": workgroup cap of one AdamW launch (0 = 256, one streaming workgroup per CU).
+ *   4 = 64-wide ring-2, 5 = 128-wide single-buffered, 6 = the persistent ping-pong kernel of gemm_bf16_pptr.hip (256 x 256 tiles, one workgroup per CU) for
+ *   every shape it takes, 7 = auto without it.  Auto takes it for the large expert GEMMs of the training backward unless "bwd_coexec" is 1.
+ * "bwd_coexec": 1 = the caller runs other kernels beside the backward chain (FusedAdamW.step(overlap=True), ArenaGradReducer's collectives set it):
+ *   the backward's large GEMMs keep the ring kernels, whose small workgroups leave CU resources to the co-running work; 0 (default) = the backward has
+ *   the GPU to itself.  Same results either way (bit-identical kernels).  "adamw_blocks": workgroup cap of one AdamW launch (0 = 256, one streaming workgroup per CU).
  * "gemm_skinny_rows": bf16 GEMMs with M <= this many rows use the weight-streaming kernels, and mode_dit_forward runs a batch of at most this
  *   many TOKEN rows as the small-batch chain (MODE_GEMM_SMALL_ROWS) (default 32 = two environments, 0 = off).
  * "gemm_mid_rows": ungrouped bf16 GEMMs with K = 1024 and at most this many rows (more than "gemm_skinny_rows") keep their weights in registers

@@ -22,6 +22,7 @@ extern int g_fuse_qkv_attn, g_fuse_qkv_attn_min_b, g_qkv_attn_w3, g_qkv_attn_wav
 extern int g_combine_row_max;
 extern int g_gemm_mid_rows;
 extern int g_tr_cfg;
+extern int g_bwd_coexec;
 extern int g_gemm_group_m;
 extern int g_adamw_blocks;
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -112,6 +113,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_pp")) { g_gemm_pp = value != 0; return MODE_OK; }
   if (!strcmp(key, "gemm_pp_min_tiles")) { g_gemm_pp_min_tiles = value; return MODE_OK; }
   if (!strcmp(key, "gemm_tr_cfg")) { g_tr_cfg = value; return MODE_OK; }
+  if (!strcmp(key, "bwd_coexec")) { g_bwd_coexec = value != 0; return MODE_OK; }
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return MODE_OK; }
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }
   if (!strcmp(key, "gemm_skinny_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_skinny_rows = value; return MODE_OK; }

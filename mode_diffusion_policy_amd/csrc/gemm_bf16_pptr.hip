@@ -510,12 +510,13 @@ static int pptr_plan(const ModeGemmDesc* d, bool force, PpTrParams& p, long& t_m
   return MODE_OK;
 }
 
-extern int g_tr_cfg;   // gemm_bf16_tr.hip ("gemm_tr_cfg" option)
+extern int g_tr_cfg;       // gemm_bf16_tr.hip ("gemm_tr_cfg" option)
+extern int g_bwd_coexec;   // gemm_bf16_tr.hip ("bwd_coexec" option)
 
 // Would mode_gemm run this descriptor on the ping-pong kernel?  The training chain asks before it shapes its operands for it (K-slice count of the
 // up-projection data gradient, the pre-gathered u rows of its weight gradient).
 bool gemm_bf16_pptr_accepts(const ModeGemmDesc* d) {
-  if (g_tr_cfg != 0 && g_tr_cfg != 6) return false;
+  if (!((g_tr_cfg == 0 && !g_bwd_coexec) || g_tr_cfg == 6)) return false;
   PpTrParams p;
   long t_max = 0;
   return pptr_plan(d, g_tr_cfg == 6, p, t_max) == MODE_OK;

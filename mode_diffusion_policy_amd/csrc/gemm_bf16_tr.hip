@@ -338,6 +338,9 @@ static int tr_launch(TrParams p, const ModeGemmDesc* d, hipStream_t s) {
 
 int g_tr_cfg = 0;   // "gemm_tr_cfg" option: 0 auto, 1 = 128-wide NS2, 2 = 64-wide NS3, 3 = 128-wide NS3, 4 = 64-wide NS2, 5 = 128-wide NS1,
                     // 6 = the persistent ping-pong kernel (gemm_bf16_pptr.hip) for every shape it takes, 7 = auto without it
+int g_bwd_coexec = 0;   // "bwd_coexec" option: 1 = other kernels (an overlapped optimizer pass, collectives) share the CUs with the backward chain - the
+                        // auto choice then keeps the ring kernels, whose small workgroups leave CU resources free (the persistent kernel owns a CU's whole
+                        // register file: measured at C2 / B = 128 with the per-block AdamW overlap, 12.8 vs 12.3 ms per step)
 int gemm_bf16_pptr_launch(const ModeGemmDesc* d, bool force, hipStream_t s);   // gemm_bf16_pptr.hip: 256 x 256 ping-pong tiles, large problems
 
 int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
@@ -354,7 +357,7 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
     if (d->K % 64 != 0 || d->K <= 0 || d->k_group_offsets || d->w_rows) return MODE_ERR_UNSUPPORTED;
   }
   if (d->M <= 0) return MODE_OK;
-  if (g_tr_cfg == 0 || g_tr_cfg == 6) {                        // large problems: the ping-pong structure (MODE_ERR_UNSUPPORTED = not its shape)
+  if ((g_tr_cfg == 0 && !g_bwd_coexec) || g_tr_cfg == 6) {     // large problems: the ping-pong structure (MODE_ERR_UNSUPPORTED = not its shape)
     const int rc = gemm_bf16_pptr_launch(d, g_tr_cfg == 6, s);
     if (rc != MODE_ERR_UNSUPPORTED) return rc;
   }

@@ -213,6 +213,8 @@ class ArenaGradReducer:
         ar = eng.arena
         ar.ensure_grad(model)
         model.grad_mode = "arena"                                               # the exchange runs over the gradient arena the backward chain writes
+        if overlap and dist.is_available() and dist.is_initialized() and dist.get_world_size(kw.get("process_group")) > 1:
+            eng.lib.mode_set_option(b"bwd_coexec", 1)                           # collectives run beside the backward: its GEMMs leave CU room (mode_hip.h)
         red = cls(ar.grad, ar.bounds["no_decay"], **kw)
         if overlap and ar.grad.device.type == "cuda":
             from .training import TrainState

@@ -237,6 +237,9 @@ class FusedAdamW:
         else:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=eng.device, priority=int(os.environ.get("MODE_OPT_PRIO", "0")))
+                # the per-block passes run BESIDE the next backward chains: tell the library, so that its large backward GEMMs keep the ring
+                # kernels that leave CU resources free (include/mode_hip.h "bwd_coexec"; process-wide like every option)
+                eng.lib.mode_set_option(b"bwd_coexec", 1)
             cur = torch.cuda.current_stream()
             blocks, rest = self._block_slices()
             done = reducer.reduce_async() if (reducer is not None and reducer.world > 1) else None    # {(lo, hi): event after the exchange}

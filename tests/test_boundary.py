@@ -375,3 +375,40 @@ def test_pp_kernel_isa_contract(tmp_path):
             assert sum("s_barrier" in x for x in b) == 8
             assert not any("scratch_" in x for x in b), name          # (1)
             assert sum("s_cbranch" in x for x in b) <= 2, name        # (2)
+
+
+def test_pptr_kernel_isa_contract(tmp_path):
+    """The backward's persistent ping-pong GEMM (gemm_bf16_pptr.hip) has the same compiled-loop contract as the forward one: counted `s_waitcnt vmcnt(N)`
+    release LDS half-tiles, so a scratch (spill) access inside an MFMA block would be a correctness bug; the K loop is straight-line code between its
+    barriers (peeled first K-step pair + loop body, 128 MFMAs / 8 barriers each, the only branch is the back edge)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "mode_diffusion_policy_amd", "csrc")
+    out = tmp_path / "pptr.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"-I{csrc}", "-S",
+                    "--cuda-device-only", os.path.join(csrc, "gemm_bf16_pptr.hip"), "-o", str(out)], check=True, capture_output=True)
+    asm = out.read_text()
+    kernels = [(m.group(1), m.start()) for m in re.finditer(r"^(_ZN4mode16gemm_pptr_kernel\w+):", asm, flags=re.M)]
+    assert len(kernels) == 4                                         # {data gradient, weight gradient} x {bf16, fp32 out}
+    for name, start in kernels:
+        body = asm[start: asm.index(".end_amdhsa_kernel", start)]
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) <= 256
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0, name      # no scratch at all
+        blocks, cur = [], []
+        for line in body.split("\n"):
+            if re.match(r"^\.LBB\w+:", line):
+                blocks.append(cur); cur = []
+            else:
+                cur.append(line)
+        blocks.append(cur)
+        mf = [b for b in blocks if any("v_mfma" in x for x in b)]
+        assert len(mf) == 2, (name, len(mf))
+        for b in mf:
+            assert sum("v_mfma" in x for x in b) == 128
+            assert sum("s_barrier" in x for x in b) == 8
+            assert not any("scratch_" in x for x in b), name
+            assert sum("s_cbranch" in x for x in b) <= 2, name
+            assert sum("ds_read_b64_tr_b16" in x for x in b) in (32, 96), name        # per K-step pair: 32 for W, + 64 for A in the weight gradient
