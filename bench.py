@@ -385,7 +385,7 @@ def cpu_baseline():
             "c1_b8": legs["c1"], "c2_b128": c2}
 
 
-def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU, zero1=None):
+def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU, zero1=None, comm_dtype=None):
     """BASELINE configs[2]/[3]: the score-matching training step of `den` (fwd + bwd + fused AdamW) on B samples per rank, data parallel over
     `world` ranks - ONE implementation shared by `--mode train`, by the default run's extra legs (N = 1) and by the N > 1 default run, so that a
     SCALE record evidences the gradient exchange.  All ranks must call it together.  Every rank owns its own shard of the synthetic batch; the
@@ -409,7 +409,7 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU, z
     if os.environ.get("MODE_ADAMW_BLOCKS"):
         m.engine.lib.mode_set_option(b"adamw_blocks", int(os.environ["MODE_ADAMW_BLOCKS"]))
     # gradient exchange dtype: fp32 like the reference's DDP (default), or MODE_DP_COMM=bf16 = half the bytes on the xGMI links
-    comm = torch.bfloat16 if os.environ.get("MODE_DP_COMM", "fp32") == "bf16" else torch.float32
+    comm = torch.bfloat16 if (comm_dtype or os.environ.get("MODE_DP_COMM", "fp32")) == "bf16" else torch.float32
     red = ArenaGradReducer.for_model(m, comm_dtype=comm) if dist is not None else None      # also with ONE rank under RCCL: same code path as N > 1
     # data-parallel step (world > 1): summed all-reduce + full optimizer pass by default (the mode closest to the reference's DDP); ZeRO-1 on request -
     # per block slice reduce-scatter of the gradients, AdamW on this rank's shard, all-gather of the bf16 compute shadow ("fp32": of the fp32 masters)
@@ -840,11 +840,13 @@ def main():
         print(f"[bench] headline done: {res['value']} {res['unit']} on {n_gpus} GPU(s)", file=sys.stderr, flush=True)
     if args.dtype == "bf16" and not args.no_extras:
         forced = os.environ.get("MODE_DP_ZERO1")                                # an explicit choice runs as the one and only leg (A/B runs)
-        legs = [("train", forced if forced is not None else "0")]
+        legs = [("train", forced if forced is not None else "0", None)]
         if world > 1 and forced is None and os.environ.get("MODE_BENCH_ZERO1_LEG", "1") == "1":
-            legs.append(("zero1", "bf16"))
+            legs.append(("zero1", "bf16", None))
+        if world > 1 and forced is None and os.environ.get("MODE_BENCH_BF16WIRE_LEG", "1") == "1":
+            legs.append(("bf16wire", "0", "bf16"))       # the plain all-reduce again with bf16 on the links (torch's bf16_compress_hook): half the bytes, summed in bf16
         limit = float(os.environ.get("MODE_TRAIN_LEG_TIMEOUT", "240"))
-        for leg, z1 in legs:
+        for leg, z1, wire in legs:
             wd = None
             if world > 1:
                 import threading
@@ -858,11 +860,11 @@ def main():
                 wd.daemon = True
                 wd.start()
             try:
-                out = train_leg(den, device, world, rank, dist, zero1=z1, steps=int(os.environ.get("MODE_BENCH_TRAIN_STEPS", "10")))
+                out = train_leg(den, device, world, rank, dist, zero1=z1, comm_dtype=wire, steps=int(os.environ.get("MODE_BENCH_TRAIN_STEPS", "10")))
                 if leg == "train":
                     res.update(out)
-                else:                                                           # second set of keys, after the headline and the all-reduce leg
-                    res.update({("zero1_" + k[len("train_"):] if k.startswith("train_") else "zero1_" + k): v for k, v in out.items()})
+                else:                                                           # further sets of keys, after the headline and the all-reduce leg
+                    res.update({(f"{leg}_" + k[len("train_"):] if k.startswith("train_") else f"{leg}_" + k): v for k, v in out.items()})
                 if rank == 0:
                     print(f"[bench] {leg} leg done: {out['train_ms_per_step']} ms/step, {out['train_samples_per_s']} samples/s, mode {out['dp_mode']}, "
                           f"{out['dp_ranks']} rank(s) on {out['dp_backend']}", file=sys.stderr, flush=True)

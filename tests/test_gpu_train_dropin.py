@@ -361,8 +361,10 @@ def test_bench_main_world2_end_to_end_through_torch_distributed_run(tmp_path):
     assert r["dry_run"] is True and r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["global_batch"] == 256 and r["value"] > 0
     assert r["dp_mode"] == "allreduce" and r["dp_ranks"] == 2 and r["dp_backend"] == "gloo" and r["train_global_batch"] == 256 and r["train_ms_per_step"] > 0
     assert r["zero1_dp_mode"] == "zero1:bf16" and r["zero1_dp_ranks"] == 2 and r["zero1_ms_per_step"] > 0
-    assert "train_leg_error" not in r and "zero1_leg_error" not in r
+    assert r["bf16wire_dp_mode"] == "allreduce" and r["bf16wire_dp_comm_dtype"] == "bf16" and r["bf16wire_ms_per_step"] > 0      # third leg: bf16 on the wire
+    assert "train_leg_error" not in r and "zero1_leg_error" not in r and "bf16wire_leg_error" not in r
     assert "[bench] headline done" in p.stderr and "[bench] train leg done" in p.stderr and "[bench] zero1 leg done" in p.stderr
+    assert "[bench] bf16wire leg done" in p.stderr
 
 
 # ---------------------------------------------------------------------------------------------- cond_router=False: token routing in TRAINING
