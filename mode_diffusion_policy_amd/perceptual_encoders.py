@@ -223,6 +223,97 @@ def _compute_dtype(x: torch.Tensor) -> torch.dtype:
     return torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
 
 
+# ---- convolutions of the TRAINING path.  Under autocast (how the reference trains, conf/config_calvin.yaml:37) every convolution costs, besides MIOpen's
+# kernels: a cast of its fp32 weight (forward), a cast of the bf16 weight gradient back (backward) and - the expensive part - MIOpen's weight-gradient
+# helpers (an fp32 workspace zeroed and cast back around every igemm_wrw kernel: 424 launches / 4.0 ms of a 43-ms agent step, the wrw kernels themselves at
+# ~100 TF/s).  A 1 x 1 / stride-1 convolution on channels_last data IS a GEMM over rows = pixels, so its weight gradient dW[Cout, Cin] = dY[R, Cout]^T X[R, Cin] is
+# exactly the library's row-major weight-gradient GEMM (mode_gemm, MODE_GEMM_A_KM | W_KN: operands where they lie, fp32 out): 36 of ResNet-50's 53 convolutions.
+# `_ConvFn` keeps MIOpen for the forward and the data gradient, takes the weight gradient of those through the HIP GEMM (K = pixels cut into groups, partial
+# sums added in group order: deterministic), hands autograd an fp32 gradient directly, and reads a compute-dtype SHADOW of the weight that is refreshed when
+# the parameter's version moves (all stale shadows of an encoder in one `_foreach_copy_`).  USE_HIP_CONV_WGRAD = False restores F.conv2d with per-call casts.
+USE_HIP_CONV_WGRAD = __import__("os").environ.get("MODE_ENC_HIPCONV", "1") == "1"     # MODE_ENC_HIPCONV=0: A/B runs
+_KOFFS: dict = {}
+
+
+def _wgrad_1x1(dy: torch.Tensor, x: torch.Tensor, wshape) -> torch.Tensor:
+    """dW of a 1 x 1 / stride-1 convolution from channels_last bf16 activations: [Cout, Cin, 1, 1] fp32."""
+    import ctypes as C
+    cout, cin = wshape[0], wshape[1]
+    R = dy.shape[0] * dy.shape[2] * dy.shape[3]
+    tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
+    G = max(1, min(R // 256, 768 // tiles))                     # ~3 workgroups per CU; every group keeps >= 4 K-steps
+    key = (R, G, dy.device)
+    offs = _KOFFS.get(key)
+    if offs is None:
+        offs = _KOFFS[key] = torch.tensor([(R * i) // G for i in range(G + 1)], dtype=torch.int32, device=dy.device)
+    part = torch.empty((G, cout, cin), dtype=torch.float32, device=dy.device)
+    d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=cout, N=cin, K=R, A=dy.data_ptr(), lda=cout, W=x.data_ptr(), ldw=cin,
+                       C=part.data_ptr(), ldc=cin, k_group_offsets=offs.data_ptr(), num_k_groups=G, c_group_stride=cout * cin,
+                       flags=L.GEMM_W_KN | L.GEMM_A_KM)
+    L.check(L.load().mode_gemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv 1x1 weight gradient")
+    return (part.sum(0) if G > 1 else part[0]).view(cout, cin, 1, 1)
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = conv2d(x, w) computed with `w_lp` (w in the compute dtype); differentiable in x and in the fp32 PARAMETER w."""
+
+    @staticmethod
+    def forward(ctx, x, w, w_lp, stride, padding):
+        ctx.save_for_backward(x, w_lp)
+        ctx.conf = (tuple(stride), tuple(padding), tuple(w.shape), w.dtype)
+        return F.conv2d(x, w_lp, None, stride, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_lp = ctx.saved_tensors
+        stride, padding, wshape, wdtype = ctx.conf
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dw = None
+        if (need_w and wshape[2] == 1 and wshape[3] == 1 and stride == (1, 1) and padding == (0, 0) and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+                and wshape[0] % 8 == 0 and wshape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last)):
+            dw = _wgrad_1x1(dy.contiguous(memory_format=torch.channels_last), x, wshape)
+            need_w = False
+        dx = None
+        if need_x or need_w:
+            dx, dwl, _ = torch.ops.aten.convolution_backward(dy, x, w_lp, None, stride, padding, (1, 1), False, (0, 0), 1, (need_x, need_w, False))
+            if need_w:
+                dw = dwl.to(wdtype)
+        return dx, dw, None, None, None
+
+
+def _shadow(conv: nn.Conv2d, dtype: torch.dtype) -> torch.Tensor:
+    """The convolution's weight in the compute dtype, cached on the module (not a buffer: never in a state_dict) and refreshed in place when the
+    parameter changes (its version counter / storage moved)."""
+    w = conv.weight
+    ent = conv.__dict__.get("_mode_lp")
+    if ent is None or ent[2].dtype != dtype or ent[2].device != w.device or ent[2].shape != w.shape:
+        ent = conv.__dict__["_mode_lp"] = [-1, 0, torch.empty_like(w, dtype=dtype)]
+    if ent[0] != w._version or ent[1] != w.data_ptr():
+        with torch.no_grad():
+            ent[2].copy_(w)
+        ent[0], ent[1] = w._version, w.data_ptr()
+    return ent[2]
+
+
+def refresh_conv_shadows(module: nn.Module, dtype: torch.dtype) -> None:
+    """All stale compute-dtype weight shadows of `module`'s convolutions in ONE multi-tensor copy (instead of one cast launch per convolution)."""
+    convs = module.__dict__.get("_mode_convs")
+    if convs is None:
+        convs = module.__dict__["_mode_convs"] = [m for m in module.modules() if isinstance(m, nn.Conv2d)]
+    src, dst = [], []
+    for c in convs:
+        w = c.weight
+        ent = c.__dict__.get("_mode_lp")
+        if ent is None or ent[2].dtype != dtype or ent[2].device != w.device or ent[2].shape != w.shape:
+            ent = c.__dict__["_mode_lp"] = [-1, 0, torch.empty_like(w, dtype=dtype)]
+        if ent[0] != w._version or ent[1] != w.data_ptr():
+            src.append(w.detach()); dst.append(ent[2])
+            ent[0], ent[1] = w._version, w.data_ptr()
+    if dst:
+        with torch.no_grad():
+            torch._foreach_copy_(dst, src)
+
+
 def _conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     """conv2d through MIOpen with the module's weight in the activations' dtype and layout.  The PARAMETER's storage is converted to channels_last
     once (values, shape and state_dict unchanged), so no per-call weight transposes are left."""
@@ -234,6 +325,10 @@ def _conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
         hit = _W_OVERRIDE.get(id(conv))
         if hit is not None and hit.dtype == _compute_dtype(x):
             return F.conv2d(x.to(hit.dtype), hit, None, conv.stride, conv.padding)
+    cd = _compute_dtype(x)
+    if (USE_HIP_CONV_WGRAD and x.is_cuda and cd == torch.bfloat16 and torch.is_grad_enabled() and (w.requires_grad or x.requires_grad) and conv.groups == 1
+            and conv.dilation == (1, 1) and conv.bias is None and isinstance(conv.padding, tuple)):
+        return _ConvFn.apply(x.to(cd), w, _shadow(conv, cd), conv.stride, conv.padding)
     return F.conv2d(x, w.to(x.dtype), None, conv.stride, conv.padding)
 
 
@@ -342,6 +437,8 @@ class _FiLMResNetPolicy(nn.Module):
     def forward(self, x, condition):
         if condition.dim() == 3:
             condition = condition.squeeze(1)
+        if USE_HIP_CONV_WGRAD and x.is_cuda and torch.is_grad_enabled() and _compute_dtype(x) == torch.bfloat16:
+            refresh_conv_shadows(self, torch.bfloat16)                              # one multi-tensor cast for all 53 weights, only when they changed
         x = self.resnet.stem(x)
         for i in range(1, 5):
             film = getattr(self, f"film{i}").params(condition.to(torch.float32))
@@ -398,6 +495,8 @@ class ResNetEncoderWithFiLM(nn.Module):
             x = x.reshape(B * t_steps, *x.shape[2:])
             if conditioning_vector is not None:
                 conditioning_vector = torch.cat([conditioning_vector for _ in range(t_steps)], dim=0)     # the reference's order (resnets.py:129)
+        if USE_HIP_CONV_WGRAD and x.is_cuda and torch.is_grad_enabled() and _compute_dtype(x) == torch.bfloat16:
+            refresh_conv_shadows(self, torch.bfloat16)
         x = bn_film_act(_conv2d(self.conv1, _to_layout(x)), self.bn1, relu=True)
         x = F.max_pool2d(x, 3, 2, 1)
         for i in range(1, 5):

@@ -390,3 +390,66 @@ def test_fused_pass_channels_last_equals_nchw(N, C_, H, W_, dtype, training):
     for a, b in zip(outs[torch.channels_last], outs[torch.contiguous_format]):
         assert a.shape == b.shape and rel(a, b) < tol, rel(a, b)
     assert rel(outs[torch.channels_last][0], outs[torch.contiguous_format][0]) < (1e-6 if not training else tol)    # eval forward: same arithmetic per element
+
+
+# ---------------------------------------------------------------------------------------------- convolutions of the training path (_ConvFn)
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Cin,Cout,H,W_,k,stride,pad", [(6, 256, 64, 56, 56, 1, 1, 0), (3, 64, 256, 17, 9, 1, 1, 0), (2, 1024, 2048, 7, 7, 1, 1, 0), (5, 72, 40, 6, 6, 1, 1, 0),
+                                                           (4, 64, 64, 14, 14, 3, 1, 1), (4, 128, 256, 14, 14, 1, 2, 0), (2, 3, 64, 32, 32, 7, 2, 3)])
+def test_conv_fn_gradients_vs_torch_fp32(N, Cin, Cout, H, W_, k, stride, pad):
+    """`_ConvFn` (MIOpen forward / data gradient on the bf16 shadow, weight gradient of 1 x 1 / stride-1 convolutions through the HIP row-major
+    weight-gradient GEMM in K-groups, fp32 gradient handed to autograd) against torch's conv2d autograd in fp32 on the same bf16-rounded values."""
+    torch.manual_seed(N + Cin + Cout)
+    conv = torch.nn.Conv2d(Cin, Cout, k, stride=stride, padding=pad, bias=False).cuda()
+    E._store_channels_last(conv)
+    x = torch.randn(N, Cin, H, W_, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = E._conv2d(conv, x)
+    assert y.dtype == torch.bfloat16 and type(y.grad_fn).__name__ == "_ConvFnBackward"
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    assert conv.weight.grad.dtype == torch.float32 and conv.weight.grad.shape == conv.weight.shape
+    xr = x.detach().float().requires_grad_(True); wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, None, stride, pad)
+    yr.backward(dy.float())
+    assert rel(y.float(), yr) < 5e-3 and rel(x.grad.float(), xr.grad) < 5e-3
+    one = k == 1 and stride == 1
+    assert rel(conv.weight.grad, wr.grad) < (1e-5 if one else 5e-3)            # the HIP path accumulates AND stores in fp32; MIOpen's returns bf16
+    # deterministic (partial sums of the K-groups are added in group order) and the shadow follows the parameter
+    g0 = conv.weight.grad.clone(); conv.weight.grad = None; x.grad = None
+    E._conv2d(conv, x).backward(dy)
+    if one:                                                                    # (MIOpen's own weight-gradient kernels add with atomics: not bit-reproducible)
+        assert torch.equal(conv.weight.grad, g0)
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+    y2 = E._conv2d(conv, x)
+    assert rel(y2.float(), 2 * yr) < 5e-3
+
+
+@pytest.mark.gpu
+def test_encoder_gradients_with_and_without_the_hip_conv_path():
+    """FiLM-ResNet-50 under autocast (eval-mode BatchNorm: training-mode statistics on a small batch make the gradients chaotic - two runs of the SAME path
+    differ by O(1) there, scripts/conv_path_ab.py): every parameter gradient with `_ConvFn` against the plain F.conv2d + autocast-cast path.  The yardstick is
+    how far the plain path is from ITSELF on a second run (MIOpen's split-K kernels add with atomics): measured 4e-2 worst tensor for both comparisons."""
+    torch.manual_seed(3)
+    enc = E.FiLMResNet50Policy(32).cuda().eval()
+    for n_, p_ in enc.named_parameters():
+        if n_.startswith("film"):
+            torch.nn.init.normal_(p_, std=0.05)
+    img = torch.randn(4, 3, 96, 96, device="cuda"); cond = torch.randn(4, 32, device="cuda")
+    grads = {}
+    for run, flag in (("hip", True), ("plain", False), ("plain2", False)):
+        enc.zero_grad(set_to_none=True)
+        E.USE_HIP_CONV_WGRAD = flag
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = enc(img, cond)
+            (out.float() ** 2).mean().backward()
+        finally:
+            E.USE_HIP_CONV_WGRAD = True
+        grads[run] = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+        assert all(g.dtype == torch.float32 for g in grads[run].values())
+    assert grads["hip"].keys() == grads["plain"].keys()
+    worst = max(rel(grads["hip"][n], grads["plain"][n]) for n in grads["hip"])
+    self_gap = max(rel(grads["plain2"][n], grads["plain"][n]) for n in grads["hip"])
+    print(f"worst tensor: hip vs plain {worst:.2e}, plain vs plain again {self_gap:.2e}")
+    assert worst < max(2.0 * self_gap, 6e-2)
