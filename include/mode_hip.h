@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MODE_HIP_ABI_VERSION 9
+#define MODE_HIP_ABI_VERSION 10
 
 typedef enum ModeStatus {
   MODE_OK = 0,
@@ -122,7 +122,7 @@ typedef struct ModeGemmDesc {
   int64_t c_group_stride;         /* C + z*c_group_stride (elements); an empty range yields an all-zero C_z                                */
   int32_t flags;                  /* MODE_GEMM_SKINNY_OK: fp32, M <= 16 may use the weight-streaming GEMV kernel (wave-tree reduction
                                      instead of the MFMA k-ordered chain: same fp32 accuracy, different rounding)                   */
-  const int32_t* w_rows;          /* MODE_GEMM_A_KM only: optional gather of W's K rows (row r of the reduction reads W[w_rows[r]])  */
+  const int32_t* w_rows;          /* MODE_GEMM_A_KM only: optional gather of W's K rows (row r of the reduction reads W[w_rows[r]]; ABI 10: a negative index reads a zero row) */
   /* fused ln_2 (bf16 only).  Producer, MODE_EPI_RESIDUAL_NORM (N % 64 == 0): */
   void* C2; int64_t ldc2;         /* bf16 [M, N]: (acc + resid) * gain[n] — the un-normalised, gain-scaled input of the next GEMM       */
   const float* gain;              /* fp32 [N]: the RMSNorm gain                                                                          */
@@ -131,6 +131,10 @@ typedef struct ModeGemmDesc {
   const float* row_ss;            /* 1 / max(sqrt(sum_j row_ss[token][j]) * K^-1/2, row_eps) before bias and activation, i.e. the GEMM   */
   int32_t row_ss_n;               /* reads A = x*gain and produces RMSNorm(x) @ W^T (K = the normalised width D)                          */
   float row_eps;
+  /* (ABI 10) w_rows in TAPS - the weight gradient of a k x k convolution as ONE product over its k*k filter taps (MODE_GEMM_A_KM | W_KN, bf16):  */
+  int32_t w_tap_cols;             /* > 0: the N output columns are N / w_tap_cols taps of w_tap_cols columns each; tap t reads columns              */
+  int64_t w_rows_tap_stride;      /* [0, w_tap_cols) of W through the index table w_rows + t * w_rows_tap_stride (elements).  w_tap_cols % 64 == 0,  */
+                                  /* N % w_tap_cols == 0.  0 = one table for all columns.  (perceptual_encoders.py: dW[Cout][tap][Cin] of a 3 x 3 conv) */
 } ModeGemmDesc;
 #define MODE_GEMM_SKINNY_OK 1
 /* Backward-pass operand layouts (bf16, epilogue NONE; replace autograd's mm_backward for nn.Linear, i.e. the `grad @ W` and

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MODE_HIP_LIB", os.path.join(_HERE, "libmode_hip.so"))
 
 MODE_BF16, MODE_F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_RESIDUAL_NORM = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 9
+ABI_VERSION = 10
 GEMM_SKINNY_OK, GEMM_W_KN, GEMM_A_KM, GEMM_UNIFORM_GROUPS, GEMM_SMALL_ROWS, GEMM_IDENTITY_ROWS = 1, 2, 4, 8, 16, 32
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -30,7 +30,8 @@ class ModeGemmDesc(C.Structure):
                 ("bias", c_vp), ("bias_expert_stride", c_i64), ("resid", c_vp), ("ldr", c_i64), ("C", c_vp), ("ldc", c_i64),
                 ("a_rows", c_vp), ("expert_offsets", c_vp), ("num_experts", c_i32), ("split_k", c_i32), ("split_stride", c_i64), ("k_group_offsets", c_vp), ("num_k_groups", c_i32),
                 ("c_group_stride", c_i64), ("flags", c_i32), ("w_rows", c_vp),
-                ("C2", c_vp), ("ldc2", c_i64), ("gain", c_vp), ("row_ss_out", c_vp), ("row_ss", c_vp), ("row_ss_n", c_i32), ("row_eps", c_f32)]
+                ("C2", c_vp), ("ldc2", c_i64), ("gain", c_vp), ("row_ss_out", c_vp), ("row_ss", c_vp), ("row_ss_n", c_i32), ("row_eps", c_f32),
+                ("w_tap_cols", c_i32), ("w_rows_tap_stride", c_i64)]
 
 
 class ModeEmbedDesc(C.Structure):

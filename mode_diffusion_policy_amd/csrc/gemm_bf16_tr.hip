@@ -31,6 +31,7 @@ struct TrParams {
   const int* offsets; int E;              // data gradient, grouped rows (MoE): expert e owns rows [offsets[e], offsets[e+1])
   const int* koffs; long c_gstride;       // weight gradient: blockIdx.z = group, K rows [koffs[z], koffs[z+1])
   const int* w_rows;                      // weight gradient: gather of W's K rows (dispatch permutation)
+  int tap_cols; long tap_stride;          // w_rows in taps: output column n belongs to tap n / tap_cols, which reads W's columns n % tap_cols through w_rows + tap * tap_stride
   int M, N, K, m_tiles, n_tiles;
   int split_k; long split_stride;         // data gradient only: blockIdx.y = K-slice, partial sums to C + slice*split_stride (the consumer adds the slabs)
 };
@@ -111,6 +112,11 @@ __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const T
   if (!A_KM && p.split_k > 1) { const int ks = p.K / p.split_k; kb = blockIdx.y * ks; ke = kb + ks; }
   const int nk = (ke - kb + BKT - 1) / BKT;
   const uint16_t* W = p.W + (long)expert * p.w_estride;
+  // taps (the k x k filter positions of a convolution's weight gradient, one product): this tile's tap selects the index table and the W columns
+  const int tap = (A_KM && p.tap_cols > 0) ? n0 / p.tap_cols : 0;
+  const int nw0 = n0 - tap * (p.tap_cols > 0 ? p.tap_cols : 0);           // first W column of the tile
+  const int nw_end = (A_KM && p.tap_cols > 0) ? p.tap_cols : p.N;
+  const int* w_rows = p.w_rows ? p.w_rows + (long)tap * p.tap_stride : nullptr;
 
   // ---- DMA sources.  [k][cols] tiles: piece P covers RPP tile rows; lane l -> row P*RPP + l / chunks_per_row, physical chunk l % chunks_per_row
   const int kra = lane >> 4, pca = lane & 15;          // [k][128] A tile (weight gradient)
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const T
 #pragma unroll
   for (int q = 0; q < NPW; ++q) {
     const int c = pcw ^ (kn_swz<BN>((wave * NPW + q) * RPP + krw) << 1);
-    kn_col_w[q] = min(n0 + c * 8, p.N - 8);
+    kn_col_w[q] = min(nw0 + c * 8, nw_end - 8);
   }
   // [rows][64 k] A tile of the data gradient (same image as the forward kernel): 8-row pieces, chunk ^ (row & 7)
   const uint16_t* a_src[4];
@@ -142,11 +148,11 @@ __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const T
 #pragma unroll
   for (int q = 0; q < NPW; ++q) widx[q] = 0;
   auto load_widx = [&](int kt) {
-    if (A_KM && NS <= 2 && p.w_rows) {
+    if (A_KM && NS <= 2 && w_rows) {
 #pragma unroll
       for (int q = 0; q < NPW; ++q) {
         const int r = kb + kt * BKT + (wave * NPW + q) * RPP + krw;
-        widx[q] = p.w_rows[min(r, ke - 1)];
+        widx[q] = w_rows[min(r, ke - 1)];
       }
     }
   };
@@ -171,9 +177,12 @@ __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const T
       long r = kb + kt * BKT + P * RPP + krw;
       if constexpr (A_KM) {
         r = min(r, (long)ke - 1);
-        if (NS <= 2 && p.w_rows) r = widx[q];
+        if (NS <= 2 && w_rows) r = widx[q];
       }
       const uint16_t* src = W + r * p.ldw + kn_col_w[q];
+      if constexpr (A_KM && NS <= 2) {
+        if (w_rows) src = r < 0 ? g_zero_row + (lane & 15) * 8 : src;       // a negative index = a zero row (out-of-image filter taps of a convolution)
+      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + A_BYTES + P * 1024), 16, 0, 0);
     }
@@ -365,6 +374,11 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.A = (const uint16_t*)d->A; p.lda = d->lda; p.W = (const uint16_t*)d->W; p.ldw = d->ldw; p.w_estride = d->w_expert_stride;
   p.C = d->C; p.ldc = d->ldc; p.offsets = d->expert_offsets; p.E = d->num_experts;
   p.koffs = d->k_group_offsets; p.c_gstride = d->c_group_stride; p.w_rows = d->w_rows;
+  p.tap_cols = 0; p.tap_stride = 0;
+  if (d->w_tap_cols > 0) {                                      // w_rows in taps: a tile must lie inside one tap
+    if (!a_km || !d->w_rows || d->w_tap_cols % 64 || d->N % d->w_tap_cols) return MODE_ERR_UNSUPPORTED;
+    p.tap_cols = d->w_tap_cols; p.tap_stride = d->w_rows_tap_stride;
+  }
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.split_k = split; p.split_stride = d->split_stride;
   p.m_tiles = p.n_tiles = 0;
@@ -376,6 +390,7 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
   // measured (profiles/): weight gradients (short K per tile, >= 3 workgroups per CU) are 4 % faster single-buffered; data gradients are not
   if (cfg == 0) cfg = (a_km && t128 >= 768) ? 5 : ((t128 * split >= 448 || d->w_rows) ? 1 : 2);      // K-slices count as workgroups
   if (d->w_rows && (cfg == 2 || cfg == 3)) cfg = 1;
+  if (p.tap_cols > 0 && p.tap_cols % 128 && (cfg == 1 || cfg == 3 || cfg == 5)) cfg = 4;      // 64-column taps: 64-wide tiles (two-slot ring: gathered rows)
   const bool ob = d->out_dtype == MODE_BF16;
 #define MODE_TR_CFG(BN, NS)                                                                     \
   {                                                                                             \

@@ -241,7 +241,7 @@ def _wgrad_1x1(dy: torch.Tensor, x: torch.Tensor, wshape) -> torch.Tensor:
     cout, cin = wshape[0], wshape[1]
     R = dy.shape[0] * dy.shape[2] * dy.shape[3]
     tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
-    G = max(1, min(R // 256, 768 // tiles))                     # ~3 workgroups per CU; every group keeps >= 4 K-steps
+    G = max(1, min(R // 256, 768 // tiles, max(4, (8 << 20) // (cout * cin * 4))))      # ~3 workgroups per CU, >= 4 K-steps per group, <= 8 MiB of partial sums
     key = (R, G, dy.device)
     offs = _KOFFS.get(key)
     if offs is None:
@@ -252,6 +252,59 @@ def _wgrad_1x1(dy: torch.Tensor, x: torch.Tensor, wshape) -> torch.Tensor:
                        flags=L.GEMM_W_KN | L.GEMM_A_KM)
     L.check(L.load().mode_gemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv 1x1 weight gradient")
     return (part.sum(0) if G > 1 else part[0]).view(cout, cin, 1, 1)
+
+
+_TAPS: dict = {}
+
+
+def _wgrad_taps(dy: torch.Tensor, x: torch.Tensor, wshape, stride, padding) -> torch.Tensor:
+    """dW of a k x k convolution (any stride, zero padding) from channels_last bf16 activations as k*k weight-gradient GEMMs, one per filter tap:
+    dW[:, :, kh, kw] = dY[R_out, Cout]^T X[rows(kh, kw), Cin] - the input rows that tap (kh, kw) pairs with the output pixels (a zero row where the tap falls
+    outside the image), gathered inside the GEMM's DMA through an index table (mode_gemm `w_rows`, -1 = zero row; cached per geometry).  Each tap writes its [Cout, Cin] slice of the channels_last
+    gradient ([Cout][kh][kw][Cin] in memory) directly: C = base + tap * Cin, ldc = k*k*Cin.  fp32 [Cout, Cin, k, k], channels_last."""
+    import ctypes as C
+    cout, cin, kh_, kw_ = wshape
+    n, _, H, W_ = x.shape
+    ho, wo = dy.shape[2], dy.shape[3]
+    ph, pw = padding
+    sh, sw = stride
+    R = n * ho * wo
+    key = (n, H, W_, kh_, kw_, sh, sw, ph, pw, x.device)
+    idx = _TAPS.get(key)
+    if idx is None:                                             # row of x that tap (a, b) pairs with output pixel (n, h, w); -1 (= a zero row) outside the image
+        dev = x.device
+        nn_ = torch.arange(n, device=dev).view(n, 1, 1); hh = torch.arange(ho, device=dev).view(1, ho, 1); ww = torch.arange(wo, device=dev).view(1, 1, wo)
+        tabs = []
+        for a in range(kh_):
+            for b in range(kw_):
+                hi, wi = hh * sh + a - ph, ww * sw + b - pw
+                ok = (hi >= 0) & (hi < H) & (wi >= 0) & (wi < W_)
+                tabs.append(torch.where(ok, (nn_ * H + hi) * W_ + wi, torch.full((), -1, device=dev)).reshape(-1))
+        idx = _TAPS[key] = torch.stack(tabs).to(torch.int32).contiguous()
+    xp = x
+    taps = kh_ * kw_
+    one_launch = cin % 64 == 0                                   # all taps as ONE product (N = taps * Cin, ABI 10 `w_tap_cols`): the dY tiles are shared through L2
+    tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * taps
+    G = max(1, min(R // 256, 512 // tiles, max(4, (8 << 20) // (cout * cin * taps * 4))))      # scripts/conv_wgrad_probe.py: 40-80 groups at 64 / 128 channels, 10-20 at 256, ~4 at 512; <= 8 MiB of partial sums
+    okey = (R, G, dy.device)
+    offs = _KOFFS.get(okey)
+    if offs is None:
+        offs = _KOFFS[okey] = torch.tensor([(R * i) // G for i in range(G + 1)], dtype=torch.int32, device=dy.device)
+    part = torch.empty((G, cout, kh_, kw_, cin), dtype=torch.float32, device=dy.device)       # channels_last order of [Cout, Cin, kh, kw]
+    lib = L.load(); st = torch.cuda.current_stream().cuda_stream
+    if one_launch:
+        d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=cout, N=taps * cin, K=R, A=dy.data_ptr(), lda=cout, W=xp.data_ptr(), ldw=cin,
+                           C=part.data_ptr(), ldc=taps * cin, k_group_offsets=offs.data_ptr(), num_k_groups=G, c_group_stride=cout * taps * cin,
+                           w_rows=idx.data_ptr(), w_tap_cols=cin, w_rows_tap_stride=R, flags=L.GEMM_W_KN | L.GEMM_A_KM)
+        L.check(lib.mode_gemm(C.byref(d), st), "conv weight gradient (taps)")
+    else:
+        for t in range(taps):
+            d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=cout, N=cin, K=R, A=dy.data_ptr(), lda=cout, W=xp.data_ptr(), ldw=cin,
+                               C=part.data_ptr() + t * cin * 4, ldc=taps * cin, k_group_offsets=offs.data_ptr(), num_k_groups=G, c_group_stride=cout * taps * cin,
+                               w_rows=idx[t].data_ptr(), flags=L.GEMM_W_KN | L.GEMM_A_KM)
+            L.check(lib.mode_gemm(C.byref(d), st), "conv weight gradient (tap GEMM)")
+    dw = part.sum(0) if G > 1 else part[0]
+    return dw.permute(0, 3, 1, 2)                                  # [Cout, Cin, kh, kw] view with channels_last strides
 
 
 class _ConvFn(torch.autograd.Function):
@@ -269,9 +322,13 @@ class _ConvFn(torch.autograd.Function):
         stride, padding, wshape, wdtype = ctx.conf
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dw = None
-        if (need_w and wshape[2] == 1 and wshape[3] == 1 and stride == (1, 1) and padding == (0, 0) and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
-                and wshape[0] % 8 == 0 and wshape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last)):
-            dw = _wgrad_1x1(dy.contiguous(memory_format=torch.channels_last), x, wshape)
+        if (need_w and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and wshape[0] % 8 == 0 and wshape[1] % 8 == 0
+                and x.is_contiguous(memory_format=torch.channels_last)):
+            dyc = dy.contiguous(memory_format=torch.channels_last)
+            if wshape[2] == 1 and wshape[3] == 1 and stride == (1, 1) and padding == (0, 0):
+                dw = _wgrad_1x1(dyc, x, wshape)
+            else:
+                dw = _wgrad_taps(dyc, x, wshape, stride, padding)
             need_w = False
         dx = None
         if need_x or need_w:

@@ -395,7 +395,8 @@ def test_fused_pass_channels_last_equals_nchw(N, C_, H, W_, dtype, training):
 # ---------------------------------------------------------------------------------------------- convolutions of the training path (_ConvFn)
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,Cin,Cout,H,W_,k,stride,pad", [(6, 256, 64, 56, 56, 1, 1, 0), (3, 64, 256, 17, 9, 1, 1, 0), (2, 1024, 2048, 7, 7, 1, 1, 0), (5, 72, 40, 6, 6, 1, 1, 0),
-                                                           (4, 64, 64, 14, 14, 3, 1, 1), (4, 128, 256, 14, 14, 1, 2, 0), (2, 3, 64, 32, 32, 7, 2, 3)])
+                                                           (4, 64, 64, 14, 14, 3, 1, 1), (4, 128, 256, 14, 14, 1, 2, 0), (2, 3, 64, 32, 32, 7, 2, 3), (3, 128, 128, 28, 28, 3, 2, 1),
+                                                           (2, 512, 512, 7, 7, 3, 1, 1), (5, 64, 64, 9, 13, 3, 1, 1)])
 def test_conv_fn_gradients_vs_torch_fp32(N, Cin, Cout, H, W_, k, stride, pad):
     """`_ConvFn` (MIOpen forward / data gradient on the bf16 shadow, weight gradient of 1 x 1 / stride-1 convolutions through the HIP row-major
     weight-gradient GEMM in K-groups, fp32 gradient handed to autograd) against torch's conv2d autograd in fp32 on the same bf16-rounded values."""
@@ -412,7 +413,7 @@ def test_conv_fn_gradients_vs_torch_fp32(N, Cin, Cout, H, W_, k, stride, pad):
     yr = torch.nn.functional.conv2d(xr, wr, None, stride, pad)
     yr.backward(dy.float())
     assert rel(y.float(), yr) < 5e-3 and rel(x.grad.float(), xr.grad) < 5e-3
-    one = k == 1 and stride == 1
+    one = Cin % 8 == 0                                                          # every shape but the 3-channel stem goes through the HIP GEMMs
     assert rel(conv.weight.grad, wr.grad) < (1e-5 if one else 5e-3)            # the HIP path accumulates AND stores in fp32; MIOpen's returns bf16
     # deterministic (partial sums of the K-groups are added in group order) and the shadow follows the parameter
     g0 = conv.weight.grad.clone(); conv.weight.grad = None; x.grad = None

@@ -289,3 +289,28 @@ def test_pptr_training_shapes_full_size(force_pptr):
         assert rel(dU[:, s].sum(0), dP[s].float() @ W1[e].float()) < 1e-5
         assert rel(dW1[e], dP[s].float().t() @ U[s].float()) < 1e-5
         o += c
+
+
+@pytest.mark.parametrize("R,Rw,M,cin,taps,groups", [(1000, 1300, 64, 64, 9, 7), (777, 900, 256, 128, 4, 3), (300, 300, 136, 192, 9, 1), (4096, 5000, 128, 64, 1, 16)])
+def test_wgrad_w_rows_in_taps(R, Rw, M, cin, taps, groups):
+    """ABI 10: one weight-gradient product over `taps` column blocks, tap t reading W's rows through its own index table (a k x k convolution's dW as
+    one launch: C[M][t * cin + c] = sum_r A[r][M] * W[idx[t][r]][c]), K cut into groups of arbitrary length."""
+    g = torch.Generator().manual_seed(R + cin)
+    A = torch.randn(R, M, generator=g).to(torch.bfloat16).cuda()
+    X = torch.randn(Rw, cin, generator=g).to(torch.bfloat16).cuda()
+    idx = torch.randint(0, Rw, (taps, R), generator=g, dtype=torch.int32)
+    idx[torch.rand(taps, R, generator=g) < 0.15] = -1                          # a negative index reads a zero row (out-of-image filter taps)
+    idx = idx.cuda()
+    cuts = sorted(torch.randint(0, R + 1, (groups - 1,), generator=g).tolist())
+    off = torch.tensor([0] + cuts + [R], dtype=torch.int32).cuda()
+    Cc = torch.full((groups, M, taps * cin), float("nan"), device="cuda")
+    d = _desc(out_dtype=L.MODE_F32, M=M, N=taps * cin, K=R, A=p(A), lda=M, W=p(X), ldw=cin, C=p(Cc), ldc=taps * cin, k_group_offsets=p(off), num_k_groups=groups,
+              c_group_stride=M * taps * cin, w_rows=p(idx), w_tap_cols=cin, w_rows_tap_stride=R, flags=L.GEMM_W_KN | L.GEMM_A_KM)
+    L.check(L.load().mode_gemm(C.byref(d), stream()), "wgrad taps")
+    tot = Cc.sum(0)
+    for t in range(taps):
+        Xt = X[idx[t].clamp_min(0).long()].float() * (idx[t] >= 0).float()[:, None]
+        assert rel(tot[:, t * cin:(t + 1) * cin], A.float().t() @ Xt) < 1e-5, t
+    bad = _desc(out_dtype=L.MODE_F32, M=M, N=taps * cin, K=R, A=p(A), lda=M, W=p(X), ldw=cin, C=p(Cc), ldc=taps * cin, w_rows=p(idx), w_tap_cols=40,
+                w_rows_tap_stride=R, flags=L.GEMM_W_KN | L.GEMM_A_KM)
+    assert L.load().mode_gemm(C.byref(bad), stream()) != 0                      # taps must be multiples of 64 columns
