@@ -420,7 +420,10 @@ __global__ __launch_bounds__(256) void bn_film_act_fwd_nhwc_kernel(const ModeBnF
   }
 }
 
-template <typename T>
+// PLAIN = no FiLM on either side (49 of a FiLM-ResNet-50's 53 BatchNorms): four of the six sums are FiLM gradients nobody reads - only sum(dv) and
+// sum(dv * xhat) are accumulated (zeros are written for the rest), and the pass is no longer VALU-bound (per 16 bytes of each operand: ~90 instead of ~200
+// vector instructions; measured inside the agent step: see DESIGN.md section 4 "Round 4").
+template <typename T, bool PLAIN>
 __global__ __launch_bounds__(256) void bn_film_act_bwd_sums_nhwc_kernel(const ModeBnFilmDesc d, const T* __restrict__ dy, const float* __restrict__ mean,
                                                                         const float* __restrict__ invstd, int S, float* __restrict__ sums) {
   constexpr int W = Nhwc<T>::W, CT = Nhwc<T>::CT;
@@ -454,6 +457,15 @@ __global__ __launch_bounds__(256) void bn_film_act_bwd_sums_nhwc_kernel(const Mo
         ldv<T, W>(x, o, xn); ldv<T, W>(dy, o, gn);
         if (res) ldv<T, W>(res, o, rn);
       }
+      if constexpr (PLAIN) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const float v1 = __builtin_fmaf(xv[j], r.sc[j], r.sh[j]);
+          const float v3 = res ? v1 + rv[j] : v1;
+          const float dv = (d.relu && v3 <= 0.f) ? 0.f : gv[j];
+          a[4 * W + j] += dv; a[5 * W + j] = __builtin_fmaf(dv, (xv[j] - mu[j]) * is[j], a[5 * W + j]);
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < W; ++j) {
         const float gy = gv[j];
@@ -466,6 +478,7 @@ __global__ __launch_bounds__(256) void bn_film_act_bwd_sums_nhwc_kernel(const Mo
         const float dv1 = r.pre ? dv2 * r.pg[j] : dv2;
         a[0 * W + j] = __builtin_fmaf(gy, v4, a[0 * W + j]); a[1 * W + j] += gy; a[2 * W + j] = __builtin_fmaf(dv2, v1, a[2 * W + j]); a[3 * W + j] += dv2;
         a[4 * W + j] += dv1; a[5 * W + j] = __builtin_fmaf(dv1, (xv[j] - mu[j]) * is[j], a[5 * W + j]);
+      }
       }
     }
   }
@@ -666,8 +679,14 @@ extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, con
   const dim3 g((d->C + CT - 1) / CT, d->N, S);
   if (phase != 2) {                                            // reductions: FiLM gradients per (n, c), BatchNorm affine gradients per channel
     if (cl) {
-      if (d->dtype == MODE_BF16) hipLaunchKernelGGL(bn_film_act_bwd_sums_nhwc_kernel<uint16_t>, g, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, S, sums);
-      else hipLaunchKernelGGL(bn_film_act_bwd_sums_nhwc_kernel<float>, g, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, S, sums);
+      const bool plain = !d->pre_gamma && !d->post_gamma;
+      if (d->dtype == MODE_BF16) {
+        if (plain) hipLaunchKernelGGL((bn_film_act_bwd_sums_nhwc_kernel<uint16_t, true>), g, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, S, sums);
+        else hipLaunchKernelGGL((bn_film_act_bwd_sums_nhwc_kernel<uint16_t, false>), g, dim3(256), 0, s, *d, (const uint16_t*)dy, mean, invstd, S, sums);
+      } else {
+        if (plain) hipLaunchKernelGGL((bn_film_act_bwd_sums_nhwc_kernel<float, true>), g, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, S, sums);
+        else hipLaunchKernelGGL((bn_film_act_bwd_sums_nhwc_kernel<float, false>), g, dim3(256), 0, s, *d, (const float*)dy, mean, invstd, S, sums);
+      }
     } else {
 #define K_BS(T, V, s_) hipLaunchKernelGGL((bn_film_act_bwd_sums_kernel<T, V>), grid, dim3(256), 0, s_, *d, (const T*)dy, mean, invstd, sums)
       BN_DISPATCH(K_BS, d->dtype, vec, s);
