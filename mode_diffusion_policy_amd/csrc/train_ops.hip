@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_bias_bf16x8_kernel(const uint1
           const float v = bf16_bits_to_f32(q ? wv[j] >> 16 : wv[j] & 0xffff), g = bf16_bits_to_f32(q ? wg[j] >> 16 : wg[j] & 0xffff);
           float dh = bf16_bits_to_f32(q ? wd[j] >> 16 : wd[j] & 0xffff);
           if (thresh) dh = drop_keep(seed, (uint64_t)(r * Hdim + c + 2 * j + q), thresh) ? dh * inv_keep : 0.f;
-          const float sgm = 1.0f / (1.0f + __expf(-g));
+          const float sgm = __builtin_amdgcn_rcpf(1.0f + __expf(-g));       // hardware reciprocal (1 ulp) like the forward's silu_f: `1.0f / x` is a ~10-instruction IEEE sequence
           dv[q] = dh * g * sgm;                                             // d/d value = silu(gate)
           dg[q] = dh * v * sgm * (1.0f + g * (1.0f - sgm));                  // d/d gate  = value * silu'(gate)
         }

@@ -235,9 +235,35 @@ USE_HIP_CONV_WGRAD = __import__("os").environ.get("MODE_ENC_HIPCONV", "1") == "1
 _KOFFS: dict = {}
 
 
+def _is_1x1(wshape, stride, padding, cin_mult: int = 64) -> bool:
+    return wshape[2] == 1 and wshape[3] == 1 and tuple(stride) == (1, 1) and tuple(padding) == (0, 0) and wshape[1] % cin_mult == 0 and wshape[0] % 64 == 0
+
+
+def _gemm_1x1_fwd(x: torch.Tensor, w_lp: torch.Tensor) -> torch.Tensor:
+    """1 x 1 / stride-1 convolution on channels_last bf16 data = Y[R, Cout] = X[R, Cin] W[Cout, Cin]^T: the library's forward GEMM (scripts/conv1x1_probe.py:
+    12-27 us where MIOpen's implicit-GEMM kernels + their split-K helpers take 20-100 us at the ResNet-50 shapes)."""
+    B, cin, H, W_ = x.shape
+    cout = w_lp.shape[0]
+    y = torch.empty((B, cout, H, W_), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=B * H * W_, N=cout, K=cin, A=x.data_ptr(), lda=cin, W=w_lp.data_ptr(), ldw=cin,
+                       C=y.data_ptr(), ldc=cout)
+    L.check(L.load().mode_gemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv 1x1 forward")
+    return y
+
+
+def _gemm_1x1_dgrad(dy: torch.Tensor, w_lp: torch.Tensor, xshape) -> torch.Tensor:
+    """dX[R, Cin] = dY[R, Cout] W[Cout, Cin]: the data-gradient GEMM on the [out, in] weight where it lies (MODE_GEMM_W_KN)."""
+    B, cin, H, W_ = xshape
+    cout = w_lp.shape[0]
+    dx = torch.empty((B, cin, H, W_), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=B * H * W_, N=cin, K=cout, A=dy.data_ptr(), lda=cout, W=w_lp.data_ptr(), ldw=cin,
+                       C=dx.data_ptr(), ldc=cin, flags=L.GEMM_W_KN)
+    L.check(L.load().mode_gemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv 1x1 data gradient")
+    return dx
+
+
 def _wgrad_1x1(dy: torch.Tensor, x: torch.Tensor, wshape) -> torch.Tensor:
     """dW of a 1 x 1 / stride-1 convolution from channels_last bf16 activations: [Cout, Cin, 1, 1] fp32."""
-    import ctypes as C
     cout, cin = wshape[0], wshape[1]
     R = dy.shape[0] * dy.shape[2] * dy.shape[3]
     tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
@@ -262,7 +288,6 @@ def _wgrad_taps(dy: torch.Tensor, x: torch.Tensor, wshape, stride, padding) -> t
     dW[:, :, kh, kw] = dY[R_out, Cout]^T X[rows(kh, kw), Cin] - the input rows that tap (kh, kw) pairs with the output pixels (a zero row where the tap falls
     outside the image), gathered inside the GEMM's DMA through an index table (mode_gemm `w_rows`, -1 = zero row; cached per geometry).  Each tap writes its [Cout, Cin] slice of the channels_last
     gradient ([Cout][kh][kw][Cin] in memory) directly: C = base + tap * Cin, ldc = k*k*Cin.  fp32 [Cout, Cin, k, k], channels_last."""
-    import ctypes as C
     cout, cin, kh_, kw_ = wshape
     n, _, H, W_ = x.shape
     ho, wo = dy.shape[2], dy.shape[3]
@@ -314,6 +339,8 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, w_lp, stride, padding):
         ctx.save_for_backward(x, w_lp)
         ctx.conf = (tuple(stride), tuple(padding), tuple(w.shape), w.dtype)
+        if x.dtype == torch.bfloat16 and _is_1x1(w.shape, stride, padding) and x.is_contiguous(memory_format=torch.channels_last):
+            return _gemm_1x1_fwd(x, w_lp)
         return F.conv2d(x, w_lp, None, stride, padding)
 
     @staticmethod
@@ -331,8 +358,13 @@ class _ConvFn(torch.autograd.Function):
                 dw = _wgrad_taps(dyc, x, wshape, stride, padding)
             need_w = False
         dx = None
+        if need_x and dy.dtype == torch.bfloat16 and _is_1x1(wshape, stride, padding, 8) and x.is_contiguous(memory_format=torch.channels_last):
+            dx = _gemm_1x1_dgrad(dy.contiguous(memory_format=torch.channels_last), w_lp, x.shape)
+            need_x = False
         if need_x or need_w:
-            dx, dwl, _ = torch.ops.aten.convolution_backward(dy, x, w_lp, None, stride, padding, (1, 1), False, (0, 0), 1, (need_x, need_w, False))
+            dxl, dwl, _ = torch.ops.aten.convolution_backward(dy, x, w_lp, None, stride, padding, (1, 1), False, (0, 0), 1, (need_x, need_w, False))
+            if need_x:
+                dx = dxl
             if need_w:
                 dw = dwl.to(wdtype)
         return dx, dw, None, None, None
@@ -378,11 +410,20 @@ def _conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     if CHANNELS_LAST and w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
         with torch.no_grad():
             w.data = w.data.contiguous(memory_format=torch.channels_last)
+    cd = _compute_dtype(x)
+    hip_1x1 = (USE_HIP_CONV_WGRAD and x.is_cuda and cd == torch.bfloat16 and conv.groups == 1 and conv.dilation == (1, 1) and conv.bias is None
+               and isinstance(conv.padding, tuple) and _is_1x1(w.shape, conv.stride, conv.padding))
     if _W_OVERRIDE is not None:
         hit = _W_OVERRIDE.get(id(conv))
-        if hit is not None and hit.dtype == _compute_dtype(x):
-            return F.conv2d(x.to(hit.dtype), hit, None, conv.stride, conv.padding)
-    cd = _compute_dtype(x)
+        if hit is not None and hit.dtype == cd:
+            xc = x.to(hit.dtype)
+            if hip_1x1 and xc.is_contiguous(memory_format=torch.channels_last):
+                return _gemm_1x1_fwd(xc, hit)
+            return F.conv2d(xc, hit, None, conv.stride, conv.padding)
+    if hip_1x1 and not (torch.is_grad_enabled() and (w.requires_grad or x.requires_grad)):
+        xc = x.to(cd)
+        if xc.is_contiguous(memory_format=torch.channels_last):
+            return _gemm_1x1_fwd(xc, _shadow(conv, cd))                           # inference: the shadow also saves the per-call weight cast
     if (USE_HIP_CONV_WGRAD and x.is_cuda and cd == torch.bfloat16 and torch.is_grad_enabled() and (w.requires_grad or x.requires_grad) and conv.groups == 1
             and conv.dilation == (1, 1) and conv.bias is None and isinstance(conv.padding, tuple)):
         return _ConvFn.apply(x.to(cd), w, _shadow(conv, cd), conv.stride, conv.padding)
