@@ -135,6 +135,11 @@ typedef struct ModeGemmDesc {
   int32_t w_tap_cols;             /* > 0: the N output columns are N / w_tap_cols taps of w_tap_cols columns each; tap t reads columns              */
   int64_t w_rows_tap_stride;      /* [0, w_tap_cols) of W through the index table w_rows + t * w_rows_tap_stride (elements).  w_tap_cols % 64 == 0,  */
                                   /* N % w_tap_cols == 0.  0 = one table for all columns.  (perceptual_encoders.py: dW[Cout][tap][Cin] of a 3 x 3 conv) */
+  /* (ABI 10) a_rows in TAPS - implicit-GEMM convolution, forward and data gradient (bf16 in / out, epilogue NONE; csrc/conv_gemm.hip):             */
+  int32_t a_tap_cols;             /* > 0: K = taps * a_tap_cols; the reduction index k = t * a_tap_cols + c reads A[a_rows[t * a_rows_tap_stride + m]][c] */
+  int64_t a_rows_tap_stride;      /* (a negative index = a zero row: the tap falls outside the image).  W: forward layout [N][K] K-contiguous (a          */
+                                  /* channels_last conv weight [Cout][taps][Cin]); with MODE_GEMM_W_KN element (k, n) = W[c * ldw + t * N + n] - the SAME     */
+                                  /* weight memory read for the data gradient (ldw = taps * Cin, N = Cin).  a_tap_cols % 64 == 0.                            */
 } ModeGemmDesc;
 #define MODE_GEMM_SKINNY_OK 1
 /* Backward-pass operand layouts (bf16, epilogue NONE; replace autograd's mm_backward for nn.Linear, i.e. the `grad @ W` and

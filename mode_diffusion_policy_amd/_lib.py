@@ -31,7 +31,7 @@ class ModeGemmDesc(C.Structure):
                 ("a_rows", c_vp), ("expert_offsets", c_vp), ("num_experts", c_i32), ("split_k", c_i32), ("split_stride", c_i64), ("k_group_offsets", c_vp), ("num_k_groups", c_i32),
                 ("c_group_stride", c_i64), ("flags", c_i32), ("w_rows", c_vp),
                 ("C2", c_vp), ("ldc2", c_i64), ("gain", c_vp), ("row_ss_out", c_vp), ("row_ss", c_vp), ("row_ss_n", c_i32), ("row_eps", c_f32),
-                ("w_tap_cols", c_i32), ("w_rows_tap_stride", c_i64)]
+                ("w_tap_cols", c_i32), ("w_rows_tap_stride", c_i64), ("a_tap_cols", c_i32), ("a_rows_tap_stride", c_i64)]
 
 
 class ModeEmbedDesc(C.Structure):

@@ -9,6 +9,7 @@ namespace mode {
 int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s);
 int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s);
 int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s);
+int gemm_bf16_conv_launch(const ModeGemmDesc* d, hipStream_t s);   // conv_gemm.hip: a_rows in taps (implicit-GEMM convolution forward / data gradient)
 struct MetaBatch {
   const int* idx; const float* w; long idx_bstride;
   int* counts; int* offsets; int* perm; int* pos; float* posw; int* poffsets; int* prow; long out_bstride;
@@ -131,6 +132,7 @@ extern "C" int mode_set_option(const char* key, int value) {
 extern "C" int mode_gemm(const ModeGemmDesc* d, void* stream) {
   if (!d || !d->A || !d->W || !d->C || d->M < 0 || d->N <= 0) return MODE_ERR_BAD_ARG;
   if (d->expert_offsets && d->num_experts <= 0) return MODE_ERR_BAD_ARG;
+  if (d->a_tap_cols > 0) return d->dtype == MODE_BF16 ? gemm_bf16_conv_launch(d, (hipStream_t)stream) : MODE_ERR_UNSUPPORTED;
   if (d->dtype == MODE_BF16 && (d->flags & (MODE_GEMM_W_KN | MODE_GEMM_A_KM))) return gemm_bf16_tr_launch(d, (hipStream_t)stream);
   if (d->dtype == MODE_BF16) return gemm_bf16_launch(d, (hipStream_t)stream);
   if (d->dtype == MODE_F32) return gemm_f32_launch(d, (hipStream_t)stream);

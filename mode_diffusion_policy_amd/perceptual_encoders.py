@@ -283,6 +283,67 @@ def _wgrad_1x1(dy: torch.Tensor, x: torch.Tensor, wshape) -> torch.Tensor:
 _TAPS: dict = {}
 
 
+def _tap_table(n, H, W_, ho, wo, kh_, kw_, sh, sw, ph, pw, dev, transposed: bool = False) -> torch.Tensor:
+    """int32 [kh*kw, rows]: forward table (rows = output pixels): the INPUT row that tap (a, b) pairs with output pixel (n, h, w); transposed (rows = input
+    pixels): the OUTPUT row whose tap (a, b) read input pixel (n, h, w).  -1 where there is none (outside the image / between the strides).  Cached."""
+    key = (n, H, W_, kh_, kw_, sh, sw, ph, pw, dev, transposed)
+    idx = _TAPS.get(key)
+    if idx is None:
+        nn_ = torch.arange(n, device=dev).view(n, 1, 1)
+        tabs = []
+        neg = torch.full((), -1, device=dev)
+        if not transposed:
+            hh = torch.arange(ho, device=dev).view(1, ho, 1); ww = torch.arange(wo, device=dev).view(1, 1, wo)
+            for a in range(kh_):
+                for b in range(kw_):
+                    hi, wi = hh * sh + a - ph, ww * sw + b - pw
+                    ok = (hi >= 0) & (hi < H) & (wi >= 0) & (wi < W_)
+                    tabs.append(torch.where(ok, (nn_ * H + hi) * W_ + wi, neg).reshape(-1))
+        else:
+            hh = torch.arange(H, device=dev).view(1, H, 1); ww = torch.arange(W_, device=dev).view(1, 1, W_)
+            for a in range(kh_):
+                for b in range(kw_):
+                    hn, wn_ = hh + ph - a, ww + pw - b
+                    h2, w2 = torch.div(hn, sh, rounding_mode="floor"), torch.div(wn_, sw, rounding_mode="floor")
+                    ok = (hn >= 0) & (wn_ >= 0) & (hn % sh == 0) & (wn_ % sw == 0) & (h2 < ho) & (w2 < wo)
+                    tabs.append(torch.where(ok, (nn_ * ho + h2) * wo + w2, neg).reshape(-1))
+        idx = _TAPS[key] = torch.stack(tabs).to(torch.int32).contiguous()
+    return idx
+
+
+def _conv_taps_ok(wshape, k_per_tap: int, w_lp: Optional[torch.Tensor] = None) -> bool:
+    """Implicit-GEMM path: 64-channel K-steps inside one tap, and the weight must lie as [Cout][kh][kw][Cin] (channels_last storage)."""
+    return k_per_tap % 64 == 0 and wshape[0] % 8 == 0 and wshape[1] % 8 == 0 and (w_lp is None or w_lp.is_contiguous(memory_format=torch.channels_last))
+
+
+def _conv_fwd_taps(x: torch.Tensor, w_lp: torch.Tensor, stride, padding) -> torch.Tensor:
+    """k x k convolution forward as one implicit-GEMM launch (mode_gemm with a_rows in taps, csrc/conv_gemm.hip): Y[R_out, Cout] = sum_t X[idx[t], :] W[:, t, :]^T."""
+    n, cin, H, W_ = x.shape
+    cout, _, kh_, kw_ = w_lp.shape
+    ho = (H + 2 * padding[0] - kh_) // stride[0] + 1; wo = (W_ + 2 * padding[1] - kw_) // stride[1] + 1
+    idx = _tap_table(n, H, W_, ho, wo, kh_, kw_, stride[0], stride[1], padding[0], padding[1], x.device)
+    y = torch.empty((n, cout, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    R = n * ho * wo
+    d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=R, N=cout, K=kh_ * kw_ * cin, A=x.data_ptr(), lda=cin, W=w_lp.data_ptr(),
+                       ldw=kh_ * kw_ * cin, C=y.data_ptr(), ldc=cout, a_rows=idx.data_ptr(), a_tap_cols=cin, a_rows_tap_stride=R)
+    L.check(L.load().mode_gemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv forward (taps)")
+    return y
+
+
+def _conv_dgrad_taps(dy: torch.Tensor, w_lp: torch.Tensor, xshape, stride, padding) -> torch.Tensor:
+    """dX[R_in, Cin] = sum_t dY[idx_T[t], :] W[:, t, :] - the same weight memory read as [k = (t, cout)][cin] (MODE_GEMM_W_KN with a_rows in taps)."""
+    n, cin, H, W_ = xshape
+    cout, _, kh_, kw_ = w_lp.shape
+    ho, wo = dy.shape[2], dy.shape[3]
+    idx = _tap_table(n, H, W_, ho, wo, kh_, kw_, stride[0], stride[1], padding[0], padding[1], dy.device, transposed=True)
+    dx = torch.empty((n, cin, H, W_), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    R = n * H * W_
+    d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=R, N=cin, K=kh_ * kw_ * cout, A=dy.data_ptr(), lda=cout, W=w_lp.data_ptr(),
+                       ldw=kh_ * kw_ * cin, C=dx.data_ptr(), ldc=cin, a_rows=idx.data_ptr(), a_tap_cols=cout, a_rows_tap_stride=R, flags=L.GEMM_W_KN)
+    L.check(L.load().mode_gemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv data gradient (taps)")
+    return dx
+
+
 def _wgrad_taps(dy: torch.Tensor, x: torch.Tensor, wshape, stride, padding) -> torch.Tensor:
     """dW of a k x k convolution (any stride, zero padding) from channels_last bf16 activations as k*k weight-gradient GEMMs, one per filter tap:
     dW[:, :, kh, kw] = dY[R_out, Cout]^T X[rows(kh, kw), Cin] - the input rows that tap (kh, kw) pairs with the output pixels (a zero row where the tap falls
@@ -294,18 +355,7 @@ def _wgrad_taps(dy: torch.Tensor, x: torch.Tensor, wshape, stride, padding) -> t
     ph, pw = padding
     sh, sw = stride
     R = n * ho * wo
-    key = (n, H, W_, kh_, kw_, sh, sw, ph, pw, x.device)
-    idx = _TAPS.get(key)
-    if idx is None:                                             # row of x that tap (a, b) pairs with output pixel (n, h, w); -1 (= a zero row) outside the image
-        dev = x.device
-        nn_ = torch.arange(n, device=dev).view(n, 1, 1); hh = torch.arange(ho, device=dev).view(1, ho, 1); ww = torch.arange(wo, device=dev).view(1, 1, wo)
-        tabs = []
-        for a in range(kh_):
-            for b in range(kw_):
-                hi, wi = hh * sh + a - ph, ww * sw + b - pw
-                ok = (hi >= 0) & (hi < H) & (wi >= 0) & (wi < W_)
-                tabs.append(torch.where(ok, (nn_ * H + hi) * W_ + wi, torch.full((), -1, device=dev)).reshape(-1))
-        idx = _TAPS[key] = torch.stack(tabs).to(torch.int32).contiguous()
+    idx = _tap_table(n, H, W_, ho, wo, kh_, kw_, sh, sw, ph, pw, x.device)
     xp = x
     taps = kh_ * kw_
     one_launch = cin % 64 == 0                                   # all taps as ONE product (N = taps * Cin, ABI 10 `w_tap_cols`): the dY tiles are shared through L2
@@ -339,8 +389,11 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, w_lp, stride, padding):
         ctx.save_for_backward(x, w_lp)
         ctx.conf = (tuple(stride), tuple(padding), tuple(w.shape), w.dtype)
-        if x.dtype == torch.bfloat16 and _is_1x1(w.shape, stride, padding) and x.is_contiguous(memory_format=torch.channels_last):
-            return _gemm_1x1_fwd(x, w_lp)
+        if x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
+            if _is_1x1(w.shape, stride, padding):
+                return _gemm_1x1_fwd(x, w_lp)
+            if _conv_taps_ok(w.shape, w.shape[1], w_lp):
+                return _conv_fwd_taps(x, w_lp, stride, padding)
         return F.conv2d(x, w_lp, None, stride, padding)
 
     @staticmethod
@@ -358,9 +411,13 @@ class _ConvFn(torch.autograd.Function):
                 dw = _wgrad_taps(dyc, x, wshape, stride, padding)
             need_w = False
         dx = None
-        if need_x and dy.dtype == torch.bfloat16 and _is_1x1(wshape, stride, padding, 8) and x.is_contiguous(memory_format=torch.channels_last):
-            dx = _gemm_1x1_dgrad(dy.contiguous(memory_format=torch.channels_last), w_lp, x.shape)
-            need_x = False
+        if need_x and dy.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
+            if _is_1x1(wshape, stride, padding, 8):
+                dx = _gemm_1x1_dgrad(dy.contiguous(memory_format=torch.channels_last), w_lp, x.shape)
+                need_x = False
+            elif _conv_taps_ok(wshape, wshape[0], w_lp):
+                dx = _conv_dgrad_taps(dy.contiguous(memory_format=torch.channels_last), w_lp, x.shape, stride, padding)
+                need_x = False
         if need_x or need_w:
             dxl, dwl, _ = torch.ops.aten.convolution_backward(dy, x, w_lp, None, stride, padding, (1, 1), False, (0, 0), 1, (need_x, need_w, False))
             if need_x:
@@ -411,19 +468,23 @@ def _conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
         with torch.no_grad():
             w.data = w.data.contiguous(memory_format=torch.channels_last)
     cd = _compute_dtype(x)
-    hip_1x1 = (USE_HIP_CONV_WGRAD and x.is_cuda and cd == torch.bfloat16 and conv.groups == 1 and conv.dilation == (1, 1) and conv.bias is None
-               and isinstance(conv.padding, tuple) and _is_1x1(w.shape, conv.stride, conv.padding))
+    hip_ok = (USE_HIP_CONV_WGRAD and x.is_cuda and cd == torch.bfloat16 and conv.groups == 1 and conv.dilation == (1, 1) and conv.bias is None
+              and isinstance(conv.padding, tuple))
+    hip_1x1 = hip_ok and _is_1x1(w.shape, conv.stride, conv.padding)
+    hip_taps = hip_ok and not hip_1x1 and _conv_taps_ok(w.shape, w.shape[1])
     if _W_OVERRIDE is not None:
         hit = _W_OVERRIDE.get(id(conv))
         if hit is not None and hit.dtype == cd:
             xc = x.to(hit.dtype)
             if hip_1x1 and xc.is_contiguous(memory_format=torch.channels_last):
                 return _gemm_1x1_fwd(xc, hit)
+            if hip_taps and xc.is_contiguous(memory_format=torch.channels_last) and hit.is_contiguous(memory_format=torch.channels_last):
+                return _conv_fwd_taps(xc, hit, conv.stride, conv.padding)
             return F.conv2d(xc, hit, None, conv.stride, conv.padding)
-    if hip_1x1 and not (torch.is_grad_enabled() and (w.requires_grad or x.requires_grad)):
+    if (hip_1x1 or hip_taps) and not (torch.is_grad_enabled() and (w.requires_grad or x.requires_grad)):
         xc = x.to(cd)
-        if xc.is_contiguous(memory_format=torch.channels_last):
-            return _gemm_1x1_fwd(xc, _shadow(conv, cd))                           # inference: the shadow also saves the per-call weight cast
+        if xc.is_contiguous(memory_format=torch.channels_last):                    # inference: the shadow also saves the per-call weight cast
+            return _gemm_1x1_fwd(xc, _shadow(conv, cd)) if hip_1x1 else _conv_fwd_taps(xc, _shadow(conv, cd), conv.stride, conv.padding)
     if (USE_HIP_CONV_WGRAD and x.is_cuda and cd == torch.bfloat16 and torch.is_grad_enabled() and (w.requires_grad or x.requires_grad) and conv.groups == 1
             and conv.dilation == (1, 1) and conv.bias is None and isinstance(conv.padding, tuple)):
         return _ConvFn.apply(x.to(cd), w, _shadow(conv, cd), conv.stride, conv.padding)
