@@ -314,3 +314,25 @@ def test_wgrad_w_rows_in_taps(R, Rw, M, cin, taps, groups):
     bad = _desc(out_dtype=L.MODE_F32, M=M, N=taps * cin, K=R, A=p(A), lda=M, W=p(X), ldw=cin, C=p(Cc), ldc=taps * cin, w_rows=p(idx), w_tap_cols=40,
                 w_rows_tap_stride=R, flags=L.GEMM_W_KN | L.GEMM_A_KM)
     assert L.load().mode_gemm(C.byref(bad), stream()) != 0                      # taps must be multiples of 64 columns
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W_,k,stride,pad", [(3, 64, 64, 12, 9, 3, 1, 1), (2, 128, 256, 15, 15, 3, 2, 1), (4, 256, 128, 8, 8, 1, 2, 0), (1, 64, 192, 5, 7, 3, 1, 1),
+                                                           (2, 512, 512, 7, 7, 3, 1, 1), (65, 64, 64, 16, 16, 3, 1, 1)])
+def test_conv_forward_and_data_gradient_as_gemm_with_a_rows_in_taps(n, cin, cout, H, W_, k, stride, pad):
+    """ABI 10 `a_tap_cols`: a k x k convolution on channels_last bf16 data as ONE mode_gemm call - forward (K-contiguous channels_last weight) and data gradient
+    (MODE_GEMM_W_KN on the same weight memory) - against torch's conv2d / its autograd in fp32 on the same bf16 values.  Index tables: -1 = outside the image
+    (forward) / no output pixel read this input through this tap (data gradient, strides)."""
+    from mode_diffusion_policy_amd import perceptual_encoders as E
+    torch.manual_seed(n * 7 + cin + cout + k)
+    x = torch.randn(n, cin, H, W_, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, k, k, device="cuda") * (k * k * cin) ** -0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = E._conv_fwd_taps(x, w, (stride, stride), (pad, pad))
+    xr = x.float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, w.float(), None, stride, pad)
+    assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert rel(y.float(), yr) < 4e-3
+    dy = torch.randn_like(y)
+    dx = E._conv_dgrad_taps(dy, w, x.shape, (stride, stride), (pad, pad))
+    yr.backward(dy.float())
+    assert dx.shape == x.shape and rel(dx.float(), xr.grad) < 4e-3
+    torch.cuda.synchronize()
