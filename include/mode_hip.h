@@ -68,6 +68,7 @@ const char* mode_hip_status_string(int status);
  * "gemm_tr_cfg": backward (transpose-read) GEMM geometry, 0 = auto, 1 = 128-wide ring-2, 2 = 64-wide ring-3, 3 = 128-wide ring-3,
  *   4 = 64-wide ring-2, 5 = 128-wide single-buffered, 6 = the persistent ping-pong kernel of gemm_bf16_pptr.hip (256 x 256 tiles, one workgroup per CU) for
  *   every shape it takes, 7 = auto without it.  Auto takes it for the large expert GEMMs of the training backward unless "bwd_coexec" is 1.
+ * "conv_ns": LDS ring depth of the implicit-GEMM convolution kernel (csrc/conv_gemm.hip): 0 = auto (3 below two workgroups per CU), 2, 3.
  * "bwd_coexec": 1 = the caller runs other kernels beside the backward chain (FusedAdamW.step(overlap=True), ArenaGradReducer's collectives set it):
  *   the backward's large GEMMs keep the ring kernels, whose small workgroups leave CU resources to the co-running work; 0 (default) = the backward has
  *   the GPU to itself.  Same results either way (bit-identical kernels).  "adamw_blocks": workgroup cap of one AdamW launch (0 = 256, one streaming workgroup per CU).
@@ -170,6 +171,28 @@ typedef struct ModeGemmDesc {
  *                             compute the row index instead of loading it (one dependent memory round trip less at the start of a workgroup). */
 #define MODE_GEMM_IDENTITY_ROWS 32
 int mode_gemm(const ModeGemmDesc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * mode_conv_bn_act_fwd (ABI 10) - INFERENCE: convolution + eval-mode BatchNorm + FiLM + residual + ReLU as ONE launch (csrc/conv_gemm.hip).
+ * Replaces, in the perceptual encoders' eval path, F.conv2d followed by the fused BatchNorm pass - i.e. conv -> bn -> (FiLM) -> (+ identity) -> relu of
+ * a ResNet block (mode/models/perceptual_encoders/pretrained_resnets.py:52-64, resnets.py:58-76): the normalised activation is computed from the fp32
+ * accumulators and written once.  channels_last bf16: x [rows, Cin], w [Cout][taps][Cin] (a channels_last conv weight), y [M, Cout].
+ *   idx            int32 [taps][M] (tap stride idx_tap_stride): input row that tap t pairs with output row m, -1 = outside the image; NULL = 1 x 1 / stride 1
+ *   y = post(relu(pre(acc * scale + shift) + residual)),  scale = bn_weight / sqrt(bn_var + bn_eps), shift = bn_bias - bn_mean * scale (bn_mean NULL: 1, 0),
+ *   pre: gamma * v + beta, post: (1 + gamma) * v + beta with gamma / beta fp32 [samples][Cout], sample = m / rows_per_sample.  Cin % 64 == 0, Cout % 8 == 0.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ModeConvBnDesc {
+  const void* x; int64_t ldx;
+  const int32_t* idx; int64_t idx_tap_stride; int32_t taps;
+  const void* w; int64_t ldw;
+  void* y; int64_t ldy;
+  int32_t M, Cin, Cout;
+  const float* bn_mean; const float* bn_var; const float* bn_weight; const float* bn_bias; float bn_eps;
+  const void* residual; int64_t ldr;
+  int32_t relu;
+  const float* pre_gamma; const float* pre_beta; const float* post_gamma; const float* post_beta; int32_t rows_per_sample;
+} ModeConvBnDesc;
+int mode_conv_bn_act_fwd(const ModeConvBnDesc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * mode_rmsnorm_cond_fwd — y = x / max(||x||_2 * D^-1/2, eps) * g  (+ cond[row / rows_per_cond])

@@ -123,6 +123,13 @@ class ModeQkvAttnDesc(C.Structure):
                 ("bqkv", c_vp), ("q_gain", c_vp), ("k_gain", c_vp), ("eps", c_f32), ("y", c_vp), ("ldy", c_i64)]
 
 
+class ModeConvBnDesc(C.Structure):
+    _fields_ = [("x", c_vp), ("ldx", c_i64), ("idx", c_vp), ("idx_tap_stride", c_i64), ("taps", c_i32), ("w", c_vp), ("ldw", c_i64), ("y", c_vp), ("ldy", c_i64),
+                ("M", c_i32), ("Cin", c_i32), ("Cout", c_i32), ("bn_mean", c_vp), ("bn_var", c_vp), ("bn_weight", c_vp), ("bn_bias", c_vp), ("bn_eps", c_f32),
+                ("residual", c_vp), ("ldr", c_i64), ("relu", c_i32), ("pre_gamma", c_vp), ("pre_beta", c_vp), ("post_gamma", c_vp), ("post_beta", c_vp),
+                ("rows_per_sample", c_i32)]
+
+
 class ModeBnFilmDesc(C.Structure):
     _fields_ = [("N", c_i32), ("C", c_i32), ("HW", c_i32), ("dtype", c_i32), ("x", c_vp), ("scale", c_vp), ("shift", c_vp), ("pre_gamma", c_vp),
                 ("pre_beta", c_vp), ("residual", c_vp), ("relu", c_i32), ("post_gamma", c_vp), ("post_beta", c_vp), ("y", c_vp),
@@ -141,6 +148,7 @@ PROTOTYPES = {
     "mode_rmsnorm_cond_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_f32, c_vp, c_vp, C.c_int, c_vp]),
     "mode_attn_block_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32, C.c_uint32, c_f32, c_vp]),
     "mode_qkv_attn_fwd": (C.c_int, [C.POINTER(ModeQkvAttnDesc), c_vp]),
+    "mode_conv_bn_act_fwd": (C.c_int, [C.POINTER(ModeConvBnDesc), c_vp]),
     "mode_attn_block_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32, C.c_uint32,
                                       c_f32, c_vp]),
     "mode_sigma_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, c_vp]),

@@ -27,6 +27,10 @@ struct ConvGemmParams {
   const uint16_t* W; long ldw;
   uint16_t* C; long ldc;
   int M, N, taps, tap_k, m_tiles, n_tiles;
+  // fused inference epilogue (FUSE): y = post_film(relu(pre_film(batch_norm_eval(acc)) + residual)), the expression of csrc/encoder_ops.hip's fused pass
+  const float* bn_mean; const float* bn_var; const float* bn_w; const float* bn_b; float bn_eps;
+  const uint16_t* res; long ldr; int relu;
+  const float* pre_g; const float* pre_b; const float* post_g; const float* post_b; int rows_per_sample;
 };
 
 namespace cg {
@@ -52,11 +56,15 @@ __device__ __forceinline__ int kn_swz(int row) {
 }
 }  // namespace cg
 
-template <bool W_KN, int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p) {
+// NS = 2: one vmcnt(0) per K-step, two workgroups per CU hide each other's round trips (the training shapes: thousands of tiles).  NS = 3: two K-steps in flight
+// under a COUNTED wait - for grids that do not even fill the part once (the rollout's batch sizes), where a K-step would otherwise cost a full memory round trip
+// (stage-4 3 x 3 at B = 32: 72 K-steps x ~2 us).  Index loads are issued BEFORE the DMA of the same iteration so that the counted wait (which leaves the newest
+// K-step's DMA instructions in flight; loads retire in order) covers them.
+template <bool W_KN, int BN, bool FUSE = false, int NS = 2>
+__global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_gemm_kernel(const ConvGemmParams p) {
   using namespace cg;
   constexpr int BM = 128, BKT = 64, TM = 64, TN = BN / 2, FM = 4, FN = TN / 16;
-  constexpr int A_BYTES = BM * BKT * 2, W_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + W_BYTES, NS = 2;
+  constexpr int A_BYTES = BM * BKT * 2, W_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + W_BYTES;
   constexpr int W_ROW = BN * 2;                                       // W_KN image: bytes per k-row
   constexpr int RPP = 1024 / W_ROW, NPW = (BKT / RPP) / 4, CHW = BN / 8; // W_KN: k-rows per 1-KiB DMA piece, pieces per wave, 16-B chunks per row
   constexpr int PB = BN / 32;                                         // forward: 8-row pieces of the [BN rows][64 k] weight tile per wave
@@ -94,16 +102,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
       b_src[q] = p.W + (long)n * p.ldw + lchunk * 8;
     }
   }
-  int aidx[4] = {0, 0, 0, 0};                                          // gathered source rows of the NEXT tile to stage
-  auto load_idx = [&](int kt) {
+  auto load_idx = [&](int kt, int (&ix)[4]) {
     if (kt < nk) {
-      const int tap = kt * BKT / p.tap_k;
-      const int* t = p.idx + (long)tap * p.idx_tstride;
+      if (p.idx) {
+        const int tap = kt * BKT / p.tap_k;
+        const int* t = p.idx + (long)tap * p.idx_tstride;
+        // hand-issued (the compiler must not know these loads are outstanding: it would put `s_waitcnt vmcnt(0)` - i.e. the DMA of the K-steps in flight -
+        // in front of their first use; the loop's own waits below cover them and pin the uses behind the wait)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) aidx[q] = t[arow_m[q]];
+        for (int q = 0; q < 4; ++q) {
+          const int* a = t + arow_m[q];
+          asm volatile("global_load_dword %0, %1, off" : "=v"(ix[q]) : "v"(a) : "memory");
+        }
+      } else {                                                       // no table: one tap, output row m reads input row m (1 x 1 / stride 1)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ix[q] = arow_m[q];
+      }
     }
   };
-  auto stage = [&](int slot, int kt) {
+  auto stage = [&](int slot, int kt, const int (&aidx)[4]) {
     char* base = smem + slot * STAGE_BYTES;
     const int k0 = kt * BKT;
     const int tap = k0 / p.tap_k, ck = k0 - tap * p.tap_k;            // tap of this K-step, first channel inside it
@@ -157,17 +174,40 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     b_off = A_BYTES + (wn * TN + fr) * 128;
   }
 
-  load_idx(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  stage(0, 0);
-  load_idx(1);
+  constexpr int LOADS = 4 + (W_KN ? NPW : PB);                        // DMA instructions per wave and K-step
   int slot = 0;
+  int ia[4] = {0, 0, 0, 0}, ib[4] = {0, 0, 0, 0};
+#define CG_WAIT_IDX(N, ix) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ix[0]), "+v"(ix[1]), "+v"(ix[2]), "+v"(ix[3]) : "n"(N) : "memory")
+  load_idx(0, ia);
+  CG_WAIT_IDX(0, ia);
+  stage(0, 0, ia);
+  load_idx(1, ia);
+  if constexpr (NS == 3) {
+    CG_WAIT_IDX(0, ia);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ib[q] = ia[q];
+    load_idx(2, ia);                                                   // requested BEFORE the DMA of K-step 1: the loop's counted wait covers it
+    __builtin_amdgcn_sched_barrier(0);
+    if (nk > 1) stage(1, 1, ib);
+  }
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // tile kt landed (this wave's pieces), the indices of tile kt+1 arrived
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) {
-      stage(slot ^ 1, kt + 1);
-      load_idx(kt + 2);
+    if constexpr (NS == 2) {
+      CG_WAIT_IDX(0, ia);                                              // tile kt landed (this wave's pieces), the indices of tile kt+1 arrived
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) {
+        stage(slot ^ 1, kt + 1, ia);
+        load_idx(kt + 2, ia);
+      }
+    } else {
+      // in flight, oldest first: DMA kt | indices kt+2 | DMA kt+1.  Needed now: tile kt and the indices of kt+2 -> the newest K-step's DMA stays in flight
+      if (kt + 1 < nk) CG_WAIT_IDX(LOADS, ia);
+      else CG_WAIT_IDX(0, ia);
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ib[q] = ia[q];                         // indices of K-step kt+2 (arrived)
+      load_idx(kt + 3, ia);                                            // requested BEFORE this iteration's DMA
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < nk) stage(slot == 0 ? 2 : slot - 1, kt + 2, ib);
     }
     const uint32_t so = slot * STAGE_BYTES;
     bf16x8 fa[2][FM];
@@ -213,7 +253,50 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     __builtin_amdgcn_sched_barrier(0);
     mma_half(std::integral_constant<int, 1>{});
     __builtin_amdgcn_sched_barrier(0);
-    slot ^= 1;
+    if constexpr (NS == 2) slot ^= 1; else slot = (slot + 1 == 3) ? 0 : slot + 1;
+  }
+
+#undef CG_WAIT_IDX
+  // ---- fused inference epilogue, in registers: a lane owns columns n .. n+3 of row m per (i, j)
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int nc = min(n0 + wn * TN + j * 16 + fq * 4, p.N - 4);                 // (columns past N are never stored)
+      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bn_mean) {                                                              // eval-mode BatchNorm folded: the expressions of chan_params / bn_prepare_kernel
+        const float4 mu = *reinterpret_cast<const float4*>(p.bn_mean + nc), va = *reinterpret_cast<const float4*>(p.bn_var + nc);
+        const float mu_[4] = {mu.x, mu.y, mu.z, mu.w}, va_[4] = {va.x, va.y, va.z, va.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[r] = 1.0f / sqrtf(va_[r] + p.bn_eps);
+        if (p.bn_w) { const float4 w4 = *reinterpret_cast<const float4*>(p.bn_w + nc); sc[0] *= w4.x; sc[1] *= w4.y; sc[2] *= w4.z; sc[3] *= w4.w; }
+        if (p.bn_b) { const float4 b4 = *reinterpret_cast<const float4*>(p.bn_b + nc); sh[0] = b4.x; sh[1] = b4.y; sh[2] = b4.z; sh[3] = b4.w; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sh[r] -= mu_[r] * sc[r];
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int mc = min(row0 + wm * TM + i * 16 + fr, row_end - 1);
+        const long fb = (long)(mc / p.rows_per_sample) * p.N + nc;                    // FiLM parameters are per (sample, channel)
+        float t[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = __builtin_fmaf(acc[i][j][r], sc[r], sh[r]);
+        if (p.pre_g) {
+          const float4 g4 = *reinterpret_cast<const float4*>(p.pre_g + fb), b4 = *reinterpret_cast<const float4*>(p.pre_b + fb);
+          t[0] = __builtin_fmaf(g4.x, t[0], b4.x); t[1] = __builtin_fmaf(g4.y, t[1], b4.y); t[2] = __builtin_fmaf(g4.z, t[2], b4.z); t[3] = __builtin_fmaf(g4.w, t[3], b4.w);
+        }
+        if (p.res) {
+          const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (long)mc * p.ldr + nc);
+          t[0] += bf16_bits_to_f32(rr.x & 0xffff); t[1] += bf16_bits_to_f32(rr.x >> 16); t[2] += bf16_bits_to_f32(rr.y & 0xffff); t[3] += bf16_bits_to_f32(rr.y >> 16);
+        }
+        if (p.relu) { t[0] = fmaxf(t[0], 0.f); t[1] = fmaxf(t[1], 0.f); t[2] = fmaxf(t[2], 0.f); t[3] = fmaxf(t[3], 0.f); }
+        if (p.post_g) {
+          const float4 g4 = *reinterpret_cast<const float4*>(p.post_g + fb), b4 = *reinterpret_cast<const float4*>(p.post_b + fb);
+          t[0] = __builtin_fmaf(1.f + g4.x, t[0], b4.x); t[1] = __builtin_fmaf(1.f + g4.y, t[1], b4.y); t[2] = __builtin_fmaf(1.f + g4.z, t[2], b4.z);
+          t[3] = __builtin_fmaf(1.f + g4.w, t[3], b4.w);
+        }
+        acc[i][j] = f32x4{t[0], t[1], t[2], t[3]};
+      }
+    }
   }
 
   // ---- epilogue: accumulators -> swizzled LDS tile -> coalesced 16-byte stores
@@ -244,12 +327,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
   }
 }
 
-template <bool W_KN, int BN>
-static int conv_launch(ConvGemmParams p, hipStream_t s) {
-  p.m_tiles = (p.M + 127) / 128;
-  p.n_tiles = (p.N + BN - 1) / BN;
-  constexpr size_t lds = 2 * (128 * 64 * 2 + (size_t)BN * 64 * 2);
-  auto kern = conv_gemm_kernel<W_KN, BN>;
+int pp_num_cus();   // gemm_bf16_pp.hip
+
+template <bool W_KN, int BN, bool FUSE, int NS>
+static int conv_launch_ns(ConvGemmParams p, hipStream_t s) {
+  constexpr size_t lds = NS * (128 * 64 * 2 + (size_t)BN * 64 * 2);
+  auto kern = conv_gemm_kernel<W_KN, BN, FUSE, NS>;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -259,6 +342,16 @@ static int conv_launch(ConvGemmParams p, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles), dim3(256), lds, s, p);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
+}
+
+int g_conv_ns = 0;   // "conv_ns" option: 0 = auto (three-slot ring when the grid has fewer than two workgroups per CU), 2 / 3 = forced
+
+template <bool W_KN, int BN, bool FUSE = false>
+static int conv_launch(ConvGemmParams p, hipStream_t s) {
+  p.m_tiles = (p.M + 127) / 128;
+  p.n_tiles = (p.N + BN - 1) / BN;
+  const bool deep = g_conv_ns ? g_conv_ns == 3 : (long)p.m_tiles * p.n_tiles < 2L * pp_num_cus();
+  return deep ? conv_launch_ns<W_KN, BN, FUSE, 3>(p, s) : conv_launch_ns<W_KN, BN, FUSE, 2>(p, s);
 }
 
 // mode_gemm with a_rows in taps (ModeGemmDesc.a_tap_cols > 0): validated here
@@ -273,6 +366,8 @@ int gemm_bf16_conv_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.A = (const uint16_t*)d->A; p.lda = d->lda; p.idx = d->a_rows; p.idx_tstride = d->a_rows_tap_stride;
   p.W = (const uint16_t*)d->W; p.ldw = d->ldw; p.C = (uint16_t*)d->C; p.ldc = d->ldc;
   p.M = d->M; p.N = d->N; p.tap_k = d->a_tap_cols; p.taps = d->K / d->a_tap_cols; p.m_tiles = p.n_tiles = 0;
+  p.bn_mean = p.bn_var = p.bn_w = p.bn_b = nullptr; p.bn_eps = 0.f; p.res = nullptr; p.ldr = 0; p.relu = 0;
+  p.pre_g = p.pre_b = p.post_g = p.post_b = nullptr; p.rows_per_sample = 1;
   const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
   const bool wide = d->N % 128 == 0 && t128 >= 384;              // enough 128-wide tiles for ~1.5 workgroups per CU; otherwise twice the workgroups
   if (w_kn) return wide ? conv_launch<true, 128>(p, s) : conv_launch<true, 64>(p, s);
@@ -280,3 +375,28 @@ int gemm_bf16_conv_launch(const ModeGemmDesc* d, hipStream_t s) {
 }
 
 }  // namespace mode
+
+// mode_conv_bn_act_fwd - inference: convolution (GEMM over the filter taps) + eval-mode BatchNorm + FiLM + residual + ReLU as ONE launch
+extern "C" int mode_conv_bn_act_fwd(const ModeConvBnDesc* d, void* stream) {
+  using namespace mode;
+  if (!d || !d->x || !d->w || !d->y || d->M < 0 || d->Cin <= 0 || d->Cout <= 0 || d->taps <= 0) return MODE_ERR_BAD_ARG;
+  if (d->Cin % 64 || d->Cout % 8 || d->ldx % 8 || d->ldw % 8 || d->ldy % 8 || (((uintptr_t)d->x | (uintptr_t)d->w | (uintptr_t)d->y) & 15)) return MODE_ERR_UNSUPPORTED;
+  if (!d->idx && d->taps != 1) return MODE_ERR_BAD_ARG;
+  if ((d->bn_mean != nullptr) != (d->bn_var != nullptr) || (d->pre_gamma != nullptr) != (d->pre_beta != nullptr) || (d->post_gamma != nullptr) != (d->post_beta != nullptr))
+    return MODE_ERR_BAD_ARG;
+  if (d->residual && (d->ldr % 4 || ((uintptr_t)d->residual & 7))) return MODE_ERR_UNSUPPORTED;
+  if ((d->pre_gamma || d->post_gamma) && d->rows_per_sample <= 0) return MODE_ERR_BAD_ARG;
+  if (((uintptr_t)d->bn_mean | (uintptr_t)d->bn_var | (uintptr_t)d->bn_weight | (uintptr_t)d->bn_bias | (uintptr_t)d->pre_gamma | (uintptr_t)d->pre_beta |
+       (uintptr_t)d->post_gamma | (uintptr_t)d->post_beta) & 15) return MODE_ERR_UNSUPPORTED;
+  if (d->M == 0) return MODE_OK;
+  ConvGemmParams p;
+  p.A = (const uint16_t*)d->x; p.lda = d->ldx; p.idx = d->idx; p.idx_tstride = d->idx_tap_stride;
+  p.W = (const uint16_t*)d->w; p.ldw = d->ldw; p.C = (uint16_t*)d->y; p.ldc = d->ldy;
+  p.M = d->M; p.N = d->Cout; p.tap_k = d->Cin; p.taps = d->taps; p.m_tiles = p.n_tiles = 0;
+  p.bn_mean = d->bn_mean; p.bn_var = d->bn_var; p.bn_w = d->bn_weight; p.bn_b = d->bn_bias; p.bn_eps = d->bn_eps;
+  p.res = (const uint16_t*)d->residual; p.ldr = d->ldr; p.relu = d->relu;
+  p.pre_g = d->pre_gamma; p.pre_b = d->pre_beta; p.post_g = d->post_gamma; p.post_b = d->post_beta; p.rows_per_sample = d->rows_per_sample > 0 ? d->rows_per_sample : 1;
+  const long t128 = (long)((d->M + 127) / 128) * ((d->Cout + 127) / 128);
+  const bool wide = d->Cout % 128 == 0 && t128 >= 384;
+  return wide ? conv_launch<false, 128, true>(p, (hipStream_t)stream) : conv_launch<false, 64, true>(p, (hipStream_t)stream);
+}

@@ -24,6 +24,7 @@ extern int g_combine_row_max;
 extern int g_gemm_mid_rows;
 extern int g_tr_cfg;
 extern int g_bwd_coexec;
+extern int g_conv_ns;
 extern int g_gemm_group_m;
 extern int g_adamw_blocks;
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -93,7 +94,7 @@ extern "C" size_t mode_hip_sizeof(const char* n) {
 #define MODE_SZ(T) if (!strcmp(n, #T)) return sizeof(T);
   MODE_SZ(ModeGemmDesc) MODE_SZ(ModeEmbedDesc) MODE_SZ(ModeHeadDesc) MODE_SZ(ModeGroupedMlpDesc) MODE_SZ(ModeDims) MODE_SZ(ModeLayerWeights)
   MODE_SZ(ModeModelWeights) MODE_SZ(ModeMetaLayout) MODE_SZ(ModeForwardArgs) MODE_SZ(ModeStashLayout) MODE_SZ(ModeTrainArgs) MODE_SZ(ModeLayerGrads)
-  MODE_SZ(ModeModelGrads) MODE_SZ(ModeLayerWeightsT) MODE_SZ(ModeModelWeightsT) MODE_SZ(ModeBnFilmDesc) MODE_SZ(ModeQkvAttnDesc)
+  MODE_SZ(ModeModelGrads) MODE_SZ(ModeLayerWeightsT) MODE_SZ(ModeModelWeightsT) MODE_SZ(ModeBnFilmDesc) MODE_SZ(ModeQkvAttnDesc) MODE_SZ(ModeConvBnDesc)
 #undef MODE_SZ
   return 0;
 }
@@ -115,6 +116,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_pp_min_tiles")) { g_gemm_pp_min_tiles = value; return MODE_OK; }
   if (!strcmp(key, "gemm_tr_cfg")) { g_tr_cfg = value; return MODE_OK; }
   if (!strcmp(key, "bwd_coexec")) { g_bwd_coexec = value != 0; return MODE_OK; }
+  if (!strcmp(key, "conv_ns")) { if (value != 0 && value != 2 && value != 3) return MODE_ERR_BAD_ARG; g_conv_ns = value; return MODE_OK; }
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return MODE_OK; }
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }
   if (!strcmp(key, "gemm_skinny_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_skinny_rows = value; return MODE_OK; }

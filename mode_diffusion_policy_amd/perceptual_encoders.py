@@ -505,6 +505,55 @@ def bn_film_act(x, bn: nn.BatchNorm2d, relu: bool = True, residual=None, pre_fil
                             bn.num_batches_tracked if bn.training else None, torch.is_grad_enabled())
 
 
+# Inference: convolution + eval-mode BatchNorm + FiLM + residual + ReLU as ONE launch (mode_conv_bn_act_fwd, csrc/conv_gemm.hip) - the rollout's encoders run
+# half the kernels and the convolution output never goes to memory un-normalised.  MODE_ENC_FUSE_CONV_BN=0: the two launches (A/B runs, tests).
+FUSE_CONV_BN = __import__("os").environ.get("MODE_ENC_FUSE_CONV_BN", "1") == "1"
+
+
+def _film_arg(t, n: int, c: int):
+    return None if t is None else t.reshape(n, c).to(torch.float32).contiguous()
+
+
+def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, relu: bool = True, residual=None, pre_film=None, post_film=None):
+    """``bn_film_act(_conv2d(conv, x), bn, ...)``; on the inference path (no grad, eval-mode BatchNorm with running statistics, bf16 compute, a channel count
+    the implicit-GEMM kernel takes) as one launch."""
+    w = conv.weight
+    cd = _compute_dtype(x)
+    if (FUSE_CONV_BN and USE_HIP_CONV_WGRAD and x.is_cuda and cd == torch.bfloat16 and not torch.is_grad_enabled() and not bn.training and bn.running_mean is not None
+            and conv.groups == 1 and conv.dilation == (1, 1) and conv.bias is None and isinstance(conv.padding, tuple) and w.shape[1] % 64 == 0 and w.shape[0] % 8 == 0):
+        w_lp = None
+        if _W_OVERRIDE is not None:
+            hit = _W_OVERRIDE.get(id(conv))
+            if hit is not None and hit.dtype == cd:
+                w_lp = hit
+        if w_lp is None:
+            if CHANNELS_LAST and not w.is_contiguous(memory_format=torch.channels_last):
+                with torch.no_grad():
+                    w.data = w.data.contiguous(memory_format=torch.channels_last)
+            w_lp = _shadow(conv, cd)
+        xc = x.to(cd)
+        n, cin, H, W_ = xc.shape
+        cout, _, kh_, kw_ = w.shape
+        sh, sw = conv.stride; ph, pw = conv.padding
+        ho = (H + 2 * ph - kh_) // sh + 1; wo = (W_ + 2 * pw - kw_) // sw + 1
+        one = kh_ == 1 and kw_ == 1 and (sh, sw) == (1, 1) and (ph, pw) == (0, 0)
+        res = None if residual is None else residual.to(cd)
+        if (xc.is_contiguous(memory_format=torch.channels_last) and (one or w_lp.is_contiguous(memory_format=torch.channels_last))
+                and (res is None or (res.shape == (n, cout, ho, wo) and res.is_contiguous(memory_format=torch.channels_last)))):
+            idx = None if one else _tap_table(n, H, W_, ho, wo, kh_, kw_, sh, sw, ph, pw, xc.device)
+            pg, pb = (_film_arg(pre_film[0], n, cout), _film_arg(pre_film[1], n, cout)) if pre_film is not None else (None, None)
+            qg, qb = (_film_arg(post_film[0], n, cout), _film_arg(post_film[1], n, cout)) if post_film is not None else (None, None)
+            y = torch.empty((n, cout, ho, wo), dtype=cd, device=xc.device, memory_format=torch.channels_last)
+            R = n * ho * wo
+            d = L.ModeConvBnDesc(x=xc.data_ptr(), ldx=cin, idx=_ptr(idx), idx_tap_stride=R, taps=kh_ * kw_, w=w_lp.data_ptr(), ldw=kh_ * kw_ * cin, y=y.data_ptr(), ldy=cout,
+                                 M=R, Cin=cin, Cout=cout, bn_mean=_ptr(bn.running_mean), bn_var=_ptr(bn.running_var), bn_weight=_ptr(bn.weight), bn_bias=_ptr(bn.bias),
+                                 bn_eps=bn.eps, residual=_ptr(res), ldr=cout, relu=int(relu), pre_gamma=_ptr(pg), pre_beta=_ptr(pb), post_gamma=_ptr(qg), post_beta=_ptr(qb),
+                                 rows_per_sample=ho * wo)
+            L.check(L.load().mode_conv_bn_act_fwd(C.byref(d), torch.cuda.current_stream().cuda_stream), "mode_conv_bn_act_fwd")
+            return y
+    return bn_film_act(_conv2d(conv, x), bn, relu=relu, residual=residual, pre_film=pre_film, post_film=post_film)
+
+
 # ------------------------------------------------------------------------------------------------------------------ trunk (parameter holders)
 class _Block(nn.Module):
     """BasicBlock (expansion 1) / Bottleneck (expansion 4) holder with the timm / torchvision attribute names."""
@@ -533,12 +582,12 @@ class _Block(nn.Module):
         stage-level FiLMLayer of pretrained_resnets.py fused into the stage's last block)."""
         identity = x
         if self.downsample is not None:
-            identity = bn_film_act(self._conv(self.downsample[0], x), self.downsample[1], relu=False)
-        out = bn_film_act(self._conv(self.conv1, x), self.bn1, relu=True)
+            identity = conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
+        out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
         if self.bottleneck:
-            out = bn_film_act(self._conv(self.conv2, out), self.bn2, relu=True)
-            return bn_film_act(self._conv(self.conv3, out), self.bn3, relu=True, residual=identity, pre_film=pre_film, post_film=post_film)
-        return bn_film_act(self._conv(self.conv2, out), self.bn2, relu=True, residual=identity, pre_film=pre_film, post_film=post_film)
+            out = conv_bn_act(self.conv2, self.bn2, out, relu=True)
+            return conv_bn_act(self.conv3, self.bn3, out, relu=True, residual=identity, pre_film=pre_film, post_film=post_film)
+        return conv_bn_act(self.conv2, self.bn2, out, relu=True, residual=identity, pre_film=pre_film, post_film=post_film)
 
 
 _ARCH = {"18": (False, (2, 2, 2, 2)), "34": (False, (3, 4, 6, 3)), "50": (True, (3, 4, 6, 3))}

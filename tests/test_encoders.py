@@ -454,3 +454,33 @@ def test_encoder_gradients_with_and_without_the_hip_conv_path():
     self_gap = max(rel(grads["plain2"][n], grads["plain"][n]) for n in grads["hip"])
     print(f"worst tensor: hip vs plain {worst:.2e}, plain vs plain again {self_gap:.2e}")
     assert worst < max(2.0 * self_gap, 6e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["r50", "r34", "r18f"])
+def test_inference_conv_bn_fusion_matches_the_two_launch_path(tag):
+    """Eval mode, no grad, autocast(bf16): convolution + eval-BatchNorm + FiLM + residual + ReLU as one launch (mode_conv_bn_act_fwd: 1 x 1, 3 x 3, strided,
+    downsample, pre- and post-FiLM blocks) against F-conv / GEMM followed by the fused BatchNorm pass, and against the fp32 module."""
+    torch.manual_seed(11)
+    enc = CTORS[tag](24).cuda().eval()
+    with torch.no_grad():
+        for n_, p_ in enc.named_parameters():
+            if "film" in n_:
+                p_.normal_(std=0.1)
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(std=0.2); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(std=0.2)
+    img = torch.randn(5, 3, 96, 80, device="cuda"); cond = torch.randn(5, 24, device="cuda")
+    outs = {}
+    for flag in (True, False):
+        E.FUSE_CONV_BN = flag
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                outs[flag] = enc(img, cond).float()
+        finally:
+            E.FUSE_CONV_BN = True
+    with torch.no_grad():
+        ref = enc(img, cond).float()                                            # fp32 activations: MIOpen + the fused pass, no bf16 anywhere
+    e_fused, e_plain, e_pair = rel(outs[True], ref), rel(outs[False], ref), rel(outs[True], outs[False])
+    print(f"{tag}: fused vs fp32 {e_fused:.2e}, two launches vs fp32 {e_plain:.2e}, fused vs two launches {e_pair:.2e}")
+    assert e_fused < 2e-2 and e_fused < 1.5 * e_plain + 2e-3                    # normalising the fp32 accumulators is not less accurate than normalising their bf16 rounding
