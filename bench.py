@@ -486,6 +486,36 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU, z
             "rccl_ranks": ranks if backend == "nccl" else None, "dp_backend": backend, "dp_ranks": ranks, "train_steps": steps}
 
 
+def agent_replan_measure(den, device):
+    """The rollout as the AGENT runs it (mode_agent.py:584-637): raw 224 x 224 frames of two cameras -> two FiLM-ResNet-50s (eval, autocast bf16) -> 10-step DDIM
+    chunk; replanning call latency with the encoders captured in a hipGraph (GraphedVisualEncoder) and eager, for 1 and 32 environments."""
+    from mode_diffusion_policy_amd import rollout as RO
+    from mode_diffusion_policy_amd.perceptual_encoders import FiLMResNet50Policy, embed_visual_obs
+    agent_extra = {}
+    enc_s, enc_g = FiLMResNet50Policy(512).to(device).eval(), FiLMResNet50Policy(512).to(device).eval()
+    for key, nb in (("agent_b1", 1), ("agent_b32", 32)):
+        gen = torch.Generator().manual_seed(3)
+        frames = {"rgb_obs": {"rgb_static": torch.randn(nb, 1, 3, 224, 224, generator=gen).to(device),
+                              "rgb_gripper": torch.randn(nb, 1, 3, 224, 224, generator=gen).to(device)}}
+        lg = torch.randn(nb, 512, generator=gen).to(device)
+        pol = RO.ChunkedRolloutPolicy(den, multistep=1, static_resnet=enc_s, gripper_resnet=enc_g)
+        plain = RO.ChunkedRolloutPolicy(den, multistep=1)
+
+        def eager_call():
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                tok = embed_visual_obs(enc_s, enc_g, frames["rgb_obs"]["rgb_static"], frames["rgb_obs"]["rgb_gripper"], lg)
+            return plain.step({"state_images": tok["state_images"].float()}, lg)
+        for name, fn in (("graphed", lambda: pol.step(frames, lg)), ("eager", eager_call)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            agent_extra[f"{key}_replan_ms_{name}_encoders"] = round((time.perf_counter() - t1) / 20 * 1e3, 3)
+    return agent_extra
+
+
 def extra_measurements(M, den, device):
     """Driver-timed numbers of the other inference configurations, in the same process as the headline run (rank 0, N = 1 only):
     configs[4] rollout (B=32 environments) and the reference's real rollout case B=1.  (The training leg is `train_leg`, run by every N.)"""
@@ -603,17 +633,23 @@ def agent_bench(args, world, rank, device, dist):
     """SURVEY section 8(f) rank 1 end to end: the reference AGENT's training step - two FiLM-ResNet-50 encoders (static + gripper camera, 224 x 224,
     conditioned on the latent goal, mode_agent.py:548-567, conf/model/mode_agent.yaml resnet_type '50', calvin_transforms.yaml) feeding the denoiser's
     score-matching loss, everything under torch.autocast(bfloat16) like the reference's trainer (conf/config_calvin.yaml:37), backward THROUGH the
-    denoiser into both encoders, AdamW on all of it (fused arena AdamW for the denoiser, torch AdamW for the encoders).  Convolutions: MIOpen;
-    BatchNorm / FiLM / ReLU / residual between them: the fused HIP pass (csrc/encoder_ops.hip).  One rank; single-GPU number."""
+    denoiser into both encoders, AdamW on all of it (fused arena AdamW for the denoiser, torch AdamW for the encoders).  Convolutions: the library's own GEMM /
+    implicit-GEMM kernels (the 3-channel stem: MIOpen); BatchNorm / FiLM / ReLU / residual between them: the fused HIP pass (csrc/encoder_ops.hip).  One rank."""
+    M, den = build_model(device, args.dtype)
+    res = agent_step_measure(den, device, args.agent_batch, args.steps, args.warmup, bool(args.miopen_benchmark))
+    print(json.dumps(res), flush=True)
+
+
+def agent_step_measure(den, device, B, steps, warmup, miopen_benchmark=False):
+    """The measurement behind `--mode agent` (also a leg of the default run, on the headline's model): returns the JSON record."""
     import math
     from mode_diffusion_policy_amd.optim import FusedAdamW
     from mode_diffusion_policy_amd.perceptual_encoders import FiLMResNet50Policy, embed_visual_obs
     from mode_diffusion_policy_amd.utils import rand_log_logistic
-    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
-    M, den = build_model(device, args.dtype)
+    torch.backends.cudnn.benchmark = bool(miopen_benchmark)
     m = den.inner_model
+    was_training = den.training
     den.train()
-    B = args.agent_batch
     torch.manual_seed(0)
     enc_s, enc_g = FiLMResNet50Policy(512).to(device).train(), FiLMResNet50Policy(512).to(device).train()
     for enc in (enc_s, enc_g):                                                 # the reference zero-initialises FiLM: give the modulation something to do
@@ -643,30 +679,31 @@ def agent_bench(args, world, rank, device, dist):
         opt_e.step()
         opt_e.zero_grad(set_to_none=True)
         return loss
-    for _ in range(max(args.warmup, 2)):                                        # includes MIOpen's per-shape algorithm search
+    for _ in range(max(warmup, 2)):                                             # includes MIOpen's per-shape algorithm search
         loss = step()
     torch.cuda.synchronize()
     assert torch.isfinite(loss.detach()).all()
     blocks, host = [], []
     for _ in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
-        host.append((time.perf_counter() - t0) / args.steps * 1e3)               # the loop returned: everything is enqueued
-        torch.cuda.synchronize(); blocks.append((time.perf_counter() - t0) / args.steps * 1e3)
+        host.append((time.perf_counter() - t0) / steps * 1e3)                    # the loop returned: everything is enqueued
+        torch.cuda.synchronize(); blocks.append((time.perf_counter() - t0) / steps * 1e3)
     step(timed=True); torch.cuda.synchronize()
     enc_fwd_ms = ev[0].elapsed_time(ev[1])
     ms = min(blocks)
     n_enc = sum(p_.numel() for e in (enc_s, enc_g) for p_ in e.parameters())
     res = {"metric": "agent-train-samples/sec (2x FiLM-ResNet-50 @224 + MoDE denoiser, B per GPU, AdamW)", "value": round(B / (ms * 1e-3), 1), "unit": "samples/s",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+           "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "bf16 (torch.autocast for the encoders, bf16 MFMA chain for the denoiser)", "data": "synthetic",
            "config": {"workload": "SURVEY 8(f)-1: MoDEAgent training step - embed_visual_obs (2 x FiLMResNet50Policy, 224 x 224 RGB, latent-goal FiLM) -> "
                                   "GCDenoiser.loss (12 layers, d=1024, 4 experts top-2) -> backward through both -> AdamW", "global_batch": B,
                       "parallelism": "single GPU"},
            "agent_ms_per_step_blocks": [round(b, 3) for b in blocks], "host_enqueue_ms_per_step": round(min(host), 3), "encoders_forward_ms": round(enc_fwd_ms, 3), "encoder_params": n_enc,
-           "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "miopen_benchmark": bool(args.miopen_benchmark)}
-    print(json.dumps(res), flush=True)
+           "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "miopen_benchmark": bool(miopen_benchmark)}
+    den.train(was_training)
+    return res
 
 
 def main():
@@ -760,31 +797,7 @@ def main():
     if rollout:
         agent_extra = {}
         if rank == 0 and not args.no_extras:
-            # the rollout as the AGENT runs it (mode_agent.py:584-637): raw 224 x 224 frames of two cameras -> two FiLM-ResNet-50s (eval, autocast bf16) ->
-            # 10-step DDIM chunk; replanning call latency with the encoders captured in a hipGraph (GraphedVisualEncoder) and eager
-            from mode_diffusion_policy_amd import rollout as RO
-            from mode_diffusion_policy_amd.perceptual_encoders import FiLMResNet50Policy, embed_visual_obs
-            enc_s, enc_g = FiLMResNet50Policy(512).to(device).eval(), FiLMResNet50Policy(512).to(device).eval()
-            for key, nb in (("agent_b1", 1), ("agent_b32", 32)):
-                gen = torch.Generator().manual_seed(3)
-                frames = {"rgb_obs": {"rgb_static": torch.randn(nb, 1, 3, 224, 224, generator=gen).to(device),
-                                      "rgb_gripper": torch.randn(nb, 1, 3, 224, 224, generator=gen).to(device)}}
-                lg = torch.randn(nb, 512, generator=gen).to(device)
-                pol = RO.ChunkedRolloutPolicy(den, multistep=1, static_resnet=enc_s, gripper_resnet=enc_g)
-                plain = RO.ChunkedRolloutPolicy(den, multistep=1)
-
-                def eager_call():
-                    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-                        tok = embed_visual_obs(enc_s, enc_g, frames["rgb_obs"]["rgb_static"], frames["rgb_obs"]["rgb_gripper"], lg)
-                    return plain.step({"state_images": tok["state_images"].float()}, lg)
-                for name, fn in (("graphed", lambda: pol.step(frames, lg)), ("eager", eager_call)):
-                    for _ in range(3):
-                        fn()
-                    torch.cuda.synchronize(); t1 = time.perf_counter()
-                    for _ in range(20):
-                        fn()
-                    torch.cuda.synchronize()
-                    agent_extra[f"{key}_replan_ms_{name}_encoders"] = round((time.perf_counter() - t1) / 20 * 1e3, 3)
+            agent_extra = agent_replan_measure(den, device)
         if rank == 0:
             print(json.dumps({
                 "metric": "action-chunks/sec (B=32 envs, 10-step DDIM per chunk)", "value": round(n_gpus * args.steps * batch / elapsed, 1),
@@ -878,6 +891,19 @@ def main():
                     wd.cancel()
             if train_failed:
                 break
+    # the path's neighbours, driver-timed in the same process (N = 1 only; after everything above, each in its own try: the headline and the
+    # training leg are never at stake) - the replanning call as the agent makes it (cameras -> two FiLM-ResNet-50s -> 10-step chunk) and the agent's training step
+    if rank == 0 and n_gpus == 1 and args.dtype == "bf16" and not args.no_extras and _dry_run_layers() == 0 and not train_failed:
+        try:
+            res.update(agent_replan_measure(den, device))
+        except Exception as e:                                                  # noqa: BLE001
+            res["agent_replan_error"] = repr(e)[:300]
+        try:
+            a = agent_step_measure(den, device, 64, 5, 2)
+            res.update({"agent_train_ms_per_step": a["ms_per_step"], "agent_train_samples_per_s": a["value"], "agent_train_batch": 64,
+                        "agent_train_host_enqueue_ms": a["host_enqueue_ms_per_step"]})
+        except Exception as e:                                                  # noqa: BLE001
+            res["agent_train_error"] = repr(e)[:300]
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
