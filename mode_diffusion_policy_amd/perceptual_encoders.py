@@ -10,7 +10,8 @@ Same constructor arguments, forward signatures and ``state_dict`` keys (``resnet
 trunks are built here from ``nn.Conv2d`` / ``nn.BatchNorm2d`` holders (neither ``timm`` nor ``torchvision`` is needed at run time —
 ``pretrained=True`` therefore means "load a checkpoint": there is no network on the box).
 
-Compute: convolutions are MIOpen calls (``torch.nn.functional.conv2d`` — SURVEY: "convs via MIOpen first"); everything BETWEEN two
+Compute: convolutions run on the library's GEMM / implicit-GEMM kernels in bf16 on channels_last data (``_ConvFn`` below; fp32 and the 3-channel stem go
+through ``torch.nn.functional.conv2d`` = MIOpen - SURVEY: "convs via MIOpen first" was round 3); everything BETWEEN two
 convolutions — BatchNorm (eval or training statistics), the FiLM modulations, the residual add and the ReLU — is ONE hand-written HIP pass over
 the activation (``mode_bn_film_act_fwd``; the reference launches 3-6 elementwise kernels there), with a HIP backward
 (``mode_bn_film_act_bwd``: one reduction pass + one dx pass, deterministic) behind ``torch.autograd`` so the encoders train through the
@@ -223,14 +224,17 @@ def _compute_dtype(x: torch.Tensor) -> torch.dtype:
     return torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
 
 
-# ---- convolutions of the TRAINING path.  Under autocast (how the reference trains, conf/config_calvin.yaml:37) every convolution costs, besides MIOpen's
-# kernels: a cast of its fp32 weight (forward), a cast of the bf16 weight gradient back (backward) and - the expensive part - MIOpen's weight-gradient
-# helpers (an fp32 workspace zeroed and cast back around every igemm_wrw kernel: 424 launches / 4.0 ms of a 43-ms agent step, the wrw kernels themselves at
-# ~100 TF/s).  A 1 x 1 / stride-1 convolution on channels_last data IS a GEMM over rows = pixels, so its weight gradient dW[Cout, Cin] = dY[R, Cout]^T X[R, Cin] is
-# exactly the library's row-major weight-gradient GEMM (mode_gemm, MODE_GEMM_A_KM | W_KN: operands where they lie, fp32 out): 36 of ResNet-50's 53 convolutions.
-# `_ConvFn` keeps MIOpen for the forward and the data gradient, takes the weight gradient of those through the HIP GEMM (K = pixels cut into groups, partial
-# sums added in group order: deterministic), hands autograd an fp32 gradient directly, and reads a compute-dtype SHADOW of the weight that is refreshed when
-# the parameter's version moves (all stale shadows of an encoder in one `_foreach_copy_`).  USE_HIP_CONV_WGRAD = False restores F.conv2d with per-call casts.
+# ---- convolutions on the library's own kernels (round 4; DESIGN.md section 4, profiles/r04_conv_probes.txt).  On channels_last bf16 activations every convolution
+# is a GEMM over rows = pixels, and the library already had the GEMMs; MIOpen (round 3: "convs via MIOpen first") cost 37 % of the agent's step - weight-gradient
+# kernels at ~100 TF/s wrapped in zero / cast helper launches, split-K forward / data-gradient kernels with the same helpers, two autocast casts per convolution.
+#   1 x 1 / stride 1   forward = mode_gemm, data gradient = MODE_GEMM_W_KN, weight gradient dW[Cout, Cin] = dY[R, Cout]^T X[R, Cin] = MODE_GEMM_A_KM | W_KN with
+#                      K = pixels cut into groups (fp32 partial sums added in group order: deterministic)
+#   k x k / strided    forward and data gradient as implicit GEMM (csrc/conv_gemm.hip: `a_rows` in taps - the A tile of a K-step is gathered from the rows its
+#                      filter tap pairs with the output pixels, -1 = outside the image), weight gradient as ONE product over the taps (`w_rows` in taps)
+#   3-channel stem     stays with MIOpen (Cin % 64 != 0)
+# `_ConvFn` hands autograd fp32 weight gradients directly and reads a compute-dtype SHADOW of the weight that is refreshed when the parameter's version moves (all
+# stale shadows of an encoder in one `_foreach_copy_`).  Inference takes the same forward kernels, and `conv_bn_act` folds the eval-mode BatchNorm / FiLM / residual
+# / ReLU into the convolution's epilogue (mode_conv_bn_act_fwd).  MODE_ENC_HIPCONV=0 restores F.conv2d with per-call casts everywhere (A/B runs).
 USE_HIP_CONV_WGRAD = __import__("os").environ.get("MODE_ENC_HIPCONV", "1") == "1"     # MODE_ENC_HIPCONV=0: A/B runs
 _KOFFS: dict = {}
 
