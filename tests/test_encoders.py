@@ -484,3 +484,32 @@ def test_inference_conv_bn_fusion_matches_the_two_launch_path(tag):
     e_fused, e_plain, e_pair = rel(outs[True], ref), rel(outs[False], ref), rel(outs[True], outs[False])
     print(f"{tag}: fused vs fp32 {e_fused:.2e}, two launches vs fp32 {e_plain:.2e}, fused vs two launches {e_pair:.2e}")
     assert e_fused < 2e-2 and e_fused < 1.5 * e_plain + 2e-3                    # normalising the fp32 accumulators is not less accurate than normalising their bf16 rounding
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("MODE_FUZZ_CONV_CASES", "16"))))     # MODE_FUZZ_CONV_CASES=200: the wide sweep
+def test_conv_fn_random_geometries(case):
+    """Random convolution geometries through `_ConvFn` (kernel 1 / 3 / 5, strides 1-2, paddings 0-2, odd image sizes, 64 ... 320 channels, batches 1 ... 9):
+    output, data gradient and weight gradient against torch's fp32 conv2d autograd on the same bf16 values; every case must take the HIP kernels."""
+    g = torch.Generator().manual_seed(9000 + case)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    k = (1, 3, 3, 5)[ri(0, 3)]; stride = ri(1, 2); pad = ri(0, min(2, k // 2 + 1)) if k > 1 else ri(0, 1) * 0
+    cin, cout = 64 * ri(1, 5), 8 * ri(1, 40)
+    n, H, W_ = ri(1, 9), ri(k + 1, 23), ri(k + 1, 23)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False).cuda()
+    E._store_channels_last(conv)
+    x = torch.randn(n, cin, H, W_, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = E._conv2d(conv, x)
+    assert type(y.grad_fn).__name__ == "_ConvFnBackward"
+    dy = torch.randn(y.shape, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    xr = x.detach().float().requires_grad_(True); wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, None, stride, pad)
+    yr.backward(dy.float())
+    tag = f"k{k} s{stride} p{pad} {cin}->{cout} n{n} {H}x{W_}"
+    assert rel(y.float(), yr) < 5e-3, tag
+    assert rel(x.grad.float(), xr.grad) < 5e-3, tag
+    assert rel(conv.weight.grad, wr.grad) < 1e-5, tag                           # fp32 accumulate and store
+    with torch.no_grad():                                                       # the inference path takes the same forward kernel
+        y2 = E._conv2d(conv, x.detach())
+    assert torch.equal(y2, y.detach()), tag
