@@ -24,6 +24,7 @@ extern int g_combine_row_max;
 extern int g_gemm_mid_rows;
 extern int g_tr_cfg;
 extern int g_bwd_coexec;
+int g_fuse_swiglu_bwd = 1;   // "fuse_swiglu_bwd" option: 1 = the training backward runs dH = dY W2 and the SwishGLU backward as one launch
 extern int g_conv_ns;
 extern int g_gemm_group_m;
 extern int g_adamw_blocks;
@@ -116,6 +117,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_pp_min_tiles")) { g_gemm_pp_min_tiles = value; return MODE_OK; }
   if (!strcmp(key, "gemm_tr_cfg")) { g_tr_cfg = value; return MODE_OK; }
   if (!strcmp(key, "bwd_coexec")) { g_bwd_coexec = value != 0; return MODE_OK; }
+  if (!strcmp(key, "fuse_swiglu_bwd")) { g_fuse_swiglu_bwd = value != 0; return MODE_OK; }
   if (!strcmp(key, "conv_ns")) { if (value != 0 && value != 2 && value != 3) return MODE_ERR_BAD_ARG; g_conv_ns = value; return MODE_OK; }
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return MODE_OK; }
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }

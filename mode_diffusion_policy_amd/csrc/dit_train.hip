@@ -15,6 +15,9 @@ namespace mode {
 int rmsnorm_bwd_launch(const float* x, const float* g, const float* dy_a, const float* dy_b, const float* G, int g_splits, long g_split_stride,
                        const int32_t* pos, int k, int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* dx_lp,
                        int lp_dtype, hipStream_t stream);   // train_ops.hip
+int gemm_bf16_tr_swiglu_bwd_launch(const ModeGemmDesc* d, const void* P, void* dP, uint32_t seed, uint32_t thresh, float inv_keep, float* bsum, hipStream_t s);   // gemm_bf16_tr.hip
+int tr_tile_offsets_launch(const int* offsets, int E, int* out, hipStream_t s);          // gemm_bf16_tr.hip
+extern int g_fuse_swiglu_bwd;                                                            // "fuse_swiglu_bwd" option (dit.hip)
 bool gemm_bf16_pptr_accepts(const ModeGemmDesc* d);                                      // gemm_bf16_pptr.hip: would mode_gemm take the ping-pong kernel?
 int gather_rows_bf16(const void* in, long ld_in, const int* rows, int n, int cols, void* out, long ld_out, hipStream_t s);   // gemm_bf16_pptr.hip
 }
@@ -323,7 +326,25 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     }
     // (2) expert down-projection: dH = dY W2 ; dW2_e = dY_e^T H_e
     ModeGemmDesc g;
-    if (tr) {                                        // bf16: operands as they lie in memory, fragments by LDS transpose reads
+    // (2) + (3) as ONE launch (bf16): the data gradient's 128 x 128 tile never leaves the chip - its epilogue reads the stashed pre-activations, applies the
+    // SwishGLU (+ dropout) backward and writes dP and the bias-gradient partial sums (one row per m-tile, summed per expert below).  Saves the 29 MB dH round
+    // trip and a 146-MB elementwise pass per layer (measured in the step: profiles/r04_train_step_kernel_stats.txt).
+    const size_t bsum_bytes = ((size_t)NK / 128 + E + 1) * 8 * D * 4;
+    const bool fuse_sb = tr && mode::g_fuse_swiglu_bwd && (4 * D) % 128 == 0 && D % 64 == 0 && E <= 16 && cswb >= bsum_bytes + 4096 + 256;
+    if (fuse_sb) {
+      float* bsum = (float*)csw;
+      int* toff = (int*)((char*)csw + bsum_bytes);
+      g = gdesc(dt, MODE_EPI_NONE, dt, NK, 4 * D, D, dYs, D, lw.w2, 4 * D, nullptr, 4 * D);
+      g.w_expert_stride = 4L * D * D; g.expert_offsets = offsets; g.num_experts = E; g.flags = MODE_GEMM_W_KN;
+      const float pd = a->mlp_pdrop;
+      const uint32_t th = pd <= 0.f ? 0u : (uint32_t)((double)pd * 4294967296.0);
+      if ((rc = mode::tr_tile_offsets_launch(offsets, E, toff, hs))) return rc;
+      if ((rc = mode::gemm_bf16_tr_swiglu_bwd_launch(&g, S + sl.P, dP, mode_stream_seed(a->seed, 2 * l + 1), th, 1.0f / (1.0f - pd), bsum, hs))) return rc;
+      if ((rc = mode_colsum(bsum, 8L * D, NK / 128 + E, 8 * D, MODE_F32, toff, 0, E, lg.b1, 0, (char*)csw + bsum_bytes + 4096, cswb - bsum_bytes - 4096, stream))) return rc;
+      g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, 4 * D, NK, dYs, D, S + sl.Hd, 4 * D, lg.w2, 4 * D);
+      g.k_group_offsets = offsets; g.num_k_groups = E; g.c_group_stride = 4L * D * D; g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
+      if ((rc = mode_gemm(&g, stream))) return rc;
+    } else if (tr) {                                 // bf16: operands as they lie in memory, fragments by LDS transpose reads
       g = gdesc(dt, MODE_EPI_NONE, dt, NK, 4 * D, D, dYs, D, lw.w2, 4 * D, dHd, 4 * D);
       g.w_expert_stride = 4L * D * D; g.expert_offsets = offsets; g.num_experts = E; g.flags = MODE_GEMM_W_KN;
       if ((rc = mode_gemm(&g, stream))) return rc;
@@ -342,7 +363,9 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       if ((rc = mode_gemm(&g, stream))) return rc;
     }
     // (3) SwishGLU (+ dropout) backward, bias gradient
-    if (dt == MODE_BF16 && D % 2 == 0 && E <= 16) {                  // one pass: dP and the per-expert column sums of dP
+    if (fuse_sb) {
+      // done inside the data-gradient GEMM above
+    } else if (dt == MODE_BF16 && D % 2 == 0 && E <= 16) {                  // one pass: dP and the per-expert column sums of dP
       if ((rc = mode_swiglu_bwd_bias(S + sl.P, dHd, dP, NK, 4 * D, dt, mode_stream_seed(a->seed, 2 * l + 1), a->mlp_pdrop, offsets, E, lg.b1, csw, cswb, stream))) return rc;
     } else {
       if ((rc = mode_swiglu_bwd(S + sl.P, dHd, dP, NK, 4 * D, dt, mode_stream_seed(a->seed, 2 * l + 1), a->mlp_pdrop, stream))) return rc;

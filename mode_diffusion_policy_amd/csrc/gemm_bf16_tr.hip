@@ -34,6 +34,10 @@ struct TrParams {
   int tap_cols; long tap_stride;          // w_rows in taps: output column n belongs to tap n / tap_cols, which reads W's columns n % tap_cols through w_rows + tap * tap_stride
   int M, N, K, m_tiles, n_tiles;
   int split_k; long split_stride;         // data gradient only: blockIdx.y = K-slice, partial sums to C + slice*split_stride (the consumer adds the slabs)
+  // EPI = 1, data gradient dH = dY W2 fused with the SwishGLU (+ dropout) backward and the bias-gradient partial sums (train_ops.hip: swiglu_bwd_bias): C is not written
+  const uint16_t* P; uint16_t* dP;        // pre-activations / their gradients [M, 2 N] (value | gate)
+  uint32_t seed, thresh; float inv_keep;  // expert-dropout stream of this layer
+  float* bsum;                            // [m-tile][2 N] column sums of the bf16-rounded dP over the tile's rows (a tile lies inside one expert's segment)
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -68,7 +72,7 @@ __device__ __forceinline__ int kn_swz(int row) {
 // BN = 128 | 64 output columns per workgroup (64: twice the workgroups for problems that would not fill 256 CUs); NS = LDS ring depth
 // (2: vmcnt(0) per K-step, 2 workgroups/CU hide each other's fill latency; 3: two tiles in flight under counted waits, for long-K
 // problems with <= 1 workgroup per CU).  The gathered-W weight gradient (w_rows) needs NS == 2.
-template <bool A_KM, bool OUT_BF16, int BN, int NS>
+template <bool A_KM, bool OUT_BF16, int BN, int NS, int EPI = 0>
 __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const TrParams p) {
   constexpr int BM = 128, BKT = 64, TM = 64, TN = BN / 2, FM = 4, FN = TN / 16;
   constexpr int W_ROW = BN * 2, W_BYTES = BKT * W_ROW;                 // bytes per k-row / per tile of the [k][n] operand
@@ -314,6 +318,74 @@ __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const T
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     constexpr int EPC = 16 / ESZ;
+    if constexpr (EPI == 1) {
+      // ---- dH tile (bf16, in LDS) -> dP = SwishGLU'(P) * dropout(dH), stored as value | gate halves; column sums of the rounded dP for the bias gradient.
+      // Thread -> 16-byte chunk ch (8 columns) of rows rbase, rbase + 16, ...: its 8 + 8 running column sums meet their 15 partners (same chunk, other rows)
+      // by two xor shuffles inside the wave and one LDS round across the four waves - fixed order, no atomics.
+      static_assert(!A_KM && OUT_BF16 && BN == 128 && EPASS == 1, "fused SwishGLU backward: 128-wide bf16 data-gradient tile");
+      constexpr int NR = BM / 16;
+      const int ch = tid & 15, rbase = tid >> 4;
+      const int n = n0 + ch * 8;
+      const long ldp = 2L * p.N;
+      uint4 pvq[NR], pgq[NR], dhq[NR];
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {                                   // all operand loads of the thread in flight together (rows past the segment re-read its last row)
+        const int rl = rbase + 16 * k;
+        const long m = row0 + min(rl, rows_valid - 1);
+        pvq[k] = *reinterpret_cast<const uint4*>(p.P + m * ldp + n); pgq[k] = *reinterpret_cast<const uint4*>(p.P + m * ldp + p.N + n);
+        dhq[k] = *reinterpret_cast<const uint4*>(smem + rl * CROW + ((ch ^ (rl & CSWZ)) << 4));
+      }
+      float sv[8], sg[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sv[j] = 0.f; sg[j] = 0.f; }
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int rl = rbase + 16 * k;
+        if (rl >= rows_valid) continue;
+        const long m = row0 + rl;
+        const uint32_t wv[4] = {pvq[k].x, pvq[k].y, pvq[k].z, pvq[k].w}, wg[4] = {pgq[k].x, pgq[k].y, pgq[k].z, pgq[k].w}, wd[4] = {dhq[k].x, dhq[k].y, dhq[k].z, dhq[k].w};
+        uint32_t ov[4], og[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float dv[2], dg[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float v = bf16_bits_to_f32(q ? wv[j] >> 16 : wv[j] & 0xffff), g_ = bf16_bits_to_f32(q ? wg[j] >> 16 : wg[j] & 0xffff);
+            float dh = bf16_bits_to_f32(q ? wd[j] >> 16 : wd[j] & 0xffff);
+            if (p.thresh) dh = drop_keep(p.seed, (uint64_t)(m * p.N + n + 2 * j + q), p.thresh) ? dh * p.inv_keep : 0.f;
+            const float sgm = __builtin_amdgcn_rcpf(1.0f + __expf(-g_));
+            dv[q] = dh * g_ * sgm;                                       // d/d value = silu(gate)
+            dg[q] = dh * v * sgm * (1.0f + g_ * (1.0f - sgm));           // d/d gate  = value * silu'(gate)
+          }
+          ov[j] = pack_bf16x2(dv[0], dv[1]); og[j] = pack_bf16x2(dg[0], dg[1]);
+          sv[2 * j] += bf16_bits_to_f32(ov[j] & 0xffff); sv[2 * j + 1] += bf16_bits_to_f32(ov[j] >> 16);
+          sg[2 * j] += bf16_bits_to_f32(og[j] & 0xffff); sg[2 * j + 1] += bf16_bits_to_f32(og[j] >> 16);
+        }
+        *reinterpret_cast<uint4*>(p.dP + m * ldp + n) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+        *reinterpret_cast<uint4*>(p.dP + m * ldp + p.N + n) = make_uint4(og[0], og[1], og[2], og[3]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {                                      // lanes 16 / 32 apart hold the same chunk of other rows
+        sv[j] += __shfl_xor(sv[j], 16, 64); sv[j] += __shfl_xor(sv[j], 32, 64);
+        sg[j] += __shfl_xor(sg[j], 16, 64); sg[j] += __shfl_xor(sg[j], 32, 64);
+      }
+      __builtin_amdgcn_s_barrier();                                    // every thread has read its dH chunks: the tile's LDS can be reused
+      float* red = reinterpret_cast<float*>(smem);                      // [4 waves][16 chunks][16]
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[(wave * 16 + ch) * 16 + j] = sv[j]; red[(wave * 16 + ch) * 16 + 8 + j] = sg[j]; }
+      }
+      __syncthreads();
+      if (tid < 16) {
+        float* o = p.bsum + (long)mt * ldp + n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          o[j] = ((red[(0 * 16 + tid) * 16 + j] + red[(1 * 16 + tid) * 16 + j]) + red[(2 * 16 + tid) * 16 + j]) + red[(3 * 16 + tid) * 16 + j];
+          o[p.N + j] = ((red[(0 * 16 + tid) * 16 + 8 + j] + red[(1 * 16 + tid) * 16 + 8 + j]) + red[(2 * 16 + tid) * 16 + 8 + j]) + red[(3 * 16 + tid) * 16 + 8 + j];
+        }
+      }
+      return;
+    }
     for (int c = tid; c < RP * CPR; c += 256) {
       const int rl = c / CPR, ch = c % CPR;
       const int ml = g * RP + rl;
@@ -327,13 +399,13 @@ __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const T
   }
 }
 
-template <bool KM, bool OB, int BN, int NS>
+template <bool KM, bool OB, int BN, int NS, int EPI = 0>
 static int tr_launch(TrParams p, const ModeGemmDesc* d, hipStream_t s) {
   p.n_tiles = (d->N + BN - 1) / BN;
   p.m_tiles = (d->M + 127) / 128 + (d->expert_offsets ? d->num_experts : 0);
   const dim3 grid(p.m_tiles * p.n_tiles, p.split_k, (KM && d->k_group_offsets) ? d->num_k_groups : 1);
   constexpr size_t lds = (size_t)NS * (128 * 64 * 2 + 64 * BN * 2);       // the output tile goes through the ring (one or two passes)
-  auto kern = gemm_tr_kernel<KM, OB, BN, NS>;
+  auto kern = gemm_tr_kernel<KM, OB, BN, NS, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -341,6 +413,37 @@ static int tr_launch(TrParams p, const ModeGemmDesc* d, hipStream_t s) {
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  MODE_LAUNCH_CHECK();
+  return MODE_OK;
+}
+
+// The down-projection's data gradient fused with the SwishGLU backward (dit_train.hip): dP[M, 2N] and per-m-tile bias-gradient partial sums from
+// dY[M, K], W2 (grouped by expert), the stashed pre-activations P.  dH itself is never written.  128 x 128 ring tile (two workgroups per CU: one's
+// epilogue - 128 KiB of P / dP traffic per tile - runs under the other's K loop).  m-tile t of the grouped tile space = row t of `bsum`.
+int gemm_bf16_tr_swiglu_bwd_launch(const ModeGemmDesc* d, const void* P, void* dP, uint32_t seed, uint32_t thresh, float inv_keep, float* bsum, hipStream_t s) {
+  if (!(d->flags & MODE_GEMM_W_KN) || (d->flags & MODE_GEMM_A_KM) || d->dtype != MODE_BF16 || d->epilogue != MODE_EPI_NONE || d->a_rows || d->w_rows) return MODE_ERR_UNSUPPORTED;
+  if (d->N % 128 || d->K % 64 || d->K <= 0 || d->split_k > 1 || d->k_group_offsets || d->lda % 8 || d->ldw % 8 || !P || !dP || !bsum) return MODE_ERR_UNSUPPORTED;
+  if ((((uintptr_t)P | (uintptr_t)dP | (uintptr_t)bsum) & 15)) return MODE_ERR_UNSUPPORTED;
+  if (d->M <= 0) return MODE_OK;
+  TrParams p;
+  p.A = (const uint16_t*)d->A; p.lda = d->lda; p.W = (const uint16_t*)d->W; p.ldw = d->ldw; p.w_estride = d->w_expert_stride;
+  p.C = nullptr; p.ldc = 0; p.offsets = d->expert_offsets; p.E = d->num_experts;
+  p.koffs = nullptr; p.c_gstride = 0; p.w_rows = nullptr; p.tap_cols = 0; p.tap_stride = 0;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.split_k = 1; p.split_stride = 0; p.m_tiles = p.n_tiles = 0;
+  p.P = (const uint16_t*)P; p.dP = (uint16_t*)dP; p.seed = seed; p.thresh = thresh; p.inv_keep = inv_keep; p.bsum = bsum;
+  return tr_launch<false, true, 128, 2, 1>(p, d, s);
+}
+
+// m-tile offsets of the grouped tile space (128-row tiles): out[e] = first m-tile of expert e, out[E] = number of real m-tiles
+__global__ void tr_tile_offsets_kernel(const int* __restrict__ offsets, int E, int* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    int t = 0;
+    out[0] = 0;
+    for (int e = 0; e < E; ++e) { t += (offsets[e + 1] - offsets[e] + 127) / 128; out[e + 1] = t; }
+  }
+}
+int tr_tile_offsets_launch(const int* offsets, int E, int* out, hipStream_t s) {
+  hipLaunchKernelGGL(tr_tile_offsets_kernel, dim3(1), dim3(64), 0, s, offsets, E, out);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
@@ -382,6 +485,7 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.split_k = split; p.split_stride = d->split_stride;
   p.m_tiles = p.n_tiles = 0;
+  p.P = nullptr; p.dP = nullptr; p.seed = p.thresh = 0; p.inv_keep = 1.f; p.bsum = nullptr;
   // geometry: enough 128x128 workgroups to put two on every CU -> NS2 ring (they hide each other's fill latency); otherwise 128x64
   // tiles (twice the workgroups) with a 3-slot ring so one workgroup keeps two tiles in flight
   const long groups = (a_km && d->k_group_offsets) ? d->num_k_groups : 1;

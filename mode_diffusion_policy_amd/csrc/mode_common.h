@@ -37,6 +37,16 @@ __host__ __device__ inline uint32_t mode_stream_seed(uint32_t seed, uint32_t str
   return x;
 }
 
+// ---- counter-based dropout (expert MLP): lowbias32 (Wellons) of (element index XOR stream seed); oracle/mode_oracle.py restates it bit for bit
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+// keep-mask: element `idx` of stream `seed` survives with probability 1-p (thresh = p * 2^32)
+__device__ __forceinline__ bool drop_keep(uint32_t seed, uint64_t idx, uint32_t thresh) {
+  return hash_u32(hash_u32((uint32_t)idx ^ seed) + (uint32_t)(idx >> 32) * 0x9e3779b9U) >= thresh;
+}
+
 // ---- wave64 reductions via cross-lane shuffles ----------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

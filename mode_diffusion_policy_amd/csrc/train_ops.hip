@@ -10,15 +10,7 @@
 
 namespace mode {
 
-__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {            // lowbias32 (Wellons): good avalanche, 6 ALU ops
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-  return x;
-}
-// keep-mask for dropout: element `idx` of stream `seed` survives with probability 1-p (thresh = p * 2^32)
-__device__ __forceinline__ bool drop_keep(uint32_t seed, uint64_t idx, uint32_t thresh) {
-  return hash_u32(hash_u32((uint32_t)idx ^ seed) + (uint32_t)(idx >> 32) * 0x9e3779b9U) >= thresh;
-}
-
+// (hash_u32 / drop_keep - the dropout keep-mask - live in mode_common.h: the fused data-gradient epilogue of gemm_bf16_tr.hip uses them too)
 template <typename T> __device__ __forceinline__ float ld1(const T* p);
 template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld1<uint16_t>(const uint16_t* p) { return bf16_bits_to_f32(*p); }

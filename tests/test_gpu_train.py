@@ -599,3 +599,32 @@ def test_training_step_with_aux_losses_vs_reference(golden, dtype, tol_l, tol_n,
     assert tot.requires_grad and float(tot) > float(act) > 0 and set(aux) == {"load_balancing_loss", "router_z_loss"}
     tot.backward()                                                            # both modalities' backward passes accumulate (one autograd pass, two nodes)
     assert all(torch.isfinite(p.grad).all() for n_, p in m.named_parameters() if n_ != "gripper_embed.weight")
+
+
+def test_fused_swiglu_backward_epilogue_matches_the_two_kernel_path():
+    """`fuse_swiglu_bwd`: the down-projection's data gradient with the SwishGLU (+ dropout) backward and the bias-gradient sums in its epilogue (gemm_bf16_tr.hip
+    EPI = 1; dH never written) against GEMM + swiglu_bwd_bias on the same stochastic step (ragged multinomial segments, expert dropout on): every gradient agrees
+    to the bf16 rounding of dH that the fused form skips; the dropout masks are the same elements (same hash of (row, column))."""
+    from mode_diffusion_policy_amd import _lib as L
+    lib = L.load()
+    grads = {}
+    for flag in (1, 0):
+        torch.manual_seed(11)
+        cfg, sd, m = build_train("c1e4", 210, "bf16", attn_pdrop=0.3, mlp_pdrop=0.1, goal_drop=0.0, use_argmax=False)
+        inp = make_inputs(cfg, 40, 91)
+        sig = O.rand_log_logistic((40,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(5))
+        c = {k: v.cuda() for k, v in inp.items()}
+        den = M.GCDenoiser(m, 0.5).train()
+        lib.mode_set_option(b"fuse_swiglu_bwd", flag)
+        try:
+            loss, _ = den.loss({"state_images": c["state_images"]}, c["actions"], c["goals"], c["noise"], sig.cuda())
+            loss.backward()
+        finally:
+            lib.mode_set_option(b"fuse_swiglu_bwd", 1)
+        grads[flag] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    assert grads[0].keys() == grads[1].keys()
+    worst = max((rel(grads[1][n], grads[0][n]), n) for n in grads[0] if float(grads[0][n].norm()) > 0)
+    print("fused vs two kernels, worst tensor:", worst)
+    assert worst[0] < 1e-2
+    b1 = [n for n in grads[0] if "experts" in n and n.endswith("bias")]
+    assert b1 and all(rel(grads[1][n], grads[0][n]) < 5e-3 for n in b1)
