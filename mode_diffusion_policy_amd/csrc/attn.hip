@@ -90,7 +90,7 @@ template <typename T2>
 __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__ qkv, const float* __restrict__ qg, const float* __restrict__ kg,
                                                        const T2* __restrict__ dY, T2* __restrict__ dqkv, float* __restrict__ dgq_part,
                                                        float* __restrict__ dgk_part, int B, int T, int H, int HD, float eps, uint32_t seed,
-                                                       uint32_t thresh, float inv_keep) {
+                                                       uint32_t thresh, float inv_keep, float* __restrict__ dbias_part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HP = HD + 1;                               // padded row (bank-conflict-free column walks)
   // v / dO (and dV, which replaces v) are kept in the INPUT dtype: for bf16 that is exact (the inputs are bf16, dV is rounded to bf16 on
@@ -306,6 +306,20 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
     }
     return u;
   };
+  if (dbias_part) {
+    // bias gradient of the packed QKV projection = column sums of dqkv: this sample's share [3 D] (summed over its T tokens, from the values AS STORED - bf16-
+    // rounded on the bf16 path, like the separate column sum over dqkv did); the caller adds the B rows with one small column sum instead of re-reading dqkv
+    for (int c = tid; c < 3 * HD; c += 256) {
+      const int which = c / HD, d = c - which * HD;
+      float sacc = 0.f;
+      for (int t = 0; t < T; ++t) {
+        float v = which == 0 ? sqh[t * HP + d] : which == 1 ? skh[t * HP + d] : tvf(sv[t * HV + d]);
+        if constexpr (sizeof(T2) == 2) v = bf16_bits_to_f32(f32_to_bf16_bits(v));
+        sacc += v;
+      }
+      dbias_part[(long)b * 3 * D + (long)which * D + h * HD + d] = sacc;
+    }
+  }
   for (int i = tid; i < T * cpr; i += 256) {            // 16-byte stores of dq | dk | dv
     const int t = i / cpr, d = (i % cpr) * VE;
     T2* o = dqkv + ((long)b * T + t) * ld + h * HD + d;
@@ -349,9 +363,11 @@ extern "C" int mode_attn_block_fwd(const void* qkv, const float* q_gain, const f
   return MODE_OK;
 }
 
-extern "C" int mode_attn_block_bwd(const void* qkv, const float* q_gain, const float* k_gain, const void* dy, void* dqkv, float* dgq_partial,
-                                   float* dgk_partial, int dtype, int B, int T, int H, int head_dim, float eps, uint32_t seed, float p_drop,
-                                   void* stream) {
+namespace mode {
+// dbias_partial (optional): [B][3 D] fp32, row b = sample b's share of the packed QKV bias gradient (dit_train.hip adds the rows)
+int attn_block_bwd_launch(const void* qkv, const float* q_gain, const float* k_gain, const void* dy, void* dqkv, float* dgq_partial,
+                          float* dgk_partial, int dtype, int B, int T, int H, int head_dim, float eps, uint32_t seed, float p_drop, float* dbias_partial,
+                          void* stream) {
   if (!qkv || !q_gain || !k_gain || !dy || !dqkv || !dgq_partial || !dgk_partial || B < 0 || T <= 0 || H <= 0) return MODE_ERR_BAD_ARG;
   if (p_drop < 0.f || p_drop >= 1.f) return MODE_ERR_BAD_ARG;
   if (B == 0) return MODE_OK;
@@ -362,10 +378,17 @@ extern "C" int mode_attn_block_bwd(const void* qkv, const float* q_gain, const f
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MODE_BF16)
     hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, dim3(B * H), dim3(256), lds, s, (const uint16_t*)qkv, q_gain, k_gain, (const uint16_t*)dy, (uint16_t*)dqkv,
-                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik);
+                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik, dbias_partial);
   else
     hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B * H), dim3(256), lds, s, (const float*)qkv, q_gain, k_gain, (const float*)dy, (float*)dqkv,
-                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik);
+                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik, dbias_partial);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
+}
+}  // namespace mode
+
+extern "C" int mode_attn_block_bwd(const void* qkv, const float* q_gain, const float* k_gain, const void* dy, void* dqkv, float* dgq_partial,
+                                   float* dgk_partial, int dtype, int B, int T, int H, int head_dim, float eps, uint32_t seed, float p_drop,
+                                   void* stream) {
+  return mode::attn_block_bwd_launch(qkv, q_gain, k_gain, dy, dqkv, dgq_partial, dgk_partial, dtype, B, T, H, head_dim, eps, seed, p_drop, nullptr, stream);
 }

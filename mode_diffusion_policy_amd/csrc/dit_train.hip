@@ -15,9 +15,11 @@ namespace mode {
 int rmsnorm_bwd_launch(const float* x, const float* g, const float* dy_a, const float* dy_b, const float* G, int g_splits, long g_split_stride,
                        const int32_t* pos, int k, int rows, int D, float eps, float* dx, int accumulate, float* dg_partial, float* dy_out, void* dx_lp,
                        int lp_dtype, hipStream_t stream);   // train_ops.hip
-int gemm_bf16_tr_swiglu_bwd_launch(const ModeGemmDesc* d, const void* P, void* dP, uint32_t seed, uint32_t thresh, float inv_keep, float* bsum, hipStream_t s);   // gemm_bf16_tr.hip
-int tr_tile_offsets_launch(const int* offsets, int E, int* out, hipStream_t s);          // gemm_bf16_tr.hip
+int gemm_bf16_tr_swiglu_bwd_launch(const ModeGemmDesc* d, const void* P, void* dP, uint32_t seed, uint32_t thresh, float inv_keep, float* bsum, int* tile_offs,
+                                   hipStream_t s);                                       // gemm_bf16_tr.hip
 extern int g_fuse_swiglu_bwd;                                                            // "fuse_swiglu_bwd" option (dit.hip)
+int attn_block_bwd_launch(const void* qkv, const float* q_gain, const float* k_gain, const void* dy, void* dqkv, float* dgq_partial, float* dgk_partial, int dtype, int B,
+                          int T, int H, int head_dim, float eps, uint32_t seed, float p_drop, float* dbias_partial, void* stream);   // attn.hip
 bool gemm_bf16_pptr_accepts(const ModeGemmDesc* d);                                      // gemm_bf16_pptr.hip: would mode_gemm take the ping-pong kernel?
 int gather_rows_bf16(const void* in, long ld_in, const int* rows, int n, int cols, void* out, long ld_out, hipStream_t s);   // gemm_bf16_pptr.hip
 }
@@ -338,8 +340,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       g.w_expert_stride = 4L * D * D; g.expert_offsets = offsets; g.num_experts = E; g.flags = MODE_GEMM_W_KN;
       const float pd = a->mlp_pdrop;
       const uint32_t th = pd <= 0.f ? 0u : (uint32_t)((double)pd * 4294967296.0);
-      if ((rc = mode::tr_tile_offsets_launch(offsets, E, toff, hs))) return rc;
-      if ((rc = mode::gemm_bf16_tr_swiglu_bwd_launch(&g, S + sl.P, dP, mode_stream_seed(a->seed, 2 * l + 1), th, 1.0f / (1.0f - pd), bsum, hs))) return rc;
+      if ((rc = mode::gemm_bf16_tr_swiglu_bwd_launch(&g, S + sl.P, dP, mode_stream_seed(a->seed, 2 * l + 1), th, 1.0f / (1.0f - pd), bsum, toff, hs))) return rc;
       if ((rc = mode_colsum(bsum, 8L * D, NK / 128 + E, 8 * D, MODE_F32, toff, 0, E, lg.b1, 0, (char*)csw + bsum_bytes + 4096, cswb - bsum_bytes - 4096, stream))) return rc;
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, 4 * D, NK, dYs, D, S + sl.Hd, 4 * D, lg.w2, 4 * D);
       g.k_group_offsets = offsets; g.num_k_groups = E; g.c_group_stride = 4L * D * D; g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
@@ -427,7 +428,10 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       if ((rc = mode_gemm(&g, stream))) return rc;
     }
     // (7) attention backward
-    if ((rc = mode_attn_block_bwd(S + sl.qkv, lw.qn_g, lw.kn_g, dyattn, dqkv, apq_l, apk_l, dt, B, T, d.H, hd, d.eps, mode_stream_seed(a->seed, 2 * l), a->attn_pdrop, stream)))
+    // (bf16: the kernel also emits each sample's share of the QKV bias gradient - the [B, 3D] partial lives in the transpose scratch this path does not use)
+    float* dbq_part = tr ? (float*)Tbig : nullptr;
+    if ((rc = mode::attn_block_bwd_launch(S + sl.qkv, lw.qn_g, lw.kn_g, dyattn, dqkv, apq_l, apk_l, dt, B, T, d.H, hd, d.eps, mode_stream_seed(a->seed, 2 * l), a->attn_pdrop,
+                                          dbq_part, stream)))
       return rc;
     // (8) QKV projection: dh1 = dqkv Wqkv ; dWqkv = dqkv^T h1 ; db = colsum(dqkv)
     if (tr) {
@@ -446,7 +450,8 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 3 * D, D, Ktok, Tbig, Np, Td, Np, lg.wqkv, D);
       if ((rc = mode_gemm(&g, stream))) return rc;
     }
-    if ((rc = colsum(dqkv, 3 * D, N, 3 * D, dt, nullptr, 0, 1, lg.bqkv, 0))) return rc;
+    if (dbq_part) { if ((rc = colsum(dbq_part, 3 * D, B, 3 * D, MODE_F32, nullptr, 0, 1, lg.bqkv, 0))) return rc; }
+    else if ((rc = colsum(dqkv, 3 * D, N, 3 * D, dt, nullptr, 0, 1, lg.bqkv, 0))) return rc;
     // (9) ln_1 (+c) backward: d x0 = d x1 (residual) + RMSNorm'(dh1); dc_b += sum_t dh1[b,t]
     if ((rc = mode_rmsnorm_bwd((const float*)(S + sl.x0), lw.ln1_g, dh1, nullptr, nullptr, nullptr, 0, N, D, d.eps, DXb, 1, dgp1, nullptr, nullptr, MODE_F32,
                                stream))) return rc;

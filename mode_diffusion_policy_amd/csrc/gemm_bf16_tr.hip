@@ -38,6 +38,7 @@ struct TrParams {
   const uint16_t* P; uint16_t* dP;        // pre-activations / their gradients [M, 2 N] (value | gate)
   uint32_t seed, thresh; float inv_keep;  // expert-dropout stream of this layer
   float* bsum;                            // [m-tile][2 N] column sums of the bf16-rounded dP over the tile's rows (a tile lies inside one expert's segment)
+  int* tile_offs;                         // [E + 1] out: first m-tile of every expert (written by workgroup 0: the segment table of the bias-gradient column sum)
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -96,6 +97,13 @@ __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const T
   const int rem = sb - grp * per_group;
   const int mt = first_m + rem % gsz, nt = rem / gsz;
 
+  if constexpr (EPI == 1) {
+    if (blockIdx.x == 0 && tid == 0 && p.tile_offs) {
+      int t = 0;
+      p.tile_offs[0] = 0;
+      for (int e = 0; e < p.E; ++e) { t += (p.offsets[e + 1] - p.offsets[e] + BM - 1) / BM; p.tile_offs[e + 1] = t; }
+    }
+  }
   int row0 = 0, row_end = 0, expert = 0;
   if (!A_KM && p.offsets) {
     int t = mt;
@@ -420,7 +428,8 @@ static int tr_launch(TrParams p, const ModeGemmDesc* d, hipStream_t s) {
 // The down-projection's data gradient fused with the SwishGLU backward (dit_train.hip): dP[M, 2N] and per-m-tile bias-gradient partial sums from
 // dY[M, K], W2 (grouped by expert), the stashed pre-activations P.  dH itself is never written.  128 x 128 ring tile (two workgroups per CU: one's
 // epilogue - 128 KiB of P / dP traffic per tile - runs under the other's K loop).  m-tile t of the grouped tile space = row t of `bsum`.
-int gemm_bf16_tr_swiglu_bwd_launch(const ModeGemmDesc* d, const void* P, void* dP, uint32_t seed, uint32_t thresh, float inv_keep, float* bsum, hipStream_t s) {
+int gemm_bf16_tr_swiglu_bwd_launch(const ModeGemmDesc* d, const void* P, void* dP, uint32_t seed, uint32_t thresh, float inv_keep, float* bsum, int* tile_offs,
+                                   hipStream_t s) {
   if (!(d->flags & MODE_GEMM_W_KN) || (d->flags & MODE_GEMM_A_KM) || d->dtype != MODE_BF16 || d->epilogue != MODE_EPI_NONE || d->a_rows || d->w_rows) return MODE_ERR_UNSUPPORTED;
   if (d->N % 128 || d->K % 64 || d->K <= 0 || d->split_k > 1 || d->k_group_offsets || d->lda % 8 || d->ldw % 8 || !P || !dP || !bsum) return MODE_ERR_UNSUPPORTED;
   if ((((uintptr_t)P | (uintptr_t)dP | (uintptr_t)bsum) & 15)) return MODE_ERR_UNSUPPORTED;
@@ -430,22 +439,9 @@ int gemm_bf16_tr_swiglu_bwd_launch(const ModeGemmDesc* d, const void* P, void* d
   p.C = nullptr; p.ldc = 0; p.offsets = d->expert_offsets; p.E = d->num_experts;
   p.koffs = nullptr; p.c_gstride = 0; p.w_rows = nullptr; p.tap_cols = 0; p.tap_stride = 0;
   p.M = d->M; p.N = d->N; p.K = d->K; p.split_k = 1; p.split_stride = 0; p.m_tiles = p.n_tiles = 0;
-  p.P = (const uint16_t*)P; p.dP = (uint16_t*)dP; p.seed = seed; p.thresh = thresh; p.inv_keep = inv_keep; p.bsum = bsum;
+  p.P = (const uint16_t*)P; p.dP = (uint16_t*)dP; p.seed = seed; p.thresh = thresh; p.inv_keep = inv_keep; p.bsum = bsum; p.tile_offs = tile_offs;
+  if (!d->expert_offsets) return MODE_ERR_UNSUPPORTED;
   return tr_launch<false, true, 128, 2, 1>(p, d, s);
-}
-
-// m-tile offsets of the grouped tile space (128-row tiles): out[e] = first m-tile of expert e, out[E] = number of real m-tiles
-__global__ void tr_tile_offsets_kernel(const int* __restrict__ offsets, int E, int* __restrict__ out) {
-  if (threadIdx.x == 0) {
-    int t = 0;
-    out[0] = 0;
-    for (int e = 0; e < E; ++e) { t += (offsets[e + 1] - offsets[e] + 127) / 128; out[e + 1] = t; }
-  }
-}
-int tr_tile_offsets_launch(const int* offsets, int E, int* out, hipStream_t s) {
-  hipLaunchKernelGGL(tr_tile_offsets_kernel, dim3(1), dim3(64), 0, s, offsets, E, out);
-  MODE_LAUNCH_CHECK();
-  return MODE_OK;
 }
 
 int g_tr_cfg = 0;   // "gemm_tr_cfg" option: 0 auto, 1 = 128-wide NS2, 2 = 64-wide NS3, 3 = 128-wide NS3, 4 = 64-wide NS2, 5 = 128-wide NS1,
@@ -485,7 +481,7 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.split_k = split; p.split_stride = d->split_stride;
   p.m_tiles = p.n_tiles = 0;
-  p.P = nullptr; p.dP = nullptr; p.seed = p.thresh = 0; p.inv_keep = 1.f; p.bsum = nullptr;
+  p.P = nullptr; p.dP = nullptr; p.seed = p.thresh = 0; p.inv_keep = 1.f; p.bsum = nullptr; p.tile_offs = nullptr;
   // geometry: enough 128x128 workgroups to put two on every CU -> NS2 ring (they hide each other's fill latency); otherwise 128x64
   // tiles (twice the workgroups) with a 3-slot ring so one workgroup keeps two tiles in flight
   const long groups = (a_km && d->k_group_offsets) ? d->num_k_groups : 1;
