@@ -182,6 +182,7 @@ int mode_gemm(const ModeGemmDesc* desc, void* stream);
  *   idx            int32 [taps][M] (tap stride idx_tap_stride): input row that tap t pairs with output row m, -1 = outside the image; NULL = 1 x 1 / stride 1
  *   y = post(relu(pre(acc * scale + shift) + residual)),  scale = bn_weight / sqrt(bn_var + bn_eps), shift = bn_bias - bn_mean * scale (bn_mean NULL: 1, 0),
  *   pre: gamma * v + beta, post: (1 + gamma) * v + beta with gamma / beta fp32 [samples][Cout], sample = m / rows_per_sample.  Cin % 64 == 0, Cout % 8 == 0.
+ * With every epilogue term absent it is the plain convolution; the training forward uses it that way with stat_sum / stat_sq.
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct ModeConvBnDesc {
   const void* x; int64_t ldx;
@@ -193,6 +194,8 @@ typedef struct ModeConvBnDesc {
   const void* residual; int64_t ldr;
   int32_t relu;
   const float* pre_gamma; const float* pre_beta; const float* post_gamma; const float* post_beta; int32_t rows_per_sample;
+  float* stat_sum; float* stat_sq;   /* optional, TRAINING forward (no epilogue terms): fp32 [ceil(M / 128)][Cout] column sums / sums of squares of y as stored, one row
+                                        per 128-row tile - the partial statistics mode_bn_prepare_partials folds for the BatchNorm that follows (one pass over y less) */
 } ModeConvBnDesc;
 int mode_conv_bn_act_fwd(const ModeConvBnDesc* desc, void* stream);
 
@@ -680,6 +683,11 @@ int mode_bn_stats(const void* x, int dtype, int N, int C, int HW, int channels_l
 int mode_bn_prepare(const void* x, int dtype, int N, int C, int HW, int channels_last, const float* weight, const float* bias, float eps, float momentum,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* var, float* invstd, float* scale,
                     float* shift, void* workspace, size_t workspace_bytes, void* stream);
+/* (ABI 10) The same fold + bookkeeping from PARTIAL sums [rows][C] (sum and sum of squares per row block) that the producing convolution wrote in its epilogue
+ * (ModeConvBnDesc.stat_sum / stat_sq): no pass over the activation.  count = elements per channel (N * HW). */
+int mode_bn_prepare_partials(const float* psum, const float* psq, int rows, double count, int C, const float* weight, const float* bias, float eps, float momentum,
+                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* var, float* invstd, float* scale,
+                             float* shift, void* stream);
 /* Backward of the fused chain.  mean / invstd [C]: the statistics scale / shift were folded from (scale = weight * invstd).  training != 0:
  * gradient through the batch statistics; 0: dx = d * scale.  Outputs: dx, dresidual (iff d->residual), dweight / dbias [C] (BatchNorm affine),
  * d_pre_* / d_post_* [N, C] (iff the corresponding FiLM is present).

@@ -127,7 +127,7 @@ class ModeConvBnDesc(C.Structure):
     _fields_ = [("x", c_vp), ("ldx", c_i64), ("idx", c_vp), ("idx_tap_stride", c_i64), ("taps", c_i32), ("w", c_vp), ("ldw", c_i64), ("y", c_vp), ("ldy", c_i64),
                 ("M", c_i32), ("Cin", c_i32), ("Cout", c_i32), ("bn_mean", c_vp), ("bn_var", c_vp), ("bn_weight", c_vp), ("bn_bias", c_vp), ("bn_eps", c_f32),
                 ("residual", c_vp), ("ldr", c_i64), ("relu", c_i32), ("pre_gamma", c_vp), ("pre_beta", c_vp), ("post_gamma", c_vp), ("post_beta", c_vp),
-                ("rows_per_sample", c_i32)]
+                ("rows_per_sample", c_i32), ("stat_sum", c_vp), ("stat_sq", c_vp)]
 
 
 class ModeBnFilmDesc(C.Structure):
@@ -211,6 +211,7 @@ PROTOTYPES = {
     "mode_bn_stats": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mode_bn_prepare": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, C.c_float, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
                                   c_vp]),
+    "mode_bn_prepare_partials": (C.c_int, [c_vp, c_vp, c_i32, C.c_double, c_i32, c_vp, c_vp, C.c_float, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mode_bn_film_act_bwd": (C.c_int, [P(ModeBnFilmDesc), c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
 }
 

@@ -31,6 +31,8 @@ struct ConvGemmParams {
   const float* bn_mean; const float* bn_var; const float* bn_w; const float* bn_b; float bn_eps;
   const uint16_t* res; long ldr; int relu;
   const float* pre_g; const float* pre_b; const float* post_g; const float* post_b; int rows_per_sample;
+  // training forward: per-m-tile column sums / sums of squares of the output AS STORED (bf16-rounded) - the partial statistics of the BatchNorm that follows
+  float* stat_sum; float* stat_sq;         // [m_tiles][N]
 };
 
 namespace cg {
@@ -318,12 +320,49 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_gemm_kernel(const C
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+  const bool stats = p.stat_sum != nullptr;
   for (int c = tid; c < BM * CPR; c += 256) {
-    const int rl = c / CPR, ch = c % CPR;
+    const int rl = c / CPR, ch = c % CPR;                              // ch = tid % CPR for every pass: a thread walks rows of ONE 8-column chunk
     const int n = n0 + ch * 8;
     if (rl >= rows_valid || n >= p.N) continue;
     const uint4 v = *reinterpret_cast<const uint4*>(smem + rl * CROW + ((ch ^ (rl & CSWZ)) << 4));
     *reinterpret_cast<uint4*>(p.C + (long)(row0 + rl) * p.ldc + n) = v;
+    if (stats) {
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = bf16_bits_to_f32(w[j] & 0xffff), b = bf16_bits_to_f32(w[j] >> 16);
+        ssum[2 * j] += a; ssum[2 * j + 1] += b;
+        ssq[2 * j] = __builtin_fmaf(a, a, ssq[2 * j]); ssq[2 * j + 1] = __builtin_fmaf(b, b, ssq[2 * j + 1]);
+      }
+    }
+  }
+  if (stats) {                                                         // (uniform) the chunk's partners: lanes CPR apart in the wave, then the four waves through LDS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if constexpr (CPR == 8) { ssum[j] += __shfl_xor(ssum[j], 8, 64); ssq[j] += __shfl_xor(ssq[j], 8, 64); }
+      ssum[j] += __shfl_xor(ssum[j], 16, 64); ssum[j] += __shfl_xor(ssum[j], 32, 64);
+      ssq[j] += __shfl_xor(ssq[j], 16, 64); ssq[j] += __shfl_xor(ssq[j], 32, 64);
+    }
+    __syncthreads();                                                   // the output tile has been read by everyone
+    float* red = reinterpret_cast<float*>(smem);                        // [4 waves][CPR][16]
+    if (lane < CPR) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { red[(wave * CPR + lane) * 16 + j] = ssum[j]; red[(wave * CPR + lane) * 16 + 8 + j] = ssq[j]; }
+    }
+    __syncthreads();
+    if (tid < CPR && n0 + tid * 8 < p.N) {
+      float* o1 = p.stat_sum + (long)mt * p.N + n0 + tid * 8;
+      float* o2 = p.stat_sq + (long)mt * p.N + n0 + tid * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o1[j] = ((red[(0 * CPR + tid) * 16 + j] + red[(1 * CPR + tid) * 16 + j]) + red[(2 * CPR + tid) * 16 + j]) + red[(3 * CPR + tid) * 16 + j];
+        o2[j] = ((red[(0 * CPR + tid) * 16 + 8 + j] + red[(1 * CPR + tid) * 16 + 8 + j]) + red[(2 * CPR + tid) * 16 + 8 + j]) + red[(3 * CPR + tid) * 16 + 8 + j];
+      }
+    }
   }
 }
 
@@ -367,7 +406,7 @@ int gemm_bf16_conv_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.W = (const uint16_t*)d->W; p.ldw = d->ldw; p.C = (uint16_t*)d->C; p.ldc = d->ldc;
   p.M = d->M; p.N = d->N; p.tap_k = d->a_tap_cols; p.taps = d->K / d->a_tap_cols; p.m_tiles = p.n_tiles = 0;
   p.bn_mean = p.bn_var = p.bn_w = p.bn_b = nullptr; p.bn_eps = 0.f; p.res = nullptr; p.ldr = 0; p.relu = 0;
-  p.pre_g = p.pre_b = p.post_g = p.post_b = nullptr; p.rows_per_sample = 1;
+  p.pre_g = p.pre_b = p.post_g = p.post_b = nullptr; p.rows_per_sample = 1; p.stat_sum = p.stat_sq = nullptr;
   const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
   const bool wide = d->N % 128 == 0 && t128 >= 384;              // enough 128-wide tiles for ~1.5 workgroups per CU; otherwise twice the workgroups
   if (w_kn) return wide ? conv_launch<true, 128>(p, s) : conv_launch<true, 64>(p, s);
@@ -396,6 +435,8 @@ extern "C" int mode_conv_bn_act_fwd(const ModeConvBnDesc* d, void* stream) {
   p.bn_mean = d->bn_mean; p.bn_var = d->bn_var; p.bn_w = d->bn_weight; p.bn_b = d->bn_bias; p.bn_eps = d->bn_eps;
   p.res = (const uint16_t*)d->residual; p.ldr = d->ldr; p.relu = d->relu;
   p.pre_g = d->pre_gamma; p.pre_b = d->pre_beta; p.post_g = d->post_gamma; p.post_b = d->post_beta; p.rows_per_sample = d->rows_per_sample > 0 ? d->rows_per_sample : 1;
+  if ((d->stat_sum != nullptr) != (d->stat_sq != nullptr) || (((uintptr_t)d->stat_sum | (uintptr_t)d->stat_sq) & 15)) return MODE_ERR_BAD_ARG;
+  p.stat_sum = d->stat_sum; p.stat_sq = d->stat_sq;
   const long t128 = (long)((d->M + 127) / 128) * ((d->Cout + 127) / 128);
   const bool wide = d->Cout % 128 == 0 && t128 >= 384;
   return wide ? conv_launch<false, 128, true>(p, (hipStream_t)stream) : conv_launch<false, 64, true>(p, (hipStream_t)stream);

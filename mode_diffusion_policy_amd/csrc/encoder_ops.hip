@@ -658,6 +658,24 @@ extern "C" int mode_bn_prepare(const void* x, int dtype, int N, int C, int HW, i
   return MODE_OK;
 }
 
+// Training statistics from partial sums somebody else produced (the convolution kernel's epilogue, mode_conv_bn_act_fwd: one row per 128-row output tile):
+// the per-channel fold + bookkeeping of mode_bn_prepare without its pass over the activation.
+extern "C" int mode_bn_prepare_partials(const float* psum, const float* psq, int rows, double count, int C, const float* weight, const float* bias, float eps,
+                                        float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* var, float* invstd,
+                                        float* scale, float* shift, void* stream) {
+  if (!psum || !psq || !mean || !var || !invstd || !scale || !shift || rows <= 0 || C <= 0 || count <= 0.0) return MODE_ERR_BAD_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return MODE_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_prepare_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, psum, psq, rows, C, count, 1, weight, bias, eps, momentum, running_mean, running_var,
+                     (long long*)num_batches_tracked, mean, var, invstd, scale, shift);
+  MODE_LAUNCH_CHECK();
+  if (num_batches_tracked && momentum < 0.f) {
+    hipLaunchKernelGGL(bn_count_step_kernel, dim3(1), dim3(1), 0, s, (long long*)num_batches_tracked);
+    MODE_LAUNCH_CHECK();
+  }
+  return MODE_OK;
+}
+
 extern "C" int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, const float* mean, const float* invstd, int training, int phase, float inv_count,
                                     void* dx, void* dresidual, float* dweight, float* dbias, float* d_pre_gamma, float* d_pre_beta, float* d_post_gamma,
                                     float* d_post_beta, void* workspace, size_t workspace_bytes, void* stream) {

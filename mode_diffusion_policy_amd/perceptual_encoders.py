@@ -66,7 +66,9 @@ class _BnFilmAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b, sync_group=None,
-                num_batches_tracked=None, grad_enabled=True):
+                num_batches_tracked=None, grad_enabled=True, stat_sum=None, stat_sq=None):
+        # ``stat_sum`` / ``stat_sq``: [row blocks, C] partial sums of x that the producing convolution wrote in its epilogue (conv_bn_act): the training
+        # statistics are folded from them instead of from another pass over x
         # ``grad_enabled``: torch.is_grad_enabled() at the CALL site (inside Function.forward it is always False, and ctx.needs_input_grad reflects the
         # inputs' requires_grad even under torch.no_grad()): under no_grad nothing will be back-propagated, whatever the parameters say
         wants_grad = grad_enabled and any(ctx.needs_input_grad)
@@ -103,10 +105,17 @@ class _BnFilmAct(torch.autograd.Function):
             # pair of ResNet-50s
             st = torch.empty(5, Cc, device=dev)
             mean, var, invstd, scale, shift = st[0], st[1], st[2], st[3], st[4]
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if training else None
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if (training and stat_sum is None) else None
             nbt = num_batches_tracked if (training and num_batches_tracked is not None and num_batches_tracked.dtype == torch.int64
                                           and num_batches_tracked.device == dev) else None
-            with torch.no_grad():
+            if training and stat_sum is not None:
+                with torch.no_grad():
+                    L.check(lib.mode_bn_prepare_partials(stat_sum.data_ptr(), stat_sq.data_ptr(), stat_sum.shape[0], float(m), Cc, _ptr(w), _ptr(b), float(eps),
+                                                         -1.0 if momentum is None else float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                                         mean.data_ptr(), var.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream()),
+                            "bn_prepare_partials")
+            else:
+              with torch.no_grad():
                 L.check(lib.mode_bn_prepare(x.data_ptr() if training else None, _dt(x), N, Cc, HW, int(cl), _ptr(w), _ptr(b), float(eps),
                                             -1.0 if momentum is None else float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(nbt), mean.data_ptr(),
                                             var.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _ptr(ws), 0 if ws is None else ws.numel(),
@@ -190,7 +199,7 @@ class _BnFilmAct(torch.autograd.Function):
         ps, qs = ctx.shapes
         rs = lambda t, shp: None if t is None else t.reshape(shp)
         # inputs: x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b
-        return dx, dw, db, None, None, None, None, None, None, dres, rs(dpg, ps), rs(dpb, ps), rs(dqg, qs), rs(dqb, qs), None, None, None
+        return dx, dw, db, None, None, None, None, None, None, dres, rs(dpg, ps), rs(dpb, ps), rs(dqg, qs), rs(dqb, qs), None, None, None, None, None
 
 
 # Activation layout inside the encoders.  True: torch.channels_last - MIOpen's implicit-GEMM convolutions run on NHWC data and wrap NCHW tensors in
@@ -348,6 +357,24 @@ def _conv_dgrad_taps(dy: torch.Tensor, w_lp: torch.Tensor, xshape, stride, paddi
     return dx
 
 
+def _conv_fwd_stats(x: torch.Tensor, w_lp: torch.Tensor, stride, padding):
+    """Training forward of a convolution that feeds a BatchNorm: y and, from the same launch's epilogue, the per-128-row-tile column sums / sums of squares of y as
+    stored (mode_conv_bn_act_fwd without epilogue terms + stat_sum / stat_sq) - the BatchNorm folds its batch statistics from them instead of re-reading y."""
+    n, cin, H, W_ = x.shape
+    cout, _, kh_, kw_ = w_lp.shape
+    sh, sw = stride; ph, pw = padding
+    ho = (H + 2 * ph - kh_) // sh + 1; wo = (W_ + 2 * pw - kw_) // sw + 1
+    one = kh_ == 1 and kw_ == 1 and (sh, sw) == (1, 1) and (ph, pw) == (0, 0)
+    idx = None if one else _tap_table(n, H, W_, ho, wo, kh_, kw_, sh, sw, ph, pw, x.device)
+    R = n * ho * wo
+    y = torch.empty((n, cout, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    st = torch.empty((2, (R + 127) // 128, cout), dtype=torch.float32, device=x.device)
+    d = L.ModeConvBnDesc(x=x.data_ptr(), ldx=cin, idx=_ptr(idx), idx_tap_stride=R, taps=kh_ * kw_, w=w_lp.data_ptr(), ldw=kh_ * kw_ * cin, y=y.data_ptr(), ldy=cout,
+                         M=R, Cin=cin, Cout=cout, relu=0, rows_per_sample=ho * wo, stat_sum=st[0].data_ptr(), stat_sq=st[1].data_ptr())
+    L.check(L.load().mode_conv_bn_act_fwd(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv forward + BatchNorm partial statistics")
+    return y, st[0], st[1]
+
+
 def _wgrad_taps(dy: torch.Tensor, x: torch.Tensor, wshape, stride, padding) -> torch.Tensor:
     """dW of a k x k convolution (any stride, zero padding) from channels_last bf16 activations as k*k weight-gradient GEMMs, one per filter tap:
     dW[:, :, kh, kw] = dY[R_out, Cout]^T X[rows(kh, kw), Cin] - the input rows that tap (kh, kw) pairs with the output pixels (a zero row where the tap falls
@@ -390,9 +417,13 @@ class _ConvFn(torch.autograd.Function):
     """y = conv2d(x, w) computed with `w_lp` (w in the compute dtype); differentiable in x and in the fp32 PARAMETER w."""
 
     @staticmethod
-    def forward(ctx, x, w, w_lp, stride, padding):
+    def forward(ctx, x, w, w_lp, stride, padding, want_stats=False):
         ctx.save_for_backward(x, w_lp)
         ctx.conf = (tuple(stride), tuple(padding), tuple(w.shape), w.dtype)
+        if want_stats:                                            # (the caller checked the kernel's contract) y + the partial BatchNorm statistics of y
+            y, ps, pq = _conv_fwd_stats(x, w_lp, stride, padding)
+            ctx.mark_non_differentiable(ps, pq)
+            return y, ps, pq
         if x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
             if _is_1x1(w.shape, stride, padding):
                 return _gemm_1x1_fwd(x, w_lp)
@@ -401,7 +432,7 @@ class _ConvFn(torch.autograd.Function):
         return F.conv2d(x, w_lp, None, stride, padding)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         x, w_lp = ctx.saved_tensors
         stride, padding, wshape, wdtype = ctx.conf
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -428,7 +459,7 @@ class _ConvFn(torch.autograd.Function):
                 dx = dxl
             if need_w:
                 dw = dwl.to(wdtype)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def _shadow(conv: nn.Conv2d, dtype: torch.dtype) -> torch.Tensor:
@@ -495,7 +526,7 @@ def _conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     return F.conv2d(x, w.to(x.dtype), None, conv.stride, conv.padding)
 
 
-def bn_film_act(x, bn: nn.BatchNorm2d, relu: bool = True, residual=None, pre_film=None, post_film=None):
+def bn_film_act(x, bn: nn.BatchNorm2d, relu: bool = True, residual=None, pre_film=None, post_film=None, stats=None):
     """``post_film(relu(pre_film(bn(x)) + residual))``; ``pre_film`` / ``post_film`` = (gamma, beta), each (N, C) (or broadcastable views of it)."""
     pg, pb = pre_film if pre_film is not None else (None, None)
     qg, qb = post_film if post_film is not None else (None, None)
@@ -506,12 +537,17 @@ def bn_film_act(x, bn: nn.BatchNorm2d, relu: bool = True, residual=None, pre_fil
             sync = bn.process_group if bn.process_group is not None else True
     training = bn.training or bn.running_mean is None                       # no running statistics -> batch statistics also in eval (nn.BatchNorm2d)
     return _BnFilmAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, relu, residual, pg, pb, qg, qb, sync,
-                            bn.num_batches_tracked if bn.training else None, torch.is_grad_enabled())
+                            bn.num_batches_tracked if bn.training else None, torch.is_grad_enabled(), *((stats[0], stats[1]) if (stats is not None and sync is None) else (None, None)))
 
 
 # Inference: convolution + eval-mode BatchNorm + FiLM + residual + ReLU as ONE launch (mode_conv_bn_act_fwd, csrc/conv_gemm.hip) - the rollout's encoders run
 # half the kernels and the convolution output never goes to memory un-normalised.  MODE_ENC_FUSE_CONV_BN=0: the two launches (A/B runs, tests).
 FUSE_CONV_BN = __import__("os").environ.get("MODE_ENC_FUSE_CONV_BN", "1") == "1"
+# training: BatchNorm partial statistics from the convolution's epilogue (ModeConvBnDesc.stat_sum / stat_sq + mode_bn_prepare_partials).  OFF by default: measured in
+# the agent's step it does not pay - 33.2-33.4 (k x k convolutions only) / 33.9-34.2 ms (all) against 33.1 without: the sums in the epilogue of a latency-bound ring
+# kernel cost what the separate, HBM-efficient statistics pass costs, and 1 x 1 convolutions would leave their tuned GEMM kernels for it.
+FUSE_CONV_STATS = __import__("os").environ.get("MODE_ENC_FUSE_CONV_STATS", "0") == "1"
+FUSE_CONV_STATS_1X1 = __import__("os").environ.get("MODE_ENC_FUSE_CONV_STATS_1X1", "0") == "1"   # ... also for 1 x 1 / stride-1 convolutions (they leave the tuned GEMM kernels for it)
 
 
 def _film_arg(t, n: int, c: int):
@@ -555,6 +591,18 @@ def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, relu: bool = True, resid
                                  rows_per_sample=ho * wo)
             L.check(L.load().mode_conv_bn_act_fwd(C.byref(d), torch.cuda.current_stream().cuda_stream), "mode_conv_bn_act_fwd")
             return y
+    if (FUSE_CONV_STATS and USE_HIP_CONV_WGRAD and x.is_cuda and cd == torch.bfloat16 and torch.is_grad_enabled() and bn.training and not isinstance(bn, nn.SyncBatchNorm)
+            and (w.requires_grad or x.requires_grad) and conv.groups == 1 and conv.dilation == (1, 1) and conv.bias is None and isinstance(conv.padding, tuple)
+            and w.shape[1] % 64 == 0 and w.shape[0] % 8 == 0 and (FUSE_CONV_STATS_1X1 or not _is_1x1(w.shape, conv.stride, conv.padding))):
+        # training: the convolution's epilogue also writes the partial batch statistics of its output (one pass over y less per BatchNorm)
+        if CHANNELS_LAST and not w.is_contiguous(memory_format=torch.channels_last):
+            with torch.no_grad():
+                w.data = w.data.contiguous(memory_format=torch.channels_last)
+        xc = x.to(cd)
+        w_lp = _shadow(conv, cd)
+        if xc.is_contiguous(memory_format=torch.channels_last) and w_lp.is_contiguous(memory_format=torch.channels_last):
+            y, ps, pq = _ConvFn.apply(xc, w, w_lp, conv.stride, conv.padding, True)
+            return bn_film_act(y, bn, relu=relu, residual=residual, pre_film=pre_film, post_film=post_film, stats=(ps, pq))
     return bn_film_act(_conv2d(conv, x), bn, relu=relu, residual=residual, pre_film=pre_film, post_film=post_film)
 
 

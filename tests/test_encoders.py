@@ -513,3 +513,36 @@ def test_conv_fn_random_geometries(case):
     with torch.no_grad():                                                       # the inference path takes the same forward kernel
         y2 = E._conv2d(conv, x.detach())
     assert torch.equal(y2, y.detach()), tag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,stride,cin,cout,H", [(1, 1, 64, 256, 28), (3, 1, 128, 128, 17), (3, 2, 64, 64, 30), (1, 2, 256, 512, 14)])
+def test_training_conv_writes_the_batchnorm_partial_statistics(k, stride, cin, cout, H):
+    """Training path of `conv_bn_act`: the convolution kernel's epilogue emits per-tile sums / sums of squares of its (bf16-rounded) output and the BatchNorm folds
+    its batch statistics from them (mode_bn_prepare_partials) - against the path that re-reads the activation: same output, same running statistics, same
+    gradients (the statistics are sums of the same stored values in another order)."""
+    torch.manual_seed(k * 10 + stride + cin)
+    res = {}
+    for flag in (True, False):
+        torch.manual_seed(5)
+        conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False).cuda()
+        E._store_channels_last(conv)
+        bn = torch.nn.BatchNorm2d(cout).cuda().train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(std=0.2)
+        x = torch.randn(7, cin, H, H + 3, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        E.FUSE_CONV_STATS, E.FUSE_CONV_STATS_1X1 = flag, flag                  # (an opt-in path: off by default, see perceptual_encoders.py)
+        try:
+            y = E.conv_bn_act(conv, bn, x, relu=True)
+            assert (type(y.grad_fn.next_functions[0][0]).__name__ == "_ConvFnBackward") and (len(y.grad_fn.next_functions) > 0)
+        finally:
+            E.FUSE_CONV_STATS, E.FUSE_CONV_STATS_1X1 = False, False
+        (y.float() ** 2).mean().backward()
+        res[flag] = (y.detach().float(), bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked), x.grad.float().clone(), conv.weight.grad.clone(),
+                     bn.weight.grad.clone(), bn.bias.grad.clone())
+    a, b = res[True], res[False]
+    assert a[3] == b[3] == 1
+    assert rel(a[1], b[1]) < 1e-5 and rel(a[2], b[2]) < 1e-5                    # running statistics
+    assert rel(a[0], b[0]) < 2e-3                                              # (an activation within a bf16 ulp of the ReLU / rounding boundary may flip)
+    for i in (4, 5, 6, 7):
+        assert rel(a[i], b[i]) < 1e-2, i
