@@ -302,6 +302,8 @@ def _tap_table(n, H, W_, ho, wo, kh_, kw_, sh, sw, ph, pw, dev, transposed: bool
     key = (n, H, W_, kh_, kw_, sh, sw, ph, pw, dev, transposed)
     idx = _TAPS.get(key)
     if idx is None:
+        if len(_TAPS) >= 256:                                   # one entry per (batch, image size, filter geometry): a training run has ~20; bounded anyway
+            _TAPS.clear()
         nn_ = torch.arange(n, device=dev).view(n, 1, 1)
         tabs = []
         neg = torch.full((), -1, device=dev)
@@ -395,6 +397,8 @@ def _wgrad_taps(dy: torch.Tensor, x: torch.Tensor, wshape, stride, padding) -> t
     okey = (R, G, dy.device)
     offs = _KOFFS.get(okey)
     if offs is None:
+        if len(_KOFFS) >= 1024:
+            _KOFFS.clear()
         offs = _KOFFS[okey] = torch.tensor([(R * i) // G for i in range(G + 1)], dtype=torch.int32, device=dy.device)
     part = torch.empty((G, cout, kh_, kw_, cin), dtype=torch.float32, device=dy.device)       # channels_last order of [Cout, Cin, kh, kw]
     lib = L.load(); st = torch.cuda.current_stream().cuda_stream
@@ -464,7 +468,8 @@ class _ConvFn(torch.autograd.Function):
 
 def _shadow(conv: nn.Conv2d, dtype: torch.dtype) -> torch.Tensor:
     """The convolution's weight in the compute dtype, cached on the module (not a buffer: never in a state_dict) and refreshed in place when the
-    parameter changes (its version counter / storage moved)."""
+    parameter changes (its version counter / storage moved).  Staleness rests on torch's version counter: optimizers, `load_state_dict`, `copy_` and every
+    other in-place torch op bump it; code that writes a parameter through a raw pointer must bump it too (`torch.autograd.graph.increment_version`)."""
     w = conv.weight
     ent = conv.__dict__.get("_mode_lp")
     if ent is None or ent[2].dtype != dtype or ent[2].device != w.device or ent[2].shape != w.shape:
