@@ -302,8 +302,7 @@ def _tap_table(n, H, W_, ho, wo, kh_, kw_, sh, sw, ph, pw, dev, transposed: bool
     key = (n, H, W_, kh_, kw_, sh, sw, ph, pw, dev, transposed)
     idx = _TAPS.get(key)
     if idx is None:
-        if len(_TAPS) >= 256:                                   # one entry per (batch, image size, filter geometry): a training run has ~20; bounded anyway
-            _TAPS.clear()
+        # (one entry per (batch, image size, filter geometry): a run has ~20.  Never evicted: captured hipGraphs - GraphedVisualEncoder - hold raw pointers into them)
         nn_ = torch.arange(n, device=dev).view(n, 1, 1)
         tabs = []
         neg = torch.full((), -1, device=dev)
@@ -397,8 +396,6 @@ def _wgrad_taps(dy: torch.Tensor, x: torch.Tensor, wshape, stride, padding) -> t
     okey = (R, G, dy.device)
     offs = _KOFFS.get(okey)
     if offs is None:
-        if len(_KOFFS) >= 1024:
-            _KOFFS.clear()
         offs = _KOFFS[okey] = torch.tensor([(R * i) // G for i in range(G + 1)], dtype=torch.int32, device=dy.device)
     part = torch.empty((G, cout, kh_, kw_, cin), dtype=torch.float32, device=dy.device)       # channels_last order of [Cout, Cin, kh, kw]
     lib = L.load(); st = torch.cuda.current_stream().cuda_stream
