@@ -661,7 +661,8 @@ def agent_step_measure(den, device, B, steps, warmup, miopen_benchmark=False):
     goal = torch.randn(B, 1, 512, generator=g).to(device)
     acts = torch.randn(B, 10, 7, generator=g).to(device); noise = torch.randn(B, 10, 7, generator=g).to(device)
     opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
-    opt_e = torch.optim.AdamW(list(enc_s.parameters()) + list(enc_g.parameters()), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    opt_e = torch.optim.AdamW(list(enc_s.parameters()) + list(enc_g.parameters()), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05,
+                              **({"fused": True} if os.environ.get("MODE_BENCH_TORCH_FUSED_ADAMW") == "1" else {}))   # (A/B: torch's own fused multi-tensor kernel; the reference uses the default)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     enc_ms = [0.0, 0.0]
 
