@@ -78,6 +78,7 @@ const char* mode_hip_status_string(int status);
  *   many TOKEN rows as the small-batch chain (MODE_GEMM_SMALL_ROWS) (default 32 = two environments, 0 = off).
  * "gemm_mid_rows": ungrouped bf16 GEMMs with K = 1024 and at most this many rows (more than "gemm_skinny_rows") keep their weights in registers
  *   and their A block in LDS - no K loop (default 128 = up to nine environments, 0 = off).
+ * "gemm_mid_rows_rn": the same kernel for MODE_EPI_RESIDUAL_NORM GEMMs (the c_proj of a block: [D, D] weight) up to this many rows (default 512 = 36 environments).
  * "fuse_ln2": 1 (default) = ln_2 folded into the c_proj / up-projection / combine kernels on the bf16 path, 0 = its own kernel.
  * "dn_split_k": K-slices of the inference path's expert down-projection, 0 = default (4, for every batch size), 1 = off, <= 8.
  * "combine_row_max": token rows up to which the MoE combine runs one workgroup per row (default: always), 0 = one wave per row.

@@ -22,6 +22,7 @@ extern int g_gemm_pp_min_tiles;
 extern int g_fuse_qkv_attn, g_fuse_qkv_attn_min_b, g_qkv_attn_w3, g_qkv_attn_waves;   // qkv_attn.hip
 extern int g_combine_row_max;
 extern int g_gemm_mid_rows;
+extern int g_gemm_mid_rows_rn;
 extern int g_tr_cfg;
 extern int g_bwd_coexec;
 int g_fuse_swiglu_bwd = 1;   // "fuse_swiglu_bwd" option: 1 = the training backward runs dH = dY W2 and the SwishGLU backward as one launch
@@ -123,6 +124,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }
   if (!strcmp(key, "gemm_skinny_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_skinny_rows = value; return MODE_OK; }
   if (!strcmp(key, "fuse_ln2")) { g_fuse_ln2 = value != 0; return MODE_OK; }
+  if (!strcmp(key, "gemm_mid_rows_rn")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_mid_rows_rn = value; return MODE_OK; }
   if (!strcmp(key, "gemm_mid_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_mid_rows = value; return MODE_OK; }
   if (!strcmp(key, "combine_row_max")) { if (value < 0) return MODE_ERR_BAD_ARG; g_combine_row_max = value; return MODE_OK; }
   if (!strcmp(key, "fuse_qkv_attn")) { g_fuse_qkv_attn = value != 0; return MODE_OK; }

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
             *reinterpret_cast<uint2*>(p.C2 + m * p.ldc2 + n) =
                 make_uint2(pack_bf16x2(f.x * gq[u].x, f.y * gq[u].y), pack_bf16x2(f.z * gq[u].z, f.w * gq[u].w));
           }
-          float ss = f.x * f.x + f.y * f.y + f.z * f.z + f.w * f.w;
+          float ss = ss4_f(f.x, f.y, f.z, f.w);                      // (shared with gemm_bf16_mid_kernel: mode_common.h)
           ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 1, 64);
           if (ok && (lane & 15) == 0) p.ss_out[m * (p.N >> 6) + (n >> 6)] = ss;
         }
@@ -406,6 +406,7 @@ int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p, int rows256,
 int pp_num_cus();                                                                                   // gemm_bf16_pp.hip: compute units of the current device (= its grid)
 int gemm_bf16_skinny_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_skinny.hip: weight streamer for a handful of rows
 int gemm_bf16_mid_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);      // gemm_bf16_skinny.hip: register-resident weights, no K loop (a few hundred rows)
+int g_gemm_mid_rows_rn = 512;   // "gemm_mid_rows_rn" option: the same kernel for the c_proj (+ residual + first half of ln_2) GEMM, whose [D, D] weight is small enough to be re-read by every 32-row block (rollout batches up to 36 environments)
 int g_gemm_mid_rows = 128;   // "gemm_mid_rows" option: ungrouped K = 1024 GEMMs with at most this many rows take gemm_bf16_mid_kernel (0 = off).  Measured chunk latency B = 4: 6.89 -> 6.60 ms, B = 8: 7.40 -> 7.14 ms; from ~200 rows on the M/32 re-reads of W through L2 cost more than the ring kernel (B = 16: 8.41 -> 8.50 ms, B = 32: 9.21 -> 9.48 ms)
 int g_gemm_cfg = CFG_AUTO;
 int g_gemm_skinny_rows = 32;   // measured (scripts/rollout_batch_probe.py): chunk latency B=1 9.4 -> 7.35 ms, B=2 8.7 -> 8.3 ms; from ~3 environments on the tiled kernel (64x64 tiles) is as fast or faster
@@ -529,7 +530,7 @@ int gemm_bf16_launch(const ModeGemmDesc* d, hipStream_t s) {
     const int rc = gemm_bf16_skinny_launch(d, p, s);
     if (rc != MODE_ERR_UNSUPPORTED || small_rows) return rc;
   }
-  if (g_gemm_cfg == CFG_AUTO && d->M <= g_gemm_mid_rows && !small_rows) {
+  if (g_gemm_cfg == CFG_AUTO && !small_rows && (d->M <= g_gemm_mid_rows || (d->epilogue == MODE_EPI_RESIDUAL_NORM && d->M <= g_gemm_mid_rows_rn))) {
     const int rc = gemm_bf16_mid_launch(d, p, s);
     if (rc != MODE_ERR_UNSUPPORTED) return rc;
   }

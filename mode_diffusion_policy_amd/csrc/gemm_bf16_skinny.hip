@@ -457,7 +457,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_mid_kernel(const GemmParams p) 
   for (int u = 0; u < KS; ++u) wraw[u] = *reinterpret_cast<const i32x4_t*>(wrow + 32 * u);
   const int perm_addr = (4 * fr + fq) * 4;
   [[maybe_unused]] float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  [[maybe_unused]] float4 rr[2];
   if constexpr (EPI == MODE_EPI_BIAS) e0 = *reinterpret_cast<const float4*>(p.bias + min(n, p.N - 4));
+  if constexpr (EPI == MODE_EPI_RESIDUAL_NORM) {                     // residual rows + gain: requested with the weights, ahead of the MFMAs
+    e0 = *reinterpret_cast<const float4*>(p.gain + min(n, p.N - 4));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rr[i] = *reinterpret_cast<const float4*>(p.resid + (long)min(mb + i * 16 + fr, p.M - 1) * p.ldr + min(n, p.N - 4));
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the DMA'd A block has landed (the compiler does not track it)
   __syncthreads();
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -477,6 +483,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_mid_kernel(const GemmParams p) 
     acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af0, acc[0], 0, 0, 0);
     acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af1, acc[1], 0, 0, 0);
   }
+  if constexpr (EPI == MODE_EPI_RESIDUAL_NORM) {
+    // x = acc + resid -> C (fp32); bf16(x * gain) -> C2; the row's sum of squares over this workgroup's 64 columns -> ss_out[row][blockIdx.x]: the 16 four-column
+    // chunks of a row sit in (wave, fq) = (j / 4, j % 4); they meet in LDS and are added in the tree order of the ring kernel's epilogue (ss16_tree), so
+    // both kernels publish bit-identical partial sums
+    __syncthreads();                                                 // everyone is done with the A image
+    float* ssb = reinterpret_cast<float*>(smem);                      // [32 rows][16 chunks]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ml = mb + i * 16 + fr;
+      const bool ok = ml < p.M && n < p.N;
+      const float x0 = acc[i][0] + rr[i].x, x1 = acc[i][1] + rr[i].y, x2 = acc[i][2] + rr[i].z, x3 = acc[i][3] + rr[i].w;
+      if (ok) {
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.C) + ((long)ml * p.ldc + n) * 4) = make_float4(x0, x1, x2, x3);
+        *reinterpret_cast<uint2*>(p.C2 + (long)ml * p.ldc2 + n) = make_uint2(pack_bf16x2(x0 * e0.x, x1 * e0.y), pack_bf16x2(x2 * e0.z, x3 * e0.w));
+      }
+      ssb[(i * 16 + fr) * 16 + wave * 4 + fq] = ok ? ss4_f(x0, x1, x2, x3) : 0.f;
+    }
+    __syncthreads();
+    if (tid < 32 && mb + tid < p.M) p.ss_out[(long)(mb + tid) * (p.N >> 6) + blockIdx.x] = ss16_tree(ssb + tid * 16);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int ml = mb + i * 16 + fr;
@@ -491,7 +518,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_mid_kernel(const GemmParams p) 
 // Medium-M launcher: ungrouped, K == 1024, no split, NONE / BIAS epilogues, N % 64 == 0.  Returns MODE_ERR_UNSUPPORTED otherwise.
 int gemm_bf16_mid_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s) {
   if (d->expert_offsets || d->a_rows || p.koffs || p.split_k != 1 || d->K != 1024 || d->N % 64 || p.ss_in) return MODE_ERR_UNSUPPORTED;
-  if (d->epilogue != MODE_EPI_NONE && d->epilogue != MODE_EPI_BIAS) return MODE_ERR_UNSUPPORTED;
+  if (d->epilogue != MODE_EPI_NONE && d->epilogue != MODE_EPI_BIAS && d->epilogue != MODE_EPI_RESIDUAL_NORM) return MODE_ERR_UNSUPPORTED;
+  if (d->epilogue == MODE_EPI_RESIDUAL_NORM && (d->out_dtype != MODE_F32 || !p.C2 || !p.gain || !p.ss_out || !p.resid)) return MODE_ERR_UNSUPPORTED;
   constexpr size_t LDS = (size_t)32 * (2048 + 16);
   const dim3 grid(d->N / 64, (d->M + 31) / 32);
   const bool ob = d->out_dtype == MODE_BF16;
@@ -508,7 +536,8 @@ int gemm_bf16_mid_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t
     }                                                                                                                                       \
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, p);                                                                                   \
   } while (0)
-  if (d->epilogue == MODE_EPI_BIAS) { if (ob) MODE_MID(MODE_EPI_BIAS, true); else MODE_MID(MODE_EPI_BIAS, false); }
+  if (d->epilogue == MODE_EPI_RESIDUAL_NORM) MODE_MID(MODE_EPI_RESIDUAL_NORM, false);
+  else if (d->epilogue == MODE_EPI_BIAS) { if (ob) MODE_MID(MODE_EPI_BIAS, true); else MODE_MID(MODE_EPI_BIAS, false); }
   else { if (ob) MODE_MID(MODE_EPI_NONE, true); else MODE_MID(MODE_EPI_NONE, false); }
 #undef MODE_MID
   MODE_LAUNCH_CHECK();

@@ -69,6 +69,16 @@ __device__ __forceinline__ float silu_f(float g) { return g * __builtin_amdgcn_r
 __device__ __forceinline__ float swiglu_f(float acc_v, float acc_g, float rs, float bv, float bg) {
   return __builtin_fmaf(acc_v, rs, bv) * silu_f(__builtin_fmaf(acc_g, rs, bg));
 }
+// Sum of squares of a lane's four consecutive columns and the 16-chunk tree of a 64-column group (fused ln_2 producer, MODE_EPI_RESIDUAL_NORM): ONE definition
+// with explicit fmas for every kernel that publishes these partial sums - the consumers' row norms, and with them the bf16 outputs, must not depend on which
+// kernel a batch size selects (batch-slice consistency).  The tree is the xor-8 / 4 / 2 / 1 butterfly of 16 lanes holding chunks 0..15, read off lane 0.
+__device__ __forceinline__ float ss4_f(float x, float y, float z, float w) {
+  return __builtin_fmaf(w, w, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+}
+__device__ __forceinline__ float ss16_tree(const float* s) {          // s[j] = chunk j's ss4_f
+  const float t0 = s[0] + s[8], t1 = s[1] + s[9], t2 = s[2] + s[10], t3 = s[3] + s[11], t4 = s[4] + s[12], t5 = s[5] + s[13], t6 = s[6] + s[14], t7 = s[7] + s[15];
+  return ((t0 + t4) + (t2 + t6)) + ((t1 + t5) + (t3 + t7));
+}
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // XCD-aware, bijective remap of a linear workgroup id: hardware places block b on XCD b % 8 (observed, speed only), so give
