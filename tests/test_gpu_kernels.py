@@ -567,3 +567,35 @@ def test_ragged_grouped_gemm_256_row_pingpong_tile(counts, epi):
     assert rel(outs[0].float(), ref) < 6e-3
     for cfg in (1, 17, 18):
         assert torch.equal(outs[cfg].view(torch.int16), outs[0].view(torch.int16)), cfg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [33, 100, 448, 512, 513])
+def test_residual_norm_epilogue_no_k_loop_kernel_is_bit_identical_to_the_ring(M):
+    """MODE_EPI_RESIDUAL_NORM (c_proj + residual + first half of ln_2) on the register-resident-weights kernel (rollout batch sizes, "gemm_mid_rows_rn") against
+    the ring kernel: the fp32 residual stream, the bf16 gain-scaled copy AND the per-64-column sums of squares must be the same bits - a sample's result must
+    not depend on the batch size it is computed in (batch-slice consistency)."""
+    import ctypes as C
+    from hip_helpers import p, stream
+    lib = L.load()
+    D = 1024
+    g = torch.Generator().manual_seed(M)
+    ya = (torch.randn(M, D, generator=g) * 0.5).to(torch.bfloat16).cuda(); wo = (torch.randn(D, D, generator=g) * D ** -0.5).to(torch.bfloat16).cuda()
+    x0 = torch.randn(M, D, generator=g).cuda(); g2 = (1 + 0.1 * torch.randn(D, generator=g)).cuda()
+    outs = {}
+    for rn in (512, 0):
+        x = torch.full((M, D), float("nan"), device="cuda"); xg = torch.zeros(M, D, dtype=torch.bfloat16, device="cuda"); ss = torch.full((M, D // 64), float("nan"), device="cuda")
+        d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_RESIDUAL_NORM, out_dtype=L.MODE_F32, M=M, N=D, K=D, A=p(ya), lda=D, W=p(wo), ldw=D, resid=p(x0), ldr=D,
+                           C=p(x), ldc=D, C2=p(xg), ldc2=D, gain=p(g2), row_ss_out=p(ss))
+        lib.mode_set_option(b"gemm_mid_rows_rn", rn)
+        try:
+            L.check(lib.mode_gemm(C.byref(d), stream()), "gemm")
+        finally:
+            lib.mode_set_option(b"gemm_mid_rows_rn", 512)
+        torch.cuda.synchronize()
+        outs[rn] = (x, xg, ss)
+    for a, b in zip(outs[512], outs[0]):
+        assert torch.equal(a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32), b.view(torch.int16 if b.dtype == torch.bfloat16 else torch.int32))
+    ref = x0 + ya.float() @ wo.float().t()
+    assert float((outs[512][0] - ref).norm() / ref.norm()) < 1e-3
+    assert float((outs[512][2].sum(1) - (outs[512][0] ** 2).sum(1)).abs().max() / (outs[512][0] ** 2).sum(1).max()) < 1e-5
