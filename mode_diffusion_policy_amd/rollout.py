@@ -64,9 +64,10 @@ def sample_loop(model, sigmas, x_t, state, goal, sampler_type: str = "ddim", ext
 
 
 # Samplers whose step loop depends on the schedule only (no data-dependent control flow, no host-side noise source): whole call capturable in a hipGraph.
-# Not here: "ddim" (its own fused graph), "lms" / "dpmpp_2_with_lms" (host-side quadrature of the schedule), "dpmpp_2m_sde" (torchsde Brownian tree on
-# the host), "dpm_adaptive" / "dpm_fast" (step sizes from error norms / host floats).
-_GRAPHABLE_SAMPLERS = ("euler", "euler_ancestral", "heun", "dpm", "ancestral", "dpmpp_2m", "dpmpp_2s", "dpmpp_2s_ancestral")
+# Not here: "ddim" and "euler" (without churn the same update: both take MoDeDiT's fused graph, samplers.sample_euler), "lms" / "dpmpp_2_with_lms"
+# (host-side quadrature of the schedule), "dpmpp_2m_sde" (torchsde Brownian tree on the host), "dpm_adaptive" / "dpm_fast" (step sizes from error
+# norms / host floats).
+_GRAPHABLE_SAMPLERS = ("euler_ancestral", "heun", "dpm", "ancestral", "dpmpp_2m", "dpmpp_2s", "dpmpp_2s_ancestral")
 
 
 class ChunkedRolloutPolicy:
@@ -141,7 +142,7 @@ class ChunkedRolloutPolicy:
 
     def _sample_graphed(self, sigmas, x, perceptual_emb, latent_goal):
         """The whole sampler call (every denoiser call, every update of the recurrence, the samplers' own noise draws) as ONE hipGraph replay - what the
-        fused DDIM path does for ``ddim``, for the samplers whose control flow does not depend on the data (euler, heun, dpm-solver(++) ...: the step
+        fused DDIM path does for ``ddim`` and ``euler``, for the samplers whose control flow does not depend on the data (heun, dpm-solver(++) ...: the step
         loop only branches on which levels of the SCHEDULE are zero).  Captured once per (sampler, batch, weights storage); the ancestral samplers' noise
         comes from torch's default generator, which hipGraph capture advances per replay.  None = not applicable (goal / token routing, training mode,
         MODE_HIP_GRAPH=0): the caller takes the step-by-step path."""

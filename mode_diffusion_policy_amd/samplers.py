@@ -196,7 +196,14 @@ class _Run:
 @torch.no_grad()
 def sample_euler(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, s_churn=0.0, s_tmin=0.0,
                  s_tmax=float("inf"), s_noise=1.0):
-    """Euler steps of Karras et al. (2022) Algorithm 2 (gc_sampling.py:165-211); an ODE solver for s_churn = 0."""
+    """Euler steps of Karras et al. (2022) Algorithm 2 (gc_sampling.py:165-211); an ODE solver for s_churn = 0.  Without churn, clipping, callback
+    and extra arguments the step  x + (x - D)/s (s' - s)  is  (s'/s) x + (1 - s'/s) D  - the fused DDIM update -, so a GCDenoiser over the HIP
+    MoDeDiT takes the whole call as one hipGraph replay (same result to fp32 rounding of the rearranged update)."""
+    if s_churn <= 0 and scaler is None and callback is None and not extra_args and _chunk_capture() is None:
+        fused = getattr(model, "first_order_ode_fused", None)
+        out = fused(state, action, goal, sigmas) if fused is not None else None
+        if out is not None:
+            return out
     run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
     for i in range(len(sigmas) - 1):
         action, sigma_hat = _churn(action, sigmas, i, s_churn, s_tmin, s_tmax, s_noise)

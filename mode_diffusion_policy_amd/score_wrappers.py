@@ -70,5 +70,14 @@ class GCDenoiser(nn.Module):
             return m.denoise_graphed(state, action, goal, sigma, self.sigma_data)
         return None
 
+    def first_order_ode_fused(self, state, action, goal, sigmas):
+        """The whole deterministic first-order solve  x <- (s'/s) x + (1 - s'/s) D(x; s)  over ``sigmas`` as one hipGraph replay
+        (``MoDeDiT.sample_ddim_fused``).  That update is both sample_ddim's (gc_sampling.py:922-951: exp(-t')/exp(-t) = s'/s, -expm1(-h) = 1 - s'/s)
+        and, multiplied out, sample_euler's without churn (gc_sampling.py:165-211: x + (x - D)/s (s' - s)).  None when the fast path does not apply."""
+        m = self.inner_model
+        if isinstance(m, MoDeDiT) and not m.training and not torch.is_grad_enabled() and torch.is_tensor(sigmas) and sigmas.dim() == 1:
+            return m.sample_ddim_fused(state, action, goal, sigmas, self.sigma_data)
+        return None
+
     def get_params(self):
         return self.inner_model.parameters()

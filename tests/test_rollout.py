@@ -268,3 +268,10 @@ def test_whole_sampler_call_as_one_graph(dtype, monkeypatch):
             plans.append(p)
         assert len(pol._chunk_graphs) == 1                                            # one capture, three replays
         assert not torch.equal(plans[0], plans[1])
+    # euler (no churn) and ddim are one update: through the policy both take the fused DDIM graph - the same plan from the same noise
+    plan = {}
+    for name in ("euler", "ddim"):
+        pol = rollout.ChunkedRolloutPolicy(den, sampler_type=name, noise_scheduler="karras", multistep=10, generator=torch.Generator(device="cuda").manual_seed(11))
+        plan[name] = pol.denoise_actions(obs, inp["goals"])
+        assert not getattr(pol, "_chunk_graphs", None)
+    assert torch.equal(plan["euler"], plan["ddim"])

@@ -177,6 +177,39 @@ def test_samplers_on_hip_denoiser(golden, dtype, tol):
         assert v < (BF16_OUT_FUZZ if (dtype == "bf16" and k.startswith("dpm_fast")) else tol), (k, v)
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_euler_without_churn_is_the_fused_first_order_solve(dtype):
+    """sample_euler with s_churn = 0 multiplies out to the DDIM update: on the HIP denoiser it takes the fused one-replay path - the same tensor as
+    sample_ddim, bit for bit - and agrees with its own step-by-step loop (forced by a callback / a scaler / churn arguments that change nothing) to
+    the rounding of the rearranged update."""
+    from test_gpu_model import build
+    cfg, sd, m = build("c1e4", 77, dtype)
+    den = M.GCDenoiser(m, 0.5).eval()
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, 6, 5).items()}
+    state = {"state_images": inp["state_images"]}
+    sig = gc_sampling.get_sigmas_exponential(10, 0.001, 80.0, "cuda")
+    fused = samplers.sample_euler(den, state, inp["x0"], inp["goals"], sig, disable=True)
+    ddim = gc_sampling.sample_ddim(den, state, inp["x0"], inp["goals"], sig, disable=True)
+    assert torch.equal(fused, ddim)
+    steps = []
+    loop = samplers.sample_euler(den, state, inp["x0"], inp["goals"], sig, disable=True, callback=lambda d: steps.append(d["i"]))
+    assert steps == list(range(10))
+    r = rel(fused, loop)
+    print(f"euler fused vs step loop, {dtype}: {r:.2e}")
+    assert r < (2e-6 if dtype == "fp32" else BF16_OUT), r
+
+    class Same:
+        def clip_output(self, x):
+            return x
+    assert torch.equal(samplers.sample_euler(den, state, inp["x0"], inp["goals"], sig, scaler=Same(), disable=True), loop)   # a scaler keeps the step loop
+    m.train()
+    try:                                                  # training mode (dropout live in the reference): never the fused path
+        assert den.first_order_ode_fused(state, inp["x0"], inp["goals"], sig) is None
+    finally:
+        m.eval()
+
+
+@pytest.mark.gpu
 def test_graphed_denoise_observation_cache_is_never_stale():
     """``denoise_graphed`` keeps the observation embeddings of one sampler run beside its graph.  Whatever changes between two calls - the tensors'
     contents in place, new tensor objects (also ones the allocator puts at a recycled address), the weights - the next call must see it: every call is
