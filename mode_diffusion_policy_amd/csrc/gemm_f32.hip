@@ -1,13 +1,17 @@
 // fp32 MFMA GEMM for gfx950: same contract as the bf16 kernel (plain / gathered / grouped, same epilogues) on
 // v_mfma_f32_16x16x4_f32 — bit-exactly a k-ordered fp32 fma chain, so the noise-conditioned router (whose top-k
 // integers must match the fp32 reference) and the fp32 parity mode of the whole denoiser run on the matrix cores
-// without any reduced-precision step.  64x64x16 tile, 4 wave64 (2x2), each wave 2x2 accumulators of 16x16.
+// without any reduced-precision step.  64x64 tile, 4 wave64 (2x2), each wave 2x2 accumulators of 16x16; K advances in LDS fills of FOUR 16-wide
+// sub-steps (one barrier pair per 64 k, the next fill's eight 16-byte loads per thread in flight under the 64 MFMAs of the current one - with one
+// sub-step per barrier every K-step cost a memory round trip: 0.7 us, the whole price of the M = 128 embedding / router products).  The MFMA sequence of
+// an output element is the same k-ascending chain whatever the fill size.
 // General in M, N, K (guarded loads/stores); float4 global loads when K % 16 == 0 and rows are 16-byte aligned.
+#include <type_traits>
 #include "mode_common.h"
 
 namespace mode {
 
-constexpr int FBM = 64, FBN = 64, FBK = 16, FNT = 256, FLD = FBK + 1;
+constexpr int FBK = 16, FNT = 256;
 
 struct GemmF32Params {
   const float* A; long lda;
@@ -18,13 +22,23 @@ struct GemmF32Params {
   const int* a_rows; const int* offsets; int E;
   const int* koffs; long c_gstride;
   int M, N, K, m_tiles, n_tiles;
-  int a_km, w_kn;                         // operand given as [K][M] / [K][N] row-major (backward-pass layouts, see MODE_GEMM_A_KM / W_KN)
 };
 
-template <int EPI, bool OUT_BF16, bool VEC>
+// LAYOUT bit 0: A given as [K][M] row-major, bit 1: W given as [K][N] row-major (backward-pass layouts, see MODE_GEMM_A_KM / W_KN).
+// SMALL: 32x32 tile (one 16x16 accumulator per wave) with 128 k per LDS fill - for products with fewer 64x64 tiles than CUs, where the serial
+// MFMA chain of an accumulator (K/4 instructions of 32 cycles) times the accumulators per wave is the run time.
+// LDS image of a fill: [tile row][FLD], the 16 k of a sub-step stored 4x4-transposed (position 4*(k%4) + k/4): lane (row fr, k-group fq) of an MFMA
+// operand reads ONE 16-byte word holding k = fq, 4+fq, 8+fq, 12+fq - its values for the sub-step's four MFMAs, i.e. the same k-ascending chain as
+// four 4-byte reads of a row-major image.  Row stride FLD = k-per-fill + 4 floats: rows 4 banks apart, the 16 rows of a fragment cover all 64.
+template <int EPI, bool OUT_BF16, bool VEC, int LAYOUT, bool SMALL>
 __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
-  __shared__ float sA[2][FBM * FLD];
-  __shared__ float sB[2][FBN * FLD];
+  constexpr int TM = SMALL ? 32 : 64, TN = TM, FSUB = SMALL ? 8 : 4, KF = FSUB * FBK, FLD = KF + 4;
+  constexpr int MI = TM / 32, NJ = TN / 32, QR = KF / 4, RS = FNT / QR, NL = TM * QR / FNT;        // NL float4 per thread, operand and fill
+  constexpr int CQ = TM / 4, KS = FNT / CQ;                                                        // [K][cols] staging: column quads per k row, k rows per step
+  constexpr bool A_KM = (LAYOUT & 1) != 0, W_KN = (LAYOUT & 2) != 0;
+  static_assert(!(SMALL && EPI == MODE_EPI_SWIGLU), "the SwiGLU epilogue pairs the two 32-row halves of a 64-row weight tile");
+  __shared__ __attribute__((aligned(16))) float sA[TM * FLD];
+  __shared__ __attribute__((aligned(16))) float sB[TN * FLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int mt = blockIdx.x / p.n_tiles, nt = blockIdx.x % p.n_tiles;
@@ -35,132 +49,176 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
     bool found = false;
     for (; e < p.E; ++e) {
       const int o0 = p.offsets[e], o1 = p.offsets[e + 1];
-      const int nt_e = (o1 - o0 + FBM - 1) / FBM;
-      if (t < nt_e) { row0 = o0 + t * FBM; row_end = min(o1, row0 + FBM); found = true; break; }
+      const int nt_e = (o1 - o0 + TM - 1) / TM;
+      if (t < nt_e) { row0 = o0 + t * TM; row_end = min(o1, row0 + TM); found = true; break; }
       t -= nt_e;
     }
     if (!found) return;
     expert = e;
   } else {
-    row0 = mt * FBM; row_end = min(p.M, row0 + FBM);
+    row0 = mt * TM; row_end = min(p.M, row0 + TM);
   }
   const float* W = p.W + (long)expert * p.w_estride;
   const float* bias = p.bias ? p.bias + (long)expert * p.bias_estride : nullptr;
-  constexpr int NOUT = (EPI == MODE_EPI_SWIGLU) ? 32 : FBN;
+  constexpr int NOUT = (EPI == MODE_EPI_SWIGLU) ? 32 : TN;
   const int n0 = nt * NOUT;
-
-  // staging: thread -> tile row (tid>>2), k quad (tid&3)
-  const int tr = tid >> 2, kq = (tid & 3) * 4;
-  const int s = min(row0 + tr, row_end - 1);
-  const long arow = p.a_rows ? (long)p.a_rows[s] : (long)s;
-  const float* a_src = p.A + arow * p.lda + kq;
-  long brow;
-  if constexpr (EPI == MODE_EPI_SWIGLU) brow = (long)min(n0 + (tr & 31), p.N - 1) + ((tr >= 32) ? p.N : 0);
-  else brow = min(n0 + tr, p.N - 1);
-  const float* b_src = W + brow * p.ldw + kq;
-
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int fr = lane & 15, fq = lane >> 4;
-  int a_row[2], b_row[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) a_row[i] = (wm * 32 + i * 16 + fr) * FLD;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int br;
-    if constexpr (EPI == MODE_EPI_SWIGLU) br = (j == 0) ? wn * 16 : 32 + wn * 16;
-    else br = wn * 32 + j * 16;
-    b_row[j] = (br + fr) * FLD;
-  }
 
   int kbeg = 0, kend = p.K;
   if (p.koffs) { kbeg = p.koffs[blockIdx.z]; kend = p.koffs[blockIdx.z + 1]; }
-  const int nk = (kend - kbeg + FBK - 1) / FBK;
-  float4 ra, rb;
-  // [K][cols] operands: thread -> k row (tid>>4), column quad (tid&15)*4; stored transposed into the same [row][k] LDS image
-  const int krow = tid >> 4, q4 = (tid & 15) * 4;
-  auto kn_load = [&](const float* base, long ld, int k, int c, int climit) -> float4 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < kend) {
-      const float* src = base + (long)k * ld + c;
-      if (VEC && c + 3 < climit) v = *reinterpret_cast<const float4*>(src);
+  const int nk = (kend - kbeg + FBK - 1) / FBK;                          // 16-wide sub-steps
+  const int nfill = (nk + FSUB - 1) / FSUB;
+
+  // ---- staging.  [rows][K] operand: float4 number tid + 256 i of a fill = tile row r0 + RS i, k quad qd (a row's KF floats are read by QR adjacent
+  // lanes).  [K][cols] operand: k row kl0 + KS i of the fill, column quad cq (a k row's tile columns are read by CQ adjacent lanes).
+  const int qd = tid % QR, r0 = tid / QR;
+  const int cq = tid % CQ, kl0 = tid / CQ;
+  const float* a_ptr[NL]; const float* b_ptr[NL];
+  int a_lds[NL], b_lds[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    if constexpr (A_KM) {
+      const int kl = kl0 + KS * i;
+      int c = row0 + 4 * cq;
+      if constexpr (VEC) c = max(min(c, p.M - 4), 0);                     // columns past M feed rows that are never stored: any in-bounds address will do
+      a_ptr[i] = p.A + (long)kl * p.lda + c;
+      a_lds[i] = 4 * cq * FLD + (kl & ~15) + 4 * (kl & 3) + ((kl >> 2) & 3);
+    } else {
+      const int s = min(row0 + r0 + RS * i, row_end - 1);
+      const long arow = p.a_rows ? (long)p.a_rows[s] : (long)s;
+      a_ptr[i] = p.A + arow * p.lda + 4 * qd;
+      a_lds[i] = (r0 + RS * i) * FLD + (qd >> 2) * 16 + (qd & 3);
+    }
+    if constexpr (W_KN) {
+      const int kl = kl0 + KS * i;
+      int c = n0 + 4 * cq;
+      if constexpr (VEC) c = max(min(c, p.N - 4), 0);
+      b_ptr[i] = W + (long)kl * p.ldw + c;
+      b_lds[i] = 4 * cq * FLD + (kl & ~15) + 4 * (kl & 3) + ((kl >> 2) & 3);
+    } else {
+      const int t = r0 + RS * i;
+      long brow;
+      if constexpr (EPI == MODE_EPI_SWIGLU) brow = (long)min(n0 + (t & 31), p.N - 1) + ((t >= 32) ? p.N : 0);
+      else brow = min(n0 + t, p.N - 1);
+      b_ptr[i] = W + brow * p.ldw + 4 * qd;
+      b_lds[i] = t * FLD + (qd >> 2) * 16 + (qd & 3);
+    }
+  }
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_row[MI], b_row[NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a_row[i] = (wm * (TM / 2) + i * 16 + fr) * FLD + 4 * fq;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    int br;
+    if constexpr (EPI == MODE_EPI_SWIGLU) br = (j == 0) ? wn * 16 : 32 + wn * 16;
+    else br = wn * (TN / 2) + j * 16;
+    b_row[j] = (br + fr) * FLD + 4 * fq;
+  }
+
+  float4 ra[NL], rb[NL];
+  // one operand's NL float4 of fill `st`.  FULL: the fill lies inside [kbeg, kend) - every load unconditional, all of them issued back to back (a load
+  // under a per-lane condition compiles to a branch + a dependent round trip); the one partial fill at the end of a K range takes the guarded form
+  auto load_rows = [&](const float* const (&ptr)[NL], float4 (&r)[NL], int st, auto full_c) {    // [rows][K]: 4 consecutive k at kbeg + st KF + 4 qd
+    constexpr bool FULL = decltype(full_c)::value;
+    const int k = kbeg + st * KF + 4 * qd;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const float* src = ptr[i] + kbeg + st * KF;
+      if constexpr (VEC && FULL) r[i] = *reinterpret_cast<const float4*>(src);
+      else if (VEC && k + 3 < kend) r[i] = *reinterpret_cast<const float4*>(src);
       else {
-        if (c + 0 < climit) v.x = src[0];
-        if (c + 1 < climit) v.y = src[1];
-        if (c + 2 < climit) v.z = src[2];
-        if (c + 3 < climit) v.w = src[3];
+        r[i].x = (k + 0 < kend) ? src[0] : 0.f; r[i].y = (k + 1 < kend) ? src[1] : 0.f;
+        r[i].z = (k + 2 < kend) ? src[2] : 0.f; r[i].w = (k + 3 < kend) ? src[3] : 0.f;
       }
     }
-    return v;
   };
-  auto gload = [&](int kt) {
-    const int k = kbeg + kt * FBK + kq;
-    if (p.a_km || p.w_kn) {
-      const int kr = kbeg + kt * FBK + krow;
-      if (p.a_km) ra = kn_load(p.A, p.lda, kr, row0 + q4, p.M);
-      else if (k + 3 < kend) ra = *reinterpret_cast<const float4*>(a_src + kbeg + kt * FBK);
-      else {
-        const float* a = a_src + kbeg + kt * FBK;
-        ra.x = (k + 0 < kend) ? a[0] : 0.f; ra.y = (k + 1 < kend) ? a[1] : 0.f; ra.z = (k + 2 < kend) ? a[2] : 0.f; ra.w = (k + 3 < kend) ? a[3] : 0.f;
+  auto load_cols = [&](const float* const (&ptr)[NL], float4 (&r)[NL], int st, auto full_c, long ld, int c0, int climit) {   // [K][cols]: 4 consecutive columns of one k row
+    constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int kl = kl0 + KS * i, k = kbeg + st * KF + kl;
+      if constexpr (VEC) {                                              // clamped row, then a select: no load under a per-lane condition
+        const int kc = FULL ? k : min(k, kend - 1);
+        const float4 v = *reinterpret_cast<const float4*>(ptr[i] + (long)(kc - kl) * ld);
+        r[i] = (FULL || k < kend) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const float* src = ptr[i] + (long)(k - kl) * ld;
+        const int c = c0 + 4 * cq;
+        const bool in = k < kend;
+        r[i].x = (in && c + 0 < climit) ? src[0] : 0.f; r[i].y = (in && c + 1 < climit) ? src[1] : 0.f;
+        r[i].z = (in && c + 2 < climit) ? src[2] : 0.f; r[i].w = (in && c + 3 < climit) ? src[3] : 0.f;
       }
-      if (p.w_kn) rb = kn_load(W, p.ldw, kr, n0 + q4, p.N);
-      else if (k + 3 < kend) rb = *reinterpret_cast<const float4*>(b_src + kbeg + kt * FBK);
-      else {
-        const float* b = b_src + kbeg + kt * FBK;
-        rb.x = (k + 0 < kend) ? b[0] : 0.f; rb.y = (k + 1 < kend) ? b[1] : 0.f; rb.z = (k + 2 < kend) ? b[2] : 0.f; rb.w = (k + 3 < kend) ? b[3] : 0.f;
-      }
-    } else if constexpr (VEC) {
-      ra = *reinterpret_cast<const float4*>(a_src + kbeg + kt * FBK);
-      rb = *reinterpret_cast<const float4*>(b_src + kbeg + kt * FBK);
-    } else {
-      const float* a = a_src + kbeg + kt * FBK; const float* b = b_src + kbeg + kt * FBK;
-      ra.x = (k + 0 < kend) ? a[0] : 0.f; ra.y = (k + 1 < kend) ? a[1] : 0.f;
-      ra.z = (k + 2 < kend) ? a[2] : 0.f; ra.w = (k + 3 < kend) ? a[3] : 0.f;
-      rb.x = (k + 0 < kend) ? b[0] : 0.f; rb.y = (k + 1 < kend) ? b[1] : 0.f;
-      rb.z = (k + 2 < kend) ? b[2] : 0.f; rb.w = (k + 3 < kend) ? b[3] : 0.f;
     }
   };
-  auto commit = [&](int buf) {
-    if (p.a_km) {
-      float* a = &sA[buf][q4 * FLD + krow];
-      a[0] = ra.x; a[FLD] = ra.y; a[2 * FLD] = ra.z; a[3 * FLD] = ra.w;
-    } else {
-      float* a = &sA[buf][tr * FLD + kq];
-      a[0] = ra.x; a[1] = ra.y; a[2] = ra.z; a[3] = ra.w;
+  auto gload_as = [&](int st, auto full_c) {
+    if constexpr (A_KM) load_cols(a_ptr, ra, st, full_c, p.lda, row0, p.M); else load_rows(a_ptr, ra, st, full_c);
+    if constexpr (W_KN) load_cols(b_ptr, rb, st, full_c, p.ldw, n0, p.N); else load_rows(b_ptr, rb, st, full_c);
+  };
+  auto gload = [&](int st) {
+    if (kbeg + (st + 1) * KF <= kend) gload_as(st, std::true_type{});
+    else gload_as(st, std::false_type{});
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      if constexpr (A_KM) { float* a = &sA[a_lds[i]]; a[0] = ra[i].x; a[FLD] = ra[i].y; a[2 * FLD] = ra[i].z; a[3 * FLD] = ra[i].w; }
+      else { float* a = &sA[a_lds[i]]; a[0] = ra[i].x; a[4] = ra[i].y; a[8] = ra[i].z; a[12] = ra[i].w; }
+      if constexpr (W_KN) { float* b = &sB[b_lds[i]]; b[0] = rb[i].x; b[FLD] = rb[i].y; b[2 * FLD] = rb[i].z; b[3 * FLD] = rb[i].w; }
+      else { float* b = &sB[b_lds[i]]; b[0] = rb[i].x; b[4] = rb[i].y; b[8] = rb[i].z; b[12] = rb[i].w; }
     }
-    if (p.w_kn) {
-      float* b = &sB[buf][q4 * FLD + krow];
-      b[0] = rb.x; b[FLD] = rb.y; b[2 * FLD] = rb.z; b[3 * FLD] = rb.w;
-    } else {
-      float* b = &sB[buf][tr * FLD + kq];
-      b[0] = rb.x; b[1] = rb.y; b[2] = rb.z; b[3] = rb.w;
-    }
+  };
+  auto frag = [&](int u, float4 (&a)[MI], float4 (&b)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float4*>(&sA[a_row[i] + u * 16]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const float4*>(&sB[b_row[j] + u * 16]);
+  };
+  auto mfmas = [&](const float4 (&a)[MI], const float4 (&b)[NJ]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float av = kk == 0 ? a[i].x : kk == 1 ? a[i].y : kk == 2 ? a[i].z : a[i].w;
+          const float bv = kk == 0 ? b[j].x : kk == 1 ? b[j].y : kk == 2 ? b[j].z : b[j].w;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);           // swapped: D[n][m]
+        }
   };
 
-  if (nk > 0) { gload(0); commit(0); }
-  for (int kt = 0; kt < nk; ++kt) {
+  if (nfill > 0) gload(0);
+  for (int st = 0; st < nfill; ++st) {
+    commit();
     __syncthreads();
-    const bool more = (kt + 1) < nk;
-    if (more) gload(kt + 1);
-    const float* At = sA[kt & 1]; const float* Bt = sB[kt & 1];
+    if (st + 1 < nfill) gload(st + 1);                                   // in flight under this fill's MFMAs
+    const int nsub = min(FSUB, nk - st * FSUB);
+    if (nsub == FSUB) {                                                  // the next sub-step's fragments are read ahead of the current one's MFMAs
+      float4 ac[MI], bc[NJ], an[MI], bn[NJ];
+      frag(0, ac, bc);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      float af[2], bf[2];
+      for (int u = 0; u < FSUB; ++u) {
+        if (u + 1 < FSUB) frag(u + 1, an, bn);
+        mfmas(ac, bc);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = At[a_row[i] + kk * 4 + fq];
+        for (int i = 0; i < MI; ++i) ac[i] = an[i];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = Bt[b_row[j] + kk * 4 + fq];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);   // swapped: D[n][m]
+        for (int j = 0; j < NJ; ++j) bc[j] = bn[j];
+      }
+    } else {
+      for (int u = 0; u < nsub; ++u) {
+        float4 ac[MI], bc[NJ];
+        frag(u, ac, bc);
+        mfmas(ac, bc);
+      }
     }
-    if (more) commit((kt + 1) & 1);
+    __syncthreads();
   }
 
   const int rows_valid = row_end - row0;
@@ -172,8 +230,8 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
     }
   };
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ml = wm * 32 + i * 16 + fr;
+  for (int i = 0; i < MI; ++i) {
+    const int ml = wm * (TM / 2) + i * 16 + fr;
     if (ml >= rows_valid) continue;
     const long m = row0 + ml;
     if constexpr (EPI == MODE_EPI_SWIGLU) {
@@ -181,14 +239,14 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (n + r < p.N) {
-          const float v = acc[i][0][r] + bias[n + r], g = acc[i][1][r] + bias[p.N + n + r];
+          const float v = acc[i][0][r] + bias[n + r], g = acc[i][NJ - 1][r] + bias[p.N + n + r];
           store(m, n + r, v * silu_f(g));
         }
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 32 + j * 16 + fq * 4;
+      for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * (TN / 2) + j * 16 + fq * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (n + r < p.N) {
@@ -308,10 +366,18 @@ static int launch_skinny(const ModeGemmDesc* d, hipStream_t s) {
   return MODE_OK;
 }
 
-template <int EPI, bool OUT_BF16>
-static int launch_f32(const GemmF32Params& p, int nblk, bool vec, int ngroups, hipStream_t s) {
-  if (vec) hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, true>), dim3(nblk, 1, ngroups), dim3(FNT), 0, s, p);
-  else hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, false>), dim3(nblk, 1, ngroups), dim3(FNT), 0, s, p);
+template <int EPI, bool OUT_BF16, int LAYOUT>
+static int launch_f32(const GemmF32Params& p, int nblk, bool vec, bool small, int ngroups, hipStream_t s) {
+  const dim3 grid(nblk, 1, ngroups), blk(FNT);
+  if constexpr (EPI == MODE_EPI_SWIGLU) {
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, true, LAYOUT, false>), grid, blk, 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, false, LAYOUT, false>), grid, blk, 0, s, p);
+  } else {
+    if (vec && small) hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, true, LAYOUT, true>), grid, blk, 0, s, p);
+    else if (vec) hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, true, LAYOUT, false>), grid, blk, 0, s, p);
+    else if (small) hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, false, LAYOUT, true>), grid, blk, 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<EPI, OUT_BF16, false, LAYOUT, false>), grid, blk, 0, s, p);
+  }
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }
@@ -331,31 +397,41 @@ int gemm_f32_launch(const ModeGemmDesc* d, hipStream_t s) {
     return launch_skinny(d, s);
   const bool a_km = (d->flags & MODE_GEMM_A_KM) != 0, w_kn = (d->flags & MODE_GEMM_W_KN) != 0;
   if (a_km || w_kn) {      // backward-pass operand layouts: plain or K-grouped only; the "a_src/b_src + k" fast path needs 16-B aligned rows
-    if (d->a_rows || d->expert_offsets || d->epilogue == MODE_EPI_SWIGLU || d->out_dtype != MODE_F32) return MODE_ERR_UNSUPPORTED;
+    if (d->a_rows || d->expert_offsets || d->epilogue != MODE_EPI_NONE || d->out_dtype != MODE_F32) return MODE_ERR_UNSUPPORTED;
     if (d->lda % 4 || d->ldw % 4 || (((uintptr_t)d->A | (uintptr_t)d->W) % 16)) return MODE_ERR_UNSUPPORTED;
     if (!a_km && d->K % 4) return MODE_ERR_UNSUPPORTED;
   }
   GemmF32Params p;
-  p.a_km = a_km; p.w_kn = w_kn;
   p.A = (const float*)d->A; p.lda = d->lda;
   p.W = (const float*)d->W; p.ldw = d->ldw; p.w_estride = d->w_expert_stride;
   p.bias = d->bias; p.bias_estride = d->bias_expert_stride;
   p.resid = d->resid; p.ldr = d->ldr; p.C = d->C; p.ldc = d->ldc;
   p.a_rows = d->a_rows; p.offsets = d->expert_offsets; p.E = d->num_experts;
   p.M = d->M; p.N = d->N; p.K = d->K;
-  const int nout = (d->epilogue == MODE_EPI_SWIGLU) ? 32 : FBN;
-  p.n_tiles = (d->N + nout - 1) / nout;
-  p.m_tiles = (d->M + FBM - 1) / FBM + (d->expert_offsets ? d->num_experts : 0);
-  const int nblk = p.m_tiles * p.n_tiles;
-  const bool vec = (a_km || w_kn) ? true
-                                  : (d->K % FBK == 0) && (d->lda % 4 == 0) && (d->ldw % 4 == 0) && (d->w_expert_stride % 4 == 0) &&
-                                        (((uintptr_t)d->A | (uintptr_t)d->W) % 16 == 0);
-  const bool ob = d->out_dtype == MODE_BF16;
   p.koffs = d->k_group_offsets; p.c_gstride = d->c_group_stride;
   const int ng = d->k_group_offsets ? d->num_k_groups : 1;
   if (d->k_group_offsets && (d->num_k_groups <= 0 || d->expert_offsets)) return MODE_ERR_BAD_ARG;
+  const bool swiglu = d->epilogue == MODE_EPI_SWIGLU;
+  // 32x32 tiles when the 64x64 cover leaves most CUs without a workgroup (bit-identical: an element's MFMA chain does not depend on the tile)
+  const long tiles64 = ((long)(d->M + 63) / 64 + (d->expert_offsets ? d->num_experts : 0)) * ((d->N + 63) / 64) * ng;
+  const bool small = !swiglu && tiles64 <= 160;
+  const int tm = small ? 32 : 64, nout = swiglu ? 32 : tm;
+  p.n_tiles = (d->N + nout - 1) / nout;
+  p.m_tiles = (d->M + tm - 1) / tm + (d->expert_offsets ? d->num_experts : 0);
+  const int nblk = p.m_tiles * p.n_tiles;
+  // float4 global loads: [rows][K] operands need K % 16 == 0 and 16-byte aligned rows; [K][cols] operands a column count that is a multiple of 4
+  const bool vec = (a_km || w_kn) ? ((!a_km || d->M % 4 == 0) && (!w_kn || d->N % 4 == 0))
+                                  : (d->K % FBK == 0) && (d->lda % 4 == 0) && (d->ldw % 4 == 0) && (d->w_expert_stride % 4 == 0) &&
+                                        (((uintptr_t)d->A | (uintptr_t)d->W) % 16 == 0);
+  const bool ob = d->out_dtype == MODE_BF16;
+  if (a_km || w_kn) {
+    const int lay = (a_km ? 1 : 0) | (w_kn ? 2 : 0);
+    if (lay == 1) return launch_f32<MODE_EPI_NONE, false, 1>(p, nblk, vec, small, ng, s);
+    if (lay == 2) return launch_f32<MODE_EPI_NONE, false, 2>(p, nblk, vec, small, ng, s);
+    return launch_f32<MODE_EPI_NONE, false, 3>(p, nblk, vec, small, ng, s);
+  }
 #define MODE_CASE(E) \
-  case E: return ob ? launch_f32<E, true>(p, nblk, vec, ng, s) : launch_f32<E, false>(p, nblk, vec, ng, s);
+  case E: return ob ? launch_f32<E, true, 0>(p, nblk, vec, small, ng, s) : launch_f32<E, false, 0>(p, nblk, vec, small, ng, s);
   switch (d->epilogue) {
     MODE_CASE(MODE_EPI_NONE)
     MODE_CASE(MODE_EPI_BIAS)

@@ -86,7 +86,7 @@ __global__ void sample_experts_kernel(const float* __restrict__ probs, const flo
   for (int j = 0; j < k; ++j) { const float v = p[idx[(long)n * k + j]]; w[(long)n * k + j] = normalize ? v / s : v; }
 }
 
-// ---- training side channels of the routers (modedit.py:584-593, 816-820, 930-969), all layers in ONE single-workgroup launch:
+// ---- training side channels of the routers (modedit.py:584-593, 816-820, 930-969): one workgroup per layer + a one-wave pass for the layer means:
 //   frac[l,e]  = share of token rows routed to expert e            lb[l] = E * sum_e mean_n(rp[l,n,e]) * frac[l,e]   (rp = combine weights scattered)
 //   zl[l]      = mean_r (log(sum_e exp(shifted[l,r,e]) + 1e-6))^2  lb_mean / zl_mean = means over the layers
 //   mask[l,n,e] (optional) = 1 where token n uses expert e         usage[l,e] (optional, int64) += token rows per expert
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(1024) void moe_aux_stats_kernel(const int* __restri
   __shared__ float s_tot[33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long N = (long)R * tpr;
-  float lb_acc = 0.f, zl_acc = 0.f;
-  for (int l = 0; l < L; ++l) {
+  {
+    const int l = blockIdx.x;
     float cnt[16], ws[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { cnt[e] = 0.f; ws[e] = 0.f; }
@@ -133,7 +133,6 @@ __global__ __launch_bounds__(1024) void moe_aux_stats_kernel(const int* __restri
 #pragma unroll
     for (int e = 0; e < 16; ++e) { cnt[e] = wave_sum(cnt[e]); ws[e] = wave_sum(ws[e]); }
     z = wave_sum(z);
-    __syncthreads();                                                   // s_part / s_tot of the previous layer are no longer read
     if (lane == 0) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) { s_part[wave][e] = cnt[e]; s_part[wave][16 + e] = ws[e]; }
@@ -154,12 +153,18 @@ __global__ __launch_bounds__(1024) void moe_aux_stats_kernel(const int* __restri
         acc += (s_tot[16 + e] / (float)R) * f;
         if (usage) usage[(long)l * E + e] += (long long)(s_tot[e] + 0.5f) * tpr;
       }
-      const float lbl = (float)E * acc, zll = s_tot[32] / (float)Rs;
-      lb[l] = lbl; zl[l] = zll;
-      lb_acc += lbl; zl_acc += zll;
+      lb[l] = (float)E * acc; zl[l] = s_tot[32] / (float)Rs;
     }
   }
-  if (tid == 0) { *lb_mean = lb_acc / (float)L; *zl_mean = zl_acc / (float)L; }
+}
+
+// means over the layers, summed in layer order
+__global__ void moe_aux_means_kernel(const float* __restrict__ lb, const float* __restrict__ zl, int L, float* __restrict__ lb_mean,
+                                     float* __restrict__ zl_mean) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float lb_acc = 0.f, zl_acc = 0.f;
+  for (int l = 0; l < L; ++l) { lb_acc += lb[l]; zl_acc += zl[l]; }
+  *lb_mean = lb_acc / (float)L; *zl_mean = zl_acc / (float)L;
 }
 
 // ---- dispatch metadata: one workgroup per problem (layer); blockDim = 1024
@@ -315,8 +320,10 @@ extern "C" int mode_moe_aux_stats(const int32_t* idx, const float* w, int L, int
   if (!idx || !w || !shifted || !frac || !lb || !zl || !lb_mean || !zl_mean || L <= 0 || R <= 0 || Rs <= 0 || tokens_per_row <= 0 || E <= 0 || k <= 0 || k > E)
     return MODE_ERR_BAD_ARG;
   if (E > 16) return MODE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(moe_aux_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, idx, w, L, R, tokens_per_row, E, k, shifted, Rs, frac, lb, zl, lb_mean,
+  hipLaunchKernelGGL(moe_aux_stats_kernel, dim3(L), dim3(1024), 0, (hipStream_t)stream, idx, w, L, R, tokens_per_row, E, k, shifted, Rs, frac, lb, zl, lb_mean,
                      zl_mean, mask, (long long*)usage);
+  MODE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(moe_aux_means_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lb, zl, L, lb_mean, zl_mean);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }

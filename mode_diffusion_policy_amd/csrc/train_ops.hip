@@ -57,8 +57,18 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const T* __restrict_
   const int ra = o0 + sp * chunk, rb = min(o1, ra + chunk);
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
   float acc = 0.f;
-  if (c < cols)
-    for (int r = ra + ty; r < rb; r += 4) acc += ld1<T>(X + (long)r * ld + c);
+  if (c < cols) {
+    // eight rows per trip, all loads requested before the first add (a serial "acc += load" loop is one memory round trip per row); the adds keep
+    // the row order
+    for (int r = ra + ty; r < rb; r += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld1<T>(X + (long)min(r + 4 * u, rb - 1) * ld + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r + 4 * u < rb) acc += v[u];
+    }
+  }
   red[ty][threadIdx.x & 63] = acc;
   __syncthreads();
   if (ty == 0 && c < cols) {
@@ -430,12 +440,19 @@ __global__ __launch_bounds__(256) void router_w3_grad_kernel(const float* __rest
   float acc[EMAX];
 #pragma unroll
   for (int e = 0; e < EMAX; ++e) acc[e] = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float h = gelu_erf_f(pre[((long)b * L + l) * H2 + n]);
-    const float* dl = dlog + ((long)l * B + b) * E;
+  for (int b0 = 0; b0 < B; b0 += 8) {                                    // eight samples' loads in flight at once; fma order = sample order
+    float x[8];
 #pragma unroll
-    for (int e = 0; e < EMAX; ++e)
-      if (e < E) acc[e] = fmaf(dl[e], h, acc[e]);
+    for (int u = 0; u < 8; ++u) x[u] = pre[((long)min(b0 + u, B - 1) * L + l) * H2 + n];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (b0 + u >= B) break;
+      const float h = gelu_erf_f(x[u]);
+      const float* dl = dlog + ((long)l * B + b0 + u) * E;
+#pragma unroll
+      for (int e = 0; e < EMAX; ++e)
+        if (e < E) acc[e] = fmaf(dl[e], h, acc[e]);
+    }
   }
 #pragma unroll
   for (int e = 0; e < EMAX; ++e)
@@ -578,14 +595,28 @@ __global__ __launch_bounds__(256) void pos_emb_bwd_kernel(const float* __restric
   if (d >= D) return;
   const int t_img = t0 + 1, t_act = t_img + n_img;
   float acc = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float* row = dx0 + (long)b * T * D + d;
-    if (r == 0) acc += row[(long)t0 * D];
-    else if (r == 1) {
-      float v = row[(long)t_act * D];
-      for (int i = 0; i < n_img; ++i) v += row[(long)(t_img + i) * D];
-      acc += v;
-    } else acc += row[(long)(t_act + r - 1) * D];
+  const int tok = r == 0 ? t0 : (r == 1 ? t_act : t_act + r - 1), extra = r == 1 ? n_img : 0;
+  for (int b0 = 0; b0 < B; b0 += 16) {                                   // sixteen samples' loads in flight at once; the adds keep the sample order
+    float v[16], e0[16], e1[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = dx0[((long)min(b0 + u, B - 1) * T + tok) * D + d];
+    if (extra > 0) {                                                     // (workgroup-uniform: whole blocks of loads, no load behind a per-lane condition)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) e0[u] = dx0[((long)min(b0 + u, B - 1) * T + t_img) * D + d];
+    }
+    if (extra > 1) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) e1[u] = dx0[((long)min(b0 + u, B - 1) * T + t_img + 1) * D + d];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (b0 + u >= B) break;
+      float x = v[u];
+      if (extra > 0) x += e0[u];
+      if (extra > 1) x += e1[u];
+      for (int i = 2; i < extra; ++i) x += dx0[((long)(b0 + u) * T + t_img + i) * D + d];
+      acc += x;
+    }
   }
   dpos[(long)r * D + d] = acc;
 }
@@ -596,7 +627,14 @@ __global__ void sigma_embed_bwd_kernel(const float* __restrict__ de1, const floa
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= D) return;
   float a = 0.f, c = 0.f;
-  for (int b = 0; b < B; ++b) { const float g = de1[(long)b * D + d]; a += g * (logf(sigma[b]) / 4.0f); c += g; }
+  for (int b0 = 0; b0 < B; b0 += 16) {                                    // sixteen samples' loads in flight at once; the adds keep the sample order
+    float g[16], sg[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int b = min(b0 + u, B - 1); g[u] = de1[(long)b * D + d]; sg[u] = sigma[b]; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (b0 + u < B) { a += g[u] * (logf(sg[u]) / 4.0f); c += g[u]; }
+  }
   dw[d] = a; db[d] = c;
 }
 
