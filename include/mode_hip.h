@@ -68,6 +68,9 @@ const char* mode_hip_status_string(int status);
  * "gemm_tr_cfg": backward (transpose-read) GEMM geometry, 0 = auto, 1 = 128-wide ring-2, 2 = 64-wide ring-3, 3 = 128-wide ring-3,
  *   4 = 64-wide ring-2, 5 = 128-wide single-buffered, 6 = the persistent ping-pong kernel of gemm_bf16_pptr.hip (256 x 256 tiles, one workgroup per CU) for
  *   every shape it takes, 7 = auto without it.  Auto takes it for the large expert GEMMs of the training backward unless "bwd_coexec" is 1.
+ * "train_dn_split": 0 (default) / 1 = the training forward cuts the expert down-projection into the inference chain's K-slices (bf16 slabs added by the
+ *   combine kernels, forward and backward).  Measured equal at C2 / B = 128 (the 256-row ping-pong tile saves 14 us per layer, the backward combine re-reads four
+ *   slabs: +14 us): kept as a switch, off.
  * "fuse_swiglu_bwd": 1 (default) = mode_dit_backward runs the down-projection's data gradient and the SwishGLU (+ dropout) backward + bias-gradient sums as
  *   ONE launch (the dH tile never leaves the chip), 0 = GEMM + mode_swiglu_bwd_bias.
  * "conv_ns": LDS ring depth of the implicit-GEMM convolution kernel (csrc/conv_gemm.hip): 0 = auto (3 below two workgroups per CU), 2, 3.

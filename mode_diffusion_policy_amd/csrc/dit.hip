@@ -25,6 +25,7 @@ extern int g_gemm_mid_rows;
 extern int g_gemm_mid_rows_rn;
 extern int g_tr_cfg;
 extern int g_bwd_coexec;
+int g_train_dn_split = 0;    // "train_dn_split" option: 1 = the training forward cuts the expert down-projection into the inference chain's K-slices (bf16 slabs)
 int g_fuse_swiglu_bwd = 1;   // "fuse_swiglu_bwd" option: 1 = the training backward runs dH = dY W2 and the SwishGLU backward as one launch
 extern int g_conv_ns;
 extern int g_gemm_group_m;
@@ -70,7 +71,7 @@ int g_dn_split_k = 0;   // "dn_split_k" option: K-slices of the inference-path e
 // 128x128 tiles; 540 -> 549 denoise-steps/s in the chain), at B=32 twice the workgroups of two slices (19.0 vs 21.9 us).  The slice count is
 // the same for EVERY batch size so that a sample's result does not depend on how many samples share its batch (bit-exact batch-slice
 // consistency, tests/test_gpu_model.py::test_c2_full_size_properties).
-static int down_proj_split(int dt, int K) {
+int down_proj_split(int dt, int K) {          // also the training forward (dit_train.hip): same slices, same combine
   if (dt != MODE_BF16) return 1;
   int s = g_dn_split_k > 0 ? g_dn_split_k : 4;
   while (s > 1 && K % (64 * s)) s /= 2;
@@ -119,6 +120,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_tr_cfg")) { g_tr_cfg = value; return MODE_OK; }
   if (!strcmp(key, "bwd_coexec")) { g_bwd_coexec = value != 0; return MODE_OK; }
   if (!strcmp(key, "fuse_swiglu_bwd")) { g_fuse_swiglu_bwd = value != 0; return MODE_OK; }
+  if (!strcmp(key, "train_dn_split")) { g_train_dn_split = value != 0; return MODE_OK; }
   if (!strcmp(key, "conv_ns")) { if (value != 0 && value != 2 && value != 3) return MODE_ERR_BAD_ARG; g_conv_ns = value; return MODE_OK; }
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return MODE_OK; }
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }

@@ -22,6 +22,11 @@ int attn_block_bwd_launch(const void* qkv, const float* q_gain, const float* k_g
                           int T, int H, int head_dim, float eps, uint32_t seed, float p_drop, float* dbias_partial, void* stream);   // attn.hip
 bool gemm_bf16_pptr_accepts(const ModeGemmDesc* d);                                      // gemm_bf16_pptr.hip: would mode_gemm take the ping-pong kernel?
 int gather_rows_bf16(const void* in, long ld_in, const int* rows, int n, int cols, void* out, long ld_out, hipStream_t s);   // gemm_bf16_pptr.hip
+int down_proj_split(int dt, int K);                                                      // dit.hip: K-slices of the expert down-projection (bf16 slabs)
+extern int g_train_dn_split;                                                             // "train_dn_split" option (dit.hip)
+static inline int train_dn_split(int dt, int K) { return g_train_dn_split ? down_proj_split(dt, K) : 1; }
+int combine_bwd_launch(const float* dy, const void* Y, int y_dtype, int y_splits, long y_split_stride, const int32_t* pos, const float* posw, int N, int D, int k,
+                       void* dYs, float* dw, void* stream);                               // train_ops.hip
 }
 
 namespace {
@@ -100,7 +105,8 @@ extern "C" int mode_dit_train_stash_layout(const ModeDims* dims, int B, int dtyp
   const size_t N = (size_t)B * dims->T, NK = N * dims->k, D = dims->D;
   Take t;
   out->x0 = t(N * D * 4); out->h1 = t(N * D * esz); out->qkv = t(N * 3 * D * esz); out->yattn = t(N * D * esz); out->x1 = t(N * D * 4);
-  out->ub = t(N * D * esz); out->P = t(NK * 8 * D * esz); out->Hd = t(NK * 4 * D * esz); out->Y = t(NK * D * esz);
+  // Y: the down-projection's split-K slabs (the inference chain's tiling: one 256-row x 256 x 1024 tile per CU; the combine kernels add the slabs)
+  out->ub = t(N * D * esz); out->P = t(NK * 8 * D * esz); out->Hd = t(NK * 4 * D * esz); out->Y = t(NK * D * esz * (size_t)train_dn_split(dtype, 4 * (int)D));
   out->layer_stride = t.o;
   Take g;
   out->xL = g(N * D * 4); out->yL = g(N * D * 4); out->u_tmp = g(N * D * 4);
@@ -134,6 +140,7 @@ static int forward_train_impl(const ModeDims* dims, const ModeModelWeights* w, c
   rc = mode_dit_train_stash_layout(dims, B, dt, &sl);
   if (rc) return rc;
   if (stash_bytes < sl.total_bytes) return MODE_ERR_WORKSPACE;
+  const int ysplit = train_dn_split(dt, 4 * D);
   char* sg = (char*)stash;
   auto L_ = [&](int l) { return sg + sl.global_bytes + (size_t)l * sl.layer_stride; };
   float* u_tmp = (float*)(sg + sl.u_tmp);
@@ -189,10 +196,11 @@ static int forward_train_impl(const ModeDims* dims, const ModeModelWeights* w, c
       if ((rc = mode_swiglu_fwd(S + sl.P, S + sl.Hd, NK, 4 * D, dt, mode_stream_seed(a->seed, 2 * l + 1), a->mlp_pdrop, stream))) return rc;
       g = gdesc(dt, MODE_EPI_NONE, dt, NK, D, 4 * D, S + sl.Hd, 4 * D, lw.w2, 4 * D, S + sl.Y, D);
       g.w_expert_stride = 4L * D * D; g.expert_offsets = meta + ml.offsets; g.num_experts = d.E;
+      g.split_k = ysplit; g.split_stride = (long)NK * D;
       if ((rc = mode_gemm(&g, stream))) return rc;
       const bool last = l + 1 == d.L;
       float* xn = last ? (float*)(sg + sl.xL) : (float*)(L_(l + 1) + sl.x0);
-      rc = mode_moe_combine_norm_fwd(u_tmp, S + sl.Y, dt, 1, 0, meta + ml.pos, reinterpret_cast<const float*>(meta + ml.posw), N, D, d.k,
+      rc = mode_moe_combine_norm_fwd(u_tmp, S + sl.Y, dt, ysplit, (long)NK * D, meta + ml.pos, reinterpret_cast<const float*>(meta + ml.posw), N, D, d.k,
                                      last ? nullptr : w->layers[l + 1].ln1_g, last ? nullptr : a->cond, T, d.eps, xn,
                                      last ? nullptr : (void*)(L_(l + 1) + sl.h1), dt, stream);
       if (rc) return rc;
@@ -302,7 +310,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     const int32_t* offsets = meta + ml.offsets; const int32_t* poff = meta + ml.poffsets; const int32_t* prow = meta + ml.prow;
     const int32_t* pos = meta + ml.pos; const float* posw = reinterpret_cast<const float*>(meta + ml.posw);
     // (1) combine backward: dY (sorted rows) and router-weight gradients
-    if ((rc = mode_moe_combine_bwd(DXa, S + sl.Y, dt, pos, posw, N, D, d.k, dYs, dwt + (size_t)l * NK, stream))) return rc;
+    if ((rc = combine_bwd_launch(DXa, S + sl.Y, dt, train_dn_split(dt, 4 * D), (long)NK * D, pos, posw, N, D, d.k, dYs, dwt + (size_t)l * NK, stream))) return rc;
     // (1b) token routing: this block's router, back-propagated in place - its input is the block's own ln_2 output, so d u gets a second term
     const float* du_router = nullptr;
     if (tokr) {

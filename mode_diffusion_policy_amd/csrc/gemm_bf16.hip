@@ -469,10 +469,11 @@ static int pick_cfg(const ModeGemmDesc* d, bool allow_pp) {
   // of the experts with a nearly empty fifth tile (measured equal to the ring kernels, scripts/ragged_pp_probe.py), 256-row tiles cover the same rows in
   // four - the up-projection of the training forward is 512 tiles = exactly two rounds: 88.9 -> 73.1 us.  Taken when the expected tile count (segment
   // lengths within 6 % of their mean) fills whole rounds of the part; anything else stays on the ring kernels.
-  if (allow_pp && d->expert_offsets && !(d->flags & MODE_GEMM_UNIFORM_GROUPS) && d->num_experts > 0 && d->split_k <= 1 &&
+  // (K-slices multiply the tiles: the training forward's down-projection in four slices is 4 experts x 4 row tiles x 4 x 4 = 256 = one tile per CU)
+  if (allow_pp && d->expert_offsets && !(d->flags & MODE_GEMM_UNIFORM_GROUPS) && d->num_experts > 0 &&
       (d->epilogue == MODE_EPI_NONE || d->epilogue == MODE_EPI_BIAS) && d->N % 256 == 0) {
     const long per = (long)((double)rows / d->num_experts * 1.06) + 1;
-    const long t4 = (long)d->num_experts * ((per + 255) / 256) * (d->N / 256);
+    const long t4 = (long)d->num_experts * ((per + 255) / 256) * (d->N / 256) * (d->split_k > 1 ? d->split_k : 1);
     const long ncu = pp_num_cus();                              // one persistent workgroup per CU: a "round" is one tile on every CU of THIS part
     const long rounds = (t4 + ncu - 1) / ncu;
     if (t4 >= ncu && t4 * 10 >= rounds * ncu * 9) return CFG_PP256;

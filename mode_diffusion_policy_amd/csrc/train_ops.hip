@@ -342,11 +342,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------ combine bwd
-// one wave per token: dYs[pos[t,j]] = posw[t,j] * dy[t]  (lp), dw[t,j] = <dy[t], Y[pos[t,j]]>
+// one wave per token: dYs[pos[t,j]] = posw[t,j] * dy[t]  (lp), dw[t,j] = <dy[t], Y[pos[t,j]]>.  Y may come as nsp split-K slabs (sp_stride elements
+// apart) of the down-projection: added in slice order in fp32, like the forward combine adds them.
 template <typename T>
-__global__ __launch_bounds__(256) void combine_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ Y, const int* __restrict__ pos,
-                                                          const float* __restrict__ posw, int N, int D, int k, T* __restrict__ dYs,
-                                                          float* __restrict__ dw) {
+__global__ __launch_bounds__(256) void combine_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ Y, int nsp, long sp_stride,
+                                                          const int* __restrict__ pos, const float* __restrict__ posw, int N, int D, int k,
+                                                          T* __restrict__ dYs, float* __restrict__ dw) {
   const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= N) return;
   for (int j = 0; j < k; ++j) {
@@ -356,15 +357,21 @@ __global__ __launch_bounds__(256) void combine_bwd_kernel(const float* __restric
     for (int d = lane * 4; d < D; d += 256) {
       const float4 g = *reinterpret_cast<const float4*>(dy + (long)t * D + d);
       if constexpr (sizeof(T) == 2) {                               // bf16: one 8-byte load / store per lane instead of four 2-byte ones
-        const uint2 y2 = *reinterpret_cast<const uint2*>(Y + p * D + d);
-        acc += g.x * bf16_bits_to_f32(y2.x & 0xffff); acc += g.y * bf16_bits_to_f32(y2.x >> 16);
-        acc += g.z * bf16_bits_to_f32(y2.y & 0xffff); acc += g.w * bf16_bits_to_f32(y2.y >> 16);
+        uint2 y2 = *reinterpret_cast<const uint2*>(Y + p * D + d);
+        float y0 = bf16_bits_to_f32(y2.x & 0xffff), y1 = bf16_bits_to_f32(y2.x >> 16), y2f = bf16_bits_to_f32(y2.y & 0xffff), y3 = bf16_bits_to_f32(y2.y >> 16);
+        for (int sp = 1; sp < nsp; ++sp) {
+          y2 = *reinterpret_cast<const uint2*>(Y + sp * sp_stride + p * D + d);
+          y0 += bf16_bits_to_f32(y2.x & 0xffff); y1 += bf16_bits_to_f32(y2.x >> 16); y2f += bf16_bits_to_f32(y2.y & 0xffff); y3 += bf16_bits_to_f32(y2.y >> 16);
+        }
+        acc += g.x * y0; acc += g.y * y1; acc += g.z * y2f; acc += g.w * y3;
         *reinterpret_cast<uint2*>(dYs + p * D + d) = make_uint2(pack_bf16x2(w * g.x, w * g.y), pack_bf16x2(w * g.z, w * g.w));
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float gv = (&g.x)[c];
-          acc += gv * ld1<T>(Y + p * D + d + c);
+          float yv = ld1<T>(Y + p * D + d + c);
+          for (int sp = 1; sp < nsp; ++sp) yv += ld1<T>(Y + sp * sp_stride + p * D + d + c);
+          acc += gv * yv;
           st1<T>(dYs + p * D + d + c, w * gv);
         }
       }
@@ -758,16 +765,25 @@ extern "C" int mode_rmsnorm_bwd(const float* x, const float* g, const float* dy_
   return mode::rmsnorm_bwd_launch(x, g, dy_a, dy_b, G, 1, 0, pos, k, rows, D, eps, dx, accumulate, dg_partial, dy_out, dx_lp, lp_dtype, (hipStream_t)stream);
 }
 
-extern "C" int mode_moe_combine_bwd(const float* dy, const void* Y, int y_dtype, const int32_t* pos, const float* posw, int N, int D, int k,
-                                    void* dYs, float* dw, void* stream) {
-  if (!dy || !Y || !pos || !posw || !dYs || !dw || N < 0 || D <= 0 || (D & 3) || k <= 0) return MODE_ERR_BAD_ARG;
+namespace mode {
+int combine_bwd_launch(const float* dy, const void* Y, int y_dtype, int y_splits, long y_split_stride, const int32_t* pos, const float* posw, int N, int D, int k,
+                       void* dYs, float* dw, void* stream) {
+  if (!dy || !Y || !pos || !posw || !dYs || !dw || N < 0 || D <= 0 || (D & 3) || k <= 0 || y_splits < 1) return MODE_ERR_BAD_ARG;
   if (N == 0) return MODE_OK;
   if (y_dtype == MODE_BF16)
-    hipLaunchKernelGGL(combine_bwd_kernel<uint16_t>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (const uint16_t*)Y, pos, posw, N, D, k, (uint16_t*)dYs, dw);
+    hipLaunchKernelGGL(combine_bwd_kernel<uint16_t>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (const uint16_t*)Y, y_splits, y_split_stride, pos, posw, N, D,
+                       k, (uint16_t*)dYs, dw);
   else
-    hipLaunchKernelGGL(combine_bwd_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (const float*)Y, pos, posw, N, D, k, (float*)dYs, dw);
+    hipLaunchKernelGGL(combine_bwd_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (const float*)Y, y_splits, y_split_stride, pos, posw, N, D, k,
+                       (float*)dYs, dw);
   MODE_LAUNCH_CHECK();
   return MODE_OK;
+}
+}  // namespace mode
+
+extern "C" int mode_moe_combine_bwd(const float* dy, const void* Y, int y_dtype, const int32_t* pos, const float* posw, int N, int D, int k,
+                                    void* dYs, float* dw, void* stream) {
+  return mode::combine_bwd_launch(dy, Y, y_dtype, 1, 0, pos, posw, N, D, k, dYs, dw, stream);
 }
 
 extern "C" int mode_rowcopy_f32(const float* src, int64_t ld_src, int s0, int sstride, const int32_t* sidx, float* dst, int64_t ld_dst, int d0,

@@ -570,6 +570,43 @@ def test_ragged_grouped_gemm_256_row_pingpong_tile(counts, epi):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("counts", [(871, 925, 903, 885), (896, 896, 896, 896), (2000, 0, 1500, 84), (1030, 1024, 770, 760)])
+def test_ragged_down_projection_in_k_slices_on_the_256_row_pingpong_tile(counts):
+    """The training forward's expert down-projection [NK, 4D] x [D, 4D]^T with ragged segments in FOUR K-slices (bf16 slabs, as the inference chain cuts it):
+    the heuristic takes the 256-row ping-pong tile (4 experts x 4 row tiles x 4 column tiles x 4 slices = one tile per CU).  Every slab bit-identical to the
+    ring kernels' and to the forced 256-row tile; the slab sum correct against fp32 torch; slabs NaN-prefilled."""
+    import ctypes as C
+    from hip_helpers import p, stream
+    lib = L.load()
+    E, K, N, S = 4, 4096, 1024, 4
+    M = sum(counts)
+    torch.manual_seed(M)
+    A = (torch.randn(M, K) * 0.5).to(torch.bfloat16).to(dev())
+    W = (torch.randn(E, N, K) * K ** -0.5).to(torch.bfloat16).to(dev())
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=dev())
+    outs = {}
+    for cfg in (0, 1, 18):
+        Y = torch.full((S, M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+        d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=M, N=N, K=K, A=p(A), lda=K, W=p(W), ldw=K, w_expert_stride=N * K,
+                           C=p(Y), ldc=N, expert_offsets=p(off), num_experts=E, split_k=S, split_stride=M * N)
+        lib.mode_set_option(b"gemm_cfg", cfg)
+        try:
+            L.check(lib.mode_gemm(C.byref(d), stream()), "gemm")
+        finally:
+            lib.mode_set_option(b"gemm_cfg", 0)
+        torch.cuda.synchronize()
+        outs[cfg] = Y
+    ref = torch.empty(M, N)
+    lo = 0
+    for e, c in enumerate(counts):
+        ref[lo:lo + c] = A[lo:lo + c].float().cpu() @ W[e].float().cpu().t()
+        lo += c
+    assert rel(outs[0].float().sum(0), ref) < 6e-3
+    for cfg in (1, 18):
+        assert torch.equal(outs[cfg].view(torch.int16), outs[0].view(torch.int16)), cfg
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M", [33, 100, 448, 512, 513])
 def test_residual_norm_epilogue_no_k_loop_kernel_is_bit_identical_to_the_ring(M):
     """MODE_EPI_RESIDUAL_NORM (c_proj + residual + first half of ln_2) on the register-resident-weights kernel (rollout batch sizes, "gemm_mid_rows_rn") against

@@ -628,3 +628,32 @@ def test_fused_swiglu_backward_epilogue_matches_the_two_kernel_path():
     assert worst[0] < 1e-2
     b1 = [n for n in grads[0] if "experts" in n and n.endswith("bias")]
     assert b1 and all(rel(grads[1][n], grads[0][n]) < 5e-3 for n in b1)
+
+
+@pytest.mark.gpu
+def test_training_forward_with_the_down_projection_in_k_slices():
+    """`train_dn_split` = 1: the training forward cuts the expert down-projection into the inference chain's K-slices (bf16 slabs; the forward combine and the
+    backward combine - the router-weight gradients <dy, Y> - add them in slice order) against the one-slab default on the same stochastic step: loss and every
+    gradient agree to the bf16 rounding of the partial slabs."""
+    from mode_diffusion_policy_amd import _lib as L
+    lib = L.load()
+    out = {}
+    for flag in (1, 0):
+        torch.manual_seed(11)
+        cfg, sd, m = build_train("c1e4", 210, "bf16", attn_pdrop=0.3, mlp_pdrop=0.1, goal_drop=0.0, use_argmax=False)
+        inp = make_inputs(cfg, 40, 91)
+        sig = O.rand_log_logistic((40,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(5))
+        c = {k: v.cuda() for k, v in inp.items()}
+        den = M.GCDenoiser(m, 0.5).train()
+        lib.mode_set_option(b"train_dn_split", flag)
+        try:
+            loss, _ = den.loss({"state_images": c["state_images"]}, c["actions"], c["goals"], c["noise"], sig.cuda())
+            loss.backward()
+        finally:
+            lib.mode_set_option(b"train_dn_split", 0)
+        out[flag] = (float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert abs(out[1][0] - out[0][0]) < 2e-3 * abs(out[0][0])
+    assert out[0][1].keys() == out[1][1].keys()
+    worst = max((rel(out[1][1][n], out[0][1][n]), n) for n in out[0][1] if float(out[0][1][n].norm()) > 0)
+    print("K-sliced down-projection vs one slab, worst tensor:", worst)
+    assert worst[0] < 2e-2
