@@ -27,12 +27,15 @@ struct GemmF32Params {
 // LAYOUT bit 0: A given as [K][M] row-major, bit 1: W given as [K][N] row-major (backward-pass layouts, see MODE_GEMM_A_KM / W_KN).
 // SMALL: 32x32 tile (one 16x16 accumulator per wave) with 128 k per LDS fill - for products with fewer 64x64 tiles than CUs, where the serial
 // MFMA chain of an accumulator (K/4 instructions of 32 cycles) times the accumulators per wave is the run time.
-// LDS image of a fill: [tile row][FLD], the 16 k of a sub-step stored 4x4-transposed (position 4*(k%4) + k/4): lane (row fr, k-group fq) of an MFMA
-// operand reads ONE 16-byte word holding k = fq, 4+fq, 8+fq, 12+fq - its values for the sub-step's four MFMAs, i.e. the same k-ascending chain as
-// four 4-byte reads of a row-major image.  Row stride FLD = k-per-fill + 4 floats: rows 4 banks apart, the 16 rows of a fragment cover all 64.
+// LDS image of a fill: [tile row][KF], the 16 k of a sub-step u stored 4x4-transposed as four 16-byte chunks c = k % 4 holding k/4 = 0..3: lane (row fr,
+// k-group fq) of an MFMA operand reads ONE chunk = its values for the sub-step's four MFMAs, i.e. the same k-ascending chain as four 4-byte reads of a
+// row-major image.  Chunk (u, c) of row r lies at slot (4u + c) ^ (r & 15) of the row: the 16-lane groups in which ds_read_b128 is served (MI355X_MICROARCH.md
+// "LDS": each holds every fragment row once, with two different fq) then hit 16 different 16-byte slots, and the staging maps below make every 32-lane group of
+// a ds_write_b32 hit 32 different banks for both operand layouts (a padded row-major image measured 50 % - [rows][K] - to 80 % - [K][cols] - of its LDS
+// cycles as bank conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
 template <int EPI, bool OUT_BF16, bool VEC, int LAYOUT, bool SMALL>
 __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
-  constexpr int TM = SMALL ? 32 : 64, TN = TM, FSUB = SMALL ? 8 : 4, KF = FSUB * FBK, FLD = KF + 4;
+  constexpr int TM = SMALL ? 32 : 64, TN = TM, FSUB = SMALL ? 8 : 4, KF = FSUB * FBK, FLD = KF;
   constexpr int MI = TM / 32, NJ = TN / 32, QR = KF / 4, RS = FNT / QR, NL = TM * QR / FNT;        // NL float4 per thread, operand and fill
   constexpr int CQ = TM / 4, KS = FNT / CQ;                                                        // [K][cols] staging: column quads per k row, k rows per step
   constexpr bool A_KM = (LAYOUT & 1) != 0, W_KN = (LAYOUT & 2) != 0;
@@ -68,10 +71,17 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
   const int nk = (kend - kbeg + FBK - 1) / FBK;                          // 16-wide sub-steps
   const int nfill = (nk + FSUB - 1) / FSUB;
 
-  // ---- staging.  [rows][K] operand: float4 number tid + 256 i of a fill = tile row r0 + RS i, k quad qd (a row's KF floats are read by QR adjacent
-  // lanes).  [K][cols] operand: k row kl0 + KS i of the fill, column quad cq (a k row's tile columns are read by CQ adjacent lanes).
-  const int qd = tid % QR, r0 = tid / QR;
-  const int cq = tid % CQ, kl0 = tid / CQ;
+  // ---- staging.  A thread moves NL float4 per operand and fill; step i covers RS tile rows ([rows][K] operand) / KS k rows ([K][cols] operand).
+  // [rows][K]: a 32-lane group = 4 rows x 8 adjacent k quads (128 B of each row), lane bits {q = quad & 3, sub-step bit 0, row & 3}: the four dwords a
+  // lane stores (k = 4 quad + j -> chunk j, dword q) land on banks 16 (u ^ r>>2 & 1) + 4 (j ^ r & 3) + q - all 32 different.
+  // [K][cols]: a 32-lane group = 16 k rows x 2 adjacent column quads, so that dword (k>>2 & 3) of chunk (k & 3) of rows 4 cq + j covers 32 banks too
+  // (lanes along the columns, as coalescing alone would have it, put 32 lanes on 4 banks).
+  constexpr int UB = QR / 8;                                             // values of (sub-step >> 1)
+  const int l5 = tid & 31, hi5 = tid >> 5;
+  const int q_ = l5 & 3, su = ((l5 >> 2) & 1) + 2 * (hi5 % UB), qd = 4 * su + q_, r0 = (l5 >> 3) + 4 * (hi5 / UB);
+  const int cq = (tid >> 4) % CQ, kl0 = (tid & 15) + 16 * (tid / (16 * CQ));
+  const int rj = r0 & 3, kj = kl0 & 3;                                   // XOR term of the element-j chunk: constant over the steps
+  auto chunk_base = [](int u, int x) { return 4 * (((u >> 2) << 4) | (((u & 3) ^ (x & 3)) << 2)); };   // dword offset of chunk (u, c = 0 ^ ...) before the c term
   const float* a_ptr[NL]; const float* b_ptr[NL];
   int a_lds[NL], b_lds[NL];
 #pragma unroll
@@ -81,26 +91,26 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
       int c = row0 + 4 * cq;
       if constexpr (VEC) c = max(min(c, p.M - 4), 0);                     // columns past M feed rows that are never stored: any in-bounds address will do
       a_ptr[i] = p.A + (long)kl * p.lda + c;
-      a_lds[i] = 4 * cq * FLD + (kl & ~15) + 4 * (kl & 3) + ((kl >> 2) & 3);
+      a_lds[i] = 4 * cq * FLD + chunk_base(kl >> 4, cq) + ((kl >> 2) & 3);
     } else {
-      const int s = min(row0 + r0 + RS * i, row_end - 1);
+      const int t = r0 + RS * i, s = min(row0 + t, row_end - 1);
       const long arow = p.a_rows ? (long)p.a_rows[s] : (long)s;
       a_ptr[i] = p.A + arow * p.lda + 4 * qd;
-      a_lds[i] = (r0 + RS * i) * FLD + (qd >> 2) * 16 + (qd & 3);
+      a_lds[i] = t * FLD + chunk_base(su, t >> 2) + q_;
     }
     if constexpr (W_KN) {
       const int kl = kl0 + KS * i;
       int c = n0 + 4 * cq;
       if constexpr (VEC) c = max(min(c, p.N - 4), 0);
       b_ptr[i] = W + (long)kl * p.ldw + c;
-      b_lds[i] = 4 * cq * FLD + (kl & ~15) + 4 * (kl & 3) + ((kl >> 2) & 3);
+      b_lds[i] = 4 * cq * FLD + chunk_base(kl >> 4, cq) + ((kl >> 2) & 3);
     } else {
       const int t = r0 + RS * i;
       long brow;
       if constexpr (EPI == MODE_EPI_SWIGLU) brow = (long)min(n0 + (t & 31), p.N - 1) + ((t >= 32) ? p.N : 0);
       else brow = min(n0 + t, p.N - 1);
       b_ptr[i] = W + brow * p.ldw + 4 * qd;
-      b_lds[i] = t * FLD + (qd >> 2) * 16 + (qd & 3);
+      b_lds[i] = t * FLD + chunk_base(su, t >> 2) + q_;
     }
   }
 
@@ -111,16 +121,19 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
-  int a_row[MI], b_row[NJ];
+  int a_row[MI], b_row[NJ];                                              // fragment row + this lane's chunk term 4 (fq ^ (fr & 3))
 #pragma unroll
-  for (int i = 0; i < MI; ++i) a_row[i] = (wm * (TM / 2) + i * 16 + fr) * FLD + 4 * fq;
+  for (int i = 0; i < MI; ++i) a_row[i] = (wm * (TM / 2) + i * 16 + fr) * FLD + 4 * (fq ^ (fr & 3));
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     int br;
     if constexpr (EPI == MODE_EPI_SWIGLU) br = (j == 0) ? wn * 16 : 32 + wn * 16;
     else br = wn * (TN / 2) + j * 16;
-    b_row[j] = (br + fr) * FLD + 4 * fq;
+    b_row[j] = (br + fr) * FLD + 4 * (fq ^ (fr & 3));
   }
+  int xoff[4];                                                           // sub-step term 16 ((u & 3) ^ (fr >> 2)); u >> 2 adds 64
+#pragma unroll
+  for (int v = 0; v < 4; ++v) xoff[v] = 16 * (v ^ (fr >> 2));
 
   float4 ra[NL], rb[NL];
   // one operand's NL float4 of fill `st`.  FULL: the fill lies inside [kbeg, kend) - every load unconditional, all of them issued back to back (a load
@@ -168,17 +181,18 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
   auto commit = [&]() {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      if constexpr (A_KM) { float* a = &sA[a_lds[i]]; a[0] = ra[i].x; a[FLD] = ra[i].y; a[2 * FLD] = ra[i].z; a[3 * FLD] = ra[i].w; }
-      else { float* a = &sA[a_lds[i]]; a[0] = ra[i].x; a[4] = ra[i].y; a[8] = ra[i].z; a[12] = ra[i].w; }
-      if constexpr (W_KN) { float* b = &sB[b_lds[i]]; b[0] = rb[i].x; b[FLD] = rb[i].y; b[2 * FLD] = rb[i].z; b[3 * FLD] = rb[i].w; }
-      else { float* b = &sB[b_lds[i]]; b[0] = rb[i].x; b[4] = rb[i].y; b[8] = rb[i].z; b[12] = rb[i].w; }
+      // element j of a float4: [K][cols] - tile row 4 cq + j, chunk (k & 3) ^ j;  [rows][K] - chunk j ^ (row & 3) of the thread's row
+      if constexpr (A_KM) { float* a = &sA[a_lds[i]]; a[4 * kj] = ra[i].x; a[FLD + 4 * (kj ^ 1)] = ra[i].y; a[2 * FLD + 4 * (kj ^ 2)] = ra[i].z; a[3 * FLD + 4 * (kj ^ 3)] = ra[i].w; }
+      else { float* a = &sA[a_lds[i]]; a[4 * rj] = ra[i].x; a[4 * (rj ^ 1)] = ra[i].y; a[4 * (rj ^ 2)] = ra[i].z; a[4 * (rj ^ 3)] = ra[i].w; }
+      if constexpr (W_KN) { float* b = &sB[b_lds[i]]; b[4 * kj] = rb[i].x; b[FLD + 4 * (kj ^ 1)] = rb[i].y; b[2 * FLD + 4 * (kj ^ 2)] = rb[i].z; b[3 * FLD + 4 * (kj ^ 3)] = rb[i].w; }
+      else { float* b = &sB[b_lds[i]]; b[4 * rj] = rb[i].x; b[4 * (rj ^ 1)] = rb[i].y; b[4 * (rj ^ 2)] = rb[i].z; b[4 * (rj ^ 3)] = rb[i].w; }
     }
   };
   auto frag = [&](int u, float4 (&a)[MI], float4 (&b)[NJ]) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float4*>(&sA[a_row[i] + u * 16]);
+    for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float4*>(&sA[a_row[i] + (u >> 2) * 64 + xoff[u & 3]]);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const float4*>(&sB[b_row[j] + u * 16]);
+    for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const float4*>(&sB[b_row[j] + (u >> 2) * 64 + xoff[u & 3]]);
   };
   auto mfmas = [&](const float4 (&a)[MI], const float4 (&b)[NJ]) {
 #pragma unroll
@@ -212,10 +226,13 @@ __global__ __launch_bounds__(FNT) void gemm_f32_kernel(const GemmF32Params p) {
         for (int j = 0; j < NJ; ++j) bc[j] = bn[j];
       }
     } else {
-      for (int u = 0; u < nsub; ++u) {
-        float4 ac[MI], bc[NJ];
-        frag(u, ac, bc);
-        mfmas(ac, bc);
+#pragma unroll
+      for (int u = 0; u < FSUB; ++u) {                                   // (u stays a compile-time index of the chunk offsets)
+        if (u < nsub) {
+          float4 ac[MI], bc[NJ];
+          frag(u, ac, bc);
+          mfmas(ac, bc);
+        }
       }
     }
     __syncthreads();
