@@ -171,6 +171,49 @@ def test_gemm_f32(M, N, K, epi):
         assert rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("K", [64, 1000, 1024, 2112])
+def test_gemm_f32_result_does_not_depend_on_tile_or_operand_layout(K):
+    """gemm_f32.hip picks 32 x 32 tiles (128-k LDS fills) for products with few tiles and 64 x 64 (64-k fills) otherwise, and takes either operand as [rows][K] or
+    [K][cols]: an output element is the same k-ascending v_mfma_f32_16x16x4_f32 chain in every case - the same rows of A inside a larger product, and the same
+    product through the transposed-operand layouts (K-grouped: partial slabs), must give the same BITS.  Also K % 16 != 0 tails and a K that ends inside a fill."""
+    import ctypes as C
+    from hip_helpers import p, stream
+    lib = L.load()
+    N = 256
+    A = rnd(600, K, seed=5).to(dev()); W = rnd(N, K, seed=6, scale=K ** -0.5).to(dev())
+
+    def run(M, a=None, w=None, flags=0, **kw):
+        a = A if a is None else a; w = W if w is None else w
+        out = torch.full((kw.get("num_k_groups", 1), M, N), float("nan"), device=dev())
+        d = L.ModeGemmDesc(dtype=L.MODE_F32, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=M, N=N, K=K, A=p(a), lda=a.stride(0), W=p(w), ldw=w.stride(0), C=p(out), ldc=N,
+                           flags=flags, **kw)
+        L.check(lib.mode_gemm(C.byref(d), stream()), "gemm")
+        torch.cuda.synchronize()
+        return out
+    small, large = run(64)[0], run(600)[0]                       # 8 x 8 tiles of 32 x 32 against 10 x 4 tiles of 64 x 64
+    ref = A.double() @ W.double().t()
+    assert rel(large, ref.float()) < 1e-5
+    assert torch.equal(small.view(torch.int32), large[:64].view(torch.int32))
+    if K % 4 == 0:
+        At = A[:64].t().contiguous(); Wt = W.t().contiguous()     # [K][M], [K][N]
+        for flags, a, w in ((L.GEMM_W_KN, A[:64].contiguous(), Wt), (L.GEMM_A_KM | L.GEMM_W_KN, At, Wt), (L.GEMM_A_KM, At, W)):
+            assert torch.equal(run(64, a, w, flags)[0].view(torch.int32), small.view(torch.int32)), flags
+        # K-groups: the slab of group g is the chain over its own k range - equal to the plain product of that column range
+        ng = 4 if K % 16 == 0 else 0
+        if ng:
+            off = torch.arange(0, K + 1, K // ng, dtype=torch.int32, device=dev())
+            slabs = run(64, At, Wt, L.GEMM_A_KM | L.GEMM_W_KN, k_group_offsets=p(off), num_k_groups=ng, c_group_stride=64 * N)
+            for g in range(ng):
+                k0, k1 = g * (K // ng), (g + 1) * (K // ng)
+                a_g = A[:64, k0:k1].contiguous(); w_g = W[:, k0:k1].contiguous()
+                out = torch.full((64, N), float("nan"), device=dev())
+                d = L.ModeGemmDesc(dtype=L.MODE_F32, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=64, N=N, K=k1 - k0, A=p(a_g), lda=k1 - k0, W=p(w_g), ldw=k1 - k0,
+                                   C=p(out), ldc=N)
+                L.check(lib.mode_gemm(C.byref(d), stream()), "gemm")
+                torch.cuda.synchronize()
+                assert torch.equal(slabs[g].view(torch.int32), out.view(torch.int32)), g
+
+
 # ------------------------------------------------------------------------------------------------------------ row kernels
 @pytest.mark.parametrize("rows,D", [(7, 64), (1792, 1024), (112, 256)])
 def test_rmsnorm_cond(rows, D):
