@@ -77,6 +77,29 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const T* __restrict_
     else partial[((long)seg * nsplit + sp) * cols + c] = v;
   }
 }
+// Short fixed-length segments (the per-sample token sums of the conditioning gradient: 14 rows): one thread per (segment, 4 columns), every row of the
+// segment requested before the first add; the additions follow stage 1's order (rows r % 4 = 0..3 in four chains, then (s0 + s1) + (s2 + s3)) - same bits.
+template <int MAXR>
+__global__ __launch_bounds__(256) void colsum_shortseg_kernel(const float* __restrict__ X, long ld, int rows, int cols, int seg_len, float* __restrict__ out,
+                                                              int accumulate) {
+  const int c4 = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y;
+  if (c4 * 4 >= cols) return;
+  const int o0 = seg * seg_len, n = min(rows, o0 + seg_len) - o0;
+  float4 v[MAXR];
+#pragma unroll
+  for (int r = 0; r < MAXR; ++r) v[r] = *reinterpret_cast<const float4*>(X + (long)(o0 + min(r, n - 1)) * ld + c4 * 4);
+  float4 a[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int r = 0; r < MAXR; ++r)
+    if (r < n) { a[r & 3].x += v[r].x; a[r & 3].y += v[r].y; a[r & 3].z += v[r].z; a[r & 3].w += v[r].w; }
+  float4 s4 = make_float4((a[0].x + a[1].x) + (a[2].x + a[3].x), (a[0].y + a[1].y) + (a[2].y + a[3].y), (a[0].z + a[1].z) + (a[2].z + a[3].z),
+                          (a[0].w + a[1].w) + (a[2].w + a[3].w));
+  float4* o = reinterpret_cast<float4*>(out + (long)seg * cols + c4 * 4);
+  if (accumulate) { const float4 p = *o; s4.x = p.x + s4.x; s4.y = p.y + s4.y; s4.z = p.z + s4.z; s4.w = p.w + s4.w; }
+  *o = s4;
+}
 // stage 2: out[seg][col] (+)= sum over splits in order
 __global__ void colsum_stage2_kernel(const float* __restrict__ partial, int nseg, int nsplit, int cols, float* __restrict__ out, int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -682,6 +705,13 @@ extern "C" int mode_colsum(const void* X, int64_t ld, int rows, int cols, int dt
   if (!X || !out || rows < 0 || cols <= 0) return MODE_ERR_BAD_ARG;
   if (nseg < 1) nseg = 1;
   const int nsplit = colsum_nsplit(rows, cols, nseg);
+  if (nsplit == 1 && dtype == MODE_F32 && !seg_offsets && seg_len > 0 && seg_len <= 16 && nseg > 1 && cols % 4 == 0 && ld % 4 == 0 &&
+      (((uintptr_t)X | (uintptr_t)out) & 15) == 0 && (long)nseg * seg_len <= (long)rows + seg_len - 1) {
+    hipLaunchKernelGGL(colsum_shortseg_kernel<16>, dim3((cols / 4 + 255) / 256, nseg), dim3(256), 0, (hipStream_t)stream, (const float*)X, (long)ld, rows, cols, seg_len, out,
+                       accumulate);
+    MODE_LAUNCH_CHECK();
+    return MODE_OK;
+  }
   if (nsplit > 1 && (!workspace || workspace_bytes < (size_t)nseg * nsplit * cols * 4)) return MODE_ERR_WORKSPACE;   // single-stage sums need none
   float* partial = (float*)workspace;
   const dim3 grid((cols + 63) / 64, nsplit, nseg);
@@ -765,11 +795,54 @@ extern "C" int mode_rmsnorm_bwd(const float* x, const float* g, const float* dy_
   return mode::rmsnorm_bwd_launch(x, g, dy_a, dy_b, G, 1, 0, pos, k, rows, D, eps, dx, accumulate, dg_partial, dy_out, dx_lp, lp_dtype, (hipStream_t)stream);
 }
 
+// bf16, one slab, D = 256 NIT, k <= KMAX: the slot indices, then every Y / dy load of the token are requested before the first use (the generic kernel walks
+// j and d serially: k x D/256 dependent round trips, 9 us for 7 MB at C2); per (t, j) the same lane-strided fma chain + butterfly as above - same bits.
+template <int NIT, int KMAX>
+__global__ __launch_bounds__(256) void combine_bwd_bf16_kernel(const float* __restrict__ dy, const uint16_t* __restrict__ Y, const int* __restrict__ pos,
+                                                               const float* __restrict__ posw, int N, int k, uint16_t* __restrict__ dYs, float* __restrict__ dw) {
+  constexpr int D = 256 * NIT;
+  const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= N) return;
+  long pj[KMAX]; float wj[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) { const int jj = min(j, k - 1); pj[j] = pos[(long)t * k + jj]; wj[j] = posw[(long)t * k + jj]; }
+  float4 g[NIT]; uint2 y[KMAX][NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) g[it] = *reinterpret_cast<const float4*>(dy + (long)t * D + it * 256 + lane * 4);
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) y[j][it] = *reinterpret_cast<const uint2*>(Y + pj[j] * D + it * 256 + lane * 4);
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    if (j >= k) break;
+    float acc = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const float4 gv = g[it]; const uint2 y2 = y[j][it];
+      acc += gv.x * bf16_bits_to_f32(y2.x & 0xffff); acc += gv.y * bf16_bits_to_f32(y2.x >> 16);
+      acc += gv.z * bf16_bits_to_f32(y2.y & 0xffff); acc += gv.w * bf16_bits_to_f32(y2.y >> 16);
+      *reinterpret_cast<uint2*>(dYs + pj[j] * D + it * 256 + lane * 4) = make_uint2(pack_bf16x2(wj[j] * gv.x, wj[j] * gv.y), pack_bf16x2(wj[j] * gv.z, wj[j] * gv.w));
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dw[(long)t * k + j] = acc;
+  }
+}
+
 namespace mode {
 int combine_bwd_launch(const float* dy, const void* Y, int y_dtype, int y_splits, long y_split_stride, const int32_t* pos, const float* posw, int N, int D, int k,
                        void* dYs, float* dw, void* stream) {
   if (!dy || !Y || !pos || !posw || !dYs || !dw || N < 0 || D <= 0 || (D & 3) || k <= 0 || y_splits < 1) return MODE_ERR_BAD_ARG;
   if (N == 0) return MODE_OK;
+  if (y_dtype == MODE_BF16 && y_splits == 1 && k <= 2 && (D == 1024 || D == 512 || D == 256) && ((((uintptr_t)dy) & 15) | (((uintptr_t)Y | (uintptr_t)dYs) & 7)) == 0) {
+    const dim3 grid((N + 3) / 4), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 1024) hipLaunchKernelGGL((combine_bwd_bf16_kernel<4, 2>), grid, blk, 0, s, dy, (const uint16_t*)Y, pos, posw, N, k, (uint16_t*)dYs, dw);
+    else if (D == 512) hipLaunchKernelGGL((combine_bwd_bf16_kernel<2, 2>), grid, blk, 0, s, dy, (const uint16_t*)Y, pos, posw, N, k, (uint16_t*)dYs, dw);
+    else hipLaunchKernelGGL((combine_bwd_bf16_kernel<1, 2>), grid, blk, 0, s, dy, (const uint16_t*)Y, pos, posw, N, k, (uint16_t*)dYs, dw);
+    MODE_LAUNCH_CHECK();
+    return MODE_OK;
+  }
   if (y_dtype == MODE_BF16)
     hipLaunchKernelGGL(combine_bwd_kernel<uint16_t>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (const uint16_t*)Y, y_splits, y_split_stride, pos, posw, N, D,
                        k, (uint16_t*)dYs, dw);

@@ -123,9 +123,9 @@ def test_rmsnorm_bwd_with_gather(rows, D, k):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_combine_bwd(dtype):
+@pytest.mark.parametrize("N,D,k", [(200, 256, 2), (203, 1024, 2), (50, 512, 1), (64, 1024, 3), (30, 768, 2)])     # (bf16, k <= 2, D = 256 / 512 / 1024: the all-loads-first kernel)
+def test_combine_bwd(dtype, N, D, k):
     lib = L.load()
-    N, D, k = 200, 256, 2
     dy = rnd(N, D, seed=13); Y = rnd(N * k, D, seed=14).to(dtype)
     pos = torch.randperm(N * k, generator=torch.Generator().manual_seed(15)).int(); posw = torch.rand(N * k, generator=torch.Generator().manual_seed(16))
     dYs = torch.zeros(N * k, D, dtype=dtype, device=dev()); dw = torch.empty(N * k, device=dev())
