@@ -1,10 +1,11 @@
 // fp32 MFMA GEMM for gfx950: same contract as the bf16 kernel (plain / gathered / grouped, same epilogues) on
 // v_mfma_f32_16x16x4_f32 — bit-exactly a k-ordered fp32 fma chain, so the noise-conditioned router (whose top-k
 // integers must match the fp32 reference) and the fp32 parity mode of the whole denoiser run on the matrix cores
-// without any reduced-precision step.  64x64 tile, 4 wave64 (2x2), each wave 2x2 accumulators of 16x16; K advances in LDS fills of FOUR 16-wide
-// sub-steps (one barrier pair per 64 k, the next fill's eight 16-byte loads per thread in flight under the 64 MFMAs of the current one - with one
-// sub-step per barrier every K-step cost a memory round trip: 0.7 us, the whole price of the M = 128 embedding / router products).  The MFMA sequence of
-// an output element is the same k-ascending chain whatever the fill size.
+// without any reduced-precision step.  64x64 tile (32x32 for products with few tiles), 4 wave64 (2x2), each wave 2x2 (1) accumulators of 16x16; K advances in
+// LDS fills of FOUR (EIGHT) 16-wide sub-steps: one barrier pair per fill, the next fill's eight 16-byte loads per thread in flight under the MFMAs of the current one
+// (with one sub-step per barrier every K-step cost a memory round trip - 0.7 us - and four dependent ds_read_b32 + MFMA groups: the whole price of the M = 128
+// embedding / router products).  The MFMA sequence of an output element is the same k-ascending chain whatever the tile and the fill size
+// (tests/test_gpu_kernels.py::test_gemm_f32_result_does_not_depend_on_tile_or_operand_layout).
 // General in M, N, K (guarded loads/stores); float4 global loads when K % 16 == 0 and rows are 16-byte aligned.
 #include <type_traits>
 #include "mode_common.h"

@@ -93,8 +93,7 @@ __global__ void sample_experts_kernel(const float* __restrict__ probs, const flo
 // Fixed summation order (per-thread strided partials -> xor butterfly -> waves in order): deterministic, no atomics.  E <= 16.
 __global__ __launch_bounds__(1024) void moe_aux_stats_kernel(const int* __restrict__ idx, const float* __restrict__ w, int L, int R, int tpr, int E, int k,
                                                              const float* __restrict__ shifted, int Rs, float* __restrict__ frac, float* __restrict__ lb,
-                                                             float* __restrict__ zl, float* __restrict__ lb_mean, float* __restrict__ zl_mean,
-                                                             float* __restrict__ mask, long long* __restrict__ usage) {
+                                                             float* __restrict__ zl, float* __restrict__ mask, long long* __restrict__ usage) {
   __shared__ float s_part[16][33];
   __shared__ float s_tot[33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -320,8 +319,8 @@ extern "C" int mode_moe_aux_stats(const int32_t* idx, const float* w, int L, int
   if (!idx || !w || !shifted || !frac || !lb || !zl || !lb_mean || !zl_mean || L <= 0 || R <= 0 || Rs <= 0 || tokens_per_row <= 0 || E <= 0 || k <= 0 || k > E)
     return MODE_ERR_BAD_ARG;
   if (E > 16) return MODE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(moe_aux_stats_kernel, dim3(L), dim3(1024), 0, (hipStream_t)stream, idx, w, L, R, tokens_per_row, E, k, shifted, Rs, frac, lb, zl, lb_mean,
-                     zl_mean, mask, (long long*)usage);
+  hipLaunchKernelGGL(moe_aux_stats_kernel, dim3(L), dim3(1024), 0, (hipStream_t)stream, idx, w, L, R, tokens_per_row, E, k, shifted, Rs, frac, lb, zl, mask,
+                     (long long*)usage);
   MODE_LAUNCH_CHECK();
   hipLaunchKernelGGL(moe_aux_means_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lb, zl, L, lb_mean, zl_mean);
   MODE_LAUNCH_CHECK();
