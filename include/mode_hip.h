@@ -68,6 +68,8 @@ const char* mode_hip_status_string(int status);
  * "gemm_tr_cfg": backward (transpose-read) GEMM geometry, 0 = auto, 1 = 128-wide ring-2, 2 = 64-wide ring-3, 3 = 128-wide ring-3,
  *   4 = 64-wide ring-2, 5 = 128-wide single-buffered, 6 = the persistent ping-pong kernel of gemm_bf16_pptr.hip (256 x 256 tiles, one workgroup per CU) for
  *   every shape it takes, 7 = auto without it.  Auto takes it for the large expert GEMMs of the training backward unless "bwd_coexec" is 1.
+ * "attn_bwd_mfma": 1 (default) = the attention backward's five small matrix products run on v_mfma_f32_16x16x4_f32 (head_dim % 16 == 0; exact fp32 like
+ *   the VALU form, another summation order), 0 = the VALU form.
  * "train_dn_split": 0 (default) / 1 = the training forward cuts the expert down-projection into the inference chain's K-slices (bf16 slabs added by the
  *   combine kernels, forward and backward).  Measured equal at C2 / B = 128 (the 256-row ping-pong tile saves 14 us per layer, the backward combine re-reads four
  *   slabs: +14 us): kept as a switch, off.

@@ -86,7 +86,10 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 
 // ---- backward (training): one 256-thread workgroup per (sample, head), everything in LDS, fp32 VALU in the forward's order.
 // dY [B*T, D] (T2 = bf16/f32) -> dqkv [B*T, 3D]; per-workgroup partial gradients of the qk-norm gains: dgq/dgk [B*H, HD].
-template <typename T2>
+// MF: the five small matrix products (S = q_hat k_hat^T and dPd = dO V^T over the head dim; dq_hat = dS k_hat, dk_hat = dS^T q_hat, dV = Pd^T dO over the tokens) on
+// v_mfma_f32_16x16x4_f32 - exact fp32 like the VALU form, but an operand element is read from LDS once per 16 outputs: the VALU form moved ~0.8 MB of LDS
+// reads per (sample, head) - with four workgroups per CU these two phases were LDS-bandwidth-bound and two thirds of the kernel's 38 us.  head_dim % 16 == 0.
+template <typename T2, bool MF>
 __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__ qkv, const float* __restrict__ qg, const float* __restrict__ kg,
                                                        const T2* __restrict__ dY, T2* __restrict__ dqkv, float* __restrict__ dgq_part,
                                                        float* __restrict__ dgk_part, int B, int T, int H, int HD, float eps, uint32_t seed,
@@ -104,11 +107,13 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
   // probability-sized tiles are zero-padded to 16 x 16 (row stride 16): branch-free 16-term dot products, float4 broadcast reads
   float* sp = skh + T * HP + ((4 - ((4 * T * HP) & 3)) & 3);   // P [query][key]                    (16-byte aligned)
   float* sds = sp + 256;                               // dPd, then dS   [query][key]
-  float* spdT = sds + 256;                             // dropped probabilities, transposed [key][query]
-  float* sdsT = spdT + 256;                            // dS transposed                     [key][query]
+  float* spdT = sds + 256;                             // dropped probabilities, transposed [key][query]   (VALU form only: the MFMA form keeps them in sp)
+  float* sdsT = MF ? sds + 256 : spdT + 256;           // dS transposed                     [key][query]
   float* srq = sdsT + 256;                             // 1/norm per token (q)              [T]
   float* srk = srq + T;                                // (k)
-  TV* sv = reinterpret_cast<TV*>(srk + T + ((4 - ((2 * T) & 3)) & 3));   // v, later dV   [T][HV]   (16-byte aligned)
+  float* sgq = srk + T + ((4 - ((2 * T) & 3)) & 3);    // qk-norm gains [HD] (read per element in three phases: from LDS, not through the vector cache)
+  float* sgk = sgq + HD;
+  TV* sv = reinterpret_cast<TV*>(sgk + HD);            // v, later dV   [T][HV]   (16-byte aligned: HD % 4 == 0)
   TV* sdo = sv + T * HV;                               // dO
   auto tvf = [](TV x) -> float { if constexpr (sizeof(TV) == 2) return bf16_bits_to_f32(x); else return x; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,7 +132,8 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
       dst[0] = __uint_as_float(u.x); dst[1] = __uint_as_float(u.y); dst[2] = __uint_as_float(u.z); dst[3] = __uint_as_float(u.w);
     }
   };
-  for (int i = tid; i < 4 * 256; i += 256) sp[i] = 0.f;   // zero padding of the four 16x16 tiles (written sparsely below)
+  for (int i = tid; i < (MF ? 3 : 4) * 256; i += 256) sp[i] = 0.f;   // zero padding of the 16x16 tiles (written sparsely below)
+  for (int d = tid; d < HD; d += 256) { sgq[d] = qg[d]; sgk[d] = kg[d]; }
   for (int i = tid; i < T * cpr; i += 256) {
     const int t = i / cpr, d = (i % cpr) * VE;
     const T2* r = qkv + ((long)b * T + t) * ld + h * HD + d;
@@ -159,11 +165,46 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
   __syncthreads();
   for (int i = tid; i < T * HD; i += 256) {
     const int t = i / HD, d = i % HD;
-    sqh[t * HP + d] = sq[t * HP + d] * srq[t] * qg[d];
-    skh[t * HP + d] = sk[t * HP + d] * srk[t] * kg[d];
+    sqh[t * HP + d] = sq[t * HP + d] * srq[t] * sgq[d];
+    skh[t * HP + d] = sk[t * HP + d] * srk[t] * sgk[d];
   }
   __syncthreads();
   const float scale = rsqrtf((float)HD);
+  if constexpr (MF) {
+    // wave 0: S = q_hat k_hat^T * scale, wave 1: dPd = dO V^T - D[i][j] += A[i][d] B[d][j], four head dims per instruction; a lane supplies A[i = l & 15][d0 + (l >> 4)]
+    // and B[..][j = l & 15] and ends up with rows i = 4 (l >> 4) + r of column j.  Rows / columns >= T read a clamped (finite) row: their outputs are not stored.
+    if (wave < 2) {
+      const int fr = min(lane & 15, T - 1), fq = lane >> 4;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (wave == 0) {
+        const float* qa = sqh + fr * HP + fq; const float* kb = skh + fr * HP + fq;
+        for (int d0 = 0; d0 < HD; d0 += 16) {
+          float a[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { a[u] = qa[d0 + 4 * u]; bv[u] = kb[d0 + 4 * u]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u], acc, 0, 0, 0);
+        }
+      } else {
+        const TV* oa = sdo + fr * HV + fq; const TV* vb = sv + fr * HV + fq;
+        for (int d0 = 0; d0 < HD; d0 += 16) {
+          float a[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { a[u] = tvf(oa[d0 + 4 * u]); bv[u] = tvf(vb[d0 + 4 * u]); }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u], acc, 0, 0, 0);
+        }
+      }
+      const int ki = lane & 15;
+      float* dst = wave == 0 ? sp : sds;
+      const float mul = wave == 0 ? scale : 1.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = 4 * (lane >> 4) + r;
+        if (qi < T && ki <= qi) dst[qi * 16 + ki] = acc[r] * mul;
+      }
+    }
+  } else
   // S = q_hat k_hat^T * scale (causal) and dPd = dO V^T: four lanes per (query, key) pair, each a quarter of the head dim with two
   // independent accumulator pairs (the one-thread-per-pair loop was a 128-deep chain of dependent LDS reads), xor-shuffle combine
   {
@@ -219,8 +260,9 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
     for (int o = 1; o < 16; o <<= 1) rs += __shfl_xor(rs, o, 64);
     const float dS = pv * (dP - rs) * scale;
     if (qi < T && ki < T) {
-      sp[qi * 16 + ki] = pv; sds[qi * 16 + ki] = dS;
-      spdT[ki * 16 + qi] = pv * m; sdsT[ki * 16 + qi] = dS;
+      if constexpr (MF) sp[qi * 16 + ki] = pv * m;               // the MFMA form reads the dropped probabilities [query][key]
+      else { sp[qi * 16 + ki] = pv; spdT[ki * 16 + qi] = pv * m; }
+      sds[qi * 16 + ki] = dS; sdsT[ki * 16 + qi] = dS;
     }
   }
   __syncthreads();
@@ -228,6 +270,46 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
   // One thread per (role, head-dim column) — role 0: dq_hat, role 1: dV and dk_hat.  The T column values a thread needs are read from
   // LDS once into registers, the P / dS coefficients are wave-uniform broadcast reads, so the FMAs are independent of LDS latency.
   // Results stay in registers across the barrier: they overwrite q_hat / k_hat / v in place.   (host side guarantees 2*HD <= 256, T <= 16)
+  if constexpr (MF) {
+    // 16-column tiles of the head dim, tile t on wave t % 4 (head_dim <= 128: at most two per wave); per tile three products over the token index k (four per
+    // instruction): dq_hat[i][d] = dS[i][k] k_hat[k][d], dk_hat[j][d] = dS[k][j] q_hat[k][d], dV[j][d] = Pd[k][j] dO[k][d].  The coefficient tiles are zero beyond
+    // T and above the diagonal; the other operand's rows k >= T are clamped (0 x finite).  Results wait in registers for the barrier, then replace q_hat / k_hat / v.
+    const int fr = lane & 15, fq = lane >> 4, nt = HD / 16;
+    f32x4 rq[2], rk[2], rv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      rq[u] = f32x4{0.f, 0.f, 0.f, 0.f}; rk[u] = rq[u]; rv[u] = rq[u];
+      const int t = wave + 4 * u;
+      if (t < nt) {
+        const int d = t * 16 + fr;
+#pragma unroll
+        for (int k0 = 0; k0 < 16; k0 += 4) {
+          const int k = k0 + fq, kc = min(k, T - 1);
+          const float a_dq = sdsT[k * 16 + fr], a_dk = sds[k * 16 + fr], a_dv = sp[k * 16 + fr];
+          const float b_k = skh[kc * HP + d], b_q = sqh[kc * HP + d], b_o = tvf(sdo[kc * HV + d]);
+          rq[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_dq, b_k, rq[u], 0, 0, 0);
+          rk[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_dk, b_q, rk[u], 0, 0, 0);
+          rv[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_dv, b_o, rv[u], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = wave + 4 * u;
+      if (t < nt) {
+        const int d = t * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * fq + r;
+          if (row < T) {
+            sqh[row * HP + d] = rq[u][r]; skh[row * HP + d] = rk[u][r];
+            if constexpr (sizeof(TV) == 2) sv[row * HV + d] = f32_to_bf16_bits(rv[u][r]); else sv[row * HV + d] = rv[u][r];
+          }
+        }
+      }
+    }
+  } else
   {
     constexpr int TMAX = 16;
     const int role = tid / HD, d = tid % HD;
@@ -282,17 +364,18 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kernel(const T2* __restrict__
     float cq = 0.f, ck = 0.f;
     if (t < T) {
 #pragma unroll 4
-      for (int d = l16; d < HD; d += 16) { cq += qg[d] * sqh[t * HP + d] * sq[t * HP + d]; ck += kg[d] * skh[t * HP + d] * sk[t * HP + d]; }
+      for (int d = l16; d < HD; d += 16) { cq += sgq[d] * sqh[t * HP + d] * sq[t * HP + d]; ck += sgk[d] * skh[t * HP + d] * sk[t * HP + d]; }
     }
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) { cq += __shfl_xor(cq, o, 64); ck += __shfl_xor(ck, o, 64); }
     if (t < T) {
       const float rq = srq[t], rk = srk[t];
       const bool clq = rq >= 1.0f / eps, clk = rk >= 1.0f / eps;
+      const float cqs = clq ? 0.f : cq * rq * rq * rq / (float)HD, cks = clk ? 0.f : ck * rk * rk * rk / (float)HD;   // per token, not per element (a division each)
 #pragma unroll 4
       for (int d = l16; d < HD; d += 16) {
-        sqh[t * HP + d] = qg[d] * sqh[t * HP + d] * rq - (clq ? 0.f : sq[t * HP + d] * cq * rq * rq * rq / (float)HD);
-        skh[t * HP + d] = kg[d] * skh[t * HP + d] * rk - (clk ? 0.f : sk[t * HP + d] * ck * rk * rk * rk / (float)HD);
+        sqh[t * HP + d] = sgq[d] * sqh[t * HP + d] * rq - sq[t * HP + d] * cqs;
+        skh[t * HP + d] = sgk[d] * skh[t * HP + d] * rk - sk[t * HP + d] * cks;
       }
     }
   }
@@ -364,6 +447,7 @@ extern "C" int mode_attn_block_fwd(const void* qkv, const float* q_gain, const f
 }
 
 namespace mode {
+int g_attn_bwd_mfma = 1;   // "attn_bwd_mfma" option: 1 = the attention backward's matrix products on fp32 MFMA (head_dim % 16 == 0), 0 = the VALU form
 // dbias_partial (optional): [B][3 D] fp32, row b = sample b's share of the packed QKV bias gradient (dit_train.hip adds the rows)
 int attn_block_bwd_launch(const void* qkv, const float* q_gain, const float* k_gain, const void* dy, void* dqkv, float* dgq_partial,
                           float* dgk_partial, int dtype, int B, int T, int H, int head_dim, float eps, uint32_t seed, float p_drop, float* dbias_partial,
@@ -371,17 +455,18 @@ int attn_block_bwd_launch(const void* qkv, const float* q_gain, const float* k_g
   if (!qkv || !q_gain || !k_gain || !dy || !dqkv || !dgq_partial || !dgk_partial || B < 0 || T <= 0 || H <= 0) return MODE_ERR_BAD_ARG;
   if (p_drop < 0.f || p_drop >= 1.f) return MODE_ERR_BAD_ARG;
   if (B == 0) return MODE_OK;
-  const size_t lds = dtype == MODE_BF16 ? ((size_t)4 * T * (head_dim + 1) + 4 + 4 * 256 + 2 * T + 4) * 4 + (size_t)2 * T * (head_dim + 8) * 2
-                                        : ((size_t)6 * T * (head_dim + 1) + 4 + 4 * 256 + 2 * T + 4) * 4;
+  const bool mf = head_dim % 16 == 0 && g_attn_bwd_mfma;
+  const size_t tiles = mf ? 3 : 4;                             // 16 x 16 coefficient tiles (the MFMA form needs no transposed copy of the dropped probabilities)
+  const size_t lds = dtype == MODE_BF16 ? ((size_t)4 * T * (head_dim + 1) + 4 + tiles * 256 + 2 * T + 4 + 2 * head_dim) * 4 + (size_t)2 * T * (head_dim + 8) * 2
+                                        : ((size_t)6 * T * (head_dim + 1) + 4 + tiles * 256 + 2 * T + 4 + 2 * head_dim) * 4;
   if (lds > 64 * 1024 || head_dim > 128 || T > 16 || head_dim % (dtype == MODE_BF16 ? 8 : 4)) return MODE_ERR_UNSUPPORTED;
   const uint32_t th = attn_thresh(p_drop); const float ik = 1.0f / (1.0f - p_drop);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MODE_BF16)
-    hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, dim3(B * H), dim3(256), lds, s, (const uint16_t*)qkv, q_gain, k_gain, (const uint16_t*)dy, (uint16_t*)dqkv,
-                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik, dbias_partial);
-  else
-    hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B * H), dim3(256), lds, s, (const float*)qkv, q_gain, k_gain, (const float*)dy, (float*)dqkv,
-                       dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik, dbias_partial);
+#define MODE_ATTN_BWD(T2, MF) hipLaunchKernelGGL((attn_bwd_kernel<T2, MF>), dim3(B * H), dim3(256), lds, s, (const T2*)qkv, q_gain, k_gain, (const T2*)dy, (T2*)dqkv, \
+                                                 dgq_partial, dgk_partial, B, T, H, head_dim, eps, seed, th, ik, dbias_partial)
+  if (dtype == MODE_BF16) { if (mf) MODE_ATTN_BWD(uint16_t, true); else MODE_ATTN_BWD(uint16_t, false); }
+  else { if (mf) MODE_ATTN_BWD(float, true); else MODE_ATTN_BWD(float, false); }
+#undef MODE_ATTN_BWD
   MODE_LAUNCH_CHECK();
   return MODE_OK;
 }

@@ -186,6 +186,16 @@ def test_attention_backward(dtype, B, T, Hh, hd, p):
     if p > 0:                                                                 # forward with the same mask
         yf = H.attn(qd, qgd, kgd, B, T, Hh, hd, seed=seed, p_drop=p)
         assert rel(yf.float(), y.detach()) < (2e-2 if dtype == torch.bfloat16 else 1e-5)
+    # the VALU form of the five matrix products ("attn_bwd_mfma" 0; the only form for head_dim % 16 != 0): same results to fp32 summation order
+    dq2 = torch.full_like(dqkv, float("nan")); pq2 = torch.empty_like(pq); pk2 = torch.empty_like(pk)
+    lib.mode_set_option(b"attn_bwd_mfma", 0)
+    try:
+        L.check(lib.mode_attn_block_bwd(qd.data_ptr(), qgd.data_ptr(), kgd.data_ptr(), dyd.data_ptr(), dq2.data_ptr(), pq2.data_ptr(), pk2.data_ptr(),
+                                        DT[dtype], B, T, Hh, hd, 1e-6, seed, p, H.stream()))
+    finally:
+        lib.mode_set_option(b"attn_bwd_mfma", 1)
+    assert rel(dq2.float(), dqkv.float()) < (4e-3 if dtype == torch.bfloat16 else 2e-6)     # bf16: an occasional last-bit difference of a stored value
+    assert rel(pq2, pq) < 1e-5 and rel(pk2, pk) < 1e-5
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
