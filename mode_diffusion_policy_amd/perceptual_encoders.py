@@ -260,7 +260,7 @@ def _gemm_1x1_fwd(x: torch.Tensor, w_lp: torch.Tensor) -> torch.Tensor:
     y = torch.empty((B, cout, H, W_), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=B * H * W_, N=cout, K=cin, A=x.data_ptr(), lda=cin, W=w_lp.data_ptr(), ldw=cin,
                        C=y.data_ptr(), ldc=cout)
-    L.check(L.load().mode_gemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv 1x1 forward")
+    L.check(L.load().mode_gemm(C.byref(d), _stream()), "conv 1x1 forward")
     return y
 
 
@@ -271,7 +271,7 @@ def _gemm_1x1_dgrad(dy: torch.Tensor, w_lp: torch.Tensor, xshape) -> torch.Tenso
     dx = torch.empty((B, cin, H, W_), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
     d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=B * H * W_, N=cin, K=cout, A=dy.data_ptr(), lda=cout, W=w_lp.data_ptr(), ldw=cin,
                        C=dx.data_ptr(), ldc=cin, flags=L.GEMM_W_KN)
-    L.check(L.load().mode_gemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv 1x1 data gradient")
+    L.check(L.load().mode_gemm(C.byref(d), _stream()), "conv 1x1 data gradient")
     return dx
 
 
@@ -289,7 +289,7 @@ def _wgrad_1x1(dy: torch.Tensor, x: torch.Tensor, wshape) -> torch.Tensor:
     d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=cout, N=cin, K=R, A=dy.data_ptr(), lda=cout, W=x.data_ptr(), ldw=cin,
                        C=part.data_ptr(), ldc=cin, k_group_offsets=offs.data_ptr(), num_k_groups=G, c_group_stride=cout * cin,
                        flags=L.GEMM_W_KN | L.GEMM_A_KM)
-    L.check(L.load().mode_gemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv 1x1 weight gradient")
+    L.check(L.load().mode_gemm(C.byref(d), _stream()), "conv 1x1 weight gradient")
     return (part.sum(0) if G > 1 else part[0]).view(cout, cin, 1, 1)
 
 
@@ -340,7 +340,7 @@ def _conv_fwd_taps(x: torch.Tensor, w_lp: torch.Tensor, stride, padding) -> torc
     R = n * ho * wo
     d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=R, N=cout, K=kh_ * kw_ * cin, A=x.data_ptr(), lda=cin, W=w_lp.data_ptr(),
                        ldw=kh_ * kw_ * cin, C=y.data_ptr(), ldc=cout, a_rows=idx.data_ptr(), a_tap_cols=cin, a_rows_tap_stride=R)
-    L.check(L.load().mode_gemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv forward (taps)")
+    L.check(L.load().mode_gemm(C.byref(d), _stream()), "conv forward (taps)")
     return y
 
 
@@ -354,7 +354,7 @@ def _conv_dgrad_taps(dy: torch.Tensor, w_lp: torch.Tensor, xshape, stride, paddi
     R = n * H * W_
     d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=R, N=cin, K=kh_ * kw_ * cout, A=dy.data_ptr(), lda=cout, W=w_lp.data_ptr(),
                        ldw=kh_ * kw_ * cin, C=dx.data_ptr(), ldc=cin, a_rows=idx.data_ptr(), a_tap_cols=cout, a_rows_tap_stride=R, flags=L.GEMM_W_KN)
-    L.check(L.load().mode_gemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv data gradient (taps)")
+    L.check(L.load().mode_gemm(C.byref(d), _stream()), "conv data gradient (taps)")
     return dx
 
 
@@ -372,7 +372,7 @@ def _conv_fwd_stats(x: torch.Tensor, w_lp: torch.Tensor, stride, padding):
     st = torch.empty((2, (R + 127) // 128, cout), dtype=torch.float32, device=x.device)
     d = L.ModeConvBnDesc(x=x.data_ptr(), ldx=cin, idx=_ptr(idx), idx_tap_stride=R, taps=kh_ * kw_, w=w_lp.data_ptr(), ldw=kh_ * kw_ * cin, y=y.data_ptr(), ldy=cout,
                          M=R, Cin=cin, Cout=cout, relu=0, rows_per_sample=ho * wo, stat_sum=st[0].data_ptr(), stat_sq=st[1].data_ptr())
-    L.check(L.load().mode_conv_bn_act_fwd(C.byref(d), torch.cuda.current_stream().cuda_stream), "conv forward + BatchNorm partial statistics")
+    L.check(L.load().mode_conv_bn_act_fwd(C.byref(d), _stream()), "conv forward + BatchNorm partial statistics")
     return y, st[0], st[1]
 
 
@@ -398,7 +398,7 @@ def _wgrad_taps(dy: torch.Tensor, x: torch.Tensor, wshape, stride, padding) -> t
     if offs is None:
         offs = _KOFFS[okey] = torch.tensor([(R * i) // G for i in range(G + 1)], dtype=torch.int32, device=dy.device)
     part = torch.empty((G, cout, kh_, kw_, cin), dtype=torch.float32, device=dy.device)       # channels_last order of [Cout, Cin, kh, kw]
-    lib = L.load(); st = torch.cuda.current_stream().cuda_stream
+    lib = L.load(); st = _stream()
     if one_launch:
         d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=cout, N=taps * cin, K=R, A=dy.data_ptr(), lda=cout, W=xp.data_ptr(), ldw=cin,
                            C=part.data_ptr(), ldc=taps * cin, k_group_offsets=offs.data_ptr(), num_k_groups=G, c_group_stride=cout * taps * cin,
@@ -591,7 +591,7 @@ def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, relu: bool = True, resid
                                  M=R, Cin=cin, Cout=cout, bn_mean=_ptr(bn.running_mean), bn_var=_ptr(bn.running_var), bn_weight=_ptr(bn.weight), bn_bias=_ptr(bn.bias),
                                  bn_eps=bn.eps, residual=_ptr(res), ldr=cout, relu=int(relu), pre_gamma=_ptr(pg), pre_beta=_ptr(pb), post_gamma=_ptr(qg), post_beta=_ptr(qb),
                                  rows_per_sample=ho * wo)
-            L.check(L.load().mode_conv_bn_act_fwd(C.byref(d), torch.cuda.current_stream().cuda_stream), "mode_conv_bn_act_fwd")
+            L.check(L.load().mode_conv_bn_act_fwd(C.byref(d), _stream()), "mode_conv_bn_act_fwd")
             return y
     if (FUSE_CONV_STATS and USE_HIP_CONV_WGRAD and x.is_cuda and cd == torch.bfloat16 and torch.is_grad_enabled() and bn.training and not isinstance(bn, nn.SyncBatchNorm)
             and (w.requires_grad or x.requires_grad) and conv.groups == 1 and conv.dilation == (1, 1) and conv.bias is None and isinstance(conv.padding, tuple)
