@@ -106,7 +106,14 @@ __global__ void colsum_stage2_kernel(const float* __restrict__ partial, int nseg
   if (i >= (long)nseg * cols) return;
   const int seg = i / cols, c = i % cols;
   float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += partial[((long)seg * nsplit + k) * cols + c];
+  for (int k0 = 0; k0 < nsplit; k0 += 8) {                               // eight partials requested per trip, added in split order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[((long)seg * nsplit + min(k0 + u, nsplit - 1)) * cols + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + u < nsplit) s += v[u];
+  }
   out[i] = accumulate ? out[i] + s : s;
 }
 
