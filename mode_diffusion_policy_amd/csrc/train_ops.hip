@@ -802,10 +802,11 @@ extern "C" int mode_rmsnorm_bwd(const float* x, const float* g, const float* dy_
   return mode::rmsnorm_bwd_launch(x, g, dy_a, dy_b, G, 1, 0, pos, k, rows, D, eps, dx, accumulate, dg_partial, dy_out, dx_lp, lp_dtype, (hipStream_t)stream);
 }
 
-// bf16, one slab, D = 256 NIT, k <= KMAX: the slot indices, then every Y / dy load of the token are requested before the first use (the generic kernel walks
-// j and d serially: k x D/256 dependent round trips, 9 us for 7 MB at C2); per (t, j) the same lane-strided fma chain + butterfly as above - same bits.
-template <int NIT, int KMAX>
-__global__ __launch_bounds__(256) void combine_bwd_bf16_kernel(const float* __restrict__ dy, const uint16_t* __restrict__ Y, const int* __restrict__ pos,
+// bf16, D = 256 NIT, k <= KMAX, NSP split-K slabs of Y: the slot indices, then every Y / dy load of the token are requested before the first use (the generic kernel
+// walks j and d serially: k x D/256 dependent round trips, 9 us for 7 MB at C2); per (t, j) the same lane-strided fma chain + butterfly as above, slabs added in
+// slice order - same bits.
+template <int NIT, int KMAX, int NSP>
+__global__ __launch_bounds__(256) void combine_bwd_bf16_kernel(const float* __restrict__ dy, const uint16_t* __restrict__ Y, long sp_stride, const int* __restrict__ pos,
                                                                const float* __restrict__ posw, int N, int k, uint16_t* __restrict__ dYs, float* __restrict__ dw) {
   constexpr int D = 256 * NIT;
   const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -813,22 +814,30 @@ __global__ __launch_bounds__(256) void combine_bwd_bf16_kernel(const float* __re
   long pj[KMAX]; float wj[KMAX];
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) { const int jj = min(j, k - 1); pj[j] = pos[(long)t * k + jj]; wj[j] = posw[(long)t * k + jj]; }
-  float4 g[NIT]; uint2 y[KMAX][NIT];
+  float4 g[NIT]; uint2 y[KMAX][NSP][NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) g[it] = *reinterpret_cast<const float4*>(dy + (long)t * D + it * 256 + lane * 4);
 #pragma unroll
   for (int j = 0; j < KMAX; ++j)
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) y[j][it] = *reinterpret_cast<const uint2*>(Y + pj[j] * D + it * 256 + lane * 4);
+    for (int sp = 0; sp < NSP; ++sp)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) y[j][sp][it] = *reinterpret_cast<const uint2*>(Y + sp * sp_stride + pj[j] * D + it * 256 + lane * 4);
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) {
     if (j >= k) break;
     float acc = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const float4 gv = g[it]; const uint2 y2 = y[j][it];
-      acc += gv.x * bf16_bits_to_f32(y2.x & 0xffff); acc += gv.y * bf16_bits_to_f32(y2.x >> 16);
-      acc += gv.z * bf16_bits_to_f32(y2.y & 0xffff); acc += gv.w * bf16_bits_to_f32(y2.y >> 16);
+      const float4 gv = g[it];
+      float y0 = bf16_bits_to_f32(y[j][0][it].x & 0xffff), y1 = bf16_bits_to_f32(y[j][0][it].x >> 16);
+      float y2 = bf16_bits_to_f32(y[j][0][it].y & 0xffff), y3 = bf16_bits_to_f32(y[j][0][it].y >> 16);
+#pragma unroll
+      for (int sp = 1; sp < NSP; ++sp) {
+        y0 += bf16_bits_to_f32(y[j][sp][it].x & 0xffff); y1 += bf16_bits_to_f32(y[j][sp][it].x >> 16);
+        y2 += bf16_bits_to_f32(y[j][sp][it].y & 0xffff); y3 += bf16_bits_to_f32(y[j][sp][it].y >> 16);
+      }
+      acc += gv.x * y0; acc += gv.y * y1; acc += gv.z * y2; acc += gv.w * y3;
       *reinterpret_cast<uint2*>(dYs + pj[j] * D + it * 256 + lane * 4) = make_uint2(pack_bf16x2(wj[j] * gv.x, wj[j] * gv.y), pack_bf16x2(wj[j] * gv.z, wj[j] * gv.w));
     }
     acc = wave_sum(acc);
@@ -841,12 +850,14 @@ int combine_bwd_launch(const float* dy, const void* Y, int y_dtype, int y_splits
                        void* dYs, float* dw, void* stream) {
   if (!dy || !Y || !pos || !posw || !dYs || !dw || N < 0 || D <= 0 || (D & 3) || k <= 0 || y_splits < 1) return MODE_ERR_BAD_ARG;
   if (N == 0) return MODE_OK;
-  if (y_dtype == MODE_BF16 && y_splits == 1 && k <= 2 && (D == 1024 || D == 512 || D == 256) && ((((uintptr_t)dy) & 15) | (((uintptr_t)Y | (uintptr_t)dYs) & 7)) == 0) {
+  if (y_dtype == MODE_BF16 && (y_splits == 1 || y_splits == 4) && k <= 2 && (D == 1024 || D == 512 || D == 256) &&
+      ((((uintptr_t)dy) & 15) | (((uintptr_t)Y | (uintptr_t)dYs) & 7)) == 0 && y_split_stride % 4 == 0) {
     const dim3 grid((N + 3) / 4), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (D == 1024) hipLaunchKernelGGL((combine_bwd_bf16_kernel<4, 2>), grid, blk, 0, s, dy, (const uint16_t*)Y, pos, posw, N, k, (uint16_t*)dYs, dw);
-    else if (D == 512) hipLaunchKernelGGL((combine_bwd_bf16_kernel<2, 2>), grid, blk, 0, s, dy, (const uint16_t*)Y, pos, posw, N, k, (uint16_t*)dYs, dw);
-    else hipLaunchKernelGGL((combine_bwd_bf16_kernel<1, 2>), grid, blk, 0, s, dy, (const uint16_t*)Y, pos, posw, N, k, (uint16_t*)dYs, dw);
+#define MODE_CB(NIT, NSP) hipLaunchKernelGGL((combine_bwd_bf16_kernel<NIT, 2, NSP>), grid, blk, 0, s, dy, (const uint16_t*)Y, (long)y_split_stride, pos, posw, N, k, (uint16_t*)dYs, dw)
+    if (y_splits == 1) { if (D == 1024) MODE_CB(4, 1); else if (D == 512) MODE_CB(2, 1); else MODE_CB(1, 1); }
+    else { if (D == 1024) MODE_CB(4, 4); else if (D == 512) MODE_CB(2, 4); else MODE_CB(1, 4); }
+#undef MODE_CB
     MODE_LAUNCH_CHECK();
     return MODE_OK;
   }
