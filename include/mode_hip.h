@@ -71,8 +71,8 @@ const char* mode_hip_status_string(int status);
  * "attn_bwd_mfma": 1 (default) = the attention backward's five small matrix products run on v_mfma_f32_16x16x4_f32 (head_dim % 16 == 0; exact fp32 like
  *   the VALU form, another summation order), 0 = the VALU form.
  * "train_dn_split": 0 (default) / 1 = the training forward cuts the expert down-projection into the inference chain's K-slices (bf16 slabs added by the
- *   combine kernels, forward and backward).  Measured equal at C2 / B = 128 (the 256-row ping-pong tile saves 14 us per layer, the backward combine re-reads four
- *   slabs: +14 us): kept as a switch, off.
+ *   combine kernels, forward and backward).  Measured 11.37 -> 11.33 ms per step at C2 / B = 128 (the 256-row ping-pong tile saves 14 us per layer, the combine
+ *   kernels read four slabs instead of one) for 22 MB more stash per layer and another rounding of the block output: kept as a switch, off.
  * "fuse_swiglu_bwd": 1 (default) = mode_dit_backward runs the down-projection's data gradient and the SwishGLU (+ dropout) backward + bias-gradient sums as
  *   ONE launch (the dH tile never leaves the chip), 0 = GEMM + mode_swiglu_bwd_bias.
  * "conv_ns": LDS ring depth of the implicit-GEMM convolution kernel (csrc/conv_gemm.hip): 0 = auto (3 below two workgroups per CU), 2, 3.
