@@ -36,13 +36,16 @@ acts = torch.randn(B, 10, 7, generator=g).to(dev); noise = torch.randn(B, 10, 7,
 
 
 def grads():
-    m.engine.arena.grad_pending = False                      # as after optimizer.step() / zero_grad(): the next backward overwrites the arena (a second one would accumulate)
+    for p_ in m.parameters():                                # as after zero_grad(set_to_none=True): the next backward writes fresh gradients
+        p_.grad = None
+    if getattr(m.engine.arena, "grad", None) is not None:
+        m.engine.arena.grad_pending = False                  # grad_mode="arena": the next backward overwrites the arena (a second one would accumulate)
     torch.manual_seed(123)
     sg = rand_log_logistic((B,), loc=math.log(0.5), scale=0.5, min_value=1e-3, max_value=80.0, device=dev)
     loss, _ = den.loss({"state_images": img}, acts, goal, noise, sg)
     loss.backward()
     torch.cuda.synchronize()
-    return m.engine.arena.grad.clone(), float(loss.detach())
+    return torch.cat([p_.grad.reshape(-1).float() for p_ in m.parameters() if p_.grad is not None]).clone(), float(loss.detach())
 
 
 ref_g, ref_l = grads()
