@@ -372,11 +372,10 @@ template <bool W_KN, int BN, bool FUSE, int NS>
 static int conv_launch_ns(ConvGemmParams p, hipStream_t s) {
   constexpr size_t lds = NS * (128 * 64 * 2 + (size_t)BN * 64 * 2);
   auto kern = conv_gemm_kernel<W_KN, BN, FUSE, NS>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
+  static LdsLimitOnce lds_once;
+  if (lds > 48 * 1024) {
+    const int rc = lds_once.ensure(reinterpret_cast<const void*>(kern), (int)lds);
+    if (rc != MODE_OK) return rc;
   }
   hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles), dim3(256), lds, s, p);
   MODE_LAUNCH_CHECK();

@@ -422,11 +422,10 @@ static int launch_cfg(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   p.n_tiles = (d->N + NOUT - 1) / NOUT;
   p.m_tiles = (d->M + BM - 1) / BM + (d->expert_offsets ? d->num_experts : 0);
   auto kern = gemm_bf16_kernel<BM, BN, WM, WN, NS, EPI, OUT_BF16, LR>;
-  static bool attr_set = false;
-  if (!attr_set && LDS > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
+  static LdsLimitOnce lds_once;
+  if (LDS > 64 * 1024) {
+    const int rc = lds_once.ensure(reinterpret_cast<const void*>(kern), (int)LDS);
+    if (rc != MODE_OK) return rc;
   }
   hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles, p.split_k, d->k_group_offsets ? d->num_k_groups : 1), dim3(WM * WN * 64), LDS, s, p);
   MODE_LAUNCH_CHECK();

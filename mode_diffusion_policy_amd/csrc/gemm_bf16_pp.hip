@@ -545,15 +545,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
 // ------------------------------------------------------------------------------------------------------------ host side
 int pp_num_cus() {   // also used by the tile heuristic (gemm_bf16.hip: pick_cfg)
-  static int ncu[16] = {0};
+  static std::atomic<int> ncu[kMaxDevices];                   // zero-initialised; a racing first call writes the same value twice
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
-  if (!ncu[dev]) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+  int n = ncu[dev].load(std::memory_order_relaxed);
+  if (!n) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 256;
+    n = v > 0 ? v : 256;
+    ncu[dev].store(n, std::memory_order_relaxed);
   }
-  return ncu[dev];
+  return n;
 }
 
 template <int EPI, bool OUT_BF16, int FM1>
@@ -565,14 +567,10 @@ static int pp_launch(GemmParams p, const ModeGemmDesc* d, hipStream_t s) {
   const int ncu = pp_num_cus();
   const int grid = (int)(t_max < ncu ? t_max : ncu);           // one persistent workgroup per CU (140 KiB of LDS each)
   auto kern = gemm_pp_kernel<EPI, OUT_BF16, FM1>;
-  static bool attr_set[16] = {false};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16) dev = 0;
-  if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_TOTAL);
-    if (e != hipSuccess) return (int)e;
-    attr_set[dev] = true;
+  static LdsLimitOnce lds_once;
+  {
+    const int rc = lds_once.ensure(reinterpret_cast<const void*>(kern), pp::LDS_TOTAL);
+    if (rc != MODE_OK) return rc;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pp::LDS_TOTAL, s, p);
   MODE_LAUNCH_CHECK();

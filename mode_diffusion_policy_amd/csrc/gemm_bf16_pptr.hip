@@ -464,14 +464,10 @@ static int pptr_launch(const PpTrParams& p, long t_max, hipStream_t s) {
   const int ncu = pp_num_cus();
   const int grid = (int)(t_max < ncu ? t_max : ncu);           // one persistent workgroup per CU (128 KiB of LDS each)
   auto kern = gemm_pptr_kernel<A_KM, OUT_BF16>;
-  static bool attr_set[16] = {false};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16) dev = 0;
-  if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pptr::LDS_TOTAL);
-    if (e != hipSuccess) return (int)e;
-    attr_set[dev] = true;
+  static LdsLimitOnce lds_once;
+  {
+    const int rc = lds_once.ensure(reinterpret_cast<const void*>(kern), pptr::LDS_TOTAL);
+    if (rc != MODE_OK) return rc;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pptr::LDS_TOTAL, s, p);
   MODE_LAUNCH_CHECK();

@@ -526,13 +526,10 @@ int gemm_bf16_mid_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t
 #define MODE_MID(E, OB)                                                                                                                     \
   do {                                                                                                                                      \
     auto kern = gemm_bf16_mid_kernel<E, OB>;                                                                                                \
-    static bool attr_set[16] = {false};                                                                                                     \
-    int dev = 0;                                                                                                                            \
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return MODE_ERR_UNSUPPORTED;                                              \
-    if (!attr_set[dev]) {                                                                                                                   \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);      \
-      if (e != hipSuccess) return (int)e;                                                                                                   \
-      attr_set[dev] = true;                                                                                                                 \
+    static LdsLimitOnce lds_once;                                                                                                           \
+    {                                                                                                                                       \
+      const int rc = lds_once.ensure(reinterpret_cast<const void*>(kern), (int)LDS);                                                       \
+      if (rc != MODE_OK) return rc;                                                                                                         \
     }                                                                                                                                       \
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, p);                                                                                   \
   } while (0)
@@ -555,15 +552,10 @@ static int launch_skinny(const GemmParams& p, int groups, hipStream_t s) {
     if (kspl == 1024) {                                              // the chain's shapes: A block through LDS
       constexpr size_t LDS = (size_t)MT * 16 * (2048 + 16) + RS;
       auto kern = gemm_bf16_stream_kernel<MT, EPI, OUT_BF16>;
-      static bool attr_set[16] = {false};
-      int dev = 0;
+      static LdsLimitOnce lds_once;
       if (LDS > 64 * 1024) {
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return MODE_ERR_UNSUPPORTED;
-        if (!attr_set[dev]) {
-          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-          if (e != hipSuccess) return (int)e;
-          attr_set[dev] = true;
-        }
+        const int rc = lds_once.ensure(reinterpret_cast<const void*>(kern), (int)LDS);
+        if (rc != MODE_OK) return rc;
       }
       hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, p);
       MODE_LAUNCH_CHECK();

@@ -414,11 +414,10 @@ static int tr_launch(TrParams p, const ModeGemmDesc* d, hipStream_t s) {
   const dim3 grid(p.m_tiles * p.n_tiles, p.split_k, (KM && d->k_group_offsets) ? d->num_k_groups : 1);
   constexpr size_t lds = (size_t)NS * (128 * 64 * 2 + 64 * BN * 2);       // the output tile goes through the ring (one or two passes)
   auto kern = gemm_tr_kernel<KM, OB, BN, NS, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
+  static LdsLimitOnce lds_once;
+  {
+    const int rc = lds_once.ensure(reinterpret_cast<const void*>(kern), (int)lds);
+    if (rc != MODE_OK) return rc;
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
   MODE_LAUNCH_CHECK();

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "mode_hip.h"
 
 namespace mode {
@@ -140,5 +142,25 @@ extern int g_gemm_cfg;
     hipError_t e__ = hipGetLastError();                      \
     if (e__ != hipSuccess) return (int)e__;                  \
   } while (0)
+
+// ---- host: raise a kernel's dynamic-LDS limit once PER DEVICE ---------------------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: a process that drives several GPUs (a threaded replica
+// server, a test that hops devices) must set it on each of them, or the first > 64-KiB-LDS launch on the second device fails.  One instance per
+// kernel instantiation (a function-local `static LdsLimitOnce`); a bit per device ordinal, set after the attribute call succeeded.  Thread-safe:
+// two racing threads at worst both make the (idempotent) call.  Devices >= kMaxDevices are refused (MODE_ERR_UNSUPPORTED) rather than aliased.
+constexpr int kMaxDevices = 64;
+struct LdsLimitOnce {
+  std::atomic<uint64_t> done{0};
+  int ensure(const void* kern, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return MODE_ERR_UNSUPPORTED;
+    const uint64_t bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return MODE_OK;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done.fetch_or(bit, std::memory_order_release);
+    return MODE_OK;
+  }
+};
 
 }  // namespace mode

@@ -245,14 +245,10 @@ extern "C" int mode_qkv_attn_fwd(const ModeQkvAttnDesc* d, void* stream) {
   const bool w8 = g_qkv_attn_waves == 8;
   auto kern = w8 ? (w3 ? qkv_attn_kernel<128, true, 2> : qkv_attn_kernel<128, false, 2>) : (w3 ? qkv_attn_kernel<128, true, 1> : qkv_attn_kernel<128, false, 1>);
   const int lds = w3 ? LDS3 : LDS2;
-  static bool attr_set[2][2][16] = {{{false}}};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16) dev = 0;
-  if (!attr_set[w8][w3][dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set[w8][w3][dev] = true;
+  static LdsLimitOnce lds_once[2][2];
+  {
+    const int rc = lds_once[w8][w3].ensure(reinterpret_cast<const void*>(kern), lds);
+    if (rc != MODE_OK) return rc;
   }
   hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.H), dim3(w8 ? 512 : 256), lds, (hipStream_t)stream, p);
   MODE_LAUNCH_CHECK();

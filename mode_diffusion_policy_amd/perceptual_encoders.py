@@ -245,7 +245,6 @@ def _compute_dtype(x: torch.Tensor) -> torch.dtype:
 # stale shadows of an encoder in one `_foreach_copy_`).  Inference takes the same forward kernels, and `conv_bn_act` folds the eval-mode BatchNorm / FiLM / residual
 # / ReLU into the convolution's epilogue (mode_conv_bn_act_fwd).  MODE_ENC_HIPCONV=0 restores F.conv2d with per-call casts everywhere (A/B runs).
 USE_HIP_CONV_WGRAD = __import__("os").environ.get("MODE_ENC_HIPCONV", "1") == "1"     # MODE_ENC_HIPCONV=0: A/B runs
-_KOFFS: dict = {}
 
 
 def _is_1x1(wshape, stride, padding, cin_mult: int = 64) -> bool:
@@ -281,10 +280,10 @@ def _wgrad_1x1(dy: torch.Tensor, x: torch.Tensor, wshape) -> torch.Tensor:
     R = dy.shape[0] * dy.shape[2] * dy.shape[3]
     tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
     G = max(1, min(R // 256, 768 // tiles, max(4, (8 << 20) // (cout * cin * 4))))      # ~3 workgroups per CU, >= 4 K-steps per group, <= 8 MiB of partial sums
-    key = (R, G, dy.device)
-    offs = _KOFFS.get(key)
+    key = ("koffs", R, G, dy.device)
+    offs = _TABLES.get(key)
     if offs is None:
-        offs = _KOFFS[key] = torch.tensor([(R * i) // G for i in range(G + 1)], dtype=torch.int32, device=dy.device)
+        offs = _TABLES.put(key, torch.tensor([(R * i) // G for i in range(G + 1)], dtype=torch.int32, device=dy.device))
     part = torch.empty((G, cout, cin), dtype=torch.float32, device=dy.device)
     d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=cout, N=cin, K=R, A=dy.data_ptr(), lda=cout, W=x.data_ptr(), ldw=cin,
                        C=part.data_ptr(), ldc=cin, k_group_offsets=offs.data_ptr(), num_k_groups=G, c_group_stride=cout * cin,
@@ -293,16 +292,54 @@ def _wgrad_1x1(dy: torch.Tensor, x: torch.Tensor, wshape) -> torch.Tensor:
     return (part.sum(0) if G > 1 else part[0]).view(cout, cin, 1, 1)
 
 
-_TAPS: dict = {}
+class _TableCache:
+    """Byte-bounded LRU for the int32 index tables of the implicit-GEMM convolutions (tap tables: ~0.35 MB per sample and distinct batch size for a
+    ResNet-50 at 224 x 224; K-group offsets: bytes).  A ragged last batch or a varying environment count would otherwise grow device memory without
+    bound.  Eviction only drops the CACHE's reference: a table in use by an in-flight autograd graph stays alive through `ctx`, and a captured
+    hipGraph - which holds raw pointers - pins its tables through :attr:`sink` (GraphedVisualEncoder sets it around warm-up + capture and keeps the
+    list next to the graph).  MODE_ENC_TABLE_CACHE_MB (default 256) sets the bound."""
+
+    def __init__(self):
+        import collections
+        import os
+        self.d = collections.OrderedDict()
+        self.bytes = 0
+        self.limit = int(float(os.environ.get("MODE_ENC_TABLE_CACHE_MB", "256")) * (1 << 20))
+        self.sink = None                                                       # a list while a GraphedVisualEncoder warms up / captures
+
+    def get(self, key):
+        t = self.d.get(key)
+        if t is not None:
+            self.d.move_to_end(key)
+            if self.sink is not None:
+                self.sink.append(t)
+        return t
+
+    def put(self, key, t):
+        self.d[key] = t
+        self.bytes += t.numel() * t.element_size()
+        if self.sink is not None:
+            self.sink.append(t)
+        while self.bytes > self.limit and len(self.d) > 1:
+            _, old = self.d.popitem(last=False)
+            self.bytes -= old.numel() * old.element_size()
+        return t
+
+    def __len__(self):
+        return len(self.d)
+
+
+_TABLES = _TableCache()
 
 
 def _tap_table(n, H, W_, ho, wo, kh_, kw_, sh, sw, ph, pw, dev, transposed: bool = False) -> torch.Tensor:
     """int32 [kh*kw, rows]: forward table (rows = output pixels): the INPUT row that tap (a, b) pairs with output pixel (n, h, w); transposed (rows = input
-    pixels): the OUTPUT row whose tap (a, b) read input pixel (n, h, w).  -1 where there is none (outside the image / between the strides).  Cached."""
-    key = (n, H, W_, kh_, kw_, sh, sw, ph, pw, dev, transposed)
-    idx = _TAPS.get(key)
+    pixels): the OUTPUT row whose tap (a, b) read input pixel (n, h, w).  -1 where there is none (outside the image / between the strides).  Cached
+    (LRU, `_TableCache`)."""
+    key = ("taps", n, H, W_, kh_, kw_, sh, sw, ph, pw, dev, transposed)
+    idx = _TABLES.get(key)
     if idx is None:
-        # (one entry per (batch, image size, filter geometry): a run has ~20.  Never evicted: captured hipGraphs - GraphedVisualEncoder - hold raw pointers into them)
+        # one entry per (batch, image size, filter geometry): a run with one batch size has ~20
         nn_ = torch.arange(n, device=dev).view(n, 1, 1)
         tabs = []
         neg = torch.full((), -1, device=dev)
@@ -321,7 +358,7 @@ def _tap_table(n, H, W_, ho, wo, kh_, kw_, sh, sw, ph, pw, dev, transposed: bool
                     h2, w2 = torch.div(hn, sh, rounding_mode="floor"), torch.div(wn_, sw, rounding_mode="floor")
                     ok = (hn >= 0) & (wn_ >= 0) & (hn % sh == 0) & (wn_ % sw == 0) & (h2 < ho) & (w2 < wo)
                     tabs.append(torch.where(ok, (nn_ * ho + h2) * wo + w2, neg).reshape(-1))
-        idx = _TAPS[key] = torch.stack(tabs).to(torch.int32).contiguous()
+        idx = _TABLES.put(key, torch.stack(tabs).to(torch.int32).contiguous())
     return idx
 
 
@@ -393,10 +430,10 @@ def _wgrad_taps(dy: torch.Tensor, x: torch.Tensor, wshape, stride, padding) -> t
     one_launch = cin % 64 == 0                                   # all taps as ONE product (N = taps * Cin, ABI 10 `w_tap_cols`): the dY tiles are shared through L2
     tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * taps
     G = max(1, min(R // 256, 512 // tiles, max(4, (8 << 20) // (cout * cin * taps * 4))))      # scripts/conv_wgrad_probe.py: 40-80 groups at 64 / 128 channels, 10-20 at 256, ~4 at 512; <= 8 MiB of partial sums
-    okey = (R, G, dy.device)
-    offs = _KOFFS.get(okey)
+    okey = ("koffs", R, G, dy.device)
+    offs = _TABLES.get(okey)
     if offs is None:
-        offs = _KOFFS[okey] = torch.tensor([(R * i) // G for i in range(G + 1)], dtype=torch.int32, device=dy.device)
+        offs = _TABLES.put(okey, torch.tensor([(R * i) // G for i in range(G + 1)], dtype=torch.int32, device=dy.device))
     part = torch.empty((G, cout, kh_, kw_, cin), dtype=torch.float32, device=dy.device)       # channels_last order of [Cout, Cin, kh, kw]
     lib = L.load(); st = _stream()
     if one_launch:
@@ -463,6 +500,11 @@ class _ConvFn(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+def _wver(conv: nn.Conv2d):
+    """What a cached copy of `conv.weight` is valid for: torch's version counter + the module's invalidation generation (invalidate_conv_shadows)."""
+    return (conv.weight._version, conv.__dict__.get("_mode_wgen", 0))
+
+
 def _shadow(conv: nn.Conv2d, dtype: torch.dtype) -> torch.Tensor:
     """The convolution's weight in the compute dtype, cached on the module (not a buffer: never in a state_dict) and refreshed in place when the
     parameter changes (its version counter / storage moved).  Staleness rests on torch's version counter: optimizers, `load_state_dict`, `copy_` and every
@@ -471,15 +513,20 @@ def _shadow(conv: nn.Conv2d, dtype: torch.dtype) -> torch.Tensor:
     ent = conv.__dict__.get("_mode_lp")
     if ent is None or ent[2].dtype != dtype or ent[2].device != w.device or ent[2].shape != w.shape:
         ent = conv.__dict__["_mode_lp"] = [-1, 0, torch.empty_like(w, dtype=dtype)]
-    if ent[0] != w._version or ent[1] != w.data_ptr():
+    if ent[0] != _wver(conv) or ent[1] != w.data_ptr():
         with torch.no_grad():
             ent[2].copy_(w)
-        ent[0], ent[1] = w._version, w.data_ptr()
+        ent[0], ent[1] = _wver(conv), w.data_ptr()
     return ent[2]
 
 
-def refresh_conv_shadows(module: nn.Module, dtype: torch.dtype) -> None:
-    """All stale compute-dtype weight shadows of `module`'s convolutions in ONE multi-tensor copy (instead of one cast launch per convolution)."""
+def refresh_conv_shadows(module: nn.Module, dtype: torch.dtype, force: bool = False) -> None:
+    """The compute-dtype weight shadows of `module`'s convolutions in ONE multi-tensor copy (instead of one cast launch per convolution).
+    ``force=False`` copies only the shadows whose parameter's version counter / storage moved.  ``force=True`` copies all of them: the encoders'
+    TRAINING forward (grad mode) does that once per call, because a write through ``p.data`` (``p.data.copy_(ema)``, ``p.data.mul_()``,
+    ``w.data.normal_()``) does NOT bump ``p._version`` and a version-gated cache would silently keep computing with the old weights in both the
+    forward and the backward (53 tensors, one `_foreach_copy_`: ~20 us beside a 30-ms step).  Inference (no-grad, the captured graphs) stays
+    version-gated - code that writes weights through ``.data`` there calls :func:`invalidate_conv_shadows` (the checkpoint loader does)."""
     convs = module.__dict__.get("_mode_convs")
     if convs is None:
         convs = module.__dict__["_mode_convs"] = [m for m in module.modules() if isinstance(m, nn.Conv2d)]
@@ -489,12 +536,22 @@ def refresh_conv_shadows(module: nn.Module, dtype: torch.dtype) -> None:
         ent = c.__dict__.get("_mode_lp")
         if ent is None or ent[2].dtype != dtype or ent[2].device != w.device or ent[2].shape != w.shape:
             ent = c.__dict__["_mode_lp"] = [-1, 0, torch.empty_like(w, dtype=dtype)]
-        if ent[0] != w._version or ent[1] != w.data_ptr():
+        if force or ent[0] != _wver(c) or ent[1] != w.data_ptr():
             src.append(w.detach()); dst.append(ent[2])
-            ent[0], ent[1] = w._version, w.data_ptr()
+            ent[0], ent[1] = _wver(c), w.data_ptr()
     if dst:
         with torch.no_grad():
             torch._foreach_copy_(dst, src)
+
+
+def invalidate_conv_shadows(module: nn.Module) -> None:
+    """Mark every cached compute-dtype convolution weight under `module` stale (eager shadows AND the copies `GraphedVisualEncoder` replays
+    against): the next forward re-casts them in place.  Call it after writing weights in a way torch's version counter does not see -
+    ``p.data.copy_() / p.data.mul_()`` (EMA swaps), raw-pointer writes.  In-place ops on the Parameter itself, optimizers and
+    ``load_state_dict`` bump the counter and need no call."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            m.__dict__["_mode_wgen"] = m.__dict__.get("_mode_wgen", 0) + 1
 
 
 def _conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
@@ -700,7 +757,7 @@ class _FiLMResNetPolicy(nn.Module):
         if condition.dim() == 3:
             condition = condition.squeeze(1)
         if USE_HIP_CONV_WGRAD and x.is_cuda and torch.is_grad_enabled() and _compute_dtype(x) == torch.bfloat16:
-            refresh_conv_shadows(self, torch.bfloat16)                              # one multi-tensor cast for all 53 weights, only when they changed
+            refresh_conv_shadows(self, torch.bfloat16, force=True)                  # one multi-tensor cast for all 53 weights; unconditional: `.data` writes bump no version
         x = self.resnet.stem(x)
         for i in range(1, 5):
             film = getattr(self, f"film{i}").params(condition.to(torch.float32))
@@ -758,7 +815,7 @@ class ResNetEncoderWithFiLM(nn.Module):
             if conditioning_vector is not None:
                 conditioning_vector = torch.cat([conditioning_vector for _ in range(t_steps)], dim=0)     # the reference's order (resnets.py:129)
         if USE_HIP_CONV_WGRAD and x.is_cuda and torch.is_grad_enabled() and _compute_dtype(x) == torch.bfloat16:
-            refresh_conv_shadows(self, torch.bfloat16)
+            refresh_conv_shadows(self, torch.bfloat16, force=True)
         x = bn_film_act(_conv2d(self.conv1, _to_layout(x)), self.bn1, relu=True)
         x = F.max_pool2d(x, 3, 2, 1)
         for i in range(1, 5):
@@ -834,9 +891,9 @@ class GraphedVisualEncoder:
             ent = cache.get(ck)
             if ent is None:
                 ent = cache[ck] = [None, None, torch.empty_like(w, dtype=dtype)]
-            if ent[0] != w._version or ent[1] != w.data_ptr():
+            if ent[0] != _wver(m) or ent[1] != w.data_ptr():
                 ent[2].copy_(w)
-                ent[0], ent[1] = w._version, w.data_ptr()
+                ent[0], ent[1] = _wver(m), w.data_ptr()
             out[id(m)] = ent[2]
         return out
 
@@ -864,6 +921,8 @@ class GraphedVisualEncoder:
             side.wait_stream(torch.cuda.current_stream(dev))
             global _W_OVERRIDE
             saved, _W_OVERRIDE = _W_OVERRIDE, self._weights(wdt)
+            saved_sink, _TABLES.sink = _TABLES.sink, []                          # every index table the warm-up / capture touches: pinned next to the graph
+            ent["tables"] = _TABLES.sink
             try:
                 with torch.cuda.stream(side):                                    # outside the capture: MIOpen's algorithm search, code-object loads
                     for _ in range(2):
@@ -874,6 +933,7 @@ class GraphedVisualEncoder:
                     ent["out"] = self._eager(ent["s"], ent["g"], ent["c"])
             finally:
                 _W_OVERRIDE = saved
+                _TABLES.sink = saved_sink
             ent["graph"] = graph
             self._graphs[key] = ent
         self._weights(wdt)                                                       # weights whose version moved since the last call: re-cast in place

@@ -7,6 +7,7 @@ those producers are out of scope here, so this harness starts at their outputs a
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -221,19 +222,40 @@ class ChunkedRolloutPolicy:
         return current
 
 
+def _read_checkpoint_file(path: str) -> Dict[str, torch.Tensor]:
+    """The file forms `MoDEAgent.load_pretrained_parameters` accepts (mode_agent.py:141-158): a checkpoint DIRECTORY holding
+    ``model_cleaned.safetensors`` (preferred) or ``model_cleaned.pt``; a ``.safetensors`` file; a Lightning ``.ckpt`` / ``torch.save``d dict whose
+    weights sit under ``'state_dict'`` (a bare state_dict is accepted too).  Lightning checkpoints carry hyper-parameter objects, which torch >= 2.6
+    refuses under its ``weights_only=True`` default: the safe load is tried first and the full unpickler only after it fails - the reference
+    (torch 2.2) always unpickles; load only checkpoints you trust."""
+    if os.path.isdir(path):
+        st, pt = os.path.join(path, "model_cleaned.safetensors"), os.path.join(path, "model_cleaned.pt")
+        if os.path.exists(st):
+            path = st
+        elif os.path.exists(pt):
+            path = pt
+        else:
+            raise FileNotFoundError(f"No cleaned weights found in {path}")     # the reference's message (mode_agent.py:155)
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    try:
+        blob = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as safe_err:                                               # pickle.UnpicklingError and friends: non-tensor objects in the file
+        try:
+            blob = torch.load(path, map_location="cpu", weights_only=False)
+        except Exception as e:
+            raise RuntimeError(f"cannot read checkpoint {path}: weights_only load failed with {safe_err!r}, full unpickling with {e!r}") from e
+    return blob.get("state_dict", blob) if isinstance(blob, dict) else blob
+
+
 def load_denoiser_checkpoint(model, source, prefix: str = "model.inner_model.", strict: bool = False):
     """Load the denoiser's tensors from an agent checkpoint: a ``.safetensors`` file (the published HF weights), a ``torch.save``d
     ``state_dict`` / Lightning checkpoint, or an in-memory mapping.  Keys are matched by name after stripping the agent's prefix
     (``model.inner_model.`` — mode_agent.py:209-251 loads by key and skips the CLIP / ResNet tensors, which belong to the out-of-scope
     encoders); the kernel-side layout is untouched because the Parameters are arena views.  Returns (missing, unexpected, skipped_shape)."""
-    if isinstance(source, (str, bytes)):
-        path = source if isinstance(source, str) else source.decode()
-        if path.endswith(".safetensors"):
-            from safetensors.torch import load_file
-            sd = load_file(path)
-        else:
-            sd = torch.load(path, map_location="cpu")
-            sd = sd.get("state_dict", sd)
+    if isinstance(source, (str, bytes, os.PathLike)):
+        sd = _read_checkpoint_file(os.fsdecode(source))
     else:
         sd = dict(source)
     own = model.state_dict()
@@ -315,14 +337,8 @@ def load_agent_checkpoint(target, source, strict: bool = False, verbose: bool = 
     ``target``: ``{'model': GCDenoiser, 'static_resnet': m, 'gripper_resnet': m}`` (any subset), a ``ChunkedRolloutPolicy`` built with encoders, or an
     object with those attributes.  Returns ``{'direct', 'reshaped', 'skipped', 'missing', 'unexpected'}`` (counts for the first two, key lists for the
     rest; keys carry the agent-level prefix).  Parameters are written in place (arena views, the graphs' static pointers stay valid)."""
-    if isinstance(source, (str, bytes)):
-        path = source if isinstance(source, str) else source.decode()
-        if path.endswith(".safetensors"):
-            from safetensors.torch import load_file
-            sd = load_file(path)
-        else:
-            sd = torch.load(path, map_location="cpu")
-            sd = sd.get("state_dict", sd)
+    if isinstance(source, (str, bytes, os.PathLike)):
+        sd = _read_checkpoint_file(os.fsdecode(source))
     else:
         sd = dict(source)
     parts = _agent_parts(target)
@@ -353,8 +369,10 @@ def load_agent_checkpoint(target, source, strict: bool = False, verbose: bool = 
         name, sub = tkey.split(".", 1)
         picked[name][sub] = fitted
     missing, unexpected = [], []
+    from .perceptual_encoders import invalidate_conv_shadows
     for name, mod in parts.items():
         res = mod.load_state_dict(picked[name], strict=strict)
+        invalidate_conv_shadows(mod)                                             # cached compute-dtype conv weights are re-cast on next use, whatever the loader's write path
         missing += [f"{name}.{k}" for k in res.missing_keys]
         unexpected += [f"{name}.{k}" for k in res.unexpected_keys]
     if verbose:

@@ -203,6 +203,11 @@ def sample_euler(model, state, action, goal, sigmas, scaler=None, extra_args=Non
         fused = getattr(model, "first_order_ode_fused", None)
         out = fused(state, action, goal, sigmas) if fused is not None else None
         if out is not None:
+            # The reference draws `eps = randn_like(action)` on EVERY step, churn or not (gc_sampling.py:196), and so does the step loop below: the
+            # fused route makes the same draws and discards them, so the generator leaves this call in the state the reference leaves it in (the
+            # next chunk's initial latent for a given seed is the reference's).  n tiny launches, ~3 us of host each.
+            for _ in range(len(sigmas) - 1):
+                torch.randn_like(action)
             return out
     run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
     for i in range(len(sigmas) - 1):

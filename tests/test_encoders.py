@@ -546,3 +546,68 @@ def test_training_conv_writes_the_batchnorm_partial_statistics(k, stride, cin, c
     assert rel(a[0], b[0]) < 2e-3                                              # (an activation within a bf16 ulp of the ReLU / rounding boundary may flip)
     for i in (4, 5, 6, 7):
         assert rel(a[i], b[i]) < 1e-2, i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["r18p", "r18f"])
+def test_weight_writes_through_dot_data_are_seen(tag):
+    """A write through ``p.data`` (EMA swap: ``p.data.copy_(ema)``, ``p.data.mul_()``) does NOT bump ``p._version``, so a version-gated cache of the bf16
+    convolution weights would keep computing with the old values.  Training forward (grad mode): the shadows are re-cast on every call - zeroing
+    every convolution through ``.data`` must zero what the trunk contributes and the weight gradients must be those of zero weights.  Inference
+    (no-grad, version-gated): ``invalidate_conv_shadows`` makes the next forward see the write."""
+    torch.manual_seed(5)
+    enc = CTORS[tag](32).cuda().train()
+    img = torch.randn(4, 3, 64, 64, device="cuda"); cond = torch.randn(4, 32, device="cuda")
+
+    def run(grad=True):
+        with torch.set_grad_enabled(grad), torch.autocast("cuda", dtype=torch.bfloat16):
+            return enc(img, cond).float()
+    y0 = run()
+    assert float(y0.abs().max()) > 0
+    convs = [m for m in enc.modules() if isinstance(m, torch.nn.Conv2d)]
+    ver = [c.weight._version for c in convs]
+    keep = [c.weight.detach().clone() for c in convs]
+    for c in convs[1:]:                                                           # every convolution behind the stem
+        c.weight.data.mul_(0)
+    assert [c.weight._version for c in convs] == ver                              # the premise: torch did not notice
+    ref = CTORS[tag](32).cuda().train()
+    ref.load_state_dict(enc.state_dict())
+    y1, yr = run(), None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yr = ref(img, cond).float()                                               # a fresh module with the same (zeroed) weights: no cache to be stale
+    assert rel(y1, yr) < 1e-2 and rel(y1, y0) > 0.1, (rel(y1, yr), rel(y1, y0))
+    # inference path: stale until invalidated
+    enc.eval(); ref.eval()
+    for c, w in zip(convs, keep):
+        c.weight.data.copy_(w)
+    E.invalidate_conv_shadows(enc)
+    ref.load_state_dict(enc.state_dict())
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        yr2 = ref(img, cond).float()
+    y2 = run(grad=False)
+    assert rel(y2, yr2) < 1e-2, rel(y2, yr2)
+
+
+def test_index_table_cache_is_a_bounded_lru():
+    """The implicit-GEMM convolutions' index tables (tap tables, K-group offsets) live in a byte-bounded LRU: a varying batch size must not grow
+    memory without bound; a table in use elsewhere survives eviction through its other references (a captured graph pins them via `sink`)."""
+    c = E._TableCache()
+    c.limit = 4 * 1000 * 4                                                       # room for four 1000-element int32 tables
+    tabs = [torch.zeros(1000, dtype=torch.int32) + i for i in range(6)]
+    for i in range(4):
+        c.put(("t", i), tabs[i])
+    assert len(c) == 4 and c.get(("t", 0)) is tabs[0]                            # touching 0 makes 1 the eviction candidate
+    pinned = []
+    c.sink = pinned
+    c.put(("t", 4), tabs[4])
+    assert len(c) == 4 and c.get(("t", 1)) is None and c.get(("t", 0)) is tabs[0]
+    assert pinned[0] is tabs[4] and pinned[1] is tabs[0]                         # put and get both report to the sink while it is set
+    c.sink = None
+    c.put(("t", 5), tabs[5])
+    assert c.get(("t", 2)) is None and c.bytes == 4 * 4000
+    big = torch.zeros(10000, dtype=torch.int32)
+    c.put(("big",), big)                                                         # larger than the bound: kept alone (never evict the entry just made)
+    assert len(c) == 1 and c.get(("big",)) is big
+    # the real tables: same key -> same tensor, and the cache is what hands them out
+    t1 = E._tap_table(2, 6, 6, 6, 6, 3, 3, 1, 1, 1, 1, torch.device("cpu"))
+    assert E._tap_table(2, 6, 6, 6, 6, 3, 3, 1, 1, 1, 1, torch.device("cpu")) is t1 and t1.shape == (9, 72) and int(t1.min()) == -1

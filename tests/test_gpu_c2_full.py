@@ -55,7 +55,7 @@ def c2():
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_c2_full_forward_and_ddim_vs_oracle(c2, dtype):
+def test_c2_full_forward_and_ddim_vs_oracle(c2, golden, dtype):
     cfg, sd, inp, sched = c2["cfg"], c2["sd"], c2["inp"], c2["sched"]
     m = _model(cfg, sd, dtype).eval()
     c = {k: v.cuda() for k, v in inp.items()}
@@ -79,6 +79,16 @@ def test_c2_full_forward_and_ddim_vs_oracle(c2, dtype):
         assert torch.equal(m._last_topk[l].cpu().long(), wi), l
     print(f"C2 B=128 {dtype}: forward rel-L2 {e_f:.2e}, 10-step DDIM rel-L2 {e_x:.2e} (graph {e_g:.2e}); tol {OUT[dtype]:g}; top-k margin {c2['margin']:.1e}")
     assert e_f < OUT[dtype] and e_x < OUT[dtype] and e_g < OUT[dtype]
+    # ... and against the REFERENCE itself: fixture F17 = the reference's MoDeDiT / GCDenoiser / sample_ddim on these very inputs
+    # (oracle/gen_golden_c2_full.py; modedit.py:741-809, gc_sampling.py:922-951) - outputs, per-step sampler inputs, expert ids of every (step, layer)
+    g = golden("F17_c2_full")
+    assert int(g["B"]) == B and int(g["seed"]) == SEED and np.array_equal(g["sigmas"], sched.numpy())
+    r_f, r_x, r_g = rel(f, g["forward"]), rel(x, g["x_final"]), rel(xg, g["x_final"])
+    assert np.array_equal(m._last_topk.cpu().numpy().transpose(1, 0, 2), g["topk_idx"])            # [n, L, k]: bit-exact vs the reference's router
+    assert np.array_equal(idx[:, 0, :].numpy(), g["fwd_topk_idx"])
+    r_s = max(rel(steps[i][:4], g["action_in"][i]) for i in range(10))
+    print(f"C2 B=128 {dtype} vs REFERENCE fixture F17: forward {r_f:.2e}, DDIM {r_x:.2e} (graph {r_g:.2e}), worst per-step sampler input {r_s:.2e}")
+    assert r_f < OUT[dtype] and r_x < OUT[dtype] and r_g < OUT[dtype] and r_s < OUT[dtype]
     assert rel(x, xg) < OUT[dtype]                                              # generic (callback) path vs the fused hipGraph path
 
 

@@ -679,3 +679,38 @@ def test_residual_norm_epilogue_no_k_loop_kernel_is_bit_identical_to_the_ring(M)
     ref = x0 + ya.float() @ wo.float().t()
     assert float((outs[512][0] - ref).norm() / ref.norm()) < 1e-3
     assert float((outs[512][2].sum(1) - (outs[512][0] ** 2).sum(1)).abs().max() / (outs[512][0] ** 2).sum(1).max()) < 1e-5
+
+
+def test_large_lds_kernels_keep_their_launch_attribute_per_device():
+    """hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: every launcher of a > 64-KiB-LDS kernel keeps a per-device "done" bit
+    (mode_common.h: LdsLimitOnce) instead of one process-wide flag.  With one GPU in the box the table is exercised by device round trips: the
+    154-KiB ping-pong GEMM, the 160-KiB fused QKV + attention and a ring kernel launch before and after `set_device` hops (and on every visible
+    device, if there are several) and keep returning the same bits."""
+    M_, N_, K_ = 1792, 2048, 1024
+    A = rnd(M_, K_, seed=71).to(torch.bfloat16); W = rnd(N_, K_, seed=72, scale=K_ ** -0.5).to(torch.bfloat16)
+    hh = rnd(8 * 14, 1024, seed=73).to(torch.bfloat16); wq = rnd(3072, 1024, seed=74, scale=1 / 32).to(torch.bfloat16); bq = rnd(3072, seed=75)
+    lib = L.load()
+    outs = []
+    ndev = torch.cuda.device_count()
+    try:
+        for rnd_trip in range(2):
+            for d_ in range(ndev):
+                torch.cuda.set_device(d_)
+                dv = torch.device("cuda", d_)
+                lib.mode_set_option(b"gemm_cfg", 17)                                # the persistent ping-pong kernel (154 KiB of LDS)
+                o1 = H.gemm(A.to(dv), W.to(dv), out_dtype=torch.bfloat16)
+                lib.mode_set_option(b"gemm_cfg", 4)                                 # the three-slot 128 x 64 ring (72 KiB)
+                o2 = H.gemm(A.to(dv), W.to(dv), out_dtype=torch.bfloat16)
+                lib.mode_set_option(b"gemm_cfg", 0)
+                g1 = torch.ones(128, device=dv)
+                rc, o3 = H.qkv_attn(hh.to(dv), wq.to(dv), bq.to(dv), g1, g1, 8, 14, 8)
+                assert rc == 0
+                torch.cuda.synchronize(dv)
+                outs.append((o1.cpu(), o2.cpu(), o3.cpu()))
+    finally:
+        lib.mode_set_option(b"gemm_cfg", 0)
+        torch.cuda.set_device(0)
+    ref = A.float() @ W.float().t()
+    assert rel(outs[0][0].float(), ref) < 6e-3
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))

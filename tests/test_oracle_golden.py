@@ -189,3 +189,31 @@ def test_oracle_token_routing_vs_reference(golden):
         assert float((out - torch.from_numpy(g[f"{tag}_out"])).norm() / torch.from_numpy(g[f"{tag}_out"]).norm()) < 2e-5
     x = O.sample_ddim(sd, cfg, 0.5, inp["state_images"], inp["x0"], inp["goals"], torch.from_numpy(g["sigmas"]))
     assert float((x - torch.from_numpy(g["x_final"])).norm() / torch.from_numpy(g["x_final"]).norm()) < 2e-5
+
+
+def test_oracle_full_size_benchmark_workload_vs_reference(golden):
+    """F17 (oracle/gen_golden_c2_full.py): the BENCHMARKED workload - 12 layers, d = 1024, 4 experts top-2, obs 2048, B = 128, seed 400 - produced by the
+    reference's own `MoDeDiT` + `GCDenoiser` + `sample_ddim` (modedit.py:741-809, gc_sampling.py:922-951).  The oracle reproduces the forward at
+    sigma = sched[3], the 10-step DDIM chunk, the sampler's intermediate actions and the expert ids of every (step, layer): twelve layers of depth
+    pinned to the reference directly.  ~25 s of CPU."""
+    g = golden("F17_c2_full")
+    cfg = get_config(str(g["cfg"])); B, seed = int(g["B"]), int(g["seed"])
+    assert (cfg.n_layers, cfg.embed_dim, cfg.num_experts, cfg.top_k, cfg.obs_dim, B) == (12, 1024, 4, 2, 2048, 128)
+    assert float(g["margin"]) > 1e-5, "fixture too close to a top-k tie"
+    sd = make_state_dict(cfg, seed); inp = make_inputs(cfg, B, seed + 1)
+    sched = torch.from_numpy(g["sigmas"])
+    assert torch.equal(sched, O.get_sigmas_exponential(10, 1e-3, 80.0))
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    with torch.no_grad():
+        f, aux = O.dit_forward(sd, cfg, inp["state_images"], inp["actions"], inp["goals"], float(g["sigma_fwd"]) * torch.ones(B), return_aux=True)
+        x, xs = O.sample_ddim(sd, cfg, 0.5, inp["state_images"], inp["x0"], inp["goals"], sched, trace=True)
+    assert np.array_equal(torch.stack(aux.topk_idx)[:, 0, 0, :].numpy(), g["fwd_topk_idx"])
+    emb = O.sigma_embedding(sd, sched[:-1])
+    for l in range(cfg.n_layers):
+        _, p = O.router_probs(sd, l, emb)
+        wi, _ = O.topk_route(p, cfg.top_k, cfg.router_normalize)
+        assert np.array_equal(wi.numpy(), g["topk_idx"][:, l, :]), l
+    assert rel(f, g["forward"]) < TOL and rel(x, g["x_final"]) < TOL
+    for i in range(1, 10):                                                       # the reference's callback `action` at step i = the update of step i-1
+        assert rel(xs[i - 1][:4], g["action_in"][i]) < TOL, i
+    assert np.array_equal(inp["x0"][:4].numpy(), g["action_in"][0])

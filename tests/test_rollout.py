@@ -129,6 +129,24 @@ def test_agent_checkpoint_loader_reference_key_names(tmp_path):
         pass
     a = _Agent(); a.model, a.static_resnet, a.gripper_resnet = den, stat, grip
     assert rollout.load_agent_checkpoint(a, path)["direct"] == res["direct"]
+    # the reference also takes the checkpoint DIRECTORY (model_cleaned.safetensors inside, mode_agent.py:143-155) ...
+    assert rollout.load_agent_checkpoint(a, str(tmp_path))["direct"] == res["direct"]
+    assert rollout.load_agent_checkpoint(a, tmp_path)["direct"] == res["direct"]                   # os.PathLike
+    # ... a directory with model_cleaned.pt only, and an empty one (its FileNotFoundError)
+    d2 = tmp_path / "pt_only"; d2.mkdir()
+    torch.save({"state_dict": {k: v.contiguous() for k, v in ck.items()}}, d2 / "model_cleaned.pt")
+    assert rollout.load_agent_checkpoint(a, str(d2))["direct"] == res["direct"]
+    d3 = tmp_path / "empty"; d3.mkdir()
+    with pytest.raises(FileNotFoundError, match="No cleaned weights"):
+        rollout.load_agent_checkpoint(a, str(d3))
+    # a Lightning-style .ckpt carries non-tensor objects next to the weights: torch >= 2.6 refuses it under weights_only=True, the loader retries
+    import argparse
+    lightning = {"state_dict": {k: v.contiguous() for k, v in ck.items()}, "hyper_parameters": argparse.Namespace(lr=1e-4), "epoch": 3}
+    torch.save(lightning, tmp_path / "last.ckpt")
+    assert rollout.load_agent_checkpoint(a, str(tmp_path / "last.ckpt"))["direct"] == res["direct"]
+    with pytest.raises(RuntimeError, match="cannot read checkpoint"):
+        (tmp_path / "garbage.ckpt").write_bytes(b"not a checkpoint")
+        rollout.load_agent_checkpoint(a, str(tmp_path / "garbage.ckpt"))
 
 
 @pytest.mark.gpu

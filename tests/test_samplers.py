@@ -188,12 +188,18 @@ def test_euler_without_churn_is_the_fused_first_order_solve(dtype):
     inp = {k: v.cuda() for k, v in make_inputs(cfg, 6, 5).items()}
     state = {"state_images": inp["state_images"]}
     sig = gc_sampling.get_sigmas_exponential(10, 0.001, 80.0, "cuda")
+    torch.cuda.manual_seed(123)
     fused = samplers.sample_euler(den, state, inp["x0"], inp["goals"], sig, disable=True)
+    after_fused = torch.randn(4, device="cuda")
     ddim = gc_sampling.sample_ddim(den, state, inp["x0"], inp["goals"], sig, disable=True)
     assert torch.equal(fused, ddim)
     steps = []
+    torch.cuda.manual_seed(123)
     loop = samplers.sample_euler(den, state, inp["x0"], inp["goals"], sig, disable=True, callback=lambda d: steps.append(d["i"]))
+    after_loop = torch.randn(4, device="cuda")
     assert steps == list(range(10))
+    # the reference draws eps on every step even without churn (gc_sampling.py:196): both routes leave the generator in the same state
+    assert torch.equal(after_fused, after_loop)
     r = rel(fused, loop)
     print(f"euler fused vs step loop, {dtype}: {r:.2e}")
     assert r < (2e-6 if dtype == "fp32" else BF16_OUT), r
