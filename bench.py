@@ -405,7 +405,10 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU, z
     A_len, A = m.action_seq_len, m.action_dim
     img = torch.randn(B, m.n_img_tokens, m.obs_dim, generator=g).to(device); goal = torch.randn(B, 1, m.goal_dim, generator=g).to(device)
     acts = torch.randn(B, A_len, A, generator=g).to(device); noise = torch.randn(B, A_len, A, generator=g).to(device)
-    opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)         # mode_agent.yaml:24-29, two groups as mode_agent.py:365-384
+    # single process: the expert matrices (88 % of the parameters) are updated in the epilogue of their weight-gradient GEMMs (ModeAdamWFuse) - no
+    # gradient store / re-read for them and no optimizer pass beside the backward; world > 1 exchanges gradients, so it keeps the two-pass update
+    fuse = world == 1 and os.environ.get("MODE_FUSE_EXPERT_STEP", "1") == "1" and m.engine.compute_dtype == "bf16"
+    opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, fuse_expert_step=fuse)   # mode_agent.yaml:24-29, two groups as mode_agent.py:365-384
     if os.environ.get("MODE_ADAMW_BLOCKS"):
         m.engine.lib.mode_set_option(b"adamw_blocks", int(os.environ["MODE_ADAMW_BLOCKS"]))
     # gradient exchange dtype: fp32 like the reference's DDP (default), or MODE_DP_COMM=bf16 = half the bytes on the xGMI links
@@ -428,7 +431,9 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU, z
     ev_bwd = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
     ev_end = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
     it = [0]
-    overlap = os.environ.get("MODE_OPT_OVERLAP", "1") == "1"
+    # the rest of the optimizer pass: overlapped per block with the backward (which then keeps the ring kernels for its other large GEMMs, "bwd_coexec"), or -
+    # with the expert matrices out of it, 0.4 ms of HBM time - after the backward, which then runs its big data-gradient GEMM on the persistent kernel
+    overlap = os.environ.get("MODE_OPT_OVERLAP", "0" if fuse else "1") == "1"
 
     def step():
         sig = rand_log_logistic((B,), loc=math.log(SIGMA_DATA), scale=0.5, min_value=SIGMA_MIN, max_value=SIGMA_MAX, device=device)
@@ -476,12 +481,25 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU, z
     d = m.engine.dims
     fl = 3.0 * flops_per_denoise_step(B, L=d.L, D=d.D, H=d.H, T=d.T, E=d.E, k=d.k, O=d.O, G=d.G, A=d.A_dim, A_len=d.A_len)   # fwd + bwd ~ 3x forward
     backend = dist.get_backend() if dist is not None else None
-    return {"train_ms_per_step": round(ms, 3), "train_samples_per_s": round(world * B / (ms * 1e-3), 1), "train_global_batch": B * world,
+    # How to read a SCALE curve: the bytes one rank puts on its xGMI links per step for this leg (ring algorithms: all-reduce 2 (N-1)/N x payload,
+    # reduce-scatter and all-gather (N-1)/N each) and the time they need at ~300 GB/s of ring bandwidth per GPU (7 links x ~153 GB/s peak; rings are
+    # per-link bound).  A leg can only scale if dp_budget_ms fits under the backward (~2/3 of the single-GPU step): the fp32 all-reduce of 686 M
+    # parameters does NOT at N = 8 (4.8 GB, ~16 ms against an ~11.7-ms step); the bf16 wire and the ZeRO-1 legs (2.4 GB, ~8 ms) are the ones that can.
+    n_par = sum(p_.numel() for p_ in m.parameters())
+    gb = 2 if comm == torch.bfloat16 else 4
+    frac = (world - 1) / world if world > 1 else 0.0
+    if z1:
+        wire = frac * n_par * gb + frac * n_par * (2 if z1 == "bf16" else 4)      # reduce-scatter of the gradients + all-gather of the updated weights
+    else:
+        wire = 2.0 * frac * n_par * gb
+    exposed = round(sum(ev_bwd[i].elapsed_time(ev_end[i]) for i in range(ev_lo, ev_lo + steps)) / steps, 3)
+    return {"fused_expert_step": bool(fuse), "optimizer_overlap": bool(overlap), "dp_wire_gb": round(wire / 1e9, 3), "dp_budget_ms": round(wire / 300e9 * 1e3, 2), "exposed_exchange_ms": exposed,
+            "train_ms_per_step": round(ms, 3), "train_samples_per_s": round(world * B / (ms * 1e-3), 1), "train_global_batch": B * world,
             "train_mfma_frac": round(fl / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4), "train_tflops_per_gpu": round(fl / (ms * 1e-3) / 1e12, 1),
             "dp_mode": ("zero1:" + z1) if z1 else ("allreduce" if (red is not None and world > 1) else "single"),
             "dp_comm_dtype": "bf16" if comm == torch.bfloat16 else "fp32",
             # what is NOT hidden behind the backward: gradient exchange + optimizer (+ weight all-gather) still running after its last kernel
-            "exposed_exchange_and_optimizer_ms": round(sum(ev_bwd[i].elapsed_time(ev_end[i]) for i in range(ev_lo, ev_lo + steps)) / steps, 3),
+            "exposed_exchange_and_optimizer_ms": exposed,
             "train_ms_per_step_blocks": [round(b / steps * 1e3, 3) for b in blocks],
             "rccl_ranks": ranks if backend == "nccl" else None, "dp_backend": backend, "dp_ranks": ranks, "train_steps": steps}
 

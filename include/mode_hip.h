@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MODE_HIP_ABI_VERSION 10
+#define MODE_HIP_ABI_VERSION 11
 
 typedef enum ModeStatus {
   MODE_OK = 0,
@@ -111,6 +111,25 @@ int mode_probe_mfma_burn(const uint32_t* seed, float* out, int workgroups, int i
  *   total number of sorted rows (N_tokens * top_k).  Workgroups derive their (expert, row range) on the device: no host sync.
  * a_rows (optional): int32[M]; logical row m of A is read from A[a_rows[m]] (MoE gather by the dispatch permutation).
  * ------------------------------------------------------------------------------------------------------------------ */
+/* (ABI 11) AdamW applied in the EPILOGUE of a weight-gradient GEMM (MODE_GEMM_A_KM | MODE_GEMM_W_KN, bf16 operands, fp32 output, no split-K):
+ * the gradient tile never goes to memory - every output element g = grad_scale * acc updates its parameter, its two moments and the bf16 compute
+ * shadow in place, with exactly the arithmetic (and the operation order) of mode_adamw_step, so the result is bit-identical to "write dW, then
+ * run the optimizer pass".  26 instead of 34 bytes of HBM traffic per parameter, and no optimizer pass left to compete with the backward for the
+ * expert matrices (88 % of the denoiser's parameters).  All arenas share the gradient arena's element offsets: the GEMM's C pointer (which is NOT
+ * written) locates the tile: offset = C - grad_base.  Replaces, for those tensors, torch.optim.AdamW.step as configured by
+ * mode/models/mode_agent.py:365-392 (the reference neither clips nor accumulates gradients: conf/config_libero.yaml:45). */
+typedef struct ModeAdamWFuse {
+  const float* grad_base;                 /* first element of the gradient arena (address arithmetic only: never read, never written)   */
+  float* param_base;                      /* fp32 master weights                                                                        */
+  float* exp_avg_base; float* exp_avg_sq_base;
+  uint16_t* lp_base;                      /* bf16 compute shadow, or NULL                                                               */
+  float* ema_base; float ema_rate;        /* optional EMA of the weights: e -= ema_rate * (e - w) (mode/callbacks/ema.py:119-126); NULL = off */
+  float lr, beta1, beta2, eps, weight_decay;
+  int32_t step;                           /* 1-based optimizer step this update belongs to (bias correction)                            */
+  float grad_scale;
+  float* gsq;                             /* optional: one float per workgroup of the launch (grid order: z-major, then tile) = sum of squares of the   */
+  int64_t gsq_capacity;                   /* scaled gradient over the workgroup's tile, so ||g||^2 stays observable (mode_agent.py:304-363); floats available at gsq */
+} ModeAdamWFuse;
 typedef struct ModeGemmDesc {
   int32_t dtype;              /* ModeDType of A and W                                     */
   int32_t epilogue;           /* ModeEpilogue                                             */
@@ -149,6 +168,8 @@ typedef struct ModeGemmDesc {
   int64_t a_rows_tap_stride;      /* (a negative index = a zero row: the tap falls outside the image).  W: forward layout [N][K] K-contiguous (a          */
                                   /* channels_last conv weight [Cout][taps][Cin]); with MODE_GEMM_W_KN element (k, n) = W[c * ldw + t * N + n] - the SAME     */
                                   /* weight memory read for the data gradient (ldw = taps * Cin, N = Cin).  a_tap_cols % 64 == 0.                            */
+  const ModeAdamWFuse* adamw;     /* (ABI 11) non-NULL: weight-gradient GEMM with the AdamW update in its epilogue (see ModeAdamWFuse); C only locates the tile. */
+                                  /* MODE_ERR_UNSUPPORTED unless bf16 operands, MODE_GEMM_A_KM | W_KN, fp32 out, epilogue NONE, N % 128 == 0, ldc == N row pitch of the parameter */
 } ModeGemmDesc;
 #define MODE_GEMM_SKINNY_OK 1
 /* Backward-pass operand layouts (bf16, epilogue NONE; replace autograd's mm_backward for nn.Linear, i.e. the `grad @ W` and
@@ -624,7 +645,13 @@ typedef struct ModeTrainArgs {
    * place: d u gets the router's term, r_pre / the batched conditioning-row router backward are not used. */
   int32_t token_routing;
   float* tr_pre; float* tr_shifted; int32_t* tr_topk_idx; float* tr_topk_w;
+  /* (ABI 11, backward only) non-NULL: the expert matrices w1 / w2 of every block are UPDATED by their weight-gradient GEMMs (ModeAdamWFuse) instead of
+   * receiving a gradient: grads->layers[l].w1 / .w2 only locate the tensors inside the arenas and are not written.  bf16 compute mode only
+   * (MODE_ERR_UNSUPPORTED otherwise).  gsq (optional) receives mode_adamw_fuse_gsq_floats(dims) floats: per block [w2 tiles | w1 tiles], block l at
+   * l * (that count / L); their sum is the squared norm of the scaled expert-matrix gradients of the step. */
+  const ModeAdamWFuse* fuse_adamw;
 } ModeTrainArgs;
+int64_t mode_adamw_fuse_gsq_floats(const ModeDims* dims);   /* L * E * 12 * ceil(D/128)^2 */
 int mode_dit_forward_train(const ModeDims* dims, const ModeModelWeights* w, const ModeTrainArgs* a, void* stash, size_t stash_bytes,
                            void* stream);
 /* One layer of the training forward in two phases (see ModeTrainArgs.token_routing): phase 0 = [token embedding if layer == 0,] QKV, attention,

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MODE_HIP_LIB", os.path.join(_HERE, "libmode_hip.so"))
 
 MODE_BF16, MODE_F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_RESIDUAL_NORM = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 10
+ABI_VERSION = 11
 GEMM_SKINNY_OK, GEMM_W_KN, GEMM_A_KM, GEMM_UNIFORM_GROUPS, GEMM_SMALL_ROWS, GEMM_IDENTITY_ROWS = 1, 2, 4, 8, 16, 32
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -24,6 +24,14 @@ class ModeHipUnavailable(RuntimeError):
     pass
 
 
+class ModeAdamWFuse(C.Structure):
+    """AdamW in the epilogue of a weight-gradient GEMM (include/mode_hip.h, ABI 11): arena base pointers (same element offsets as the gradient
+    arena), the step's hyper-parameters, optional per-workgroup sums of squares of the gradient."""
+    _fields_ = [("grad_base", c_vp), ("param_base", c_vp), ("exp_avg_base", c_vp), ("exp_avg_sq_base", c_vp), ("lp_base", c_vp), ("ema_base", c_vp),
+                ("ema_rate", c_f32), ("lr", c_f32), ("beta1", c_f32), ("beta2", c_f32), ("eps", c_f32), ("weight_decay", c_f32), ("step", c_i32),
+                ("grad_scale", c_f32), ("gsq", c_vp), ("gsq_capacity", c_i64)]
+
+
 class ModeGemmDesc(C.Structure):
     _fields_ = [("dtype", c_i32), ("epilogue", c_i32), ("out_dtype", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("A", c_vp), ("lda", c_i64), ("W", c_vp), ("ldw", c_i64), ("w_expert_stride", c_i64),
@@ -31,7 +39,8 @@ class ModeGemmDesc(C.Structure):
                 ("a_rows", c_vp), ("expert_offsets", c_vp), ("num_experts", c_i32), ("split_k", c_i32), ("split_stride", c_i64), ("k_group_offsets", c_vp), ("num_k_groups", c_i32),
                 ("c_group_stride", c_i64), ("flags", c_i32), ("w_rows", c_vp),
                 ("C2", c_vp), ("ldc2", c_i64), ("gain", c_vp), ("row_ss_out", c_vp), ("row_ss", c_vp), ("row_ss_n", c_i32), ("row_eps", c_f32),
-                ("w_tap_cols", c_i32), ("w_rows_tap_stride", c_i64), ("a_tap_cols", c_i32), ("a_rows_tap_stride", c_i64)]
+                ("w_tap_cols", c_i32), ("w_rows_tap_stride", c_i64), ("a_tap_cols", c_i32), ("a_rows_tap_stride", c_i64),
+                ("adamw", C.POINTER(ModeAdamWFuse))]
 
 
 class ModeEmbedDesc(C.Structure):
@@ -91,7 +100,7 @@ class ModeTrainArgs(C.Structure):
                 ("meta", c_vp), ("meta_layer_stride", c_i64), ("topk_idx", c_vp), ("topk_layer_stride", c_i64), ("idx_per_token", c_i32),
                 ("probs", c_vp), ("r_pre", c_vp), ("F", c_vp), ("layer_events", c_vp), ("shifted", c_vp), ("aux_lb_coef", c_vp), ("aux_z_coef", c_vp),
                 ("d_state_images", c_vp), ("d_goals", c_vp), ("token_routing", c_i32), ("tr_pre", c_vp), ("tr_shifted", c_vp), ("tr_topk_idx", c_vp),
-                ("tr_topk_w", c_vp)]
+                ("tr_topk_w", c_vp), ("fuse_adamw", C.POINTER(ModeAdamWFuse))]
 
 
 class ModeLayerGrads(C.Structure):
@@ -203,6 +212,7 @@ PROTOTYPES = {
     "mode_adamw_step": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i32, C.c_float, c_vp, c_vp,
                                   C.c_float, c_vp]),
     "mode_ema_update": (C.c_int, [c_vp, c_vp, c_i64, C.c_float, c_vp]),
+    "mode_adamw_fuse_gsq_floats": (c_i64, [P(ModeDims)]),
     "mode_dit_backward": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeModelWeightsT), P(ModeTrainArgs), c_vp, c_vp, P(ModeModelGrads),
                                     c_vp, c_sz, c_vp]),
     "mode_dit_forward": (C.c_int, [P(ModeDims), P(ModeModelWeights), P(ModeForwardArgs), c_vp, c_sz, c_vp]),

@@ -99,6 +99,7 @@ extern "C" size_t mode_hip_sizeof(const char* n) {
   MODE_SZ(ModeGemmDesc) MODE_SZ(ModeEmbedDesc) MODE_SZ(ModeHeadDesc) MODE_SZ(ModeGroupedMlpDesc) MODE_SZ(ModeDims) MODE_SZ(ModeLayerWeights)
   MODE_SZ(ModeModelWeights) MODE_SZ(ModeMetaLayout) MODE_SZ(ModeForwardArgs) MODE_SZ(ModeStashLayout) MODE_SZ(ModeTrainArgs) MODE_SZ(ModeLayerGrads)
   MODE_SZ(ModeModelGrads) MODE_SZ(ModeLayerWeightsT) MODE_SZ(ModeModelWeightsT) MODE_SZ(ModeBnFilmDesc) MODE_SZ(ModeQkvAttnDesc) MODE_SZ(ModeConvBnDesc)
+  MODE_SZ(ModeAdamWFuse)
 #undef MODE_SZ
   return 0;
 }
@@ -142,6 +143,8 @@ extern "C" int mode_set_option(const char* key, int value) {
 extern "C" int mode_gemm(const ModeGemmDesc* d, void* stream) {
   if (!d || !d->A || !d->W || !d->C || d->M < 0 || d->N <= 0) return MODE_ERR_BAD_ARG;
   if (d->expert_offsets && d->num_experts <= 0) return MODE_ERR_BAD_ARG;
+  if (d->adamw && !(d->dtype == MODE_BF16 && d->a_tap_cols <= 0 && (d->flags & MODE_GEMM_W_KN) && (d->flags & MODE_GEMM_A_KM)))
+    return MODE_ERR_UNSUPPORTED;                               // the fused optimizer epilogue exists for the bf16 row-major weight gradient only
   if (d->a_tap_cols > 0) return d->dtype == MODE_BF16 ? gemm_bf16_conv_launch(d, (hipStream_t)stream) : MODE_ERR_UNSUPPORTED;
   if (d->dtype == MODE_BF16 && (d->flags & (MODE_GEMM_W_KN | MODE_GEMM_A_KM))) return gemm_bf16_tr_launch(d, (hipStream_t)stream);
   if (d->dtype == MODE_BF16) return gemm_bf16_launch(d, (hipStream_t)stream);

@@ -229,6 +229,12 @@ extern "C" int mode_dit_forward_train_layer(const ModeDims* dims, const ModeMode
 }
 
 // ----------------------------------------------------------------------------------------------------------------- backward
+extern "C" int64_t mode_adamw_fuse_gsq_floats(const ModeDims* dims) {
+  if (!dims || dims->D <= 0 || dims->E <= 0 || dims->L <= 0) return 0;
+  const long t = (dims->D + 127) / 128;
+  return (long)dims->L * dims->E * 12 * t * t;
+}
+
 extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w, const ModeModelWeightsT* wt, const ModeTrainArgs* a,
                                  const void* stash, const float* dF, const ModeModelGrads* gr, void* workspace, size_t workspace_bytes,
                                  void* stream) {
@@ -301,6 +307,14 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
   float* st1 = (float*)(ws + W.st1); float* st2 = (float*)(ws + W.st2);
 #define ZERO(ptr, bytes) if (hipMemsetAsync((ptr), 0, (bytes), hs) != hipSuccess) return (int)hipGetLastError();
 
+  // (ABI 11) AdamW in the epilogue of the expert weight-gradient GEMMs: bf16 transpose-read path only
+  ModeAdamWFuse fz;
+  const long t128 = (D + 127) / 128;
+  const long fz_w2 = (long)E * t128 * (4 * t128), fz_w1 = (long)E * (8 * t128) * t128, fz_per_layer = fz_w2 + fz_w1;
+  if (a->fuse_adamw) {
+    if (!tr || (4 * D) % 128 || D % 128) return MODE_ERR_UNSUPPORTED;
+    if (a->fuse_adamw->gsq && a->fuse_adamw->gsq_capacity < fz_per_layer * d.L) return MODE_ERR_WORKSPACE;
+  }
   for (int l = d.L - 1; l >= 0; --l) {
     const ModeLayerWeights& lw = w->layers[l];
     const ModeLayerWeightsT* lt = &wt->layers[l];
@@ -352,6 +366,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       if ((rc = mode_colsum(bsum, 8L * D, NK / 128 + E, 8 * D, MODE_F32, toff, 0, E, lg.b1, 0, (char*)csw + bsum_bytes + 4096, cswb - bsum_bytes - 4096, stream))) return rc;
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, 4 * D, NK, dYs, D, S + sl.Hd, 4 * D, lg.w2, 4 * D);
       g.k_group_offsets = offsets; g.num_k_groups = E; g.c_group_stride = 4L * D * D; g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
+      if (a->fuse_adamw) { fz = *a->fuse_adamw; if (fz.gsq) { fz.gsq += (long)l * fz_per_layer; fz.gsq_capacity = fz_w2; } g.adamw = &fz; }   // W2 is updated here: no gradient is written
       if ((rc = mode_gemm(&g, stream))) return rc;
     } else if (tr) {                                 // bf16: operands as they lie in memory, fragments by LDS transpose reads
       g = gdesc(dt, MODE_EPI_NONE, dt, NK, 4 * D, D, dYs, D, lw.w2, 4 * D, dHd, 4 * D);
@@ -359,6 +374,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       if ((rc = mode_gemm(&g, stream))) return rc;
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, 4 * D, NK, dYs, D, S + sl.Hd, 4 * D, lg.w2, 4 * D);
       g.k_group_offsets = offsets; g.num_k_groups = E; g.c_group_stride = 4L * D * D; g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
+      if (a->fuse_adamw) { fz = *a->fuse_adamw; if (fz.gsq) { fz.gsq += (long)l * fz_per_layer; fz.gsq_capacity = fz_w2; } g.adamw = &fz; }   // W2 is updated here: no gradient is written
       if ((rc = mode_gemm(&g, stream))) return rc;
     } else {
       g = gdesc(dt, MODE_EPI_NONE, dt, NK, 4 * D, D, dYs, D, lt->w2T, D, dHd, 4 * D);
@@ -394,7 +410,8 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, 8 * D, D, NK, dP, 8 * D, Td2, D, lg.w1, D);
       g.k_group_offsets = offsets; g.num_k_groups = E; g.c_group_stride = 8L * D * D;
       g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
-      if (mode::gemm_bf16_pptr_accepts(&g)) {                   // it reads its K rows where they lie: sorted-order copy of the u rows first (7 MB)
+      if (a->fuse_adamw) { fz = *a->fuse_adamw; if (fz.gsq) { fz.gsq += (long)l * fz_per_layer + fz_w2; fz.gsq_capacity = fz_w1; } g.adamw = &fz; }   // W1 likewise (ring kernel: gathers u through perm)
+      if (!a->fuse_adamw && mode::gemm_bf16_pptr_accepts(&g)) { // it reads its K rows where they lie: sorted-order copy of the u rows first (7 MB)
         if ((rc = mode::gather_rows_bf16(S + sl.ub, D, meta + ml.perm, NK, D, Td2, D, hs))) return rc;
       } else {
         g.W = S + sl.ub; g.w_rows = meta + ml.perm;             // ring kernel: u rows gathered through perm inside the GEMM

@@ -39,6 +39,10 @@ struct TrParams {
   uint32_t seed, thresh; float inv_keep;  // expert-dropout stream of this layer
   float* bsum;                            // [m-tile][2 N] column sums of the bf16-rounded dP over the tile's rows (a tile lies inside one expert's segment)
   int* tile_offs;                         // [E + 1] out: first m-tile of every expert (written by workgroup 0: the segment table of the bias-gradient column sum)
+  // EPI = 2, weight gradient with the AdamW update in its epilogue (ModeAdamWFuse, include/mode_hip.h): C is not written; the pointers below are
+  // already offset to this GEMM's output tensor (group z at + z * c_gstride elements, row pitch ldc)
+  float* ad_p; float* ad_m; float* ad_v; uint16_t* ad_lp; float* ad_ema; float* ad_gsq;
+  float ad_decay, ad_b1, ad_b2, ad_eps, ad_step_size, ad_inv_bc2_sqrt, ad_gscale, ad_ema_rate;
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -95,7 +99,13 @@ __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const T
   const int grp = sb / per_group, first_m = grp * GROUP_M;
   const int gsz = min(p.m_tiles - first_m, GROUP_M);
   const int rem = sb - grp * per_group;
-  const int mt = first_m + rem % gsz, nt = rem / gsz;
+  int mt = first_m + rem % gsz, nt = rem / gsz;
+  if constexpr (EPI == 2) {
+    // the fused optimizer epilogue is HBM-bound: workgroups that run side by side take CONSECUTIVE column tiles of one row band, so that together they
+    // stream whole parameter rows (a column of tiles shares its low address bits - with m fastest, every concurrently streaming workgroup would sit on
+    // the same few memory channels)
+    mt = sb / p.n_tiles; nt = sb - mt * p.n_tiles;
+  }
 
   if constexpr (EPI == 1) {
     if (blockIdx.x == 0 && tid == 0 && p.tile_offs) {
@@ -394,6 +404,94 @@ __global__ __launch_bounds__(256, (NS == 1 ? 3 : 2)) void gemm_tr_kernel(const T
       }
       return;
     }
+    if constexpr (EPI == 2) {
+      // ---- fp32 gradient tile (in LDS) -> AdamW in place: p, m, v (+ bf16 shadow, + EMA) of the tile's elements; the gradient itself is never stored.
+      // A thread owns 16-byte chunk `ch` of rows rl0, rl0 + 8, ...: a wave covers two whole 512-byte rows per round - 4 full cache lines of each of the
+      // three arenas.  Four rounds' worth of loads (12 x 16 B per thread) are in flight before the first use; the accesses are non-temporal (every byte
+      // is touched once per step), the shadow store is a normal one (the next forward reads it).  Arithmetic = adamw_kernel's, operation for operation
+      // (train_ops.hip): with the same gradient bits the fused and the two-pass update produce the same parameter bits.
+      // Two or three workgroups share a CU (32 KiB of LDS, <= 168 registers): while this one streams 416 KiB, the others run their K loops.
+      static_assert(A_KM && !OUT_BF16 && BN == 128, "fused AdamW: 128-wide fp32 weight-gradient tile");
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      // chunks per thread and pass (two passes of 64 rows: 8) and chunks per batch: four - 12 loads of 16 B per thread in flight; the other wave row's
+      // accumulators are still live during the first pass.  (Measured and not kept: the two-slot ring with the whole tile in LDS and all 48 loads of a
+      // thread in flight, two workgroups per CU - the epilogue alone is no faster, the fused launch slower, 11.7 vs 11.3 ms per step; batches of two; plain
+      // instead of non-temporal accesses - no difference.  profiles/r05_fused_adamw.txt)
+      constexpr int NCH = RP * CPR / 256, UB = 4;
+      static_assert(NCH % UB == 0, "chunk batches");
+      const long gofs = (long)blockIdx.z * p.c_gstride;
+      float gs2 = 0.f;
+#pragma unroll 1
+      for (int u0 = 0; u0 < NCH; u0 += UB) {
+        f4 P[UB], M[UB], V[UB], G[UB];
+        // element offset of chunk u0 + u of this thread (rows past the tile / columns past N clamp to the tile's first element: every load is
+        // unconditional - one round trip for all of them - and recomputed rather than kept: registers)
+        auto where = [&](int u, long& eo) -> bool {
+          const int c = tid + (u0 + u) * 256;
+          const int rl = c / CPR, ch = c % CPR;
+          const int ml = g * RP + rl;
+          const int n = n0 + ch * EPC;
+          const bool ok = ml < rows_valid && n < p.N;
+          eo = gofs + (long)(row0 + (ok ? ml : 0)) * p.ldc + (ok ? n : n0);
+          return ok;
+        };
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          long eo;
+          where(u, eo);
+          const int c = tid + (u0 + u) * 256;
+          const int rl = c / CPR, ch = c % CPR;
+          P[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.ad_p + eo));
+          M[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.ad_m + eo));
+          V[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.ad_v + eo));
+          G[u] = *reinterpret_cast<const f4*>(smem + rl * CROW + ((ch ^ (rl & CSWZ)) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);                               // every global load of the batch is issued before the first chunk is touched
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          long eo_;
+          if (!where(u, eo_)) continue;
+          const long eo[1] = {eo_};
+#define MODE_EO eo[0]
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float gr = __fmul_rn(G[u][j], p.ad_gscale);
+            gs2 = __builtin_fmaf(gr, gr, gs2);
+            float w = P[u][j], m_ = M[u][j], v_ = V[u][j];
+            adamw_update_f(w, m_, v_, gr, p.ad_decay, p.ad_b1, p.ad_b2, p.ad_eps, p.ad_step_size, p.ad_inv_bc2_sqrt);
+            P[u][j] = w; M[u][j] = m_; V[u][j] = v_;
+          }
+          __builtin_nontemporal_store(P[u], reinterpret_cast<f4*>(p.ad_p + MODE_EO));
+          __builtin_nontemporal_store(M[u], reinterpret_cast<f4*>(p.ad_m + MODE_EO));
+          __builtin_nontemporal_store(V[u], reinterpret_cast<f4*>(p.ad_v + MODE_EO));
+          if (p.ad_ema) {
+            f4 Ev = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.ad_ema + MODE_EO));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Ev[j] = Ev[j] - p.ad_ema_rate * (Ev[j] - P[u][j]);
+            __builtin_nontemporal_store(Ev, reinterpret_cast<f4*>(p.ad_ema + MODE_EO));
+          }
+          if (p.ad_lp) {
+            u2 o; o[0] = pack_bf16x2(P[u][0], P[u][1]); o[1] = pack_bf16x2(P[u][2], P[u][3]);
+            *reinterpret_cast<u2*>(p.ad_lp + MODE_EO) = o;
+          }
+#undef MODE_EO
+        }
+      }
+      if (p.ad_gsq) {                                                  // ||g||^2 of this tile: wave butterfly, then the four waves through LDS (fixed order)
+        gs2 = wave_sum(gs2);
+        __builtin_amdgcn_s_barrier();                                  // every thread has read its gradient chunks of this pass
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) red[wave] = gs2;
+        __syncthreads();
+        if (tid == 0) {
+          float* o = p.ad_gsq + ((long)blockIdx.z * gridDim.x + blockIdx.x);
+          const float t = (red[0] + red[1]) + (red[2] + red[3]);
+          *o = (g == 0 ? 0.f : *o) + t;                                // pass 1 adds to what pass 0 of the same workgroup stored
+        }
+      }
+      continue;
+    }
     for (int c = tid; c < RP * CPR; c += 256) {
       const int rl = c / CPR, ch = c % CPR;
       const int ml = g * RP + rl;
@@ -439,8 +537,38 @@ int gemm_bf16_tr_swiglu_bwd_launch(const ModeGemmDesc* d, const void* P, void* d
   p.koffs = nullptr; p.c_gstride = 0; p.w_rows = nullptr; p.tap_cols = 0; p.tap_stride = 0;
   p.M = d->M; p.N = d->N; p.K = d->K; p.split_k = 1; p.split_stride = 0; p.m_tiles = p.n_tiles = 0;
   p.P = (const uint16_t*)P; p.dP = (uint16_t*)dP; p.seed = seed; p.thresh = thresh; p.inv_keep = inv_keep; p.bsum = bsum; p.tile_offs = tile_offs;
+  p.ad_p = p.ad_m = p.ad_v = p.ad_ema = p.ad_gsq = nullptr; p.ad_lp = nullptr;
   if (!d->expert_offsets) return MODE_ERR_UNSUPPORTED;
   return tr_launch<false, true, 128, 2, 1>(p, d, s);
+}
+
+// Weight gradient dW[M, N] (per K-group z: + z * c_group_stride) = A^T W whose epilogue applies AdamW to the parameter tile the C pointer locates
+// (ModeAdamWFuse, include/mode_hip.h).  Single-buffered 128 x 128 ring tile, three workgroups per CU: the 416 KiB of p / m / v / shadow traffic of one
+// workgroup's epilogue run under the other workgroups' K loops - these launches are HBM-bound (26 B per parameter against ~7 us of MFMA work per tile).
+// The scalars are derived exactly as mode_adamw_step derives them (train_ops.hip), so both paths round alike.
+static int tr_adamw_launch(const ModeGemmDesc* d, hipStream_t s) {
+  const ModeAdamWFuse* z = d->adamw;
+  if (!(d->flags & MODE_GEMM_A_KM) || d->out_dtype != MODE_F32 || d->split_k > 1 || d->w_tap_cols > 0 || d->N % 128 || d->ldc % 4) return MODE_ERR_UNSUPPORTED;
+  if (!z->grad_base || !z->param_base || !z->exp_avg_base || !z->exp_avg_sq_base || !d->C || z->step < 1) return MODE_ERR_BAD_ARG;
+  const long ofs = reinterpret_cast<const float*>(d->C) - z->grad_base;
+  if (ofs < 0 || (ofs & 3) || (d->k_group_offsets && (d->c_group_stride & 3))) return MODE_ERR_BAD_ARG;
+  if (((uintptr_t)z->param_base | (uintptr_t)z->exp_avg_base | (uintptr_t)z->exp_avg_sq_base | (uintptr_t)z->ema_base) & 15 || ((uintptr_t)z->lp_base & 7)) return MODE_ERR_BAD_ARG;
+  TrParams p;
+  p.A = (const uint16_t*)d->A; p.lda = d->lda; p.W = (const uint16_t*)d->W; p.ldw = d->ldw; p.w_estride = d->w_expert_stride;
+  p.C = nullptr; p.ldc = d->ldc; p.offsets = nullptr; p.E = 0;
+  p.koffs = d->k_group_offsets; p.c_gstride = d->c_group_stride; p.w_rows = d->w_rows; p.tap_cols = 0; p.tap_stride = 0;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.split_k = 1; p.split_stride = 0; p.m_tiles = p.n_tiles = 0;
+  p.P = nullptr; p.dP = nullptr; p.seed = p.thresh = 0; p.inv_keep = 1.f; p.bsum = nullptr; p.tile_offs = nullptr;
+  const double bc1 = 1.0 - pow((double)z->beta1, z->step), bc2 = 1.0 - pow((double)z->beta2, z->step);
+  p.ad_p = z->param_base + ofs; p.ad_m = z->exp_avg_base + ofs; p.ad_v = z->exp_avg_sq_base + ofs;
+  p.ad_lp = z->lp_base ? z->lp_base + ofs : nullptr; p.ad_ema = z->ema_base ? z->ema_base + ofs : nullptr; p.ad_ema_rate = z->ema_rate;
+  p.ad_decay = 1.f - z->lr * z->weight_decay; p.ad_b1 = z->beta1; p.ad_b2 = z->beta2; p.ad_eps = z->eps;
+  p.ad_step_size = (float)(z->lr / bc1); p.ad_inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)); p.ad_gscale = z->grad_scale;
+  const long groups = d->k_group_offsets ? d->num_k_groups : 1;
+  const long wgs = groups * ((d->M + 127) / 128) * (d->N / 128);
+  if (z->gsq && z->gsq_capacity < wgs) return MODE_ERR_WORKSPACE;
+  p.ad_gsq = z->gsq;
+  return tr_launch<true, false, 128, 1, 2>(p, d, s);
 }
 
 int g_tr_cfg = 0;   // "gemm_tr_cfg" option: 0 auto, 1 = 128-wide NS2, 2 = 64-wide NS3, 3 = 128-wide NS3, 4 = 64-wide NS2, 5 = 128-wide NS1,
@@ -464,6 +592,7 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
     if (d->K % 64 != 0 || d->K <= 0 || d->k_group_offsets || d->w_rows) return MODE_ERR_UNSUPPORTED;
   }
   if (d->M <= 0) return MODE_OK;
+  if (d->adamw) return tr_adamw_launch(d, s);                  // weight gradient with the optimizer in its epilogue (ModeAdamWFuse)
   if ((g_tr_cfg == 0 && !g_bwd_coexec) || g_tr_cfg == 6) {     // large problems: the ping-pong structure (MODE_ERR_UNSUPPORTED = not its shape)
     const int rc = gemm_bf16_pptr_launch(d, g_tr_cfg == 6, s);
     if (rc != MODE_ERR_UNSUPPORTED) return rc;
@@ -481,6 +610,7 @@ int gemm_bf16_tr_launch(const ModeGemmDesc* d, hipStream_t s) {
   p.split_k = split; p.split_stride = d->split_stride;
   p.m_tiles = p.n_tiles = 0;
   p.P = nullptr; p.dP = nullptr; p.seed = p.thresh = 0; p.inv_keep = 1.f; p.bsum = nullptr; p.tile_offs = nullptr;
+  p.ad_p = p.ad_m = p.ad_v = p.ad_ema = p.ad_gsq = nullptr; p.ad_lp = nullptr;
   // geometry: enough 128x128 workgroups to put two on every CU -> NS2 ring (they hide each other's fill latency); otherwise 128x64
   // tiles (twice the workgroups) with a 3-slot ring so one workgroup keeps two tiles in flight
   const long groups = (a_km && d->k_group_offsets) ? d->num_k_groups : 1;

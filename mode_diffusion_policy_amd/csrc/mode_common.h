@@ -81,6 +81,17 @@ __device__ __forceinline__ float ss16_tree(const float* s) {          // s[j] = 
   const float t0 = s[0] + s[8], t1 = s[1] + s[9], t2 = s[2] + s[10], t3 = s[3] + s[11], t4 = s[4] + s[12], t5 = s[5] + s[13], t6 = s[6] + s[14], t7 = s[7] + s[15];
   return ((t0 + t4) + (t2 + t6)) + ((t1 + t5) + (t3 + t7));
 }
+// One AdamW element update (torch's single-tensor order: decay the weight, m += (g - m)(1 - b1), v = v b2 + (1 - b2) g g, w -= step_size m / (sqrt(v) / sqrt(bc2) + eps)).
+// ONE definition with every product / sum spelled out (explicit fmas, explicitly un-fused multiplies): the streaming optimizer pass (train_ops.hip:
+// adamw_kernel) and the weight-gradient GEMM's fused epilogue (gemm_bf16_tr.hip, EPI = 2) must round alike - left to the compiler, `v * b2 + (1 - b2) * g * g`
+// was contracted differently in the two kernels (seen: ~0.5 % of the second moments one ulp apart after the second step).
+__device__ __forceinline__ void adamw_update_f(float& w, float& m, float& v, float gr, float decay, float b1, float b2, float eps, float step_size, float inv_bc2_sqrt) {
+  const float wd = __fmul_rn(w, decay);
+  m = __builtin_fmaf(__fsub_rn(gr, m), __fsub_rn(1.f, b1), m);
+  v = __builtin_fmaf(v, b2, __fmul_rn(__fmul_rn(__fsub_rn(1.f, b2), gr), gr));
+  const float denom = __builtin_fmaf(__fsqrt_rn(v), inv_bc2_sqrt, eps);
+  w = __builtin_fmaf(-step_size, __fdiv_rn(m, denom), wd);
+}
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // XCD-aware, bijective remap of a linear workgroup id: hardware places block b on XCD b % 8 (observed, speed only), so give

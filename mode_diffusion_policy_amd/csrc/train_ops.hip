@@ -979,13 +979,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       if (i >= n4) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float gr = G[u][j] * gscale;
-        float w = P[u][j] * decay;
-        M[u][j] = M[u][j] + (gr - M[u][j]) * (1.f - b1);
-        V[u][j] = V[u][j] * b2 + (1.f - b2) * gr * gr;
-        const float denom = sqrtf(V[u][j]) * inv_bc2_sqrt + eps;
-        w -= step_size * (M[u][j] / denom);
-        P[u][j] = w;
+        const float gr = __fmul_rn(G[u][j], gscale);
+        float w = P[u][j], m_ = M[u][j], v_ = V[u][j];
+        mode::adamw_update_f(w, m_, v_, gr, decay, b1, b2, eps, step_size, inv_bc2_sqrt);
+        P[u][j] = w; M[u][j] = m_; V[u][j] = v_;
       }
       __builtin_nontemporal_store(P[u], reinterpret_cast<f4*>(p) + i);
       __builtin_nontemporal_store(M[u], reinterpret_cast<f4*>(m) + i);

@@ -8,6 +8,7 @@ for the 685 M-parameter denoiser) and also emits the bf16 compute shadow, so the
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Dict, Tuple
 
@@ -18,7 +19,19 @@ from .engine import _stream
 
 
 class FusedAdamW:
-    def __init__(self, model, lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05):
+    """``fuse_expert_step=True`` (opt-in; single process, no gradient accumulation - what the reference's training loop is,
+    conf/config_libero.yaml:45): the expert matrices ``w1`` / ``w2`` of every block - 604 M of the 686 M parameters - are updated INSIDE their
+    weight-gradient GEMMs (``ModeAdamWFuse``, include/mode_hip.h; ``csrc/gemm_bf16_tr.hip`` EPI = 2): the backward chain reads p / m / v, applies
+    this class's arithmetic to the fp32 accumulators and writes p / m / v and the bf16 shadow back - the gradients of those tensors are never
+    stored or re-read (26 instead of 34 bytes per parameter) and no optimizer pass is left to compete with the backward for them.  ``step()``
+    then covers the remaining 12 %.  The backward picks the hyper-parameters up from this object when it runs, so set the step's learning rate
+    BEFORE ``loss.backward()`` (a scheduler stepped after ``optimizer.step()``, as Lightning does, satisfies that) and pass a gradient scale via
+    ``opt.fused_grad_scale``.  Results are bit-identical to the two-pass update (same gradient bits, same expression order).
+    ``p.grad`` of the expert matrices is not produced in this mode; ``opt.fused_grad_sq()`` returns their squared gradient norm for logging
+    (mode_agent.py:304-363)."""
+
+    def __init__(self, model, lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
+                 fuse_expert_step: bool = False):
         self.model = model
         eng = model.engine                                   # adopts the parameters into the arena
         self.eng, self.arena = eng, eng.arena
@@ -33,11 +46,73 @@ class FusedAdamW:
         self._master_sharded = self._state_sharded = False
         self.param_groups = [dict(name="decay", lr=lr, betas=betas, eps=eps, weight_decay=weight_decay),
                              dict(name="no_decay", lr=lr, betas=betas, eps=eps, weight_decay=0.0)]
+        # ---- expert matrices updated by their weight-gradient GEMMs (see the class docstring)
+        self.fuse_expert_step = bool(fuse_expert_step)
+        self.fused_grad_scale = 1.0
+        self.fused_ema = None                                    # an ArenaEMA whose schedule the fused update honours (else pass ema= to step(): a separate pass over the expert ranges)
+        self._fused_pending = False                              # a backward has applied the expert update of step step_count + 1
+        self._fused_struct = self._fused_gsq = None
+        if self.fuse_expert_step:
+            if eng.compute_dtype != "bf16":
+                raise ValueError("fuse_expert_step needs the bf16 compute mode (the fused epilogue lives in the bf16 weight-gradient GEMM)")
+            model._fused_optimizer = self                        # training.py's backward asks this object for the ModeAdamWFuse of the step
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         """The next backward overwrites the gradient arena instead of accumulating into it (no memset pass: the backward chain writes every
         element of the reducible region, exact zeros for un-routed experts included)."""
         self.arena.grad_pending = False
+
+    # ---- fused expert step ---------------------------------------------------------------------------------------------------
+    def _expert_ranges(self):
+        """Arena element ranges [lo, hi) of every block's w1 and w2 (decay region), ascending."""
+        ar, Ly = self.arena, self.model.num_layers
+        out = []
+        for i in range(Ly):
+            for nm in (f"l{i}.w1", f"l{i}.w2"):
+                lo = ar.offset(nm)
+                out.append((lo, lo + ar.w[nm].numel()))
+        return sorted(out)
+
+    def fused_step_struct(self, accumulate: bool):
+        """Called by the backward (training.py) right before the chain runs: the ModeAdamWFuse of optimizer step ``step_count + 1``, or None when
+        this backward must write gradients as usual.  Raises where a fused update would be silently wrong."""
+        if not self.fuse_expert_step:
+            return None
+        eng, ar = self.eng, self.arena
+        if eng.arena is not ar:
+            raise RuntimeError("the parameter arena was rebuilt (model.to()/half()?): create a new FusedAdamW")
+        if accumulate or self._fused_pending:
+            raise RuntimeError("fuse_expert_step: a second backward before optimizer.step() (gradient accumulation) cannot be fused - the first "
+                               "backward has already updated the expert matrices; construct FusedAdamW(fuse_expert_step=False)")
+        if any(not p.requires_grad for n, p in eng.named_params() if ".experts." in n and n.endswith("weight")):
+            raise NotImplementedError("fuse_expert_step with frozen expert matrices")
+        ar.ensure_grad(self.model)
+        gd = self.param_groups[0]
+        ema_base, rate = None, 0.0
+        if self.fused_ema is not None and self.fused_ema.should_apply(self.step_count + 1):
+            self.fused_ema.ensure(ar)
+            ema_base, rate = self.fused_ema.flat.data_ptr(), 1.0 - self.fused_ema.get_decay(self.step_count + 1)
+        if self._fused_gsq is None:
+            n = int(eng.lib.mode_adamw_fuse_gsq_floats(C.byref(eng.dims)))
+            self._fused_gsq = torch.zeros(n, dtype=torch.float32, device=eng.device)
+        st = L.ModeAdamWFuse(grad_base=ar.grad.data_ptr(), param_base=ar.flat.data_ptr(), exp_avg_base=self.exp_avg.data_ptr(),
+                             exp_avg_sq_base=self.exp_avg_sq.data_ptr(), lp_base=ar.lp.data_ptr() if ar.lp is not None else None, ema_base=ema_base,
+                             ema_rate=float(rate), lr=float(gd["lr"]), beta1=float(gd["betas"][0]), beta2=float(gd["betas"][1]), eps=float(gd["eps"]),
+                             weight_decay=float(gd["weight_decay"]), step=self.step_count + 1, grad_scale=float(self.fused_grad_scale),
+                             gsq=self._fused_gsq.data_ptr(), gsq_capacity=self._fused_gsq.numel())
+        self._fused_struct = st                                  # keeps the ctypes object alive across the call
+        return st
+
+    def fused_backward_done(self) -> None:
+        """The backward chain has updated the expert matrices (masters AND bf16 shadow, in step with each other).  The arena's version moves in
+        ``step()`` (``weights_updated``), as for every update this optimizer makes through raw pointers."""
+        self._fused_pending = True
+
+    def fused_grad_sq(self) -> torch.Tensor:
+        """Squared L2 norm of the (scaled) expert-matrix gradients of the last fused backward (device scalar)."""
+        if self._fused_gsq is None:
+            raise RuntimeError("no fused backward has run yet")
+        return self._fused_gsq.double().sum()
 
     def _frozen_ranges(self):
         """Arena element ranges of parameters with ``requires_grad == False`` (``freeze_router()`` for fine-tuning, mode_agent.py:762-766):
@@ -57,7 +132,7 @@ class FusedAdamW:
         return merged
 
     def _launch(self, lo: int, hi: int, gp, lp, grad_scale: float) -> None:
-        for flo, fhi in self._frozen:                          # carve frozen slices out of [lo, hi)
+        for flo, fhi in self._frozen:                          # carve frozen slices (and, after a fused backward, the expert matrices) out of [lo, hi)
             if flo < hi and fhi > lo:
                 if lo < flo:
                     self._launch_raw(lo, flo, gp, lp, grad_scale)
@@ -214,8 +289,28 @@ class FusedAdamW:
         use_zero1 = bool(zero1) and reducer is not None and eng.device.type == "cuda"
         if use_zero1:
             self._validate_zero1(reducer, zero1, ema)
+        fused = self._fused_pending
+        if self.fuse_expert_step and not fused:
+            raise RuntimeError("fuse_expert_step: optimizer.step() without a fused backward since the last step (was the loss back-propagated "
+                               "through MoDeDiT in training mode?)")
+        if fused:
+            if use_zero1 or (reducer is not None and reducer.world > 1):
+                raise NotImplementedError("fuse_expert_step is a single-process mode: the expert matrices were updated from this rank's gradients only")
+            if float(grad_scale) != float(self.fused_grad_scale):
+                raise ValueError(f"step(grad_scale={grad_scale}) differs from the scale the fused backward applied ({self.fused_grad_scale}): set "
+                                 "opt.fused_grad_scale before loss.backward()")
         self.step_count += 1
         self._frozen = self._frozen_ranges()
+        if fused:                                               # the expert matrices are done: the passes below skip them exactly like frozen tensors
+            spans = sorted([list(x) for x in self._frozen] + [list(x) for x in self._expert_ranges()])
+            merged = []
+            for lo_, hi_ in spans:
+                if merged and lo_ <= merged[-1][1]:
+                    merged[-1][1] = max(merged[-1][1], hi_)
+                else:
+                    merged.append([lo_, hi_])
+            self._frozen = merged
+            self._fused_pending = False
         self._ema_now = (None, 0.0)
         if ema is not None and ema.should_apply(self.step_count):
             ema.ensure(ar)
@@ -238,8 +333,10 @@ class FusedAdamW:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=eng.device, priority=int(os.environ.get("MODE_OPT_PRIO", "0")))
                 # the per-block passes run BESIDE the next backward chains: tell the library, so that its large backward GEMMs keep the ring
-                # kernels that leave CU resources free (include/mode_hip.h "bwd_coexec"; process-wide like every option)
-                eng.lib.mode_set_option(b"bwd_coexec", 1)
+                # kernels that leave CU resources free (include/mode_hip.h "bwd_coexec"; process-wide like every option).  Not with the expert
+                # matrices updated inside the backward: what is left per block is a 4-M-parameter pass (22 us) that fits between the kernels
+                if not self.fuse_expert_step:
+                    eng.lib.mode_set_option(b"bwd_coexec", 1)
             cur = torch.cuda.current_stream()
             blocks, rest = self._block_slices()
             done = reducer.reduce_async() if (reducer is not None and reducer.world > 1) else None    # {(lo, hi): event after the exchange}
@@ -255,6 +352,21 @@ class FusedAdamW:
                     self._launch(lo, hi, gd, lp, grad_scale)
                 self._launch(ar.bounds["decay"], ar.bounds["no_decay"], gn, lp, grad_scale)
             cur.wait_stream(self._side)
+        if fused and self._ema_now[0] is not None and self.fused_ema is not self._ema_now[0]:
+            ema_, rate_ = self._ema_now                          # the fused epilogue did not know about this EMA: one stand-alone pass over the expert ranges
+            for lo_, hi_ in self._expert_ranges():
+                L.check(eng.lib.mode_ema_update(ema_.flat[lo_:hi_].data_ptr(), ar.flat[lo_:hi_].data_ptr(), hi_ - lo_, float(rate_), _stream()), "ema_update")
+        if fused and self.fused_ema is not None and self.fused_ema.should_apply(self.step_count) and self._ema_now[0] is None:
+            # the fused epilogue applied the EMA to the expert matrices; the rest of the arena follows here (ema= was not passed to step())
+            ema_ = self.fused_ema
+            rate_ = 1.0 - ema_.get_decay(self.step_count)
+            n_all = ar.bounds["total"]
+            prev = 0
+            for lo_, hi_ in self._expert_ranges() + [(n_all, n_all)]:
+                if prev < lo_:
+                    L.check(eng.lib.mode_ema_update(ema_.flat[prev:lo_].data_ptr(), ar.flat[prev:lo_].data_ptr(), lo_ - prev, float(rate_), _stream()), "ema_update")
+                prev = hi_
+            ema_.mark_applied(self.step_count)
         eng.weights_updated(lp_synced=lp is not None)
         ar.grad_pending = False                                  # gradients consumed: the next backward starts a fresh sum
 

@@ -383,8 +383,19 @@ def dit_forward_train(model, states, actions, goals, sigma, uncond=False):
         if debug_cov:
             flat.fill_(float("nan"))
         mg, gv = ts.grad_tables(flat)
+        # (ABI 11) FusedAdamW(fuse_expert_step=True): the expert matrices are UPDATED by their weight-gradient GEMMs - arena mode, first backward of the
+        # step only (the optimizer object refuses accumulation); their slices of the gradient arena are not written
+        fopt = getattr(model, "_fused_optimizer", None)
+        fz = None
+        if fopt is not None and fopt.fuse_expert_step:
+            if grad_mode != "arena":
+                raise RuntimeError("FusedAdamW(fuse_expert_step=True) needs model.grad_mode == 'arena' (it was changed after the optimizer was built)")
+            fz = fopt.fused_step_struct(accumulate)
+        args.fuse_adamw = C.pointer(fz) if fz is not None else None
         L.check(lib.mode_dit_backward(C.byref(d), C.byref(eng._mw), C.byref(ts.wt), C.byref(args), stash.data_ptr(), dF.data_ptr(), C.byref(mg),
                                       ts._ws.data_ptr(), ts._ws.numel(), _stream()), "backward")
+        if fz is not None:
+            fopt.fused_backward_done()
         if debug_cov:
             holes = [n for n in names if not bool(torch.isfinite(gv[n]).all())]
             if holes:

@@ -160,6 +160,133 @@ def test_fused_adamw_matches_torch_adamw(dtype, overlap):
     assert float(l2) != float(loss)
 
 
+@pytest.mark.parametrize("stochastic,ema", [(False, False), (True, False), (True, True)])
+def test_fused_expert_step_is_bit_identical_to_the_two_pass_update(stochastic, ema):
+    """FusedAdamW(fuse_expert_step=True): the expert matrices (88 % of the parameters) are updated in the EPILOGUE of their weight-gradient GEMMs
+    (ModeAdamWFuse; gradients never stored).  Same gradient bits + same expression order => after three steps EVERY parameter, both Adam moments,
+    the bf16 shadow and (when on) the EMA equal the ordinary backward + optimizer pass bit for bit - deterministic config and the stochastic
+    training path (multinomial routing + both dropouts under a shared seed).  Both agree with torch.optim.AdamW to fp32 rounding; the squared
+    gradient norm of the skipped tensors is reported; misuse (accumulation, a step without a backward, a different scale) raises."""
+    from mode_diffusion_policy_amd.ddp import optimizer_param_groups
+    from mode_diffusion_policy_amd.optim import ArenaEMA, FusedAdamW
+    over = dict(attn_pdrop=0.3, mlp_pdrop=0.1, use_argmax=False) if stochastic else {}
+    cfg, sd, ma = build_train("c1e4", 41, "bf16", **over)
+    _, _, mb = build_train("c1e4", 41, "bf16", **over)
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, 16, 5).items()}
+    dena, denb = M.GCDenoiser(ma, 0.5).train(), M.GCDenoiser(mb, 0.5).train()
+    sig = torch.full((16,), 0.9, device="cuda")
+    oa = FusedAdamW(ma, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    ob = FusedAdamW(mb, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, fuse_expert_step=True)
+    ea = ArenaEMA(ma, decay=0.99) if ema else None
+    eb = ArenaEMA(mb, decay=0.99) if ema else None
+    ob.fused_ema = eb
+    ref = {n: p.detach().clone().requires_grad_(True) for n, p in ma.named_parameters()}
+
+    class _Holder(torch.nn.Module):
+        def named_parameters(self_inner, *a, **k):
+            return iter(ref.items())
+    topt = torch.optim.AdamW(optimizer_param_groups(_Holder(), 0.05), lr=1e-3, betas=(0.9, 0.95))
+    experts = [n for n, _ in ma.named_parameters() if ".experts." in n and n.endswith("weight")]
+    assert len(experts) == 2 * cfg.num_experts * cfg.n_layers
+    st = {"state_images": inp["state_images"]}
+    for step in range(3):
+        for g in oa.param_groups + ob.param_groups + topt.param_groups:      # a moving learning rate: picked up by the backward of the fused path
+            g["lr"] = 1e-3 * (1.0 - 0.2 * step)
+        torch.manual_seed(100 + step); torch.cuda.manual_seed(100 + step)
+        la, _ = dena.loss(st, inp["actions"], inp["goals"], inp["noise"], sig)
+        la.backward()
+        torch.manual_seed(100 + step); torch.cuda.manual_seed(100 + step)
+        lb, _ = denb.loss(st, inp["actions"], inp["goals"], inp["noise"], sig)
+        lb.backward()
+        assert float(la) == float(lb) and ma._last_seed == mb._last_seed
+        gsq_ref = sum(float(p.grad.double().pow(2).sum()) for n, p in ma.named_parameters() if n in experts)
+        assert abs(float(ob.fused_grad_sq()) - gsq_ref) <= 1e-5 * gsq_ref
+        for n, p in ma.named_parameters():
+            ref[n].grad = None if p.grad is None else p.grad.detach().clone()
+        oa.step(ema=ea); ob.step(ema=eb if step == 1 else None)      # step 1: EMA through step(), steps 0 / 2: through the fused_ema hook - same result
+        topt.step()
+        torch.cuda.synchronize()
+        for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert torch.equal(pa.detach(), pb.detach()), (step, n)
+            assert rel(pb.detach(), ref[n].detach()) < 2e-6, (step, n)
+        assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq), step
+        ara, arb = ma.engine.arena, mb.engine.arena
+        assert arb.lp_synced and torch.equal(ara.lp, arb.lp), step
+        if ema:
+            assert torch.equal(ea.flat, eb.flat), step
+    # the fused path never wrote the expert gradients; everything else it did
+    gb = dict(mb.named_parameters())
+    assert all(torch.equal(gb[n].grad, dict(ma.named_parameters())[n].grad) for n in gb if n not in experts and gb[n].grad is not None)
+    # misuse
+    with pytest.raises(RuntimeError, match="without a fused backward"):
+        ob.step()
+    lb, _ = denb.loss(st, inp["actions"], inp["goals"], inp["noise"], sig)
+    lb.backward()
+    with pytest.raises(ValueError, match="grad_scale"):
+        ob.step(grad_scale=0.5)
+    l2, _ = denb.loss(st, inp["actions"], inp["goals"], inp["noise"], sig)
+    with pytest.raises(RuntimeError, match="gradient accumulation"):
+        l2.backward()
+    ob.step()
+
+
+def test_fused_adamw_epilogue_gemm_vs_gemm_plus_adamw_kernel():
+    """The C-ABI entry on its own: mode_gemm(weight gradient, adamw=...) == mode_gemm(weight gradient) followed by mode_adamw_step on the same
+    buffers, bit for bit - ragged K-groups (an empty one included: its gradient is exactly zero and the update still applies decay and moment
+    decay), rows gathered through w_rows, M / N that are not multiples of the 128-tile in M, the per-workgroup sums of squares."""
+    import ctypes as C
+    from mode_diffusion_policy_amd import _lib as L
+    lib = L.load()
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    E, M_, N_, R = 4, 200, 256, 700                                            # dW_e[M_, N_] = dY_e^T X_e, rows of expert e = [off[e], off[e+1])
+    offs = torch.tensor([0, 250, 250, 517, 700], dtype=torch.int32, device=dev)
+    dY = (torch.randn(R, M_, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    X = (torch.randn(900, N_, generator=g)).to(torch.bfloat16).to(dev)
+    rows = torch.randint(0, 900, (R,), generator=g, dtype=torch.int32).to(dev)
+    n = E * M_ * N_
+    pad = 64                                                                    # the tensors sit at an offset inside larger arenas
+    mk = lambda scale: (torch.randn(n + 2 * pad, generator=g) * scale).to(dev)
+    p0, m0, v0 = mk(0.1), mk(0.01), mk(0.001).abs()
+    st = torch.cuda.current_stream().cuda_stream
+    hyper = dict(lr=3e-3, beta1=0.9, beta2=0.95, eps=1e-8, weight_decay=0.05, step=4, grad_scale=0.7)
+
+    def desc(Cbuf, fz=None):
+        return L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=M_, N=N_, K=R, A=dY.data_ptr(), lda=M_, W=X.data_ptr(), ldw=N_,
+                              C=Cbuf, ldc=N_, k_group_offsets=offs.data_ptr(), num_k_groups=E, c_group_stride=M_ * N_, flags=L.GEMM_W_KN | L.GEMM_A_KM,
+                              w_rows=rows.data_ptr(), adamw=None if fz is None else C.pointer(fz))
+    # two-pass reference
+    grad = torch.full((n + 2 * pad,), float("nan"), device=dev)
+    pa, ma_, va = p0.clone(), m0.clone(), v0.clone()
+    lpa = torch.zeros(n + 2 * pad, dtype=torch.bfloat16, device=dev); ema_a = p0.clone()
+    L.check(lib.mode_gemm(C.byref(desc(grad[pad:].data_ptr())), st), "gemm")
+    assert float(grad[pad + M_ * N_: pad + 2 * M_ * N_].abs().max()) == 0.0    # the empty group
+    L.check(lib.mode_adamw_step(pa[pad:].data_ptr(), grad[pad:].data_ptr(), ma_[pad:].data_ptr(), va[pad:].data_ptr(), n, hyper["lr"], hyper["beta1"], hyper["beta2"],
+                                hyper["eps"], hyper["weight_decay"], hyper["step"], hyper["grad_scale"], lpa[pad:].data_ptr(), ema_a[pad:].data_ptr(), 0.01, st), "adamw")
+    # fused
+    pb, mb_, vb = p0.clone(), m0.clone(), v0.clone()
+    lpb = torch.zeros_like(lpa); ema_b = p0.clone()
+    gbase = torch.empty(n + 2 * pad, device=dev).fill_(123.0)                    # never read or written: only locates the tile
+    wgs = E * ((M_ + 127) // 128) * (N_ // 128)
+    gsq = torch.full((wgs,), float("nan"), device=dev)
+    fz = L.ModeAdamWFuse(grad_base=gbase.data_ptr(), param_base=pb.data_ptr(), exp_avg_base=mb_.data_ptr(), exp_avg_sq_base=vb.data_ptr(), lp_base=lpb.data_ptr(),
+                         ema_base=ema_b.data_ptr(), ema_rate=0.01, gsq=gsq.data_ptr(), gsq_capacity=wgs, **hyper)
+    L.check(lib.mode_gemm(C.byref(desc(gbase[pad:].data_ptr(), fz)), st), "gemm+adamw")
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and torch.equal(ma_, mb_) and torch.equal(va, vb) and torch.equal(lpa, lpb) and torch.equal(ema_a, ema_b)
+    assert float(gbase.min()) == 123.0 and float(gbase.max()) == 123.0
+    want = float((grad[pad: pad + n].double() * hyper["grad_scale"]).pow(2).sum())
+    assert abs(float(gsq.double().sum()) - want) <= 1e-5 * want
+    assert not torch.equal(pa[pad: pad + n], p0[pad: pad + n]) and torch.equal(pa[:pad], p0[:pad]) and torch.equal(pa[pad + n:], p0[pad + n:])
+    # refusals: not a weight gradient / bf16 output / split-K / too few gsq slots
+    bad = desc(gbase[pad:].data_ptr(), fz); bad.flags = L.GEMM_W_KN
+    assert lib.mode_gemm(C.byref(bad), st) == -2
+    bad = desc(gbase[pad:].data_ptr(), fz); bad.out_dtype = L.MODE_BF16
+    assert lib.mode_gemm(C.byref(bad), st) == -2
+    fz.gsq_capacity = wgs - 1
+    assert lib.mode_gemm(C.byref(desc(gbase[pad:].data_ptr(), fz)), st) == -3
+
+
 def test_arena_reducer_overlap_slices_and_events():
     """Data-parallel exchange on the gradient arena (ddp.ArenaGradReducer): per-block slices in backward order, each gated by the event the
     backward chain records for that block; the slices tile the optimised part of the arena exactly once.  Runs the real stream / event /
