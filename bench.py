@@ -81,7 +81,7 @@ def synthetic_inputs(device, B):
 
 class PowerSampler:
     """Socket power and shader clock of THIS process's GPU, sampled from the amdgpu hwmon files while a timed region runs.  The expert GEMMs
-    run the socket into its power cap (1377 W of 1400 W, 1.8-1.9 GHz instead of the 2.4 GHz the 2.5 PF/s peak is quoted at),
+    run the socket into its power cap (LABNOTES.md section 8: 1377 W of 1400 W, 1.8-1.9 GHz instead of the 2.4 GHz the 2.5 PF/s peak is quoted at),
     so the clock under load belongs next to every fraction-of-peak this file reports.  Best effort: every field is None when sysfs is not
     readable (other driver, container without /sys)."""
 
@@ -142,7 +142,7 @@ class PowerSampler:
 def sustained_mfma_peak(device, seconds=1.2):
     """What the socket sustains in bf16 MFMA at its power cap: register-resident v_mfma_f32_16x16x32_bf16 on every SIMD (mode_probe_mfma_burn,
     csrc/probe.hip), back-to-back launches for `seconds`, rate of the last block.  The datasheet peak (2.5 PF/s at 2.4 GHz) is what every `frac`
-    of this file is quoted against; this number says how much of it the box delivers under load."""
+    of this file is quoted against; this number says how much of it the box delivers under load (LABNOTES.md section 8)."""
     import ctypes as C
     from mode_diffusion_policy_amd import _lib as L
     lib = L.load()
@@ -226,7 +226,7 @@ def dominant_kernel_roofline(den, device, reps=240):
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command (FETCH_SIZE doubled: gfx950 correction, MI355X_MICROARCH.md "HBM");
     # null when the summary is absent or was taken on another kernel.
     traffic, src = None, None
-    for fn in ("r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json"):                 # the newest committed collection that sampled THIS kernel
+    for fn in ("r05_gemm_pmc.json", "r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json"):                 # the newest committed collection that sampled THIS kernel
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", fn)))
             ent = pj["kernels"].get("expert_up_projection")
@@ -237,7 +237,7 @@ def dominant_kernel_roofline(den, device, reps=240):
             pass
     return {"bound": "mfma", "kernel": "gemm_pp_kernel<SWIGLU, bf16, 224x256> (grouped expert up-projection + fused ln_2 scale + SwiGLU, M=3584 K=1024 N=2x4096)",
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            # algorithmic bytes per launch (2 of 4 experts active under uniform sigma): A 3.7 MB + W1 33.6 MB + H 29.4 MB = 66.6 MB
+            # algorithmic bytes per launch (2 of 4 experts active under uniform sigma): A 3.7 MB + W1 33.6 MB + H 29.4 MB = 66.6 MB (LABNOTES.md section 4)
             "traffic": traffic, "traffic_source": src, "algorithmic_bytes": 66.6e6, "avg_launch_us": round(us, 2), "flops_per_launch": flops,
             "power": ps.summary()}
 
@@ -449,7 +449,7 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU, z
     torch.cuda.synchronize()
     assert torch.isfinite(loss.detach()).all()
     # Timed blocks of `steps` steps until the two fastest agree within 5 % (at most 8; all listed), the fastest reported.  (Rounds 1-2 saw 2-4x slower
-    # blocks in some processes and blamed the box; round 3 found the cause - the training node leaked every step's activation stash, DESIGN.md section 4
+    # blocks in some processes and blamed the box; round 3 found the cause - the training node leaked every step's activation stash, LABNOTES.md section 4
     # "Round 3" - and with the leak fixed 800 consecutive steps stay within 0.5 %.  The block list stays in the line as the evidence.)
     blocks = []
     for _ in range(8):
@@ -679,8 +679,13 @@ def agent_step_measure(den, device, B, steps, warmup, miopen_benchmark=False):
     goal = torch.randn(B, 1, 512, generator=g).to(device)
     acts = torch.randn(B, 10, 7, generator=g).to(device); noise = torch.randn(B, 10, 7, generator=g).to(device)
     opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
-    opt_e = torch.optim.AdamW(list(enc_s.parameters()) + list(enc_g.parameters()), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05,
-                              **({"fused": True} if os.environ.get("MODE_BENCH_TORCH_FUSED_ADAMW") == "1" else {}))   # (A/B: torch's own fused multi-tensor kernel; the reference uses the default)
+    enc_params = list(enc_s.parameters()) + list(enc_g.parameters())
+    if os.environ.get("MODE_BENCH_FLAT_ADAMW", "1") == "1":                     # the encoders' 51 M parameters as ONE mode_adamw_step launch (optim.FlatAdamW)
+        from mode_diffusion_policy_amd.optim import FlatAdamW
+        opt_e = FlatAdamW(enc_params, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    else:
+        opt_e = torch.optim.AdamW(enc_params, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05,
+                                  **({"fused": True} if os.environ.get("MODE_BENCH_TORCH_FUSED_ADAMW") == "1" else {}))   # (A/B: torch's foreach / fused multi-tensor kernels; the reference uses the default)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     enc_ms = [0.0, 0.0]
 

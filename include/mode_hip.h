@@ -681,7 +681,8 @@ int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w, const Mod
 
 /* ------------------------------------------------------------------------------------------------------------------
  * FiLM-ResNet perceptual encoders (mode/models/perceptual_encoders/pretrained_resnets.py:5-60, resnets.py:27-200,
- * mode_agent.py:548-567): the producer of `state_images`.  Convolutions stay library calls (MIOpen via the caller); these entry points are
+ * mode_agent.py:548-567): the producer of `state_images`.  The convolutions themselves are mode_gemm calls (1 x 1; a_rows / w_rows in taps for k x k: csrc/conv_gemm.hip) except the 3-channel stem, which the caller leaves
+ * to MIOpen; these entry points are
  * everything between two convolutions as ONE pass over the activation (NCHW, or channels_last - ModeBnFilmDesc.channels_last):
  *   y = post_film( relu( pre_film( x * scale[c] + shift[c] ) + residual ) )
  *   pre_film : v = pre_gamma[n,c] * v + pre_beta[n,c]          (BasicBlockWithModulation, resnets.py:64-71: after bn2, before the skip add)

@@ -1,5 +1,5 @@
-// FiLM-ResNet perceptual encoders: the producer of `state_images`.  The convolutions stay library calls (MIOpen through
-// PyTorch's conv2d - SURVEY: "convs via MIOpen first"); what is hand-written here is everything BETWEEN two convolutions, which the reference
+// FiLM-ResNet perceptual encoders: the producer of `state_images`.  The convolutions are conv_gemm.hip / mode_gemm
+// (round 4: every one but the 3-channel 7 x 7 stem, which stays a MIOpen call through PyTorch's conv2d); this file is everything BETWEEN two convolutions, which the reference
 // runs as 3-6 separate elementwise / reduction launches per block:
 //
 //   y = post_film( relu( pre_film( batch_norm(x) ) + residual ) )
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void bn_film_act_fwd_nhwc_kernel(const ModeBnF
 
 // PLAIN = no FiLM on either side (49 of a FiLM-ResNet-50's 53 BatchNorms): four of the six sums are FiLM gradients nobody reads - only sum(dv) and
 // sum(dv * xhat) are accumulated (zeros are written for the rest), and the pass is no longer VALU-bound (per 16 bytes of each operand: ~90 instead of ~200
-// vector instructions; measured inside the agent step: see DESIGN.md section 4 "Round 4").
+// vector instructions; measured inside the agent step: see LABNOTES.md section 4 "Round 4").
 template <typename T, bool PLAIN>
 __global__ __launch_bounds__(256) void bn_film_act_bwd_sums_nhwc_kernel(const ModeBnFilmDesc d, const T* __restrict__ dy, const float* __restrict__ mean,
                                                                         const float* __restrict__ invstd, int S, float* __restrict__ sums) {

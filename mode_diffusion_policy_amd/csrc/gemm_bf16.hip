@@ -399,7 +399,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
 // ------------------------------------------------------------------------------------------------------------ host side
 // geometry ids (also the values of the "gemm_cfg" option; 0 = auto)
 // (ids 2, 3, 5, 7, 9-12, 15 were measured-and-rejected geometries of round 1 - deeper rings, 256-wide one-barrier tiles, a persistent 256x256 kernel with
-// a serial epilogue - removed once the ping-pong kernel superseded them; the numbers stay in DESIGN.md)
+// a serial epilogue - removed once the ping-pong kernel superseded them; the numbers stay in LABNOTES.md)
 enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x64_NS3 = 4, CFG_128x128_NS1 = 6, CFG_128x64_NS2 = 8, CFG_128x128_NS1_4WG = 13, CFG_64x64_NS3 = 14,
        CFG_PP224 = 17, CFG_PP256 = 18 };
 int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p, int rows256, hipStream_t s);   // gemm_bf16_pp.hip: persistent ping-pong kernel, 224 / 256 x 256 tiles

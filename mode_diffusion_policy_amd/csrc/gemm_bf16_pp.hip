@@ -37,7 +37,7 @@
 // the 4 n-runs 56 rows each) so that together they cover every line once; without it a workgroup touches every fourth line of its own tiles.  The touch
 // is issued right behind a counted wait, so it rides INSIDE the vmcnt budget (the waits of those two waves allow one more instruction in flight).
 // (First form, every wave touching 64 lines per K-step: 576-585 instead of 628-631 denoise-steps/s - the vector-memory path is the loop's bottleneck.)  scripts/build_pp_variant.sh builds libmode_hip_<tag>.so; scripts/pp_l2touch_probe.py times it against the shipped library in one
-// process.  Result and reading: profiles/r05_pp_l2touch.txt, DESIGN.md.
+// process.  Result and reading: profiles/r05_pp_l2touch.txt, LABNOTES.md.
 #ifndef PP_L2_TOUCH
 #define PP_L2_TOUCH 0
 #endif
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
   bool fresh = true;
   // Everything the K loop calls is resolved at compile time (no run-time switches: the shipped loop is straight-line code between its barriers;
-  // the timing ablations and cycle stamps that measured it in round 2 are gone from the product library - the numbers stay in DESIGN.md).
+  // the timing ablations and cycle stamps that measured it in round 2 are gone from the product library - the numbers stay in LABNOTES.md).
   auto rdA = [&](auto T_, auto H_) __attribute__((always_inline)) {
     constexpr int t = decltype(T_)::value, h = decltype(H_)::value;
     constexpr int base = (t * 2 + h) * HALF_BYTES, nf = h ? FM1 : 4;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     //   R(P0, t): reads W0 W1 A0 of K-step t;  stages A1[t+1]           R(P1, t): reads A1[t];  stages W0 W1 A0 of K-step t+2
     // and every read section ends in ONE counted wait that leaves the newest K-step's worth of DMA (8 instructions; 6 on the waves that stage
     // no A half 1) in flight: everything a later phase reads was issued before those.  (Round-2 measurements behind this shape - the eight-phase
-    // loop, barrier hand-over inside a cluster, per-phase cycle stamps - are in DESIGN.md §4.)
+    // loop, barrier hand-over inside a cluster, per-phase cycle stamps - are in LABNOTES.md §4.)
     // The FIRST pair of a tile is peeled (K-steps 0 and 1 were resident before it began and the previous tile's stores may still be draining -
     // vmcnt counts them - so it takes no waits, skips the A1[1] stage and requests the bias slice), and the wave role is a template argument:
     // between two barriers there is no branch.

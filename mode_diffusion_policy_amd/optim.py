@@ -385,6 +385,85 @@ class FusedAdamW:
             g.update(s)
 
 
+class FlatAdamW:
+    """``torch.optim.AdamW`` for an ARBITRARY list of fp32 device parameters - the perceptual encoders next to the denoiser (``mode_agent.py:289``: the
+    reference hands every parameter of the agent to one AdamW) - as ONE ``mode_adamw_step`` launch per parameter group instead of torch's multi-tensor
+    loop (~37 launches / 1.6 ms per step for two FiLM-ResNet-50s).  The parameters are re-pointed at views of one flat buffer per group (names, shapes,
+    strides incl. channels_last, ``state_dict`` untouched - what ``arena.py`` does for the denoiser) and their ``.grad`` at views of a flat gradient
+    buffer that autograd accumulates into in place.  Same arithmetic as ``FusedAdamW`` (``adamw_update_f``), i.e. torch's single-tensor order.
+
+    Differences from torch, by construction: ``zero_grad()`` zeroes the flat buffer and keeps the ``.grad`` views (``set_to_none`` is ignored); a
+    parameter that receives NO gradient in a step is still decayed (torch skips it) - hand this class parameters that are all trained.  The update
+    writes through raw pointers, so the parameters' version counters are bumped explicitly (cached bf16 weight shadows must notice)."""
+
+    def __init__(self, params, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        groups = list(params)
+        if groups and not isinstance(groups[0], dict):
+            groups = [dict(params=groups)]
+        self.param_groups, self._flat = [], []
+        self.lib = L.load()
+        self.step_count = 0
+        for g in groups:
+            ps = [p for p in g["params"] if p.requires_grad]
+            if not ps:
+                continue
+            dev = ps[0].device
+            for p in ps:
+                if p.dtype != torch.float32 or p.device != dev or dev.type != "cuda":
+                    raise ValueError("FlatAdamW: fp32 parameters on one ROCm device per group")
+                dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                if not dense:
+                    raise ValueError("FlatAdamW: parameters must be dense (contiguous or channels_last)")
+            sizes = [(p.numel() + 3) // 4 * 4 for p in ps]                        # every tensor starts on a 16-byte boundary
+            n = sum(sizes)
+            flat, grad = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+            views, o = [], 0
+            with torch.no_grad():
+                for p, sz in zip(ps, sizes):
+                    w = torch.as_strided(flat, p.shape, p.stride(), o)
+                    w.copy_(p)
+                    p.data = w
+                    views.append(torch.as_strided(grad, p.shape, p.stride(), o))
+                    o += sz
+            grp = {k: v for k, v in g.items() if k != "params"}
+            grp.setdefault("lr", lr); grp.setdefault("betas", betas); grp.setdefault("eps", eps); grp.setdefault("weight_decay", weight_decay)
+            grp["params"] = ps
+            self.param_groups.append(grp)
+            self._flat.append(dict(flat=flat, grad=grad, views=views, exp_avg=torch.zeros(n, device=dev), exp_avg_sq=torch.zeros(n, device=dev), n=n))
+        self.zero_grad()
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        for grp, f in zip(self.param_groups, self._flat):
+            f["grad"].zero_()
+            for p, gv in zip(grp["params"], f["views"]):
+                if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
+                    p.grad = gv                                                 # autograd accumulates into this view in place from now on
+
+    @torch.no_grad()
+    def step(self, grad_scale: float = 1.0) -> None:
+        self.step_count += 1
+        for grp, f in zip(self.param_groups, self._flat):
+            for p, gv in zip(grp["params"], f["views"]):
+                if p.grad is not None and p.grad.data_ptr() != gv.data_ptr():   # someone replaced .grad (set_to_none elsewhere + a fresh backward): fold it in
+                    gv.add_(p.grad)
+                    p.grad = gv
+            L.check(self.lib.mode_adamw_step(f["flat"].data_ptr(), f["grad"].data_ptr(), f["exp_avg"].data_ptr(), f["exp_avg_sq"].data_ptr(), f["n"],
+                                             float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]), float(grp["weight_decay"]),
+                                             self.step_count, float(grad_scale), None, None, 0.0, _stream()), "adamw_step")
+            torch.autograd.graph.increment_version(grp["params"])                 # raw-pointer write: version-gated caches (conv weight shadows) must see it
+
+    def state_dict(self) -> Dict:
+        return {"step": self.step_count, "exp_avg": [f["exp_avg"] for f in self._flat], "exp_avg_sq": [f["exp_avg_sq"] for f in self._flat],
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        self.step_count = int(sd["step"])
+        for f, m_, v_ in zip(self._flat, sd["exp_avg"], sd["exp_avg_sq"]):
+            f["exp_avg"].copy_(m_); f["exp_avg_sq"].copy_(v_)
+        for g, s_ in zip(self.param_groups, sd["param_groups"]):
+            g.update(s_)
+
+
 class ArenaEMA:
     """Exponential moving average of the denoiser weights over the flat arena (replaces the ``EMA`` Lightning callback,
     mode/callbacks/ema.py:36-141, for the denoiser's parameters): ``e -= (1 - decay_t) * (e - w)`` with the callback's warm-up schedule

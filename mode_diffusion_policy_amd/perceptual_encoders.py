@@ -233,7 +233,7 @@ def _compute_dtype(x: torch.Tensor) -> torch.dtype:
     return torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
 
 
-# ---- convolutions on the library's own kernels (round 4; DESIGN.md section 4, profiles/r04_conv_probes.txt).  On channels_last bf16 activations every convolution
+# ---- convolutions on the library's own kernels (round 4; LABNOTES.md section 4, profiles/r04_conv_probes.txt).  On channels_last bf16 activations every convolution
 # is a GEMM over rows = pixels, and the library already had the GEMMs; MIOpen (round 3: "convs via MIOpen first") cost 37 % of the agent's step - weight-gradient
 # kernels at ~100 TF/s wrapped in zero / cast helper launches, split-K forward / data-gradient kernels with the same helpers, two autocast casts per convolution.
 #   1 x 1 / stride 1   forward = mode_gemm, data gradient = MODE_GEMM_W_KN, weight gradient dW[Cout, Cin] = dY[R, Cout]^T X[R, Cin] = MODE_GEMM_A_KM | W_KN with

@@ -4,7 +4,7 @@ Neither ``timm`` nor ``torchvision`` exists in the build image, so the reference
 be constructed as they are.  ``oracle/gen_golden_encoders.py`` registers this trunk under the two names their constructors call
 (``timm.create_model``, ``torchvision.models.resnet18``) and then runs the REFERENCE classes on top of it: what fixture F15 pins is the
 reference's FiLM wiring / forward / autograd; the trunk's equality with timm's is by construction of the textbook architecture and the
-``state_dict`` key / shape contract only (parity of the trunk itself: unpinned - DESIGN.md section 8).
+``state_dict`` key / shape contract only (parity of the trunk itself: unpinned - LABNOTES.md section 8).
 """
 from __future__ import annotations
 

@@ -1,9 +1,9 @@
 """Per-kernel averages of the rocprofv3 --pmc passes written by scripts/collect_profiles.sh (<root>/pmc*/p_counter_collection.csv).
 
-Prints a table and writes a machine-readable summary (default profiles/r04_gemm_pmc.json) that bench.py reads `roofline.traffic` from:
+Prints a table and writes a machine-readable summary (default profiles/r05_gemm_pmc.json) that bench.py reads `roofline.traffic` from:
 HBM bytes per launch = FETCH_SIZE x 2 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KB.
 
-    python scripts/pmc_summary.py gpurun_out/prof_final profiles/r04_gemm_pmc.json
+    python scripts/pmc_summary.py gpurun_out/prof_final profiles/r05_gemm_pmc.json
 """
 import csv
 import glob
@@ -12,7 +12,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_final"
-out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r04_gemm_pmc.json"
+out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r05_gemm_pmc.json"
 ROLES = [("gemm_pp_kernel<4, true, 3", "expert_up_projection"), ("gemm_pp_kernel<0, true, 3", "expert_down_projection"),
          ("gemm_bf16_kernel<128, 64, 2, 2, 2, 1,", "qkv_projection"), ("gemm_bf16_kernel<64, 64, 2, 2, 3, 5,", "c_proj_residual_ln2"),
          ("combine_norm_row_kernel", "combine_ln1"), ("attn_bf16_kernel", "attention"), ("qkv_attn_kernel", "qkv_projection+attention")]

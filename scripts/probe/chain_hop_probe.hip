@@ -1,5 +1,5 @@
 // What does one device-side producer -> consumer hop cost when consecutive kernels of a dependent chain run on two streams and the consumer WAITS ON A
-// FLAG instead of on the kernel boundary?  (the legal form of cross-kernel overlap for the small-batch sampler chain.)
+// FLAG instead of on the kernel boundary?  (LABNOTES.md section 8: the legal form of cross-kernel overlap for the small-batch sampler chain.)
 //   chain of NK kernels; kernel i (NWG workgroups of 256 threads): [optional: stream `wbytes` of private "weights" into registers first - the part a
 //   real consumer could prefetch], spin until counter[i-1] == NWG, acquire, read the previous kernel's 64-KiB output, add, write its own, release,
 //   counter[i] += 1 per workgroup.

@@ -5,7 +5,7 @@
 // Persistent FOUR-wave bf16 MFMA GEMM for gfx950 - the expert projections at large batch:
 //   C[M,N] = epilogue(A[M,K] @ W[N,K]^T), row-gathered / grouped (MoE, uniform groups) / K-sliced; epilogues SWIGLU (+ fused ln_2 row scale) and NONE, bf16 out.
 //
-// What changed against the eight-wave ping-pong kernel, and why (measurements: scripts/probe/w3_kloop_probe.hip, w4k64_probe.hip):
+// What changed against the eight-wave ping-pong kernel, and why (measurements: scripts/probe/w3_kloop_probe.hip, w4k64_probe.hip, LABNOTES.md section 4):
 //   * ONE wave per SIMD with the 512-register budget: a wave owns 112 rows x 128 weight rows of the 224 x 256 tile (7 x 8 accumulator fragments = 224 AGPRs).
 //     Per K-step the four waves read 4 x (112 + 128) x 128 B = 120 KiB of fragments from LDS; eight waves of 112 x 64 read 176 KiB.  With the 60 KiB the
 //     operand DMA writes, the eight-wave form keeps the LDS port busy for 1 850 cycles of a K-step whose MFMAs need 1 792 - it was LDS-port bound whatever

@@ -1,4 +1,4 @@
-// K-loop probe for a FOUR-wave formulation of the 224x256 ping-pong GEMM (see DESIGN.md "what comes next"): one wave per SIMD with the
+// K-loop probe for a FOUR-wave formulation of the 224x256 ping-pong GEMM (see LABNOTES.md section 8): one wave per SIMD with the
 // 512-register budget, each wave owning 112 rows x 128 columns (7 x 8 accumulator fragments), operands streamed by LDS-DMA into a ring of NS
 // k32-granular slots (224 + 256 rows x 64 B = 30 KiB each), fragments of k32-step s+1 read under the MFMAs of step s, one barrier per k32 step
 // (BPK = 2) or per K-step (BPK = 1).  Real operands, real DMA, result checked against a naive kernel.  Prints cycles per K-step (64 k):

@@ -1,4 +1,4 @@
-"""Host-side restatement of the fused ln_2 algebra, CPU: moving RMSNorm's per-row division behind the GEMM and summing
+"""Host-side restatement of the fused ln_2 algebra (LABNOTES.md §4), CPU: moving RMSNorm's per-row division behind the GEMM and summing
 per-64-column partial sums of squares gives the oracle's ln_2 -> expert up-projection result.  The HIP kernels implement exactly these
 steps (MODE_EPI_RESIDUAL_NORM producer, MODE_EPI_SWIGLU row-scale consumer); their GPU parity is tests/test_gpu_kernels.py."""
 import torch
