@@ -678,7 +678,8 @@ def agent_step_measure(den, device, B, steps, warmup, miopen_benchmark=False):
     rgb_s = torch.randn(B, 1, 3, 224, 224, generator=g).to(device); rgb_g = torch.randn(B, 1, 3, 224, 224, generator=g).to(device)
     goal = torch.randn(B, 1, 512, generator=g).to(device)
     acts = torch.randn(B, 10, 7, generator=g).to(device); noise = torch.randn(B, 10, 7, generator=g).to(device)
-    opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    fuse = os.environ.get("MODE_FUSE_EXPERT_STEP", "1") == "1" and m.engine.compute_dtype == "bf16"     # single process: expert matrices updated inside the backward (train_leg)
+    opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, fuse_expert_step=fuse)
     enc_params = list(enc_s.parameters()) + list(enc_g.parameters())
     if os.environ.get("MODE_BENCH_FLAT_ADAMW", "1") == "1":                     # the encoders' 51 M parameters as ONE mode_adamw_step launch (optim.FlatAdamW)
         from mode_diffusion_policy_amd.optim import FlatAdamW
@@ -699,7 +700,7 @@ def agent_step_measure(den, device, B, steps, warmup, miopen_benchmark=False):
                 ev[1].record()
             loss, _ = den.loss(emb, acts, goal, noise, sig)
         loss.backward()
-        opt.step(overlap=True)
+        opt.step(overlap=not fuse)
         opt_e.step()
         opt_e.zero_grad(set_to_none=True)
         return loss
@@ -724,7 +725,8 @@ def agent_step_measure(den, device, B, steps, warmup, miopen_benchmark=False):
            "config": {"workload": "SURVEY 8(f)-1: MoDEAgent training step - embed_visual_obs (2 x FiLMResNet50Policy, 224 x 224 RGB, latent-goal FiLM) -> "
                                   "GCDenoiser.loss (12 layers, d=1024, 4 experts top-2) -> backward through both -> AdamW", "global_batch": B,
                       "parallelism": "single GPU"},
-           "agent_ms_per_step_blocks": [round(b, 3) for b in blocks], "host_enqueue_ms_per_step": round(min(host), 3), "encoders_forward_ms": round(enc_fwd_ms, 3), "encoder_params": n_enc,
+           "agent_ms_per_step_blocks": [round(b, 3) for b in blocks], "host_enqueue_ms_per_step": round(min(host), 3), "encoders_forward_ms": round(enc_fwd_ms, 3), "encoder_params": n_enc, "fused_expert_step": bool(fuse),
+           "encoder_optimizer": type(opt_e).__name__,
            "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "miopen_benchmark": bool(miopen_benchmark)}
     den.train(was_training)
     return res

@@ -611,3 +611,43 @@ def test_index_table_cache_is_a_bounded_lru():
     # the real tables: same key -> same tensor, and the cache is what hands them out
     t1 = E._tap_table(2, 6, 6, 6, 6, 3, 3, 1, 1, 1, 1, torch.device("cpu"))
     assert E._tap_table(2, 6, 6, 6, 6, 3, 3, 1, 1, 1, 1, torch.device("cpu")) is t1 and t1.shape == (9, 72) and int(t1.min()) == -1
+
+
+@pytest.mark.gpu
+def test_flat_adamw_matches_torch_adamw_on_an_encoder():
+    """optim.FlatAdamW (the encoders' optimizer as ONE mode_adamw_step launch per group) against torch.optim.AdamW on a FiLM-ResNet-18 for three
+    training steps with identical gradients: every parameter within fp32 rounding, channels_last convolution weights keep their strides,
+    state_dict keys / shapes are untouched, the raw-pointer update is seen by the version-gated weight shadows, two groups with their own decay."""
+    from mode_diffusion_policy_amd.optim import FlatAdamW
+    torch.manual_seed(9)
+    a = E.FiLMResNet18Policy(32).cuda().train()
+    b = E.FiLMResNet18Policy(32).cuda().train()
+    b.load_state_dict(a.state_dict())
+    keys = {k: tuple(v.shape) for k, v in a.state_dict().items()}
+    strides = {n: p.stride() for n, p in a.named_parameters()}
+    split = lambda m: [dict(params=[p for n, p in m.named_parameters() if p.dim() > 1], weight_decay=0.05),
+                       dict(params=[p for n, p in m.named_parameters() if p.dim() <= 1], weight_decay=0.0)]
+    oa = FlatAdamW(split(a), lr=2e-3, betas=(0.9, 0.95))
+    ob = torch.optim.AdamW(split(b), lr=2e-3, betas=(0.9, 0.95))
+    assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == keys and {n: p.stride() for n, p in a.named_parameters()} == strides
+    img = torch.randn(4, 3, 64, 64, device="cuda"); cond = torch.randn(4, 32, device="cuda")
+    for step in range(3):
+        oa.zero_grad(); ob.zero_grad(set_to_none=True)
+        ver = [p._version for p in a.parameters()]
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            (b(img, cond).float() ** 2).mean().backward()
+        for pa, pb in zip(a.parameters(), b.parameters()):                       # identical gradients: accumulated INTO the flat views, as autograd would
+            pa.grad.add_(pb.grad)
+        oa.step(); ob.step()
+        torch.cuda.synchronize()
+        assert all(p._version > v for p, v in zip(a.parameters(), ver))
+        for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            assert rel(pa.detach(), pb.detach()) < 2e-6, (step, n)
+    # autograd itself accumulates into the flat views in place, and a replaced .grad is folded in by step()
+    oa.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        (a(img, cond).float() ** 2).mean().backward()
+    g0 = next(iter(a.parameters())).grad
+    assert g0.data_ptr() == oa._flat[0]["views"][0].data_ptr() and float(g0.abs().max()) > 0
+    sd = oa.state_dict()
+    assert sd["step"] == 3 and len(sd["exp_avg"]) == 2
