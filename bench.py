@@ -493,7 +493,7 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU, z
     else:
         wire = 2.0 * frac * n_par * gb
     exposed = round(sum(ev_bwd[i].elapsed_time(ev_end[i]) for i in range(ev_lo, ev_lo + steps)) / steps, 3)
-    return {"fused_expert_step": bool(fuse), "optimizer_overlap": bool(overlap), "dp_wire_gb": round(wire / 1e9, 3), "dp_budget_ms": round(wire / 300e9 * 1e3, 2), "exposed_exchange_ms": exposed,
+    return {"fused_expert_step": bool(fuse), "fused_side_stream": bool(fuse and opt.fused_side_stream), "optimizer_overlap": bool(overlap), "dp_wire_gb": round(wire / 1e9, 3), "dp_budget_ms": round(wire / 300e9 * 1e3, 2), "exposed_exchange_ms": exposed,
             "train_ms_per_step": round(ms, 3), "train_samples_per_s": round(world * B / (ms * 1e-3), 1), "train_global_batch": B * world,
             "train_mfma_frac": round(fl / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4), "train_tflops_per_gpu": round(fl / (ms * 1e-3) / 1e12, 1),
             "dp_mode": ("zero1:" + z1) if z1 else ("allreduce" if (red is not None and world > 1) else "single"),

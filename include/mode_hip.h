@@ -129,6 +129,11 @@ typedef struct ModeAdamWFuse {
   float grad_scale;
   float* gsq;                             /* optional: one float per workgroup of the launch (grid order: z-major, then tile) = sum of squares of the   */
   int64_t gsq_capacity;                   /* scaled gradient over the workgroup's tile, so ||g||^2 stays observable (mode_agent.py:304-363); floats available at gsq */
+  /* mode_dit_backward only (ignored by mode_gemm): run the HBM-bound weight-gradient + optimizer launches on a SECOND stream, beside the MFMA-bound
+   * data-gradient chain of the same and the following blocks.  side_events = hipEvent_t[4] owned by the caller ([0] / [1]: "the data gradient that reads
+   * W2 / W1 of this block has been issued" - main -> side; [2] / [3]: "both weight-gradient launches of an even / odd block are done" - side -> main, which
+   * waits for them before it reuses that block parity's dY / dP buffers and once more before it returns).  NULL side_stream = everything on the one stream. */
+  void* side_stream; void* const* side_events;
 } ModeAdamWFuse;
 typedef struct ModeGemmDesc {
   int32_t dtype;              /* ModeDType of A and W                                     */

@@ -29,7 +29,7 @@ class ModeAdamWFuse(C.Structure):
     arena), the step's hyper-parameters, optional per-workgroup sums of squares of the gradient."""
     _fields_ = [("grad_base", c_vp), ("param_base", c_vp), ("exp_avg_base", c_vp), ("exp_avg_sq_base", c_vp), ("lp_base", c_vp), ("ema_base", c_vp),
                 ("ema_rate", c_f32), ("lr", c_f32), ("beta1", c_f32), ("beta2", c_f32), ("eps", c_f32), ("weight_decay", c_f32), ("step", c_i32),
-                ("grad_scale", c_f32), ("gsq", c_vp), ("gsq_capacity", c_i64)]
+                ("grad_scale", c_f32), ("gsq", c_vp), ("gsq_capacity", c_i64), ("side_stream", c_vp), ("side_events", c_vp)]
 
 
 class ModeGemmDesc(C.Structure):

@@ -48,7 +48,7 @@ ModeGemmDesc gdesc(int dtype, int epi, int out_dtype, int M, int N, int K, const
 
 struct TrainWs {   // backward workspace offsets
   size_t dxa, dxb, dyl, dys, dhd, dp, dus, dwt, t_big, t_mid, t_d, t_d2, dx1lp, dyattn, dqkv, dh1, dgp, apq, apk, csw, dcond, dlog, dhid, dpre,
-      st1, st2, tmp_rd, demb, de1, dimg, dgoal, tr_dlog, tr_dpre, tr_u, tr_du, total;
+      st1, st2, tmp_rd, demb, de1, dimg, dgoal, tr_dlog, tr_dpre, tr_u, tr_du, dys2, dp2, total;
 };
 
 TrainWs train_ws(const ModeDims& d, int B, int dtype) {
@@ -83,6 +83,9 @@ TrainWs train_ws(const ModeDims& d, int B, int dtype) {
   w.demb = t((size_t)B * D * 4); w.de1 = t((size_t)B * D * 4); w.dimg = t((size_t)B * d.n_img * D * 4); w.dgoal = t((size_t)B * D * 4);
   // token routing (cond_router=False): one layer's router backward - dlogits [N,E], dpre [N,2D], recomputed ln_2 output [N,D], d u from the router [N,D]
   w.tr_dlog = t(N * (size_t)d.E * 4); w.tr_dpre = t(N * 2 * D * 4); w.tr_u = t(N * D * 4); w.tr_du = t(N * D * 4);
+  // second dY / dP pair (bf16 only): with the fused weight-gradient + optimizer launches on a side stream (ModeAdamWFuse.side_stream) odd blocks use these, so
+  // that the side stream may still read block l's operands while the chain writes block l-1's
+  w.dys2 = t(dtype == MODE_BF16 ? NK * D * esz : 0); w.dp2 = t(dtype == MODE_BF16 ? NK * 8 * D * esz : 0);
   w.total = t.o;
   return w;
 }
@@ -306,6 +309,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
   float* dlog = (float*)(ws + W.dlog); float* dhid = (float*)(ws + W.dhid); float* dpre = (float*)(ws + W.dpre);
   float* st1 = (float*)(ws + W.st1); float* st2 = (float*)(ws + W.st2);
 #define ZERO(ptr, bytes) if (hipMemsetAsync((ptr), 0, (bytes), hs) != hipSuccess) return (int)hipGetLastError();
+#define MODE_HIP_OK(call) if ((call) != hipSuccess) return (int)hipGetLastError();
 
   // (ABI 11) AdamW in the epilogue of the expert weight-gradient GEMMs: bf16 transpose-read path only
   ModeAdamWFuse fz;
@@ -315,6 +319,18 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     if (!tr || (4 * D) % 128 || D % 128) return MODE_ERR_UNSUPPORTED;
     if (a->fuse_adamw->gsq && a->fuse_adamw->gsq_capacity < fz_per_layer * d.L) return MODE_ERR_WORKSPACE;
   }
+  // Second stream for the fused weight-gradient + optimizer launches (ModeAdamWFuse.side_stream): they are HBM-bound, the data-gradient chain MFMA-bound.
+  // Block parity selects the dY / dP buffers (the transposed-operand scratch of the fp32 path, unused here, is the second pair), so that the side stream may
+  // lag one block behind the chain.
+  const bool side = a->fuse_adamw && a->fuse_adamw->side_stream && a->fuse_adamw->side_events;
+  hipStream_t ss = side ? (hipStream_t)a->fuse_adamw->side_stream : hs;
+  hipEvent_t ev_w2 = nullptr, ev_w1 = nullptr, ev_done[2] = {nullptr, nullptr};
+  if (side) {
+    ev_w2 = (hipEvent_t)a->fuse_adamw->side_events[0]; ev_w1 = (hipEvent_t)a->fuse_adamw->side_events[1];
+    ev_done[0] = (hipEvent_t)a->fuse_adamw->side_events[2]; ev_done[1] = (hipEvent_t)a->fuse_adamw->side_events[3];
+    if (!ev_w2 || !ev_w1 || !ev_done[0] || !ev_done[1]) return MODE_ERR_BAD_ARG;
+  }
+  bool done_rec[2] = {false, false};
   for (int l = d.L - 1; l >= 0; --l) {
     const ModeLayerWeights& lw = w->layers[l];
     const ModeLayerWeightsT* lt = &wt->layers[l];
@@ -323,6 +339,11 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     const int32_t* meta = a->meta + (long)l * a->meta_layer_stride;
     const int32_t* offsets = meta + ml.offsets; const int32_t* poff = meta + ml.poffsets; const int32_t* prow = meta + ml.prow;
     const int32_t* pos = meta + ml.pos; const float* posw = reinterpret_cast<const float*>(meta + ml.posw);
+    const int par = l & 1;
+    if (side) {                                                  // this block's dY / dP pair; the side stream must be done with the block that used it last
+      dYs = par ? ws + W.dys2 : ws + W.dys; dP = par ? ws + W.dp2 : ws + W.dp;
+      if (done_rec[par]) MODE_HIP_OK(hipStreamWaitEvent(hs, ev_done[par], 0));
+    }
     // (1) combine backward: dY (sorted rows) and router-weight gradients
     if ((rc = combine_bwd_launch(DXa, S + sl.Y, dt, train_dn_split(dt, 4 * D), (long)NK * D, pos, posw, N, D, d.k, dYs, dwt + (size_t)l * NK, stream))) return rc;
     // (1b) token routing: this block's router, back-propagated in place - its input is the block's own ln_2 output, so d u gets a second term
@@ -367,7 +388,8 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, 4 * D, NK, dYs, D, S + sl.Hd, 4 * D, lg.w2, 4 * D);
       g.k_group_offsets = offsets; g.num_k_groups = E; g.c_group_stride = 4L * D * D; g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
       if (a->fuse_adamw) { fz = *a->fuse_adamw; if (fz.gsq) { fz.gsq += (long)l * fz_per_layer; fz.gsq_capacity = fz_w2; } g.adamw = &fz; }   // W2 is updated here: no gradient is written
-      if ((rc = mode_gemm(&g, stream))) return rc;
+      if (side) { MODE_HIP_OK(hipEventRecord(ev_w2, hs)); MODE_HIP_OK(hipStreamWaitEvent(ss, ev_w2, 0)); }   // ... after the data gradient above has read it
+      if ((rc = mode_gemm(&g, side ? (void*)ss : stream))) return rc;
     } else if (tr) {                                 // bf16: operands as they lie in memory, fragments by LDS transpose reads
       g = gdesc(dt, MODE_EPI_NONE, dt, NK, 4 * D, D, dYs, D, lw.w2, 4 * D, dHd, 4 * D);
       g.w_expert_stride = 4L * D * D; g.expert_offsets = offsets; g.num_experts = E; g.flags = MODE_GEMM_W_KN;
@@ -375,7 +397,8 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, D, 4 * D, NK, dYs, D, S + sl.Hd, 4 * D, lg.w2, 4 * D);
       g.k_group_offsets = offsets; g.num_k_groups = E; g.c_group_stride = 4L * D * D; g.flags = MODE_GEMM_W_KN | MODE_GEMM_A_KM;
       if (a->fuse_adamw) { fz = *a->fuse_adamw; if (fz.gsq) { fz.gsq += (long)l * fz_per_layer; fz.gsq_capacity = fz_w2; } g.adamw = &fz; }   // W2 is updated here: no gradient is written
-      if ((rc = mode_gemm(&g, stream))) return rc;
+      if (side) { MODE_HIP_OK(hipEventRecord(ev_w2, hs)); MODE_HIP_OK(hipStreamWaitEvent(ss, ev_w2, 0)); }   // ... after the data gradient above has read it
+      if ((rc = mode_gemm(&g, side ? (void*)ss : stream))) return rc;
     } else {
       g = gdesc(dt, MODE_EPI_NONE, dt, NK, 4 * D, D, dYs, D, lt->w2T, D, dHd, 4 * D);
       g.w_expert_stride = 4L * D * D; g.expert_offsets = offsets; g.num_experts = E;
@@ -416,7 +439,9 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       } else {
         g.W = S + sl.ub; g.w_rows = meta + ml.perm;             // ring kernel: u rows gathered through perm inside the GEMM
       }
-      if ((rc = mode_gemm(&g, stream))) return rc;
+      if (side) { MODE_HIP_OK(hipEventRecord(ev_w1, hs)); MODE_HIP_OK(hipStreamWaitEvent(ss, ev_w1, 0)); }   // dU (reads W1) is on the chain: W1 may be updated behind it
+      if ((rc = mode_gemm(&g, side ? (void*)ss : stream))) return rc;
+      if (side) { MODE_HIP_OK(hipEventRecord(ev_done[par], ss)); done_rec[par] = true; }
     } else {
       g = gdesc(dt, MODE_EPI_NONE, MODE_F32, NK, D, 8 * D, dP, 8 * D, lt->w1T, 8 * D, dUs, D);
       g.w_expert_stride = 8L * D * D; g.expert_offsets = offsets; g.num_experts = E;
@@ -485,6 +510,10 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
     float* t_ = DXa; DXa = DXb; DXb = t_;                    // DXa now holds d x_l
   }
 
+  if (side) {                                                    // join: the chain's stream owns the parameters again when the call returns
+    for (int q = 0; q < 2; ++q)
+      if (done_rec[q]) MODE_HIP_OK(hipStreamWaitEvent(hs, ev_done[q], 0));
+  }
   // ---- RMSNorm gain gradients of all layers: one segmented column sum per kind when the gradient slots are layer-contiguous
   {
     const int Ly = d.L;

@@ -31,7 +31,7 @@ class FusedAdamW:
     (mode_agent.py:304-363)."""
 
     def __init__(self, model, lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
-                 fuse_expert_step: bool = False):
+                 fuse_expert_step: bool = False, fused_side_stream: bool = True):
         self.model = model
         eng = model.engine                                   # adopts the parameters into the arena
         self.eng, self.arena = eng, eng.arena
@@ -52,6 +52,10 @@ class FusedAdamW:
         self.fused_ema = None                                    # an ArenaEMA whose schedule the fused update honours (else pass ema= to step(): a separate pass over the expert ranges)
         self._fused_pending = False                              # a backward has applied the expert update of step step_count + 1
         self._fused_struct = self._fused_gsq = None
+        # the fused weight-gradient + optimizer launches are HBM-bound, the data-gradient chain MFMA-bound: the backward runs them on a second stream
+        # (ModeAdamWFuse.side_stream; joined before mode_dit_backward returns).  False = everything on the one stream.
+        self.fused_side_stream = bool(fused_side_stream) and os.environ.get("MODE_FUSED_SIDE_STREAM", "1") == "1"
+        self._fused_side = None                                  # (stream, [4 events], ctypes array of their handles)
         if self.fuse_expert_step:
             if eng.compute_dtype != "bf16":
                 raise ValueError("fuse_expert_step needs the bf16 compute mode (the fused epilogue lives in the bf16 weight-gradient GEMM)")
@@ -95,7 +99,16 @@ class FusedAdamW:
         if self._fused_gsq is None:
             n = int(eng.lib.mode_adamw_fuse_gsq_floats(C.byref(eng.dims)))
             self._fused_gsq = torch.zeros(n, dtype=torch.float32, device=eng.device)
-        st = L.ModeAdamWFuse(grad_base=ar.grad.data_ptr(), param_base=ar.flat.data_ptr(), exp_avg_base=self.exp_avg.data_ptr(),
+        side_stream, side_events = None, None
+        if self.fused_side_stream and not torch.cuda.is_current_stream_capturing():
+            if self._fused_side is None:
+                stream = torch.cuda.Stream(device=eng.device)
+                evs = [torch.cuda.Event() for _ in range(4)]
+                for ev in evs:
+                    ev.record()                                                 # forces creation of the underlying hipEvent
+                self._fused_side = (stream, evs, (C.c_void_p * 4)(*[ev.cuda_event for ev in evs]))
+            side_stream, side_events = self._fused_side[0].cuda_stream, C.cast(self._fused_side[2], C.c_void_p)
+        st = L.ModeAdamWFuse(side_stream=side_stream, side_events=side_events, grad_base=ar.grad.data_ptr(), param_base=ar.flat.data_ptr(), exp_avg_base=self.exp_avg.data_ptr(),
                              exp_avg_sq_base=self.exp_avg_sq.data_ptr(), lp_base=ar.lp.data_ptr() if ar.lp is not None else None, ema_base=ema_base,
                              ema_rate=float(rate), lr=float(gd["lr"]), beta1=float(gd["betas"][0]), beta2=float(gd["betas"][1]), eps=float(gd["eps"]),
                              weight_decay=float(gd["weight_decay"]), step=self.step_count + 1, grad_scale=float(self.fused_grad_scale),

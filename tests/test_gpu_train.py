@@ -160,8 +160,9 @@ def test_fused_adamw_matches_torch_adamw(dtype, overlap):
     assert float(l2) != float(loss)
 
 
+@pytest.mark.parametrize("side_stream", [True, False])
 @pytest.mark.parametrize("stochastic,ema", [(False, False), (True, False), (True, True)])
-def test_fused_expert_step_is_bit_identical_to_the_two_pass_update(stochastic, ema):
+def test_fused_expert_step_is_bit_identical_to_the_two_pass_update(stochastic, ema, side_stream):
     """FusedAdamW(fuse_expert_step=True): the expert matrices (88 % of the parameters) are updated in the EPILOGUE of their weight-gradient GEMMs
     (ModeAdamWFuse; gradients never stored).  Same gradient bits + same expression order => after three steps EVERY parameter, both Adam moments,
     the bf16 shadow and (when on) the EMA equal the ordinary backward + optimizer pass bit for bit - deterministic config and the stochastic
@@ -176,7 +177,7 @@ def test_fused_expert_step_is_bit_identical_to_the_two_pass_update(stochastic, e
     dena, denb = M.GCDenoiser(ma, 0.5).train(), M.GCDenoiser(mb, 0.5).train()
     sig = torch.full((16,), 0.9, device="cuda")
     oa = FusedAdamW(ma, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
-    ob = FusedAdamW(mb, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, fuse_expert_step=True)
+    ob = FusedAdamW(mb, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, fuse_expert_step=True, fused_side_stream=side_stream)   # side stream: the fused launches beside the chain
     ea = ArenaEMA(ma, decay=0.99) if ema else None
     eb = ArenaEMA(mb, decay=0.99) if ema else None
     ob.fused_ema = eb
