@@ -20,7 +20,8 @@ B = 128
 g = torch.Generator().manual_seed(1)
 img = torch.randn(B, 2, 2048, generator=g).to(dev); goal = torch.randn(B, 1, 512, generator=g).to(dev)
 acts = torch.randn(B, 10, 7, generator=g).to(dev); noise = torch.randn(B, 10, 7, generator=g).to(dev)
-opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+FUSE = os.environ.get("MODE_FUSE_EXPERT_STEP", "1") == "1"
+opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, fuse_expert_step=FUSE)
 T = {"sigma": 0.0, "loss": 0.0, "backward": 0.0, "opt": 0.0}
 
 
@@ -32,7 +33,7 @@ def step(rec):
     t2 = time.perf_counter()
     loss.backward()
     t3 = time.perf_counter()
-    opt.step(overlap=True)
+    opt.step(overlap=not FUSE)
     t4 = time.perf_counter()
     if rec:
         T["sigma"] += t1 - t0; T["loss"] += t2 - t1; T["backward"] += t3 - t2; T["opt"] += t4 - t3
