@@ -728,6 +728,59 @@ class _Trunk(nn.Module):
         return F.max_pool2d(x, 3, 2, 1)
 
 
+# ---- the encoders' small Linears (FiLM gamma / beta, FilmModule, fc) on the library's fp32 MFMA GEMM instead of hipBLASLt: y = x W^T + b, dx = dy W, dW = dy^T x from
+#      row-major operands where they lie (exact fp32 fma chains; conditioning vectors are 512 wide, the products tiny).  MODE_ENC_HIPLINEAR=0: nn.Linear (A/B runs).
+USE_HIP_LINEAR = __import__("os").environ.get("MODE_ENC_HIPLINEAR", "1") == "1"
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        M_, K_ = x.shape
+        N_ = w.shape[0]
+        y = torch.empty(M_, N_, dtype=torch.float32, device=x.device)
+        d = L.ModeGemmDesc(dtype=L.MODE_F32, epilogue=L.EPI_BIAS if b is not None else L.EPI_NONE, out_dtype=L.MODE_F32, M=M_, N=N_, K=K_, A=x.data_ptr(), lda=K_,
+                           W=w.data_ptr(), ldw=w.stride(0), bias=_ptr(b), C=y.data_ptr(), ldc=N_, flags=L.GEMM_SKINNY_OK)
+        L.check(L.load().mode_gemm(C.byref(d), _stream()), "linear fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        M_, K_ = x.shape
+        N_ = w.shape[0]
+        lib, st = L.load(), _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:                                            # dx[M, K] = dy[M, N] @ W[N, K]  (W as [K_red = N][cols = K]: MODE_GEMM_W_KN)
+            dx = torch.empty(M_, K_, dtype=torch.float32, device=x.device)
+            d = L.ModeGemmDesc(dtype=L.MODE_F32, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=M_, N=K_, K=N_, A=dy.data_ptr(), lda=N_, W=w.data_ptr(), ldw=w.stride(0),
+                               C=dx.data_ptr(), ldc=K_, flags=L.GEMM_W_KN)
+            L.check(lib.mode_gemm(C.byref(d), st), "linear dx")
+        if ctx.needs_input_grad[1]:                                            # dW[N, K] = dy[M, N]^T @ x[M, K]  (both operands [K_red = M][cols])
+            dw = torch.empty(N_, K_, dtype=torch.float32, device=x.device)
+            d = L.ModeGemmDesc(dtype=L.MODE_F32, epilogue=L.EPI_NONE, out_dtype=L.MODE_F32, M=N_, N=K_, K=M_, A=dy.data_ptr(), lda=N_, W=x.data_ptr(), ldw=K_,
+                               C=dw.data_ptr(), ldc=K_, flags=L.GEMM_W_KN | L.GEMM_A_KM)
+            L.check(lib.mode_gemm(C.byref(d), st), "linear dW")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db
+
+
+def _linear(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """``lin(x)`` for 2-d fp32-parameter Linears on the device: the library's GEMM; anything else: nn.Linear."""
+    w = lin.weight
+    if (USE_HIP_LINEAR and x.is_cuda and x.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous() and x.shape[1] % 4 == 0 and w.shape[0] % 4 == 0
+            and x.shape[0] > 0):
+        return _LinearFn.apply(x, w, lin.bias)
+    return lin(x)
+
+
 class FiLMLayer(nn.Module):
     """gamma / beta = Linear(condition): x <- (1 + gamma) x + beta, zero-initialised (pretrained_resnets.py:5-23).  Holds parameters; the modulation
     itself is fused into the preceding BatchNorm pass."""
@@ -741,7 +794,7 @@ class FiLMLayer(nn.Module):
             nn.init.zeros_(lin.weight); nn.init.zeros_(lin.bias)
 
     def params(self, condition):
-        return self.gamma(condition), self.beta(condition)
+        return _linear(self.gamma, condition), _linear(self.beta, condition)
 
 
 class _FiLMResNetPolicy(nn.Module):
@@ -787,7 +840,7 @@ class FilmModule(nn.Module):
         self.modulation = nn.Sequential(nn.SiLU(), nn.Linear(input_size, 4 * hidden_size, bias=True))
 
     def forward(self, c):
-        x = self.modulation(c).chunk(2, dim=-1)
+        x = _linear(self.modulation[1], self.modulation[0](c)).chunk(2, dim=-1)
         return x[0].chunk(2, dim=-1), x[1].chunk(2, dim=-1)
 
 
@@ -822,7 +875,7 @@ class ResNetEncoderWithFiLM(nn.Module):
             mods = getattr(self, f"film_module{i}")(conditioning_vector.to(torch.float32)) if conditioning_vector is not None else (None, None)
             for j, blk in enumerate(getattr(self, f"layer{i}")):
                 x = blk(x, pre_film=mods[j])
-        x = self.fc(x.mean(dim=(2, 3)).to(self.fc.weight.dtype))
+        x = _linear(self.fc, x.mean(dim=(2, 3)).to(self.fc.weight.dtype))
         if series:
             x = x.reshape(B, t_steps, self.latent_dim)
         return x

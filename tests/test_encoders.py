@@ -651,3 +651,28 @@ def test_flat_adamw_matches_torch_adamw_on_an_encoder():
     assert g0.data_ptr() == oa._flat[0]["views"][0].data_ptr() and float(g0.abs().max()) > 0
     sd = oa.state_dict()
     assert sd["step"] == 3 and len(sd["exp_avg"]) == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M_,K_,N_,bias", [(4, 32, 64, True), (64, 512, 2048, True), (1, 512, 256, True), (7, 36, 20, False), (130, 512, 96, True)])
+def test_encoder_linears_on_the_library_gemm_vs_torch(M_, K_, N_, bias):
+    """`_LinearFn` (the FiLM gamma / beta Linears, FilmModule, fc: y = x W^T + b, dx = dy W, dW = dy^T x, db = colsum(dy) through mode_gemm's fp32 MFMA kernel,
+    row-major operands where they lie) against nn.Linear in float64; also under autocast(bf16), where it stays an fp32 product."""
+    torch.manual_seed(M_ + N_)
+    lin = torch.nn.Linear(K_, N_, bias=bias).cuda()
+    x = torch.randn(M_, K_, device="cuda", requires_grad=True)
+    dy = torch.randn(M_, N_, device="cuda")
+    for ac in (False, True):
+        x.grad = None; lin.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+            y = E._linear(lin, x)
+        assert y.dtype == torch.float32
+        y.backward(dy)
+        x64 = x.detach().double().requires_grad_(True)
+        w64 = lin.weight.detach().double().requires_grad_(True)
+        b64 = lin.bias.detach().double().requires_grad_(True) if bias else None
+        y64 = torch.nn.functional.linear(x64, w64, b64)
+        y64.backward(dy.double())
+        assert rel(y, y64) < 1e-5 and rel(x.grad, x64.grad) < 1e-5 and rel(lin.weight.grad, w64.grad) < 1e-5
+        if bias:
+            assert rel(lin.bias.grad, b64.grad) < 1e-5
