@@ -48,13 +48,22 @@ __device__ __forceinline__ void lds_read_seq(bf16x8* dst, uint32_t addr) {
 }
 
 // q | k | v tile of the epilogue in LDS: rows of 3 * HD bf16 + 16 bytes (the 16 token rows a ds_read_b128 group touches land on 16 distinct 4-bank groups)
+// The GEMM epilogue stores 8 bytes per lane, 16 lanes = 16 consecutive tile rows per LDS cycle group: with a 196-dword pitch rows r and r + 8 share their banks
+// (2-way conflict on every store: 147 K conflict cycles per launch in round 4's PMC pass).  Rows with bit 3 set therefore keep the two 8-byte halves of every
+// 16-byte chunk SWAPPED (store address ^ 8); the readers below swap them back in registers.
 template <int HD>
 struct LdsSrc {
   static constexpr int PITCH = 3 * HD * 2 + 16;
   const char* tile;   // first token row of this sample
-  __device__ __forceinline__ uint4 q(int row, int d0) const { return *reinterpret_cast<const uint4*>(tile + row * PITCH + d0 * 2); }
-  __device__ __forceinline__ uint4 k(int row, int d0) const { return *reinterpret_cast<const uint4*>(tile + row * PITCH + (HD + d0) * 2); }
-  __device__ __forceinline__ uint4 v(int row, int d0) const { return *reinterpret_cast<const uint4*>(tile + row * PITCH + (2 * HD + d0) * 2); }
+  int row0;           // its row index inside the tile (the half-swap goes by the TILE row)
+  __device__ __forceinline__ uint4 ld(int row, int byte) const {
+    const uint4 t = *reinterpret_cast<const uint4*>(tile + row * PITCH + byte);
+    const bool sw = ((row0 + row) & 8) != 0;
+    return make_uint4(sw ? t.z : t.x, sw ? t.w : t.y, sw ? t.x : t.z, sw ? t.y : t.w);
+  }
+  __device__ __forceinline__ uint4 q(int row, int d0) const { return ld(row, d0 * 2); }
+  __device__ __forceinline__ uint4 k(int row, int d0) const { return ld(row, (HD + d0) * 2); }
+  __device__ __forceinline__ uint4 v(int row, int d0) const { return ld(row, (2 * HD + d0) * 2); }
 };
 }  // namespace qa
 
@@ -201,7 +210,8 @@ __global__ __launch_bounds__(WM * 256, 1) void qkv_attn_kernel(const QkvAttnPara
     for (int i = 0; i < FM; ++i) {
       f32x4 v = acc[i][j];
       v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      *reinterpret_cast<uint2*>(smem + (wm * TM + i * 16 + fr) * PITCH + nl * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      const int trow = wm * TM + i * 16 + fr;
+      *reinterpret_cast<uint2*>(smem + trow * PITCH + ((nl * 2) ^ (trow & 8))) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(WM * 256, 1) void qkv_attn_kernel(const QkvAttnPara
   // ---- epilogue 2: wave w = sample w of the group: qk-RMSNorm, causal softmax, PV - the stand-alone kernel's body on LDS operands
   if (wave < ns) {
     const int b = s0 + wave;
-    const LdsSrc<HD> src{smem + wave * p.T * PITCH};
+    const LdsSrc<HD> src{smem + wave * p.T * PITCH, wave * p.T};
     attn_wave_bf16<(HD + 31) / 32>(src, p.qg, p.kg, p.y + (long)b * p.T * p.ldy + head * HD, p.ldy, p.T, HD, p.eps, 0u, 0u, 1.0f, b * p.H + head, lane);
   }
 }
