@@ -886,6 +886,7 @@ class ResNetEncoderWithFiLM(nn.Module):
 # the two camera towers on two streams (agent training step B = 64, same box alternating: 30.5 / 30.2 -> 27.0 / 27.8 ms, then host-bound: 26.7-27.3 ms of enqueue);
 # MODE_ENC_TWO_STREAMS=0: one stream (A/B runs)
 TWO_TOWER_STREAMS = __import__("os").environ.get("MODE_ENC_TWO_STREAMS", "1") == "1"
+TWO_TOWER_CAPTURE = __import__("os").environ.get("MODE_ENC_TWO_STREAMS_CAPTURE", "1") == "1"   # also inside GraphedVisualEncoder's captures (two graph branches)
 _TOWER_STREAMS: dict = {}
 
 
@@ -895,7 +896,8 @@ def embed_visual_obs(static_resnet, gripper_resnet, rgb_static, rgb_gripper, lat
     B, T = rgb_static.shape[0], rgb_static.shape[1]
     s = rgb_static.reshape(B * T, *rgb_static.shape[2:]); g = rgb_gripper.reshape(B * T, *rgb_gripper.shape[2:])
     args = (latent_goal,) if latent_goal is not None else ()
-    if TWO_TOWER_STREAMS and s.is_cuda and not torch.cuda.is_current_stream_capturing():
+    capturing = s.is_cuda and torch.cuda.is_current_stream_capturing()
+    if TWO_TOWER_STREAMS and s.is_cuda and (TWO_TOWER_CAPTURE or not capturing):
         # The two camera towers are independent: the gripper tower runs on a second stream (its backward too - autograd replays a node on the stream its
         # forward ran on), so that one tower's HBM-bound BatchNorm passes overlap the other's MFMA-bound convolution GEMMs.
         cur = torch.cuda.current_stream(s.device)
@@ -906,8 +908,9 @@ def embed_visual_obs(static_resnet, gripper_resnet, rgb_static, rgb_gripper, lat
         with torch.cuda.stream(side):
             gt = gripper_resnet(g, *args)
         st = static_resnet(s, *args)
-        cur.wait_stream(side)
-        gt.record_stream(cur)
+        cur.wait_stream(side)                                                # (under capture: the side stream's work becomes a second branch of the graph)
+        if not capturing:
+            gt.record_stream(cur)
     else:
         st, gt = static_resnet(s, *args), gripper_resnet(g, *args)
     return {"state_images": torch.cat([st.reshape(B, T, -1), gt.reshape(B, T, -1)], dim=1)}
