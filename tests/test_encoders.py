@@ -632,19 +632,22 @@ def test_flat_adamw_matches_torch_adamw_on_an_encoder():
     assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == keys and {n: p.stride() for n, p in a.named_parameters()} == strides
     img = torch.randn(4, 3, 64, 64, device="cuda"); cond = torch.randn(4, 32, device="cuda")
     for step in range(3):
-        oa.zero_grad(); ob.zero_grad(set_to_none=True)
+        oa.zero_grad(set_to_none=step != 1); ob.zero_grad(set_to_none=True)      # step 1: .grad = zeroed views of the flat buffer (in-place accumulation); else: gathered by step()
         ver = [p._version for p in a.parameters()]
         with torch.autocast("cuda", dtype=torch.bfloat16):
             (b(img, cond).float() ** 2).mean().backward()
-        for pa, pb in zip(a.parameters(), b.parameters()):                       # identical gradients: accumulated INTO the flat views, as autograd would
-            pa.grad.add_(pb.grad)
+        for pa, pb in zip(a.parameters(), b.parameters()):                       # identical gradients
+            if pa.grad is None:
+                pa.grad = pb.grad.detach().clone()
+            else:
+                pa.grad.add_(pb.grad)
         oa.step(); ob.step()
         torch.cuda.synchronize()
         assert all(p._version > v for p, v in zip(a.parameters(), ver))
         for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
             assert rel(pa.detach(), pb.detach()) < 2e-6, (step, n)
-    # autograd itself accumulates into the flat views in place, and a replaced .grad is folded in by step()
-    oa.zero_grad()
+    # set_to_none=False: autograd itself accumulates into the flat views in place
+    oa.zero_grad(set_to_none=False)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         (a(img, cond).float() ** 2).mean().backward()
     g0 = next(iter(a.parameters())).grad
