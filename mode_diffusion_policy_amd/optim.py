@@ -85,6 +85,9 @@ class FusedAdamW:
         eng, ar = self.eng, self.arena
         if eng.arena is not ar:
             raise RuntimeError("the parameter arena was rebuilt (model.to()/half()?): create a new FusedAdamW")
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            raise NotImplementedError("fuse_expert_step is a single-process mode (the expert matrices would be updated from this rank's gradients only): "
+                                      "construct FusedAdamW(fuse_expert_step=False) under torch.distributed with more than one rank")
         if accumulate or self._fused_pending:
             raise RuntimeError("fuse_expert_step: a second backward before optimizer.step() (gradient accumulation) cannot be fused - the first "
                                "backward has already updated the expert matrices; construct FusedAdamW(fuse_expert_step=False)")
