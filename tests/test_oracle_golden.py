@@ -217,3 +217,29 @@ def test_oracle_full_size_benchmark_workload_vs_reference(golden):
     for i in range(1, 10):                                                       # the reference's callback `action` at step i = the update of step i-1
         assert rel(xs[i - 1][:4], g["action_in"][i]) < TOL, i
     assert np.array_equal(inp["x0"][:4].numpy(), g["action_in"][0])
+
+
+def test_oracle_full_size_training_step_vs_reference(golden):
+    """F18 (oracle/gen_golden_c2_train.py): the deterministic training step of the full-size model (12 layers, d = 1024, B = 16, both auxiliary router losses)
+    run by the reference's own modules + autograd: the oracle's autograd reproduces the losses, the expert ids and every gradient - twelve layers of BACKWARD
+    depth pinned to the reference directly.  ~40 s of CPU."""
+    g = golden("F18_c2_train")
+    cfg = get_config(str(g["cfg"])); B, seed = int(g["B"]), int(g["seed"])
+    assert (cfg.n_layers, cfg.embed_dim, cfg.num_experts, cfg.top_k) == (12, 1024, 4, 2) and float(g["margin"]) > 1e-5
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    sd = {k: v.clone().requires_grad_(True) for k, v in make_state_dict(cfg, seed).items()}
+    inp = make_inputs(cfg, B, seed + 1)
+    tot, act, lb, z = O.training_total_loss(sd, cfg, 0.5, inp["state_images"], inp["actions"], inp["goals"], inp["noise"], torch.from_numpy(g["sigma"]),
+                                            float(g["gamma"]), float(g["delta"]))
+    tot.backward()
+    assert abs(float(tot) - float(g["total"])) < 1e-5 * abs(float(g["total"])) and abs(float(act) - float(g["act"])) < 1e-5 * abs(float(g["act"]))
+    assert abs(float(lb) - float(g["lb"])) < 1e-5 and abs(float(z) - float(g["z"])) < 1e-5
+    gn = dict(zip(g["gn_keys"].tolist(), g["gn_vals"].tolist()))
+    for n, ref in gn.items():
+        if ref > 1e-6:
+            assert abs(float(sd[n].grad.norm()) - ref) / ref < 1e-4, n
+    for key in g.files:
+        if key.startswith("g:") and gn[key[2:]] > 1e-6:
+            assert rel(sd[key[2:]].grad, g[key]) < 1e-4, key
+        if key.startswith("gs:") and gn[key[3:]] > 1e-6:
+            assert float((sd[key[3:]].grad.reshape(-1)[:len(g[key])] - torch.from_numpy(g[key])).norm()) < 1e-4 * gn[key[3:]], key
