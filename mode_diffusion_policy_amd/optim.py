@@ -59,6 +59,8 @@ class FusedAdamW:
         if self.fuse_expert_step:
             if eng.compute_dtype != "bf16":
                 raise ValueError("fuse_expert_step needs the bf16 compute mode (the fused epilogue lives in the bf16 weight-gradient GEMM)")
+            if model.embed_dim % 128:
+                raise ValueError("fuse_expert_step needs embed_dim % 128 == 0 (128-column tiles of the fused weight-gradient launches)")
             model._fused_optimizer = self                        # training.py's backward asks this object for the ModeAdamWFuse of the step
 
     def zero_grad(self, set_to_none: bool = False) -> None:
