@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MODE_HIP_ABI_VERSION 11
+#define MODE_HIP_ABI_VERSION 12
 
 typedef enum ModeStatus {
   MODE_OK = 0,
@@ -736,6 +736,37 @@ int mode_bn_prepare_partials(const float* psum, const float* psq, int rows, doub
 int mode_bn_film_act_bwd(const ModeBnFilmDesc* d, const void* dy, const float* mean, const float* invstd, int training, int phase, float inv_count,
                          void* dx, void* dresidual, float* dweight, float* dbias, float* d_pre_gamma, float* d_pre_beta, float* d_post_gamma,
                          float* d_post_beta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * (ABI 12) The encoders' entry (csrc/conv_stem.hip): the small-channel k x k convolution whose input is the camera image (ResNet conv1: 3 -> 64
+ * channels, 7 x 7, stride 2, padding 3 - reference mode/models/perceptual_encoders/resnets.py:96 torchvision `resnet18`, pretrained_resnets.py:29 timm
+ * `resnet50`) and the max-pool behind it (`maxpool`, 3 x 3 / stride 2 / padding 1).  Replaces the last MIOpen / aten kernels of the encoders.
+ *   x        the image [N, Cin, H, W] addressed by ELEMENT strides (NCHW, channels_last, a slice ...), fp32 or bf16; fp32 is rounded to bf16
+ *            (nearest-even) as it is read, i.e. the result equals the convolution of x.to(bf16)
+ *   w        [Cout][kh][kw][Cin] bf16 = the channels_last storage of the [Cout, Cin, kh, kw] weight; Cout % 16 == 0, Cout <= 64, kh * kw * Cin <= 256
+ *   forward  y [N * ho * wo][Cout] bf16 (channels_last), fp32 accumulation; optional epilogue on the fp32 sums (inference): eval-mode BatchNorm
+ *            (bn_mean / bn_var both NULL or both [Cout]; bn_weight / bn_bias may be NULL = 1 / 0; folded as in mode_conv_bn_act_fwd) and ReLU
+ *   wgrad    dw_part [mode_stem_conv_wgrad_slabs()][Cout][kh][kw][Cin] fp32 partial sums, one slab per workgroup; dW = their sum in slab order
+ *            (dy [N * ho * wo][Cout] bf16).  There is no data gradient: nothing upstream of the image is trained.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ModeStemConvDesc {
+  const void* x; int32_t x_dtype;                  /* MODE_F32 | MODE_BF16 */
+  int64_t sxn, sxc, sxh, sxw;                      /* element strides of x */
+  int32_t N, H, W, Cin, kh, kw, sh, sw, ph, pw, Cout;
+  const void* w;
+  void* y;                                                            /* forward */
+  const float* bn_mean; const float* bn_var; const float* bn_weight; const float* bn_bias; float bn_eps; int32_t relu;
+  const void* dy; float* dw_part;                                     /* weight gradient */
+} ModeStemConvDesc;
+int mode_stem_conv_fwd(const ModeStemConvDesc* d, void* stream);
+int mode_stem_conv_wgrad_slabs(const ModeStemConvDesc* d);            /* number of partial slabs mode_stem_conv_wgrad writes (0: bad descriptor) */
+int mode_stem_conv_wgrad(const ModeStemConvDesc* d, void* stream);
+/* Max-pool k x k / stride s / padding pad (2 * pad <= k) on channels_last data [N][H][W][C] (C % 8 == 0; MODE_F32 | MODE_BF16) with aten's selection
+ * rule (a later element replaces the maximum iff it is greater or NaN).  argmax (may be NULL in inference) [N][ho][wo][C] uint8 = window position
+ * a * k + b of the selected element; the backward sums, per INPUT pixel, the dy of the windows that selected it (fp32 sum in ascending window
+ * order, no atomics). */
+int mode_maxpool_nhwc_fwd(const void* x, int dtype, int N, int H, int W, int C, int k, int s, int pad, void* y, uint8_t* argmax, void* stream);
+int mode_maxpool_nhwc_bwd(const void* dy, const uint8_t* argmax, int dtype, int N, int H, int W, int C, int k, int s, int pad, void* dx, void* stream);
 
 #ifdef __cplusplus
 }

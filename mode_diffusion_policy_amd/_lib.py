@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MODE_HIP_LIB", os.path.join(_HERE, "libmode_hip.so"))
 
 MODE_BF16, MODE_F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_RESIDUAL_NORM = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 11
+ABI_VERSION = 12
 GEMM_SKINNY_OK, GEMM_W_KN, GEMM_A_KM, GEMM_UNIFORM_GROUPS, GEMM_SMALL_ROWS, GEMM_IDENTITY_ROWS = 1, 2, 4, 8, 16, 32
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -145,6 +145,13 @@ class ModeBnFilmDesc(C.Structure):
                 ("bn_weight", c_vp), ("bn_bias", c_vp), ("bn_mean", c_vp), ("bn_var", c_vp), ("bn_eps", c_f32), ("channels_last", c_i32)]
 
 
+class ModeStemConvDesc(C.Structure):
+    _fields_ = [("x", c_vp), ("x_dtype", c_i32), ("sxn", c_i64), ("sxc", c_i64), ("sxh", c_i64), ("sxw", c_i64), ("N", c_i32), ("H", c_i32), ("W", c_i32),
+                ("Cin", c_i32), ("kh", c_i32), ("kw", c_i32), ("sh", c_i32), ("sw", c_i32), ("ph", c_i32), ("pw", c_i32), ("Cout", c_i32), ("w", c_vp),
+                ("y", c_vp), ("bn_mean", c_vp), ("bn_var", c_vp), ("bn_weight", c_vp), ("bn_bias", c_vp), ("bn_eps", c_f32), ("relu", c_i32), ("dy", c_vp),
+                ("dw_part", c_vp)]
+
+
 P = C.POINTER
 # name -> (restype, argtypes): every symbol include/mode_hip.h declares
 PROTOTYPES = {
@@ -223,6 +230,11 @@ PROTOTYPES = {
                                   c_vp]),
     "mode_bn_prepare_partials": (C.c_int, [c_vp, c_vp, c_i32, C.c_double, c_i32, c_vp, c_vp, C.c_float, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mode_bn_film_act_bwd": (C.c_int, [P(ModeBnFilmDesc), c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mode_stem_conv_fwd": (C.c_int, [P(ModeStemConvDesc), c_vp]),
+    "mode_stem_conv_wgrad_slabs": (C.c_int, [P(ModeStemConvDesc)]),
+    "mode_stem_conv_wgrad": (C.c_int, [P(ModeStemConvDesc), c_vp]),
+    "mode_maxpool_nhwc_fwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "mode_maxpool_nhwc_bwd": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -99,7 +99,7 @@ extern "C" size_t mode_hip_sizeof(const char* n) {
   MODE_SZ(ModeGemmDesc) MODE_SZ(ModeEmbedDesc) MODE_SZ(ModeHeadDesc) MODE_SZ(ModeGroupedMlpDesc) MODE_SZ(ModeDims) MODE_SZ(ModeLayerWeights)
   MODE_SZ(ModeModelWeights) MODE_SZ(ModeMetaLayout) MODE_SZ(ModeForwardArgs) MODE_SZ(ModeStashLayout) MODE_SZ(ModeTrainArgs) MODE_SZ(ModeLayerGrads)
   MODE_SZ(ModeModelGrads) MODE_SZ(ModeLayerWeightsT) MODE_SZ(ModeModelWeightsT) MODE_SZ(ModeBnFilmDesc) MODE_SZ(ModeQkvAttnDesc) MODE_SZ(ModeConvBnDesc)
-  MODE_SZ(ModeAdamWFuse)
+  MODE_SZ(ModeAdamWFuse) MODE_SZ(ModeStemConvDesc)
 #undef MODE_SZ
   return 0;
 }

@@ -10,8 +10,9 @@ Same constructor arguments, forward signatures and ``state_dict`` keys (``resnet
 trunks are built here from ``nn.Conv2d`` / ``nn.BatchNorm2d`` holders (neither ``timm`` nor ``torchvision`` is needed at run time —
 ``pretrained=True`` therefore means "load a checkpoint": there is no network on the box).
 
-Compute: convolutions run on the library's GEMM / implicit-GEMM kernels in bf16 on channels_last data (``_ConvFn`` below; fp32 and the 3-channel stem go
-through ``torch.nn.functional.conv2d`` = MIOpen - SURVEY: "convs via MIOpen first" was round 3); everything BETWEEN two
+Compute: convolutions run on the library's GEMM / implicit-GEMM kernels in bf16 on channels_last data (``_ConvFn`` below; the 3-channel stem and the
+max-pool on csrc/conv_stem.hip, ``stem_conv_bn_pool``; an fp32 compute dtype goes through ``torch.nn.functional.conv2d`` = MIOpen - SURVEY: "convs via MIOpen
+first" was round 3); everything BETWEEN two
 convolutions — BatchNorm (eval or training statistics), the FiLM modulations, the residual add and the ReLU — is ONE hand-written HIP pass over
 the activation (``mode_bn_film_act_fwd``; the reference launches 3-6 elementwise kernels there), with a HIP backward
 (``mode_bn_film_act_bwd``: one reduction pass + one dx pass, deterministic) behind ``torch.autograd`` so the encoders train through the
@@ -240,7 +241,7 @@ def _compute_dtype(x: torch.Tensor) -> torch.dtype:
 #                      K = pixels cut into groups (fp32 partial sums added in group order: deterministic)
 #   k x k / strided    forward and data gradient as implicit GEMM (csrc/conv_gemm.hip: `a_rows` in taps - the A tile of a K-step is gathered from the rows its
 #                      filter tap pairs with the output pixels, -1 = outside the image), weight gradient as ONE product over the taps (`w_rows` in taps)
-#   3-channel stem     stays with MIOpen (Cin % 64 != 0)
+#   3-channel stem     csrc/conv_stem.hip (`stem_conv_bn_pool` below): the im2col tile of 8 x 16 output pixels is built on chip from the image as it lies
 # `_ConvFn` hands autograd fp32 weight gradients directly and reads a compute-dtype SHADOW of the weight that is refreshed when the parameter's version moves (all
 # stale shadows of an encoder in one `_foreach_copy_`).  Inference takes the same forward kernels, and `conv_bn_act` folds the eval-mode BatchNorm / FiLM / residual
 # / ReLU into the convolution's epilogue (mode_conv_bn_act_fwd).  MODE_ENC_HIPCONV=0 restores F.conv2d with per-call casts everywhere (A/B runs).
@@ -667,6 +668,126 @@ def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, x, relu: bool = True, resid
     return bn_film_act(_conv2d(conv, x), bn, relu=relu, residual=residual, pre_film=pre_film, post_film=post_film)
 
 
+# ---- the encoders' entry on the library's kernels (round 5, csrc/conv_stem.hip, ABI 12): conv1 (3 -> 64 channels, 7 x 7 / 2: too few channels for the implicit-GEMM
+# path, MIOpen until now) gathers its im2col tile from the image as it lies (fp32 NCHW: the bf16 rounding and the layout change happen in the gather), the max-pool
+# keeps window positions for a gather-form backward.  With them no MIOpen / aten compute kernel is left in the encoders.  MODE_ENC_HIPSTEM=0: F.conv2d / F.max_pool2d.
+USE_HIP_STEM = __import__("os").environ.get("MODE_ENC_HIPSTEM", "1") == "1"
+_DT = {torch.float32: L.MODE_F32, torch.bfloat16: L.MODE_BF16}
+
+
+def _stem_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
+    w = conv.weight
+    return (USE_HIP_STEM and x.is_cuda and x.dim() == 4 and x.dtype in _DT and _compute_dtype(x) == torch.bfloat16 and conv.groups == 1 and conv.dilation == (1, 1)
+            and conv.bias is None and isinstance(conv.padding, tuple) and w.shape[1] % 64 != 0 and w.shape[0] % 16 == 0 and w.shape[0] <= 64
+            and w.shape[1] * w.shape[2] * w.shape[3] <= 256 and x.shape[1] == w.shape[1]
+            and (7 * conv.stride[0] + w.shape[2]) * (15 * conv.stride[1] + w.shape[3]) * w.shape[1] <= 8192)      # the input patch of an 8 x 16-pixel tile is staged on chip
+
+
+def _stem_desc(x: torch.Tensor, w_lp: torch.Tensor, stride, padding, **kw):
+    n, cin, H, W_ = x.shape
+    cout, _, kh_, kw_ = w_lp.shape
+    return L.ModeStemConvDesc(x=x.data_ptr(), x_dtype=_DT[x.dtype], sxn=x.stride(0), sxc=x.stride(1), sxh=x.stride(2), sxw=x.stride(3), N=n, H=H, W=W_, Cin=cin,
+                              kh=kh_, kw=kw_, sh=stride[0], sw=stride[1], ph=padding[0], pw=padding[1], Cout=cout, w=w_lp.data_ptr(), **kw)
+
+
+def _stem_fwd(x: torch.Tensor, w_lp: torch.Tensor, stride, padding, bn: Optional[nn.BatchNorm2d] = None, relu: bool = False) -> torch.Tensor:
+    """conv2d(x.to(bf16), w_lp) as channels_last bf16 (one launch; `bn`: + eval-mode BatchNorm on the fp32 sums, `relu`)."""
+    assert w_lp.dtype == torch.bfloat16 and w_lp.is_contiguous(memory_format=torch.channels_last)
+    n, _, H, W_ = x.shape
+    cout, _, kh_, kw_ = w_lp.shape
+    ho = (H + 2 * padding[0] - kh_) // stride[0] + 1; wo = (W_ + 2 * padding[1] - kw_) // stride[1] + 1
+    y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    ep = {} if bn is None else dict(bn_mean=_ptr(bn.running_mean), bn_var=_ptr(bn.running_var), bn_weight=_ptr(bn.weight), bn_bias=_ptr(bn.bias), bn_eps=bn.eps)
+    d = _stem_desc(x, w_lp, stride, padding, y=y.data_ptr(), relu=int(relu), **ep)
+    L.check(L.load().mode_stem_conv_fwd(C.byref(d), _stream()), "stem convolution forward")
+    return y
+
+
+class _StemConvFn(torch.autograd.Function):
+    """y = conv2d(image, w) for the small-channel stem; differentiable in the fp32 PARAMETER w (the image needs no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w, w_lp, stride, padding):
+        ctx.save_for_backward(x, w_lp)
+        ctx.conf = (tuple(stride), tuple(padding), w.dtype)
+        return _stem_fwd(x, w_lp, stride, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_lp = ctx.saved_tensors
+        stride, padding, wdtype = ctx.conf
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            cout, cin, kh_, kw_ = w_lp.shape
+            dyc = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            d = _stem_desc(x, w_lp, stride, padding, dy=dyc.data_ptr())
+            lib = L.load()
+            slabs = lib.mode_stem_conv_wgrad_slabs(C.byref(d))
+            part = torch.empty((slabs, cout, kh_, kw_, cin), dtype=torch.float32, device=dy.device)      # channels_last order of [Cout, Cin, kh, kw]
+            d.dw_part = part.data_ptr()
+            L.check(lib.mode_stem_conv_wgrad(C.byref(d), _stream()), "stem convolution weight gradient")
+            dw = (part.sum(0) if slabs > 1 else part[0]).permute(0, 3, 1, 2).to(wdtype)
+        if ctx.needs_input_grad[0]:                                  # (not a path the encoders take: the input is the camera image)
+            dx = torch.ops.aten.convolution_backward(dy, x.to(dy.dtype), w_lp.to(dy.dtype), None, stride, padding, (1, 1), False, (0, 0), 1, (True, False, False))[0]
+        return dx, dw, None, None, None
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        n, c, H, W_ = x.shape
+        ho = (H + 2 * p - k) // s + 1; wo = (W_ + 2 * p - k) // s + 1
+        y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        arg = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device) if ctx.needs_input_grad[0] else None     # window positions only when a backward will follow
+        L.check(L.load().mode_maxpool_nhwc_fwd(x.data_ptr(), _DT[x.dtype], n, H, W_, c, k, s, p, y.data_ptr(), _ptr(arg), _stream()), "max-pool forward")
+        ctx.conf = (k, s, p, tuple(x.shape))
+        if arg is not None:
+            ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        k, s, p, (n, c, H, W_) = ctx.conf
+        dyc = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty((n, c, H, W_), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        L.check(L.load().mode_maxpool_nhwc_bwd(dyc.data_ptr(), arg.data_ptr(), _DT[dy.dtype], n, H, W_, c, k, s, p, dx.data_ptr(), _stream()), "max-pool backward")
+        return dx, None, None, None
+
+
+def max_pool(x: torch.Tensor, k: int = 3, s: int = 2, p: int = 1) -> torch.Tensor:
+    """F.max_pool2d(x, k, s, p) on channels_last activations through the library (forward + gather-form backward)."""
+    if (USE_HIP_STEM and x.is_cuda and x.dim() == 4 and x.dtype in _DT and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last)
+            and 2 * p <= k <= 15 and x.shape[2] + 2 * p >= k and x.shape[3] + 2 * p >= k):
+        return _MaxPoolFn.apply(x, k, s, p)
+    return F.max_pool2d(x, k, s, p)
+
+
+def stem_conv_bn_pool(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> torch.Tensor:
+    """``max_pool2d(relu(bn(conv(x))), 3, 2, 1)`` - the trunk's entry (timm / torchvision ResNet: conv1, bn1, act1 / relu, maxpool)."""
+    if not _stem_ok(conv, x):
+        return max_pool(bn_film_act(_conv2d(conv, _to_layout(x)), bn, relu=True))
+    w = conv.weight
+    if not w.is_contiguous(memory_format=torch.channels_last):
+        with torch.no_grad():
+            w.data = w.data.contiguous(memory_format=torch.channels_last)
+    w_lp = None
+    if _W_OVERRIDE is not None:
+        hit = _W_OVERRIDE.get(id(conv))
+        if hit is not None and hit.dtype == torch.bfloat16 and hit.is_contiguous(memory_format=torch.channels_last):
+            w_lp = hit
+    train = torch.is_grad_enabled() and (w.requires_grad or x.requires_grad)
+    if w_lp is None:
+        w_lp = _shadow(conv, torch.bfloat16)
+    if train:
+        y = bn_film_act(_StemConvFn.apply(x, w, w_lp, conv.stride, conv.padding), bn, relu=True)
+    elif FUSE_CONV_BN and not bn.training and bn.running_mean is not None:
+        y = _stem_fwd(x, w_lp, conv.stride, conv.padding, bn=bn, relu=True)          # inference: convolution + BatchNorm + ReLU in one launch
+    else:
+        y = bn_film_act(_stem_fwd(x, w_lp, conv.stride, conv.padding), bn, relu=True)
+    return max_pool(y)
+
+
 # ------------------------------------------------------------------------------------------------------------------ trunk (parameter holders)
 class _Block(nn.Module):
     """BasicBlock (expansion 1) / Bottleneck (expansion 4) holder with the timm / torchvision attribute names."""
@@ -726,8 +847,7 @@ class _Trunk(nn.Module):
         _store_channels_last(self)
 
     def stem(self, x):
-        x = bn_film_act(_conv2d(self.conv1, _to_layout(x)), self.bn1, relu=True)
-        return F.max_pool2d(x, 3, 2, 1)
+        return stem_conv_bn_pool(self.conv1, self.bn1, x)
 
 
 # ---- the encoders' small Linears (FiLM gamma / beta, FilmModule, fc) on the library's fp32 MFMA GEMM instead of hipBLASLt: y = x W^T + b, dx = dy W, dW = dy^T x from
@@ -871,8 +991,7 @@ class ResNetEncoderWithFiLM(nn.Module):
                 conditioning_vector = torch.cat([conditioning_vector for _ in range(t_steps)], dim=0)     # the reference's order (resnets.py:129)
         if USE_HIP_CONV_WGRAD and x.is_cuda and torch.is_grad_enabled() and _compute_dtype(x) == torch.bfloat16:
             refresh_conv_shadows(self, torch.bfloat16, force=True)
-        x = bn_film_act(_conv2d(self.conv1, _to_layout(x)), self.bn1, relu=True)
-        x = F.max_pool2d(x, 3, 2, 1)
+        x = stem_conv_bn_pool(self.conv1, self.bn1, x)
         for i in range(1, 5):
             mods = getattr(self, f"film_module{i}")(conditioning_vector.to(torch.float32)) if conditioning_vector is not None else (None, None)
             for j, blk in enumerate(getattr(self, f"layer{i}")):
