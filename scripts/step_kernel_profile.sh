@@ -25,8 +25,17 @@ with open(f"gpurun_out/step_{mode}_seq.txt", "w") as out:
         a = agg.setdefault(r["Kernel_Name"][:160], [0, 0.0]); a[0] += 1; a[1] += (e - s) / 1e3
     out.write(f"step span {span:.1f} us, {hi - lo} kernels\n")
 tot = sum(v[1] for v in agg.values())
+busy = 0; cur_s = cur_e = None                                # union of the kernel intervals = time at least one kernel is on the device
+for r in rows[lo:hi]:
+    s = int(r["Start_Timestamp"]); e = int(r["End_Timestamp"])
+    if cur_e is None or s > cur_e:
+        busy += (cur_e - cur_s) if cur_e is not None else 0
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy = (busy + (cur_e - cur_s)) / 1e3
 with open(f"gpurun_out/step_{mode}_stats.txt", "w") as out:
-    out.write(f"one steady-state step of bench.py --mode {mode}: span {span:.1f} us, {hi - lo} kernels, kernel time {tot:.1f} us (queues overlap)\n")
+    out.write(f"one steady-state step of bench.py --mode {mode}: span {span:.1f} us, {hi - lo} kernels, kernel time {tot:.1f} us (queues overlap), device busy {busy:.1f} us = {100 * busy / span:.0f}% of the span\n")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         out.write(f"{v[1]:10.1f} us {100 * v[1] / span:5.1f}% {v[0]:5d} x  {k}\n")
 PY
