@@ -63,7 +63,8 @@ const char* mode_hip_status_string(int status);
  *   18 = the same kernel with 256-row tiles (epilogues NONE / BIAS; the heuristic takes it for RAGGED expert segments whose expected tiles fill whole
  *   rounds of the part: the training forward's up-projection).  A forced geometry that does not take a shape falls back to the heuristic's choice.
  *   Every forward geometry produces bit-identical results (k-ordered fp32 MFMA chain, explicit-fma epilogues).
- * "gemm_pp": 1 (default) = the heuristic may pick geometries 17 / 18; "gemm_pp_min_tiles": tile count from which it does (default 200).
+ * "gemm_pp": 1 (default) = the heuristic may pick geometries 17 / 18; "gemm_pp_min_tiles": tile count from which it does (default 200);
+ * "gemm_pp_min_tiles_up": the same for the SwiGLU epilogue, i.e. the expert up-projection (default 190: 10-step chunk at B = 44 / 48 10.8 / 11.3 -> 10.5 / 10.9 ms).
  * "gemm_group_m": m-tiles per XCD rasterisation group of the ring kernels (0 = default).
  * "gemm_tr_cfg": backward (transpose-read) GEMM geometry, 0 = auto, 1 = 128-wide ring-2, 2 = 64-wide ring-3, 3 = 128-wide ring-3,
  *   4 = 64-wide ring-2, 5 = 128-wide single-buffered, 6 = the persistent ping-pong kernel of gemm_bf16_pptr.hip (256 x 256 tiles, one workgroup per CU) for

@@ -411,6 +411,7 @@ int g_gemm_mid_rows = 128;   // "gemm_mid_rows" option: ungrouped K = 1024 GEMMs
 int g_gemm_cfg = CFG_AUTO;
 int g_gemm_skinny_rows = 32;   // measured (scripts/rollout_batch_probe.py): chunk latency B=1 9.4 -> 7.35 ms, B=2 8.7 -> 8.3 ms; from ~3 environments on the tiled kernel (64x64 tiles) is as fast or faster
 int g_gemm_pp_min_tiles = 200;   // "gemm_pp_min_tiles" option
+int g_gemm_pp_min_tiles_up = 190;   // "gemm_pp_min_tiles_up" option: the threshold for the SwiGLU epilogue (the expert up-projection): 192 tiles (B = 41 .. 48) already pay, 160 do not
 int g_gemm_pp = 1;        // "gemm_pp" option: 1 = large problems go to the persistent ping-pong kernel (gemm_bf16_pp.hip), 0 = 128x128 family only
 int g_gemm_group_m = 0;   // "gemm_group_m" option: m-tiles per rasterisation group (0 = default 8; >= m_tiles = n-major partition over the XCDs)
 
@@ -462,7 +463,7 @@ static int pick_cfg(const ModeGemmDesc* d, bool allow_pp) {
       (d->epilogue == MODE_EPI_SWIGLU || d->epilogue == MODE_EPI_NONE || d->epilogue == MODE_EPI_BIAS)) {
     const int nout = d->epilogue == MODE_EPI_SWIGLU ? 128 : 256;
     const long tpp = ((rows + 223) / 224) * (d->N / nout) * (d->split_k > 1 ? d->split_k : 1);
-    if (d->N % nout == 0 && tpp >= g_gemm_pp_min_tiles) return CFG_PP224;
+    if (d->N % nout == 0 && tpp >= (d->epilogue == MODE_EPI_SWIGLU ? g_gemm_pp_min_tiles_up : g_gemm_pp_min_tiles)) return CFG_PP224;
   }
   // RAGGED expert segments (device-side offsets, no uniformity promise: the training forward's per-token multinomial routing): 224-row tiles leave half
   // of the experts with a nearly empty fifth tile (measured equal to the ring kernels, scripts/ragged_pp_probe.py), 256-row tiles cover the same rows in
