@@ -59,12 +59,15 @@ const char* mode_hip_status_string(int status);
  * that changes results (the round-2 timing ablations and cycle-stamp buffers of the GEMM kernels were removed from the product).
  * "gemm_cfg": bf16 forward GEMM tile geometry, 0 = auto (default), 1 = 128x128 ring-2, 4 = 128x64 ring-3, 6 = 128x128 single-buffered
  *   (3 workgroups/CU), 8 = 128x64 ring-2, 13 = 128x128 single-buffered with <= 128 VGPRs (4 workgroups/CU), 14 = 64x64 ring-3 (no SwiGLU),
+ *   20 = 128x128 ring-3 (one workgroup per CU; NONE epilogue only),
  *   17 = persistent ping-pong kernel with 224-row x 256-column tiles (gemm_bf16_pp.hip; epilogues NONE / BIAS / SWIGLU).
  *   18 = the same kernel with 256-row tiles (epilogues NONE / BIAS; the heuristic takes it for RAGGED expert segments whose expected tiles fill whole
  *   rounds of the part: the training forward's up-projection).  A forced geometry that does not take a shape falls back to the heuristic's choice.
  *   Every forward geometry produces bit-identical results (k-ordered fp32 MFMA chain, explicit-fma epilogues).
  * "gemm_pp": 1 (default) = the heuristic may pick geometries 17 / 18; "gemm_pp_min_tiles": tile count from which it does (default 200);
  * "gemm_pp_min_tiles_up": the same for the SwiGLU epilogue, i.e. the expert up-projection (default 190: 10-step chunk at B = 44 / 48 10.8 / 11.3 -> 10.5 / 10.9 ms).
+ * "gemm_dn_ring3": 1 (default) = a K-sliced GEMM that fills one round of the part with 128x128 tiles (160 .. 288 workgroups) takes them on a 3-slot ring
+ *   (geometry 20) instead of twice as many 128x64 tiles; bit-identical.
  * "gemm_group_m": m-tiles per XCD rasterisation group of the ring kernels (0 = default).
  * "gemm_tr_cfg": backward (transpose-read) GEMM geometry, 0 = auto, 1 = 128-wide ring-2, 2 = 64-wide ring-3, 3 = 128-wide ring-3,
  *   4 = 64-wide ring-2, 5 = 128-wide single-buffered, 6 = the persistent ping-pong kernel of gemm_bf16_pptr.hip (256 x 256 tiles, one workgroup per CU) for

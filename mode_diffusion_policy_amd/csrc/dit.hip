@@ -20,6 +20,7 @@ extern int g_gemm_cfg;
 extern int g_gemm_pp;
 extern int g_gemm_pp_min_tiles;
 extern int g_gemm_pp_min_tiles_up;
+extern int g_gemm_dn_ring3;
 extern int g_fuse_qkv_attn, g_fuse_qkv_attn_min_b, g_qkv_attn_w3, g_qkv_attn_waves;   // qkv_attn.hip
 extern int g_combine_row_max;
 extern int g_gemm_mid_rows;
@@ -121,6 +122,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_pp")) { g_gemm_pp = value != 0; return MODE_OK; }
   if (!strcmp(key, "gemm_pp_min_tiles")) { g_gemm_pp_min_tiles = value; return MODE_OK; }
   if (!strcmp(key, "gemm_pp_min_tiles_up")) { g_gemm_pp_min_tiles_up = value; return MODE_OK; }
+  if (!strcmp(key, "gemm_dn_ring3")) { g_gemm_dn_ring3 = value != 0; return MODE_OK; }
   if (!strcmp(key, "gemm_tr_cfg")) { g_tr_cfg = value; return MODE_OK; }
   if (!strcmp(key, "bwd_coexec")) { g_bwd_coexec = value != 0; return MODE_OK; }
   if (!strcmp(key, "fuse_swiglu_bwd")) { g_fuse_swiglu_bwd = value != 0; return MODE_OK; }

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 16 ? 1 : (LR ? LR : (NS ==
 // (ids 2, 3, 5, 7, 9-12, 15 were measured-and-rejected geometries of round 1 - deeper rings, 256-wide one-barrier tiles, a persistent 256x256 kernel with
 // a serial epilogue - removed once the ping-pong kernel superseded them; the numbers stay in LABNOTES.md)
 enum { CFG_AUTO = 0, CFG_128x128_NS2 = 1, CFG_128x64_NS3 = 4, CFG_128x128_NS1 = 6, CFG_128x64_NS2 = 8, CFG_128x128_NS1_4WG = 13, CFG_64x64_NS3 = 14,
-       CFG_PP224 = 17, CFG_PP256 = 18 };
+       CFG_PP224 = 17, CFG_PP256 = 18, CFG_128x128_NS3 = 20 };
 int gemm_bf16_pp_launch(const ModeGemmDesc* d, const GemmParams& p, int rows256, hipStream_t s);   // gemm_bf16_pp.hip: persistent ping-pong kernel, 224 / 256 x 256 tiles
 int pp_num_cus();                                                                                   // gemm_bf16_pp.hip: compute units of the current device (= its grid)
 int gemm_bf16_skinny_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t s);   // gemm_bf16_skinny.hip: weight streamer for a handful of rows
@@ -409,6 +409,7 @@ int gemm_bf16_mid_launch(const ModeGemmDesc* d, const GemmParams& p, hipStream_t
 int g_gemm_mid_rows_rn = 512;   // "gemm_mid_rows_rn" option: the same kernel for the c_proj (+ residual + first half of ln_2) GEMM, whose [D, D] weight is small enough to be re-read by every 32-row block (rollout batches up to 36 environments)
 int g_gemm_mid_rows = 128;   // "gemm_mid_rows" option: ungrouped K = 1024 GEMMs with at most this many rows take gemm_bf16_mid_kernel (0 = off).  Measured chunk latency B = 4: 6.89 -> 6.60 ms, B = 8: 7.40 -> 7.14 ms; from ~200 rows on the M/32 re-reads of W through L2 cost more than the ring kernel (B = 16: 8.41 -> 8.50 ms, B = 32: 9.21 -> 9.48 ms)
 int g_gemm_cfg = CFG_AUTO;
+int g_gemm_dn_ring3 = 1;   // "gemm_dn_ring3" option: 1 = a K-sliced GEMM whose 128x128 tiles x slices fill ONE round of the part (160 .. 288 workgroups: the expert down-projection of 17 .. 36 environments) takes 128x128 tiles on a 3-slot ring, one workgroup per CU, instead of twice as many 128x64 tiles (a third less L2 -> LDS traffic; 10-step chunk B = 24: 8.29 -> 8.11 ms, B = 32: 8.90 -> 8.73 ms).  Also tried there for the up-projection: 128x256 tiles on a 3-slot ring, one 8-wave workgroup per CU - 8.93 vs 8.90 ms, removed
 int g_gemm_skinny_rows = 32;   // measured (scripts/rollout_batch_probe.py): chunk latency B=1 9.4 -> 7.35 ms, B=2 8.7 -> 8.3 ms; from ~3 environments on the tiled kernel (64x64 tiles) is as fast or faster
 int g_gemm_pp_min_tiles = 200;   // "gemm_pp_min_tiles" option
 int g_gemm_pp_min_tiles_up = 190;   // "gemm_pp_min_tiles_up" option: the threshold for the SwiGLU epilogue (the expert up-projection): 192 tiles (B = 41 .. 48) already pay, 160 do not
@@ -443,6 +444,8 @@ static int launch_epi(const GemmParams& p, const ModeGemmDesc* d, int cfg, hipSt
     case CFG_128x128_NS1_4WG: return launch_cfg<128, 128, 2, 2, 1, EPI, OUT_BF16, 4>(p, d, s);   // <= 128 VGPRs: four 32-KiB workgroups per CU
     case CFG_64x64_NS3:
       if constexpr (EPI == MODE_EPI_SWIGLU) return MODE_ERR_UNSUPPORTED; else return launch_cfg<64, 64, 2, 2, 3, EPI, OUT_BF16>(p, d, s);
+    case CFG_128x128_NS3:
+      if constexpr (EPI == MODE_EPI_NONE) return launch_cfg<128, 128, 2, 2, 3, EPI, OUT_BF16, 1>(p, d, s); else return MODE_ERR_UNSUPPORTED;
     default: return MODE_ERR_BAD_ARG;
   }
 }
@@ -480,6 +483,7 @@ static int pick_cfg(const ModeGemmDesc* d, bool allow_pp) {
   }
   const int nout128 = (d->epilogue == MODE_EPI_SWIGLU) ? 64 : 128;
   const long t128 = ((rows + 127) / 128) * ((d->N + nout128 - 1) / nout128);
+  if (g_gemm_dn_ring3 && d->split_k > 1 && d->epilogue == MODE_EPI_NONE && t128 * d->split_k >= 160 && t128 * d->split_k <= 256 + 32) return CFG_128x128_NS3;
   const long t64 = ((rows + 127) / 128) * ((d->N + 63) / 64);
   if (d->split_k > 1) {   // split-K (down-projection, dit.hip down_proj_split): slices are extra workgroups
     if (t128 * d->split_k >= 448) return CFG_128x128_NS2;

@@ -35,7 +35,7 @@ def test_header_symbols_all_exported():
     assert lib.mode_hip_status_string(-2).decode().startswith("unsupported")
     assert lib.mode_set_option(b"gemm_cfg", 0) == 0 and lib.mode_set_option(b"nope", 1) == -2
     for key, default, bad in ((b"dn_split_k", 0, 9), (b"gemm_skinny_rows", 32, -1), (b"fuse_ln2", 1, None), (b"adamw_blocks", 0, None),
-                              (b"combine_row_max", 0x7fffffff, -1), (b"gemm_pp", 1, None), (b"gemm_pp_min_tiles", 200, None),
+                              (b"combine_row_max", 0x7fffffff, -1), (b"gemm_pp", 1, None), (b"gemm_pp_min_tiles", 200, None), (b"gemm_pp_min_tiles_up", 190, None), (b"gemm_dn_ring3", 1, None),
                               (b"gemm_group_m", 0, None), (b"gemm_tr_cfg", 0, None), (b"gemm_mid_rows", 128, -1),
                               (b"fuse_qkv_attn", 1, None), (b"fuse_qkv_attn_min_b", 56, -1), (b"qkv_attn_w3", 1, None), (b"qkv_attn_waves", 8, 5)):
         assert lib.mode_set_option(key, default) == 0, key                                  # documented knobs exist (include/mode_hip.h)

@@ -135,7 +135,34 @@ def _grouped_gather_gemm(dtype, N_tok, E, k, D):
     assert rel(hh.float(), href) < (5e-3 if dtype == torch.bfloat16 else 1e-6)
 
 
-@pytest.mark.parametrize("cfg", [0, 4, 17, 18])
+@pytest.mark.parametrize("rows_per_expert", [448, 336, 500])
+def test_one_round_down_projection_geometry_is_bit_identical(rows_per_expert):
+    """The K-sliced, grouped expert down-projection of 17 .. 36 environments (two active experts, 4 slices of K = 4096) fills ONE round of the part with
+    128 x 128 tiles and takes them on a 3-slot ring (geometry 20, "gemm_dn_ring3"): same k-ordered fp32 chain as the 128 x 64 tiles it replaces -
+    bit-identical slabs (a sample's result must not depend on the batch it shares), correct against fp64."""
+    import ctypes as C
+    E, D, S = 2, 1024, 4
+    NK = E * rows_per_expert
+    hid = rnd(NK, 4 * D, seed=31).to(torch.bfloat16).to(dev()); W2 = rnd(E, D, 4 * D, seed=32, scale=(4 * D) ** -0.5).to(torch.bfloat16).to(dev())
+    offs = torch.tensor([0, rows_per_expert, NK], dtype=torch.int32, device=dev())
+    lib = L.load(); out = {}
+    for tag, opt in (("ring3", 1), ("tiles64", 0)):
+        lib.mode_set_option(b"gemm_dn_ring3", opt)
+        try:
+            Y = torch.full((S, NK, D), float("nan"), dtype=torch.bfloat16, device=dev())
+            d = L.ModeGemmDesc(dtype=L.MODE_BF16, epilogue=L.EPI_NONE, out_dtype=L.MODE_BF16, M=NK, N=D, K=4 * D, A=hid.data_ptr(), lda=4 * D, W=W2.data_ptr(),
+                               ldw=4 * D, w_expert_stride=4 * D * D, C=Y.data_ptr(), ldc=D, expert_offsets=offs.data_ptr(), num_experts=E, split_k=S,
+                               split_stride=NK * D)
+            L.check(lib.mode_gemm(C.byref(d), H.stream()))
+            out[tag] = Y
+        finally:
+            lib.mode_set_option(b"gemm_dn_ring3", 1)
+    assert torch.equal(out["ring3"], out["tiles64"])
+    want = torch.cat([hid[e * rows_per_expert:(e + 1) * rows_per_expert].double().cpu() @ W2[e].double().cpu().t() for e in range(E)])
+    assert rel(out["ring3"].float().sum(0), want.float()) < 6e-3
+
+
+@pytest.mark.parametrize("cfg", [0, 4, 17, 18, 20])
 @pytest.mark.parametrize("S", [2, 4])
 def test_gemm_bf16_split_k(cfg, S):
     """split-K: slice z writes its partial sums to slab z; the slabs add up to the un-split product."""
