@@ -355,7 +355,7 @@ int mode_embed_tokens_fwd(const ModeEmbedDesc* d, void* stream);
  * tokens only:  F = Linear(D, A)(RMSNorm(u + sum_j w Y))  (modedit.py:807-808, 818);
  *   denoised = F * c_out + x_a * c_skip (score_wrappers.py:79-80);  x_next = r * x_a + (1 - r) * denoised,
  *   r = sigma_next / sigma (gc_sampling.py:948-950).
- * scal: fp32 [B or 1][4] = {c_skip, c_out, r, unused}; scal == NULL => write F only (training / raw forward).
+ * scal: fp32 [B or 1][4] = {c_skip, c_out, r, c (multistep weight, see den_prev; 0 for DDIM)}; scal == NULL => write F only (training / raw forward).
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct ModeHeadDesc {
   int32_t B, T, D, A_len, A_dim, k;
@@ -369,6 +369,11 @@ typedef struct ModeHeadDesc {
   float* denoised;                             /* may be NULL */
   float* x_next;                               /* may be NULL; may alias x_a */
   const float* u_ss; int32_t u_ss_n; const float* u_gain;   /* fused ln_2: u is un-normalised, see mode_moe_combine_norm_fused_fwd (NULL = u as is) */
+  /* ABI 12.  Two-point multistep update (DPM-Solver++(2M), gc_sampling.py:700-734): with den_prev != NULL and c = scal[3] != 0 the update uses
+   * denoised_d = (1 + c) * denoised - c * den_prev instead of denoised, c = 1 / (2 r), r = h_last / h; x_next = r_sigma * x_a + (1 - r_sigma) * denoised_d is
+   * the same exponential-integrator step as DDIM's.  den_prev = the `denoised` output of the previous step (the caller ping-pongs two buffers).
+   * NULL (or c == 0: the first step, the step to sigma = 0) = the DDIM update, bit for bit. */
+  const float* den_prev;
 } ModeHeadDesc;
 int mode_head_ddim_fwd(const ModeHeadDesc* d, void* stream);
 
@@ -595,6 +600,7 @@ typedef struct ModeForwardArgs {
    * MODE_GEMM_UNIFORM_GROUPS | MODE_GEMM_IDENTITY_ROWS to the expert GEMMs (gather indices computed, not loaded).  0 = no promise (always
    * correct).  It is NOT inferred from cond_row_stride: a shared conditioning row with per-sample routing is a legal call. */
   int32_t uniform_routing;
+  const float* den_prev;                             /* ABI 12: ModeHeadDesc.den_prev of the chain's head (two-point multistep samplers); NULL = none */
 } ModeForwardArgs;
 int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w, const ModeForwardArgs* a,
                      void* workspace, size_t workspace_bytes, void* stream);

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
   const long oidx = (long)ar * h.A_dim + lane;
   const float bo = act_lane ? h.b_out[lane] : 0.f;
   const float* scp = h.scal ? h.scal + (long)b * h.scal_stride : nullptr;
-  const float sc0 = scp ? scp[0] : 0.f, sc1 = scp ? scp[1] : 0.f, sc2 = scp ? scp[2] : 0.f;
+  const float sc0 = scp ? scp[0] : 0.f, sc1 = scp ? scp[1] : 0.f, sc2 = scp ? scp[2] : 0.f, sc3 = (scp && h.den_prev) ? scp[3] : 0.f;
   const float xa = (scp && act_lane) ? h.x_a[oidx] : 0.f;
   float ssq = 0.f;
   for_chunks<NCH>(D, lane, [&](int d) {
@@ -451,7 +451,9 @@ __global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
     if (scp) {
       const float den = F * sc1 + xa * sc0;               // F*c_out + x*c_skip      (score_wrappers.py:79-80)
       if (h.denoised) h.denoised[oidx] = den;
-      if (h.x_next) h.x_next[oidx] = sc2 * xa + (1.0f - sc2) * den;   // r*x + (1-r)*denoised (gc_sampling.py:948-950)
+      float dd = den;                                     // two-point multistep (DPM-Solver++(2M), gc_sampling.py:724-727): (1 + 1/(2r)) D - (1/(2r)) D_old
+      if (h.den_prev && sc3 != 0.0f) dd = (1.0f + sc3) * den - sc3 * h.den_prev[oidx];
+      if (h.x_next) h.x_next[oidx] = sc2 * xa + (1.0f - sc2) * dd;    // r*x + (1-r)*denoised (gc_sampling.py:948-950)
     }
   }
 }
@@ -733,7 +735,7 @@ __global__ __launch_bounds__(256) void head_ddim_row_kernel(const ModeHeadDesc h
   const float bo = h.b_out[jo];
   const bool has_sc = h.scal != nullptr;
   const float* scp = has_sc ? h.scal + (long)b * h.scal_stride : h.b_out;   // (never used when !has_sc)
-  const float sc0 = scp[0], sc1 = has_sc ? scp[1] : 0.f, sc2 = has_sc ? scp[2] : 0.f;
+  const float sc0 = scp[0], sc1 = has_sc ? scp[1] : 0.f, sc2 = has_sc ? scp[2] : 0.f, sc3 = (has_sc && h.den_prev) ? scp[3] : 0.f;
   const float xa = (has_sc ? h.x_a : h.b_out)[has_sc ? oidx : 0];
   float4 v[NC], gq[NC], wq[NC][8];
   float ssq = 0.f;
@@ -805,7 +807,9 @@ __global__ __launch_bounds__(256) void head_ddim_row_kernel(const ModeHeadDesc h
     if (has_sc) {
       const float den = F * sc1 + xa * sc0;               // F*c_out + x*c_skip      (score_wrappers.py:79-80)
       if (h.denoised) h.denoised[oidx] = den;
-      if (h.x_next) h.x_next[oidx] = sc2 * xa + (1.0f - sc2) * den;   // r*x + (1-r)*denoised (gc_sampling.py:948-950)
+      float dd = den;                                     // two-point multistep (DPM-Solver++(2M), gc_sampling.py:724-727): (1 + 1/(2r)) D - (1/(2r)) D_old
+      if (h.den_prev && sc3 != 0.0f) dd = (1.0f + sc3) * den - sc3 * h.den_prev[oidx];
+      if (h.x_next) h.x_next[oidx] = sc2 * xa + (1.0f - sc2) * dd;    // r*x + (1-r)*denoised (gc_sampling.py:948-950)
     }
   }
 }

@@ -390,7 +390,7 @@ class MoDeDiT(nn.Module):
         self._account_usage(ent["meta"], eng.meta_layout(B * self.seq_len), B * self.seq_len)
         return ent["out"].clone()
 
-    def _schedule_state(self, eng, sig, B, sigma_data: float, out=None):
+    def _schedule_state(self, eng, sig, B, sigma_data: float, out=None, solver: str = "ddim"):
         """Everything of a DDIM run that depends on the noise SCHEDULE only (not on the observations): per-step EDM scalings, the sigma
         embeddings, and the routing of all steps and layers with its dispatch records.  The reference resolves the same thing once per noise level
         and caches it (precompute_experts_for_inference / the cache read at modedit.py:542-546); here it is a set of device tensors the captured
@@ -401,8 +401,15 @@ class MoDeDiT(nn.Module):
         n = sig.numel() - 1
         s, nxt = sig[:-1].contiguous(), sig[1:]
         s2 = s * s + sigma_data ** 2
+        ms = torch.zeros_like(s)
+        if solver == "dpmpp_2m" and n > 1:
+            # DPM-Solver++(2M), gc_sampling.py:700-734: from the second step on (and not into sigma = 0) the update takes (1 + 1/(2r)) D - (1/(2r)) D_old
+            # for D, r = h_last / h in t = -ln sigma; scal[:, 3] = 1/(2r) in the reference's operation order, 0 where the plain step applies
+            h = s.log() - nxt.log()
+            r = h[:-1] / h[1:]
+            ms[1:] = torch.where(nxt[1:] > 0, 1.0 / (2.0 * r), torch.zeros_like(r))
         st = dict(c_in=(1.0 / s2.sqrt()).contiguous(),
-                  scal=torch.stack([sigma_data ** 2 / s2, s * sigma_data / s2.sqrt(), nxt / s, torch.zeros_like(s)], 1).contiguous(),
+                  scal=torch.stack([sigma_data ** 2 / s2, s * sigma_data / s2.sqrt(), nxt / s, ms], 1).contiguous(),
                   emb_all=eng.sigma_embed(s))                            # [n, D]: one conditioning row per step
         cached = None
         if all(blk.fused_experts for blk in self.blocks) and getattr(self, "_fused_for", None) == eng._wkey:
@@ -423,7 +430,7 @@ class MoDeDiT(nn.Module):
         out["from_cache"] = st["from_cache"]
         return out
 
-    def _ddim_steps(self, eng, img, goals, x, sched, n: int):
+    def _ddim_steps(self, eng, img, goals, x, sched, n: int, den=None):
         """The observation-dependent launch chain of a DDIM run: embeddings of the observations + n denoiser forwards with the fused EDM / DDIM
         update; pure launches, no host sync -> capturable.  Reads the schedule state by pointer."""
         B, T = x.shape[0], self.seq_len
@@ -432,8 +439,10 @@ class MoDeDiT(nn.Module):
         emb_all, meta, c_in, scal = sched["emb_all"], sched["meta"], sched["c_in"], sched["scal"]
         for s in range(n):
             e = emb_all[s]
+            # `den` ([2, B, A_len, A_dim]; two-point multistep solvers): the head also writes this step's denoised prediction and reads the previous one
+            mk = {} if den is None else dict(denoised=den[s & 1], den_prev=den[(s - 1) & 1] if s > 0 else None)
             eng.forward(B, e, 0, e, 0, meta.data_ptr() + 4 * s * ml.total_words, n * ml.total_words, goal_e, img_e, x,
-                        c_in=c_in.data_ptr() + 4 * s, c_in_stride=0, scal_ptr=scal.data_ptr() + 16 * s, scal_stride=0, x_next=x, uniform=True)
+                        c_in=c_in.data_ptr() + 4 * s, c_in_stride=0, scal_ptr=scal.data_ptr() + 16 * s, scal_stride=0, x_next=x, uniform=True, **mk)
         return ml
 
     def _account_ddim_usage(self, sched, ml, n, n_tokens):
@@ -447,10 +456,13 @@ class MoDeDiT(nn.Module):
             blk.total_tokens_processed += n_tokens * n
 
     @torch.no_grad()
-    def sample_ddim_fused(self, states, action, goals, sigmas, sigma_data: float):
+    def sample_ddim_fused(self, states, action, goals, sigmas, sigma_data: float, solver: str = "ddim"):
         """sample_ddim (gc_sampling.py:922-951) o GCDenoiser o MoDeDiT as one hipGraph replay.  The graph holds only what depends on the
         observations (embeddings + the denoiser forwards); sigma embeddings, routing, dispatch and the EDM scalings of the schedule live in a
-        schedule state that is rebuilt only when the sigma VALUES, the weights or the batch size change."""
+        schedule state that is rebuilt only when the sigma VALUES, the weights or the batch size change.
+        ``solver="dpmpp_2m"``: sample_dpmpp_2m (gc_sampling.py:700-734) on the same chain - its step is DDIM's exponential-integrator step applied to a
+        two-point extrapolation of the denoised prediction, which the head kernel forms from the previous step's prediction (ModeHeadDesc.den_prev)."""
+        assert solver in ("ddim", "dpmpp_2m"), solver
         import os
         eng = self.engine
         dev, B = eng.device, action.shape[0]
@@ -463,21 +475,29 @@ class MoDeDiT(nn.Module):
         n = sig.numel() - 1
         if self.use_goal_in_routing or not self.cond_router:             # routing depends on the sample / the tokens: per-step generic path
             x = x0.clone()
+            prev = None
             for i in range(n):
                 den = self.denoise({"state_images": img}, x, goals, sig[i].reshape(1), sigma_data)
                 r = sig[i + 1] / sig[i]
-                x = r * x + (1.0 - r) * den
+                dd = den
+                if solver == "dpmpp_2m" and prev is not None and float(sig[i + 1]) > 0:
+                    c = 1.0 / (2.0 * ((sig[i - 1].log() - sig[i].log()) / (sig[i].log() - sig[i + 1].log())))
+                    dd = (1.0 + c) * den - c * prev
+                x = r * x + (1.0 - r) * dd
+                prev = den
             return x
         use_graph = os.environ.get("MODE_HIP_GRAPH", "1") != "0"
+        multi = solver != "ddim"
         if not use_graph:
             x = x0.clone().contiguous()
-            sched = self._schedule_state(eng, sig, B, sigma_data)
-            ml = self._ddim_steps(eng, img, goals, x, sched, n)
+            sched = self._schedule_state(eng, sig, B, sigma_data, solver=solver)
+            ml = self._ddim_steps(eng, img, goals, x, sched, n, den=torch.empty((2,) + tuple(x.shape), dtype=torch.float32, device=dev) if multi else None)
             self._last_topk = sched["idx"]
             self._account_ddim_usage(sched, ml, n, B * self.seq_len)
             return x
         key = (B, sig.numel(), eng.compute_dtype, eng._structs_for, str(dev), float(sigma_data))   # arena pointers are static: weight updates keep graphs valid
-        ent = self._route_cache.get("graph")
+        gkey = "graph" if not multi else "graph:" + solver                  # one captured chain per solver
+        ent = self._route_cache.get(gkey)
         # identity of the schedule: a host-side tag of its VALUES when the tensor came from a get_sigmas_* / get_noise_schedule generator (the
         # agent builds a fresh tensor per chunk, mode_agent.py:752) - else the caller's tensor OBJECT (kept alive below, so neither its id nor its
         # storage can be recycled while the key is live) -, the weights, and the routing cache generation.  No device read on either path.
@@ -494,19 +514,20 @@ class MoDeDiT(nn.Module):
             # the graph owns its workspace: the engine's shared scratch buffer is re-allocated whenever a larger chain (a training step, a
             # bigger batch) asks for more, and a replay would then read freed memory
             st["ws"] = torch.empty(max(eng.workspace_bytes(B, 0), eng.workspace_bytes(0, n)), dtype=torch.uint8, device=dev)
+            st["den"] = torch.zeros((2,) + tuple(x0.shape), dtype=torch.float32, device=dev) if multi else None
             with eng.pinned_workspace(st["ws"]):
-                st["sched"] = self._schedule_state(eng, st["sig"], B, sigma_data)
+                st["sched"] = self._schedule_state(eng, st["sig"], B, sigma_data, solver=solver)
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):                            # warm-up: loads code objects
-                    self._ddim_steps(eng, st["img"], st["goals"], st["x"], st["sched"], n)
+                    self._ddim_steps(eng, st["img"], st["goals"], st["x"], st["sched"], n, den=st["den"])
                 torch.cuda.current_stream(dev).wait_stream(side)
                 g = torch.cuda.CUDAGraph()
                 with capture_graph(g):
-                    st["ml"] = self._ddim_steps(eng, st["img"], st["goals"], st["x"], st["sched"], n)
+                    st["ml"] = self._ddim_steps(eng, st["img"], st["goals"], st["x"], st["sched"], n, den=st["den"])
             st["graph"], st["sched_key"] = g, sched_key
             st["sig_ref"] = sigmas if tag is None else None
-            self._route_cache["graph"] = ent = st
+            self._route_cache[gkey] = ent = st
         elif ent["sched_key"] != sched_key:
             # an UNTAGGED foreign tensor object that may carry the same values: one small device compare (host sync) - the rare path; tagged
             # schedules and a reused tensor object never get here with an unchanged schedule
@@ -515,7 +536,7 @@ class MoDeDiT(nn.Module):
             if not same_values:
                 ent["sig"].copy_(sig)
                 with eng.pinned_workspace(ent["ws"]):
-                    self._schedule_state(eng, ent["sig"], B, sigma_data, out=ent["sched"])
+                    self._schedule_state(eng, ent["sig"], B, sigma_data, out=ent["sched"], solver=solver)
             ent["sched_key"] = sched_key
         ent["img"].copy_(img); ent["goals"].copy_(goals); ent["x"].copy_(x0)
         ent["graph"].replay()

@@ -65,10 +65,11 @@ def sample_loop(model, sigmas, x_t, state, goal, sampler_type: str = "ddim", ext
 
 
 # Samplers whose step loop depends on the schedule only (no data-dependent control flow, no host-side noise source): whole call capturable in a hipGraph.
-# Not here: "ddim" and "euler" (without churn the same update: both take MoDeDiT's fused graph, samplers.sample_euler), "lms" / "dpmpp_2_with_lms"
+# Not here: "ddim" and "euler" (without churn the same update: both take MoDeDiT's fused graph, samplers.sample_euler) and "dpmpp_2m" (the same chain with the
+# two-point extrapolation inside the head kernel, samplers.sample_dpmpp_2m -> GCDenoiser.dpmpp_2m_fused), "lms" / "dpmpp_2_with_lms"
 # (host-side quadrature of the schedule), "dpmpp_2m_sde" (torchsde Brownian tree on the host), "dpm_adaptive" / "dpm_fast" (step sizes from error
 # norms / host floats).
-_GRAPHABLE_SAMPLERS = ("euler_ancestral", "heun", "dpm", "ancestral", "dpmpp_2m", "dpmpp_2s", "dpmpp_2s_ancestral")
+_GRAPHABLE_SAMPLERS = ("euler_ancestral", "heun", "dpm", "ancestral", "dpmpp_2s", "dpmpp_2s_ancestral")
 
 
 class ChunkedRolloutPolicy:

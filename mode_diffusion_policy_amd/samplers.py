@@ -335,7 +335,13 @@ def sample_lms(model, state, action, goal, sigmas, scaler=None, extra_args=None,
 
 @torch.no_grad()
 def sample_dpmpp_2m(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None):
-    """DPM-Solver++(2M): exponential-integrator steps with a two-point extrapolation of the denoised prediction (gc_sampling.py:700-734)."""
+    """DPM-Solver++(2M): exponential-integrator steps with a two-point extrapolation of the denoised prediction (gc_sampling.py:700-734).  Without
+    callback and extra arguments a GCDenoiser over the HIP MoDeDiT takes the whole call as one hipGraph replay (the extrapolation inside the head kernel)."""
+    if callback is None and not extra_args and _chunk_capture() is None:
+        fused = getattr(model, "dpmpp_2m_fused", None)
+        out = fused(state, action, goal, sigmas) if fused is not None else None
+        if out is not None:
+            return out
     run = _Run(model, state, goal, action, extra_args, callback, None, "action")
     zeros = _zero_levels(sigmas)
     previous = None

@@ -79,5 +79,13 @@ class GCDenoiser(nn.Module):
             return m.sample_ddim_fused(state, action, goal, sigmas, self.sigma_data)
         return None
 
+    def dpmpp_2m_fused(self, state, action, goal, sigmas):
+        """sample_dpmpp_2m (gc_sampling.py:700-734) as one hipGraph replay: the same chain as the first-order solve, the head kernel applying the step to the
+        two-point extrapolation (1 + 1/(2r)) D - (1/(2r)) D_old of the denoised prediction.  None when the fast path does not apply."""
+        m = self.inner_model
+        if isinstance(m, MoDeDiT) and not m.training and not torch.is_grad_enabled() and torch.is_tensor(sigmas) and sigmas.dim() == 1:
+            return m.sample_ddim_fused(state, action, goal, sigmas, self.sigma_data, solver="dpmpp_2m")
+        return None
+
     def get_params(self):
         return self.inner_model.parameters()

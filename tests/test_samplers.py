@@ -248,3 +248,42 @@ def test_graphed_denoise_observation_cache_is_never_stale():
         m.tok_emb.weight.mul_(1.1); m.goal_emb.weight.add_(0.01)
     check("weights changed in place")
     sig = torch.tensor(0.2, device="cuda"); check("another sigma, same observations")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_dpmpp_2m_takes_the_fused_multistep_chain(dtype):
+    """sample_dpmpp_2m on the HIP denoiser is one hipGraph replay whose head kernel forms the two-point extrapolation (ModeHeadDesc.den_prev): equal to its own
+    step loop (forced by a callback) to fp32 rounding, for exponential / Karras schedules, 1- and 2-level schedules (no multistep step at all), repeated
+    and interleaved with the DDIM graph (one captured chain per solver), and not in training mode."""
+    from test_gpu_model import build
+    cfg, sd, m = build("c1e4", 78, dtype)
+    den = M.GCDenoiser(m, 0.5).eval()
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, 6, 9).items()}
+    state = {"state_images": inp["state_images"]}
+    tol = 3e-6 if dtype == "fp32" else BF16_OUT
+    for sig in (gc_sampling.get_sigmas_exponential(10, 0.001, 80.0, "cuda"), gc_sampling.get_sigmas_karras(7, 0.01, 40.0, 7.0, "cuda"),
+                gc_sampling.get_sigmas_exponential(2, 0.01, 10.0, "cuda"), gc_sampling.get_sigmas_exponential(1, 0.5, 0.5, "cuda")):
+        steps = []
+        loop = samplers.sample_dpmpp_2m(den, state, inp["x0"], inp["goals"], sig, disable=True, callback=lambda d: steps.append(d["i"]))
+        assert steps == list(range(len(sig) - 1))
+        fused = samplers.sample_dpmpp_2m(den, state, inp["x0"], inp["goals"], sig, disable=True)
+        assert rel(fused, loop) < tol, (len(sig), rel(fused, loop))
+        ddim = gc_sampling.sample_ddim(den, state, inp["x0"], inp["goals"], sig, disable=True)           # the other solver's graph in between
+        again = samplers.sample_dpmpp_2m(den, state, inp["x0"], inp["goals"], sig, disable=True)
+        assert torch.equal(fused, again)
+        if len(sig) <= 3:
+            assert torch.equal(fused, ddim)                       # no step has both a predecessor and a non-zero target: the plain update, bit for bit
+        else:
+            assert rel(fused, ddim) > 10 * tol                    # a different solver, not the DDIM chain under another name
+    # a second input on the cached graph
+    inp2 = {k: v.cuda() for k, v in make_inputs(cfg, 6, 10).items()}
+    sig = gc_sampling.get_sigmas_exponential(10, 0.001, 80.0, "cuda")
+    f2 = samplers.sample_dpmpp_2m(den, {"state_images": inp2["state_images"]}, inp2["x0"], inp2["goals"], sig, disable=True)
+    l2 = samplers.sample_dpmpp_2m(den, {"state_images": inp2["state_images"]}, inp2["x0"], inp2["goals"], sig, disable=True, callback=lambda d: None)
+    assert rel(f2, l2) < tol
+    m.train()
+    try:
+        assert den.dpmpp_2m_fused(state, inp["x0"], inp["goals"], sig) is None
+    finally:
+        m.eval()
