@@ -62,12 +62,27 @@ def _desc(x, scale, shift, pre, res, relu, post, y, cl=False, raw_bn=None) -> L.
     return d
 
 
+_BN_WS = {}
+
+
+def _bn_ws_bytes(lib, N, Cc, HW, dt, cl) -> int:
+    """mode_bn_workspace_bytes, memoised per geometry (a ctypes call per BatchNorm pass otherwise)."""
+    key = (N, Cc, HW, dt, cl)
+    v = _BN_WS.get(key)
+    if v is None:
+        v = _BN_WS[key] = lib.mode_bn_workspace_bytes(N, Cc, HW, dt, cl)
+    return v
+
+
 class _BnFilmAct(torch.autograd.Function):
     """y = post_film(relu(pre_film(batch_norm(x)) + residual)) as one HIP launch (two for training statistics); see csrc/encoder_ops.hip."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b, sync_group=None,
-                num_batches_tracked=None, grad_enabled=True, stat_sum=None, stat_sq=None):
+    def forward(ctx, x, weight, bias, residual, pre_g, pre_b, post_g, post_b, cfg):
+        # cfg: everything that is not differentiable, as ONE argument (Function.apply walks its arguments several times: 19 of them were ~2 ms of host
+        # time per agent step over the 106 BatchNorms) - (running_mean, running_var, training, momentum, eps, relu, sync_group, num_batches_tracked,
+        # grad_enabled, stat_sum, stat_sq)
+        running_mean, running_var, training, momentum, eps, relu, sync_group, num_batches_tracked, grad_enabled, stat_sum, stat_sq = cfg
         # ``stat_sum`` / ``stat_sq``: [row blocks, C] partial sums of x that the producing convolution wrote in its epilogue (conv_bn_act): the training
         # statistics are folded from them instead of from another pass over x
         # ``grad_enabled``: torch.is_grad_enabled() at the CALL site (inside Function.forward it is always False, and ctx.needs_input_grad reflects the
@@ -81,13 +96,13 @@ class _BnFilmAct(torch.autograd.Function):
         fmt = torch.channels_last if cl else torch.contiguous_format
         x = x.contiguous(memory_format=fmt)
         N, Cc = x.shape[0], x.shape[1]
-        HW = x[0, 0].numel()
+        HW = x.shape[2] * x.shape[3] if x.dim() == 4 else x[0, 0].numel()
         dev = x.device
-        wsb = lib.mode_bn_workspace_bytes(N, Cc, HW, _dt(x), int(cl))
         f32 = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
-        w, b = f32(weight), f32(bias)
-        m = N * HW
         fp32_buf = lambda t: t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == dev)
+        w = weight if fp32_buf(weight) else f32(weight)                   # (only their pointers are used)
+        b = bias if fp32_buf(bias) else f32(bias)
+        m = N * HW
         if (not training and not wants_grad and running_mean is not None and fp32_buf(running_mean) and fp32_buf(running_var)
                 and Cc % 4 == 0):
             # inference (the rollout): the eval-mode BatchNorm is folded INSIDE the pass from the module's own buffers - one launch per BatchNorm
@@ -104,25 +119,22 @@ class _BnFilmAct(torch.autograd.Function):
             # one call: (row sums +) per-channel statistics, invstd, folded scale / shift, and nn.BatchNorm2d's bookkeeping in place (running
             # statistics with the unbiased variance, num_batches_tracked) - a dozen torch launches per BatchNorm otherwise, 106 BatchNorms per
             # pair of ResNet-50s
-            st = torch.empty(5, Cc, device=dev)
-            mean, var, invstd, scale, shift = st[0], st[1], st[2], st[3], st[4]
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if (training and stat_sum is None) else None
+            mean, var, invstd, scale, shift = torch.empty(5, Cc, device=dev).unbind(0)
+            ws = torch.empty(_bn_ws_bytes(lib, N, Cc, HW, _dt(x), int(cl)), dtype=torch.uint8, device=dev) if (training and stat_sum is None) else None
             nbt = num_batches_tracked if (training and num_batches_tracked is not None and num_batches_tracked.dtype == torch.int64
                                           and num_batches_tracked.device == dev) else None
-            if training and stat_sum is not None:
-                with torch.no_grad():
-                    L.check(lib.mode_bn_prepare_partials(stat_sum.data_ptr(), stat_sq.data_ptr(), stat_sum.shape[0], float(m), Cc, _ptr(w), _ptr(b), float(eps),
-                                                         -1.0 if momentum is None else float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
-                                                         mean.data_ptr(), var.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream()),
-                            "bn_prepare_partials")
+            if training and stat_sum is not None:                              # (Function.forward runs with grad mode off: no no_grad() context needed)
+                L.check(lib.mode_bn_prepare_partials(stat_sum.data_ptr(), stat_sq.data_ptr(), stat_sum.shape[0], float(m), Cc, _ptr(w), _ptr(b), float(eps),
+                                                     -1.0 if momentum is None else float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                                     mean.data_ptr(), var.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream()),
+                        "bn_prepare_partials")
             else:
-              with torch.no_grad():
                 L.check(lib.mode_bn_prepare(x.data_ptr() if training else None, _dt(x), N, Cc, HW, int(cl), _ptr(w), _ptr(b), float(eps),
                                             -1.0 if momentum is None else float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(nbt), mean.data_ptr(),
                                             var.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _ptr(ws), 0 if ws is None else ws.numel(),
                                             _stream()), "bn_prepare")
         else:
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            ws = torch.empty(_bn_ws_bytes(lib, N, Cc, HW, _dt(x), int(cl)), dtype=torch.uint8, device=dev)
             if training:
                 mean = torch.empty(Cc, device=dev); var = torch.empty(Cc, device=dev)
                 L.check(lib.mode_bn_stats(x.data_ptr(), _dt(x), N, Cc, HW, int(cl), mean.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn_stats")
@@ -174,13 +186,17 @@ class _BnFilmAct(torch.autograd.Function):
         post = (rest[2 if has_pre else 0], rest[3 if has_pre else 1]) if has_post else None
         N, Cc = x.shape[0], x.shape[1]
         dev = x.device
-        dy = dy.to(x.dtype).contiguous(memory_format=fmt)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        if not dy.is_contiguous(memory_format=fmt):
+            dy = dy.contiguous(memory_format=fmt)
         dx = torch.empty_like(x, memory_format=fmt)
         dres = torch.empty_like(x, memory_format=fmt) if has_res else None
-        dw = torch.empty(Cc, device=dev); db = torch.empty(Cc, device=dev)
-        dpg = torch.empty(N, Cc, device=dev) if has_pre else None; dpb = torch.empty(N, Cc, device=dev) if has_pre else None
-        dqg = torch.empty(N, Cc, device=dev) if has_post else None; dqb = torch.empty(N, Cc, device=dev) if has_post else None
-        ws = torch.empty(lib.mode_bn_workspace_bytes(N, Cc, x[0, 0].numel(), _dt(x), int(cl)), dtype=torch.uint8, device=dev)
+        dw = torch.empty(Cc, device=dev); db = torch.empty(Cc, device=dev)      # (leaf gradients: own tensors, so that AccumulateGrad can take them without a copy)
+        dpg, dpb = torch.empty(2, N, Cc, device=dev).unbind(0) if has_pre else (None, None)
+        dqg, dqb = torch.empty(2, N, Cc, device=dev).unbind(0) if has_post else (None, None)
+        HW = x.shape[2] * x.shape[3] if x.dim() == 4 else x[0, 0].numel()
+        ws = torch.empty(_bn_ws_bytes(lib, N, Cc, HW, _dt(x), int(cl)), dtype=torch.uint8, device=dev)
         d = _desc(x, scale, shift, pre, res if has_res else None, relu, post, None, cl)
         d.y = x.data_ptr()                                                     # unused by the backward; the descriptor check wants a pointer
         def call(phase, inv_count, dw_, db_):
@@ -199,8 +215,8 @@ class _BnFilmAct(torch.autograd.Function):
             call(2, 1.0, tot[0].contiguous(), tot[1].contiguous())
         ps, qs = ctx.shapes
         rs = lambda t, shp: None if t is None else t.reshape(shp)
-        # inputs: x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual, pre_g, pre_b, post_g, post_b
-        return dx, dw, db, None, None, None, None, None, None, dres, rs(dpg, ps), rs(dpb, ps), rs(dqg, qs), rs(dqb, qs), None, None, None, None, None
+        # inputs: x, weight, bias, residual, pre_g, pre_b, post_g, post_b, cfg
+        return dx, dw, db, dres, rs(dpg, ps), rs(dpb, ps), rs(dqg, qs), rs(dqb, qs), None
 
 
 # Activation layout inside the encoders.  True: torch.channels_last - MIOpen's implicit-GEMM convolutions run on NHWC data and wrap NCHW tensors in
@@ -598,8 +614,10 @@ def bn_film_act(x, bn: nn.BatchNorm2d, relu: bool = True, residual=None, pre_fil
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.process_group) > 1:
             sync = bn.process_group if bn.process_group is not None else True
     training = bn.training or bn.running_mean is None                       # no running statistics -> batch statistics also in eval (nn.BatchNorm2d)
-    return _BnFilmAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, relu, residual, pg, pb, qg, qb, sync,
-                            bn.num_batches_tracked if bn.training else None, torch.is_grad_enabled(), *((stats[0], stats[1]) if (stats is not None and sync is None) else (None, None)))
+    s0, s1 = (stats[0], stats[1]) if (stats is not None and sync is None) else (None, None)
+    return _BnFilmAct.apply(x, bn.weight, bn.bias, residual, pg, pb, qg, qb,
+                            (bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, relu, sync, bn.num_batches_tracked if bn.training else None,
+                             torch.is_grad_enabled(), s0, s1))
 
 
 # Inference: convolution + eval-mode BatchNorm + FiLM + residual + ReLU as ONE launch (mode_conv_bn_act_fwd, csrc/conv_gemm.hip) - the rollout's encoders run
