@@ -498,6 +498,7 @@ extern "C" int mode_stem_conv_fwd(const ModeStemConvDesc* d, void* stream) {
   if ((d->bn_mean == nullptr) != (d->bn_var == nullptr)) return MODE_ERR_BAD_ARG;
   if (p.tiles == 0) return MODE_OK;
   if (!d->y) return MODE_ERR_BAD_ARG;
+  if (reinterpret_cast<uintptr_t>(d->y) & 15) return MODE_ERR_UNSUPPORTED;                 // 16-byte row chunks
   p.y = (uint16_t*)d->y; p.bn_mean = d->bn_mean; p.bn_var = d->bn_var; p.bn_w = d->bn_weight; p.bn_b = d->bn_bias; p.bn_eps = d->bn_eps; p.relu = d->relu;
   return stem_dispatch(p, false, p.tiles < 512 ? p.tiles : 512, (hipStream_t)stream);      // one resident round (2 workgroups per CU)
 }
@@ -512,6 +513,7 @@ extern "C" int mode_stem_conv_wgrad(const ModeStemConvDesc* d, void* stream) {
   StemParams p;
   if (int rc = stem_params(d, p)) return rc;
   if ((!d->dy && p.tiles > 0) || !d->dw_part) return MODE_ERR_BAD_ARG;
+  if (reinterpret_cast<uintptr_t>(d->dy) & 15) return MODE_ERR_UNSUPPORTED;
   p.dy = (const uint16_t*)d->dy; p.part = d->dw_part;
   return stem_dispatch(p, true, mode_stem_conv_wgrad_slabs(d), (hipStream_t)stream);      // no pixels: one workgroup writes a zero slab
 }
@@ -530,6 +532,7 @@ extern "C" int mode_maxpool_nhwc_fwd(const void* x, int dtype, int N, int H, int
   PoolParams p{};
   if (int rc = pool_params(dtype, N, H, W, C, k, s, pad, p)) return rc;
   if (!x || !y) return MODE_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15 || (reinterpret_cast<uintptr_t>(argmax) & 7)) return MODE_ERR_UNSUPPORTED;
   p.x = x; p.y = y; p.arg = argmax;
   const long total = (long)N * p.ho * p.wo * (C >> 3);
   if (total == 0) return MODE_OK;
@@ -544,6 +547,7 @@ extern "C" int mode_maxpool_nhwc_bwd(const void* dy, const uint8_t* argmax, int 
   PoolParams p{};
   if (int rc = pool_params(dtype, N, H, W, C, k, s, pad, p)) return rc;
   if (!dy || !argmax || !dx) return MODE_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15 || (reinterpret_cast<uintptr_t>(argmax) & 7)) return MODE_ERR_UNSUPPORTED;
   p.x = dy; p.y = dx; p.arg = const_cast<uint8_t*>(argmax);
   const long total = (long)N * H * W * (C >> 3);
   if (total == 0) return MODE_OK;

@@ -738,6 +738,8 @@ class _StemConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             cout, cin, kh_, kw_ = w_lp.shape
             dyc = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            if dyc.data_ptr() % 16:                                   # (a view at an odd offset: the kernel reads 16-byte row chunks)
+                dyc = dyc.clone(memory_format=torch.channels_last)
             d = _stem_desc(x, w_lp, stride, padding, dy=dyc.data_ptr())
             lib = L.load()
             slabs = lib.mode_stem_conv_wgrad_slabs(C.byref(d))
@@ -768,6 +770,8 @@ class _MaxPoolFn(torch.autograd.Function):
         (arg,) = ctx.saved_tensors
         k, s, p, (n, c, H, W_) = ctx.conf
         dyc = dy.contiguous(memory_format=torch.channels_last)
+        if dyc.data_ptr() % 16:
+            dyc = dyc.clone(memory_format=torch.channels_last)
         dx = torch.empty((n, c, H, W_), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
         L.check(L.load().mode_maxpool_nhwc_bwd(dyc.data_ptr(), arg.data_ptr(), _DT[dy.dtype], n, H, W_, c, k, s, p, dx.data_ptr(), _stream()), "max-pool backward")
         return dx, None, None, None
@@ -776,7 +780,7 @@ class _MaxPoolFn(torch.autograd.Function):
 def max_pool(x: torch.Tensor, k: int = 3, s: int = 2, p: int = 1) -> torch.Tensor:
     """F.max_pool2d(x, k, s, p) on channels_last activations through the library (forward + gather-form backward)."""
     if (USE_HIP_STEM and x.is_cuda and x.dim() == 4 and x.dtype in _DT and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last)
-            and 2 * p <= k <= 15 and x.shape[2] + 2 * p >= k and x.shape[3] + 2 * p >= k):
+            and 2 * p <= k <= 15 and x.shape[2] + 2 * p >= k and x.shape[3] + 2 * p >= k and x.data_ptr() % 16 == 0):
         return _MaxPoolFn.apply(x, k, s, p)
     return F.max_pool2d(x, k, s, p)
 

@@ -182,3 +182,33 @@ def test_stem_conv_random_geometries(case):
     dy = torch.randn(ref.shape, generator=g).to(torch.bfloat16).cuda()
     y.backward(dy.contiguous(memory_format=torch.channels_last)); ref.backward(dy.double())
     assert rel(wp.grad, wr.grad) < 1e-4, (k, cin, cout, s, p, N, H, W_)
+
+
+def test_misaligned_views_are_handled():
+    """The kernels move 16-byte chunks: an activation / gradient that starts at an odd offset of its storage takes aten (max-pool input) or a
+    realigned copy (gradients) - same results."""
+    from mode_diffusion_policy_amd import perceptual_encoders as E
+    g = torch.Generator().manual_seed(2)
+    buf = torch.relu(torch.randn(2 * 9 * 9 * 16 + 4, generator=g)).to(torch.bfloat16).cuda()
+    x = buf[4:].view(2, 9, 9, 16).permute(0, 3, 1, 2)                          # channels_last view, 8 bytes into the storage
+    assert x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 8
+    assert torch.equal(E.max_pool(x), F.max_pool2d(x, 3, 2, 1))
+    xa = x.contiguous(memory_format=torch.channels_last).clone().requires_grad_(True); xb = xa.detach().clone().requires_grad_(True)
+    ya = E.max_pool(xa); yb = F.max_pool2d(xb, 3, 2, 1)
+    dbuf = torch.randn(ya.numel() + 4, generator=g).to(torch.bfloat16).cuda()
+    dy = dbuf[4:].view(2, ya.shape[2], ya.shape[3], 16).permute(0, 3, 1, 2)
+    assert dy.data_ptr() % 16 == 8
+    ya.backward(dy); yb.backward(dy)
+    assert torch.allclose(xa.grad.float(), xb.grad.float(), rtol=1e-2, atol=1e-2)
+    # stem weight gradient with a misaligned dy
+    img = torch.randn(2, 3, 20, 20, generator=g).cuda()
+    w = (torch.randn(16, 3, 7, 7, generator=g) * 0.1).cuda()
+    w_lp = w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wp = w.clone().requires_grad_(True)
+    y = E._StemConvFn.apply(img, wp, w_lp, (2, 2), (3, 3))
+    dbuf = torch.randn(y.numel() + 4, generator=g).to(torch.bfloat16).cuda()
+    dys = dbuf[4:].view(2, y.shape[2], y.shape[3], 16).permute(0, 3, 1, 2)
+    y.backward(dys)
+    wr = w_lp.double().requires_grad_(True)
+    F.conv2d(img.to(torch.bfloat16).double(), wr, None, 2, 3).backward(dys.double())
+    assert rel(wp.grad, wr.grad) < 1e-4
