@@ -611,8 +611,10 @@ def extra_measurements(M, den, device):
         out[f"sampler_{name}_denoise_steps_per_s"] = round(n * N_SAMPLING_STEPS / (time.perf_counter() - t0), 1)
     # the same samplers through the rollout policy (MoDEAgent.denoise_actions' path): the WHOLE sampler call as one hipGraph replay
     from mode_diffusion_policy_amd import rollout as RO
-    for name in ("euler", "dpmpp_2m"):
-        for key, nb in ((f"sampler_{name}_policy_denoise_steps_per_s", B_PER_GPU), (f"sampler_{name}_policy_b1_ms_per_chunk", 1)):
+    for name in ("euler", "dpmpp_2m", "heun"):               # heun: 2 n - 1 = 19 denoiser evaluations per chunk (two-stage solver on the fused chain)
+        evals = 2 * N_SAMPLING_STEPS - 1 if name == "heun" else N_SAMPLING_STEPS
+        for key, nb in ((f"sampler_{name}_policy_" + ("denoiser_evals_per_s" if name == "heun" else "denoise_steps_per_s"), B_PER_GPU),
+                        (f"sampler_{name}_policy_b1_ms_per_chunk", 1)):
             im, gl, _ = synthetic_inputs(device, nb)
             pol = RO.ChunkedRolloutPolicy(den, sampler_type=name, num_sampling_steps=N_SAMPLING_STEPS, sigma_min=SIGMA_MIN, sigma_max=SIGMA_MAX, multistep=1)
             for _ in range(3):
@@ -624,7 +626,7 @@ def extra_measurements(M, den, device):
                 pol.denoise_actions({"state_images": im}, gl)
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
-            out[key] = round(n * N_SAMPLING_STEPS / el, 1) if nb > 1 else round(el / n * 1e3, 3)
+            out[key] = round(n * evals / el, 1) if nb > 1 else round(el / n * 1e3, 3)
     return out
 
 

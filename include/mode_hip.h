@@ -374,6 +374,11 @@ typedef struct ModeHeadDesc {
    * the same exponential-integrator step as DDIM's.  den_prev = the `denoised` output of the previous step (the caller ping-pongs two buffers).
    * NULL (or c == 0: the first step, the step to sigma = 0) = the DDIM update, bit for bit. */
   const float* den_prev;
+  /* ABI 12.  General linear update for the two-stage solvers (Heun, DPM-Solver-2, DPM-Solver++(2S): gc_sampling.py:257-373, 956-994), whose every stage is a
+   * linear combination of the stage's input, its denoised prediction and at most two earlier tensors:
+   *   x_next = lin[0] * x_a + lin[1] * denoised + lin[2] * aux1 + lin[3] * aux2        (lin: fp32 [4], shared by the batch; aux1 / aux2 may be NULL)
+   * lin != NULL replaces the DDIM / multistep update above (scal still supplies c_skip / c_out).  x_next may alias x_a, aux1 or aux2 (element-wise). */
+  const float* lin; const float* aux1; const float* aux2;
 } ModeHeadDesc;
 int mode_head_ddim_fwd(const ModeHeadDesc* d, void* stream);
 
@@ -601,6 +606,7 @@ typedef struct ModeForwardArgs {
    * correct).  It is NOT inferred from cond_row_stride: a shared conditioning row with per-sample routing is a legal call. */
   int32_t uniform_routing;
   const float* den_prev;                             /* ABI 12: ModeHeadDesc.den_prev of the chain's head (two-point multistep samplers); NULL = none */
+  const float* lin; const float* aux1; const float* aux2;   /* ABI 12: ModeHeadDesc.lin / aux1 / aux2 (two-stage solvers); NULL = none */
 } ModeForwardArgs;
 int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w, const ModeForwardArgs* a,
                      void* workspace, size_t workspace_bytes, void* stream);

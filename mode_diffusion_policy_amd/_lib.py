@@ -54,7 +54,7 @@ class ModeHeadDesc(C.Structure):
     _fields_ = [("B", c_i32), ("T", c_i32), ("D", c_i32), ("A_len", c_i32), ("A_dim", c_i32), ("k", c_i32),
                 ("u", c_vp), ("Y", c_vp), ("y_dtype", c_i32), ("y_splits", c_i32), ("y_split_stride", c_i64), ("pos", c_vp), ("posw", c_vp), ("g", c_vp), ("eps", c_f32),
                 ("w_out", c_vp), ("b_out", c_vp), ("x_a", c_vp), ("scal", c_vp), ("scal_stride", c_i64),
-                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp), ("u_ss", c_vp), ("u_ss_n", c_i32), ("u_gain", c_vp), ("den_prev", c_vp)]
+                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp), ("u_ss", c_vp), ("u_ss_n", c_i32), ("u_gain", c_vp), ("den_prev", c_vp), ("lin", c_vp), ("aux1", c_vp), ("aux2", c_vp)]
 
 
 class ModeDims(C.Structure):
@@ -124,7 +124,7 @@ class ModeForwardArgs(C.Structure):
     _fields_ = [("B", c_i32), ("dtype", c_i32), ("emb_t", c_vp), ("emb_row_stride", c_i64), ("cond", c_vp),
                 ("cond_row_stride", c_i64), ("meta", c_vp), ("meta_layer_stride", c_i64), ("goal_e", c_vp), ("img_e", c_vp),
                 ("actions", c_vp), ("c_in", c_vp), ("c_in_stride", c_i64), ("scal", c_vp), ("scal_stride", c_i64),
-                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp), ("topk_idx_out", c_vp), ("uniform_routing", c_i32), ("den_prev", c_vp)]
+                ("F", c_vp), ("denoised", c_vp), ("x_next", c_vp), ("topk_idx_out", c_vp), ("uniform_routing", c_i32), ("den_prev", c_vp), ("lin", c_vp), ("aux1", c_vp), ("aux2", c_vp)]
 
 
 class ModeQkvAttnDesc(C.Structure):

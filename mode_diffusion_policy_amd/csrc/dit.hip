@@ -397,7 +397,7 @@ extern "C" int mode_dit_forward(const ModeDims* dims, const ModeModelWeights* w,
       hd.u = x; hd.Y = ybuf; hd.y_dtype = dt; hd.y_splits = ysplit; hd.y_split_stride = (long)NK * D; hd.pos = meta + ml.pos; hd.posw = reinterpret_cast<const float*>(meta + ml.posw);
       hd.g = w->ln_g; hd.eps = d.eps; hd.u_ss = fuse ? rowss : nullptr; hd.u_ss_n = ssn; hd.u_gain = lw.ln2_g; hd.w_out = w->w_out; hd.b_out = w->b_out;
       hd.x_a = a->actions; hd.scal = a->scal; hd.scal_stride = a->scal_stride;
-      hd.F = a->F; hd.denoised = a->denoised; hd.x_next = a->x_next; hd.den_prev = a->den_prev;
+      hd.F = a->F; hd.denoised = a->denoised; hd.x_next = a->x_next; hd.den_prev = a->den_prev; hd.lin = a->lin; hd.aux1 = a->aux1; hd.aux2 = a->aux2;
       rc = mode_head_ddim_fwd(&hd, stream);
       if (rc) return rc;
     }

@@ -453,7 +453,16 @@ __global__ __launch_bounds__(256) void head_ddim_kernel(const ModeHeadDesc h) {
       if (h.denoised) h.denoised[oidx] = den;
       float dd = den;                                     // two-point multistep (DPM-Solver++(2M), gc_sampling.py:724-727): (1 + 1/(2r)) D - (1/(2r)) D_old
       if (h.den_prev && sc3 != 0.0f) dd = (1.0f + sc3) * den - sc3 * h.den_prev[oidx];
-      if (h.x_next) h.x_next[oidx] = sc2 * xa + (1.0f - sc2) * dd;    // r*x + (1-r)*denoised (gc_sampling.py:948-950)
+      if (h.x_next) {
+        if (h.lin) {                                        // two-stage solvers: a linear combination of this stage's input / prediction and two earlier tensors
+          float v = __builtin_fmaf(h.lin[0], xa, h.lin[1] * den);
+          if (h.aux1) v = __builtin_fmaf(h.lin[2], h.aux1[oidx], v);
+          if (h.aux2) v = __builtin_fmaf(h.lin[3], h.aux2[oidx], v);
+          h.x_next[oidx] = v;
+        } else {
+          h.x_next[oidx] = sc2 * xa + (1.0f - sc2) * dd;    // r*x + (1-r)*denoised (gc_sampling.py:948-950)
+        }
+      }
     }
   }
 }
@@ -809,7 +818,16 @@ __global__ __launch_bounds__(256) void head_ddim_row_kernel(const ModeHeadDesc h
       if (h.denoised) h.denoised[oidx] = den;
       float dd = den;                                     // two-point multistep (DPM-Solver++(2M), gc_sampling.py:724-727): (1 + 1/(2r)) D - (1/(2r)) D_old
       if (h.den_prev && sc3 != 0.0f) dd = (1.0f + sc3) * den - sc3 * h.den_prev[oidx];
-      if (h.x_next) h.x_next[oidx] = sc2 * xa + (1.0f - sc2) * dd;    // r*x + (1-r)*denoised (gc_sampling.py:948-950)
+      if (h.x_next) {
+        if (h.lin) {                                        // two-stage solvers: a linear combination of this stage's input / prediction and two earlier tensors
+          float v = __builtin_fmaf(h.lin[0], xa, h.lin[1] * den);
+          if (h.aux1) v = __builtin_fmaf(h.lin[2], h.aux1[oidx], v);
+          if (h.aux2) v = __builtin_fmaf(h.lin[3], h.aux2[oidx], v);
+          h.x_next[oidx] = v;
+        } else {
+          h.x_next[oidx] = sc2 * xa + (1.0f - sc2) * dd;    // r*x + (1-r)*denoised (gc_sampling.py:948-950)
+        }
+      }
     }
   }
 }

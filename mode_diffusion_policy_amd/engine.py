@@ -233,15 +233,16 @@ class DitEngine:
 
     def forward(self, B: int, emb_t, emb_stride: int, cond, cond_stride: int, meta_ptr: int, meta_layer_stride: int, goal_e, img_e,
                 actions, c_in=None, c_in_stride: int = 0, scal_ptr: Optional[int] = None, scal_stride: int = 0, F=None,
-                denoised=None, x_next=None, topk_out=None, uniform: bool = False, den_prev=None) -> None:
+                denoised=None, x_next=None, topk_out=None, uniform: bool = False, den_prev=None, lin_ptr: Optional[int] = None, aux1=None, aux2=None) -> None:
         """``meta_ptr=None``: token routing (cond_router=False) - every block routes inside the chain; ``topk_out`` int32 [L, B*T, k] receives the experts.
         ``uniform``: the dispatch records were built from ONE routing row for the whole batch (``dispatch(..., R=1, ...)``) - see ModeForwardArgs.
-        ``den_prev``: the previous step's ``denoised`` for the head's two-point multistep update (scal[3] = its weight; ModeHeadDesc.den_prev)."""
+        ``den_prev``: the previous step's ``denoised`` for the head's two-point multistep update (scal[3] = its weight; ModeHeadDesc.den_prev).
+        ``lin_ptr`` / ``aux1`` / ``aux2``: the head's general linear update of the two-stage solvers (ModeHeadDesc.lin)."""
         a = L.ModeForwardArgs(B=B, dtype=self.dt, emb_t=_ptr(emb_t), emb_row_stride=emb_stride, cond=_ptr(cond),
                               cond_row_stride=cond_stride, meta=meta_ptr, meta_layer_stride=meta_layer_stride,
                               goal_e=_ptr(goal_e), img_e=_ptr(img_e), actions=_ptr(actions), c_in=_ptr(c_in) if torch.is_tensor(c_in) else c_in,
                               c_in_stride=c_in_stride, scal=scal_ptr, scal_stride=scal_stride, F=_ptr(F), denoised=_ptr(denoised),
                               x_next=_ptr(x_next), topk_idx_out=_ptr(topk_out), uniform_routing=int(bool(uniform) and meta_ptr is not None),
-                              den_prev=_ptr(den_prev))
+                              den_prev=_ptr(den_prev), lin=lin_ptr, aux1=_ptr(aux1), aux2=_ptr(aux2))
         ws, wsn = self.workspace(B, 0)
         L.check(self.lib.mode_dit_forward(C.byref(self.dims), C.byref(self._mw), C.byref(a), ws, wsn, _stream()), "dit_forward")

@@ -390,7 +390,7 @@ class MoDeDiT(nn.Module):
         self._account_usage(ent["meta"], eng.meta_layout(B * self.seq_len), B * self.seq_len)
         return ent["out"].clone()
 
-    def _schedule_state(self, eng, sig, B, sigma_data: float, out=None, solver: str = "ddim"):
+    def _schedule_state(self, eng, sig, B, sigma_data: float, out=None, solver: str = "ddim", lin=None):
         """Everything of a DDIM run that depends on the noise SCHEDULE only (not on the observations): per-step EDM scalings, the sigma
         embeddings, and the routing of all steps and layers with its dispatch records.  The reference resolves the same thing once per noise level
         and caches it (precompute_experts_for_inference / the cache read at modedit.py:542-546); here it is a set of device tensors the captured
@@ -398,8 +398,13 @@ class MoDeDiT(nn.Module):
         CONSUMED here - no router launch at all; otherwise the fp32 router runs on the device.  With ``out`` the results are written in place
         (the graph has the pointers baked in)."""
         T, Ly = self.seq_len, self.num_layers
-        n = sig.numel() - 1
-        s, nxt = sig[:-1].contiguous(), sig[1:]
+        if lin is not None:
+            # two-stage solvers (sample_two_stage_fused): `sig` lists the sigma of EVERY denoiser evaluation, `lin` [n, 4] the linear update of each
+            n = sig.numel()
+            s, nxt = sig.contiguous(), torch.zeros_like(sig)
+        else:
+            n = sig.numel() - 1
+            s, nxt = sig[:-1].contiguous(), sig[1:]
         s2 = s * s + sigma_data ** 2
         ms = torch.zeros_like(s)
         if solver == "dpmpp_2m" and n > 1:
@@ -423,9 +428,11 @@ class MoDeDiT(nn.Module):
             idx, w, _, _ = eng.route(st["emb_all"])                      # [L, n, k]: routing for ALL steps up front
         N = B * T
         st.update(idx=idx.contiguous(), w=w.contiguous(), meta=eng.dispatch(idx.contiguous(), w.contiguous(), Ly * n, 1, N, N), from_cache=cached is not None)
+        if lin is not None:
+            st["lin"] = lin.to(device=eng.device, dtype=torch.float32).contiguous()
         if out is None:
             return st
-        for k_ in ("c_in", "scal", "emb_all", "idx", "w", "meta"):
+        for k_ in ("c_in", "scal", "emb_all", "idx", "w", "meta") + (("lin",) if lin is not None else ()):
             out[k_].copy_(st[k_])
         out["from_cache"] = st["from_cache"]
         return out
@@ -444,6 +451,126 @@ class MoDeDiT(nn.Module):
             eng.forward(B, e, 0, e, 0, meta.data_ptr() + 4 * s * ml.total_words, n * ml.total_words, goal_e, img_e, x,
                         c_in=c_in.data_ptr() + 4 * s, c_in_stride=0, scal_ptr=scal.data_ptr() + 16 * s, scal_stride=0, x_next=x, uniform=True, **mk)
         return ml
+
+    # ---- two-stage solvers on the fused chain (Heun, DPM-Solver-2, DPM-Solver++(2S)) -------------------------------------------------------
+    @staticmethod
+    def _two_stage_plan(solver: str, sv):
+        """Host plan of a deterministic two-stage solver over the levels ``sv`` (python floats): one entry per DENOISER EVALUATION -
+        (sigma, x_in, x_out, (l0, l1, l2, l3), aux1, aux2, den_out) with buffer ids 0 = state, 1 = probe, 2 = first-stage prediction (None = unused);
+        the head computes x_out = l0 x_in + l1 D(x_in; sigma) + l2 aux1 + l3 aux2 (ModeHeadDesc.lin).  The recurrences are the reference's
+        (gc_sampling.py:257-312 sample_heun, :315-373 sample_dpm_2, :956-994 sample_dpmpp_2s; churn 0), multiplied out:
+          Euler into sigma' (all three, and the only stage of a step into sigma' = 0):  x + (x - D)/s (s' - s) = (s'/s) x + (1 - s'/s) D
+          Heun corrector:   x + ((x - D)/s + (p - D_p)/s') dt/2,  p = Euler probe at s'
+          DPM-Solver-2:     x + (m - D_m)/s_m (s' - s),  m = Euler probe at s_m = sqrt(s s') (log-midpoint)
+          DPM-Solver++(2S): m = (s_m/s) x - expm1(-h/2) D;  x' = (s'/s) x - expm1(-h) D_m,  h = ln s - ln s'"""
+        import math
+        plan = []
+        for i in range(len(sv) - 1):
+            s_, t_ = sv[i], sv[i + 1]
+            if t_ == 0.0:
+                plan.append((s_, 0, 0, (0.0, 1.0, 0.0, 0.0), None, None, None))
+                continue
+            if solver == "heun":
+                r, dt = t_ / s_, t_ - s_
+                plan.append((s_, 0, 1, (r, 1.0 - r, 0.0, 0.0), None, None, 2))
+                plan.append((t_, 1, 0, (dt / (2 * t_), -dt / (2 * t_), 1.0 + dt / (2 * s_), -dt / (2 * s_)), 0, 2, None))
+                continue
+            # the log-midpoint exactly as the step loops compute it (fp32 tensor ops): the denoiser is evaluated at the same sigma bits
+            sm = float(torch.tensor(s_, dtype=torch.float32).log().lerp(torch.tensor(t_, dtype=torch.float32).log(), 0.5).exp()) if solver == "dpm_2" else \
+                float((0.5 * (torch.tensor(s_, dtype=torch.float32).log() + torch.tensor(t_, dtype=torch.float32).log())).exp())
+            if solver == "dpm_2":
+                r1, dt = sm / s_, t_ - s_
+                plan.append((s_, 0, 1, (r1, 1.0 - r1, 0.0, 0.0), None, None, None))
+                plan.append((sm, 1, 0, (dt / sm, -dt / sm, 1.0, 0.0), 0, None, None))
+            elif solver == "dpmpp_2s":
+                h = math.log(s_) - math.log(t_)
+                plan.append((s_, 0, 1, (sm / s_, -math.expm1(-0.5 * h), 0.0, 0.0), None, None, None))
+                plan.append((sm, 1, 0, (0.0, -math.expm1(-h), t_ / s_, 0.0), 0, None, None))
+            else:
+                raise ValueError(solver)
+        return plan
+
+    def _plan_steps(self, eng, img, goals, bufs, sched, plan):
+        """The launch chain of a two-stage solve: one denoiser forward per plan entry, the head applying the entry's linear update between the three
+        [B, A_len, A_dim] buffers `bufs`; pure launches -> capturable.  Coefficients, scalings, embeddings and routing are read by pointer."""
+        B, T = bufs[0].shape[0], self.seq_len
+        img_e, goal_e = eng.embed_obs(img, goals)
+        ml = eng.meta_layout(B * T)
+        emb_all, meta, c_in, scal, lin = sched["emb_all"], sched["meta"], sched["c_in"], sched["scal"], sched["lin"]
+        m = len(plan)
+        for j, (_, xin, xout, _, a1, a2, dout) in enumerate(plan):
+            e = emb_all[j]
+            eng.forward(B, e, 0, e, 0, meta.data_ptr() + 4 * j * ml.total_words, m * ml.total_words, goal_e, img_e, bufs[xin],
+                        c_in=c_in.data_ptr() + 4 * j, c_in_stride=0, scal_ptr=scal.data_ptr() + 16 * j, scal_stride=0, x_next=bufs[xout], uniform=True,
+                        denoised=None if dout is None else bufs[dout], lin_ptr=lin.data_ptr() + 16 * j,
+                        aux1=None if a1 is None else bufs[a1], aux2=None if a2 is None else bufs[a2])
+        return ml
+
+    @torch.no_grad()
+    def sample_two_stage_fused(self, states, action, goals, sigmas, sigma_data: float, solver: str):
+        """sample_heun / sample_dpm_2 / sample_dpmpp_2s (deterministic: no churn, no clipping, no callback) as ONE hipGraph replay of the fused chain:
+        every stage of these solvers is linear in (stage input, its prediction, the step's state, the first stage's prediction), which the head kernel
+        applies (ModeHeadDesc.lin).  The schedule-dependent part - which sigma every evaluation sees, the coefficients, embeddings, routing - is a
+        plan rebuilt only when the schedule values, the weights or the batch size change.  None when the fast path does not apply."""
+        import os
+        assert solver in ("heun", "dpm_2", "dpmpp_2s"), solver
+        eng = self.engine
+        dev, B = eng.device, action.shape[0]
+        if (B == 0 or self.use_goal_in_routing or not self.cond_router or os.environ.get("MODE_HIP_GRAPH", "1") == "0" or sigmas.numel() < 2):
+            return None
+        img, goals = self._prep_obs(eng, states, goals)
+        sig = sigmas.detach().to(device=dev, dtype=torch.float32).contiguous()
+        x0 = action.detach().to(device=dev, dtype=torch.float32)
+        self._check_batch(B, img, goals, x0)
+        tag = getattr(sigmas, "_mode_sched", None)
+        if tag is not None and sigmas._version != tag[3]:
+            tag = None
+        sid = ("tag", tag) if tag is not None else ("obj", id(sigmas), sigmas._version)
+        sched_key = (sid, eng._wkey, getattr(self, "_fused_gen", 0))
+        key = (B, sig.numel(), eng.compute_dtype, eng._structs_for, str(dev), float(sigma_data))
+        gkey = "graph:" + solver
+        ent = self._route_cache.get(gkey)
+        fresh = ent is None or ent["key"] != key
+        if not fresh and ent["sched_key"] != sched_key:
+            same_values = (tag is None and ent["sched_key"][1:] == sched_key[1:] and bool(torch.equal(sig, ent["sig"])))
+            ent["sig_ref"] = sigmas if tag is None else None
+            if same_values:
+                ent["sched_key"] = sched_key
+            else:
+                plan = self._two_stage_plan(solver, [float(v) for v in sig.tolist()])          # (host sync: only when the schedule changed)
+                if [e[1:3] + e[4:] for e in plan] != [e[1:3] + e[4:] for e in ent["plan"]]:
+                    fresh = True                                                              # another zero pattern: another chain
+                else:
+                    ent["sig"].copy_(sig); ent["plan"] = plan
+                    ev = torch.tensor([e[0] for e in plan], dtype=torch.float32, device=dev)
+                    with eng.pinned_workspace(ent["ws"]):
+                        self._schedule_state(eng, ev, B, sigma_data, out=ent["sched"], lin=torch.tensor([e[3] for e in plan], dtype=torch.float32))
+                    ent["sched_key"] = sched_key
+        if fresh:
+            plan = self._two_stage_plan(solver, [float(v) for v in sig.tolist()])
+            m = len(plan)
+            st = dict(key=key, img=img.clone(), goals=goals.clone(), sig=sig.clone(), plan=plan,
+                      bufs=[torch.zeros_like(x0).contiguous() for _ in range(3)])
+            st["ws"] = torch.empty(max(eng.workspace_bytes(B, 0), eng.workspace_bytes(0, m)), dtype=torch.uint8, device=dev)
+            ev = torch.tensor([e[0] for e in plan], dtype=torch.float32, device=dev)
+            with eng.pinned_workspace(st["ws"]):
+                st["sched"] = self._schedule_state(eng, ev, B, sigma_data, lin=torch.tensor([e[3] for e in plan], dtype=torch.float32))
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):                            # warm-up: loads code objects
+                    self._plan_steps(eng, st["img"], st["goals"], st["bufs"], st["sched"], plan)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with capture_graph(g):
+                    st["ml"] = self._plan_steps(eng, st["img"], st["goals"], st["bufs"], st["sched"], plan)
+            st["graph"], st["sched_key"] = g, sched_key
+            st["sig_ref"] = sigmas if tag is None else None
+            self._route_cache[gkey] = ent = st
+        ent["img"].copy_(img); ent["goals"].copy_(goals); ent["bufs"][0].copy_(x0)
+        ent["graph"].replay()
+        self._last_topk = ent["sched"]["idx"]
+        self._account_ddim_usage(ent["sched"], ent["ml"], len(ent["plan"]), B * self.seq_len)
+        return ent["bufs"][0].clone()
 
     def _account_ddim_usage(self, sched, ml, n, n_tokens):
         """Expert-usage counters of a whole DDIM run (modedit.py:568-572, 594): one device-side add per chunk, outside the graph."""

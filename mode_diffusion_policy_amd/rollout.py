@@ -66,10 +66,11 @@ def sample_loop(model, sigmas, x_t, state, goal, sampler_type: str = "ddim", ext
 
 # Samplers whose step loop depends on the schedule only (no data-dependent control flow, no host-side noise source): whole call capturable in a hipGraph.
 # Not here: "ddim" and "euler" (without churn the same update: both take MoDeDiT's fused graph, samplers.sample_euler) and "dpmpp_2m" (the same chain with the
-# two-point extrapolation inside the head kernel, samplers.sample_dpmpp_2m -> GCDenoiser.dpmpp_2m_fused), "lms" / "dpmpp_2_with_lms"
+# two-point extrapolation inside the head kernel, samplers.sample_dpmpp_2m -> GCDenoiser.dpmpp_2m_fused), "heun" / "dpm" / "dpmpp_2s" (two-stage solvers: every
+# stage's linear update inside the head kernel, GCDenoiser.two_stage_fused), "lms" / "dpmpp_2_with_lms"
 # (host-side quadrature of the schedule), "dpmpp_2m_sde" (torchsde Brownian tree on the host), "dpm_adaptive" / "dpm_fast" (step sizes from error
 # norms / host floats).
-_GRAPHABLE_SAMPLERS = ("euler_ancestral", "heun", "dpm", "ancestral", "dpmpp_2s", "dpmpp_2s_ancestral")
+_GRAPHABLE_SAMPLERS = ("euler_ancestral", "ancestral", "dpmpp_2s_ancestral")
 
 
 class ChunkedRolloutPolicy:
@@ -136,7 +137,8 @@ class ChunkedRolloutPolicy:
             self.need_precompute_experts_for_inference = False
         sigmas = self._schedule(dev)
         x = torch.randn((len(latent_goal), self.act_window_size, self.action_dim), device=dev, generator=self.generator) * self.sigma_max
-        if self.sampler_type in _GRAPHABLE_SAMPLERS and not extra_args:
+        graphable = _GRAPHABLE_SAMPLERS + (("heun", "dpm", "dpmpp_2s") if __import__("os").environ.get("MODE_TWO_STAGE_FUSED", "1") == "0" else ())
+        if self.sampler_type in graphable and not extra_args:
             out = self._sample_graphed(sigmas, x, perceptual_emb, latent_goal)
             if out is not None:
                 return out

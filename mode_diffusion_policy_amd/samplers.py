@@ -235,10 +235,30 @@ def sample_euler_ancestral(model, state, action, goal, sigmas, scaler=None, extr
     return action
 
 
+def _two_stage_fused(model, state, action, goal, sigmas, solver, draws: bool):
+    """The fused route of the deterministic two-stage solvers (GCDenoiser.two_stage_fused); ``draws``: the reference draws ``eps = randn_like(action)``
+    on every step of this sampler, churn or not - made and discarded here too, so the generator leaves the call as the reference leaves it."""
+    import os
+    if os.environ.get("MODE_TWO_STAGE_FUSED", "1") == "0":               # A/B runs: the step loop (captured whole by the rollout policy, as before)
+        return None
+    fused = getattr(model, "two_stage_fused", None)
+    out = fused(state, action, goal, sigmas, solver) if fused is not None else None
+    if out is not None and draws:
+        for _ in range(len(sigmas) - 1):
+            torch.randn_like(action)
+    return out
+
+
 @torch.no_grad()
 def sample_heun(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, s_churn=0.0, s_tmin=0.0,
                 s_tmax=float("inf"), s_noise=1.0):
-    """Heun (2nd-order) steps of Algorithm 2: Euler predictor, trapezoidal corrector, plain Euler into sigma = 0 (gc_sampling.py:257-312)."""
+    """Heun (2nd-order) steps of Algorithm 2: Euler predictor, trapezoidal corrector, plain Euler into sigma = 0 (gc_sampling.py:257-312).  Without
+    churn, clipping, callback and extra arguments a GCDenoiser over the HIP MoDeDiT takes the whole call as one hipGraph replay (both stages' updates
+    inside the head kernel; same result to fp32 rounding of the multiplied-out recurrence)."""
+    if s_churn <= 0 and scaler is None and callback is None and not extra_args and _chunk_capture() is None:
+        out = _two_stage_fused(model, state, action, goal, sigmas, "heun", draws=True)
+        if out is not None:
+            return out
     run = _Run(model, state, goal, action, extra_args, callback, scaler, "x")
     zeros = _zero_levels(sigmas)
     for i in range(len(sigmas) - 1):
@@ -260,7 +280,11 @@ def sample_heun(model, state, action, goal, sigmas, scaler=None, extra_args=None
 @torch.no_grad()
 def sample_dpm_2(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, s_churn=0.0, s_tmin=0.0,
                  s_tmax=float("inf"), s_noise=1.0):
-    """Midpoint method in log-sigma (DPM-Solver-2 flavoured), Euler into sigma = 0 (gc_sampling.py:315-373)."""
+    """Midpoint method in log-sigma (DPM-Solver-2 flavoured), Euler into sigma = 0 (gc_sampling.py:315-373).  Fused route as in sample_heun."""
+    if s_churn <= 0 and scaler is None and callback is None and not extra_args and _chunk_capture() is None:
+        out = _two_stage_fused(model, state, action, goal, sigmas, "dpm_2", draws=True)
+        if out is not None:
+            return out
     run = _Run(model, state, goal, action, extra_args, callback, scaler, "action")
     zeros = _zero_levels(sigmas)
     for i in range(len(sigmas) - 1):
@@ -388,7 +412,11 @@ def sample_dpmpp_2s_ancestral(model, state, action, goal, sigmas, scaler=None, e
 
 @torch.no_grad()
 def sample_dpmpp_2s(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, eta=1.0):
-    """Deterministic DPM-Solver++(2S) (gc_sampling.py:956-994)."""
+    """Deterministic DPM-Solver++(2S) (gc_sampling.py:956-994).  Fused route as in sample_heun (this sampler draws no noise)."""
+    if scaler is None and callback is None and not extra_args and _chunk_capture() is None:
+        out = _two_stage_fused(model, state, action, goal, sigmas, "dpmpp_2s", draws=False)
+        if out is not None:
+            return out
     run = _Run(model, state, goal, action, extra_args, callback, scaler, "action")
     zeros = _zero_levels(sigmas)
     for i in range(len(sigmas) - 1):

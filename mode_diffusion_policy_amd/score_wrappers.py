@@ -87,5 +87,13 @@ class GCDenoiser(nn.Module):
             return m.sample_ddim_fused(state, action, goal, sigmas, self.sigma_data, solver="dpmpp_2m")
         return None
 
+    def two_stage_fused(self, state, action, goal, sigmas, solver: str):
+        """sample_heun / sample_dpm_2 / sample_dpmpp_2s without churn, clipping or callback as one hipGraph replay (``MoDeDiT.sample_two_stage_fused``:
+        every stage's update is linear and runs inside the head kernel).  None when the fast path does not apply."""
+        m = self.inner_model
+        if isinstance(m, MoDeDiT) and not m.training and not torch.is_grad_enabled() and torch.is_tensor(sigmas) and sigmas.dim() == 1:
+            return m.sample_two_stage_fused(state, action, goal, sigmas, self.sigma_data, solver)
+        return None
+
     def get_params(self):
         return self.inner_model.parameters()

@@ -293,14 +293,19 @@ def test_whole_sampler_call_as_one_graph(dtype, monkeypatch):
         plan[name] = pol.denoise_actions(obs, inp["goals"])
         assert not getattr(pol, "_chunk_graphs", None)
     assert torch.equal(plan["euler"], plan["ddim"])
-    # dpmpp_2m: the fused chain with the two-point extrapolation in the head kernel (no policy-level capture), equal to the step-by-step path
-    pol = rollout.ChunkedRolloutPolicy(den, sampler_type="dpmpp_2m", noise_scheduler="karras", multistep=10, generator=torch.Generator(device="cuda").manual_seed(11))
-    ref = rollout.ChunkedRolloutPolicy(den, sampler_type="dpmpp_2m", noise_scheduler="karras", multistep=10, generator=torch.Generator(device="cuda").manual_seed(11))
-    tokens0 = int(m.blocks[0].total_tokens_processed)
-    p = pol.denoise_actions(obs, inp["goals"])
-    calls = (int(m.blocks[0].total_tokens_processed) - tokens0) // (B * m.seq_len)
-    monkeypatch.setenv("MODE_HIP_GRAPH", "0")
-    r = ref.denoise_actions(obs, inp["goals"])
-    monkeypatch.delenv("MODE_HIP_GRAPH")
-    assert not getattr(pol, "_chunk_graphs", None) and calls == 10
-    assert float((p - r).norm() / r.norm()) < tol and not torch.equal(p, plan["ddim"])
+    # dpmpp_2m (two-point extrapolation in the head kernel) and the two-stage solvers (both stages' linear updates in the head kernel): the fused chain,
+    # no policy-level capture, the same number of denoiser calls accounted, equal to the step-by-step path
+    for name, want_calls in (("dpmpp_2m", 10), ("heun", 19), ("dpm", 19), ("dpmpp_2s", 19)):
+        pol = rollout.ChunkedRolloutPolicy(den, sampler_type=name, noise_scheduler="karras", multistep=10, generator=torch.Generator(device="cuda").manual_seed(11))
+        ref = rollout.ChunkedRolloutPolicy(den, sampler_type=name, noise_scheduler="karras", multistep=10, generator=torch.Generator(device="cuda").manual_seed(11))
+        for it in range(2):
+            o = {"state_images": inp["state_images"] * (1 + 0.1 * it)}
+            tokens0 = int(m.blocks[0].total_tokens_processed)
+            p = pol.denoise_actions(o, inp["goals"])
+            calls = (int(m.blocks[0].total_tokens_processed) - tokens0) // (B * m.seq_len)
+            monkeypatch.setenv("MODE_HIP_GRAPH", "0")
+            r = ref.denoise_actions(o, inp["goals"])
+            monkeypatch.delenv("MODE_HIP_GRAPH")
+            assert not getattr(pol, "_chunk_graphs", None) and calls == want_calls, (name, calls)
+            assert float((p - r).norm() / r.norm()) < tol, (name, it, float((p - r).norm() / r.norm()))
+        assert not torch.equal(p, plan["ddim"])

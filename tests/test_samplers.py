@@ -287,3 +287,39 @@ def test_dpmpp_2m_takes_the_fused_multistep_chain(dtype):
         assert den.dpmpp_2m_fused(state, inp["x0"], inp["goals"], sig) is None
     finally:
         m.eval()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_two_stage_solvers_take_the_fused_chain(dtype):
+    """sample_heun / sample_dpm_2 / sample_dpmpp_2s (no churn, clipping, callback) on the HIP denoiser: one hipGraph replay with both stages' linear updates
+    inside the head kernel (ModeHeadDesc.lin) - equal to their own step loops (forced by a callback) to fp32 rounding of the multiplied-out recurrence,
+    for two schedules and a two-level schedule (a single Euler step into sigma = 0), repeatable, a new schedule on the cached graph, the generator left
+    where the step loop leaves it, and never in training mode."""
+    from test_gpu_model import build
+    cfg, sd, m = build("c1e4", 79, dtype)
+    den = M.GCDenoiser(m, 0.5).eval()
+    inp = {k: v.cuda() for k, v in make_inputs(cfg, 6, 12).items()}
+    state = {"state_images": inp["state_images"]}
+    tol = 1e-5 if dtype == "fp32" else BF16_OUT
+    fns = {"heun": samplers.sample_heun, "dpm_2": samplers.sample_dpm_2, "dpmpp_2s": samplers.sample_dpmpp_2s}
+    for name, fn in fns.items():
+        for sig in (gc_sampling.get_sigmas_exponential(10, 0.001, 80.0, "cuda"), gc_sampling.get_sigmas_karras(6, 0.01, 40.0, 7.0, "cuda"),
+                    gc_sampling.get_sigmas_exponential(1, 0.5, 0.5, "cuda")):
+            steps = []
+            torch.cuda.manual_seed(5)
+            loop = fn(den, state, inp["x0"], inp["goals"], sig, disable=True, callback=lambda d: steps.append(d["i"]))
+            after_loop = torch.randn(3, device="cuda")
+            assert steps == list(range(len(sig) - 1))
+            torch.cuda.manual_seed(5)
+            fused = fn(den, state, inp["x0"], inp["goals"], sig, disable=True)
+            after_fused = torch.randn(3, device="cuda")
+            assert torch.equal(after_loop, after_fused), name
+            assert rel(fused, loop) < tol, (name, len(sig), rel(fused, loop))
+            assert torch.equal(fused, fn(den, state, inp["x0"], inp["goals"], sig, disable=True))
+        assert "graph:" + name in m._route_cache
+    m.train()
+    try:
+        assert den.two_stage_fused(state, inp["x0"], inp["goals"], gc_sampling.get_sigmas_exponential(4, 0.01, 10.0, "cuda"), "heun") is None
+    finally:
+        m.eval()
