@@ -323,3 +323,37 @@ def test_two_stage_solvers_take_the_fused_chain(dtype):
         assert den.two_stage_fused(state, inp["x0"], inp["goals"], gc_sampling.get_sigmas_exponential(4, 0.01, 10.0, "cuda"), "heun") is None
     finally:
         m.eval()
+
+
+def test_two_stage_plans_reproduce_the_reference_samplers_on_the_oracle_denoiser(golden):
+    """Host logic of the fused two-stage solvers (MoDeDiT._two_stage_plan: which sigma each denoiser evaluation sees, which buffers it reads / writes, the four
+    coefficients of its linear update) executed on the CPU with the ORACLE's denoiser: the multiplied-out recurrences reproduce the reference's heun /
+    dpm_2 / dpmpp_2s outputs (F10) for every schedule of the fixture - the same plan drives the head kernel on the GPU."""
+    from mode_diffusion_policy_amd.modedit import MoDeDiT
+    g = golden("F10_samplers")
+    cfg = get_config("c1e4"); sd = make_state_dict(cfg, int(g["seed"])); inp = make_inputs(cfg, 8, int(g["seed"]) + 1)
+    seen = 0
+    for key in g.files:
+        if ":" not in key:
+            continue
+        name, sched = key.split(":")
+        if name not in ("heun", "dpm_2", "dpmpp_2s"):
+            continue
+        sig = torch.from_numpy(g[f"sigmas_{sched}"])
+        plan = MoDeDiT._two_stage_plan(name, [float(v) for v in sig.tolist()])
+        assert len(plan) == 2 * (len(sig) - 1) - int(float(sig[-1]) == 0.0)
+        bufs = [inp["x0"].clone().double(), torch.zeros_like(inp["x0"]).double(), torch.zeros_like(inp["x0"]).double()]
+        for sigma, xin, xout, lin, a1, a2, dout in plan:
+            x = bufs[xin]
+            den = O.denoiser_forward(sd, cfg, 0.5, inp["state_images"], x.float(), inp["goals"], torch.full((8,), sigma)).double()
+            v = lin[0] * x + lin[1] * den
+            if a1 is not None:
+                v = v + lin[2] * bufs[a1]
+            if a2 is not None:
+                v = v + lin[3] * bufs[a2]
+            if dout is not None:
+                bufs[dout] = den
+            bufs[xout] = v
+        assert rel(bufs[0], g[key]) < 2e-5, (key, rel(bufs[0], g[key]))
+        seen += 1
+    assert seen >= 3
