@@ -406,13 +406,7 @@ class MoDeDiT(nn.Module):
             n = sig.numel() - 1
             s, nxt = sig[:-1].contiguous(), sig[1:]
         s2 = s * s + sigma_data ** 2
-        ms = torch.zeros_like(s)
-        if solver == "dpmpp_2m" and n > 1:
-            # DPM-Solver++(2M), gc_sampling.py:700-734: from the second step on (and not into sigma = 0) the update takes (1 + 1/(2r)) D - (1/(2r)) D_old
-            # for D, r = h_last / h in t = -ln sigma; scal[:, 3] = 1/(2r) in the reference's operation order, 0 where the plain step applies
-            h = s.log() - nxt.log()
-            r = h[:-1] / h[1:]
-            ms[1:] = torch.where(nxt[1:] > 0, 1.0 / (2.0 * r), torch.zeros_like(r))
+        ms = self._dpmpp_2m_weights(sig) if (solver == "dpmpp_2m" and lin is None) else torch.zeros_like(s)
         st = dict(c_in=(1.0 / s2.sqrt()).contiguous(),
                   scal=torch.stack([sigma_data ** 2 / s2, s * sigma_data / s2.sqrt(), nxt / s, ms], 1).contiguous(),
                   emb_all=eng.sigma_embed(s))                            # [n, D]: one conditioning row per step
@@ -436,6 +430,19 @@ class MoDeDiT(nn.Module):
             out[k_].copy_(st[k_])
         out["from_cache"] = st["from_cache"]
         return out
+
+    @staticmethod
+    def _dpmpp_2m_weights(sig):
+        """DPM-Solver++(2M), gc_sampling.py:700-734: from the second step on (and not into sigma = 0) the update takes (1 + 1/(2r)) D - (1/(2r)) D_old for D,
+        r = h_last / h in t = -ln sigma.  Returns [n] fp32: 1/(2r) per step in the reference's operation order, 0 where the plain step applies
+        (the head kernel's scal[:, 3], ModeHeadDesc.den_prev)."""
+        s, nxt = sig[:-1], sig[1:]
+        ms = torch.zeros_like(s)
+        if s.numel() > 1:
+            h = s.log() - nxt.log()
+            r = h[:-1] / h[1:]
+            ms[1:] = torch.where(nxt[1:] > 0, 1.0 / (2.0 * r), torch.zeros_like(r))
+        return ms
 
     def _ddim_steps(self, eng, img, goals, x, sched, n: int, den=None):
         """The observation-dependent launch chain of a DDIM run: embeddings of the observations + n denoiser forwards with the fused EDM / DDIM

@@ -357,3 +357,28 @@ def test_two_stage_plans_reproduce_the_reference_samplers_on_the_oracle_denoiser
         assert rel(bufs[0], g[key]) < 2e-5, (key, rel(bufs[0], g[key]))
         seen += 1
     assert seen >= 3
+
+
+def test_dpmpp_2m_multistep_weights_reproduce_the_reference_on_the_oracle_denoiser(golden):
+    """Host logic of the fused DPM-Solver++(2M) chain (MoDeDiT._dpmpp_2m_weights -> scal[:, 3]) with the head kernel's update written out on the CPU:
+    x <- r x + (1 - r) ((1 + c) D - c D_old), c = 0 on the first step and into sigma = 0 - the reference's outputs (F10) on the oracle's denoiser."""
+    from mode_diffusion_policy_amd.modedit import MoDeDiT
+    g = golden("F10_samplers")
+    cfg = get_config("c1e4"); sd = make_state_dict(cfg, int(g["seed"])); inp = make_inputs(cfg, 8, int(g["seed"]) + 1)
+    seen = 0
+    for key in g.files:
+        if not key.startswith("dpmpp_2m:"):
+            continue
+        sig = torch.from_numpy(g["sigmas_" + key.split(":")[1]])
+        c = MoDeDiT._dpmpp_2m_weights(sig)
+        assert float(c[0]) == 0.0 and (float(sig[-1]) != 0.0 or float(c[-1]) == 0.0) and bool((c[1:-1] > 0).all())
+        x = inp["x0"].clone(); prev = None
+        for i in range(len(sig) - 1):
+            den = O.denoiser_forward(sd, cfg, 0.5, inp["state_images"], x, inp["goals"], sig[i] * torch.ones(8))
+            dd = den if (prev is None or float(c[i]) == 0.0) else (1.0 + c[i]) * den - c[i] * prev
+            r = sig[i + 1] / sig[i]
+            x = r * x + (1.0 - r) * dd
+            prev = den
+        assert rel(x, g[key]) < 2e-5, (key, rel(x, g[key]))
+        seen += 1
+    assert seen >= 1
