@@ -28,7 +28,15 @@ class FusedAdamW:
     BEFORE ``loss.backward()`` (a scheduler stepped after ``optimizer.step()``, as Lightning does, satisfies that) and pass a gradient scale via
     ``opt.fused_grad_scale``.  Results are bit-identical to the two-pass update (same gradient bits, same expression order).
     ``p.grad`` of the expert matrices is not produced in this mode; ``opt.fused_grad_sq()`` returns their squared gradient norm for logging
-    (mode_agent.py:304-363)."""
+    (mode_agent.py:304-363).
+
+    The expert update is IRREVERSIBLE once ``loss.backward()`` has run, so everything that can refuse the step is checked before the chain launches
+    (``fused_step_struct``: arena identity, world size, accumulation, frozen experts; a registered ``fused_ema`` is allocated there, i.e. from the
+    pre-update weights).  ``step()`` never leaves a half-applied step behind: when its arguments disagree with what the backward applied (a different
+    ``grad_scale``, a multi-rank reducer, an EMA that did not exist before the backward) it first COMPLETES the step with the backward's settings -
+    remaining 12 % of the parameters, ``step_count``, shadow versions - and only then raises.  Skipping ``step()`` after a fused backward (e.g. a
+    non-finite-loss guard) is unsupported - the experts have already moved; call ``finish_fused_step()`` to bring the rest of the arena to the same
+    step before continuing."""
 
     def __init__(self, model, lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
                  fuse_expert_step: bool = False, fused_side_stream: bool = True):
@@ -57,11 +65,34 @@ class FusedAdamW:
         self.fused_side_stream = bool(fused_side_stream) and os.environ.get("MODE_FUSED_SIDE_STREAM", "1") == "1"
         self._fused_side = None                                  # (stream, [4 events], ctypes array of their handles)
         if self.fuse_expert_step:
-            if eng.compute_dtype != "bf16":
+            self.fuse_expert_step = False
+            self.set_fuse_expert_step(True)                      # model._fused_optimizer = self: training.py's backward asks this object for the ModeAdamWFuse of the step
+
+    def set_fuse_expert_step(self, on: bool) -> None:
+        """Switch the fused expert step on / off between optimizer steps (same object, same moment buffers: `bench.py` times both modes on the state it
+        allocated at start-up).  Refused while a fused backward is pending."""
+        if self._fused_pending:
+            raise RuntimeError("set_fuse_expert_step(): a fused backward is pending - call step() / finish_fused_step() first")
+        on = bool(on)
+        if on:
+            if self.eng.compute_dtype != "bf16":
                 raise ValueError("fuse_expert_step needs the bf16 compute mode (the fused epilogue lives in the bf16 weight-gradient GEMM)")
-            if model.embed_dim % 128:
+            if self.model.embed_dim % 128:
                 raise ValueError("fuse_expert_step needs embed_dim % 128 == 0 (128-column tiles of the fused weight-gradient launches)")
-            model._fused_optimizer = self                        # training.py's backward asks this object for the ModeAdamWFuse of the step
+            self.model._fused_optimizer = self
+        elif getattr(self.model, "_fused_optimizer", None) is self:
+            self.model._fused_optimizer = None
+        self.fuse_expert_step = on
+
+    def reset_state(self) -> None:
+        """Back to a freshly constructed optimizer WITHOUT re-allocating: moments zeroed in place, step count 0."""
+        if self._fused_pending:
+            raise RuntimeError("reset_state(): a fused backward is pending - call step() / finish_fused_step() first")
+        if self._state_sharded or self._master_sharded:
+            raise RuntimeError("reset_state(): ZeRO-1 state is sharded - call gather_state(reducer) first")
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        self.step_count = 0
+        self.arena.grad_pending = False
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         """The next backward overwrites the gradient arena instead of accumulating into it (no memset pass: the backward chain writes every
@@ -98,8 +129,9 @@ class FusedAdamW:
         ar.ensure_grad(self.model)
         gd = self.param_groups[0]
         ema_base, rate = None, 0.0
+        if self.fused_ema is not None:
+            self.fused_ema.ensure(ar)                            # (first call: a copy of the PRE-update weights, as the callback's on_train_start makes it)
         if self.fused_ema is not None and self.fused_ema.should_apply(self.step_count + 1):
-            self.fused_ema.ensure(ar)
             ema_base, rate = self.fused_ema.flat.data_ptr(), 1.0 - self.fused_ema.get_decay(self.step_count + 1)
         if self._fused_gsq is None:
             n = int(eng.lib.mode_adamw_fuse_gsq_floats(C.byref(eng.dims)))
@@ -131,6 +163,14 @@ class FusedAdamW:
         if self._fused_gsq is None:
             raise RuntimeError("no fused backward has run yet")
         return self._fused_gsq.double().sum()
+
+    def finish_fused_step(self) -> None:
+        """Completes a fused step whose expert update already ran inside ``loss.backward()``: the remaining parameters take the same optimizer step
+        (the backward's ``fused_grad_scale``, the registered ``fused_ema``), ``step_count`` advances, the pending flag clears.  This is what
+        ``step()`` does in fused mode; call it directly where a training loop would otherwise SKIP ``step()`` (a skipped step is not supported in
+        this mode - see the class docstring).  No-op when nothing is pending."""
+        if self._fused_pending:
+            self.step()
 
     def _frozen_ranges(self):
         """Arena element ranges of parameters with ``requires_grad == False`` (``freeze_router()`` for fine-tuning, mode_agent.py:762-766):
@@ -236,9 +276,8 @@ class FusedAdamW:
         the ranks with different step counts / partially updated slices)."""
         if zero1 not in ("fp32", "bf16"):
             raise ValueError("zero1 must be None, 'fp32' or 'bf16'")
-        if ema is not None and ema.should_apply(self.step_count + 1):
-            raise NotImplementedError("ZeRO-1 step with a fused EMA (each rank only updates its shard): step without `ema=`, then call "
-                                      "opt.gather_state(reducer) and ArenaEMA.update(step) - the stand-alone pass must see exact masters")
+        # (an `ema=` is sharded like the moments: each rank averages its own shard - where it holds exact fp32 masters in both gather modes - and
+        #  gather_state() completes it; mode/callbacks/ema.py:101-126 runs the callback on every rank after every optimizer step)
         ar = self.arena
         n_red, dec, world = ar.bounds["no_decay"], ar.bounds["decay"], reducer.world
         spans = sorted((sl[0], sl[1]) for sl in reducer.slices)
@@ -254,7 +293,7 @@ class FusedAdamW:
     @torch.no_grad()
     def gather_state(self, reducer) -> None:
         """After ZeRO-1 steps every rank holds current Adam moments (and, with ``zero1='bf16'``, exact fp32 masters) for its OWN shards only.
-        All-gathers ``exp_avg`` / ``exp_avg_sq`` per slice and the masters, so that ``state_dict()`` / a checkpoint written by any rank - or a
+        All-gathers ``exp_avg`` / ``exp_avg_sq`` (and every EMA that was passed to those steps) per slice and the masters, so that ``state_dict()`` / a checkpoint written by any rank - or a
         stand-alone ``ArenaEMA.update`` - sees the complete, exact state.  Collective: all ranks call it."""
         self.gather_master(reducer)
         if getattr(self, "_state_sharded", False):
@@ -262,9 +301,15 @@ class FusedAdamW:
             for sl in reducer.slices:
                 for buf in (self.exp_avg, self.exp_avg_sq):
                     evs.append(reducer.all_gather_async(buf, sl[0], sl[1], after=None))
+            for em in getattr(self, "_sharded_emas", []):             # EMAs updated inside ZeRO-1 steps: every rank averaged its own shards
+                for sl in reducer.slices:
+                    evs.append(reducer.all_gather_async(em.flat, sl[0], sl[1], after=None))
             for e in evs:
                 if e is not None:
                     torch.cuda.current_stream().wait_event(e)
+            for em in getattr(self, "_sharded_emas", []):
+                em._sharded = False
+            self._sharded_emas = []
             self._state_sharded = False
 
     @torch.no_grad()
@@ -279,7 +324,7 @@ class FusedAdamW:
         self._master_sharded = False
 
     @torch.no_grad()
-    def step(self, grad_scale: float = 1.0, overlap: bool = False, reducer=None, ema=None, zero1=None) -> None:
+    def step(self, grad_scale=None, overlap: bool = False, reducer=None, ema=None, zero1=None) -> None:
         """One AdamW update of the whole arena.
 
         Default: (exchange gradients through ``reducer`` — its collectives overlap the backward —, then) two launches over the decay / no-decay
@@ -305,18 +350,30 @@ class FusedAdamW:
         if ar.grad is None:
             raise RuntimeError("no gradients: run a training forward + backward first")
         use_zero1 = bool(zero1) and reducer is not None and eng.device.type == "cuda"
-        if use_zero1:
-            self._validate_zero1(reducer, zero1, ema)
         fused = self._fused_pending
         if self.fuse_expert_step and not fused:
             raise RuntimeError("fuse_expert_step: optimizer.step() without a fused backward since the last step (was the loss back-propagated "
                                "through MoDeDiT in training mode?)")
+        deferred = None                                         # fused mode: a disagreement with what the backward applied - the step is COMPLETED first (class docstring)
         if fused:
+            done_msg = "; the step was completed with the backward's settings (parameters, moments and step count are consistent)"
             if use_zero1 or (reducer is not None and reducer.world > 1):
-                raise NotImplementedError("fuse_expert_step is a single-process mode: the expert matrices were updated from this rank's gradients only")
-            if float(grad_scale) != float(self.fused_grad_scale):
-                raise ValueError(f"step(grad_scale={grad_scale}) differs from the scale the fused backward applied ({self.fused_grad_scale}): set "
-                                 "opt.fused_grad_scale before loss.backward()")
+                deferred = NotImplementedError("fuse_expert_step is a single-process mode: the expert matrices were updated from this rank's gradients only" + done_msg)
+                reducer, use_zero1 = None, False
+            if grad_scale is not None and float(grad_scale) != float(self.fused_grad_scale):
+                deferred = ValueError(f"step(grad_scale={grad_scale}) differs from the scale the fused backward applied ({self.fused_grad_scale}): set "
+                                      "opt.fused_grad_scale before loss.backward()" + done_msg)
+            grad_scale = self.fused_grad_scale
+            if ema is not None and ema is not self.fused_ema and ema.flat is None and ema.should_apply(self.step_count + 1) \
+                    and ema.get_decay(self.step_count + 1) != 0.0:
+                # this EMA did not exist when the backward updated the experts: its first copy would start from post-update expert weights (with a zero
+                # decay - the schedule's first step - the average equals the new weights either way and nothing is lost)
+                deferred = RuntimeError("fuse_expert_step: register the EMA as opt.fused_ema (or call ema.ensure(arena)) BEFORE the first backward - it is "
+                                        "initialised from the pre-update weights" + done_msg)
+        if grad_scale is None:
+            grad_scale = 1.0
+        if use_zero1:
+            self._validate_zero1(reducer, zero1, ema)
         self.step_count += 1
         self._frozen = self._frozen_ranges()
         if fused:                                               # the expert matrices are done: the passes below skip them exactly like frozen tensors
@@ -330,10 +387,15 @@ class FusedAdamW:
             self._frozen = merged
             self._fused_pending = False
         self._ema_now = (None, 0.0)
+        fe = self.fused_ema if fused else None                   # the backward applied this EMA to the expert matrices iff its schedule says so for this step
+        fe_rest = fe is not None and fe is not ema and fe.should_apply(self.step_count)
         if ema is not None and ema.should_apply(self.step_count):
             ema.ensure(ar)
             self._ema_now = (ema, 1.0 - ema.get_decay(self.step_count))
             ema.mark_applied(self.step_count)
+            if use_zero1 and reducer.world > 1:
+                ema._sharded = True                              # current on this rank's shards only until gather_state()
+                self._sharded_emas = [e for e in getattr(self, "_sharded_emas", []) if e is not ema] + [ema]
         lp = ar.lp if eng.compute_dtype == "bf16" else None
         gd, gn = self.param_groups
         train = getattr(eng, "_train", None)
@@ -374,9 +436,9 @@ class FusedAdamW:
             ema_, rate_ = self._ema_now                          # the fused epilogue did not know about this EMA: one stand-alone pass over the expert ranges
             for lo_, hi_ in self._expert_ranges():
                 L.check(eng.lib.mode_ema_update(ema_.flat[lo_:hi_].data_ptr(), ar.flat[lo_:hi_].data_ptr(), hi_ - lo_, float(rate_), _stream()), "ema_update")
-        if fused and self.fused_ema is not None and self.fused_ema.should_apply(self.step_count) and self._ema_now[0] is None:
-            # the fused epilogue applied the EMA to the expert matrices; the rest of the arena follows here (ema= was not passed to step())
-            ema_ = self.fused_ema
+        if fe_rest:
+            # the fused epilogue applied the registered EMA to the expert matrices; the rest of the arena follows here (step() got no ema=, or another one)
+            ema_ = fe
             rate_ = 1.0 - ema_.get_decay(self.step_count)
             n_all = ar.bounds["total"]
             prev = 0
@@ -387,6 +449,8 @@ class FusedAdamW:
             ema_.mark_applied(self.step_count)
         eng.weights_updated(lp_synced=lp is not None)
         ar.grad_pending = False                                  # gradients consumed: the next backward starts a fresh sum
+        if deferred is not None:
+            raise deferred
 
     # ---- checkpointing (same information as torch's optimizer state, flat)
     def state_dict(self) -> Dict:
@@ -410,9 +474,10 @@ class FlatAdamW:
     strides incl. channels_last, ``state_dict`` untouched - what ``arena.py`` does for the denoiser) and their ``.grad`` at views of a flat gradient
     buffer that autograd accumulates into in place.  Same arithmetic as ``FusedAdamW`` (``adamw_update_f``), i.e. torch's single-tensor order.
 
-    Difference from torch, by construction: a parameter that receives NO gradient in a step is still decayed and its moments still decay (torch skips
-    it) - hand this class parameters that are all trained.  The update
-    writes through raw pointers, so the parameters' version counters are bumped explicitly (cached bf16 weight shadows must notice)."""
+    Like torch, a parameter whose ``.grad`` is None in a step is SKIPPED (no decay, moments untouched: FiLM modules that saw no conditioning vector,
+    parameters frozen later): the flat launch is cut into the runs of tensors that do have a gradient.  The update writes through raw pointers, so the
+    parameters' version counters are bumped explicitly (cached bf16 weight shadows must notice); a parameter whose storage was re-pointed after
+    construction (``module.to()`` / ``.half()``) is refused in ``step()`` rather than silently left behind."""
 
     def __init__(self, params, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
         groups = list(params)
@@ -447,7 +512,11 @@ class FlatAdamW:
             grp.setdefault("lr", lr); grp.setdefault("betas", betas); grp.setdefault("eps", eps); grp.setdefault("weight_decay", weight_decay)
             grp["params"] = ps
             self.param_groups.append(grp)
-            self._flat.append(dict(flat=flat, grad=grad, views=views, exp_avg=torch.zeros(n, device=dev), exp_avg_sq=torch.zeros(n, device=dev), n=n))
+            offs, o = [], 0
+            for sz in sizes:
+                offs.append((o, o + sz)); o += sz
+            self._flat.append(dict(flat=flat, grad=grad, views=views, exp_avg=torch.zeros(n, device=dev), exp_avg_sq=torch.zeros(n, device=dev), n=n,
+                                   spans=offs, ptrs=[p.data_ptr() for p in ps]))
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         """``set_to_none=True`` (default, like torch): drop the gradients - the next backward hands autograd-owned tensors to ``.grad`` (no accumulation
@@ -467,19 +536,25 @@ class FlatAdamW:
     def step(self, grad_scale: float = 1.0) -> None:
         self.step_count += 1
         for grp, f in zip(self.param_groups, self._flat):
-            src, dst, missing = [], [], []
-            for p, gv in zip(grp["params"], f["views"]):
+            src, dst, runs = [], [], []
+            for p, gv, (lo, hi), ptr in zip(grp["params"], f["views"], f["spans"], f["ptrs"]):
+                if p.data_ptr() != ptr:
+                    raise RuntimeError("FlatAdamW: a parameter's storage moved after construction (module.to() / .half()?): create a new FlatAdamW")
                 if p.grad is None:
-                    missing.append(gv)                                          # (torch would skip the tensor; here it sees a zero gradient - see the class docstring)
-                elif p.grad.data_ptr() != gv.data_ptr():
+                    continue                                                    # torch skips a tensor without a gradient: no decay, moments untouched
+                if p.grad.data_ptr() != gv.data_ptr():
                     src.append(p.grad); dst.append(gv)
+                if runs and runs[-1][1] == lo:
+                    runs[-1][1] = hi
+                else:
+                    runs.append([lo, hi])
             if dst:
                 torch._foreach_copy_(dst, src)                                  # all gradients into the flat buffer: one multi-tensor launch
-            if missing:
-                torch._foreach_zero_(missing)
-            L.check(self.lib.mode_adamw_step(f["flat"].data_ptr(), f["grad"].data_ptr(), f["exp_avg"].data_ptr(), f["exp_avg_sq"].data_ptr(), f["n"],
-                                             float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]), float(grp["weight_decay"]),
-                                             self.step_count, float(grad_scale), None, None, 0.0, _stream()), "adamw_step")
+            for lo, hi in runs:                                                 # ONE launch when every tensor has a gradient (the usual step)
+                L.check(self.lib.mode_adamw_step(f["flat"][lo:hi].data_ptr(), f["grad"][lo:hi].data_ptr(), f["exp_avg"][lo:hi].data_ptr(),
+                                                 f["exp_avg_sq"][lo:hi].data_ptr(), hi - lo, float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]),
+                                                 float(grp["eps"]), float(grp["weight_decay"]), self.step_count, float(grad_scale), None, None, 0.0, _stream()),
+                        "adamw_step")
             torch.autograd.graph.increment_version(grp["params"])                 # raw-pointer write: version-gated caches (conv weight shadows) must see it
 
     def state_dict(self) -> Dict:
@@ -511,6 +586,12 @@ class ArenaEMA:
         self.inv_gamma, self.power, self.min_value, self.max_value = inv_gamma, power, min_value, max_value
         self.flat = None
         self._cur_step = None
+        self._sharded = False                                    # True between a ZeRO-1 step(ema=self) and FusedAdamW.gather_state(): own shards only
+
+    def _need_complete(self, what: str) -> None:
+        if self._sharded:
+            raise RuntimeError(f"ArenaEMA.{what}: the average is current on each rank's own shards only after ZeRO-1 steps - call "
+                               "optimizer.gather_state(reducer) on every rank first")
 
     def get_decay(self, optimization_step: int) -> float:
         step = max(0, optimization_step - self.start_step - 1)
@@ -533,6 +614,7 @@ class ArenaEMA:
         sharded (bf16-rounded) masters refused instead of averaged."""
         if not self.should_apply(step):
             return
+        self._need_complete("update()")
         if optimizer is not None and (getattr(optimizer, "_master_sharded", False)):
             raise RuntimeError("ArenaEMA.update(): the fp32 masters of the other ranks' shards are bf16-rounded after zero1='bf16' steps - call "
                                "optimizer.gather_state(reducer) first")
@@ -545,6 +627,7 @@ class ArenaEMA:
     @torch.no_grad()
     def swap(self) -> None:
         """Exchange the live weights with the averaged ones (call again to swap back)."""
+        self._need_complete("swap()")
         eng = self.model.engine
         self.ensure(eng.arena)
         tmp = eng.arena.flat.clone()

@@ -137,7 +137,7 @@ class ChunkedRolloutPolicy:
             self.need_precompute_experts_for_inference = False
         sigmas = self._schedule(dev)
         x = torch.randn((len(latent_goal), self.act_window_size, self.action_dim), device=dev, generator=self.generator) * self.sigma_max
-        graphable = _GRAPHABLE_SAMPLERS + (("heun", "dpm", "dpmpp_2s") if __import__("os").environ.get("MODE_TWO_STAGE_FUSED", "1") == "0" else ())
+        graphable = _GRAPHABLE_SAMPLERS + (("heun", "dpm", "dpmpp_2s") if os.environ.get("MODE_TWO_STAGE_FUSED", "1") == "0" else ())
         if self.sampler_type in graphable and not extra_args:
             out = self._sample_graphed(sigmas, x, perceptual_emb, latent_goal)
             if out is not None:
@@ -245,6 +245,13 @@ def _read_checkpoint_file(path: str) -> Dict[str, torch.Tensor]:
     try:
         blob = torch.load(path, map_location="cpu", weights_only=True)
     except Exception as safe_err:                                               # pickle.UnpicklingError and friends: non-tensor objects in the file
+        # Full unpickling executes whatever the file says: only on the caller's explicit say-so (Lightning checkpoints carry omegaconf objects and need it;
+        # the reference's own loader, mode_agent.py:135-160, reads the cleaned tensor files above, which never get here)
+        if not (trust_pickle or os.environ.get("MODE_TRUST_CKPT", "0") == "1"):
+            raise RuntimeError(f"cannot read checkpoint {path} with weights_only=True ({safe_err!r}); pass trust_pickle=True / set MODE_TRUST_CKPT=1 to allow "
+                               "full unpickling of a file you trust") from safe_err
+        import warnings
+        warnings.warn(f"loading {path} with the full unpickler (trusted by the caller)")
         try:
             blob = torch.load(path, map_location="cpu", weights_only=False)
         except Exception as e:

@@ -23,5 +23,15 @@ if "layers" in legs:
     bench.layer_kernel_breakdown(den, dev)
 if "extras" in legs:
     bench.extra_measurements(M, den, dev)
-t = bench.train_leg(den, dev, 1, 0, None)
-print(json.dumps({"legs": legs, "train_ms": t["train_ms_per_step"]}), flush=True)
+if "flush" in legs:
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+if "prealloc" in legs:                      # (set before everything else by the env var below)
+    pass
+with bench.PowerSampler(0, period_s=0.01) as ps:
+    t = bench.train_leg(den, dev, 1, 0, None, steps=int(os.environ.get("PROBE_STEPS", "10")))
+st = torch.cuda.memory_stats()
+print(json.dumps({"legs": legs, "train_ms": t["train_ms_per_step"], "blocks": t["train_ms_per_step_blocks"],
+                  "power": {k: v for k, v in ps.summary().items() if k in ("socket_w_avg", "sclk_mhz_avg", "sclk_mhz_min")},
+                  "reserved_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 2), "allocated_gb": round(torch.cuda.memory_allocated() / 2 ** 30, 2),
+                  "segments": st.get("segment.all.current")}), flush=True)

@@ -654,6 +654,28 @@ def test_flat_adamw_matches_torch_adamw_on_an_encoder():
     assert g0.data_ptr() == oa._flat[0]["views"][0].data_ptr() and float(g0.abs().max()) > 0
     sd = oa.state_dict()
     assert sd["step"] == 3 and len(sd["exp_avg"]) == 2
+    # a step in which some tensors have NO gradient (no conditioning vector seen / frozen later): torch skips them - no decay, moments untouched
+    oa.zero_grad(set_to_none=True); ob.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        (b(img, cond).float() ** 2).mean().backward()
+    skipped = [n for i, (n, _) in enumerate(a.named_parameters()) if i % 3 == 1]
+    before = {n: p.detach().clone() for n, p in a.named_parameters() if n in skipped}
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if n in skipped:
+            pa.grad = None; pb.grad = None
+        else:
+            pa.grad = pb.grad.detach().clone()
+    oa.step(); ob.step()
+    torch.cuda.synchronize()
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel(pa.detach(), pb.detach()) < 2e-6, n
+        if n in skipped:
+            assert torch.equal(pa.detach(), before[n]), n
+    # storage re-pointed behind the optimizer's back is refused, not silently left behind
+    p0 = next(iter(a.parameters()))
+    p0.data = p0.data.clone()
+    with pytest.raises(RuntimeError, match="storage moved"):
+        oa.step()
 
 
 @pytest.mark.gpu

@@ -221,14 +221,43 @@ def test_fused_expert_step_is_bit_identical_to_the_two_pass_update(stochastic, e
     # misuse
     with pytest.raises(RuntimeError, match="without a fused backward"):
         ob.step()
+    # the expert update inside the backward is irreversible: a step() whose arguments disagree with it COMPLETES the step (the backward's scale) and
+    # only then raises - parameters, moments and the step count stay consistent and the next backward is accepted
+    torch.manual_seed(500); torch.cuda.manual_seed(500)
+    la, _ = dena.loss(st, inp["actions"], inp["goals"], inp["noise"], sig); la.backward(); oa.step(ema=ea)
+    torch.manual_seed(500); torch.cuda.manual_seed(500)
     lb, _ = denb.loss(st, inp["actions"], inp["goals"], inp["noise"], sig)
     lb.backward()
-    with pytest.raises(ValueError, match="grad_scale"):
-        ob.step(grad_scale=0.5)
+    n_before = ob.step_count
+    with pytest.raises(ValueError, match="grad_scale.*completed"):
+        ob.step(grad_scale=0.5, ema=eb)
+    assert ob.step_count == n_before + 1 and not ob._fused_pending
+    torch.cuda.synchronize()
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(pa.detach(), pb.detach()), n
+    assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
+    if ema:
+        assert torch.equal(ea.flat, eb.flat)
+    # gradient accumulation is refused BEFORE the second chain runs; a skipped step() is finished by finish_fused_step()
+    lb, _ = denb.loss(st, inp["actions"], inp["goals"], inp["noise"], sig)
+    lb.backward()
     l2, _ = denb.loss(st, inp["actions"], inp["goals"], inp["noise"], sig)
     with pytest.raises(RuntimeError, match="gradient accumulation"):
         l2.backward()
-    ob.step()
+    ob.finish_fused_step()
+    assert ob.step_count == n_before + 2 and not ob._fused_pending
+    ob.finish_fused_step()                                                      # nothing pending: no-op
+    assert ob.step_count == n_before + 2
+    # an EMA that did not exist when the backward ran (and whose schedule would average, decay != 0): completed, then refused
+    lb, _ = denb.loss(st, inp["actions"], inp["goals"], inp["noise"], sig)
+    lb.backward()
+    late = ArenaEMA(mb, decay=0.99)
+    if ob.fused_ema is None:
+        with pytest.raises(RuntimeError, match="BEFORE the first backward.*completed"):
+            ob.step(ema=late)
+        assert not ob._fused_pending
+    else:
+        ob.step()
 
 
 def test_fused_adamw_epilogue_gemm_vs_gemm_plus_adamw_kernel():
@@ -602,17 +631,26 @@ def _dp_worker(rank, world, port, mode, comm, outdir):
         sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(9)).cuda()
         sl = slice(rank * B // world, (rank + 1) * B // world)
         den = M.GCDenoiser(m, 0.5).train()
+        from mode_diffusion_policy_amd.optim import ArenaEMA
         opt = FusedAdamW(m, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
         zero1 = mode.split(":")[1] if mode.startswith("zero1") else None
         red = ArenaGradReducer.for_model(m, mode="allreduce" if zero1 else mode, comm_dtype=torch.bfloat16 if comm == "bf16" else torch.float32)
+        ema = ArenaEMA(m, decay=0.99, min_value=0.5)                                 # min_value: a real average from the first step on
         for step in range(2):
             loss, _ = den.loss({"state_images": inp["state_images"][sl]}, inp["actions"][sl], inp["goals"][sl], inp["noise"][sl], sig[sl])
             loss.backward()
-            opt.step(reducer=red, overlap=True, zero1=zero1)
+            opt.step(reducer=red, overlap=True, zero1=zero1, ema=ema)                # the callback's EMA in the same call - also under ZeRO-1 (sharded like the moments)
         if zero1:
-            opt.gather_master(red)
+            try:
+                ema.swap()
+                raise AssertionError("a sharded EMA must refuse swap()")
+            except RuntimeError as e:
+                assert "gather_state" in str(e)
+            opt.gather_state(red)
         torch.cuda.synchronize()
         out = {n: p.detach().cpu() for n, p in m.named_parameters()}
+        out["__ema__"] = ema.flat[: m.engine.arena.bounds["no_decay"]].cpu()
+        out["__exp_avg__"] = opt.exp_avg.cpu()
         # one more backward + the bare exchange: the reduced gradient itself (the optimizer's sign-like first steps amplify rounding noise)
         m.engine.arena.grad_pending = False
         loss, _ = den.loss({"state_images": inp["state_images"][sl]}, inp["actions"][sl], inp["goals"][sl], inp["noise"][sl], sig[sl])
@@ -647,11 +685,21 @@ def test_data_parallel_world2_equals_single_process_on_concatenated_batch(tmp_pa
     inp = {k: v.cuda() for k, v in make_inputs(cfg, B, 55).items()}
     sig = O.rand_log_logistic((B,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(9)).cuda()
     den = M.GCDenoiser(m, 0.5).train()
+    from mode_diffusion_policy_amd.optim import ArenaEMA
     opt = FusedAdamW(m, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    ema = ArenaEMA(m, decay=0.99, min_value=0.5)
     for step in range(2):
         loss, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
         loss.backward()
-        opt.step()
+        opt.step(ema=ema)
+    # (0) the EMA the ranks hold after the same calls (ZeRO-1: each rank averaged its own shards, gather_state() completed it): identical on every
+    #     rank, and - as a moving average of the weights - as close to the single-process EMA as the weights themselves are (checked in (b) below)
+    assert torch.equal(w[0]["__ema__"], w[1]["__ema__"]) and torch.equal(w[0]["__exp_avg__"], w[1]["__exp_avg__"])
+    nred = m.engine.arena.bounds["no_decay"]
+    ema_ref, w_ref, w_init = ema.flat[:nred].cpu().double(), m.engine.arena.flat[:nred].detach().cpu().double(), None
+    e_ema = float((w[0]["__ema__"].double() - ema_ref).norm() / (ema_ref - w_ref).norm().clamp_min(1e-30))
+    assert e_ema < (3e-1 if (comm == "bf16" or mode == "zero1:bf16") else 1.5e-1), e_ema     # relative to the distance EMA <-> weights (an update-sized quantity)
+    w[0].pop("__ema__"); w[1].pop("__ema__"); w[0].pop("__exp_avg__"); w[1].pop("__exp_avg__")
     # (a) the exchanged gradient == the whole-batch gradient (bf16 GEMMs of two half batches vs one whole batch: rounding-level differences)
     m.engine.arena.grad_pending = False
     loss, _ = den.loss({"state_images": inp["state_images"]}, inp["actions"], inp["goals"], inp["noise"], sig)
