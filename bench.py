@@ -452,6 +452,8 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU, z
         opt.set_fuse_expert_step(fuse)
         for gi, grp in enumerate(opt.param_groups):
             grp["lr"], grp["weight_decay"] = 1e-4, (0.05 if gi == 0 else 0.0)
+    if os.environ.get("MODE_ADAMW_WS"):                                        # A/B: 0 = the ring kernel for the fused weight-gradient + AdamW launches, 1 = the wave-specialised one
+        m.engine.lib.mode_set_option(b"adamw_ws", int(os.environ["MODE_ADAMW_WS"]))
     if os.environ.get("MODE_ADAMW_BLOCKS"):
         m.engine.lib.mode_set_option(b"adamw_blocks", int(os.environ["MODE_ADAMW_BLOCKS"]))
     # gradient exchange dtype: fp32 like the reference's DDP (default), or MODE_DP_COMM=bf16 = half the bytes on the xGMI links

@@ -116,6 +116,8 @@ extern "C" const char* mode_hip_status_string(int status) {
   }
 }
 
+extern "C" __attribute__((weak)) int mode_trws_set_option(const char* key, int value);
+
 extern "C" int mode_set_option(const char* key, int value) {
   if (!key) return MODE_ERR_BAD_ARG;
   if (!strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return MODE_OK; }
@@ -131,6 +133,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "conv_ns")) { if (value != 0 && value != 2 && value != 3) return MODE_ERR_BAD_ARG; g_conv_ns = value; return MODE_OK; }
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return MODE_OK; }
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }
+  if (mode_trws_set_option) { const int rc = mode_trws_set_option(key, value); if (rc != MODE_ERR_UNSUPPORTED) return rc; }   // probe build only (scripts/probe/gemm_bf16_trws.hip)
   if (!strcmp(key, "gemm_skinny_rows")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_skinny_rows = value; return MODE_OK; }
   if (!strcmp(key, "fuse_ln2")) { g_fuse_ln2 = value != 0; return MODE_OK; }
   if (!strcmp(key, "gemm_mid_rows_rn")) { if (value < 0) return MODE_ERR_BAD_ARG; g_gemm_mid_rows_rn = value; return MODE_OK; }

@@ -64,6 +64,12 @@ class FusedAdamW:
         # (ModeAdamWFuse.side_stream; joined before mode_dit_backward returns).  False = everything on the one stream.
         self.fused_side_stream = bool(fused_side_stream) and os.environ.get("MODE_FUSED_SIDE_STREAM", "1") == "1"
         self._fused_side = None                                  # (stream, [4 events], ctypes array of their handles)
+        prev = getattr(model, "_fused_optimizer", None)
+        if prev is not None and prev is not self:
+            # a NEW optimizer takes the model over: an earlier fuse_expert_step optimizer must not keep updating the experts inside the backward
+            if prev._fused_pending:
+                raise RuntimeError("another FusedAdamW of this model has a fused backward pending: call its step() / finish_fused_step() first")
+            model._fused_optimizer = None
         if self.fuse_expert_step:
             self.fuse_expert_step = False
             self.set_fuse_expert_step(True)                      # model._fused_optimizer = self: training.py's backward asks this object for the ModeAdamWFuse of the step
