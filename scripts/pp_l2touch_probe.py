@@ -1,4 +1,4 @@
-"""Round-5 experiment: the L2 run-ahead touch of the persistent ping-pong GEMM (gemm_bf16_pp.hip, -DPP_L2_TOUCH=d [-DPP_L2_TOUCH_SPLIT=1]) against the
+"""Round-5 experiment: the L2 run-ahead touch of the persistent ping-pong GEMM (scripts/probe/gemm_bf16_pp_l2touch.hip, -DPP_L2_TOUCH=d [-DPP_L2_TOUCH_SPLIT=1]) against the
 shipped kernel, in ONE process (every library is its own ctypes handle), interleaved rounds, the config-2 expert shapes at B = 128:
   * up-projection   [3584 x 1024] x [2 x 8192 x 1024]  (SwiGLU + fused ln_2, gathered identity rows, uniform routing)
   * down-projection [3584 x 4096] x [1024 x 4096] in 4 K-slices

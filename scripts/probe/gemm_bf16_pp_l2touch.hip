@@ -30,7 +30,20 @@
 #include "mode_common.h"
 #include <type_traits>
 
-// (Round 5's L2 run-ahead variant of this kernel - built, bit-identical, measured, lost: profiles/r05_pp_l2touch.txt - lives in scripts/probe/gemm_bf16_pp_l2touch.hip.)
+// Round-5 experiment (VERDICT r04 "next" #1a), OFF in the shipped library: an L2-only run-ahead of the operand stream.  -DPP_L2_TOUCH=d makes waves 6 and 7
+// (224-row tile: the two waves with the lighter DMA load) issue ONE dword LDS-DMA load per K-step into a landing strip nobody reads, touching the cache
+// lines of K-step kt + 2 + d - wave 6 lines of the W tile, wave 7 lines of the A tile - so that the operand DMA of that K-step, d steps later, finds them in
+// the XCD's L2.  -DPP_L2_TOUCH_SPLIT=1 divides the lines among the workgroups of the XCD that share them (W: the 8 m-tiles of a band touch 32 lines each, A:
+// the 4 n-runs 56 rows each) so that together they cover every line once; without it a workgroup touches every fourth line of its own tiles.  The touch
+// is issued right behind a counted wait, so it rides INSIDE the vmcnt budget (the waits of those two waves allow one more instruction in flight).
+// (First form, every wave touching 64 lines per K-step: 576-585 instead of 628-631 denoise-steps/s - the vector-memory path is the loop's bottleneck.)  scripts/build_pp_variant.sh builds libmode_hip_<tag>.so; scripts/pp_l2touch_probe.py times it against the shipped library in one
+// process.  Result and reading: profiles/r05_pp_l2touch.txt, LABNOTES.md.
+#ifndef PP_L2_TOUCH
+#define PP_L2_TOUCH 0
+#endif
+#ifndef PP_L2_TOUCH_SPLIT
+#define PP_L2_TOUCH_SPLIT 0
+#endif
 
 namespace mode {
 
@@ -42,7 +55,12 @@ constexpr int LDS_B = 4 * HALF_BYTES;                      // W[t][h] at 64 KiB 
 constexpr int LDS_BIAS = 8 * HALF_BYTES;                   // 8 x 1 KiB: one bias slot per wave (each wave DMAs and reads its own copy)
 constexpr int LDS_NRM = LDS_BIAS + 8 * 1024;               // 2 x 256 floats: inverse row norms of the fused ln_2 (double-buffered per restart)
 constexpr int LDS_SS = LDS_NRM + 2 * 1024;                 // 256 rows x 64 B: per-64-column partial sums of squares of the tile's rows (DMA'd at a restart)
+#if PP_L2_TOUCH
+constexpr int LDS_PF = LDS_SS + 256 * 64;                  // 8 x 256 B: landing strip of the L2 touches (never read)
+constexpr int LDS_TOTAL = LDS_PF + 8 * 256;
+#else
 constexpr int LDS_TOTAL = LDS_SS + 256 * 64;               // 154 KiB of the CU's 160
+#endif
 constexpr int GM = 8;                                      // m-tiles per rasterisation band
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -235,6 +253,36 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
   Tile cur, nxt;
   map_tile(L, cur);
+#if PP_L2_TOUCH
+  // Only the two waves that stage no A half 1 (waves 6 and 7 of the 224-row tile: two DMA instructions per K-step fewer than the others) issue touches:
+  // wave 6 the W lines, wave 7 the A lines - ONE extra vector-memory instruction per K-step on each (the all-waves form cost 5-8 % in the chain: the
+  // vector-memory path is what the loop is bound by).  The touch is an LDS-DMA dword load into a landing strip nobody reads: a VGPR destination
+  // would be written whenever the data arrives, long after the compiler considers the instruction complete.
+  uint32_t pf_off = 0;                                           // this lane's line: byte offset from the tile's W base (wave 6) / from Ak (wave 7)
+  auto pf_set = [&](const Tile& t) __attribute__((always_inline)) {
+    if (wave == 6) {                                             // W: logical row jj of the 256-row tile (half jj >> 7)
+#if PP_L2_TOUCH_SPLIT
+      const int jj = (t.m & 7) * 32 + (lane & 31);               // the 8 m-tiles of a band walk the same W tiles: each touches 32 of the 256 lines
+#else
+      const int jj = lane * 4;                                   // every fourth line of the 256
+#endif
+      pf_off = (uint32_t)((long)(jj >> 7) * w_half + (long)(jj & 127) * p.ldw * 2);
+    } else {                                                     // A: tile row jj (clamped to the segment's last row; identity / ungathered rows only)
+#if PP_L2_TOUCH_SPLIT
+      const int jj = ((t.n / RN) & 3) * 56 + min(lane, 55);      // the n-runs of a band walk the same A tile: four of them share an XCD
+#else
+      const int jj = min(lane * 4, BM - 1);
+#endif
+      int srow = min(t.row0 + jj, t.row_end - 1);
+      if (p.a_rows != nullptr) srow = p.identity_rows ? srow - t.seg0 : 0;
+      pf_off = (uint32_t)((long)srow * p.lda * 2);
+    }
+  };
+  auto pf_touch = [&](const char* base) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + pf_off),
+                                     (__attribute__((address_space(3))) void*)(smem + LDS_PF + wave * 256), 4, 0, 16);   // aux 16 = sc1: served by L2, not kept in L1
+  };
+#endif
   int nrm_par = 0;
   uint32_t a_off[2][2] = {{0, 0}, {0, 0}};                     // byte offsets of this lane's A rows (gathered) from p.A, per half / piece
   const char* Ak = nullptr;
@@ -254,6 +302,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
       const int last = cur.row_end - 1;
       Ak = reinterpret_cast<const char*>(p.A) + (long)cur.slice * nk * BKK * 2;
       Wc = w_tile_base(cur);
+#if PP_L2_TOUCH
+      pf_set(cur);
+#endif
       // ONE dependent round trip: the gathered-row indices of this lane's four A pieces and of its two norm-row pieces (fused ln_2), together
       const bool do_nrm = SWI && p.ss_in;
       int srow[2][2], nrow[2];
@@ -367,12 +418,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   PP_SB();
     auto kpair = [&](auto A1_, auto FIRST_, int kt) __attribute__((always_inline)) {
       constexpr bool a1 = decltype(A1_)::value != 0, first = decltype(FIRST_)::value != 0;
-      constexpr int NW = a1 ? 8 : 6;
+      constexpr bool pf = PP_L2_TOUCH != 0 && !a1;               // waves 6 / 7 (the role without A half 1) carry the L2 touches
+      constexpr int NW = (a1 ? 8 : 6) + (pf ? 1 : 0);            // + the touch of a K-step (issued right behind a wait: always inside the budget)
       const bool cross = kt + 2 >= nk;
       const int k2 = cross ? kt + 2 - nk : kt + 2;             // K-step (kt+2) inside its own output tile
       const char* A1 = Ak + (long)(kt + 1) * 128;
       const char* A2 = Ak + (long)k2 * 128;
       const char* W2 = (cross ? Wn : Wc) + (long)k2 * 128;
+#if PP_L2_TOUCH
+      // lines of K-steps kt + 2 + d and kt + 3 + d (d = PP_L2_TOUCH): W of this or the next output tile, A of the same rows (wraps to the tile's k = 0)
+      const int kp0 = kt + 2 + PP_L2_TOUCH, kp1 = kp0 + 1;
+      const bool x0 = kp0 >= nk, x1 = kp1 >= nk;
+      const int kq0 = x0 ? kp0 - nk : kp0, kq1 = x1 ? kp1 - nk : kp1;
+      const char* T0 = (wave == 6 ? (x0 ? Wn : Wc) : Ak) + (long)kq0 * 128;
+      const char* T1 = (wave == 6 ? (x1 ? Wn : Wc) : Ak) + (long)kq1 * 128;
+#endif
       // P0 of K-step kt [buffer 0]
       rdB(_0, _0); rdB(_0, _1);
       PP_SB();
@@ -392,6 +452,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bl,
                                          (__attribute__((address_space(3))) void*)(smem + LDS_BIAS + wave * 1024), 16, 0, 0);
       }
+#if PP_L2_TOUCH
+      if constexpr (pf) pf_touch(T0);
+#endif
       PP_COMPUTE2(_1)
       // P0 of K-step kt+1 [buffer 1]
       rdB(_1, _0); rdB(_1, _1);
@@ -406,6 +469,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
       stage(_1, _1, _1, W2 + w_half + 128, b_off[0], b_off[1]);
       stage(_0, _1, _0, A2 + 128, a_off[0][0], a_off[0][1]);
       wait_vmcnt<NW>();
+#if PP_L2_TOUCH
+      if constexpr (pf) pf_touch(T1);
+#endif
       PP_COMPUTE2(_1)
     };
     auto kloop = [&](auto A1_) __attribute__((always_inline)) {
