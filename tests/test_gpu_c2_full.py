@@ -215,3 +215,77 @@ def test_c2_b32_precached_rollout_vs_oracle(c2, dtype):
     # a second replanning call replays the same graph on fresh noise and stays on the oracle
     plan2 = pol.denoise_actions(obs, c["goals"])
     assert not torch.equal(plan2, plan) and torch.isfinite(plan2).all()
+
+
+# ---------------------------------------------------------------------------------------------- the >= 6x leg's numerics: bf16 on the wire, full depth
+DP_NAMES = ["tok_emb.weight", "goal_emb.weight", "action_emb.weight", "sigma_linear.weight", "pos_emb", "out.weight", "ln.g",
+            "blocks.0.attn.query.weight", "blocks.0.attn.c_proj.weight", "blocks.0.ln_1.g", "blocks.5.ln_2.g", "blocks.11.attn.value.weight",
+            "blocks.3.experts.expert_1.mlp.0.project.weight", "blocks.11.experts.expert_2.mlp.2.weight", "blocks.7.attn.q_norm.g",
+            "blocks.0.experts.expert_0.mlp.2.weight", "blocks.6.attn.value.bias"]
+
+
+def _bf16wire_worker(rank, world, port, outdir, Bt):
+    """One rank of `bench.py --gpus N`'s bf16wire leg on cuda:0 (both ranks share the GPU; gloo carries the device tensors): the FULL-SIZE model on its half
+    of the batch, deterministic mode, gradients exchanged by ArenaGradReducer with bf16 on the wire (the sum is formed in bf16)."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mode_diffusion_policy_amd.ddp import ArenaGradReducer
+        torch.cuda.set_device(0)
+        cfg = get_config("c2")
+        sd = make_state_dict(cfg, SEED)
+        inp = make_inputs(cfg, Bt, SEED + 5)
+        sig = O.rand_log_logistic((Bt,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(4))
+        m = _model(cfg, sd, "bf16", attn_pdrop=0.0, mlp_pdrop=0.0, goal_drop=0.0, use_argmax=True).train()
+        den = M.GCDenoiser(m, 0.5).train()
+        red = ArenaGradReducer.for_model(m, mode="allreduce", comm_dtype=torch.bfloat16)
+        sl = slice(rank * Bt // world, (rank + 1) * Bt // world)
+        c = {k: v[sl].cuda() for k, v in inp.items() if k != "x0"}
+        loss, _ = den.loss({"state_images": c["state_images"]}, c["actions"], c["goals"], c["noise"], sig[sl].cuda())
+        loss.backward()
+        scale = red.reduce()
+        torch.cuda.synchronize()
+        g = {n: (p.grad.detach() * scale).cpu() for n, p in m.named_parameters() if n in DP_NAMES}
+        g["__idx__"] = m._last_topk.cpu().reshape(cfg.n_layers, -1, cfg.top_k)
+        torch.save(g, os.path.join(outdir, f"g{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c2_full_bf16_wire_exchange_vs_oracle_whole_batch_gradients(tmp_path):
+    """configs[3]'s claim leg (bench.py `bf16wire_*`, DESIGN.md section 6: the only exchange whose wire time fits under the step at N = 8) sums the per-rank
+    gradients in bf16 on the links - a numerics change the reference's fp32 DDP all-reduce (mode/training_calvin.py:92-103) does not make.  Pinned here at FULL
+    depth: two ranks, each the full-size model on half of a B = 16 batch, gradient exchange with bf16 on the wire; the exchanged mean gradient of a sample
+    of tensors from every part of the network stays inside BF16_GRAD_FULL_DEPTH of the ORACLE's fp32 autograd on the concatenated batch (the tolerance the
+    single-process bf16 backward is held to, tests/tolerances.py) and is identical on both ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    Bt = 16
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_bf16wire_worker, args=(r, 2, port, str(tmp_path), Bt)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    g = [torch.load(tmp_path / f"g{r}.pt") for r in range(2)]
+    cfg = get_config("c2")
+    sd = make_state_dict(cfg, SEED)
+    inp = make_inputs(cfg, Bt, SEED + 5)
+    sig = O.rand_log_logistic((Bt,), float(np.log(0.5)), 0.5, 1e-3, 80.0, generator=torch.Generator().manual_seed(4))
+    # the ranks' routing decisions (fp32 router, per-sample sigma): rank r holds rows of its half
+    idx = torch.cat([g[0].pop("__idx__"), g[1].pop("__idx__")], dim=1).long()          # [L, B, k]
+    sdg = {k: (v.clone().requires_grad_(True) if k in DP_NAMES else v) for k, v in sd.items()}
+    ref_loss, _ = O.denoiser_loss(sdg, cfg, 0.5, inp["state_images"], inp["actions"], inp["goals"], inp["noise"], sig,
+                                  topk_idx=[idx[l].view(Bt, 1, cfg.top_k).expand(Bt, cfg.seq_len, cfg.top_k) for l in range(cfg.n_layers)])
+    ref_loss.backward()
+    worst = (0.0, "")
+    for n in DP_NAMES:
+        assert torch.equal(g[0][n], g[1][n]), n                                          # every rank holds the same exchanged gradient, bit for bit
+        e = rel(g[0][n], sdg[n].grad)
+        worst = max(worst, (e, n))
+        assert e < BF16_GRAD_FULL_DEPTH, (n, e)
+    print(f"C2 full depth, world 2, bf16 on the wire: worst exchanged gradient vs the oracle's whole-batch autograd {worst[0]:.2e} ({worst[1]}); tol {BF16_GRAD_FULL_DEPTH:g}")

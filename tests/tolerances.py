@@ -13,9 +13,12 @@ bf16 arithmetic (conditioning-row routing: the shipped configuration).
       are noisier in bf16 for ANY implementation: the reference's own gap there is 0.6-1.7e-2 (oracle/measure_bf16_fwd_gap_geometries.py ->
       tests/golden/bf16_fwd_gap_geometries.json); measured here <= 1.12e-2 over 400 random geometries.
     - loss: 1e-2 (reference gap <= 7e-4).
-    - model output of the TRAINING forward (per-token multinomial routing, attention dropout 0.3 / expert dropout 0.1 with their 1/(1-p)
-      rescaling): 4e-2, the envelope of the gradients that are computed from it (measured 2.0e-2 at full C2 size, B = 128; eval-mode forward
-      at the same size: 5e-3).
+    - model output of the TRAINING forward (per-sample log-logistic sigma; per-token multinomial routing, attention dropout 0.3 / expert dropout 0.1
+      with their 1/(1-p) rescaling): 2.5e-2.  oracle/measure_bf16_train_out_gap.py -> tests/golden/bf16_train_out_gap.json: the reference's
+      GCDenoiser.loss at full C2 size, fp32 vs autocast with an fp32 router + sigma embedding, identical routing and identical dropout masks -
+      deterministic routing 1.34e-2 (B = 16) / 1.57e-2 (B = 128), stochastic path 2.10e-2 / 2.25e-2 (two seeds, B = 128): envelope 2.25e-2.
+      Measured here: 1.2e-2 (F18, deterministic) ... 2.0e-2 (stochastic, B = 128); eval-mode forward at the same size: 5e-3.  (Rounds 3-5 used 4e-2,
+      "the envelope of the gradients", without a measurement of this quantity behind it.)
     - gradients of the one- / two-block fixtures (oracle/measure_bf16_grad_gap.py -> tests/golden/bf16_grad_gap.json): per tensor 4e-2 (reference:
       worst 3.8e-2, attention key bias; medians 0.7-1.1e-2), gradient norms 2.5e-2 (reference <= 2.3e-2).
     - gradients of the FULL 12-block model (oracle/measure_bf16_grad_gap_c2_full.py -> tests/golden/bf16_grad_gap_c2_full.json: the reference
@@ -36,7 +39,7 @@ BF16_LOSS = 1e-2
 BF16_GRAD = 4e-2
 BF16_GRAD_NORM = 2.5e-2
 BF16_GRAD_FULL_DEPTH = 6e-2
-BF16_TRAIN_OUT = 4e-2
+BF16_TRAIN_OUT = 2.5e-2       # tests/golden/bf16_train_out_gap.json: reference envelope 2.25e-2
 
 BF16_TOKROUTE_AGREE = 0.97
 BF16_TOKROUTE_OUT = 5e-2
