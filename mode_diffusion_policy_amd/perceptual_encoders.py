@@ -333,8 +333,10 @@ class _TableCache:
         return t
 
     def put(self, key, t):
-        if TWO_TOWER_STREAMS and t.is_cuda:
-            torch.cuda.current_stream(t.device).synchronize()                   # the other tower's stream may use the table right away: built before it is published
+        if TWO_TOWER_STREAMS and t.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # the other tower's stream may use the table right away: built before it is published.  (Under hipGraph capture a host synchronize is illegal - and
+            # not needed: both towers' launches are captured in fork / join order behind the build.)
+            torch.cuda.current_stream(t.device).synchronize()
         self.d[key] = t
         self.bytes += t.numel() * t.element_size()
         if self.sink is not None:
@@ -803,11 +805,21 @@ def stem_conv_bn_pool(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> t
         w_lp = _shadow(conv, torch.bfloat16)
     if train:
         y = bn_film_act(_StemConvFn.apply(x, w, w_lp, conv.stride, conv.padding), bn, relu=True)
-    elif FUSE_CONV_BN and not bn.training and bn.running_mean is not None:
+    elif FUSE_CONV_BN and not bn.training and bn.running_mean is not None and _bn_fusable(bn):
         y = _stem_fwd(x, w_lp, conv.stride, conv.padding, bn=bn, relu=True)          # inference: convolution + BatchNorm + ReLU in one launch
     else:
         y = bn_film_act(_stem_fwd(x, w_lp, conv.stride, conv.padding), bn, relu=True)
     return max_pool(y)
+
+
+def _bn_fusable(bn) -> bool:
+    """The folded conv + BatchNorm inference launch bypasses autograd and reads the BatchNorm statistics / affine terms as raw fp32 pointers: only when nothing of
+    the BatchNorm can want a gradient (a frozen convolution in front of a trainable eval-mode BatchNorm must keep the autograd path) and every tensor is fp32
+    and contiguous (an encoder cast to bfloat16 would otherwise be read as garbage)."""
+    ts = [t for t in (bn.running_mean, bn.running_var, bn.weight, bn.bias) if t is not None]
+    if torch.is_grad_enabled() and any(getattr(t, "requires_grad", False) for t in (bn.weight, bn.bias) if t is not None):
+        return False
+    return all(t.dtype == torch.float32 and t.is_contiguous() for t in ts)
 
 
 # ------------------------------------------------------------------------------------------------------------------ trunk (parameter holders)

@@ -225,7 +225,7 @@ class ChunkedRolloutPolicy:
         return current
 
 
-def _read_checkpoint_file(path: str) -> Dict[str, torch.Tensor]:
+def _read_checkpoint_file(path: str, trust_pickle: bool = False) -> Dict[str, torch.Tensor]:
     """The file forms `MoDEAgent.load_pretrained_parameters` accepts (mode_agent.py:141-158): a checkpoint DIRECTORY holding
     ``model_cleaned.safetensors`` (preferred) or ``model_cleaned.pt``; a ``.safetensors`` file; a Lightning ``.ckpt`` / ``torch.save``d dict whose
     weights sit under ``'state_dict'`` (a bare state_dict is accepted too).  Lightning checkpoints carry hyper-parameter objects, which torch >= 2.6
@@ -259,13 +259,13 @@ def _read_checkpoint_file(path: str) -> Dict[str, torch.Tensor]:
     return blob.get("state_dict", blob) if isinstance(blob, dict) else blob
 
 
-def load_denoiser_checkpoint(model, source, prefix: str = "model.inner_model.", strict: bool = False):
+def load_denoiser_checkpoint(model, source, prefix: str = "model.inner_model.", strict: bool = False, trust_pickle: bool = False):
     """Load the denoiser's tensors from an agent checkpoint: a ``.safetensors`` file (the published HF weights), a ``torch.save``d
     ``state_dict`` / Lightning checkpoint, or an in-memory mapping.  Keys are matched by name after stripping the agent's prefix
     (``model.inner_model.`` — mode_agent.py:209-251 loads by key and skips the CLIP / ResNet tensors, which belong to the out-of-scope
     encoders); the kernel-side layout is untouched because the Parameters are arena views.  Returns (missing, unexpected, skipped_shape)."""
     if isinstance(source, (str, bytes, os.PathLike)):
-        sd = _read_checkpoint_file(os.fsdecode(source))
+        sd = _read_checkpoint_file(os.fsdecode(source), trust_pickle)
     else:
         sd = dict(source)
     own = model.state_dict()
@@ -336,7 +336,7 @@ def _agent_parts(target) -> Dict[str, torch.nn.Module]:
     return parts
 
 
-def load_agent_checkpoint(target, source, strict: bool = False, verbose: bool = False) -> Dict[str, object]:
+def load_agent_checkpoint(target, source, strict: bool = False, verbose: bool = False, trust_pickle: bool = False) -> Dict[str, object]:
     """Load ONE agent checkpoint - the published HF ``.safetensors``, a Lightning ``.ckpt`` / ``torch.save``d ``state_dict`` or a mapping - into the
     denoiser AND both perceptual encoders, as ``MoDEAgent.load_pretrained_parameters`` does (mode_agent.py:135-251): CLIP tensors are skipped
     (``'visual'`` / ``'clip'`` in the key), keys the agent does not know are retried under the prefix table of older releases
@@ -346,9 +346,12 @@ def load_agent_checkpoint(target, source, strict: bool = False, verbose: bool = 
 
     ``target``: ``{'model': GCDenoiser, 'static_resnet': m, 'gripper_resnet': m}`` (any subset), a ``ChunkedRolloutPolicy`` built with encoders, or an
     object with those attributes.  Returns ``{'direct', 'reshaped', 'skipped', 'missing', 'unexpected'}`` (counts for the first two, key lists for the
-    rest; keys carry the agent-level prefix).  Parameters are written in place (arena views, the graphs' static pointers stay valid)."""
+    rest; keys carry the agent-level prefix).  Parameters are written in place (arena views, the graphs' static pointers stay valid).
+
+    Files are read with ``weights_only=True``; a file that needs the full unpickler (a Lightning ``.ckpt`` with omegaconf / argparse objects next to the weights)
+    is only read on the caller's say-so - ``trust_pickle=True`` or ``MODE_TRUST_CKPT=1`` - because unpickling executes what the file says."""
     if isinstance(source, (str, bytes, os.PathLike)):
-        sd = _read_checkpoint_file(os.fsdecode(source))
+        sd = _read_checkpoint_file(os.fsdecode(source), trust_pickle)
     else:
         sd = dict(source)
     parts = _agent_parts(target)

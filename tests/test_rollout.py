@@ -143,10 +143,16 @@ def test_agent_checkpoint_loader_reference_key_names(tmp_path):
     import argparse
     lightning = {"state_dict": {k: v.contiguous() for k, v in ck.items()}, "hyper_parameters": argparse.Namespace(lr=1e-4), "epoch": 3}
     torch.save(lightning, tmp_path / "last.ckpt")
-    assert rollout.load_agent_checkpoint(a, str(tmp_path / "last.ckpt"))["direct"] == res["direct"]
+    # ... but only when the caller says the file is trusted (full unpickling executes what the file says)
+    with pytest.raises(RuntimeError, match="trust_pickle=True"):
+        rollout.load_agent_checkpoint(a, str(tmp_path / "last.ckpt"))
+    with pytest.warns(UserWarning, match="full unpickler"):
+        assert rollout.load_agent_checkpoint(a, str(tmp_path / "last.ckpt"), trust_pickle=True)["direct"] == res["direct"]
+    (tmp_path / "garbage.ckpt").write_bytes(b"not a checkpoint")
     with pytest.raises(RuntimeError, match="cannot read checkpoint"):
-        (tmp_path / "garbage.ckpt").write_bytes(b"not a checkpoint")
         rollout.load_agent_checkpoint(a, str(tmp_path / "garbage.ckpt"))
+    with pytest.raises(RuntimeError, match="cannot read checkpoint"):
+        rollout.load_agent_checkpoint(a, str(tmp_path / "garbage.ckpt"), trust_pickle=True)
 
 
 @pytest.mark.gpu
