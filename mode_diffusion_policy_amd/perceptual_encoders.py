@@ -472,6 +472,18 @@ def _wgrad_taps(dy: torch.Tensor, x: torch.Tensor, wshape, stride, padding) -> t
     return dw.permute(0, 3, 1, 2)                                  # [Cout, Cin, kh, kw] view with channels_last strides
 
 
+def _aten_conv(x, w, stride, padding, why: str):
+    """The ONLY way into ``F.conv2d`` (MIOpen on a ROCm device).  CPU tensors (parameter-holder use, the CPU tests' reference) and the fp32 compute dtype (the
+    reference-precision / debugging mode: the library's convolutions are bf16 MFMA kernels) take it by design; the explicit A/B switches MODE_ENC_HIPCONV=0 /
+    MODE_ENC_HIPSTEM=0 too.  A bf16 convolution on a ROCm device that the library's kernels do not cover (groups, dilation, a bias, channel counts that are not
+    multiples of 8, a layout other than channels_last) is an ERROR, not a silent change of backend - unless MODE_ENC_ATEN_FALLBACK=1 says so."""
+    import os
+    if x.is_cuda and x.dtype == torch.bfloat16 and USE_HIP_CONV_WGRAD and USE_HIP_STEM and os.environ.get("MODE_ENC_ATEN_FALLBACK", "0") != "1":
+        raise RuntimeError(f"perceptual_encoders: bf16 convolution outside the library's kernels ({why}; weight {tuple(w.shape)}, input {tuple(x.shape)}, "
+                           f"channels_last={x.is_contiguous(memory_format=torch.channels_last)}): set MODE_ENC_ATEN_FALLBACK=1 to run it through aten / MIOpen")
+    return F.conv2d(x, w, None, stride, padding)
+
+
 class _ConvFn(torch.autograd.Function):
     """y = conv2d(x, w) computed with `w_lp` (w in the compute dtype); differentiable in x and in the fp32 PARAMETER w."""
 
@@ -488,7 +500,7 @@ class _ConvFn(torch.autograd.Function):
                 return _gemm_1x1_fwd(x, w_lp)
             if _conv_taps_ok(w.shape, w.shape[1], w_lp):
                 return _conv_fwd_taps(x, w_lp, stride, padding)
-        return F.conv2d(x, w_lp, None, stride, padding)
+        return _aten_conv(x, w_lp, stride, padding, "training forward")
 
     @staticmethod
     def backward(ctx, dy, *_unused):
@@ -595,7 +607,7 @@ def _conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
                 return _gemm_1x1_fwd(xc, hit)
             if hip_taps and xc.is_contiguous(memory_format=torch.channels_last) and hit.is_contiguous(memory_format=torch.channels_last):
                 return _conv_fwd_taps(xc, hit, conv.stride, conv.padding)
-            return F.conv2d(xc, hit, None, conv.stride, conv.padding)
+            return _aten_conv(xc, hit, conv.stride, conv.padding, "captured weight shadow")
     if (hip_1x1 or hip_taps) and not (torch.is_grad_enabled() and (w.requires_grad or x.requires_grad)):
         xc = x.to(cd)
         if xc.is_contiguous(memory_format=torch.channels_last):                    # inference: the shadow also saves the per-call weight cast
@@ -603,7 +615,7 @@ def _conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     if (USE_HIP_CONV_WGRAD and x.is_cuda and cd == torch.bfloat16 and torch.is_grad_enabled() and (w.requires_grad or x.requires_grad) and conv.groups == 1
             and conv.dilation == (1, 1) and conv.bias is None and isinstance(conv.padding, tuple)):
         return _ConvFn.apply(x.to(cd), w, _shadow(conv, cd), conv.stride, conv.padding)
-    return F.conv2d(x, w.to(x.dtype), None, conv.stride, conv.padding)
+    return _aten_conv(x, w.to(x.dtype), conv.stride, conv.padding, "unsupported geometry / layout")
 
 
 def bn_film_act(x, bn: nn.BatchNorm2d, relu: bool = True, residual=None, pre_film=None, post_film=None, stats=None):

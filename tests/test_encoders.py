@@ -397,13 +397,19 @@ def test_fused_pass_channels_last_equals_nchw(N, C_, H, W_, dtype, training):
 @pytest.mark.parametrize("N,Cin,Cout,H,W_,k,stride,pad", [(6, 256, 64, 56, 56, 1, 1, 0), (3, 64, 256, 17, 9, 1, 1, 0), (2, 1024, 2048, 7, 7, 1, 1, 0), (5, 72, 40, 6, 6, 1, 1, 0),
                                                            (4, 64, 64, 14, 14, 3, 1, 1), (4, 128, 256, 14, 14, 1, 2, 0), (2, 3, 64, 32, 32, 7, 2, 3), (3, 128, 128, 28, 28, 3, 2, 1),
                                                            (2, 512, 512, 7, 7, 3, 1, 1), (5, 64, 64, 9, 13, 3, 1, 1)])
-def test_conv_fn_gradients_vs_torch_fp32(N, Cin, Cout, H, W_, k, stride, pad):
+def test_conv_fn_gradients_vs_torch_fp32(N, Cin, Cout, H, W_, k, stride, pad, monkeypatch):
     """`_ConvFn` (MIOpen forward / data gradient on the bf16 shadow, weight gradient of 1 x 1 / stride-1 convolutions through the HIP row-major
     weight-gradient GEMM in K-groups, fp32 gradient handed to autograd) against torch's conv2d autograd in fp32 on the same bf16-rounded values."""
     torch.manual_seed(N + Cin + Cout)
     conv = torch.nn.Conv2d(Cin, Cout, k, stride=stride, padding=pad, bias=False).cuda()
     E._store_channels_last(conv)
     x = torch.randn(N, Cin, H, W_, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    if (Cin, Cout) in ((72, 40), (3, 64)):
+        # geometries OUTSIDE the library's kernels (channel counts that are not multiples of 64 / 8; the 3-channel case as a plain convolution): a bf16
+        # convolution on a ROCm device does not change backend silently - it raises, and runs through aten / MIOpen only on the caller's say-so
+        with pytest.raises(RuntimeError, match="MODE_ENC_ATEN_FALLBACK=1"):
+            E._conv2d(conv, x)
+        monkeypatch.setenv("MODE_ENC_ATEN_FALLBACK", "1")
     y = E._conv2d(conv, x)
     assert y.dtype == torch.bfloat16 and type(y.grad_fn).__name__ == "_ConvFnBackward"
     dy = torch.randn_like(y)

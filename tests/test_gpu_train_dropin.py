@@ -365,6 +365,12 @@ def test_bench_main_world2_end_to_end_through_torch_distributed_run(tmp_path):
     assert "train_leg_error" not in r and "zero1_leg_error" not in r and "bf16wire_leg_error" not in r
     assert "[bench] headline done" in p.stderr and "[bench] train leg done" in p.stderr and "[bench] zero1 leg done" in p.stderr
     assert "[bench] bf16wire leg done" in p.stderr
+    # the scaling anchor: every rank's two-pass step WITHOUT the exchange, and each leg's throughput against N x that
+    assert r["train_twopass_local_ms_per_step"] > 0 and "[bench] twopass leg done" in p.stderr and r["scaling_claim_leg"] == "bf16wire"
+    for k in ("scaling_vs_twopass_n1", "zero1_scaling_vs_twopass_n1", "bf16wire_scaling_vs_twopass_n1"):
+        assert 0.0 < r[k] <= 2.0 * 1.5, (k, r[k])                                # = N x local / leg; two ranks SHARE one GPU here, so only sanity is checked
+    assert abs(r["scaling_vs_twopass_n1"] - 2 * r["train_twopass_local_ms_per_step"] / r["train_ms_per_step"]) < 2e-3
+    assert r["fused_expert_step"] is False and "train_twopass_ms_per_step" not in r     # (N = 1 only: the fused-epilogue step and its two-pass anchor)
 
 
 # ---------------------------------------------------------------------------------------------- cond_router=False: token routing in TRAINING
