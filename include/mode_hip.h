@@ -74,9 +74,11 @@ const char* mode_hip_status_string(int status);
  *   every shape it takes, 7 = auto without it.  Auto takes it for the large expert GEMMs of the training backward unless "bwd_coexec" is 1.
  * "attn_bwd_mfma": 1 (default) = the attention backward's five small matrix products run on v_mfma_f32_16x16x4_f32 (head_dim % 16 == 0; exact fp32 like
  *   the VALU form, another summation order), 0 = the VALU form.
- * "train_dn_split": 0 (default) / 1 = the training forward cuts the expert down-projection into the inference chain's K-slices (bf16 slabs added by the
- *   combine kernels, forward and backward).  Measured 11.37 -> 11.33 ms per step at C2 / B = 128 (the 256-row ping-pong tile saves 14 us per layer, the combine
- *   kernels read four slabs instead of one) for 22 MB more stash per layer and another rounding of the block output: kept as a switch, off.
+ * "train_dn_split": 1 = the training forward cuts the expert down-projection into the inference chain's K-slices (bf16 slabs added by the combine kernels,
+ *   forward and backward; 22 MB more stash per layer at C2 / B = 128), 0 = one fp32-accumulated slab, -1 (default) = by batch size: slices from 2048 sorted rows
+ *   on (the four slices then give the 256-row ping-pong kernel one tile per CU, and a training forward with dropouts off equals the inference forward bit for
+ *   bit).  Round 4 measured 11.37 -> 11.33 ms per step and left it off; with the optimizer inside the backward (round 5) the forward's time is no longer
+ *   hidden behind an optimizer pass: 10.35-10.52 -> 10.23-10.25 ms (round 6).
  * "fuse_swiglu_bwd": 1 (default) = mode_dit_backward runs the down-projection's data gradient and the SwishGLU (+ dropout) backward + bias-gradient sums as
  *   ONE launch (the dH tile never leaves the chip), 0 = GEMM + mode_swiglu_bwd_bias.
  * "conv_ns": LDS ring depth of the implicit-GEMM convolution kernel (csrc/conv_gemm.hip): 0 = auto (3 below two workgroups per CU), 2, 3.

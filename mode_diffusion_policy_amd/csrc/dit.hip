@@ -28,7 +28,7 @@ extern int g_gemm_mid_rows_rn;
 extern int g_tr_cfg;
 extern int g_bwd_coexec;
 extern int g_attn_bwd_mfma;   // attn.hip
-int g_train_dn_split = 0;    // "train_dn_split" option: 1 = the training forward cuts the expert down-projection into the inference chain's K-slices (bf16 slabs)
+int g_train_dn_split = -1;   // "train_dn_split" option: 1 = the training forward cuts the expert down-projection into the inference chain's K-slices (bf16 slabs), 0 = one slab, -1 = by batch size (dit_train.hip: train_dn_split)
 int g_fuse_swiglu_bwd = 1;   // "fuse_swiglu_bwd" option: 1 = the training backward runs dH = dY W2 and the SwishGLU backward as one launch
 extern int g_conv_ns;
 extern int g_gemm_group_m;
@@ -129,7 +129,7 @@ extern "C" int mode_set_option(const char* key, int value) {
   if (!strcmp(key, "bwd_coexec")) { g_bwd_coexec = value != 0; return MODE_OK; }
   if (!strcmp(key, "fuse_swiglu_bwd")) { g_fuse_swiglu_bwd = value != 0; return MODE_OK; }
   if (!strcmp(key, "attn_bwd_mfma")) { g_attn_bwd_mfma = value != 0; return MODE_OK; }
-  if (!strcmp(key, "train_dn_split")) { g_train_dn_split = value != 0; return MODE_OK; }
+  if (!strcmp(key, "train_dn_split")) { g_train_dn_split = value < 0 ? -1 : (value != 0); return MODE_OK; }
   if (!strcmp(key, "conv_ns")) { if (value != 0 && value != 2 && value != 3) return MODE_ERR_BAD_ARG; g_conv_ns = value; return MODE_OK; }
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return MODE_OK; }
   if (!strcmp(key, "adamw_blocks")) { g_adamw_blocks = value; return MODE_OK; }

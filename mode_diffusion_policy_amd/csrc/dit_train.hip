@@ -24,7 +24,14 @@ bool gemm_bf16_pptr_accepts(const ModeGemmDesc* d);                             
 int gather_rows_bf16(const void* in, long ld_in, const int* rows, int n, int cols, void* out, long ld_out, hipStream_t s);   // gemm_bf16_pptr.hip
 int down_proj_split(int dt, int K);                                                      // dit.hip: K-slices of the expert down-projection (bf16 slabs)
 extern int g_train_dn_split;                                                             // "train_dn_split" option (dit.hip)
-static inline int train_dn_split(int dt, int K) { return g_train_dn_split ? down_proj_split(dt, K) : 1; }
+// K-slices of the training forward's expert down-projection (bf16 slabs, added in slice order by the forward and the backward combine): -1 = auto - the
+// inference chain's slices (then the training forward with dropouts off IS the inference forward, bit for bit) from 2048 sorted rows on, where the four
+// slices give the persistent ping-pong kernel exactly one 256 x 256 tile per CU (round 6: 53 -> ~33 us per block, 10.35-10.52 -> 10.23-10.25 ms per step);
+// one fp32-accumulated slab below that (small batches: the ring kernel has enough tiles, and one rounding less).  0 / 1 force either form.
+static inline int train_dn_split(int dt, int K, long NK) {
+  const bool on = g_train_dn_split < 0 ? NK >= 2048 : g_train_dn_split != 0;
+  return on ? down_proj_split(dt, K) : 1;
+}
 int combine_bwd_launch(const float* dy, const void* Y, int y_dtype, int y_splits, long y_split_stride, const int32_t* pos, const float* posw, int N, int D, int k,
                        void* dYs, float* dw, void* stream);                               // train_ops.hip
 }
@@ -109,7 +116,7 @@ extern "C" int mode_dit_train_stash_layout(const ModeDims* dims, int B, int dtyp
   Take t;
   out->x0 = t(N * D * 4); out->h1 = t(N * D * esz); out->qkv = t(N * 3 * D * esz); out->yattn = t(N * D * esz); out->x1 = t(N * D * 4);
   // Y: the down-projection's split-K slabs (the inference chain's tiling: one 256-row x 256 x 1024 tile per CU; the combine kernels add the slabs)
-  out->ub = t(N * D * esz); out->P = t(NK * 8 * D * esz); out->Hd = t(NK * 4 * D * esz); out->Y = t(NK * D * esz * (size_t)train_dn_split(dtype, 4 * (int)D));
+  out->ub = t(N * D * esz); out->P = t(NK * 8 * D * esz); out->Hd = t(NK * 4 * D * esz); out->Y = t(NK * D * esz * (size_t)train_dn_split(dtype, 4 * (int)D, (long)NK));
   out->layer_stride = t.o;
   Take g;
   out->xL = g(N * D * 4); out->yL = g(N * D * 4); out->u_tmp = g(N * D * 4);
@@ -143,7 +150,7 @@ static int forward_train_impl(const ModeDims* dims, const ModeModelWeights* w, c
   rc = mode_dit_train_stash_layout(dims, B, dt, &sl);
   if (rc) return rc;
   if (stash_bytes < sl.total_bytes) return MODE_ERR_WORKSPACE;
-  const int ysplit = train_dn_split(dt, 4 * D);
+  const int ysplit = train_dn_split(dt, 4 * D, NK);
   char* sg = (char*)stash;
   auto L_ = [&](int l) { return sg + sl.global_bytes + (size_t)l * sl.layer_stride; };
   float* u_tmp = (float*)(sg + sl.u_tmp);
@@ -345,7 +352,7 @@ extern "C" int mode_dit_backward(const ModeDims* dims, const ModeModelWeights* w
       if (done_rec[par]) MODE_HIP_OK(hipStreamWaitEvent(hs, ev_done[par], 0));
     }
     // (1) combine backward: dY (sorted rows) and router-weight gradients
-    if ((rc = combine_bwd_launch(DXa, S + sl.Y, dt, train_dn_split(dt, 4 * D), (long)NK * D, pos, posw, N, D, d.k, dYs, dwt + (size_t)l * NK, stream))) return rc;
+    if ((rc = combine_bwd_launch(DXa, S + sl.Y, dt, train_dn_split(dt, 4 * D, NK), (long)NK * D, pos, posw, N, D, d.k, dYs, dwt + (size_t)l * NK, stream))) return rc;
     // (1b) token routing: this block's router, back-propagated in place - its input is the block's own ln_2 output, so d u gets a second term
     const float* du_router = nullptr;
     if (tokr) {

@@ -826,7 +826,7 @@ def test_training_forward_with_the_down_projection_in_k_slices():
             loss, _ = den.loss({"state_images": c["state_images"]}, c["actions"], c["goals"], c["noise"], sig.cuda())
             loss.backward()
         finally:
-            lib.mode_set_option(b"train_dn_split", 0)
+            lib.mode_set_option(b"train_dn_split", -1)                          # back to the default: by batch size
         out[flag] = (float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
     assert abs(out[1][0] - out[0][0]) < 2e-3 * abs(out[0][0])
     assert out[0][1].keys() == out[1][1].keys()
