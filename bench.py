@@ -747,18 +747,12 @@ def agent_step_measure(den, device, B, steps, warmup, miopen_benchmark=False, op
                                   **({"fused": True} if os.environ.get("MODE_BENCH_TORCH_FUSED_ADAMW") == "1" else {}))   # (A/B: torch's foreach / fused multi-tensor kernels; the reference uses the default)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     enc_ms = [0.0, 0.0]
-    # the towers' forward and backward as two hipGraph replays (perceptual_encoders.GraphedTrainingTowers): the step is host-bound on their ~1 200 launches
-    towers = None
-    if os.environ.get("MODE_AGENT_GRAPH", "1") == "1":
-        from mode_diffusion_policy_amd.perceptual_encoders import GraphedTrainingTowers
-        towers = GraphedTrainingTowers(enc_s, enc_g, rgb_s, rgb_g, goal.squeeze(1))
-
     def step(timed=False):
         sig = rand_log_logistic((B,), loc=math.log(0.5), scale=0.5, min_value=1e-3, max_value=80.0, device=device)
         if timed:
             ev[0].record()
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            emb = towers(rgb_s, rgb_g, goal.squeeze(1)) if towers is not None else embed_visual_obs(enc_s, enc_g, rgb_s, rgb_g, goal.squeeze(1))
+            emb = embed_visual_obs(enc_s, enc_g, rgb_s, rgb_g, goal.squeeze(1))
             if timed:
                 ev[1].record()
             loss, _ = den.loss(emb, acts, goal, noise, sig)
@@ -789,7 +783,7 @@ def agent_step_measure(den, device, B, steps, warmup, miopen_benchmark=False, op
                                   "GCDenoiser.loss (12 layers, d=1024, 4 experts top-2) -> backward through both -> AdamW", "global_batch": B,
                       "parallelism": "single GPU"},
            "agent_ms_per_step_blocks": [round(b, 3) for b in blocks], "host_enqueue_ms_per_step": round(min(host), 3), "encoders_forward_ms": round(enc_fwd_ms, 3), "encoder_params": n_enc, "fused_expert_step": bool(fuse),
-           "encoder_optimizer": type(opt_e).__name__, "encoders_graphed": towers is not None,
+           "encoder_optimizer": type(opt_e).__name__,
            "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "miopen_benchmark": bool(miopen_benchmark)}
     den.train(was_training)
     return res

@@ -1081,56 +1081,6 @@ def embed_visual_obs(static_resnet, gripper_resnet, rgb_static, rgb_gripper, lat
     return {"state_images": torch.cat([st.reshape(B, T, -1), gt.reshape(B, T, -1)], dim=1)}
 
 
-class GraphedTrainingTowers:
-    """``embed_visual_obs`` for TRAINING as two hipGraph replays per step - one for the forward of both camera towers, one for their backward
-    (``torch.cuda.make_graphed_callables``: an autograd-aware capture, parameters keep receiving ``.grad``).
-
-    Why: the agent's training step (two FiLM-ResNet-50s + the denoiser, mode_agent.py:386-440) is HOST-bound - ~1 200 of its ~1 530 launches are the
-    encoders' microsecond kernels issued from Python (22 of 25 ms of enqueue per step at B = 64).  Their launch sequence does not depend on the data, so it
-    is captured once for the given input shapes and replayed; the denoiser part and the optimizers stay eager.  What the graphs read - parameters,
-    BatchNorm buffers, the bf16 weight shadows the training forward re-casts on every call - lives at fixed addresses; in-place updates (optimizer steps, EMA
-    swaps, ``load_state_dict``) are seen by the next replay.  Re-allocated parameters (``.to()``, ``.half()``), another batch size / image size or a switch
-    to eval mode need a new object (checked: the call raises).
-
-    ``rgb_static`` / ``rgb_gripper`` (B, T, C, H, W) and ``latent_goal`` (B, cond_dim) are SAMPLE inputs of the shapes the step will use (three eager
-    warm-up passes run on them first: index tables, code objects).  The call returns ``{'state_images': (B, 2 T, obs_dim)}`` like ``embed_visual_obs``."""
-
-    def __init__(self, static_resnet: nn.Module, gripper_resnet: nn.Module, rgb_static, rgb_gripper, latent_goal, autocast_dtype: Optional[torch.dtype] = torch.bfloat16):
-        if not (static_resnet.training and gripper_resnet.training):
-            raise ValueError("GraphedTrainingTowers captures the TRAINING forward / backward: put both encoders in train() mode first (inference: GraphedVisualEncoder)")
-        self.static_resnet, self.gripper_resnet, self.autocast_dtype = static_resnet, gripper_resnet, autocast_dtype
-        self._shapes = (tuple(rgb_static.shape), tuple(rgb_gripper.shape), tuple(latent_goal.shape))
-        outer = self
-
-        class _Both(nn.Module):
-            def __init__(self):
-                super().__init__()
-                self.static_resnet, self.gripper_resnet = static_resnet, gripper_resnet
-
-            def forward(self, rs, rg, lg):
-                import contextlib
-                # (cache_enabled=False: autocast's weight-cast cache must not outlive a capture - torch.cuda.make_graphed_callables' contract)
-                ac = torch.autocast("cuda", dtype=outer.autocast_dtype, cache_enabled=False) if outer.autocast_dtype is not None else contextlib.nullcontext()
-                with ac:
-                    return embed_visual_obs(self.static_resnet, self.gripper_resnet, rs, rg, lg)["state_images"]
-        self._both = _Both()
-        self._key = self._param_key()
-        sample = (rgb_static.detach().clone(), rgb_gripper.detach().clone(), latent_goal.detach().clone())
-        self._call = torch.cuda.make_graphed_callables(self._both, sample, num_warmup_iters=3, allow_unused_input=True)
-
-    def _param_key(self):
-        return hash(tuple(t.data_ptr() for m in (self.static_resnet, self.gripper_resnet) for t in list(m.parameters()) + list(m.buffers())))
-
-    def __call__(self, rgb_static, rgb_gripper, latent_goal):
-        if (tuple(rgb_static.shape), tuple(rgb_gripper.shape), tuple(latent_goal.shape)) != self._shapes:
-            raise ValueError(f"GraphedTrainingTowers was captured for input shapes {self._shapes}")
-        if not (self.static_resnet.training and self.gripper_resnet.training):
-            raise RuntimeError("GraphedTrainingTowers: the encoders left train() mode (the captured graphs hold the training forward / backward)")
-        if self._param_key() != self._key:
-            raise RuntimeError("GraphedTrainingTowers: a parameter or buffer of the encoders was re-allocated since the capture: build a new object")
-        return {"state_images": self._call(rgb_static, rgb_gripper, latent_goal)}
-
-
 class GraphedVisualEncoder:
     """``embed_visual_obs`` for the rollout as ONE hipGraph replay per call.
 
