@@ -226,7 +226,7 @@ def dominant_kernel_roofline(den, device, reps=240):
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command (FETCH_SIZE doubled: gfx950 correction, MI355X_MICROARCH.md "HBM");
     # null when the summary is absent or was taken on another kernel.
     traffic, src = None, None
-    for fn in ("r05_gemm_pmc.json", "r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json"):                 # the newest committed collection that sampled THIS kernel
+    for fn in ("r06_gemm_pmc.json", "r05_gemm_pmc.json", "r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json"):                 # the newest committed collection that sampled THIS kernel
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", fn)))
             ent = pj["kernels"].get("expert_up_projection")
