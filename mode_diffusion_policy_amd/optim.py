@@ -52,6 +52,7 @@ class FusedAdamW:
         self._ema_now = (None, 0.0)
         self._frozen = []
         self._master_sharded = self._state_sharded = False
+        self._sharded_emas = []                                  # ArenaEMAs updated inside ZeRO-1 steps since the last gather_state(): current on each rank's shards only
         self.param_groups = [dict(name="decay", lr=lr, betas=betas, eps=eps, weight_decay=weight_decay),
                              dict(name="no_decay", lr=lr, betas=betas, eps=eps, weight_decay=0.0)]
         # ---- expert matrices updated by their weight-gradient GEMMs (see the class docstring)
@@ -307,13 +308,13 @@ class FusedAdamW:
             for sl in reducer.slices:
                 for buf in (self.exp_avg, self.exp_avg_sq):
                     evs.append(reducer.all_gather_async(buf, sl[0], sl[1], after=None))
-            for em in getattr(self, "_sharded_emas", []):             # EMAs updated inside ZeRO-1 steps: every rank averaged its own shards
+            for em in self._sharded_emas:                             # EMAs updated inside ZeRO-1 steps: every rank averaged its own shards
                 for sl in reducer.slices:
                     evs.append(reducer.all_gather_async(em.flat, sl[0], sl[1], after=None))
             for e in evs:
                 if e is not None:
                     torch.cuda.current_stream().wait_event(e)
-            for em in getattr(self, "_sharded_emas", []):
+            for em in self._sharded_emas:
                 em._sharded = False
             self._sharded_emas = []
             self._state_sharded = False
@@ -401,7 +402,7 @@ class FusedAdamW:
             ema.mark_applied(self.step_count)
             if use_zero1 and reducer.world > 1:
                 ema._sharded = True                              # current on this rank's shards only until gather_state()
-                self._sharded_emas = [e for e in getattr(self, "_sharded_emas", []) if e is not ema] + [ema]
+                self._sharded_emas = [e for e in self._sharded_emas if e is not ema] + [ema]
         lp = ar.lp if eng.compute_dtype == "bf16" else None
         gd, gn = self.param_groups
         train = getattr(eng, "_train", None)
