@@ -452,7 +452,7 @@ def train_leg(den, device, world, rank, dist, steps=10, warmup=3, B=B_PER_GPU, z
         opt.set_fuse_expert_step(fuse)
         for gi, grp in enumerate(opt.param_groups):
             grp["lr"], grp["weight_decay"] = 1e-4, (0.05 if gi == 0 else 0.0)
-    if os.environ.get("MODE_ADAMW_WS"):                                        # A/B: 0 = the ring kernel for the fused weight-gradient + AdamW launches, 1 = the wave-specialised one
+    if os.environ.get("MODE_ADAMW_WS"):                                        # A/B in the PROBE build only (scripts/probe/build_trws_variant.sh; the shipped library ignores the key): 0 = ring kernel, 1 = wave-specialised
         m.engine.lib.mode_set_option(b"adamw_ws", int(os.environ["MODE_ADAMW_WS"]))
     for opt_key in ("train_dn_split", "fuse_swiglu_bwd", "gemm_tr_cfg"):              # A/B of library options inside the training leg: MODE_OPT_<KEY>=<int>
         if os.environ.get("MODE_OPT_" + opt_key.upper()):
