@@ -412,3 +412,38 @@ def test_pptr_kernel_isa_contract(tmp_path):
             assert not any("scratch_" in x for x in b), name
             assert sum("s_cbranch" in x for x in b) <= 2, name
             assert sum("ds_read_b64_tr_b16" in x for x in b) in (32, 96), name        # per K-step pair: 32 for W, + 64 for A in the weight gradient
+
+
+def test_training_side_api_surface():
+    """Host-side contract of the round-6 training / loader additions (no GPU): the optimizer exposes the calls INTEGRATION.md section 3 names, the
+    EMA's schedule is the callback's (mode/callbacks/ema.py:101-126) and a sharded EMA refuses to be read, the checkpoint readers take the explicit
+    trust switch and never unpickle without it."""
+    import inspect
+    import pickle
+    from mode_diffusion_policy_amd import optim, rollout
+    for name in ("finish_fused_step", "set_fuse_expert_step", "reset_state", "gather_state", "fused_grad_sq"):
+        assert callable(getattr(optim.FusedAdamW, name)), name
+    assert inspect.signature(optim.FusedAdamW.step).parameters["grad_scale"].default is None      # fused mode: the backward's scale unless the caller insists
+    for fn in (rollout.load_denoiser_checkpoint, rollout.load_agent_checkpoint, rollout._read_checkpoint_file):
+        assert inspect.signature(fn).parameters["trust_pickle"].default is False, fn.__name__
+
+    class _M:                                                                   # ArenaEMA only keeps the reference until it is used
+        pass
+    ema = optim.ArenaEMA(_M(), decay=0.999)
+    # warm-up schedule of the callback: decay_t = 1 - (1 + t')^-2/3 with t' = max(0, t - start - 1), clamped to [min_value, max_value]
+    assert ema.get_decay(1) == 0.0 and abs(ema.get_decay(2) - (1 - 2 ** (-2 / 3))) < 1e-12 and ema.get_decay(10 ** 9) == 0.9999
+    assert ema.should_apply(1) and not optim.ArenaEMA(_M(), start_step=5).should_apply(3)
+    ema._sharded = True
+    for call in (lambda: ema.swap(), lambda: ema.update(3)):
+        with pytest.raises(RuntimeError, match="gather_state"):
+            call()
+    # a file that needs the full unpickler is refused without the switch (and says how to allow it)
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "x.ckpt")
+        with open(path, "wb") as f:
+            pickle.dump({"state_dict": {}, "obj": inspect.Signature()}, f)
+        os.environ.pop("MODE_TRUST_CKPT", None)
+        with pytest.raises(RuntimeError, match="trust_pickle=True"):
+            rollout._read_checkpoint_file(path)
